@@ -1,0 +1,216 @@
+"""ctypes binding of the CPU oracle (oracle/rdis_oracle.c) and of oracle/_ref.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under rdis_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_nrc.so")
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+FUNC_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double))
+GRAD_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+class _Result(C.Structure):
+    _fields_ = [("fret", C.c_double), ("delta", C.c_double), ("finit", C.c_double),
+                ("iters", C.c_int32), ("status", C.c_int32),
+                ("nfeval", C.c_int64), ("ngeval", C.c_int64)]
+
+
+@dataclass
+class CGDResult:
+    fret: float
+    delta: float
+    finit: float
+    iters: int
+    status: int
+    nfeval: int
+    ngeval: int
+    x: np.ndarray
+
+
+def build(force: bool = False) -> None:
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "rdis_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.ro_ba_factor_eval.restype = C.c_double
+        L.ro_ba_factor_eval.argtypes = [_f64p, C.c_double, C.c_double]
+        L.ro_ba_factor_grad.restype = C.c_double
+        L.ro_ba_factor_grad.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
+        L.ro_create_ba.restype = C.c_void_p
+        L.ro_create_ba.argtypes = [C.c_int64, _f64p, _f64p, _f64p, C.c_int64, _i64p, _i64p, _f64p]
+        L.ro_create_nlp.restype = C.c_void_p
+        L.ro_create_nlp.argtypes = [C.c_int64, _f64p, _f64p, _f64p, C.c_int64, _f64p, _i64p,
+                                    _i64p, _f64p, _f64p, _u8p]
+        L.ro_destroy.argtypes = [C.c_void_p]
+        L.ro_set_emulate_stale_cache.argtypes = [C.c_void_p, C.c_int]
+        L.ro_assign.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
+        L.ro_get_x.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
+        L.ro_eval_factors.restype = C.c_double
+        L.ro_eval_factors.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.ro_compute_gradient.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p, C.c_int]
+        L.ro_eval_each.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
+        L.ro_grad_each_ba.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
+        L.ro_cgd_optimize.argtypes = [C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_void_p, _f64p,
+                                      C.c_int32, C.c_double, C.c_int, C.POINTER(_Result)]
+        L.ro_frprmn.restype = C.c_int
+        L.ro_frprmn.argtypes = [C.c_int, _f64p, FUNC_CB, GRAD_CB, C.c_void_p, C.c_int, C.c_double,
+                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _opt_i64(a):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class OracleProblem:
+    """CPU oracle instance for one rdis_amd.problems.PackedProblem."""
+
+    def __init__(self, pp, emulate_stale_cache: bool = True):
+        L = lib()
+        self.pp = pp
+        x0 = np.ascontiguousarray(pp.x0, dtype=np.float64)
+        lo = np.ascontiguousarray(pp.lo, dtype=np.float64)
+        hi = np.ascontiguousarray(pp.hi, dtype=np.float64)
+        if pp.kind == 0:
+            self.h = L.ro_create_ba(pp.nvars, x0, lo, hi, pp.nfac,
+                                    np.ascontiguousarray(pp.cam_vid0), np.ascontiguousarray(pp.pt_vid0),
+                                    np.ascontiguousarray(pp.obs.reshape(-1)))
+        else:
+            self.h = L.ro_create_nlp(pp.nvars, x0, lo, hi, pp.nfac, pp.coeff, pp.rowptr, pp.vid,
+                                     pp.expo, pp.cons, pp.sine)
+        L.ro_set_emulate_stale_cache(self.h, int(emulate_stale_cache))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ro_destroy(self.h)
+            self.h = None
+
+    def assign(self, vid, val):
+        v, vp = _opt_i64(vid)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        lib().ro_assign(self.h, val.shape[0], vp, val)
+
+    def get_x(self, vid=None):
+        v, vp = _opt_i64(vid)
+        n = self.pp.nvars if v is None else v.shape[0]
+        out = np.empty(n)
+        lib().ro_get_x(self.h, n, vp, out)
+        return out
+
+    def eval(self, fac=None) -> float:
+        f, fp = _opt_i64(fac)
+        return lib().ro_eval_factors(self.h, self.pp.nfac if f is None else f.shape[0], fp)
+
+    def gradient(self, fac=None, merge: bool = False) -> np.ndarray:
+        f, fp = _opt_i64(fac)
+        g = np.empty(self.pp.nvars)
+        lib().ro_compute_gradient(self.h, self.pp.nfac if f is None else f.shape[0], fp, g, int(merge))
+        return g
+
+    def eval_each(self, fac=None) -> np.ndarray:
+        f, fp = _opt_i64(fac)
+        n = self.pp.nfac if f is None else f.shape[0]
+        out = np.empty(n)
+        lib().ro_eval_each(self.h, n, fp, out)
+        return out
+
+    def grad_each_ba(self, fac=None) -> np.ndarray:
+        f, fp = _opt_i64(fac)
+        n = self.pp.nfac if f is None else f.shape[0]
+        out = np.empty(n * 12)
+        lib().ro_grad_each_ba(self.h, n, fp, out)
+        return out.reshape(n, 12)
+
+    def cgd(self, free_vid=None, fac=None, x=None, maxiters: int = 50, ftol: float = 3e-8,
+            merge: bool = False) -> CGDResult:
+        fv = np.arange(self.pp.nvars, dtype=np.int64) if free_vid is None else \
+            np.ascontiguousarray(free_vid, dtype=np.int64)
+        f, fp = _opt_i64(fac)
+        xv = self.get_x(fv) if x is None else np.array(x, dtype=np.float64)
+        res = _Result()
+        lib().ro_cgd_optimize(self.h, fv.shape[0], fv, self.pp.nfac if f is None else f.shape[0], fp,
+                              xv, maxiters, ftol, int(merge), C.byref(res))
+        return CGDResult(res.fret, res.delta, res.finit, res.iters, res.status, res.nfeval,
+                         res.ngeval, xv)
+
+
+def ba_factor_eval(vals, ox, oy) -> float:
+    return lib().ro_ba_factor_eval(np.ascontiguousarray(vals, dtype=np.float64), ox, oy)
+
+
+def ba_factor_grad(vals, ox, oy):
+    g = np.empty(12)
+    e = lib().ro_ba_factor_grad(np.ascontiguousarray(vals, dtype=np.float64), ox, oy, g)
+    return e, g
+
+
+def _wrap_callbacks(f, df, n):
+    def cf(_ctx, xp):
+        return float(f(np.ctypeslib.as_array(xp, shape=(n,)).copy()))
+
+    def cg(_ctx, xp, gp):
+        g = np.asarray(df(np.ctypeslib.as_array(xp, shape=(n,)).copy()), dtype=np.float64)
+        np.ctypeslib.as_array(gp, shape=(n,))[:] = g
+    return FUNC_CB(cf), GRAD_CB(cg)
+
+
+def frprmn(f, df, x0, maxiters=50, ftol=3e-8):
+    """restated minimiser on python callbacks -> (reason, x, fret, iter)"""
+    x = np.array(x0, dtype=np.float64)
+    cf, cg = _wrap_callbacks(f, df, x.shape[0])
+    fret, it = C.c_double(), C.c_int()
+    rc = lib().ro_frprmn(x.shape[0], x, cf, cg, None, maxiters, ftol, C.byref(fret), C.byref(it))
+    return rc, x, fret.value, it.value
+
+
+_ref = None
+
+
+def ref_available() -> bool:
+    build()
+    return os.path.exists(_REF)
+
+
+def ref_frprmn(f, df, x0, maxiters=50, ftol=3e-8):
+    """the REFERENCE's nrc::Frprmn (oracle/_ref) on python callbacks"""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REF)
+        _ref.ref_frprmn.restype = C.c_int
+        _ref.ref_frprmn.argtypes = [C.c_int, _f64p, FUNC_CB, GRAD_CB, C.c_void_p, C.c_int,
+                                    C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    x = np.array(x0, dtype=np.float64)
+    cf, cg = _wrap_callbacks(f, df, x.shape[0])
+    fret, it = C.c_double(), C.c_int()
+    rc = _ref.ref_frprmn(x.shape[0], x, cf, cg, None, maxiters, ftol, C.byref(fret), C.byref(it))
+    return rc, x, fret.value, it.value

@@ -1,0 +1,769 @@
+/*
+ * rdis_oracle.c -- CPU ORACLE (test infrastructure only; see rdis_oracle.h).
+ *
+ * Plain C99, no dependencies beyond libm.  Build with -O2 -ffp-contract=off so
+ * the arithmetic matches an x86-64 g++ -O2 build of the reference (no FMA).
+ * Every function cites the reference lines it restates (paths are relative to
+ * /root/reference).
+ */
+#include "rdis_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ===========================================================================
+ * Bundle-adjustment reprojection factor
+ * =========================================================================*/
+
+typedef struct {
+    double v[3];      /* unit rotation axis (or raw r when theta == 0) */
+    double theta;     /* |r| */
+    double s, c;      /* sin/cos theta (theta > 0 only) */
+    double w[3];      /* v x q */
+    double d;         /* v . q */
+    double P[3];      /* point in the camera frame */
+    double pp[2];     /* -P.xy / P.z */
+    double r2, dstn;  /* |pp|^2 and 1 + k1 r2 + k2 r2^2 */
+    double res[2];    /* pixel residual */
+} ba_fwd;
+
+/* Forward projection.  Snavely camera: angle-axis rotation (Rodrigues),
+ * translation, perspective divide with the -z convention, two-term radial
+ * distortion, focal scaling.
+ * src/bundleadjust/BundleAdjustmentFactor.cpp:266-335 (rotate+translate),
+ * BundleAdjustmentFactor.h:80-107 (divide, distort, error),
+ * BundleAdjustmentCommon.h:81-93 (normalize). */
+static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
+{
+    const double *r = x, *tr = x + 3, *q = x + 9;
+    const double f = x[6], k1 = x[7], k2 = x[8];
+
+    t->theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (t->theta != 0.0) {
+        t->v[0] = r[0] / t->theta; t->v[1] = r[1] / t->theta; t->v[2] = r[2] / t->theta;
+    } else {
+        t->v[0] = r[0]; t->v[1] = r[1]; t->v[2] = r[2];
+    }
+    const double *v = t->v;
+    t->w[0] = v[1] * q[2] - v[2] * q[1];
+    t->w[1] = v[2] * q[0] - v[0] * q[2];
+    t->w[2] = v[0] * q[1] - v[1] * q[0];
+    if (t->theta > 0.0) {
+        t->c = cos(t->theta);
+        t->s = sin(t->theta);
+        const double omc = 1 - t->c;
+        t->d = v[0] * q[0] + v[1] * q[1] + v[2] * q[2];
+        for (int i = 0; i < 3; ++i)
+            t->P[i] = q[i] * t->c + t->w[i] * t->s + v[i] * omc * t->d;
+    } else {
+        /* first-order rotation near zero: q + r x q (.cpp:304-329) */
+        t->c = 1.0; t->s = 0.0; t->d = 0.0;
+        for (int i = 0; i < 3; ++i) t->P[i] = q[i] + t->w[i];
+    }
+    for (int i = 0; i < 3; ++i) t->P[i] += tr[i];
+
+    t->pp[0] = -t->P[0] / t->P[2];
+    t->pp[1] = -t->P[1] / t->P[2];
+    t->r2 = t->pp[0] * t->pp[0] + t->pp[1] * t->pp[1];
+    t->dstn = 1 + t->r2 * (k1 + k2 * t->r2);
+    const double pix0 = f * t->dstn * t->pp[0];
+    const double pix1 = f * t->dstn * t->pp[1];
+    t->res[0] = pix0 - ox;
+    t->res[1] = pix1 - oy;
+    return (t->res[0] * t->res[0] + t->res[1] * t->res[1]) / 2.0;
+}
+
+/* BundleAdjustmentFactor::evalFactor(NumericVec) (.cpp:160-185) */
+double ro_ba_factor_eval(const double vals[12], double obsx, double obsy)
+{
+    ba_fwd t;
+    return ba_forward(vals, obsx, obsy, &t);
+}
+
+/* Analytic gradient of one reprojection factor.  The reference
+ * (BundleAdjustmentFactor.cpp:351-554) expands the chain rule forward, one
+ * variable at a time; this oracle back-propagates adjoints through the same
+ * forward model instead (derived from the mathematics, SURVEY.md 8a note 8).
+ * Both are the exact derivative; they differ only in rounding. */
+double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
+{
+    ba_fwd t;
+    const double E = ba_forward(x, ox, oy, &t);
+    const double *q = x + 9, *v = t.v;
+    const double f = x[6], k1 = x[7], k2 = x[8];
+
+    /* pix = f * dstn * pp ; E = |pix - obs|^2 / 2 */
+    const double rp = t.res[0] * t.pp[0] + t.res[1] * t.pp[1];
+    g[6] = t.dstn * rp;                 /* dE/df    */
+    const double adst = f * rp;         /* dE/ddstn */
+    g[7] = adst * t.r2;                 /* dE/dk1   */
+    g[8] = adst * t.r2 * t.r2;          /* dE/dk2   */
+    const double ar2 = adst * (k1 + 2.0 * k2 * t.r2);
+    const double app0 = f * t.dstn * t.res[0] + 2.0 * ar2 * t.pp[0];
+    const double app1 = f * t.dstn * t.res[1] + 2.0 * ar2 * t.pp[1];
+
+    /* pp = -P.xy / P.z */
+    double a[3];
+    a[0] = -app0 / t.P[2];
+    a[1] = -app1 / t.P[2];
+    a[2] = -(app0 * t.pp[0] + app1 * t.pp[1]) / t.P[2];
+
+    /* P = R q + t */
+    g[3] = a[0]; g[4] = a[1]; g[5] = a[2];
+
+    const double av = a[0] * v[0] + a[1] * v[1] + a[2] * v[2];
+    const double aq = a[0] * q[0] + a[1] * q[1] + a[2] * q[2];
+    /* q x a and v x a */
+    const double qxa[3] = { q[1] * a[2] - q[2] * a[1], q[2] * a[0] - q[0] * a[2],
+                            q[0] * a[1] - q[1] * a[0] };
+    const double vxa[3] = { v[1] * a[2] - v[2] * a[1], v[2] * a[0] - v[0] * a[2],
+                            v[0] * a[1] - v[1] * a[0] };
+    if (t.theta > 0.0) {
+        const double omc = 1 - t.c;
+        /* dE/dq = R^T a (rotation by -theta about v) */
+        for (int i = 0; i < 3; ++i)
+            g[9 + i] = a[i] * t.c - vxa[i] * t.s + v[i] * omc * av;
+        /* R q as a function of (v, theta), v = r/theta, theta = |r| */
+        const double aw = a[0] * t.w[0] + a[1] * t.w[1] + a[2] * t.w[2];
+        const double gth = -aq * t.s + aw * t.c + av * t.d * t.s;
+        double gv[3];
+        for (int i = 0; i < 3; ++i)
+            gv[i] = t.s * qxa[i] + omc * (a[i] * t.d + q[i] * av);
+        const double vgv = v[0] * gv[0] + v[1] * gv[1] + v[2] * gv[2];
+        for (int i = 0; i < 3; ++i)
+            g[i] = (gv[i] - v[i] * vgv) / t.theta + v[i] * gth;
+    } else {
+        /* theta == 0: P = q + r x q.  (The reference divides by theta here and
+         * has no guard, BundleAdjustmentFactor.cpp:376,407-409.) */
+        for (int i = 0; i < 3; ++i) {
+            g[9 + i] = a[i] - vxa[i];
+            g[i] = qxa[i];
+        }
+    }
+    return E;
+}
+
+/* ===========================================================================
+ * Nonlinear product factor
+ * =========================================================================*/
+
+/* rdis::power, src/util/numeric.cpp:12-23 */
+static double nlp_power(double val, double e)
+{
+    if (e == 0.) return 1.;
+    if (e == 1.) return val;
+    if (e == 2.) return val * val;
+    return pow(val, e);
+}
+
+/* ===========================================================================
+ * Problem container
+ * =========================================================================*/
+
+struct ro_problem {
+    int kind;
+    int64_t nvars, nfac;
+    double *x, *lo, *hi;
+    /* BA */
+    int64_t *cam, *pt;
+    double *obs;
+    /* NLP */
+    double *coeff, *expo, *cons;
+    int64_t *rowptr, *vid;
+    uint8_t *sine;
+    /* cached factor values + variable->factor adjacency (Factor.h:228-234,
+     * Variable.cpp:66-88) */
+    int emulate;
+    double *fcache;
+    uint8_t *fdirty;
+    int64_t *v2f_ptr, *v2f_idx;
+};
+
+static void *dup_mem(const void *src, size_t bytes)
+{
+    void *d = malloc(bytes ? bytes : 1);
+    if (src && bytes) memcpy(d, src, bytes);
+    return d;
+}
+
+static int64_t fac_arity(const ro_problem *p, int64_t f)
+{
+    return p->kind == RO_KIND_BA ? 12 : p->rowptr[f + 1] - p->rowptr[f];
+}
+
+static int64_t fac_var(const ro_problem *p, int64_t f, int64_t k)
+{
+    if (p->kind == RO_KIND_BA) return k < 9 ? p->cam[f] + k : p->pt[f] + (k - 9);
+    return p->vid[p->rowptr[f] + k];
+}
+
+static void build_adjacency(ro_problem *p)
+{
+    p->v2f_ptr = calloc((size_t)p->nvars + 1, sizeof(int64_t));
+    for (int64_t f = 0; f < p->nfac; ++f)
+        for (int64_t k = 0, a = fac_arity(p, f); k < a; ++k) p->v2f_ptr[fac_var(p, f, k) + 1]++;
+    for (int64_t v = 0; v < p->nvars; ++v) p->v2f_ptr[v + 1] += p->v2f_ptr[v];
+    p->v2f_idx = malloc(sizeof(int64_t) * (size_t)(p->v2f_ptr[p->nvars] ? p->v2f_ptr[p->nvars] : 1));
+    int64_t *fill = calloc((size_t)p->nvars + 1, sizeof(int64_t));
+    for (int64_t f = 0; f < p->nfac; ++f)
+        for (int64_t k = 0, a = fac_arity(p, f); k < a; ++k) {
+            int64_t v = fac_var(p, f, k);
+            p->v2f_idx[p->v2f_ptr[v] + fill[v]++] = f;
+        }
+    free(fill);
+    p->fcache = calloc((size_t)p->nfac + 1, sizeof(double));
+    p->fdirty = malloc((size_t)p->nfac + 1);
+    memset(p->fdirty, 1, (size_t)p->nfac + 1);
+}
+
+static ro_problem *alloc_common(int kind, int64_t nvars, const double *x0,
+                                const double *lo, const double *hi, int64_t nfac)
+{
+    ro_problem *p = calloc(1, sizeof(*p));
+    p->kind = kind; p->nvars = nvars; p->nfac = nfac; p->emulate = 1;
+    p->x = dup_mem(x0, sizeof(double) * (size_t)nvars);
+    p->lo = dup_mem(lo, sizeof(double) * (size_t)nvars);
+    p->hi = dup_mem(hi, sizeof(double) * (size_t)nvars);
+    return p;
+}
+
+ro_problem *ro_create_ba(int64_t nvars, const double *x0, const double *lo,
+                         const double *hi, int64_t nfac, const int64_t *cam_vid0,
+                         const int64_t *pt_vid0, const double *obs)
+{
+    ro_problem *p = alloc_common(RO_KIND_BA, nvars, x0, lo, hi, nfac);
+    p->cam = dup_mem(cam_vid0, sizeof(int64_t) * (size_t)nfac);
+    p->pt = dup_mem(pt_vid0, sizeof(int64_t) * (size_t)nfac);
+    p->obs = dup_mem(obs, sizeof(double) * 2 * (size_t)nfac);
+    build_adjacency(p);
+    return p;
+}
+
+ro_problem *ro_create_nlp(int64_t nvars, const double *x0, const double *lo,
+                          const double *hi, int64_t nfac, const double *coeff,
+                          const int64_t *rowptr, const int64_t *vid,
+                          const double *expo, const double *cons,
+                          const uint8_t *sine)
+{
+    ro_problem *p = alloc_common(RO_KIND_NLP, nvars, x0, lo, hi, nfac);
+    const size_t nnz = (size_t)rowptr[nfac];
+    p->coeff = dup_mem(coeff, sizeof(double) * (size_t)nfac);
+    p->rowptr = dup_mem(rowptr, sizeof(int64_t) * ((size_t)nfac + 1));
+    p->vid = dup_mem(vid, sizeof(int64_t) * nnz);
+    p->expo = dup_mem(expo, sizeof(double) * nnz);
+    p->cons = dup_mem(cons, sizeof(double) * nnz);
+    p->sine = dup_mem(sine, nnz);
+    build_adjacency(p);
+    return p;
+}
+
+void ro_destroy(ro_problem *p)
+{
+    if (!p) return;
+    free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
+    free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
+    free(p->sine); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
+    free(p);
+}
+
+void ro_set_emulate_stale_cache(ro_problem *p, int on)
+{
+    p->emulate = on;
+    memset(p->fdirty, 1, (size_t)p->nfac + 1);
+}
+
+/* Variable::assign for an already-assigned variable (src/Variable.cpp:66-88):
+ * the value is always stored; the variable's factors are told to recompute
+ * only when |new - old| >= 1e-12. */
+static void assign_one(ro_problem *p, int64_t v, double val)
+{
+    if (!(fabs(val - p->x[v]) < 1e-12)) {
+        for (int64_t k = p->v2f_ptr[v]; k < p->v2f_ptr[v + 1]; ++k) p->fdirty[p->v2f_idx[k]] = 1;
+    }
+    p->x[v] = val;
+}
+
+void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val)
+{
+    for (int64_t i = 0; i < nvid; ++i) assign_one(p, vid ? vid[i] : i, val[i]);
+}
+
+void ro_get_x(const ro_problem *p, int64_t nvid, const int64_t *vid, double *out)
+{
+    for (int64_t i = 0; i < nvid; ++i) out[i] = p->x[vid ? vid[i] : i];
+}
+
+/* VariableDomain::closestVal for a single-interval domain
+ * (src/VariableDomain.cpp:158-163; CGD asserts one sub-interval, CGDSubspaceOptimizer.cpp:119) */
+static double closest_val(double val, double lo, double hi)
+{
+    if (lo <= val && val <= hi) return val;
+    if (val < lo) return lo;
+    return hi;
+}
+
+static void gather_ba(const ro_problem *p, int64_t f, double vals[12])
+{
+    const double *c = p->x + p->cam[f], *q = p->x + p->pt[f];
+    for (int k = 0; k < 9; ++k) vals[k] = c[k];
+    vals[9] = q[0]; vals[10] = q[1]; vals[11] = q[2];
+}
+
+/* NonlinearProductFactor::evalFactor (src/NonlinearProductFactor.cpp:186-209);
+ * useExponential is never set on this path (.cpp:110 asserts it off). */
+static double nlp_eval(const ro_problem *p, int64_t f)
+{
+    double prod = 1;
+    for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) {
+        double val = p->x[p->vid[k]];
+        if (p->cons[k] != 0) val -= p->cons[k];
+        if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
+        if (p->sine[k]) val = sin(val);
+        prod *= val;
+    }
+    return prod * p->coeff[f];
+}
+
+/* NonlinearProductFactor::getDerivative (src/NonlinearProductFactor.cpp:149-178) */
+static double nlp_deriv(const ro_problem *p, int64_t f, int64_t wrt)
+{
+    double prod = 1;
+    for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) {
+        double val = p->x[p->vid[k]];
+        if (p->vid[k] == wrt) {
+            if (p->expo[k] == 1 && !p->sine[k]) continue; /* d/dx (x-k) = 1 */
+            val -= p->cons[k];
+            const double inner_e = nlp_power(val, p->expo[k]);
+            val = nlp_power(val, p->expo[k] - 1.0);
+            val *= p->expo[k];
+            if (p->sine[k]) val *= cos(inner_e);
+            prod *= val;
+        } else {
+            if (p->cons[k] != 0) val -= p->cons[k];
+            if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
+            if (p->sine[k]) val = sin(val);
+            prod *= val;
+        }
+    }
+    return prod * p->coeff[f];
+}
+
+static double factor_value_nocache(const ro_problem *p, int64_t f)
+{
+    if (p->kind == RO_KIND_BA) {
+        double vals[12];
+        gather_ba(p, f, vals);
+        return ro_ba_factor_eval(vals, p->obs[2 * f], p->obs[2 * f + 1]);
+    }
+    return nlp_eval(p, f);
+}
+
+/* Factor::eval -> evalFactorCached (src/Factor.cpp:110-119, Factor.h:228-234) */
+static double factor_value(ro_problem *p, int64_t f)
+{
+    if (!p->emulate) return factor_value_nocache(p, f);
+    if (p->fdirty[f]) {
+        p->fcache[f] = factor_value_nocache(p, f);
+        p->fdirty[f] = 0;
+    }
+    return p->fcache[f];
+}
+
+/* OptimizableFunction::evalFactors (src/OptimizableFunction.cpp:95-135):
+ * MinSum product is '+', identity 0, accumulated in list order. */
+double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
+{
+    double feval = 0.0;
+    for (int64_t i = 0; i < nf; ++i) feval = feval + factor_value(p, fac ? fac[i] : i);
+    return feval;
+}
+
+void ro_eval_each(ro_problem *p, int64_t nf, const int64_t *fac, double *fvals)
+{
+    for (int64_t i = 0; i < nf; ++i) fvals[i] = factor_value_nocache(p, fac ? fac[i] : i);
+}
+
+void ro_grad_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g12)
+{
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i;
+        double vals[12];
+        gather_ba(p, f, vals);
+        ro_ba_factor_grad(vals, p->obs[2 * f], p->obs[2 * f + 1], g12 + 12 * i);
+    }
+}
+
+/* one factor's PartialGradient as (vid, value) pairs sorted by vid
+ * (BundleAdjustmentFactor.cpp:338-348, Factor.cpp:142-151; flat_map order) */
+static int factor_partials(const ro_problem *p, int64_t f, int64_t *vids, double *vals)
+{
+    int n;
+    if (p->kind == RO_KIND_BA) {
+        double x[12], g[12];
+        gather_ba(p, f, x);
+        ro_ba_factor_grad(x, p->obs[2 * f], p->obs[2 * f + 1], g);
+        for (int k = 0; k < 12; ++k) { vids[k] = fac_var(p, f, k); vals[k] = g[k]; }
+        n = 12;
+    } else {
+        n = (int)fac_arity(p, f);
+        for (int k = 0; k < n; ++k) {
+            vids[k] = p->vid[p->rowptr[f] + k];
+            vals[k] = nlp_deriv(p, f, vids[k]);
+        }
+    }
+    for (int i = 1; i < n; ++i) { /* insertion sort by vid */
+        int64_t kv = vids[i]; double kx = vals[i]; int j = i - 1;
+        while (j >= 0 && vids[j] > kv) { vids[j + 1] = vids[j]; vals[j + 1] = vals[j]; --j; }
+        vids[j + 1] = kv; vals[j + 1] = kx;
+    }
+    return n;
+}
+
+/* OptimizableFunction::computeGradientOfSum (src/OptimizableFunction.cpp:248-262)
+ * with productGradient (src/State.h:157-210).  The first contribution to a
+ * variable is copied, later ones are added, always in factor-list order. */
+void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *g, int merge)
+{
+    int64_t vids[64]; double vals[64];
+    int64_t maxar = 12;
+    if (p->kind == RO_KIND_NLP)
+        for (int64_t f = 0; f < p->nfac; ++f) if (fac_arity(p, f) > maxar) maxar = fac_arity(p, f);
+    int64_t *vb = vids; double *xb = vals;
+    if (maxar > 64) { vb = malloc(sizeof(int64_t) * (size_t)maxar); xb = malloc(sizeof(double) * (size_t)maxar); }
+
+    if (!merge) {
+        uint8_t *seen = calloc((size_t)p->nvars + 1, 1);
+        memset(g, 0, sizeof(double) * (size_t)p->nvars);
+        for (int64_t i = 0; i < nf; ++i) {
+            const int n = factor_partials(p, fac ? fac[i] : i, vb, xb);
+            for (int k = 0; k < n; ++k) {
+                if (!seen[vb[k]]) { g[vb[k]] = xb[k]; seen[vb[k]] = 1; }
+                else g[vb[k]] = g[vb[k]] + xb[k];
+            }
+        }
+        free(seen);
+    } else {
+        /* sorted (vid,value) vector, merged factor by factor: the reference's
+         * cost model (linear walk + vector insert per factor). */
+        int64_t cap = 1024, len = 0;
+        int64_t *mv = malloc(sizeof(int64_t) * (size_t)cap);
+        double *mx = malloc(sizeof(double) * (size_t)cap);
+        for (int64_t i = 0; i < nf; ++i) {
+            const int n = factor_partials(p, fac ? fac[i] : i, vb, xb);
+            if (len + n > cap) {
+                while (len + n > cap) cap *= 2;
+                mv = realloc(mv, sizeof(int64_t) * (size_t)cap);
+                mx = realloc(mx, sizeof(double) * (size_t)cap);
+            }
+            if (len == 0) {
+                memcpy(mv, vb, sizeof(int64_t) * (size_t)n);
+                memcpy(mx, xb, sizeof(double) * (size_t)n);
+                len = n;
+                continue;
+            }
+            int64_t i1 = 0; int i2 = 0;
+            while (i2 < n) {
+                if (i1 == len || mv[i1] > vb[i2]) {
+                    memmove(mv + i1 + 1, mv + i1, sizeof(int64_t) * (size_t)(len - i1));
+                    memmove(mx + i1 + 1, mx + i1, sizeof(double) * (size_t)(len - i1));
+                    mv[i1] = vb[i2]; mx[i1] = xb[i2]; ++len; ++i1; ++i2;
+                } else if (mv[i1] == vb[i2]) {
+                    mx[i1] = mx[i1] + xb[i2]; ++i1; ++i2;
+                } else {
+                    ++i1;
+                }
+            }
+        }
+        memset(g, 0, sizeof(double) * (size_t)p->nvars);
+        for (int64_t k = 0; k < len; ++k) g[mv[k]] = mx[k];
+        free(mv); free(mx);
+    }
+    if (vb != vids) { free(vb); free(xb); }
+}
+
+/* ===========================================================================
+ * The minimiser: Polak-Ribiere conjugate gradients with a derivative-aware
+ * Brent line search (external/include/minimize_nrc.h).  Restated from the
+ * published algorithm with the reference's constants and evaluation order.
+ * =========================================================================*/
+
+typedef struct {
+    int n;
+    ro_func_cb f;
+    ro_grad_cb df;
+    void *ctx;
+    const double *p, *xi; /* line: p + a * xi */
+    double *xt, *dft;
+    int failed;           /* set by a NaN in the callbacks */
+} line_t;
+
+/* Df1dim::operator() (minimize_nrc.h:432-436) */
+static double line_f(line_t *L, double a)
+{
+    for (int j = 0; j < L->n; ++j) L->xt[j] = L->p[j] + a * L->xi[j];
+    return L->f(L->ctx, L->xt);
+}
+
+/* Df1dim::df (minimize_nrc.h:439-447): slope at the xt left by line_f */
+static double line_df(line_t *L)
+{
+    double s = 0.0;
+    L->df(L->ctx, L->xt, L->dft);
+    for (int j = 0; j < L->n; ++j) s += L->dft[j] * L->xi[j];
+    return s;
+}
+
+typedef struct { double ax, bx, cx, fa, fb, fc; } bracket_t;
+
+/* Bracketmethod::bracket (minimize_nrc.h:80-151): walk downhill from (a,b)
+ * with golden-ratio growth and bounded parabolic extrapolation until
+ * f(bx) <= f(cx). */
+static void bracket_min(bracket_t *B, double a, double b, line_t *L)
+{
+    const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;
+    double ax = a, bx = b, cx, fa, fb, fc, fu, tmp;
+    fa = line_f(L, ax);
+    fb = line_f(L, bx);
+    if (fb > fa) {
+        tmp = ax; ax = bx; bx = tmp;
+        tmp = fa; fa = fb; fb = tmp;
+    }
+    cx = bx + GOLD * (bx - ax);
+    fc = line_f(L, cx);
+    while (fb > fc) {
+        const double r = (bx - ax) * (fb - fc);
+        const double q = (bx - cx) * (fb - fa);
+        const double qr = q - r;
+        double u = bx - ((bx - cx) * q - (bx - ax) * r) /
+                            (2.0 * copysign(fmax(fabs(qr), TINY), qr));
+        const double ulim = bx + GLIMIT * (cx - bx);
+        if ((bx - u) * (u - cx) > 0.0) {          /* u between b and c */
+            fu = line_f(L, u);
+            if (fu < fc) { ax = bx; bx = u; fa = fb; fb = fu; break; }
+            if (fu > fb) { cx = u; fc = fu; break; }
+            u = cx + GOLD * (cx - bx);
+            fu = line_f(L, u);
+        } else if ((cx - u) * (u - ulim) > 0.0) { /* u between c and the limit */
+            fu = line_f(L, u);
+            if (fu < fc) {
+                const double unew = u + GOLD * (u - cx);
+                bx = cx; cx = u; u = unew;
+                fb = fc; fc = fu; fu = line_f(L, u);
+            }
+        } else if ((u - ulim) * (ulim - cx) >= 0.0) { /* clip to the limit */
+            u = ulim;
+            fu = line_f(L, u);
+        } else {
+            u = cx + GOLD * (cx - bx);
+            fu = line_f(L, u);
+        }
+        ax = bx; bx = cx; cx = u;
+        fa = fb; fb = fc; fc = fu;
+    }
+    B->ax = ax; B->bx = bx; B->cx = cx; B->fa = fa; B->fb = fb; B->fc = fc;
+}
+
+/* Dbrent::minimize (minimize_nrc.h:284-404).  Returns 0 and sets xmin/fmin,
+ * or 1 when 100 iterations did not converge (the reference throws). */
+static int dbrent_min(const bracket_t *B, line_t *L, double *xmin, double *fmin)
+{
+    const int ITMAX = 100;
+    const double tol = 3.0e-8; /* Dbrent default ctor; independent of ftol (:288,:499) */
+    const double ZEPS = DBL_EPSILON * 1.0e-3;
+    double a = (B->ax < B->cx ? B->ax : B->cx);
+    double b = (B->ax > B->cx ? B->ax : B->cx);
+    double x, w, v, fx, fw, fv, dx, dw, dv, u, fu, du;
+    double d = 0.0, e = 0.0;
+    x = w = v = B->bx;
+    fw = fv = fx = line_f(L, x);
+    dw = dv = dx = line_df(L);
+    for (int it = 0; it < ITMAX; ++it) {
+        const double xm = 0.5 * (a + b);
+        const double tol1 = tol * fabs(x) + ZEPS;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) { *fmin = fx; *xmin = x; return 0; }
+        int bisect = 1;
+        if (fabs(e) > tol1) {
+            /* secant steps through (x,dx) and each of (w,dw), (v,dv) */
+            double d1 = 2.0 * (b - a), d2 = d1;
+            if (dw != dx) d1 = (w - x) * dx / (dx - dw);
+            if (dv != dx) d2 = (v - x) * dx / (dx - dv);
+            const double u1 = x + d1, u2 = x + d2;
+            const int ok1 = (a - u1) * (u1 - b) > 0.0 && dx * d1 <= 0.0;
+            const int ok2 = (a - u2) * (u2 - b) > 0.0 && dx * d2 <= 0.0;
+            const double olde = e;
+            e = d;
+            if (ok1 || ok2) {
+                if (ok1 && ok2) d = (fabs(d1) < fabs(d2) ? d1 : d2);
+                else if (ok1) d = d1;
+                else d = d2;
+                if (fabs(d) <= fabs(0.5 * olde)) {
+                    u = x + d;
+                    if (u - a < tol2 || b - u < tol2) d = copysign(tol1, xm - x);
+                    bisect = 0;
+                }
+            }
+        }
+        if (bisect) { e = (dx >= 0.0 ? a - x : b - x); d = 0.5 * e; }
+        if (fabs(d) >= tol1) {
+            u = x + d;
+            fu = line_f(L, u);
+        } else {
+            u = x + copysign(tol1, d);
+            fu = line_f(L, u);
+            if (fu > fx) { *fmin = fx; *xmin = x; return 0; }
+        }
+        du = line_df(L);
+        if (fu <= fx) {
+            if (u >= x) a = x; else b = x;
+            v = w; fv = fw; dv = dw;
+            w = x; fw = fx; dw = dx;
+            x = u; fx = fu; dx = du;
+        } else {
+            if (u < x) a = u; else b = u;
+            if (fu <= fw || w == x) {
+                v = w; fv = fw; dv = dw;
+                w = u; fw = fu; dw = du;
+            } else if (fu < fv || v == x || v == w) {
+                v = u; fv = fu; dv = du;
+            }
+        }
+    }
+    return 1;
+}
+
+/* Frprmn::minimize (minimize_nrc.h:619-691) with Dlinemethod::linmin (:492-513) */
+int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
+              int maxiters, double ftol, double *fret_out, int *iter_out)
+{
+    const double EPS = 1.0e-18, GTOL = 1.0e-8;
+    double *buf = malloc(sizeof(double) * (size_t)(6 * n + 6));
+    double *p = buf, *xi = p + n, *g = xi + n, *h = g + n, *xt = h + n, *dft = xt + n;
+    line_t L = { n, f, df, ctx, p, xi, xt, dft, 0 };
+    int reason = RO_EXIT_ITMAX, iter = 0;
+    double fret = DBL_MAX;
+
+    memcpy(p, x, sizeof(double) * (size_t)n);
+    double fp = f(ctx, p);
+    df(ctx, p, xi);
+    for (int j = 0; j < n; ++j) { g[j] = -xi[j]; xi[j] = h[j] = g[j]; }
+
+    for (int its = 0; its < maxiters; ++its) {
+        iter = its;
+        /* linmin: bracket from (0,1), Brent with derivatives, move p */
+        bracket_t B;
+        double amin, fmin;
+        bracket_min(&B, 0.0, 1.0, &L);
+        if (dbrent_min(&B, &L, &amin, &fmin)) { reason = RO_EXIT_DBRENT_ITMAX; goto done; }
+        for (int j = 0; j < n; ++j) { xi[j] *= amin; p[j] += xi[j]; }
+        fret = fmin;
+
+        if (2.0 * fabs(fret - fp) <= ftol * (fabs(fret) + fabs(fp) + EPS)) { reason = RO_EXIT_FTOL; goto done; }
+        fp = fret;
+        df(ctx, p, xi);
+        double test = 0.0;
+        const double den = fmax(fabs(fp), 1.0);
+        for (int j = 0; j < n; ++j) {
+            const double t = fabs(xi[j]) * fmax(fabs(p[j]), 1.0) / den;
+            if (t > test) test = t;
+        }
+        if (test < GTOL) { reason = RO_EXIT_GTOL; goto done; }
+        double gg = 0.0, dgg = 0.0;
+        for (int j = 0; j < n; ++j) {
+            gg += g[j] * g[j];
+            dgg += (xi[j] + g[j]) * xi[j];
+        }
+        if (gg == 0.0) { reason = RO_EXIT_GGZERO; goto done; }
+        const double gam = dgg / gg;
+        for (int j = 0; j < n; ++j) {
+            g[j] = -xi[j];
+            xi[j] = h[j] = g[j] + gam * h[j];
+        }
+    }
+done:
+    memcpy(x, p, sizeof(double) * (size_t)n);
+    *fret_out = fret;
+    *iter_out = iter;
+    free(buf);
+    return reason;
+}
+
+/* ===========================================================================
+ * CGDSubspaceOptimizer::optimize and its SubfunctionFD functor
+ * (src/optimizers/CGDSubspaceOptimizer.cpp:19-98, 124-184)
+ * =========================================================================*/
+
+typedef struct {
+    ro_problem *p;
+    int64_t nfree, nf;
+    const int64_t *free_vid, *fac;
+    double *gdense;
+    int merge, saw_nan;
+    int64_t nfeval, ngeval;
+} sub_t;
+
+/* SubfunctionFD::quickAssignVals (.cpp:160-184) */
+static void sub_assign(sub_t *S, const double *x)
+{
+    for (int64_t i = 0; i < S->nfree; ++i) {
+        const int64_t v = S->free_vid[i];
+        if (isnan(x[i])) S->saw_nan = 1;
+        assign_one(S->p, v, closest_val(x[i], S->p->lo[v], S->p->hi[v]));
+    }
+}
+
+/* SubfunctionFD::operator() (.cpp:124-132); coeff = +1 for MinSum */
+static double sub_f(void *ctx, const double *x)
+{
+    sub_t *S = ctx;
+    ++S->nfeval;
+    sub_assign(S, x);
+    return ro_eval_factors(S->p, S->nf, S->fac);
+}
+
+/* SubfunctionFD::df (.cpp:135-157) */
+static void sub_df(void *ctx, const double *x, double *deriv)
+{
+    sub_t *S = ctx;
+    ++S->ngeval;
+    sub_assign(S, x);
+    ro_compute_gradient(S->p, S->nf, S->fac, S->gdense, S->merge);
+    for (int64_t i = 0; i < S->nfree; ++i) deriv[i] = S->gdense[S->free_vid[i]];
+}
+
+void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
+                     int64_t nf, const int64_t *fac, double *xval,
+                     int32_t maxiters, double ftol, int merge, ro_result *out)
+{
+    memset(out, 0, sizeof(*out));
+    if (nf == 0) { out->status = RO_EXIT_EMPTY; return; } /* .cpp:26-29 */
+
+    sub_t S = { p, nfree, nf, free_vid, fac, NULL, merge, 0, 0, 0 };
+    S.gdense = malloc(sizeof(double) * (size_t)(p->nvars + 1));
+    double *xinit = malloc(sizeof(double) * (size_t)(nfree + 1));
+    double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));
+
+    /* SubspaceOptimizer::quickAssignVals(vars, xval, true) then sfd(xval) */
+    const double finit = sub_f(&S, xval);
+    memcpy(xinit, xval, sizeof(double) * (size_t)nfree);
+    memcpy(xw, xval, sizeof(double) * (size_t)nfree);
+
+    double fret; int iter;
+    int reason = ro_frprmn((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter);
+    if (S.saw_nan) reason = RO_EXIT_NAN;
+
+    sub_assign(&S, xw); /* assign gdmin.p with sanitisation (.cpp:61) */
+    int status = reason;
+    if (fret > finit) { /* negative progress: restore (.cpp:66-80) */
+        status |= RO_STATUS_ROLLED_BACK;
+        fret = sub_f(&S, xinit);
+    }
+    for (int64_t i = 0; i < nfree; ++i) xval[i] = p->x[free_vid[i]]; /* .cpp:84-86 */
+
+    out->fret = fret; out->finit = finit; out->delta = fret - finit;
+    out->iters = iter; out->status = status;
+    out->nfeval = S.nfeval; out->ngeval = S.ngeval;
+    free(S.gdense); free(xinit); free(xw);
+}

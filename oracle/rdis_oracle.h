@@ -1,0 +1,120 @@
+/*
+ * rdis_oracle.h -- CPU ORACLE for the RDIS subspace-solver hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and the cpu_baseline leg of bench.py may link or call
+ * it.  The product path (rdis_amd/csrc, include/rdis_hip.h) never does.
+ *
+ * It is a plain-C restatement of the reference's algorithm for the path
+ * (citations are path:line under /root/reference):
+ *   - factor evaluation         src/bundleadjust/BundleAdjustmentFactor.cpp:160-185,266-335
+ *                               src/NonlinearProductFactor.cpp:186-209, 149-178
+ *   - sum over a factor list    src/OptimizableFunction.cpp:95-135
+ *   - gradient of the sum       src/OptimizableFunction.cpp:234-262, src/State.h:157-210
+ *   - clamp-assign              src/optimizers/CGDSubspaceOptimizer.cpp:160-184,
+ *                               src/Variable.cpp:66-88, src/VariableDomain.cpp:158-163
+ *   - Polak-Ribiere CG, line minimisation, Brent-with-derivatives, bracketing
+ *                               external/include/minimize_nrc.h:80-151,284-404,410-513,585-692
+ *   - the solver wrapper        src/optimizers/CGDSubspaceOptimizer.cpp:19-98
+ *
+ * Pinning status: see oracle/README.md (golden values of SURVEY.md section 8c,
+ * the reference's own data/testpoly.txt minima, and bit-exact agreement of the
+ * minimiser with the reference's minimize_nrc.h built as oracle/_ref).
+ */
+#ifndef RDIS_ORACLE_H_
+#define RDIS_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RO_KIND_BA = 0, RO_KIND_NLP = 1 };
+
+/* exit reason of the CG loop (low byte of status) */
+enum {
+    RO_EXIT_FTOL = 0,      /* minimize_nrc.h:649 */
+    RO_EXIT_GTOL = 1,      /* minimize_nrc.h:663 */
+    RO_EXIT_GGZERO = 2,    /* minimize_nrc.h:675 */
+    RO_EXIT_ITMAX = 3,     /* minimize_nrc.h:690 (thrown, swallowed by CGD) */
+    RO_EXIT_DBRENT_ITMAX = 4, /* minimize_nrc.h:403 (thrown, swallowed by CGD) */
+    RO_EXIT_NAN = 5,       /* CGDSubspaceOptimizer.cpp:175 assert */
+    RO_EXIT_EMPTY = 6      /* CGDSubspaceOptimizer.cpp:26-29 */
+};
+#define RO_STATUS_ROLLED_BACK 0x100 /* CGDSubspaceOptimizer.cpp:66-80 */
+
+typedef struct ro_problem ro_problem;
+
+/* ---- single-factor arithmetic ------------------------------------------- */
+/* vals = [rx,ry,rz,tx,ty,tz,f,k1,k2,X,Y,Z] (BundleAdjustmentCommon.h:36-59) */
+double ro_ba_factor_eval(const double vals[12], double obsx, double obsy);
+double ro_ba_factor_grad(const double vals[12], double obsx, double obsy,
+                         double grad[12]);
+
+/* ---- problems -------------------------------------------------------------*/
+/* BA: factor i reads the 9 variables cam_vid0[i]..+8 and pt_vid0[i]..+2. */
+ro_problem *ro_create_ba(int64_t nvars, const double *x0, const double *lo,
+                         const double *hi, int64_t nfac, const int64_t *cam_vid0,
+                         const int64_t *pt_vid0, const double *obs);
+/* NLP: factor i = coeff[i] * prod_k g((x[vid[k]]-cons[k])^expo[k]),
+ * k in rowptr[i]..rowptr[i+1], g = sin iff sine[k]. */
+ro_problem *ro_create_nlp(int64_t nvars, const double *x0, const double *lo,
+                          const double *hi, int64_t nfac, const double *coeff,
+                          const int64_t *rowptr, const int64_t *vid,
+                          const double *expo, const double *cons,
+                          const uint8_t *sine);
+void ro_destroy(ro_problem *p);
+
+/* emulate Variable::assign's "|delta| < 1e-12 => factors not notified" rule
+ * (src/Variable.cpp:70-76) together with the cached factor value
+ * (src/Factor.h:228-234).  Default 1 (reference-faithful). */
+void ro_set_emulate_stale_cache(ro_problem *p, int on);
+
+void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val);
+void ro_get_x(const ro_problem *p, int64_t nvid, const int64_t *vid, double *out);
+
+/* sum over the listed factors in list order (fac == NULL: all factors 0..n-1) */
+double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac);
+/* dense gradient (length nvars, zero where untouched); per-variable
+ * contributions are added in factor-list order.  merge != 0 runs the
+ * reference's sorted-(vid,value)-vector merge per factor (same result,
+ * reference cost model). */
+void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac,
+                         double *g, int merge);
+/* per-factor values and 12 (BA) / arity (NLP, CSR order) partials */
+void ro_eval_each(ro_problem *p, int64_t nf, const int64_t *fac, double *fvals);
+void ro_grad_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g12);
+
+/* ---- the solver ------------------------------------------------------------*/
+typedef struct {
+    double fret;     /* returned value */
+    double delta;    /* deltaFval */
+    double finit;    /* initialFval */
+    int32_t iters;   /* Frprmn::iter (index of the last iteration started) */
+    int32_t status;  /* RO_EXIT_* | RO_STATUS_ROLLED_BACK */
+    int64_t nfeval;  /* calls of SubfunctionFD::operator() */
+    int64_t ngeval;  /* calls of SubfunctionFD::df */
+} ro_result;
+
+/* CGDSubspaceOptimizer::optimize over free variables free_vid[0..nfree) and
+ * factors fac[0..nf) (NULL = all).  xval is in free_vid order, overwritten
+ * with the final clamped values; the problem's variables are left assigned to
+ * them.  merge selects the gradient cost model (see ro_compute_gradient). */
+void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
+                     int64_t nf, const int64_t *fac, double *xval,
+                     int32_t maxiters, double ftol, int merge, ro_result *out);
+
+/* generic entry to the restated minimiser, for the bit-exact comparison with
+ * oracle/_ref (the reference's own minimize_nrc.h): minimise func over n
+ * variables starting from x. */
+typedef double (*ro_func_cb)(void *ctx, const double *x);
+typedef void (*ro_grad_cb)(void *ctx, const double *x, double *g);
+/* returns exit reason; x <- Frprmn::p, *fret <- Frprmn::fret, *iter <- Frprmn::iter */
+int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
+              int maxiters, double ftol, double *fret, int *iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDIS_ORACLE_H_ */

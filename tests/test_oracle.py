@@ -1,0 +1,225 @@
+"""Pins the CPU oracle (oracle/rdis_oracle.c) before anything is compared with it:
+
+* against the reference's golden values (tests/golden/reference_golden.json),
+* against the reference's own documented minima of data/testpoly.txt,
+* bit for bit against the reference's minimize_nrc.h built as oracle/_ref.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rdis_amd import problems as P
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+# ---------------------------------------------------------------- BA factor
+def test_ba_factor0_value_and_gradient(golden):
+    g0 = golden["ba_factor0"]
+    vals = np.array(g0["cam"] + g0["pt"])
+    e = O.ba_factor_eval(vals, *g0["obs"])
+    assert e == g0["E"]                      # same expression order -> bit-exact
+    e2, g = O.ba_factor_grad(vals, *g0["obs"])
+    assert e2 == g0["E"]
+    # adjoint-mode derivative vs the reference's forward chain rule: rounding only
+    assert rel(g, g0["grad"]) < 1e-13
+
+
+def test_ba_gradient_matches_central_differences():
+    p = P.load_bal(ncams=5, npts=30)
+    o = O.OracleProblem(p)
+    g = o.grad_each_ba()
+    rng = np.random.default_rng(3)
+    for f in rng.choice(p.nfac, 8, replace=False):
+        vals = np.concatenate([p.x0[p.cam_vid0[f]:p.cam_vid0[f] + 9], p.x0[p.pt_vid0[f]:p.pt_vid0[f] + 3]])
+        for k in range(12):
+            h = 1e-6 * max(1.0, abs(vals[k])) if k not in (7, 8) else 1e-9
+            a, b = vals.copy(), vals.copy()
+            a[k] += h
+            b[k] -= h
+            fd = (O.ba_factor_eval(a, *p.obs[f]) - O.ba_factor_eval(b, *p.obs[f])) / (2 * h)
+            assert abs(fd - g[f, k]) <= 2e-4 * max(abs(g[f, k]), 1e-3), (f, k)
+
+
+def test_ba_theta_zero_branch():
+    # theta == 0 takes the first-order branch P = q + r x q (reference .cpp:304-329)
+    vals = np.array([0, 0, 0, 0.1, -0.2, -3.0, 400.0, -3e-7, 5e-13, 0.3, -0.4, 0.5])
+    e, g = O.ba_factor_grad(vals, 10.0, -20.0)
+    assert np.isfinite(e) and np.all(np.isfinite(g))
+    tiny = vals.copy()
+    tiny[0] = 1e-9
+    e2, g2 = O.ba_factor_grad(tiny, 10.0, -20.0)
+    assert abs(e - e2) < 1e-6 * e
+    assert rel(g[3:], g2[3:]) < 1e-6
+
+
+def test_ladybug_full_eval_and_gradient(golden):
+    gl = golden["ladybug_full"]
+    p = P.load_bal()
+    assert (p.nvars, p.nfac) == (gl["nvars"], gl["nfac"])
+    o = O.OracleProblem(p)
+    each = o.eval_each()
+    assert each[1] == gl["E_factor1"] and each[31842] == gl["E_factor31842"]
+    assert abs(o.eval() - gl["f_xinit"]) <= 1e-15 * gl["f_xinit"]
+    g = o.gradient()
+    gmax = np.max(np.abs(g))
+    assert abs(np.linalg.norm(g) - gl["grad_norm2"]) < 1e-13 * gl["grad_norm2"]
+    assert np.max(np.abs(g[0:9] - gl["grad_0_8"])) < 1e-14 * gmax
+    assert np.max(np.abs(g[441:444] - gl["grad_441_443"])) < 1e-14 * gmax
+    assert abs(g[23768] - gl["grad_23768"]) < 1e-14 * gmax
+    # the reference's sorted-vector merge and dense accumulation are the same sum
+    sub = np.arange(0, 4000, dtype=np.int64)
+    assert np.array_equal(o.gradient(sub, merge=True), o.gradient(sub, merge=False))
+
+
+def test_bal_subsets_match_reference_sizes(golden):
+    for key in ("ladybug_5_30", "ladybug_49_500", "ladybug_49_2000"):
+        c = golden["cgd"][key]
+        p = P.load_bal(ncams=c["ncams"], npts=c["npts"])
+        assert (p.nvars, p.nfac) == (c["nvars"], c["nfac"])
+    c = golden["cgd"]["ladybug_5_30"]
+    o = O.OracleProblem(P.load_bal(ncams=5, npts=30))
+    assert abs(o.eval() - c["f0"]) < 1e-14 * c["f0"]
+    assert abs(np.linalg.norm(o.gradient()) - c["grad_norm2"]) < 1e-13 * c["grad_norm2"]
+
+
+# ---------------------------------------------------------------- NLP / poly
+def test_testpoly_known_answers(golden):
+    t = golden["testpoly"]
+    p = P.load_poly()
+    assert (p.nvars, p.nfac) == (t["nvars"], t["nfac"])
+    assert list(p.lo) == t["lo"] and list(p.hi) == t["hi"]
+    o = O.OracleProblem(p)
+    o.assign(None, np.array([1.0, -2.0]))
+    assert o.eval() == t["f_1_m2"]
+    o.assign(None, np.array([-4.6601, -4.6601]))
+    assert o.eval() == t["f_m46601"]
+    # the reference's documented minima (data/testpoly.txt:17-22), 4 digits
+    for fmin, a, b in t["documented_minima"]:
+        o.assign(None, np.array([a, b]))
+        assert abs(o.eval() - fmin) < 2e-4
+
+
+def test_testpoly_cgd_golden(golden):
+    t = golden["testpoly"]
+    o = O.OracleProblem(P.load_poly())
+    for case in t["cgd"]:
+        r = o.cgd(x=np.array(case["start"]), maxiters=t["cgd_maxiters"])
+        assert r.fret == case["fret"], case          # converged: bit-exact
+        if "x" in case:
+            assert list(r.x) == case["x"]
+        assert r.status in (0, 1, 2)
+
+
+def test_sinusoid_shape_and_derivative(golden):
+    s = P.make_high_dim_sinusoid()
+    assert (s.nvars, s.nfac) == (golden["sinusoid"]["nvars"], golden["sinusoid"]["nfac"])
+    assert np.sum(np.diff(s.rowptr) == 1) == 242 and np.sum(np.diff(s.rowptr) == 2) == 120
+    o = O.OracleProblem(s)
+    x = np.random.default_rng(1).uniform(-6.28, 6.28, s.nvars)
+    o.assign(None, x)
+    g = o.gradient()
+    for j in (0, 5, 39, 120):
+        a, b = x.copy(), x.copy()
+        a[j] += 1e-6
+        b[j] -= 1e-6
+        o.assign(None, a)
+        fa = o.eval()
+        o.assign(None, b)
+        fb = o.eval()
+        assert abs((fa - fb) / 2e-6 - g[j]) < 1e-6 * max(1, abs(g[j]))
+
+
+# ---------------------------------------------------------------- minimiser
+def _rosen(x):
+    return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+
+
+def _rosen_g(x):
+    g = np.zeros_like(x)
+    g[:-1] = -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+    g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+    return g
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("maxiters", [1, 2, 7, 25, 400])
+def test_minimiser_bit_exact_vs_reference_header(maxiters):
+    """restated Frprmn/linmin/Dbrent/bracket == the reference's minimize_nrc.h"""
+    rng = np.random.default_rng(maxiters)
+    cases = [(_rosen, _rosen_g, rng.uniform(-2, 2, 6)),
+             (lambda x: float(np.sum(np.cos(x) + 0.05 * x * x)), lambda x: -np.sin(x) + 0.1 * x,
+              rng.uniform(-6, 6, 9)),
+             (lambda x: float(np.sum((x - 1.5) ** 4)), lambda x: 4 * (x - 1.5) ** 3, rng.uniform(-3, 3, 3)),
+             (lambda x: 0.0 * x[0] + 7.0, lambda x: np.zeros_like(x), np.array([1.0, 2.0]))]
+    for f, g, x0 in cases:
+        a = O.frprmn(f, g, x0, maxiters, 3e-8)
+        b = O.ref_frprmn(f, g, x0, maxiters, 3e-8)
+        assert a[0] == b[0] or (b[0] == 0 and a[0] in (0, 1, 2))
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+def test_minimiser_bit_exact_on_bundle_adjustment():
+    p = P.load_bal(ncams=5, npts=30)
+    o = O.OracleProblem(p, emulate_stale_cache=False)
+
+    def f(x):
+        o.assign(None, np.clip(x, p.lo, p.hi))
+        return o.eval()
+
+    def g(x):
+        o.assign(None, np.clip(x, p.lo, p.hi))
+        return o.gradient()
+    a = O.frprmn(f, g, p.x0, 25, 3e-8)
+    b = O.ref_frprmn(f, g, p.x0, 25, 3e-8)
+    assert a[0] == b[0] == 3                       # "Too many iterations in frprmn"
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] == 24
+
+
+# ---------------------------------------------------------------- CGD wrapper
+def test_cgd_chaos_band(golden):
+    """25 unconverged CG iterations are a chaotic map of the start point: the
+    oracle lands inside the band the reference's golden end points live in."""
+    c = golden["cgd"]["ladybug_5_30"]
+    p = P.load_bal(ncams=5, npts=30)
+    r = O.OracleProblem(p).cgd(maxiters=c["maxiters"])
+    assert r.finit == pytest.approx(c["f0"], rel=1e-14)
+    assert r.status == 3 and r.iters == 24
+    assert abs(r.fret - c["fret"]) < 0.05 * c["fret"]
+    assert abs(r.nfeval - c["nfeval"]) < 0.15 * c["nfeval"]
+    frets = []
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = P.load_bal(ncams=5, npts=30)
+        q.x0 = q.x0 * (1 + 1e-15 * rng.standard_normal(q.nvars))
+        frets.append(O.OracleProblem(q).cgd(maxiters=25).fret)
+    assert max(frets) - min(frets) > 1e-4 * c["fret"]        # the band is real
+    # ... while one line minimisation is reproducible to Brent's own tolerance
+    a = O.OracleProblem(p).cgd(maxiters=1).fret
+    q = P.load_bal(ncams=5, npts=30)
+    q.x0 = q.x0 * (1 + 1e-15 * rng.standard_normal(q.nvars))
+    assert abs(O.OracleProblem(q).cgd(maxiters=1).fret - a) < 1e-6 * a
+
+
+def test_cgd_contract_details():
+    p = P.load_poly()
+    o = O.OracleProblem(p)
+    # empty factor list: returns 0, delta 0, x untouched (CGDSubspaceOptimizer.cpp:26-29)
+    r = o.cgd(fac=np.zeros(0, dtype=np.int64), x=np.array([3.0, 4.0]))
+    assert (r.fret, r.delta, r.status) == (0.0, 0.0, 6) and list(r.x) == [3.0, 4.0]
+    # start outside the domain is clamped before the first evaluation
+    r = o.cgd(x=np.array([100.0, -100.0]), maxiters=50)
+    o2 = O.OracleProblem(p)
+    o2.assign(None, np.array([8.0, -9.0]))
+    assert r.finit == o2.eval()
+    assert np.all(r.x >= p.lo) and np.all(r.x <= p.hi) and r.delta <= 0
+    # a sub-function: only x0 free, only the factors that mention x0
+    fac = np.array([0, 1, 5], dtype=np.int64)
+    o3 = O.OracleProblem(p)
+    o3.assign(None, np.array([0.0, 2.0]))
+    r = o3.cgd(free_vid=np.array([0]), fac=fac, x=np.array([0.0]), maxiters=50)
+    assert abs(r.x[0] - (-4.6601175)) < 1e-5 and o3.get_x()[1] == 2.0
