@@ -1,0 +1,179 @@
+/*
+ * rdis_hip.h -- C ABI of the MI355X (gfx950) subspace-solver path for RDIS.
+ *
+ * The reference has no FFI: its boundary for this path is C++ virtual dispatch,
+ *     Numeric SubspaceOptimizer::optimize(const VariablePtrVec& vars,
+ *         const FactorPtrVec& factors, NumericVec& xval, Numeric& deltaFval,
+ *         const bool printdbg)                       (src/SubspaceOptimizer.h:37-39)
+ * called from RDISOptimizer::getValueFromDomain (src/RDISOptimizer.cpp:1067) and
+ * BCDOptimizer::optimize (src/optimizers/BCDOptimizer.cpp:149).  The drop-in
+ * `rdis::HipCGDSubspaceOptimizer` (rdis_amd/host/) implements that virtual and
+ * reaches the GPU only through the entry points below (plain pointers and sizes,
+ * no C++ or torch types).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *  - every function returns 0 or a negative RDIS_HIP_E* code; nothing throws
+ *    across the ABI; rdis_hip_last_error() gives the text for the last failure
+ *    on a context.
+ *  - variable / factor ids are int64 like the reference's VariableID / FactorID
+ *    (src/common.h:30-32): variable ids dense 0..N-1 in creation order, factor id
+ *    = index in the function's factor list.  (Narrowed to int32 on the device;
+ *    N, F and nnz must be < 2^31.)
+ *  - the caller owns all host buffers; device memory belongs to the handles.
+ *  - one context per GPU; calls on a context are serialised by the caller (the
+ *    reference path is single-threaded and not re-entrant either).
+ *  - fp64 throughout ("Numeric = double", src/common.h:25).
+ */
+#ifndef RDIS_HIP_H_
+#define RDIS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDIS_HIP_ABI_VERSION 1
+
+enum {
+    RDIS_HIP_OK = 0,
+    RDIS_HIP_EINVAL = -1,   /* bad argument (NULL, negative size, id out of range) */
+    RDIS_HIP_ENOMEM = -2,   /* host or device allocation failed */
+    RDIS_HIP_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
+    RDIS_HIP_EOVERLAP = -4, /* components of a plan are not independent */
+    RDIS_HIP_ERANGE = -5    /* size exceeds the int32 device index range */
+};
+
+/* exit reason of one component solve = status & 0xff; these replace the
+ * exceptions / asserts the reference uses inside optimize()
+ * (src/optimizers/CGDSubspaceOptimizer.cpp:42-58, :175;
+ *  external/include/minimize_nrc.h:649,663,675,690,403) */
+enum {
+    RDIS_HIP_EXIT_FTOL = 0,         /* 2|df| <= ftol(|f|+|fp|+1e-18) */
+    RDIS_HIP_EXIT_GTOL = 1,         /* scaled gradient below 1e-8 */
+    RDIS_HIP_EXIT_GGZERO = 2,       /* gradient exactly zero */
+    RDIS_HIP_EXIT_ITMAX = 3,        /* "Too many iterations in frprmn" (normal for BA) */
+    RDIS_HIP_EXIT_DBRENT_ITMAX = 4, /* "Too many iterations in routine dbrent" */
+    RDIS_HIP_EXIT_NAN = 5,          /* a NaN objective (the reference asserts) */
+    RDIS_HIP_EXIT_EMPTY = 6,        /* empty factor list: returns 0, touches nothing */
+    RDIS_HIP_EXIT_SYNC_TIMEOUT = 7  /* device-side barrier gave up (never expected) */
+};
+#define RDIS_HIP_STATUS_ROLLED_BACK 0x100 /* negative progress: initial x restored
+                                             (CGDSubspaceOptimizer.cpp:66-80) */
+
+typedef struct rdis_hip_ctx rdis_hip_ctx;
+typedef struct rdis_hip_problem rdis_hip_problem;
+typedef struct rdis_hip_plan rdis_hip_plan;
+
+/* ---- context ------------------------------------------------------------------ */
+int rdis_hip_abi_version(void);
+int rdis_hip_device_count(void);
+int rdis_hip_create(int device, rdis_hip_ctx **out);
+void rdis_hip_destroy(rdis_hip_ctx *ctx);
+const char *rdis_hip_last_error(const rdis_hip_ctx *ctx);
+/* run on a caller-provided hipStream_t (NULL: the context's own stream) */
+int rdis_hip_set_stream(rdis_hip_ctx *ctx, void *hip_stream);
+int rdis_hip_synchronize(rdis_hip_ctx *ctx);
+
+/* ---- an OptimizableFunction in packed form --------------------------------------
+ * x0/lo/hi: assigned value and single-interval domain of every variable
+ * (VariableDomain::interval(), src/VariableDomain.h:53; CGD asserts one
+ * sub-interval, CGDSubspaceOptimizer.cpp:119).
+ *
+ * upload_ba replaces F BundleAdjustmentFactor objects
+ * (src/bundleadjust/BundleAdjustmentFactor.h:18-31): factor i reads variables
+ * cam_vid0[i]..+8 = [rx ry rz tx ty tz f k1 k2] and pt_vid0[i]..+2 = [X Y Z]
+ * (BundleAdjustmentFunction.h:88-96) and the observation obs[2i], obs[2i+1]. */
+int rdis_hip_upload_ba(rdis_hip_ctx *ctx, int64_t nvars, const double *x0, const double *lo,
+                       const double *hi, int64_t nfac, const int64_t *cam_vid0,
+                       const int64_t *pt_vid0, const double *obs, rdis_hip_problem **out);
+/* upload_nlp replaces F NonlinearProductFactor objects
+ * (src/NonlinearProductFactor.h:21-113): factor i = coeff[i] * prod over
+ * k in [rowptr[i], rowptr[i+1]) of g((x[vid[k]] - cons[k])^expo[k]), g = sin iff sine[k]. */
+int rdis_hip_upload_nlp(rdis_hip_ctx *ctx, int64_t nvars, const double *x0, const double *lo,
+                        const double *hi, int64_t nfac, const double *coeff,
+                        const int64_t *rowptr, const int64_t *vid, const double *expo,
+                        const double *cons, const uint8_t *sine, rdis_hip_problem **out);
+void rdis_hip_free_problem(rdis_hip_problem *p);
+
+/* Variable::assign for already-assigned variables (src/Variable.cpp:66-88): the
+ * constants an outer optimiser fixes before a solve.  vid == NULL: vid = 0..n-1. */
+int rdis_hip_set_x(rdis_hip_problem *p, int64_t n, const int64_t *vid, const double *val);
+int rdis_hip_get_x(rdis_hip_problem *p, int64_t n, const int64_t *vid, double *out);
+
+/* ---- batched factor evaluation at the currently assigned x ----------------------
+ * fac == NULL: all factors 0..nf-1 (nf must then equal the factor count).
+ * eval      : OptimizableFunction::evalFactors (src/OptimizableFunction.cpp:95-135)
+ * eval_grad : ... + computeGradient(facs, pg) (src/OptimizableFunction.cpp:234-262);
+ *             g is dense over all N variables (0 where no listed factor touches it);
+ *             each g[v] is accumulated in factor-list order like the reference.
+ * eval_each / grad_each_ba: per-factor values / 12 partials, for kernel parity tests
+ *             (Factor::eval, BundleAdjustmentFactor::computeGradient). */
+int rdis_hip_eval(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f);
+int rdis_hip_eval_grad(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f, double *g);
+int rdis_hip_eval_each(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *fvals);
+int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *g12);
+
+/* ---- the solver: CGDSubspaceOptimizer::optimize for a batch of independent
+ * components --------------------------------------------------------------------
+ * Component c optimises the free variables free_vid[free_ptr[c] .. free_ptr[c+1])
+ * over the factors fac_id[fac_ptr[c] .. fac_ptr[c+1]) (each list in the order the
+ * reference would pass vars / factors).  Components must be independent: no
+ * shared free variable and no factor of one reading a free variable of another
+ * (they are connected components of the residual factor graph,
+ * src/Component.cpp:508-549); otherwise RDIS_HIP_EOVERLAP.
+ *
+ * x_inout (free-variable order, concatenated over components): start values in,
+ * final clamped values out; the problem's variables are left assigned to them
+ * (post-condition of optimize(), CGDSubspaceOptimizer.cpp:84-86).  maxiters / ftol
+ * are SubspaceOptimizer's SSmaxit / SSftol (src/SubspaceOptimizer.cpp:15-32).
+ * Per component: fret (returned value), delta (deltaFval), iters (Frprmn::iter),
+ * status (RDIS_HIP_EXIT_* | RDIS_HIP_STATUS_ROLLED_BACK), nfeval / ngeval (calls
+ * of SubfunctionFD::operator() / ::df the reference would have made).  Any output
+ * pointer may be NULL. */
+int rdis_hip_cgd_batch(rdis_hip_problem *p, int64_t ncomp, const int64_t *free_ptr,
+                       const int64_t *free_vid, const int64_t *fac_ptr, const int64_t *fac_id,
+                       double *x_inout, int32_t maxiters, double ftol, double *fret,
+                       double *delta, int32_t *iters, int32_t *status, int64_t *nfeval,
+                       int64_t *ngeval);
+
+/* The same in three steps, so that a decomposition is analysed and uploaded once
+ * and solved many times with everything resident in HBM:
+ *   plan_create : validate + upload the decomposition, build the per-variable
+ *                 gather lists, allocate workspace
+ *   plan_set_start : (optional) new start values, free-variable order; NULL = take
+ *                 the problem's currently assigned x
+ *   plan_solve  : reset the free variables to the start and run the solver
+ *                 (asynchronous on the context's stream)
+ *   plan_fetch  : wait and copy results out (any pointer may be NULL) */
+int rdis_hip_plan_create(rdis_hip_problem *p, int64_t ncomp, const int64_t *free_ptr,
+                         const int64_t *free_vid, const int64_t *fac_ptr, const int64_t *fac_id,
+                         rdis_hip_plan **out);
+void rdis_hip_plan_destroy(rdis_hip_plan *plan);
+int rdis_hip_plan_set_start(rdis_hip_plan *plan, const double *x_start);
+int rdis_hip_plan_solve(rdis_hip_plan *plan, int32_t maxiters, double ftol);
+int rdis_hip_plan_fetch(rdis_hip_plan *plan, double *x_out, double *fret, double *delta,
+                        int32_t *iters, int32_t *status, int64_t *nfeval, int64_t *ngeval);
+/* sum of fret over the plan's components, left on the device (for the RCCL
+ * all-reduce of the top-level objective, src/RDISOptimizer.cpp:1491-1494);
+ * returns a device pointer to one double valid until the next plan_solve. */
+int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
+
+/* tuning / introspection ---------------------------------------------------------- */
+/* option names: "block_threads" (workgroup size of the per-component solver, 0 = auto),
+ * "coop_min_factors" (components with at least this many factors are solved by the
+ * multi-workgroup cooperative kernel; 0 = never), "coop_workgroups", "coop_threads",
+ * "trace_records" (per-component trace capacity, 0 = off). */
+int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);
+/* device time of the solver kernel(s) of the last plan_solve, measured with HIP
+ * events on the launch stream; launches = number of kernel launches it covers */
+int rdis_hip_plan_last_kernel_ms(rdis_hip_plan *plan, double *ms, int32_t *launches);
+/* solver trace of component c of the last solve (trace_records > 0): up to cap
+ * records of 4 doubles {tag, a, b, c}; *nrec = records written by the device */
+int rdis_hip_plan_get_trace(rdis_hip_plan *plan, int64_t comp, double *rec4, int64_t cap,
+                            int64_t *nrec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDIS_HIP_H_ */

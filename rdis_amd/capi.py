@@ -1,0 +1,308 @@
+"""ctypes binding of the C ABI in include/rdis_hip.h (rdis_amd/lib/librdis_hip.so).
+
+There is no fallback of any kind: if the HIP library is missing or a call fails
+this module raises.  The oracle (oracle/) is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librdis_hip.so")
+
+EXIT_NAMES = {0: "ftol", 1: "gtol", 2: "gg==0", 3: "itmax", 4: "dbrent-itmax", 5: "nan",
+              6: "empty", 7: "sync-timeout"}
+STATUS_ROLLED_BACK = 0x100
+
+_ERRORS = {-1: "EINVAL", -2: "ENOMEM", -3: "EDEVICE", -4: "EOVERLAP", -5: "ERANGE"}
+
+
+class RdisHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rdis_hip error {_ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+_f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# every symbol include/rdis_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "rdis_hip_abi_version": (C.c_int, []),
+    "rdis_hip_device_count": (C.c_int, []),
+    "rdis_hip_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "rdis_hip_destroy": (None, [_vp]),
+    "rdis_hip_last_error": (C.c_char_p, [_vp]),
+    "rdis_hip_set_stream": (C.c_int, [_vp, _vp]),
+    "rdis_hip_synchronize": (C.c_int, [_vp]),
+    "rdis_hip_upload_ba": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "rdis_hip_upload_nlp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "rdis_hip_free_problem": (None, [_vp]),
+    "rdis_hip_set_x": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rdis_hip_get_x": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rdis_hip_eval": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_double)]),
+    "rdis_hip_eval_grad": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_double), _vp]),
+    "rdis_hip_eval_each": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rdis_hip_grad_each_ba": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rdis_hip_cgd_batch": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_double,
+                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdis_hip_plan_create": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "rdis_hip_plan_destroy": (None, [_vp]),
+    "rdis_hip_plan_set_start": (C.c_int, [_vp, _vp]),
+    "rdis_hip_plan_solve": (C.c_int, [_vp, C.c_int32, C.c_double]),
+    "rdis_hip_plan_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdis_hip_plan_objective_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "rdis_hip_plan_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "rdis_hip_plan_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RdisHipError(-3, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               f"(make -C rdis_amd/csrc). There is no CPU fallback.")
+    # If torch is (going to be) used in this process its bundled HIP runtime must be
+    # the one this library binds to: both carry SONAME libamdhip64.so.7, so whichever
+    # is loaded first serves both.  Import torch first when it is already requested.
+    if "torch" in sys.modules or os.environ.get("RDIS_HIP_WITH_TORCH") == "1":
+        import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rdis_hip_abi_version() != 1:
+        raise RdisHipError(-1, "ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a) -> Optional[np.ndarray]:
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+class Context:
+    """rdis_hip_ctx: one per GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.rdis_hip_create(device, C.byref(h))
+        if rc:
+            raise RdisHipError(rc, f"rdis_hip_create(device={device}) failed "
+                                   f"({self.lib.rdis_hip_device_count()} HIP devices visible)")
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc:
+            raise RdisHipError(rc, self.lib.rdis_hip_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self.check(self.lib.rdis_hip_set_stream(self.h, _vp(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self.check(self.lib.rdis_hip_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rdis_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class BatchResult:
+    x: np.ndarray
+    fret: np.ndarray
+    delta: np.ndarray
+    iters: np.ndarray
+    status: np.ndarray
+    nfeval: np.ndarray
+    ngeval: np.ndarray
+
+    @property
+    def exit_reason(self):
+        return self.status & 0xFF
+
+    @property
+    def rolled_back(self):
+        return (self.status & STATUS_ROLLED_BACK) != 0
+
+
+class Problem:
+    """rdis_hip_problem built from an rdis_amd.problems.PackedProblem."""
+
+    def __init__(self, ctx: Context, pp):
+        self.ctx, self.pp = ctx, pp
+        lib = ctx.lib
+        h = _vp()
+        x0, lo, hi = _f(pp.x0), _f(pp.lo), _f(pp.hi)
+        if pp.kind == 0:
+            cam, pt, obs = _i(pp.cam_vid0), _i(pp.pt_vid0), _f(pp.obs).reshape(-1)
+            rc = lib.rdis_hip_upload_ba(ctx.h, pp.nvars, _ptr(x0), _ptr(lo), _ptr(hi), pp.nfac,
+                                        _ptr(cam), _ptr(pt), _ptr(obs), C.byref(h))
+        else:
+            rc = lib.rdis_hip_upload_nlp(ctx.h, pp.nvars, _ptr(x0), _ptr(lo), _ptr(hi), pp.nfac,
+                                         _ptr(_f(pp.coeff)), _ptr(_i(pp.rowptr)), _ptr(_i(pp.vid)),
+                                         _ptr(_f(pp.expo)), _ptr(_f(pp.cons)),
+                                         _ptr(np.ascontiguousarray(pp.sine, dtype=np.uint8)), C.byref(h))
+        ctx.check(rc)
+        self.h = h
+        self.nvars, self.nfac = pp.nvars, pp.nfac
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.rdis_hip_free_problem(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_x(self, val, vid=None):
+        val, vid = _f(val), _i(vid)
+        self.ctx.check(self.ctx.lib.rdis_hip_set_x(self.h, val.shape[0], _ptr(vid), _ptr(val)))
+
+    def get_x(self, vid=None) -> np.ndarray:
+        vid = _i(vid)
+        n = self.nvars if vid is None else vid.shape[0]
+        out = np.empty(n)
+        self.ctx.check(self.ctx.lib.rdis_hip_get_x(self.h, n, _ptr(vid), _ptr(out)))
+        return out
+
+    def _nf(self, fac):
+        fac = _i(fac)
+        return fac, (self.nfac if fac is None else fac.shape[0])
+
+    def eval(self, fac=None) -> float:
+        fac, nf = self._nf(fac)
+        f = C.c_double()
+        self.ctx.check(self.ctx.lib.rdis_hip_eval(self.h, nf, _ptr(fac), C.byref(f)))
+        return f.value
+
+    def eval_grad(self, fac=None):
+        fac, nf = self._nf(fac)
+        f = C.c_double()
+        g = np.empty(self.nvars)
+        self.ctx.check(self.ctx.lib.rdis_hip_eval_grad(self.h, nf, _ptr(fac), C.byref(f), _ptr(g)))
+        return f.value, g
+
+    def eval_each(self, fac=None) -> np.ndarray:
+        fac, nf = self._nf(fac)
+        out = np.empty(nf)
+        self.ctx.check(self.ctx.lib.rdis_hip_eval_each(self.h, nf, _ptr(fac), _ptr(out)))
+        return out
+
+    def grad_each_ba(self, fac=None) -> np.ndarray:
+        fac, nf = self._nf(fac)
+        out = np.empty(nf * 12)
+        self.ctx.check(self.ctx.lib.rdis_hip_grad_each_ba(self.h, nf, _ptr(fac), _ptr(out)))
+        return out.reshape(nf, 12)
+
+    def cgd_batch(self, free_ptr, free_vid, fac_ptr, fac_id, x, maxiters=50, ftol=3e-8) -> BatchResult:
+        free_ptr, free_vid, fac_ptr, fac_id = _i(free_ptr), _i(free_vid), _i(fac_ptr), _i(fac_id)
+        nc = free_ptr.shape[0] - 1
+        x = np.array(x, dtype=np.float64)
+        r = BatchResult(x, np.empty(nc), np.empty(nc), np.empty(nc, np.int32), np.empty(nc, np.int32),
+                        np.empty(nc, np.int64), np.empty(nc, np.int64))
+        self.ctx.check(self.ctx.lib.rdis_hip_cgd_batch(
+            self.h, nc, _ptr(free_ptr), _ptr(free_vid), _ptr(fac_ptr), _ptr(fac_id), _ptr(x), maxiters, ftol,
+            _ptr(r.fret), _ptr(r.delta), _ptr(r.iters), _ptr(r.status), _ptr(r.nfeval), _ptr(r.ngeval)))
+        return r
+
+
+class Plan:
+    """rdis_hip_plan: a decomposition resident on the device, solvable many times."""
+
+    def __init__(self, prob: Problem, free_ptr=None, free_vid=None, fac_ptr=None, fac_id=None):
+        pp = prob.pp
+        if free_ptr is None:
+            if pp.comp_free_ptr is None:
+                pp.single_component()
+            free_ptr, free_vid, fac_ptr, fac_id = pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id
+        self.prob, self.ctx = prob, prob.ctx
+        self.free_ptr, self.free_vid = _i(free_ptr), _i(free_vid)
+        self.fac_ptr, self.fac_id = _i(fac_ptr), _i(fac_id)
+        self.ncomp = self.free_ptr.shape[0] - 1
+        self.nfree = int(self.free_ptr[-1])
+        h = _vp()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_create(prob.h, self.ncomp, _ptr(self.free_ptr), _ptr(self.free_vid),
+                                                         _ptr(self.fac_ptr), _ptr(self.fac_id), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.rdis_hip_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_set_option(self.h, name.encode(), int(value)))
+
+    def set_start(self, x=None):
+        x = None if x is None else _f(x)
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_set_start(self.h, _ptr(x)))
+
+    def solve(self, maxiters=50, ftol=3e-8):
+        """asynchronous launch on the context's stream"""
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_solve(self.h, maxiters, ftol))
+
+    def fetch(self, want_x=True) -> BatchResult:
+        nc = self.ncomp
+        r = BatchResult(np.empty(self.nfree) if want_x else None, np.empty(nc), np.empty(nc),
+                        np.empty(nc, np.int32), np.empty(nc, np.int32), np.empty(nc, np.int64),
+                        np.empty(nc, np.int64))
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_fetch(self.h, _ptr(r.x), _ptr(r.fret), _ptr(r.delta), _ptr(r.iters),
+                                                        _ptr(r.status), _ptr(r.nfeval), _ptr(r.ngeval)))
+        return r
+
+    def objective_device_ptr(self) -> int:
+        p = _vp()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_objective_device(self.h, C.byref(p)))
+        return p.value
+
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def get_trace(self, comp: int = 0, cap: int = 1 << 16) -> np.ndarray:
+        rec = np.zeros((cap, 4))
+        n = _i64()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_get_trace(self.h, comp, _ptr(rec), cap, C.byref(n)))
+        return rec[:min(n.value, cap)], n.value

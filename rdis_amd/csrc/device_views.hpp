@@ -1,0 +1,70 @@
+// device_views.hpp -- plain structs handed to the kernels by value: where a packed
+// problem and a decomposition plan live in HBM.
+//
+// HBM layout (structure of arrays, everything fp64 / int32, resident for the
+// lifetime of the handle):
+//   x[N]          currently assigned value of every variable (Variable::m_value);
+//                 during a solve the free entries hold the clamped trial point
+//   lo[N], hi[N]  single-interval domain (VariableDomain::interval())
+//   BA  factors:  cam[F], pt[F] first variable id of the camera / point block,
+//                 obs[F] (double2, one 16-byte load per factor)
+//   NLP factors:  coeff[F], rowptr[F+1], vid/expo/cons/sine[nnz]   (CSR)
+//   plan:         order[ncomp] (heaviest component first), free_ptr/free_vid,
+//                 fac_ptr/fac_id, v2s_ptr/v2s_idx (for every free variable the
+//                 gradient slots that feed it, in factor-list order),
+//                 ws[5 * nfree] (p, xi, g, h, x_init per component, contiguous),
+//                 dir[N] (search direction scattered by variable id; zero at
+//                 non-free variables), gfac[12F | nnz] (per-factor partials of the
+//                 last full-gradient evaluation), xstart[nfree], outputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rdis_hip {
+
+constexpr int KIND_BA = 0;
+constexpr int KIND_NLP = 1;
+
+struct ProblemView {
+    int kind;
+    int N, F;
+    double* x;
+    const double* lo;
+    const double* hi;
+    const int* cam;
+    const int* pt;
+    const double2* obs;
+    const double* coeff;
+    const int* rowptr;
+    const int* vid;
+    const double* expo;
+    const double* cons;
+    const uint8_t* sine;
+};
+
+struct PlanView {
+    int ncomp;
+    const int* order;
+    const int* free_ptr;
+    const int* free_vid;
+    const int* fac_ptr;
+    const int* fac_id;
+    const int* v2s_ptr;   // [nfree_total + 1]
+    const int* v2s_idx;   // gradient-slot ids
+    double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
+    double* dir;          // [N]
+    double* gfac;         // [12F] or [nnz]
+    const double* xstart; // [nfree_total]
+    double* xout;         // [nfree_total]
+    double* fret;
+    double* delta;
+    int* iters;
+    int* status;
+    long long* nfeval;
+    long long* ngeval;
+    double* trace;        // [ncomp][trace_cap][4] or null
+    int* trace_n;         // [ncomp]
+    int trace_cap;
+};
+
+}  // namespace rdis_hip

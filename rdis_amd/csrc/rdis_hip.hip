@@ -1,0 +1,790 @@
+// rdis_hip.hip -- implementation of the C ABI in include/rdis_hip.h: handle
+// management, uploads, plan construction (validation + gather lists) and kernel
+// launches.  gfx950 only; no CPU evaluation path exists in this library.
+#include "../../include/rdis_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "eval_kernels.hpp"
+#include "solver_coop.hpp"
+
+using namespace rdis_hip;
+
+struct rdis_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 0;
+    std::string err;
+};
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+int fail(rdis_hip_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(ctx, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail((ctx), e__ == hipErrorOutOfMemory ? RDIS_HIP_ENOMEM : RDIS_HIP_EDEVICE, \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                 \
+    } while (0)
+
+int dalloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
+    b.release();
+    if (bytes == 0) bytes = 8;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+template <class T>
+int upload(rdis_hip_ctx* c, DevBuf& b, const T* src, size_t n) {
+    int rc = dalloc(c, b, n * sizeof(T));
+    if (rc) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+template <class T>
+int upload(rdis_hip_ctx* c, DevBuf& b, const std::vector<T>& v) { return upload(c, b, v.data(), v.size()); }
+
+int grid_for(const rdis_hip_ctx* c, long long work, int threads) {
+    long long blocks = (work + threads - 1) / threads;
+    const long long cap = (long long)std::max(1, c->num_cus) * 8;  // grid-stride beyond 8 blocks/CU
+    return (int)std::max(1ll, std::min(blocks, cap));
+}
+
+}  // namespace
+
+struct rdis_hip_problem {
+    rdis_hip_ctx* ctx = nullptr;
+    int kind = KIND_BA;
+    int64_t N = 0, F = 0, nnz = 0;
+    DevBuf x, lo, hi, cam, pt, obs, coeff, rowptr, vid, expo, cons, sine;
+    std::vector<int> h_cam, h_pt, h_rowptr, h_vid;  // host copies for plan building
+    // scratch for the eval entry points
+    DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
+    DevBuf all_v2s_ptr, all_v2s_idx;  // gather lists for "all factors"
+    bool have_all_v2s = false;
+
+    ProblemView view() const {
+        ProblemView v{};
+        v.kind = kind; v.N = (int)N; v.F = (int)F;
+        v.x = x.as<double>(); v.lo = lo.as<double>(); v.hi = hi.as<double>();
+        v.cam = cam.as<int>(); v.pt = pt.as<int>(); v.obs = obs.as<double2>();
+        v.coeff = coeff.as<double>(); v.rowptr = rowptr.as<int>(); v.vid = vid.as<int>();
+        v.expo = expo.as<double>(); v.cons = cons.as<double>(); v.sine = sine.as<uint8_t>();
+        return v;
+    }
+    int64_t nslots() const { return kind == KIND_BA ? 12 * F : nnz; }
+    int arity(int f) const { return kind == KIND_BA ? 12 : h_rowptr[f + 1] - h_rowptr[f]; }
+    int var_of(int f, int k) const {
+        if (kind == KIND_BA) return k < 9 ? h_cam[f] + k : h_pt[f] + (k - 9);
+        return h_vid[h_rowptr[f] + k];
+    }
+    int slot_of(int f, int k) const { return kind == KIND_BA ? 12 * f + k : h_rowptr[f] + k; }
+};
+
+struct rdis_hip_plan {
+    rdis_hip_problem* prob = nullptr;
+    int64_t ncomp = 0, nfree = 0, nfac = 0;
+    int64_t max_fac = 0, max_free = 0;
+    DevBuf order, free_ptr, free_vid, fac_ptr, fac_id, v2s_ptr, v2s_idx;
+    DevBuf ws, dir, gfac, xstart, xout, fret, delta, iters, status, nfeval, ngeval, objective;
+    DevBuf trace, trace_n, coop_state;
+    std::vector<int> h_order, h_fac_ptr, h_free_ptr;
+    bool have_start = false;
+    // options
+    int block_threads = 0;
+    int64_t coop_min_factors = 0;
+    int coop_workgroups = 0, coop_threads = 256;
+    int trace_records = 0;
+    // timing of the last solve
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_launches = 0;
+    bool timed = false;
+
+    PlanView view() const {
+        PlanView v{};
+        v.ncomp = (int)ncomp;
+        v.order = order.as<int>();
+        v.free_ptr = free_ptr.as<int>(); v.free_vid = free_vid.as<int>();
+        v.fac_ptr = fac_ptr.as<int>(); v.fac_id = fac_id.as<int>();
+        v.v2s_ptr = v2s_ptr.as<int>(); v.v2s_idx = v2s_idx.as<int>();
+        v.ws = ws.as<double>(); v.dir = dir.as<double>(); v.gfac = gfac.as<double>();
+        v.xstart = xstart.as<double>(); v.xout = xout.as<double>();
+        v.fret = fret.as<double>(); v.delta = delta.as<double>();
+        v.iters = iters.as<int>(); v.status = status.as<int>();
+        v.nfeval = nfeval.as<long long>(); v.ngeval = ngeval.as<long long>();
+        v.trace = trace_records > 0 ? trace.as<double>() : nullptr;
+        v.trace_n = trace_n.as<int>();
+        v.trace_cap = trace_records;
+        return v;
+    }
+};
+
+// =====================================================================================
+// context
+// =====================================================================================
+extern "C" int rdis_hip_abi_version(void) { return RDIS_HIP_ABI_VERSION; }
+
+extern "C" int rdis_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
+    if (!out) return RDIS_HIP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RDIS_HIP_EDEVICE;
+    rdis_hip_ctx* c = new (std::nothrow) rdis_hip_ctx;
+    if (!c) return RDIS_HIP_ENOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RDIS_HIP_EDEVICE;
+    }
+    c->own_stream = true;
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+extern "C" void rdis_hip_destroy(rdis_hip_ctx* c) {
+    if (!c) return;
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* rdis_hip_last_error(const rdis_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int rdis_hip_set_stream(rdis_hip_ctx* c, void* s) {
+    if (!c) return RDIS_HIP_EINVAL;
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
+    else {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return 0;
+}
+
+extern "C" int rdis_hip_synchronize(rdis_hip_ctx* c) {
+    if (!c) return RDIS_HIP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// =====================================================================================
+// problems
+// =====================================================================================
+namespace {
+int upload_common(rdis_hip_ctx* c, rdis_hip_problem* p, int64_t nvars, const double* x0, const double* lo,
+                  const double* hi) {
+    int rc;
+    if ((rc = upload(c, p->x, x0, (size_t)nvars))) return rc;
+    if ((rc = upload(c, p->lo, lo, (size_t)nvars))) return rc;
+    if ((rc = upload(c, p->hi, hi, (size_t)nvars))) return rc;
+    if ((rc = dalloc(c, p->scalar, 64))) return rc;
+    return 0;
+}
+}  // namespace
+
+extern "C" int rdis_hip_upload_ba(rdis_hip_ctx* c, int64_t nvars, const double* x0, const double* lo,
+                                  const double* hi, int64_t nfac, const int64_t* cam_vid0,
+                                  const int64_t* pt_vid0, const double* obs, rdis_hip_problem** out) {
+    if (!c || !out || nvars < 0 || nfac < 0 || (nvars && (!x0 || !lo || !hi)) ||
+        (nfac && (!cam_vid0 || !pt_vid0 || !obs)))
+        return fail(c, RDIS_HIP_EINVAL, "upload_ba: bad argument");
+    if (nvars >= (1ll << 31) - 16 || nfac >= ((1ll << 31) - 16) / 12) return fail(c, RDIS_HIP_ERANGE, "upload_ba: too large for int32 device indices");
+    HIPCHK(c, hipSetDevice(c->device));
+    rdis_hip_problem* p = new (std::nothrow) rdis_hip_problem;
+    if (!p) return fail(c, RDIS_HIP_ENOMEM, "upload_ba: host allocation");
+    p->ctx = c; p->kind = KIND_BA; p->N = nvars; p->F = nfac;
+    p->h_cam.resize((size_t)nfac); p->h_pt.resize((size_t)nfac);
+    for (int64_t i = 0; i < nfac; ++i) {
+        if (cam_vid0[i] < 0 || cam_vid0[i] + 9 > nvars || pt_vid0[i] < 0 || pt_vid0[i] + 3 > nvars) {
+            delete p;
+            return fail(c, RDIS_HIP_EINVAL, "upload_ba: variable id out of range in factor " + std::to_string(i));
+        }
+        p->h_cam[(size_t)i] = (int)cam_vid0[i];
+        p->h_pt[(size_t)i] = (int)pt_vid0[i];
+    }
+    int rc = upload_common(c, p, nvars, x0, lo, hi);
+    if (!rc) rc = upload(c, p->cam, p->h_cam);
+    if (!rc) rc = upload(c, p->pt, p->h_pt);
+    if (!rc) rc = upload(c, p->obs, obs, (size_t)(2 * nfac));
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, RDIS_HIP_EDEVICE, "upload_ba: sync");
+    if (rc) { delete p; return rc; }
+    *out = p;
+    return 0;
+}
+
+extern "C" int rdis_hip_upload_nlp(rdis_hip_ctx* c, int64_t nvars, const double* x0, const double* lo,
+                                   const double* hi, int64_t nfac, const double* coeff,
+                                   const int64_t* rowptr, const int64_t* vid, const double* expo,
+                                   const double* cons, const uint8_t* sine, rdis_hip_problem** out) {
+    if (!c || !out || nvars < 0 || nfac < 0 || (nvars && (!x0 || !lo || !hi)) || !rowptr || (nfac && !coeff))
+        return fail(c, RDIS_HIP_EINVAL, "upload_nlp: bad argument");
+    const int64_t nnz = rowptr[nfac];
+    if (nnz < 0 || (nnz && (!vid || !expo || !cons || !sine))) return fail(c, RDIS_HIP_EINVAL, "upload_nlp: bad CSR");
+    if (nvars >= (1ll << 31) - 16 || nfac >= (1ll << 31) - 16 || nnz >= (1ll << 31) - 16)
+        return fail(c, RDIS_HIP_ERANGE, "upload_nlp: too large for int32 device indices");
+    HIPCHK(c, hipSetDevice(c->device));
+    rdis_hip_problem* p = new (std::nothrow) rdis_hip_problem;
+    if (!p) return fail(c, RDIS_HIP_ENOMEM, "upload_nlp: host allocation");
+    p->ctx = c; p->kind = KIND_NLP; p->N = nvars; p->F = nfac; p->nnz = nnz;
+    p->h_rowptr.resize((size_t)nfac + 1); p->h_vid.resize((size_t)nnz);
+    for (int64_t i = 0; i <= nfac; ++i) {
+        if (rowptr[i] < 0 || (i && rowptr[i] < rowptr[i - 1])) { delete p; return fail(c, RDIS_HIP_EINVAL, "upload_nlp: rowptr not monotone"); }
+        p->h_rowptr[(size_t)i] = (int)rowptr[i];
+    }
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (vid[k] < 0 || vid[k] >= nvars) { delete p; return fail(c, RDIS_HIP_EINVAL, "upload_nlp: variable id out of range"); }
+        p->h_vid[(size_t)k] = (int)vid[k];
+    }
+    int rc = upload_common(c, p, nvars, x0, lo, hi);
+    if (!rc) rc = upload(c, p->coeff, coeff, (size_t)nfac);
+    if (!rc) rc = upload(c, p->rowptr, p->h_rowptr);
+    if (!rc) rc = upload(c, p->vid, p->h_vid);
+    if (!rc) rc = upload(c, p->expo, expo, (size_t)nnz);
+    if (!rc) rc = upload(c, p->cons, cons, (size_t)nnz);
+    if (!rc) rc = upload(c, p->sine, sine, (size_t)nnz);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, RDIS_HIP_EDEVICE, "upload_nlp: sync");
+    if (rc) { delete p; return rc; }
+    *out = p;
+    return 0;
+}
+
+extern "C" void rdis_hip_free_problem(rdis_hip_problem* p) {
+    if (!p) return;
+    (void)hipStreamSynchronize(p->ctx->stream);
+    delete p;
+}
+
+namespace {
+// stage an int64 id list as int32 on the device (nullptr stays nullptr)
+int stage_ids(rdis_hip_problem* p, int64_t n, const int64_t* ids, int64_t limit, const int** dev) {
+    rdis_hip_ctx* c = p->ctx;
+    *dev = nullptr;
+    if (!ids) return 0;
+    std::vector<int> tmp((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= limit) return fail(c, RDIS_HIP_EINVAL, "id out of range");
+        tmp[(size_t)i] = (int)ids[i];
+    }
+    if (p->tmp_idx.bytes < (size_t)n * sizeof(int)) { int rc = dalloc(c, p->tmp_idx, (size_t)n * sizeof(int)); if (rc) return rc; }
+    HIPCHK(c, hipMemcpyAsync(p->tmp_idx.p, tmp.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // tmp goes out of scope
+    *dev = p->tmp_idx.as<int>();
+    return 0;
+}
+int ensure(rdis_hip_ctx* c, DevBuf& b, size_t bytes) { return b.bytes >= bytes ? 0 : dalloc(c, b, bytes); }
+}  // namespace
+
+extern "C" int rdis_hip_set_x(rdis_hip_problem* p, int64_t n, const int64_t* vid, const double* val) {
+    if (!p || n < 0 || (n && !val)) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (n == 0) return 0;
+    if (!vid) {
+        if (n > p->N) return fail(c, RDIS_HIP_EINVAL, "set_x: n > nvars");
+        HIPCHK(c, hipMemcpyAsync(p->x.p, val, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const int* dv;
+    int rc = stage_ids(p, n, vid, p->N, &dv);
+    if (rc) return rc;
+    if ((rc = ensure(c, p->tmp_val, (size_t)n * sizeof(double)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(p->tmp_val.p, val, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    scatter_x_kernel<<<grid_for(c, n, 256), 256, 0, c->stream>>>((int)n, dv, p->tmp_val.as<double>(), p->x.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_get_x(rdis_hip_problem* p, int64_t n, const int64_t* vid, double* out) {
+    if (!p || n < 0 || (n && !out)) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (n == 0) return 0;
+    if (!vid) {
+        if (n > p->N) return fail(c, RDIS_HIP_EINVAL, "get_x: n > nvars");
+        HIPCHK(c, hipMemcpyAsync(out, p->x.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const int* dv;
+    int rc = stage_ids(p, n, vid, p->N, &dv);
+    if (rc) return rc;
+    if ((rc = ensure(c, p->tmp_out, (size_t)n * sizeof(double)))) return rc;
+    gather_x_kernel<<<grid_for(c, n, 256), 256, 0, c->stream>>>((int)n, dv, p->x.as<double>(), p->tmp_out.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, p->tmp_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// =====================================================================================
+// batched evaluation
+// =====================================================================================
+namespace {
+
+// for every variable the gradient slots that feed it, in factor-list order
+void build_v2s(const rdis_hip_problem* p, int64_t nf, const int64_t* fac, std::vector<int>& ptr,
+               std::vector<int>& idx) {
+    ptr.assign((size_t)p->N + 1, 0);
+    for (int64_t i = 0; i < nf; ++i) {
+        const int f = (int)(fac ? fac[i] : i);
+        for (int k = 0, a = p->arity(f); k < a; ++k) ++ptr[(size_t)p->var_of(f, k) + 1];
+    }
+    for (int64_t v = 0; v < p->N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+    idx.resize((size_t)ptr[(size_t)p->N]);
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < nf; ++i) {
+        const int f = (int)(fac ? fac[i] : i);
+        for (int k = 0, a = p->arity(f); k < a; ++k) idx[(size_t)fill[(size_t)p->var_of(f, k)]++] = p->slot_of(f, k);
+    }
+}
+
+int check_list(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    if (nf < 0) return fail(p->ctx, RDIS_HIP_EINVAL, "negative factor count");
+    if (!fac && nf != p->F) return fail(p->ctx, RDIS_HIP_EINVAL, "fac == NULL requires nf == factor count");
+    return 0;
+}
+
+template <bool GRAD>
+int launch_eval_sum(rdis_hip_problem* p, int nf, const int* dfac, int blocks) {
+    rdis_hip_ctx* c = p->ctx;
+    ProblemView V = p->view();
+    if (p->kind == KIND_BA)
+        eval_sum_kernel<KIND_BA, GRAD><<<blocks, 256, 0, c->stream>>>(V, nf, dfac, p->gfac.as<double>(), p->partial.as<double>());
+    else
+        eval_sum_kernel<KIND_NLP, GRAD><<<blocks, 256, 0, c->stream>>>(V, nf, dfac, p->gfac.as<double>(), p->partial.as<double>());
+    HIPCHK(c, hipGetLastError());
+    final_sum_kernel<<<1, 256, 0, c->stream>>>(blocks, p->partial.as<double>(), p->scalar.as<double>());
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+extern "C" int rdis_hip_eval(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f) {
+    if (!p || !f) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    if (nf == 0) { *f = 0.0; return 0; }
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    const int blocks = grid_for(c, nf, 256);
+    if ((rc = ensure(c, p->partial, (size_t)blocks * sizeof(double)))) return rc;
+    if ((rc = launch_eval_sum<false>(p, (int)nf, dfac, blocks))) return rc;
+    HIPCHK(c, hipMemcpyAsync(f, p->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f, double* g) {
+    if (!p || !f || !g) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    if (nf == 0) { *f = 0.0; std::fill(g, g + p->N, 0.0); return 0; }
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    // gather lists: cached for the all-factors case
+    const int *dptr, *didx;
+    DevBuf lptr, lidx;
+    if (!fac) {
+        if (!p->have_all_v2s) {
+            std::vector<int> ptr, idx;
+            build_v2s(p, nf, nullptr, ptr, idx);
+            if ((rc = upload(c, p->all_v2s_ptr, ptr))) return rc;
+            if ((rc = upload(c, p->all_v2s_idx, idx))) return rc;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            p->have_all_v2s = true;
+        }
+        dptr = p->all_v2s_ptr.as<int>(); didx = p->all_v2s_idx.as<int>();
+    } else {
+        std::vector<int> ptr, idx;
+        build_v2s(p, nf, fac, ptr, idx);
+        if ((rc = upload(c, lptr, ptr))) return rc;
+        if ((rc = upload(c, lidx, idx))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dptr = lptr.as<int>(); didx = lidx.as<int>();
+    }
+    const int blocks = grid_for(c, nf, 256);
+    if ((rc = ensure(c, p->partial, (size_t)blocks * sizeof(double)))) return rc;
+    if ((rc = ensure(c, p->gfac, (size_t)p->nslots() * sizeof(double)))) return rc;
+    if ((rc = ensure(c, p->g_all, (size_t)p->N * sizeof(double)))) return rc;
+    if ((rc = launch_eval_sum<true>(p, (int)nf, dfac, blocks))) return rc;
+    gather_grad_kernel<<<grid_for(c, p->N, 256), 256, 0, c->stream>>>((int)p->N, dptr, didx, p->gfac.as<double>(), p->g_all.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(f, p->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(g, p->g_all.p, (size_t)p->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_eval_each(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* fvals) {
+    if (!p || (nf && !fvals)) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    if (nf == 0) return 0;
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    if ((rc = ensure(c, p->tmp_out, (size_t)nf * sizeof(double)))) return rc;
+    ProblemView V = p->view();
+    const int blocks = grid_for(c, nf, 256);
+    if (p->kind == KIND_BA) eval_each_kernel<KIND_BA><<<blocks, 256, 0, c->stream>>>(V, (int)nf, dfac, p->tmp_out.as<double>());
+    else eval_each_kernel<KIND_NLP><<<blocks, 256, 0, c->stream>>>(V, (int)nf, dfac, p->tmp_out.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(fvals, p->tmp_out.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_grad_each_ba(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* g12) {
+    if (!p || (nf && !g12)) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (p->kind != KIND_BA) return fail(c, RDIS_HIP_EINVAL, "grad_each_ba: not a bundle-adjustment problem");
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    if (nf == 0) return 0;
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    if ((rc = ensure(c, p->gfac, (size_t)p->nslots() * sizeof(double)))) return rc;
+    if ((rc = ensure(c, p->tmp_out, (size_t)nf * 12 * sizeof(double)))) return rc;
+    ProblemView V = p->view();
+    partials_kernel<KIND_BA><<<grid_for(c, nf, 256), 256, 0, c->stream>>>(V, (int)nf, dfac, p->gfac.as<double>());
+    HIPCHK(c, hipGetLastError());
+    gather_rows12_kernel<<<grid_for(c, nf * 12, 256), 256, 0, c->stream>>>((int)nf, dfac, p->gfac.as<double>(), p->tmp_out.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(g12, p->tmp_out.p, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// =====================================================================================
+// plans
+// =====================================================================================
+extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const int64_t* free_ptr,
+                                    const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
+                                    rdis_hip_plan** out) {
+    if (!p || !out || ncomp < 0 || !free_ptr || !fac_ptr) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    *out = nullptr;
+    const int64_t nfree = free_ptr[ncomp], nfac = fac_ptr[ncomp];
+    if (free_ptr[0] != 0 || fac_ptr[0] != 0 || nfree < 0 || nfac < 0 || (nfree && !free_vid) || (nfac && !fac_id))
+        return fail(c, RDIS_HIP_EINVAL, "plan_create: bad CSR");
+    if (nfree >= (1ll << 31) / 5 || nfac >= (1ll << 31) - 16) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
+    HIPCHK(c, hipSetDevice(c->device));
+
+    rdis_hip_plan* L = new (std::nothrow) rdis_hip_plan;
+    if (!L) return fail(c, RDIS_HIP_ENOMEM, "plan_create: host allocation");
+    struct Guard { rdis_hip_plan* l; ~Guard() { if (l) rdis_hip_plan_destroy(l); } } guard{L};
+    L->prob = p; L->ncomp = ncomp; L->nfree = nfree; L->nfac = nfac;
+
+    // --- validate independence: free sets disjoint, factors owned once, and no
+    // factor of one component reads a free variable of another
+    std::vector<int> owner((size_t)p->N, -1), local((size_t)p->N, -1);
+    std::vector<int> h_free_ptr((size_t)ncomp + 1), h_fac_ptr((size_t)ncomp + 1);
+    std::vector<int> h_free_vid((size_t)nfree), h_fac_id((size_t)nfac);
+    for (int64_t cc = 0; cc <= ncomp; ++cc) {
+        if ((cc && (free_ptr[cc] < free_ptr[cc - 1] || fac_ptr[cc] < fac_ptr[cc - 1])))
+            return fail(c, RDIS_HIP_EINVAL, "plan_create: ptr not monotone");
+        h_free_ptr[(size_t)cc] = (int)free_ptr[cc];
+        h_fac_ptr[(size_t)cc] = (int)fac_ptr[cc];
+    }
+    for (int64_t cc = 0; cc < ncomp; ++cc)
+        for (int64_t i = free_ptr[cc]; i < free_ptr[cc + 1]; ++i) {
+            const int64_t v = free_vid[i];
+            if (v < 0 || v >= p->N) return fail(c, RDIS_HIP_EINVAL, "plan_create: free variable id out of range");
+            if (owner[(size_t)v] != -1) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: variable " + std::to_string(v) + " is free in two components (or listed twice)");
+            owner[(size_t)v] = (int)cc;
+            local[(size_t)v] = (int)(i - free_ptr[cc]);
+            h_free_vid[(size_t)i] = (int)v;
+        }
+    std::vector<char> fac_seen((size_t)p->F, 0);
+    std::vector<int> v2s_ptr((size_t)nfree + 1, 0);
+    for (int64_t cc = 0; cc < ncomp; ++cc)
+        for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
+            const int64_t f = fac_id[j];
+            if (f < 0 || f >= p->F) return fail(c, RDIS_HIP_EINVAL, "plan_create: factor id out of range");
+            if (fac_seen[(size_t)f]) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " listed twice");
+            fac_seen[(size_t)f] = 1;
+            h_fac_id[(size_t)j] = (int)f;
+            for (int k = 0, a = p->arity((int)f); k < a; ++k) {
+                const int v = p->var_of((int)f, k);
+                const int o = owner[(size_t)v];
+                if (o == -1) continue;  // a constant for this solve
+                if (o != (int)cc) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " of component " + std::to_string(cc) + " reads a free variable of component " + std::to_string(o));
+                ++v2s_ptr[(size_t)(free_ptr[cc] + local[(size_t)v]) + 1];
+            }
+        }
+    for (int64_t i = 0; i < nfree; ++i) v2s_ptr[(size_t)i + 1] += v2s_ptr[(size_t)i];
+    std::vector<int> v2s_idx((size_t)v2s_ptr[(size_t)nfree]);
+    {
+        std::vector<int> fill(v2s_ptr.begin(), v2s_ptr.end() - 1);
+        for (int64_t cc = 0; cc < ncomp; ++cc)
+            for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
+                const int f = h_fac_id[(size_t)j];
+                for (int k = 0, a = p->arity(f); k < a; ++k) {
+                    const int v = p->var_of(f, k);
+                    if (owner[(size_t)v] != (int)cc) continue;
+                    v2s_idx[(size_t)fill[(size_t)(free_ptr[cc] + local[(size_t)v])]++] = p->slot_of(f, k);
+                }
+            }
+    }
+    // heaviest components first (longest-processing-time order for the launch)
+    L->h_order.resize((size_t)ncomp);
+    std::iota(L->h_order.begin(), L->h_order.end(), 0);
+    std::stable_sort(L->h_order.begin(), L->h_order.end(), [&](int a, int b) {
+        return (fac_ptr[a + 1] - fac_ptr[a]) > (fac_ptr[b + 1] - fac_ptr[b]);
+    });
+    for (int64_t cc = 0; cc < ncomp; ++cc) {
+        L->max_fac = std::max(L->max_fac, fac_ptr[cc + 1] - fac_ptr[cc]);
+        L->max_free = std::max(L->max_free, free_ptr[cc + 1] - free_ptr[cc]);
+    }
+    L->h_fac_ptr = h_fac_ptr; L->h_free_ptr = h_free_ptr;
+
+    int rc = 0;
+    if (!rc) rc = upload(c, L->order, L->h_order);
+    if (!rc) rc = upload(c, L->free_ptr, h_free_ptr);
+    if (!rc) rc = upload(c, L->free_vid, h_free_vid);
+    if (!rc) rc = upload(c, L->fac_ptr, h_fac_ptr);
+    if (!rc) rc = upload(c, L->fac_id, h_fac_id);
+    if (!rc) rc = upload(c, L->v2s_ptr, v2s_ptr);
+    if (!rc) rc = upload(c, L->v2s_idx, v2s_idx);
+    if (!rc) rc = dalloc(c, L->ws, (size_t)(5 * nfree) * sizeof(double));
+    if (!rc) rc = dalloc(c, L->dir, (size_t)p->N * sizeof(double));
+    if (!rc) rc = dalloc(c, L->gfac, (size_t)p->nslots() * sizeof(double));
+    if (!rc) rc = dalloc(c, L->xstart, (size_t)nfree * sizeof(double));
+    if (!rc) rc = dalloc(c, L->xout, (size_t)nfree * sizeof(double));
+    if (!rc) rc = dalloc(c, L->fret, (size_t)ncomp * sizeof(double));
+    if (!rc) rc = dalloc(c, L->delta, (size_t)ncomp * sizeof(double));
+    if (!rc) rc = dalloc(c, L->iters, (size_t)ncomp * sizeof(int));
+    if (!rc) rc = dalloc(c, L->status, (size_t)ncomp * sizeof(int));
+    if (!rc) rc = dalloc(c, L->nfeval, (size_t)ncomp * sizeof(long long));
+    if (!rc) rc = dalloc(c, L->ngeval, (size_t)ncomp * sizeof(long long));
+    if (!rc) rc = dalloc(c, L->trace_n, (size_t)ncomp * sizeof(int));
+    if (!rc) rc = dalloc(c, L->objective, 64);
+    if (!rc) rc = dalloc(c, L->coop_state, coop_state_bytes());
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(L->dir.p, 0, L->dir.bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(L->coop_state.p, 0, L->coop_state.bytes, c->stream));
+    HIPCHK(c, hipEventCreate(&L->ev0));
+    HIPCHK(c, hipEventCreate(&L->ev1));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    guard.l = nullptr;
+    *out = L;
+    return 0;
+}
+
+extern "C" void rdis_hip_plan_destroy(rdis_hip_plan* L) {
+    if (!L) return;
+    if (L->prob) (void)hipStreamSynchronize(L->prob->ctx->stream);
+    if (L->ev0) (void)hipEventDestroy(L->ev0);
+    if (L->ev1) (void)hipEventDestroy(L->ev1);
+    delete L;
+}
+
+extern "C" int rdis_hip_plan_set_start(rdis_hip_plan* L, const double* xs) {
+    if (!L) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    if (L->nfree == 0) { L->have_start = true; return 0; }
+    if (xs) {
+        HIPCHK(c, hipMemcpyAsync(L->xstart.p, xs, (size_t)L->nfree * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        gather_x_kernel<<<grid_for(c, L->nfree, 256), 256, 0, c->stream>>>((int)L->nfree, L->free_vid.as<int>(), L->prob->x.as<double>(), L->xstart.as<double>());
+        HIPCHK(c, hipGetLastError());
+    }
+    L->have_start = true;
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int64_t value) {
+    if (!L || !name) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    const std::string n(name);
+    if (n == "block_threads") {
+        if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return fail(c, RDIS_HIP_EINVAL, "block_threads must be 0, 64, 128, 256, 512 or 1024");
+        L->block_threads = (int)value;
+    } else if (n == "coop_min_factors") {
+        if (value < 0) return fail(c, RDIS_HIP_EINVAL, "coop_min_factors < 0");
+        L->coop_min_factors = value;
+    } else if (n == "coop_workgroups") {
+        if (value < 0 || value > COOP_MAX_WG) return fail(c, RDIS_HIP_EINVAL, "coop_workgroups out of range");
+        L->coop_workgroups = (int)value;
+    } else if (n == "coop_threads") {
+        if (value != 64 && value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 64..512");
+        L->coop_threads = (int)value;
+    } else if (n == "trace_records") {
+        if (value < 0 || value > (1 << 22)) return fail(c, RDIS_HIP_EINVAL, "trace_records out of range");
+        L->trace_records = (int)value;
+        if (value > 0) {
+            int rc = dalloc(c, L->trace, (size_t)L->ncomp * (size_t)value * 4 * sizeof(double));
+            if (rc) return rc;
+        }
+    } else {
+        return fail(c, RDIS_HIP_EINVAL, "unknown option " + n);
+    }
+    return 0;
+}
+
+namespace {
+template <int KIND>
+int launch_wg(rdis_hip_plan* L, int threads, int grid, int order_offset, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    ProblemView P = L->prob->view();
+    PlanView V = L->view();
+    V.order += order_offset;
+    switch (threads) {
+        case 64: cgd_wg_kernel<KIND, 64><<<grid, 64, 0, c->stream>>>(P, V, maxiters, ftol); break;
+        case 128: cgd_wg_kernel<KIND, 128><<<grid, 128, 0, c->stream>>>(P, V, maxiters, ftol); break;
+        case 256: cgd_wg_kernel<KIND, 256><<<grid, 256, 0, c->stream>>>(P, V, maxiters, ftol); break;
+        case 512: cgd_wg_kernel<KIND, 512><<<grid, 512, 0, c->stream>>>(P, V, maxiters, ftol); break;
+        default: cgd_wg_kernel<KIND, 1024><<<grid, 1024, 0, c->stream>>>(P, V, maxiters, ftol); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ftol) {
+    if (!L || maxiters <= 0) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!L->have_start) { int rc = rdis_hip_plan_set_start(L, nullptr); if (rc) return rc; }
+    L->last_launches = 0;
+    L->timed = false;
+    if (L->ncomp == 0) return 0;
+
+    // components at the head of the (heaviest-first) order that are big enough go
+    // to the cooperative multi-workgroup solver, one launch each; the rest are one
+    // batched launch with one workgroup per component
+    int ncoop = 0;
+    if (L->coop_min_factors > 0)
+        while (ncoop < (int)L->ncomp) {
+            const int cc = L->h_order[(size_t)ncoop];
+            if (L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc] < L->coop_min_factors) break;
+            ++ncoop;
+        }
+    HIPCHK(c, hipEventRecord(L->ev0, c->stream));
+    for (int i = 0; i < ncoop; ++i) {
+        int rc = launch_coop(c->stream, c->num_cus, L->prob->kind, L->prob->view(), L->view(), L->h_order[(size_t)i],
+                             L->coop_workgroups, L->coop_threads, L->coop_state.p, maxiters, ftol);
+        if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
+        ++L->last_launches;
+    }
+    const int rest = (int)L->ncomp - ncoop;
+    if (rest > 0) {
+        int64_t mf = 0;
+        for (int i = ncoop; i < (int)L->ncomp; ++i) {
+            const int cc = L->h_order[(size_t)i];
+            mf = std::max<int64_t>(mf, std::max(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
+                                                (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
+        }
+        int threads = L->block_threads;
+        if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 2048 ? 512 : 1024;
+        int rc = L->prob->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, ncoop, maxiters, ftol)
+                                          : launch_wg<KIND_NLP>(L, threads, rest, ncoop, maxiters, ftol);
+        if (rc) return rc;
+        ++L->last_launches;
+    }
+    HIPCHK(c, hipEventRecord(L->ev1, c->stream));
+    L->timed = true;
+    objective_sum_kernel<<<1, 256, 0, c->stream>>>((int)L->ncomp, L->fret.as<double>(), L->objective.as<double>());
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_fetch(rdis_hip_plan* L, double* x_out, double* fret, double* delta, int32_t* iters,
+                                   int32_t* status, int64_t* nfeval, int64_t* ngeval) {
+    if (!L) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    auto cp = [&](void* dst, const DevBuf& b, size_t bytes) -> hipError_t {
+        return (dst && bytes) ? hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    };
+    HIPCHK(c, cp(x_out, L->xout, (size_t)L->nfree * sizeof(double)));
+    HIPCHK(c, cp(fret, L->fret, (size_t)L->ncomp * sizeof(double)));
+    HIPCHK(c, cp(delta, L->delta, (size_t)L->ncomp * sizeof(double)));
+    HIPCHK(c, cp(iters, L->iters, (size_t)L->ncomp * sizeof(int)));
+    HIPCHK(c, cp(status, L->status, (size_t)L->ncomp * sizeof(int)));
+    HIPCHK(c, cp(nfeval, L->nfeval, (size_t)L->ncomp * sizeof(long long)));
+    HIPCHK(c, cp(ngeval, L->ngeval, (size_t)L->ncomp * sizeof(long long)));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_objective_device(rdis_hip_plan* L, void** dev_ptr) {
+    if (!L || !dev_ptr) return RDIS_HIP_EINVAL;
+    *dev_ptr = L->objective.p;
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_last_kernel_ms(rdis_hip_plan* L, double* ms, int32_t* launches) {
+    if (!L || !ms) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    *ms = 0.0;
+    if (launches) *launches = L->last_launches;
+    if (!L->timed) return 0;
+    HIPCHK(c, hipEventSynchronize(L->ev1));
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, L->ev0, L->ev1));
+    *ms = t;
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* rec4, int64_t cap, int64_t* nrec) {
+    if (!L || !nrec || comp < 0 || comp >= L->ncomp) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    if (L->trace_records <= 0) { *nrec = 0; return 0; }
+    int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, L->trace_n.as<int>() + comp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *nrec = n;
+    const int64_t k = std::min<int64_t>(std::min<int64_t>(n, L->trace_records), cap);
+    if (rec4 && k > 0) {
+        HIPCHK(c, hipMemcpyAsync(rec4, L->trace.as<double>() + 4ll * L->trace_records * comp, (size_t)k * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int rdis_hip_cgd_batch(rdis_hip_problem* p, int64_t ncomp, const int64_t* free_ptr,
+                                  const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
+                                  double* x_inout, int32_t maxiters, double ftol, double* fret, double* delta,
+                                  int32_t* iters, int32_t* status, int64_t* nfeval, int64_t* ngeval) {
+    rdis_hip_plan* L = nullptr;
+    int rc = rdis_hip_plan_create(p, ncomp, free_ptr, free_vid, fac_ptr, fac_id, &L);
+    if (rc) return rc;
+    rc = rdis_hip_plan_set_start(L, x_inout);
+    if (!rc) rc = rdis_hip_plan_solve(L, maxiters, ftol);
+    if (!rc) rc = rdis_hip_plan_fetch(L, x_inout, fret, delta, iters, status, nfeval, ngeval);
+    rdis_hip_plan_destroy(L);
+    return rc;
+}

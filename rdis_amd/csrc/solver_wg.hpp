@@ -1,0 +1,345 @@
+// solver_wg.hpp -- one workgroup solves one component: the whole
+// CGDSubspaceOptimizer::optimize call (reference
+// src/optimizers/CGDSubspaceOptimizer.cpp:19-98) stays on the device, and a batch
+// of independent components is one launch (grid = components, heaviest first).
+//
+// Per line-search trial (SubfunctionFD::operator() / df, .cpp:124-184):
+//   phase A  every free variable: x[vid] = clamp(p + a*xi)      (quickAssignVals)
+//   phase B  every factor: gather 12 values of x, evaluate; for Brent also the 12
+//            partials dotted with the search direction -> the slope along the line
+//            needs no scatter at all
+//   reduce   wave butterfly + LDS, fixed order => bit-reproducible run to run
+// The full gradient is needed once per CG iteration only: per-factor partials go
+// to gfac[], then each free variable sums its slots in factor-list order (the same
+// order the reference's PartialGradient merge produces, src/State.h:157-210).
+#pragma once
+#include "device_views.hpp"
+#include "factors.hpp"
+#include "minimizer.hpp"
+
+namespace rdis_hip {
+
+constexpr int MAX_WAVES = 16;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) {
+    // VariableDomain::closestVal, single interval (reference src/VariableDomain.cpp:158-163)
+    if (lo <= v && v <= hi) return v;
+    return v < lo ? lo : hi;
+}
+
+// ---- factor evaluation shared by all solver variants ---------------------------
+template <int KIND, bool SLOPE>
+__device__ __forceinline__ void factor_value(const ProblemView& P, const double* __restrict__ dir,
+                                             int fid, double& f, double& s) {
+    if constexpr (KIND == KIND_BA) {
+        const int c = P.cam[fid], q = P.pt[fid];
+        const double2 o = P.obs[fid];
+        double v[12];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
+        if constexpr (SLOPE) {
+            double g[12];
+            f = ba_eval_grad(v, o.x, o.y, g);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += g[k] * dir[c + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc += g[9 + k] * dir[q + k];
+            s = acc;
+        } else {
+            f = ba_eval(v, o.x, o.y);
+            s = 0.0;
+        }
+    } else {
+        const int b = P.rowptr[fid], e = P.rowptr[fid + 1];
+        double prod = 1.0;
+        for (int k = b; k < e; ++k) prod *= nlp_term(P.x[P.vid[k]], P.expo[k], P.cons[k], P.sine[k] != 0);
+        f = prod * P.coeff[fid];
+        s = 0.0;
+        if constexpr (SLOPE) {
+            for (int k = b; k < e; ++k) {
+                const double dk = dir[P.vid[k]];
+                double d = 1.0;
+                for (int j = b; j < e; ++j) {
+                    const double xv = P.x[P.vid[j]];
+                    if (j == k) {
+                        if (P.expo[j] == 1.0 && !P.sine[j]) continue;
+                        d *= nlp_dterm(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
+                    } else {
+                        d *= nlp_term(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
+                    }
+                }
+                s += d * P.coeff[fid] * dk;
+            }
+        }
+    }
+}
+
+// per-factor partials into their gradient slots (BA: 12*fid + k, NLP: CSR position)
+template <int KIND>
+__device__ __forceinline__ void factor_partials(const ProblemView& P, double* __restrict__ gfac, int fid) {
+    if constexpr (KIND == KIND_BA) {
+        const int c = P.cam[fid], q = P.pt[fid];
+        const double2 o = P.obs[fid];
+        double v[12], g[12];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
+        ba_eval_grad(v, o.x, o.y, g);
+        double* dst = gfac + 12ll * fid;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dst[k] = g[k];
+    } else {
+        const int b = P.rowptr[fid], e = P.rowptr[fid + 1];
+        for (int k = b; k < e; ++k) {
+            double d = 1.0;
+            for (int j = b; j < e; ++j) {
+                const double xv = P.x[P.vid[j]];
+                if (j == k) {
+                    if (P.expo[j] == 1.0 && !P.sine[j]) continue;
+                    d *= nlp_dterm(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
+                } else {
+                    d *= nlp_term(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
+                }
+            }
+            gfac[k] = d * P.coeff[fid];
+        }
+    }
+}
+
+// ---- the single-workgroup environment ---------------------------------------------
+template <int KIND>
+struct WgEnv {
+    const ProblemView& P;
+    const PlanView& L;
+    int comp, n, m, tid, nt, nwaves;
+    const int* fv;    // free variable ids of this component
+    const int* fl;    // factor ids of this component
+    const int* vptr;  // v2s_ptr + free offset
+    double *p, *xi, *g, *h, *xinit;
+    double (*red)[3][MAX_WAVES];  // LDS [2][3][MAX_WAVES]
+    int parity;
+    long long nfeval, ngeval;
+    bool saw_nan;
+    double* tr;
+    int trn;
+
+    __device__ void sum3(double& a, double& b, double& mx) {
+        a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
+        const int w = tid >> 6;
+        if ((tid & 63) == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
+        __syncthreads();
+        double ra = 0.0, rb = 0.0, rm = 0.0;
+        for (int i = 0; i < nwaves; ++i) {
+            ra += red[parity][0][i]; rb += red[parity][1][i]; rm = fmax(rm, red[parity][2][i]);
+        }
+        a = ra; b = rb; mx = rm;
+        parity ^= 1;
+    }
+
+    __device__ void trace(int tag, double a, double b, double c) {
+        if (tr != nullptr && tid == 0) {
+            if (trn < L.trace_cap) {
+                double* r = tr + 4ll * trn;
+                r[0] = (double)tag; r[1] = a; r[2] = b; r[3] = c;
+            }
+            ++trn;
+        }
+    }
+
+    // SubfunctionFD::quickAssignVals at p + a*xi (reference .cpp:160-184; the
+    // trial point is formed unfused like minimize_nrc.h:434)
+    __device__ void assign_line(double a) {
+#pragma clang fp contract(off)
+        for (int i = tid; i < n; i += nt) {
+            const int v = fv[i];
+            const double t = a * xi[i];
+            P.x[v] = clampd(p[i] + t, P.lo[v], P.hi[v]);
+        }
+        __syncthreads();
+    }
+    __device__ void assign_vec(const double* src) {
+        for (int i = tid; i < n; i += nt) {
+            const int v = fv[i];
+            P.x[v] = clampd(src[i], P.lo[v], P.hi[v]);
+        }
+        __syncthreads();
+    }
+
+    template <bool SLOPE>
+    __device__ void eval_sum(double& f, double& s) {
+        double af = 0.0, as = 0.0, dummy = 0.0;
+        for (int j = tid; j < m; j += nt) {
+            double fj, sj;
+            factor_value<KIND, SLOPE>(P, L.dir, fl[j], fj, sj);
+            af += fj;
+            if constexpr (SLOPE) as += sj;
+        }
+        sum3(af, as, dummy);
+        f = af; s = as;
+        if (f != f) saw_nan = true;
+    }
+
+    __device__ double line_f(double a) {
+        ++nfeval;
+        assign_line(a);
+        double f, s;
+        eval_sum<false>(f, s);
+        trace(TR_F, a, f, 0.0);
+        return f;
+    }
+    __device__ void line_fd(double a, double& f, double& s) {
+        ++nfeval;
+        assign_line(a);
+        eval_sum<true>(f, s);
+        trace(TR_FD, a, f, s);
+    }
+    __device__ void count_slope() { ++ngeval; }
+
+    __device__ double first_eval() {  // CGD .cpp:34-39
+        const double* xs = L.xstart + (fv - L.free_vid);
+        for (int i = tid; i < n; i += nt) { p[i] = xs[i]; xinit[i] = xs[i]; xi[i] = 0.0; }
+        __syncthreads();
+        ++nfeval;
+        assign_vec(p);
+        double f, s;
+        eval_sum<false>(f, s);
+        return f;
+    }
+    __device__ double start_point() {  // nrc :628
+        ++nfeval;
+        assign_vec(p);
+        double f, s;
+        eval_sum<false>(f, s);
+        return f;
+    }
+    __device__ double eval_at(const double* src) {
+        ++nfeval;
+        assign_vec(src);
+        double f, s;
+        eval_sum<false>(f, s);
+        return f;
+    }
+
+    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p)
+    __device__ void gradient_to_xi() {
+        ++ngeval;
+        assign_vec(p);
+        for (int j = tid; j < m; j += nt) {
+            const int fid = fl[j];
+            if constexpr (KIND == KIND_BA) factor_partials<KIND>(P, L.gfac, fid);
+            else factor_partials<KIND>(P, L.gfac, fid);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            const int b = vptr[i], e = vptr[i + 1];
+            double s = 0.0;
+            if (b < e) {
+                s = L.gfac[L.v2s_idx[b]];
+                for (int k = b + 1; k < e; ++k) s += L.gfac[L.v2s_idx[k]];
+            }
+            xi[i] = s;
+        }
+        __syncthreads();
+    }
+
+    __device__ void cg_start() {
+        for (int i = tid; i < n; i += nt) { const double t = -xi[i]; g[i] = t; h[i] = t; xi[i] = t; }
+        __syncthreads();
+    }
+    __device__ void line_begin() {
+        for (int i = tid; i < n; i += nt) L.dir[fv[i]] = xi[i];
+        __syncthreads();
+    }
+    __device__ void line_end(double amin) {
+#pragma clang fp contract(off)
+        for (int i = tid; i < n; i += nt) {
+            const double t = xi[i] * amin;
+            xi[i] = t;
+            p[i] = p[i] + t;
+        }
+        __syncthreads();
+    }
+    __device__ void cg_reduce(double fp, double& test, double& gg, double& dgg) {
+#pragma clang fp contract(off)
+        const double den = fmax(fabs(fp), 1.0);
+        double a = 0.0, b = 0.0, t = 0.0;
+        for (int i = tid; i < n; i += nt) {
+            const double x = xi[i], gi = g[i];
+            t = fmax(t, fabs(x) * fmax(fabs(p[i]), 1.0) / den);
+            a = a + gi * gi;
+            b = b + (x + gi) * x;
+        }
+        sum3(a, b, t);
+        gg = a; dgg = b; test = t;
+    }
+    __device__ void cg_update(double gam) {
+#pragma clang fp contract(off)
+        for (int i = tid; i < n; i += nt) {
+            const double gn = -xi[i];
+            const double hn = gn + gam * h[i];
+            g[i] = gn; h[i] = hn; xi[i] = hn;
+        }
+        __syncthreads();
+    }
+};
+
+template <int KIND, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
+    __shared__ double red[2][3][MAX_WAVES];
+    const int comp = L.order[blockIdx.x];
+    const int f0 = L.free_ptr[comp], f1 = L.free_ptr[comp + 1];
+    const int c0 = L.fac_ptr[comp], c1 = L.fac_ptr[comp + 1];
+    const int n = f1 - f0, m = c1 - c0;
+
+    if (m == 0) {  // nothing to optimise: return 0, leave x as it was (.cpp:26-29)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) L.xout[f0 + i] = L.xstart[f0 + i];
+        if (threadIdx.x == 0) {
+            L.fret[comp] = 0.0; L.delta[comp] = 0.0; L.iters[comp] = 0;
+            L.status[comp] = EXIT_EMPTY; L.nfeval[comp] = 0; L.ngeval[comp] = 0;
+            if (L.trace_n) L.trace_n[comp] = 0;
+        }
+        return;
+    }
+
+    double* ws = L.ws + 5ll * f0;
+    WgEnv<KIND> E{P, L, comp, n, m, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
+                  L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
+                  ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
+                  red, 0, 0, 0, false,
+                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0};
+
+    const double finit = E.first_eval();
+    SolveOut r = frprmn(E, maxiters, ftol);
+    int status = r.reason;
+    double fret = r.fret;
+    E.assign_vec(E.p);  // assign gdmin.p with sanitisation (.cpp:61)
+    if (E.saw_nan) { status = EXIT_NAN; fret = DBL_MAX; }
+    if (fret > finit || E.saw_nan) {  // negative progress: restore the start (.cpp:66-80)
+        status |= STATUS_ROLLED_BACK;
+        fret = E.eval_at(E.xinit);
+    }
+    for (int i = E.tid; i < n; i += E.nt) L.xout[f0 + i] = P.x[E.fv[i]];
+    if (E.tid == 0) {
+        L.fret[comp] = fret; L.delta[comp] = fret - finit; L.iters[comp] = r.iter;
+        L.status[comp] = status; L.nfeval[comp] = E.nfeval; L.ngeval[comp] = E.ngeval;
+        if (L.trace_n) L.trace_n[comp] = E.trn;
+    }
+}
+
+}  // namespace rdis_hip
