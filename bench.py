@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: subspace-solver iterations per second on ladybug bundle
+adjustment (BASELINE.json metric), one process per GPU.
+
+A step = one pass of the hot path over one batch: CGDSubspaceOptimizer::optimize
+(SSmaxit 25, ftol 3e-8) over the workload's components, from the start state that
+is already resident in HBM, including the D2H of the results.  An iteration = one
+Frprmn outer iteration (one line minimisation), summed over components.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workloads (--workload):
+  ladybug-full   BASELINE config 4 (default, the metric's configuration): all 23769
+                 variables and 31843 factors of ladybug-49-7776 as one component.
+                 For N > 1 every rank solves one such component (N independent
+                 components of a block-diagonal problem; weak scaling) and the
+                 top-level objective is summed with an RCCL all-reduce.
+  synthetic-S    BASELINE config 5: 1000 independent 3-camera x 40-point components
+                 per rank (one workgroup each, one launch).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S"])
+    ap.add_argument("--maxiters", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
+    return ap.parse_args()
+
+
+def build_problem(workload: str, rank: int):
+    from rdis_amd import problems as P
+    if workload == "ladybug-full":
+        return P.load_bal().single_component()
+    return P.make_synthetic_ba(1000, 3, 40, first_comp=1000 * rank)
+
+
+def algorithmic_bytes(pp, nfeval: int, ngeval: int) -> float:
+    """value-only evaluation 24F + 8N + 8 bytes, value+gradient
+    24F + 16N + 8 (16 B observation + two int32 indices per factor, x read and g
+    written once per variable); every df call of the reference is counted as one
+    fused unit with the operator() call that precedes it."""
+    tot = 0.0
+    for c in range(pp.ncomp):
+        F = int(pp.comp_fac_ptr[c + 1] - pp.comp_fac_ptr[c])
+        N = int(pp.comp_free_ptr[c + 1] - pp.comp_free_ptr[c])
+        nf, ng = int(nfeval[c]), int(ngeval[c])
+        tot += max(nf - ng, 0) * (24 * F + 8 * N + 8) + ng * (24 * F + 16 * N + 8)
+    return tot
+
+
+def cpu_baseline(pp, maxiters: int):
+    """the oracle (a port of the reference's algorithm) on this box's host cores,
+    single-threaded like the reference; bounded to a few tens of seconds"""
+    from oracle import oracle as O
+    ncores = 1
+    if pp.meta.get("generator") == "synthetic_ba":
+        ncomp = 100
+        o = O.OracleProblem(pp)
+        t = time.perf_counter()
+        its = 0
+        for c in range(ncomp):
+            fv, fc = pp.component(c)
+            r = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=maxiters)
+            its += r.iters + 1
+        dt = time.perf_counter() - t
+        sample = f"first {ncomp} of 1000 components, dense gradient accumulation"
+        extra = {}
+    else:
+        o = O.OracleProblem(pp)
+        t = time.perf_counter()
+        r = o.cgd(maxiters=maxiters)
+        dt = time.perf_counter() - t
+        its = r.iters + 1
+        sample = f"the full workload once ({its} iterations), dense gradient accumulation"
+        # the reference's own cost model: sorted (vid,value)-vector merge per factor (State.h:157-210)
+        o2 = O.OracleProblem(pp)
+        t = time.perf_counter()
+        r2 = o2.cgd(maxiters=1, merge=True)
+        dt2 = time.perf_counter() - t
+        extra = {"reference_cost_model": {"value": (r2.iters + 1) / dt2, "unit": "iters/s",
+                                          "sample": "1 iteration with the reference's per-factor sorted-vector gradient merge",
+                                          "final_objective": r2.fret}}
+        extra["final_objective"] = r.fret
+    out = {"value": its / dt, "unit": "iters/s", "cores": ncores, "kind": "port", "sample": sample}
+    out.update(extra)
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs one process per GPU: launch with torch.distributed.run "
+                 f"--nproc-per-node {a.gpus} (WORLD_SIZE is {world})")
+    dist = None
+    torch = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch  # before the HIP library: one HIP runtime per process
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rdis_amd import capi
+    ctx = capi.Context(local_rank if world > 1 else 0)
+    if torch is not None:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
+
+    pp = build_problem(a.workload, rank)
+    prob = capi.Problem(ctx, pp)
+    plan = capi.Plan(prob)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        plan.set_option(k, int(v))
+    plan.set_start(pp.x0)
+
+    class _DevObjective:  # torch view of the device-side objective sum
+        def __init__(self, ptr):
+            self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    obj_t = torch.as_tensor(_DevObjective(plan.objective_device_ptr()), device=f"cuda:{local_rank}") if torch else None
+
+    def step():
+        plan.solve(a.maxiters, 3e-8)
+        if dist is not None:
+            dist.all_reduce(obj_t)  # top-level objective = sum over components (RDISOptimizer.cpp:1491-1494)
+        return plan.fetch()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(a.warmup):
+        r = step()
+    sync()
+    kms, klaunch, iters_done = 0.0, 0, 0
+    nfe = np.zeros(pp.ncomp, dtype=np.int64)
+    nge = np.zeros(pp.ncomp, dtype=np.int64)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step()
+        ms, nl = plan.last_kernel_ms()
+        kms += ms
+        klaunch += nl
+        iters_done += int(np.sum(r.iters.astype(np.int64) + 1))
+        nfe += r.nfeval
+        nge += r.ngeval
+    sync()
+    dt = time.perf_counter() - t0
+    objective_sum = plan.objective()  # after the all-reduce: whole-job objective
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        it = torch.tensor([iters_done], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(it)
+        total_iters = float(it.item())
+    else:
+        total_iters = float(iters_done)
+
+    if rank == 0:
+        abytes = algorithmic_bytes(pp, nfe, nge)
+        achieved = abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        line = {
+            "metric": "subspace-solver iters/sec (all components), ladybug BA",
+            "value": total_iters / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "ladybug-49-7776 (BAL file)" if a.workload == "ladybug-full" else "synthetic",
+            "config": {"workload": ("ladybug-49-7776 full, CGD over all 23769 variables / 31843 factors, SSmaxit 25, ftol 3e-8; "
+                                    "one such component per GPU") if a.workload == "ladybug-full" else
+                       "synthetic decomposable BA: 1000 components x (3 cameras, 40 points, 120 observations) per GPU, SSmaxit 25",
+                       "components_per_gpu": pp.ncomp, "factors_per_gpu": pp.nfac, "variables_per_gpu": pp.nvars,
+                       "parallelism": f"{world} x independent components, all-reduce of the objective"},
+            "final_objective": float(r.fret.sum()), "objective_sum_all_ranks": objective_sum,
+            "f_evals_per_s": float(nfe.sum()) * world / dt, "grad_evals_per_s": float(nge.sum()) * world / dt,
+            "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in
+                                      zip(*np.unique(r.status & 0xFF, return_counts=True))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "cgd solver kernel(s)", "kernel_ms_avg": kms / max(klaunch, 1),
+                         "algorithmic_bytes_per_launch": abytes / max(klaunch, 1)},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

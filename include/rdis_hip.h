@@ -74,6 +74,9 @@ const char *rdis_hip_last_error(const rdis_hip_ctx *ctx);
 /* run on a caller-provided hipStream_t (NULL: the context's own stream) */
 int rdis_hip_set_stream(rdis_hip_ctx *ctx, void *hip_stream);
 int rdis_hip_synchronize(rdis_hip_ctx *ctx);
+/* copy bytes from a device pointer handed out by this library to host memory
+ * (for FFI callers without HIP bindings); ordered after prior work on the stream */
+int rdis_hip_copy_to_host(rdis_hip_ctx *ctx, void *dst, const void *dev_src, int64_t bytes);
 
 /* ---- an OptimizableFunction in packed form --------------------------------------
  * x0/lo/hi: assigned value and single-interval domain of every variable
@@ -163,7 +166,8 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
 /* option names: "block_threads" (workgroup size of the per-component solver, 0 = auto),
  * "coop_min_factors" (components with at least this many factors are solved by the
  * multi-workgroup cooperative kernel; 0 = never), "coop_workgroups", "coop_threads",
- * "trace_records" (per-component trace capacity, 0 = off). */
+ * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
+ * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);
 /* device time of the solver kernel(s) of the last plan_solve, measured with HIP
  * events on the launch stream; launches = number of kernel launches it covers */
@@ -172,6 +176,10 @@ int rdis_hip_plan_last_kernel_ms(rdis_hip_plan *plan, double *ms, int32_t *launc
  * records of 4 doubles {tag, a, b, c}; *nrec = records written by the device */
 int rdis_hip_plan_get_trace(rdis_hip_plan *plan, int64_t comp, double *rec4, int64_t cap,
                             int64_t *nrec);
+
+/* p and search direction at the start of each of the first dump_iters line
+ * minimisations of component c: out[dump_iters][2][nfree_c] (dump_iters > 0) */
+int rdis_hip_plan_get_vectors(rdis_hip_plan *plan, int64_t comp, double *out, int64_t cap_doubles);
 
 #ifdef __cplusplus
 }

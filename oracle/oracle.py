@@ -24,6 +24,20 @@ FUNC_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double))
 GRAD_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
+class ReplayReport(C.Structure):
+    _fields_ = [("consumed", C.c_int64), ("first_mismatch", C.c_int64), ("step_mismatches", C.c_int64),
+                ("tag_mismatches", C.c_int64), ("underrun", C.c_int32), ("reason", C.c_int32),
+                ("iters", C.c_int32), ("fret", C.c_double), ("finit", C.c_double),
+                ("max_step_rel", C.c_double), ("max_f_rel", C.c_double), ("max_slope_rel", C.c_double),
+                ("max_iter_rel", C.c_double), ("max_vec_rel", C.c_double),
+                ("max_f_rel_near", C.c_double), ("max_slope_rel_near", C.c_double), ("last_near", C.c_int32),
+                ("synced_iters", C.c_int64),
+                ("pending_slope", C.c_double)]
+
+    def __repr__(self):
+        return "ReplayReport(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_[:-1]) + ")"
+
+
 class _Result(C.Structure):
     _fields_ = [("fret", C.c_double), ("delta", C.c_double), ("finit", C.c_double),
                 ("iters", C.c_int32), ("status", C.c_int32),
@@ -78,6 +92,12 @@ def lib() -> C.CDLL:
         L.ro_grad_each_ba.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
         L.ro_cgd_optimize.argtypes = [C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_void_p, _f64p,
                                       C.c_int32, C.c_double, C.c_int, C.POINTER(_Result)]
+        L.ro_cgd_replay.argtypes = [C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_void_p, _f64p, C.c_int32,
+                                    C.c_double, _f64p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.POINTER(ReplayReport)]
+        L.ro_cgd_record.restype = C.c_int64
+        L.ro_cgd_record.argtypes = [C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_void_p, _f64p, C.c_int32,
+                                    C.c_double, _f64p, C.c_int64]
         L.ro_frprmn.restype = C.c_int
         L.ro_frprmn.argtypes = [C.c_int, _f64p, FUNC_CB, GRAD_CB, C.c_void_p, C.c_int, C.c_double,
                                 C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -162,6 +182,42 @@ class OracleProblem:
                               xv, maxiters, ftol, int(merge), C.byref(res))
         return CGDResult(res.fret, res.delta, res.finit, res.iters, res.status, res.nfeval,
                          res.ngeval, xv)
+
+
+def _replay_args(self, free_vid, fac, x):
+    fv = np.arange(self.pp.nvars, dtype=np.int64) if free_vid is None else \
+        np.ascontiguousarray(free_vid, dtype=np.int64)
+    f, fp = _opt_i64(fac)
+    xv = self.get_x(fv) if x is None else np.ascontiguousarray(x, dtype=np.float64)
+    return fv, f, fp, xv
+
+
+def _replay(self, trace, free_vid=None, fac=None, x=None, maxiters=50, ftol=3e-8, vdump=None):
+    """feed a device trace ([n,4] records) through the oracle's solver -> ReplayReport;
+    vdump [iters,2,nfree]: the device's p / xi at the start of each line search"""
+    fv, f, fp, xv = _replay_args(self, free_vid, fac, x)
+    tr = np.ascontiguousarray(trace, dtype=np.float64).reshape(-1)
+    rep = ReplayReport()
+    xe = np.empty(fv.shape[0])
+    vd = None if vdump is None else np.ascontiguousarray(vdump, dtype=np.float64)
+    lib().ro_cgd_replay(self.h, fv.shape[0], fv, self.pp.nfac if f is None else f.shape[0], fp, xv,
+                        maxiters, ftol, tr, tr.shape[0] // 4,
+                        None if vd is None else vd.ctypes.data_as(C.c_void_p), 0 if vd is None else vd.shape[0],
+                        xe.ctypes.data_as(C.c_void_p), C.byref(rep))
+    rep.x_end = xe
+    return rep
+
+
+def _record(self, free_vid=None, fac=None, x=None, maxiters=50, ftol=3e-8, cap=1 << 16):
+    fv, f, fp, xv = _replay_args(self, free_vid, fac, x)
+    tr = np.zeros(cap * 4)
+    n = lib().ro_cgd_record(self.h, fv.shape[0], fv, self.pp.nfac if f is None else f.shape[0], fp, xv,
+                            maxiters, ftol, tr, cap)
+    return tr.reshape(cap, 4)[:min(n, cap)], n
+
+
+OracleProblem.replay = _replay
+OracleProblem.record = _record
 
 
 def ba_factor_eval(vals, ox, oy) -> float:

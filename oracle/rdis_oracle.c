@@ -489,6 +489,20 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
  * published algorithm with the reference's constants and evaluation order.
  * =========================================================================*/
 
+/* Optional overrides of the scalars the control logic sees.  The replay check
+ * (ro_cgd_replay) feeds the device's recorded values through these so that the
+ * oracle's decisions can be compared with the device's step by step. */
+typedef struct {
+    void *ctx;
+    double (*on_f)(void *ctx, double a, double f_own);
+    double (*on_slope)(void *ctx, double s_own, double s_abs, const double *xi, int n);
+    double (*on_start)(void *ctx, double fp_own);
+    void (*on_linmin)(void *ctx, double amin, double fmin);
+    void (*on_iter)(void *ctx, double *test, double *gg, double *dgg);
+    /* start of line minimisation `its`: p, xi (= h) may be inspected / replaced */
+    void (*on_vectors)(void *ctx, int its, int n, double *p, double *xi, double *h);
+} ro_hooks;
+
 typedef struct {
     int n;
     ro_func_cb f;
@@ -496,14 +510,16 @@ typedef struct {
     void *ctx;
     const double *p, *xi; /* line: p + a * xi */
     double *xt, *dft;
-    int failed;           /* set by a NaN in the callbacks */
+    const ro_hooks *hk;   /* optional value overrides (replay); NULL normally */
 } line_t;
 
 /* Df1dim::operator() (minimize_nrc.h:432-436) */
 static double line_f(line_t *L, double a)
 {
     for (int j = 0; j < L->n; ++j) L->xt[j] = L->p[j] + a * L->xi[j];
-    return L->f(L->ctx, L->xt);
+    double f = L->f(L->ctx, L->xt);
+    if (L->hk && L->hk->on_f) f = L->hk->on_f(L->hk->ctx, a, f);
+    return f;
 }
 
 /* Df1dim::df (minimize_nrc.h:439-447): slope at the xt left by line_f */
@@ -512,6 +528,11 @@ static double line_df(line_t *L)
     double s = 0.0;
     L->df(L->ctx, L->xt, L->dft);
     for (int j = 0; j < L->n; ++j) s += L->dft[j] * L->xi[j];
+    if (L->hk && L->hk->on_slope) {
+        double sabs = 0.0;
+        for (int j = 0; j < L->n; ++j) sabs += fabs(L->dft[j] * L->xi[j]);
+        s = L->hk->on_slope(L->hk->ctx, s, sabs, L->xi, L->n);
+    }
     return s;
 }
 
@@ -635,18 +656,20 @@ static int dbrent_min(const bracket_t *B, line_t *L, double *xmin, double *fmin)
 }
 
 /* Frprmn::minimize (minimize_nrc.h:619-691) with Dlinemethod::linmin (:492-513) */
-int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
-              int maxiters, double ftol, double *fret_out, int *iter_out)
+static int frprmn_ex(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
+                     int maxiters, double ftol, double *fret_out, int *iter_out,
+                     const ro_hooks *hk)
 {
     const double EPS = 1.0e-18, GTOL = 1.0e-8;
     double *buf = malloc(sizeof(double) * (size_t)(6 * n + 6));
     double *p = buf, *xi = p + n, *g = xi + n, *h = g + n, *xt = h + n, *dft = xt + n;
-    line_t L = { n, f, df, ctx, p, xi, xt, dft, 0 };
+    line_t L = { n, f, df, ctx, p, xi, xt, dft, hk };
     int reason = RO_EXIT_ITMAX, iter = 0;
     double fret = DBL_MAX;
 
     memcpy(p, x, sizeof(double) * (size_t)n);
     double fp = f(ctx, p);
+    if (hk && hk->on_start) fp = hk->on_start(hk->ctx, fp);
     df(ctx, p, xi);
     for (int j = 0; j < n; ++j) { g[j] = -xi[j]; xi[j] = h[j] = g[j]; }
 
@@ -655,10 +678,12 @@ int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
         /* linmin: bracket from (0,1), Brent with derivatives, move p */
         bracket_t B;
         double amin, fmin;
+        if (hk && hk->on_vectors) hk->on_vectors(hk->ctx, its, n, p, xi, h);
         bracket_min(&B, 0.0, 1.0, &L);
         if (dbrent_min(&B, &L, &amin, &fmin)) { reason = RO_EXIT_DBRENT_ITMAX; goto done; }
         for (int j = 0; j < n; ++j) { xi[j] *= amin; p[j] += xi[j]; }
         fret = fmin;
+        if (hk && hk->on_linmin) hk->on_linmin(hk->ctx, amin, fmin);
 
         if (2.0 * fabs(fret - fp) <= ftol * (fabs(fret) + fabs(fp) + EPS)) { reason = RO_EXIT_FTOL; goto done; }
         fp = fret;
@@ -669,12 +694,13 @@ int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
             const double t = fabs(xi[j]) * fmax(fabs(p[j]), 1.0) / den;
             if (t > test) test = t;
         }
-        if (test < GTOL) { reason = RO_EXIT_GTOL; goto done; }
         double gg = 0.0, dgg = 0.0;
         for (int j = 0; j < n; ++j) {
             gg += g[j] * g[j];
             dgg += (xi[j] + g[j]) * xi[j];
         }
+        if (hk && hk->on_iter) hk->on_iter(hk->ctx, &test, &gg, &dgg);
+        if (test < GTOL) { reason = RO_EXIT_GTOL; goto done; }
         if (gg == 0.0) { reason = RO_EXIT_GGZERO; goto done; }
         const double gam = dgg / gg;
         for (int j = 0; j < n; ++j) {
@@ -688,6 +714,12 @@ done:
     *iter_out = iter;
     free(buf);
     return reason;
+}
+
+int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
+              int maxiters, double ftol, double *fret_out, int *iter_out)
+{
+    return frprmn_ex(n, x, f, df, ctx, maxiters, ftol, fret_out, iter_out, NULL);
 }
 
 /* ===========================================================================
@@ -766,4 +798,219 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     out->iters = iter; out->status = status;
     out->nfeval = S.nfeval; out->ngeval = S.ngeval;
     free(S.gdense); free(xinit); free(xw);
+}
+
+/* ===========================================================================
+ * Replay check.  The device solver can record what its control logic saw: one
+ * record {tag, a, b, c} per event (tags as in rdis_amd/csrc/minimizer.hpp):
+ *   1 line value      a = step, b = f          2 line value+slope  c = slope
+ *   3 CG reductions   a = test, b = gg, c = dgg
+ *   4 start           a = fp                   5 line minimum a = amin, b = fmin
+ * ro_cgd_replay runs THIS file's solver on the same inputs, evaluates every
+ * quantity itself, compares it with the record, and then continues with the
+ * recorded value.  If the device implements the same algorithm, every step
+ * length the oracle asks for is bit-identical to the recorded one (the
+ * decisions are a pure function of the values seen), and the values agree to
+ * rounding.  This separates "same algorithm" from the chaotic sensitivity of
+ * the iterates to rounding.
+ * =========================================================================*/
+typedef struct {
+    const double *rec;
+    int64_t nrec, pos;
+    sub_t *S;
+    ro_replay_report *rep;
+    const double *vdump; /* [dump_iters][2][n]: the device's p and xi at the start of each line search */
+    int dump_iters;
+} replay_t;
+
+static const double *replay_next(replay_t *R, int tag_a, int tag_b)
+{
+    if (R->pos >= R->nrec) { R->rep->underrun = 1; return NULL; }
+    const double *r = R->rec + 4 * R->pos;
+    const int tag = (int)r[0];
+    if (tag != tag_a && tag != tag_b) {
+        if (R->rep->first_mismatch < 0) R->rep->first_mismatch = R->pos;
+        R->rep->tag_mismatches++;
+        return NULL;
+    }
+    R->pos++;
+    return r;
+}
+
+static void track(double *worst, double own, double dev, double scale)
+{
+    const double d = fabs(own - dev) / (scale > 0 ? scale : 1.0);
+    if (d > *worst || d != d) *worst = d;
+}
+
+static double replay_on_f(void *ctx, double a, double f_own)
+{
+    replay_t *R = ctx;
+    const double *r = replay_next(R, 1, 2);
+    if (!r) return f_own;
+    if (memcmp(&r[1], &a, sizeof(double)) != 0) {
+        if (R->rep->first_mismatch < 0) R->rep->first_mismatch = R->pos - 1;
+        R->rep->step_mismatches++;
+        track(&R->rep->max_step_rel, a, r[1], fabs(a));
+    }
+    /* scale: sum of |factor values| at the oracle's own point */
+    double sabs = 0.0;
+    for (int64_t i = 0; i < R->S->nf; ++i)
+        sabs += fabs(factor_value_nocache(R->S->p, R->S->fac ? R->S->fac[i] : i));
+    track(&R->rep->max_f_rel, f_own, r[2], sabs);
+    R->rep->last_near = fabs(f_own) <= 4.0 * fabs(R->rep->finit) + 1.0;
+    if (R->rep->last_near) track(&R->rep->max_f_rel_near, f_own, r[2], sabs);
+    R->rep->pending_slope = ((int)r[0] == 2) ? r[3] : NAN;
+    return r[2];
+}
+
+static double replay_on_slope(void *ctx, double s_own, double s_abs, const double *xi, int n)
+{
+    replay_t *R = ctx;
+    const double dev = R->rep->pending_slope;
+    /* scale = sum over factors and slots of |dE_i/dx_j * xi_j| at the currently
+     * assigned point: the slope is a sum of these terms, so this is what its
+     * rounding error is proportional to (the summed gradient entries can cancel) */
+    {
+        sub_t *S = R->S;
+        ro_problem *p = S->p;
+        double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
+        int64_t vids[64]; double vals[64];
+        for (int i = 0; i < n; ++i) dir[S->free_vid[i]] = xi[i];
+        double sc = 0.0;
+        for (int64_t i = 0; i < S->nf; ++i) {
+            const int64_t f = S->fac ? S->fac[i] : i;
+            if (fac_arity(p, f) > 64) continue;
+            const int k = factor_partials(p, f, vids, vals);
+            for (int j = 0; j < k; ++j) sc += fabs(vals[j] * dir[vids[j]]);
+        }
+        free(dir);
+        if (sc > s_abs) s_abs = sc;
+    }
+    if (dev != dev) { /* the device recorded a value-only evaluation here */
+        if (R->rep->first_mismatch < 0) R->rep->first_mismatch = R->pos - 1;
+        R->rep->tag_mismatches++;
+        return s_own;
+    }
+    track(&R->rep->max_slope_rel, s_own, dev, s_abs);
+    if (R->rep->last_near) track(&R->rep->max_slope_rel_near, s_own, dev, s_abs);
+    return dev;
+}
+
+static double replay_on_start(void *ctx, double fp_own)
+{
+    replay_t *R = ctx;
+    const double *r = replay_next(R, 4, 4);
+    if (!r) return fp_own;
+    track(&R->rep->max_f_rel, fp_own, r[1], fabs(fp_own));
+    return r[1];
+}
+
+static void replay_on_linmin(void *ctx, double amin, double fmin)
+{
+    replay_t *R = ctx;
+    const double *r = replay_next(R, 5, 5);
+    if (!r) return;
+    if (memcmp(&r[1], &amin, sizeof(double)) != 0 || memcmp(&r[2], &fmin, sizeof(double)) != 0) {
+        if (R->rep->first_mismatch < 0) R->rep->first_mismatch = R->pos - 1;
+        R->rep->step_mismatches++;
+    }
+}
+
+static void replay_on_iter(void *ctx, double *test, double *gg, double *dgg)
+{
+    replay_t *R = ctx;
+    const double *r = replay_next(R, 3, 3);
+    if (!r) return;
+    track(&R->rep->max_iter_rel, *test, r[1], fabs(*test));
+    track(&R->rep->max_iter_rel, *gg, r[2], fabs(*gg));
+    track(&R->rep->max_iter_rel, *dgg, r[3], fabs(*gg)); /* dgg can cancel; gg is its scale */
+    *test = r[1]; *gg = r[2]; *dgg = r[3];
+}
+
+/* Adopt the device's point and direction at the start of every recorded line
+ * search (after measuring how far the oracle's own had drifted): evaluations are
+ * then made at bit-identical points, so values can be compared to rounding over
+ * the whole run instead of through the problem's condition number. */
+static void replay_on_vectors(void *ctx, int its, int n, double *p, double *xi, double *h)
+{
+    replay_t *R = ctx;
+    if (!R->vdump || its >= R->dump_iters) return;
+    const double *dp = R->vdump + (size_t)2 * its * n, *dx = dp + n;
+    double pn = 0.0, xn = 0.0, pd = 0.0, xd = 0.0;
+    for (int j = 0; j < n; ++j) {
+        pn = fmax(pn, fabs(p[j])); xn = fmax(xn, fabs(xi[j]));
+        pd = fmax(pd, fabs(p[j] - dp[j])); xd = fmax(xd, fabs(xi[j] - dx[j]));
+    }
+    track(&R->rep->max_vec_rel, 0.0, pd, pn);
+    track(&R->rep->max_vec_rel, 0.0, xd, xn);
+    memcpy(p, dp, sizeof(double) * (size_t)n);
+    memcpy(xi, dx, sizeof(double) * (size_t)n);
+    memcpy(h, dx, sizeof(double) * (size_t)n);
+    R->rep->synced_iters = its + 1;
+}
+
+void ro_cgd_replay(ro_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
+                   const int64_t *fac, const double *xstart, int32_t maxiters, double ftol,
+                   const double *trace, int64_t nrec, const double *vdump, int32_t dump_iters,
+                   double *x_end, ro_replay_report *rep)
+{
+    memset(rep, 0, sizeof(*rep));
+    rep->first_mismatch = -1;
+    rep->pending_slope = NAN;
+    const int emulate = p->emulate;
+    ro_set_emulate_stale_cache(p, 0); /* the device recomputes every factor */
+    sub_t S = { p, nfree, nf, free_vid, fac, NULL, 0, 0, 0, 0 };
+    S.gdense = malloc(sizeof(double) * (size_t)(p->nvars + 1));
+    double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));
+    memcpy(xw, xstart, sizeof(double) * (size_t)nfree);
+    replay_t R = { trace, nrec, 0, &S, rep, vdump, dump_iters };
+    ro_hooks hk = { &R, replay_on_f, replay_on_slope, replay_on_start, replay_on_linmin, replay_on_iter,
+                    replay_on_vectors };
+
+    rep->finit = sub_f(&S, xw);
+    rep->reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &rep->fret, &rep->iters, &hk);
+    rep->consumed = R.pos;
+    if (x_end) memcpy(x_end, xw, sizeof(double) * (size_t)nfree);
+    free(S.gdense); free(xw);
+    ro_set_emulate_stale_cache(p, emulate);
+}
+
+/* ---- recording the oracle's own trace (self-check of the replay machinery) --- */
+typedef struct { double *rec; int64_t cap, n; } recorder_t;
+
+static void rec_put(recorder_t *T, int tag, double a, double b, double c)
+{
+    if (T->n < T->cap) { double *r = T->rec + 4 * T->n; r[0] = tag; r[1] = a; r[2] = b; r[3] = c; }
+    T->n++;
+}
+static double rec_on_f(void *ctx, double a, double f) { rec_put(ctx, 1, a, f, 0.0); return f; }
+static double rec_on_slope(void *ctx, double s, double sabs, const double *xi, int n)
+{
+    recorder_t *T = ctx; (void)sabs; (void)xi; (void)n;
+    if (T->n >= 1 && T->n <= T->cap) { double *r = T->rec + 4 * (T->n - 1); r[0] = 2; r[3] = s; }
+    return s;
+}
+static double rec_on_start(void *ctx, double fp) { rec_put(ctx, 4, fp, 0.0, 0.0); return fp; }
+static void rec_on_linmin(void *ctx, double amin, double fmin) { rec_put(ctx, 5, amin, fmin, 0.0); }
+static void rec_on_iter(void *ctx, double *t, double *gg, double *dgg) { rec_put(ctx, 3, *t, *gg, *dgg); }
+
+int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
+                      const int64_t *fac, const double *xstart, int32_t maxiters, double ftol,
+                      double *trace, int64_t cap)
+{
+    const int emulate = p->emulate;
+    ro_set_emulate_stale_cache(p, 0);
+    sub_t S = { p, nfree, nf, free_vid, fac, NULL, 0, 0, 0, 0 };
+    S.gdense = malloc(sizeof(double) * (size_t)(p->nvars + 1));
+    double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));
+    memcpy(xw, xstart, sizeof(double) * (size_t)nfree);
+    recorder_t T = { trace, cap, 0 };
+    ro_hooks hk = { &T, rec_on_f, rec_on_slope, rec_on_start, rec_on_linmin, rec_on_iter, NULL };
+    double fret; int iter;
+    (void)sub_f(&S, xw);
+    (void)frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+    free(S.gdense); free(xw);
+    ro_set_emulate_stale_cache(p, emulate);
+    return T.n;
 }

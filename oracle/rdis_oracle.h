@@ -114,6 +114,44 @@ typedef void (*ro_grad_cb)(void *ctx, const double *x, double *g);
 int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
               int maxiters, double ftol, double *fret, int *iter);
 
+/* ---- replay of a device trace (see rdis_oracle.c) ---------------------------*/
+typedef struct {
+    int64_t consumed;        /* trace records consumed */
+    int64_t first_mismatch;  /* index of the first record that did not line up, or -1 */
+    int64_t step_mismatches; /* step lengths / line minima not bit-identical */
+    int64_t tag_mismatches;  /* record kinds out of sequence */
+    int32_t underrun;        /* the oracle wanted more records than the trace holds */
+    int32_t reason;          /* oracle's exit reason when fed the device's values */
+    int32_t iters;
+    double fret, finit;
+    double max_step_rel;     /* worst |a_own - a_dev| / |a_own| among mismatching steps */
+    double max_f_rel;        /* worst |f_own - f_dev| / sum|factor values| */
+    double max_slope_rel;    /* worst |s_own - s_dev| / sum|g_j xi_j| */
+    double max_iter_rel;     /* worst relative difference of test / gg / dgg */
+    double max_vec_rel;      /* worst drift of p / xi (inf-norm relative) before each re-sync */
+    double max_f_rel_near;   /* max_f_rel / max_slope_rel restricted to trial points with
+                                |f| <= 4 |f(x0)| + 1: far-out bracketing steps (f up to 1e4 x f(x0))
+                                evaluate the projection near its pole and are ill-conditioned */
+    double max_slope_rel_near;
+    int32_t last_near;       /* internal */
+    int64_t synced_iters;    /* line searches started from the device's dumped p, xi */
+    double pending_slope;    /* internal */
+} ro_replay_report;
+
+/* vdump (may be NULL): the device's p and xi at the start of each of the first
+ * dump_iters line searches, [dump_iters][2][nfree]; the oracle adopts them so
+ * that both sides evaluate at bit-identical points.
+ * x_end (may be NULL) receives the oracle's unclamped end point Frprmn::p */
+void ro_cgd_replay(ro_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
+                   const int64_t *fac, const double *xstart, int32_t maxiters, double ftol,
+                   const double *trace, int64_t nrec, const double *vdump, int32_t dump_iters,
+                   double *x_end, ro_replay_report *rep);
+
+/* the oracle's own trace in the same record format; returns the record count */
+int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
+                      const int64_t *fac, const double *xstart, int32_t maxiters, double ftol,
+                      double *trace, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

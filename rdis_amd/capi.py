@@ -42,6 +42,7 @@ SYMBOLS = {
     "rdis_hip_last_error": (C.c_char_p, [_vp]),
     "rdis_hip_set_stream": (C.c_int, [_vp, _vp]),
     "rdis_hip_synchronize": (C.c_int, [_vp]),
+    "rdis_hip_copy_to_host": (C.c_int, [_vp, _vp, _vp, _i64]),
     "rdis_hip_upload_ba": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "rdis_hip_upload_nlp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "rdis_hip_free_problem": (None, [_vp]),
@@ -62,6 +63,7 @@ SYMBOLS = {
     "rdis_hip_plan_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "rdis_hip_plan_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -125,6 +127,11 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.rdis_hip_synchronize(self.h))
+
+    def copy_to_host(self, dev_ptr: int, nbytes: int) -> bytes:
+        buf = C.create_string_buffer(nbytes)
+        self.check(self.lib.rdis_hip_copy_to_host(self.h, buf, _vp(dev_ptr), nbytes))
+        return buf.raw
 
     def close(self):
         if getattr(self, "h", None):
@@ -291,6 +298,10 @@ class Plan:
                                                         _ptr(r.status), _ptr(r.nfeval), _ptr(r.ngeval)))
         return r
 
+    def objective(self) -> float:
+        """sum of fret over the plan's components, as computed on the device"""
+        return float(np.frombuffer(self.ctx.copy_to_host(self.objective_device_ptr(), 8), dtype=np.float64)[0])
+
     def objective_device_ptr(self) -> int:
         p = _vp()
         self.ctx.check(self.ctx.lib.rdis_hip_plan_objective_device(self.h, C.byref(p)))
@@ -300,6 +311,13 @@ class Plan:
         ms, n = C.c_double(), C.c_int32()
         self.ctx.check(self.ctx.lib.rdis_hip_plan_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def get_vectors(self, comp: int, dump_iters: int) -> np.ndarray:
+        """[dump_iters, 2, nfree_c]: p and xi at the start of each line minimisation"""
+        n = int(self.free_ptr[comp + 1] - self.free_ptr[comp])
+        out = np.zeros((dump_iters, 2, n))
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_get_vectors(self.h, comp, _ptr(out), out.size))
+        return out
 
     def get_trace(self, comp: int = 0, cap: int = 1 << 16) -> np.ndarray:
         rec = np.zeros((cap, 4))

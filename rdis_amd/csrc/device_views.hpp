@@ -65,6 +65,8 @@ struct PlanView {
     double* trace;        // [ncomp][trace_cap][4] or null
     int* trace_n;         // [ncomp]
     int trace_cap;
+    double* vdump;        // [2 * dump_iters * nfree_total] p, xi at the start of each line search, or null
+    int dump_iters;
 };
 
 }  // namespace rdis_hip

@@ -108,7 +108,7 @@ struct rdis_hip_plan {
     int64_t max_fac = 0, max_free = 0;
     DevBuf order, free_ptr, free_vid, fac_ptr, fac_id, v2s_ptr, v2s_idx;
     DevBuf ws, dir, gfac, xstart, xout, fret, delta, iters, status, nfeval, ngeval, objective;
-    DevBuf trace, trace_n, coop_state;
+    DevBuf trace, trace_n, coop_state, vdump;
     std::vector<int> h_order, h_fac_ptr, h_free_ptr;
     bool have_start = false;
     // options
@@ -116,6 +116,7 @@ struct rdis_hip_plan {
     int64_t coop_min_factors = 0;
     int coop_workgroups = 0, coop_threads = 256;
     int trace_records = 0;
+    int dump_iters = 0;
     // timing of the last solve
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_launches = 0;
@@ -136,6 +137,8 @@ struct rdis_hip_plan {
         v.trace = trace_records > 0 ? trace.as<double>() : nullptr;
         v.trace_n = trace_n.as<int>();
         v.trace_cap = trace_records;
+        v.vdump = dump_iters > 0 ? vdump.as<double>() : nullptr;
+        v.dump_iters = dump_iters;
         return v;
     }
 };
@@ -192,6 +195,14 @@ extern "C" int rdis_hip_set_stream(rdis_hip_ctx* c, void* s) {
 
 extern "C" int rdis_hip_synchronize(rdis_hip_ctx* c) {
     if (!c) return RDIS_HIP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_copy_to_host(rdis_hip_ctx* c, void* dst, const void* src, int64_t bytes) {
+    if (!c || bytes < 0 || (bytes && (!dst || !src))) return RDIS_HIP_EINVAL;
+    if (bytes == 0) return 0;
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -649,6 +660,14 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
             int rc = dalloc(c, L->trace, (size_t)L->ncomp * (size_t)value * 4 * sizeof(double));
             if (rc) return rc;
         }
+    } else if (n == "dump_iters") {
+        if (value < 0 || value > 4096 || (double)value * 2.0 * (double)L->nfree > 4e9) return fail(c, RDIS_HIP_EINVAL, "dump_iters out of range");
+        L->dump_iters = (int)value;
+        if (value > 0) {
+            int rc = dalloc(c, L->vdump, (size_t)value * 2 * (size_t)L->nfree * sizeof(double));
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(L->vdump.p, 0, L->vdump.bytes, c->stream));
+        }
     } else {
         return fail(c, RDIS_HIP_EINVAL, "unknown option " + n);
     }
@@ -772,6 +791,20 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
         HIPCHK(c, hipMemcpyAsync(rec4, L->trace.as<double>() + 4ll * L->trace_records * comp, (size_t)k * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_get_vectors(rdis_hip_plan* L, int64_t comp, double* out, int64_t cap_doubles) {
+    if (!L || !out || comp < 0 || comp >= L->ncomp) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    if (L->dump_iters <= 0) return fail(c, RDIS_HIP_EINVAL, "get_vectors: dump_iters is 0");
+    const int64_t n = L->h_free_ptr[(size_t)comp + 1] - L->h_free_ptr[(size_t)comp];
+    const int64_t want = 2ll * L->dump_iters * n;
+    if (cap_doubles < want) return fail(c, RDIS_HIP_EINVAL, "get_vectors: buffer too small");
+    if (want == 0) return 0;
+    HIPCHK(c, hipMemcpyAsync(out, L->vdump.as<double>() + 2ll * L->dump_iters * L->h_free_ptr[(size_t)comp],
+                             (size_t)want * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -137,6 +137,7 @@ struct WgEnv {
     bool saw_nan;
     double* tr;
     int trn;
+    int lm_count;  // line minimisations started
 
     __device__ void sum3(double& a, double& b, double& mx) {
         a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
@@ -263,6 +264,11 @@ struct WgEnv {
     }
     __device__ void line_begin() {
         for (int i = tid; i < n; i += nt) L.dir[fv[i]] = xi[i];
+        if (L.vdump != nullptr && lm_count < L.dump_iters) {  // debug aid for the replay check
+            double* d = L.vdump + 2ll * L.dump_iters * (fv - L.free_vid) + 2ll * lm_count * n;
+            for (int i = tid; i < n; i += nt) { d[i] = p[i]; d[n + i] = xi[i]; }
+        }
+        ++lm_count;
         __syncthreads();
     }
     __device__ void line_end(double amin) {
@@ -322,7 +328,7 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
                   L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                   ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
                   red, 0, 0, 0, false,
-                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0};
+                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
 
     const double finit = E.first_eval();
     SolveOut r = frprmn(E, maxiters, ftol);

@@ -73,6 +73,11 @@ class PackedProblem:
     def ncomp(self) -> int:
         return 0 if self.comp_free_ptr is None else int(self.comp_free_ptr.shape[0] - 1)
 
+    def component(self, c: int):
+        """(free_vid, fac_id) of component c of the stored decomposition"""
+        return (self.comp_free_vid[int(self.comp_free_ptr[c]):int(self.comp_free_ptr[c + 1])],
+                self.comp_fac_id[int(self.comp_fac_ptr[c]):int(self.comp_fac_ptr[c + 1])])
+
     def single_component(self) -> "PackedProblem":
         """Decomposition with one component = all variables, all factors (the
         BCD-with-one-block harness shape, src/optimizers/BCDOptimizer.cpp:149)."""

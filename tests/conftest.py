@@ -17,3 +17,10 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "reference_golden.json")) as fh:
         return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def gctx():
+    """one rdis_hip context on cuda:0; raises (loudly) if the HIP library or GPU is missing"""
+    from rdis_amd import capi
+    return capi.Context(0)

@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports exactly what include/rdis_hip.h declares; without a GPU it fails loudly
+instead of computing anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from rdis_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rdis_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rdis_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_bound_and_exported():
+    names = _declared()
+    assert len(names) >= 25
+    assert sorted(capi.SYMBOLS) == names          # the python binding covers the whole header
+    lib = capi.load_library()
+    for n in names:
+        assert getattr(lib, n) is not None        # dlsym succeeds
+    assert lib.rdis_hip_abi_version() == 1
+
+
+def test_no_oracle_on_the_product_path():
+    """nothing under rdis_amd/ may import, link or execute the oracle"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rdis_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in src and "rdis_oracle" not in src, os.path.join(dirpath, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.skipif(capi.load_library().rdis_hip_device_count() > 0, reason="a GPU is present")
+def test_fails_loudly_without_gpu():
+    lib = capi.load_library()
+    h = C.c_void_p()
+    assert lib.rdis_hip_create(0, C.byref(h)) == -3      # RDIS_HIP_EDEVICE, no fallback
+    with pytest.raises(capi.RdisHipError):
+        capi.Context(0)
+
+
+def test_null_arguments_are_rejected():
+    lib = capi.load_library()
+    assert lib.rdis_hip_create(0, None) == -1
+    assert lib.rdis_hip_plan_solve(None, 10, 1e-8) == -1
+    assert lib.rdis_hip_eval(None, 0, None, None) == -1

@@ -1,0 +1,134 @@
+"""Parity of the batched factor kernels (through the C ABI) with the CPU oracle
+and with the reference's golden values.  fp64; tolerances are stated per test."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rdis_amd import capi, problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    poly = P.load_poly()
+    poly.x0 = np.array([1.0, -2.0])
+    sin = P.make_high_dim_sinusoid()
+    sin.x0 = rng.uniform(-6.28, 6.28, sin.nvars)
+    return {"ladybug_5_30": P.load_bal(ncams=5, npts=30), "ladybug_49_500": P.load_bal(ncams=49, npts=500),
+            "ladybug_full": P.load_bal(), "testpoly": poly, "sinusoid": sin,
+            "synthetic": P.make_synthetic_ba(20, 3, 40)}
+
+
+CASES = _cases()
+
+
+def test_golden_factor0_and_full_gradient(golden, gctx):
+    pp = CASES["ladybug_full"]
+    g = capi.Problem(gctx, pp)
+    gl, g0 = golden["ladybug_full"], golden["ba_factor0"]
+    each = g.eval_each(np.array([0, 1, 31842]))
+    # |E_dev - E_ref| <= 1e-13 * (E + |obs|^2): the residual is a difference of pixel-scale numbers
+    scale = each + np.sum(pp.obs[[0, 1, 31842]] ** 2, axis=1)
+    assert np.all(np.abs(each - [g0["E"], gl["E_factor1"], gl["E_factor31842"]]) <= 1e-13 * scale)
+    row = g.grad_each_ba(np.array([0]))[0]
+    assert np.max(np.abs(row - g0["grad"])) <= 1e-12 * np.max(np.abs(g0["grad"]))
+    f, grad = g.eval_grad()
+    assert abs(f - gl["f_xinit"]) <= 1e-12 * gl["f_xinit"]
+    gmax = np.max(np.abs(grad))
+    assert abs(np.linalg.norm(grad) - gl["grad_norm2"]) <= 1e-12 * gl["grad_norm2"]
+    assert np.max(np.abs(grad[0:9] - gl["grad_0_8"])) <= 1e-10 * gmax          # 1e-10 rel-to-inf-norm
+    assert np.max(np.abs(grad[441:444] - gl["grad_441_443"])) <= 1e-10 * gmax
+    assert abs(grad[23768] - gl["grad_23768"]) <= 1e-10 * gmax
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_sum_gradient_and_per_factor_parity(name, gctx):
+    pp = CASES[name]
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    fo, go = o.eval(), o.gradient()
+    eo = o.eval_each()
+    fsum = np.sum(np.abs(eo))
+    assert abs(g.eval() - fo) <= 1e-12 * fsum                                  # sum: 1e-12 rel
+    f2, gg = g.eval_grad()
+    assert f2 == g.eval()                                                       # same kernel, same order
+    assert np.max(np.abs(gg - go)) <= 1e-12 * max(np.max(np.abs(go)), 1e-300)   # entries: 1e-12 rel-to-inf-norm
+    eg = g.eval_each()
+    if pp.kind == 0:
+        scale = eo + np.sum(pp.obs ** 2, axis=1)
+        assert np.all(np.abs(eg - eo) <= 1e-13 * scale)
+        a, b = o.grad_each_ba(), g.grad_each_ba()
+        assert np.max(np.abs(a - b) / np.max(np.abs(a), axis=1, keepdims=True)) <= 1e-9
+    else:
+        assert np.max(np.abs(eg - eo)) <= 1e-13 * max(np.max(np.abs(eo)), 1.0)
+
+
+def test_factor_sublists_and_linearity(gctx):
+    pp = CASES["ladybug_full"]
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    rng = np.random.default_rng(11)
+    sub = np.sort(rng.choice(pp.nfac, 5000, replace=False)).astype(np.int64)
+    rest = np.setdiff1d(np.arange(pp.nfac, dtype=np.int64), sub)
+    f_sub, g_sub = g.eval_grad(sub)
+    f_rest, g_rest = g.eval_grad(rest)
+    f_all, g_all = g.eval_grad()
+    assert abs(f_sub - o.eval(sub)) <= 1e-12 * abs(f_sub)
+    assert np.max(np.abs(g_sub - o.gradient(sub))) <= 1e-12 * np.max(np.abs(g_sub))
+    # size-independent property: the objective and gradient are additive over a partition of the factors
+    assert abs((f_sub + f_rest) - f_all) <= 1e-12 * f_all
+    assert np.max(np.abs((g_sub + g_rest) - g_all)) <= 1e-12 * np.max(np.abs(g_all))
+    # a permuted list is the same set: only the summation order changes
+    perm = rng.permutation(sub)
+    assert abs(g.eval(perm) - f_sub) <= 1e-12 * f_sub
+    # empty list
+    assert g.eval(np.zeros(0, dtype=np.int64)) == 0.0
+
+
+def test_assign_constants_and_determinism(gctx):
+    pp = CASES["ladybug_49_500"]
+    g = capi.Problem(gctx, pp)
+    o = O.OracleProblem(pp)
+    rng = np.random.default_rng(5)
+    vid = np.sort(rng.choice(pp.nvars, 300, replace=False)).astype(np.int64)
+    val = pp.x0[vid] * (1 + 1e-3 * rng.standard_normal(300))
+    g.set_x(val, vid)
+    o.assign(vid, val)
+    assert np.array_equal(g.get_x(vid), val)
+    assert np.array_equal(g.get_x(), o.get_x())
+    f1, g1 = g.eval_grad()
+    f2, g2 = g.eval_grad()
+    assert f1 == f2 and np.array_equal(g1, g2)                                  # bit-reproducible
+    assert abs(f1 - o.eval()) <= 1e-12 * f1
+
+
+def test_theta_zero_and_nlp_edge_cases(gctx):
+    # a camera with zero rotation takes the first-order branch
+    pp = P.make_synthetic_ba(1, 2, 5)
+    pp.x0[0:3] = 0.0
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    fo, go = o.eval(), o.gradient()
+    f, gg = g.eval_grad()
+    assert np.isfinite(f) and np.all(np.isfinite(gg))
+    assert abs(f - fo) <= 1e-12 * fo and np.max(np.abs(gg - go)) <= 1e-12 * np.max(np.abs(go))
+    # NLP with constants, a general exponent, exponent 0-free terms and a constant-only factor
+    terms = [(2.0, [(0, 3.0, 0.5, 0), (1, 1.0, 0.0, 1)]), (-7.0, []), (1.5, [(1, 2.0, -1.0, 1)]),
+             (0.25, [(0, 1.0, 0.0, 0), (1, 1.0, 0.0, 0), (2, 2.0, 0.0, 0)])]
+    q = P._pack_nlp(terms, np.array([1.3, -0.7, 0.9]), np.full(3, -5.0), np.full(3, 5.0), {})
+    o, g = O.OracleProblem(q), capi.Problem(gctx, q)
+    f, gg = g.eval_grad()
+    assert abs(f - o.eval()) <= 1e-13 * 10 and np.max(np.abs(gg - o.gradient())) <= 1e-13 * 10
+
+
+def test_abi_error_codes(gctx):
+    pp = CASES["ladybug_5_30"]
+    g = capi.Problem(gctx, pp)
+    with pytest.raises(capi.RdisHipError) as e:
+        g.eval(np.array([pp.nfac]))                 # factor id out of range
+    assert e.value.code == -1
+    with pytest.raises(capi.RdisHipError):
+        g.set_x(np.array([1.0]), np.array([-1]))
+    bad = P.load_bal(ncams=5, npts=30)
+    bad.pt_vid0 = bad.pt_vid0.copy()
+    bad.pt_vid0[3] = bad.nvars - 1                  # point block would run past the last variable
+    with pytest.raises(capi.RdisHipError):
+        capi.Problem(gctx, bad)
