@@ -164,8 +164,11 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
 
 /* tuning / introspection ---------------------------------------------------------- */
 /* option names: "block_threads" (workgroup size of the per-component solver, 0 = auto),
- * "coop_min_factors" (components with at least this many factors are solved by the
- * multi-workgroup cooperative kernel; 0 = never), "coop_workgroups", "coop_threads",
+ * "coop_min_factors" (bundle-adjustment components with at least this many factors are
+ * solved by the multi-workgroup cooperative kernel, one launch each; 0 = never; default
+ * 4096), "coop_max_components" (at most this many per plan, default 8; further large
+ * components stay in the batched launch), "coop_workgroups" (cap, 0 = what fits),
+ * "coop_threads" (128, 256 or 512),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);
@@ -177,6 +180,10 @@ int rdis_hip_plan_last_kernel_ms(rdis_hip_plan *plan, double *ms, int32_t *launc
 int rdis_hip_plan_get_trace(rdis_hip_plan *plan, int64_t comp, double *rec4, int64_t cap,
                             int64_t *nrec);
 
+/* shader-cycle accumulators of the last cooperative solve, as seen by lane 0 of
+ * workgroup 0: {factor arithmetic, workgroup reduce, publish, granule sweep, tail,
+ * #exchanges, #sweeps, 0} (profiling aid) */
+int rdis_hip_plan_debug_counters(rdis_hip_plan *plan, int64_t *out8);
 /* p and search direction at the start of each of the first dump_iters line
  * minimisations of component c: out[dump_iters][2][nfree_c] (dump_iters > 0) */
 int rdis_hip_plan_get_vectors(rdis_hip_plan *plan, int64_t comp, double *out, int64_t cap_doubles);

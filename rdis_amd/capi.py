@@ -64,6 +64,7 @@ SYMBOLS = {
     "rdis_hip_plan_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
+    "rdis_hip_plan_debug_counters": (C.c_int, [_vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -311,6 +312,11 @@ class Plan:
         ms, n = C.c_double(), C.c_int32()
         self.ctx.check(self.ctx.lib.rdis_hip_plan_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def debug_counters(self) -> np.ndarray:
+        out = np.zeros(32, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_debug_counters(self.h, _ptr(out)))
+        return out
 
     def get_vectors(self, comp: int, dump_iters: int) -> np.ndarray:
         """[dump_iters, 2, nfree_c]: p and xi at the start of each line minimisation"""

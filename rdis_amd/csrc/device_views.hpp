@@ -10,8 +10,11 @@
 //                 obs[F] (double2, one 16-byte load per factor)
 //   NLP factors:  coeff[F], rowptr[F+1], vid/expo/cons/sine[nnz]   (CSR)
 //   plan:         order[ncomp] (heaviest component first), free_ptr/free_vid,
-//                 fac_ptr/fac_id, v2s_ptr/v2s_idx (for every free variable the
-//                 gradient slots that feed it, in factor-list order),
+//                 fac_ptr/fac_id, v2s_ptr + slot_pos (gfac is variable-major: the
+//                 partials that feed free variable i are the contiguous range
+//                 gfac[v2s_ptr[i] .. v2s_ptr[i+1]) in factor-list order; slot_pos maps
+//                 a factor's slot to its position there, so factor lanes scatter and
+//                 variable lanes read a contiguous run),
 //                 ws[5 * nfree] (p, xi, g, h, x_init per component, contiguous),
 //                 dir[N] (search direction scattered by variable id; zero at
 //                 non-free variables), gfac[12F | nnz] (per-factor partials of the
@@ -50,10 +53,10 @@ struct PlanView {
     const int* fac_ptr;
     const int* fac_id;
     const int* v2s_ptr;   // [nfree_total + 1]
-    const int* v2s_idx;   // gradient-slot ids
+    const int* slot_pos;  // [12F | nnz] factor slot -> position in gfac (variable-major), -1 = not a free variable
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]
-    double* gfac;         // [12F] or [nnz]
+    double* gfac;         // [v2s_ptr[nfree_total]] per-factor partials, variable-major
     const double* xstart; // [nfree_total]
     double* xout;         // [nfree_total]
     double* fret;

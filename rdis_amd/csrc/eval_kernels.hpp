@@ -27,7 +27,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 partials_kernel(ProblemView P, int nf, const int* __restrict__ fac, double* __restrict__ gfac) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x)
-        factor_partials<KIND>(P, gfac, fac ? fac[i] : i);
+        factor_partials<KIND>(P, gfac, nullptr, fac ? fac[i] : i);
 }
 
 __global__ void __launch_bounds__(256)
@@ -61,7 +61,7 @@ eval_sum_kernel(ProblemView P, int nf, const int* __restrict__ fac, double* __re
         double f, s;
         factor_value<KIND, false>(P, nullptr, fid, f, s);
         acc += f;
-        if constexpr (GRAD) factor_partials<KIND>(P, gfac, fid);
+        if constexpr (GRAD) factor_partials<KIND>(P, gfac, nullptr, fid);
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) block_partial[blockIdx.x] = acc;

@@ -1,198 +1,354 @@
-// minimizer.hpp -- the subspace solver's control logic as device code.
+// minimizer.hpp -- the subspace solver's control logic as a resumable scalar
+// state machine.
 //
-// Polak-Ribiere conjugate gradients with bracketing + Brent-with-derivatives
-// line minimisation, i.e. what CGDSubspaceOptimizer::optimize drives through
-// nrc::Frprmn (reference src/optimizers/CGDSubspaceOptimizer.cpp:19-98,
-// external/include/minimize_nrc.h:80-151, 284-404, 492-513, 585-692), with the
-// reference's constants, evaluation order and exits.
+// What it computes: CGDSubspaceOptimizer::optimize (reference
+// src/optimizers/CGDSubspaceOptimizer.cpp:19-98) driving nrc::Frprmn -- Polak-
+// Ribiere conjugate gradients (external/include/minimize_nrc.h:619-691), line
+// minimisation (:492-513) by golden-section / parabolic bracketing (:80-151) and
+// Brent's method with derivatives (:284-404) -- with the reference's constants,
+// evaluation order, exits and f / df call counts.
 //
-// Every lane of the cooperating group (one workgroup, or a whole grid) runs this
-// scalar logic redundantly on group-uniform values: `Env` turns a step length
-// into a group-wide reduction, so all lanes take the same branches and nothing
-// has to be broadcast.  FP contraction is off in here so that, fed the same
-// function values, the device takes bit-identical decisions to the CPU oracle
-// (tests/test_replay.py checks exactly that).
-//
-// Env concept:
-//   double line_f(double a)                       f(clamp(p + a*xi))               [operator()]
-//   void   line_fd(double a, double&f, double&s)  f and slope d/da at the same a   [operator() then df]
-//   void   count_slope()                          the reference would have called df here
-//   double first_eval()        assign clamp(x0), return f         (CGD .cpp:34-37)
-//   double start_point()       Frprmn's fp = func(p)              (nrc :628)
-//   void   gradient_to_xi()    xi <- grad f(clamp(p))             (nrc :629, :654)
-//   void   cg_start()          g = -xi; xi = h = g                (nrc :631-635)
-//   void   line_begin()/line_end(double amin)                     (nrc :505-511)
-//   void   cg_reduce(double fp, double& test, double& gg, double& dgg)   (nrc :655-672)
-//   void   cg_update(double gam)                                  (nrc :679-683)
-//   void   trace(int tag, double a, double b, double c)
+// How: the reference nests four routines that call the objective from a dozen
+// places.  Inlined on a GPU that puts a dozen copies of the factor arithmetic
+// into one kernel (110 KB of code, more than the instruction cache: measured 69 %
+// of the solve stalled on instruction fetch).  Here the control logic is turned
+// inside out: `next()` consumes the reply to the previous request and returns
+// the next request -- "value at step a", "value and slope at step a", "gradient
+// at p", a vector update -- and the kernel's driver loop holds the ONE copy of
+// each heavy operation.  Every lane of the cooperating group runs the machine
+// redundantly on group-uniform replies, so all lanes take the same branches and
+// nothing is broadcast.  FP contraction is off in here: fed the same replies the
+// device takes bit-identical decisions to the CPU oracle (tests/test_gpu_solver.py
+// replays the device's trace through the oracle to check exactly that).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cfloat>
 
 namespace rdis_hip {
 
-// exit reasons: low byte of status (mirrors oracle RO_EXIT_*; include/rdis_hip.h)
+// exit reasons: low byte of status (include/rdis_hip.h RDIS_HIP_EXIT_*)
 enum : int {
     EXIT_FTOL = 0, EXIT_GTOL = 1, EXIT_GGZERO = 2, EXIT_ITMAX = 3, EXIT_DBRENT_ITMAX = 4,
     EXIT_NAN = 5, EXIT_EMPTY = 6, EXIT_SYNC_TIMEOUT = 7
 };
 constexpr int STATUS_ROLLED_BACK = 0x100;
 
-enum : int { TR_F = 1, TR_FD = 2, TR_ITER = 3, TR_START = 4, TR_LINMIN = 5 };
+// trace record tags (oracle/rdis_oracle.c ro_cgd_replay reads the same)
+enum : int { TR_NONE = 0, TR_F = 1, TR_FD = 2, TR_ITER = 3, TR_START = 4, TR_LINMIN = 5 };
 
-struct Bracket { double ax, bx, cx, fa, fb, fc; };
+enum : int {
+    REQ_F = 0,        // value at clamp(p + a*xi); restore: at clamp(x_init) instead   reply r0 = f
+    REQ_FD,           // value and slope d/da at clamp(p + a*xi)                        reply r0 = f, r1 = slope
+    REQ_GRAD,         // xi <- grad f(clamp(p))                       (nrc :629, :654)
+    REQ_CG_START,     // g = -xi; xi = h = g                          (nrc :631-635)
+    REQ_LINE_BEGIN,   // a new line p + a*xi starts                   (nrc :496-498)
+    REQ_LINE_END,     // xi *= a; p += xi                             (nrc :508-511)
+    REQ_CG_REDUCE,    // a = fp: reply r0 = test, r1 = gg, r2 = dgg   (nrc :655-672)
+    REQ_CG_UPDATE,    // a = gamma: g = -xi; xi = h = g + gamma*h     (nrc :679-683)
+    REQ_DONE
+};
 
-// Bracketmethod::bracket (nrc :80-151)
-template <class Env>
-__device__ void bracket_min(Env& E, Bracket& B, double a, double b) {
-#pragma clang fp contract(off)
-    const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;
-    double ax = a, bx = b, cx, fa, fb, fc, fu, tmp;
-    fa = E.line_f(ax);
-    fb = E.line_f(bx);
-    if (fb > fa) {
-        tmp = ax; ax = bx; bx = tmp;
-        tmp = fa; fa = fb; fb = tmp;
+struct Request {
+    int kind;
+    double a;
+    bool restore;
+    bool line;           // an evaluation on the current line (recorded in the trace)
+    int tr_tag;          // optional trace record emitted before the request is served
+    double tr_a, tr_b, tr_c;
+};
+
+struct CgdMachine {
+    enum : int {
+        S_BEGIN, S_FIRST, S_GRAD0, S_ITER_BEGIN, S_BR_START, S_BR_FA, S_BR_FB, S_BR_FC, S_BR_HEAD,
+        S_BR_CASE1, S_BR_CASE2, S_BR_SHIFT, S_DB_START, S_DB_FIRST, S_DB_HEAD, S_DB_EVAL,
+        S_AFTER_LINMIN, S_GRAD_ITER, S_REDUCED, S_FINISH, S_ROLLED, S_DONE
+    };
+    int maxiters;
+    double ftol;
+    int st, its, iter, reason;
+    double finit, fp, fret;
+    bool saw_nan, rolled_back;
+    long long nfeval, ngeval;
+    // bracket (nrc :80-151)
+    double ax, bx, cx, fa, fb, fc, u;
+    // Brent with derivatives (nrc :284-404)
+    double a, b, x, w, v, fx, fw, fv, dx, dw, dv, d, e, uu;
+    int it;
+    bool tiny;
+
+    __device__ void init(int maxiters_, double ftol_) {
+        maxiters = maxiters_; ftol = ftol_;
+        st = S_BEGIN; its = 0; iter = 0; reason = EXIT_ITMAX;
+        finit = 0.0; fp = 0.0; fret = DBL_MAX;
+        saw_nan = false; rolled_back = false; nfeval = 0; ngeval = 0;
+        ax = bx = cx = fa = fb = fc = u = 0.0;
+        a = b = x = w = v = fx = fw = fv = dx = dw = dv = d = e = uu = 0.0;
+        it = 0; tiny = false;
     }
-    cx = bx + GOLD * (bx - ax);
-    fc = E.line_f(cx);
-    while (fb > fc) {
-        const double r = (bx - ax) * (fb - fc);
-        const double q = (bx - cx) * (fb - fa);
-        const double qr = q - r;
-        double u = bx - ((bx - cx) * q - (bx - ax) * r) / (2.0 * copysign(fmax(fabs(qr), TINY), qr));
-        const double ulim = bx + GLIMIT * (cx - bx);
-        if ((bx - u) * (u - cx) > 0.0) {
-            fu = E.line_f(u);
-            if (fu < fc) { ax = bx; bx = u; fa = fb; fb = fu; break; }
-            if (fu > fb) { cx = u; fc = fu; break; }
-            u = cx + GOLD * (cx - bx);
-            fu = E.line_f(u);
-        } else if ((cx - u) * (u - ulim) > 0.0) {
-            fu = E.line_f(u);
-            if (fu < fc) {
-                const double unew = u + GOLD * (u - cx);
-                bx = cx; cx = u; u = unew;
-                fb = fc; fc = fu; fu = E.line_f(u);
+    __device__ int status() const { return reason | (rolled_back ? STATUS_ROLLED_BACK : 0); }
+
+    __device__ static Request req(int kind, double a = 0.0) {
+        Request r; r.kind = kind; r.a = a; r.restore = false; r.line = false; r.tr_tag = TR_NONE; r.tr_a = r.tr_b = r.tr_c = 0.0;
+        return r;
+    }
+    __device__ static Request traced(Request r, int tag, double ta, double tb, double tc) {
+        r.tr_tag = tag; r.tr_a = ta; r.tr_b = tb; r.tr_c = tc;
+        return r;
+    }
+    __device__ Request want_f(double at, bool line = true) { ++nfeval; Request r = req(REQ_F, at); r.line = line; return r; }
+    __device__ Request want_fd(double at) { ++nfeval; Request r = req(REQ_FD, at); r.line = true; return r; }
+
+    // r0, r1, r2: reply to the previous request
+    __device__ Request next(double r0, double r1, double r2) {
+#pragma clang fp contract(off)
+        const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;      // nrc :82
+        const double EPS = 1.0e-18, GTOL = 1.0e-8;                          // nrc :621-622
+        const double TOL = 3.0e-8;  // Dbrent's own default, not the solver's ftol (nrc :288, :499)
+        const double ZEPS = DBL_EPSILON * 1.0e-3;
+        const int DB_ITMAX = 100;
+        for (;;) {
+            switch (st) {
+            case S_BEGIN:  // CGD .cpp:34-37: assign clamp(x0), initialFval = sfd(xval)
+                st = S_FIRST;
+                return want_f(0.0, false);
+            case S_FIRST:
+                finit = r0;
+                if (r0 != r0) saw_nan = true;
+                ++nfeval;            // Frprmn's own fp = func(p): same point, same value (nrc :628)
+                fp = finit;
+                ++ngeval;            // func.df(p, xi) (nrc :629)
+                st = S_GRAD0;
+                return traced(req(REQ_GRAD), TR_START, fp, 0.0, 0.0);
+            case S_GRAD0:
+                its = 0;
+                st = S_ITER_BEGIN;
+                return req(REQ_CG_START);
+            case S_ITER_BEGIN:
+                if (its >= maxiters) { reason = EXIT_ITMAX; st = S_FINISH; break; }
+                iter = its;
+                st = S_BR_START;
+                return req(REQ_LINE_BEGIN);
+
+            // ---- bracket from (0, 1) ------------------------------------------------
+            case S_BR_START:
+                ax = 0.0; bx = 1.0;
+                st = S_BR_FA;
+                return want_f(ax);
+            case S_BR_FA:
+                fa = r0; if (r0 != r0) saw_nan = true;
+                st = S_BR_FB;
+                return want_f(bx);
+            case S_BR_FB:
+                fb = r0; if (r0 != r0) saw_nan = true;
+                if (fb > fa) { double t = ax; ax = bx; bx = t; t = fa; fa = fb; fb = t; }
+                cx = bx + GOLD * (bx - ax);
+                st = S_BR_FC;
+                return want_f(cx);
+            case S_BR_FC:
+                fc = r0; if (r0 != r0) saw_nan = true;
+                st = S_BR_HEAD;
+                break;
+            case S_BR_HEAD: {
+                if (!(fb > fc)) { st = S_DB_START; break; }
+                const double r = (bx - ax) * (fb - fc);
+                const double q = (bx - cx) * (fb - fa);
+                const double qr = q - r;
+                u = bx - ((bx - cx) * q - (bx - ax) * r) / (2.0 * copysign(fmax(fabs(qr), TINY), qr));
+                const double ulim = bx + GLIMIT * (cx - bx);
+                if ((bx - u) * (u - cx) > 0.0) { st = S_BR_CASE1; return want_f(u); }
+                if ((cx - u) * (u - ulim) > 0.0) { st = S_BR_CASE2; return want_f(u); }
+                if ((u - ulim) * (ulim - cx) >= 0.0) u = ulim;
+                else u = cx + GOLD * (cx - bx);
+                st = S_BR_SHIFT;
+                return want_f(u);
             }
-        } else if ((u - ulim) * (ulim - cx) >= 0.0) {
-            u = ulim;
-            fu = E.line_f(u);
-        } else {
-            u = cx + GOLD * (cx - bx);
-            fu = E.line_f(u);
-        }
-        ax = bx; bx = cx; cx = u;
-        fa = fb; fb = fc; fc = fu;
-    }
-    B.ax = ax; B.bx = bx; B.cx = cx; B.fa = fa; B.fb = fb; B.fc = fc;
-}
-
-// Dbrent::minimize (nrc :284-404); false = 100 iterations without convergence
-template <class Env>
-__device__ bool dbrent_min(Env& E, const Bracket& B, double& xmin, double& fmin) {
-#pragma clang fp contract(off)
-    const int ITMAX = 100;
-    const double tol = 3.0e-8;  // Dbrent's own default, not the solver's ftol (nrc :288,:499)
-    const double ZEPS = DBL_EPSILON * 1.0e-3;
-    double a = (B.ax < B.cx ? B.ax : B.cx);
-    double b = (B.ax > B.cx ? B.ax : B.cx);
-    double x, w, v, fx, fw, fv, dx, dw, dv, u, fu, du;
-    double d = 0.0, e = 0.0;
-    x = w = v = B.bx;
-    E.line_fd(x, fx, dx);
-    E.count_slope();
-    fw = fv = fx;
-    dw = dv = dx;
-    for (int it = 0; it < ITMAX; ++it) {
-        const double xm = 0.5 * (a + b);
-        const double tol1 = tol * fabs(x) + ZEPS;
-        const double tol2 = 2.0 * tol1;
-        if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) { fmin = fx; xmin = x; return true; }
-        bool bisect = true;
-        if (fabs(e) > tol1) {
-            double d1 = 2.0 * (b - a), d2 = d1;
-            if (dw != dx) d1 = (w - x) * dx / (dx - dw);
-            if (dv != dx) d2 = (v - x) * dx / (dx - dv);
-            const double u1 = x + d1, u2 = x + d2;
-            const bool ok1 = (a - u1) * (u1 - b) > 0.0 && dx * d1 <= 0.0;
-            const bool ok2 = (a - u2) * (u2 - b) > 0.0 && dx * d2 <= 0.0;
-            const double olde = e;
-            e = d;
-            if (ok1 || ok2) {
-                if (ok1 && ok2) d = (fabs(d1) < fabs(d2) ? d1 : d2);
-                else if (ok1) d = d1;
-                else d = d2;
-                if (fabs(d) <= fabs(0.5 * olde)) {
-                    u = x + d;
-                    if (u - a < tol2 || b - u < tol2) d = copysign(tol1, xm - x);
-                    bisect = false;
+            case S_BR_CASE1: {  // parabolic u between b and c
+                const double fu = r0; if (r0 != r0) saw_nan = true;
+                if (fu < fc) { ax = bx; bx = u; fa = fb; fb = fu; st = S_DB_START; break; }
+                if (fu > fb) { cx = u; fc = fu; st = S_DB_START; break; }
+                u = cx + GOLD * (cx - bx);
+                st = S_BR_SHIFT;
+                return want_f(u);
+            }
+            case S_BR_CASE2: {  // parabolic u between c and its limit
+                const double fu = r0; if (r0 != r0) saw_nan = true;
+                if (fu < fc) {
+                    const double unew = u + GOLD * (u - cx);
+                    bx = cx; cx = u; u = unew;
+                    fb = fc; fc = fu;
+                    st = S_BR_SHIFT;
+                    return want_f(u);
                 }
+                ax = bx; bx = cx; cx = u;
+                fa = fb; fb = fc; fc = fu;
+                st = S_BR_HEAD;
+                break;
             }
-        }
-        if (bisect) { e = (dx >= 0.0 ? a - x : b - x); d = 0.5 * e; }
-        if (fabs(d) >= tol1) {
-            u = x + d;
-            E.line_fd(u, fu, du);
-        } else {
-            u = x + copysign(tol1, d);
-            E.line_fd(u, fu, du);
-            if (fu > fx) { fmin = fx; xmin = x; return true; }
-        }
-        E.count_slope();
-        if (fu <= fx) {
-            if (u >= x) a = x; else b = x;
-            v = w; fv = fw; dv = dw;
-            w = x; fw = fx; dw = dx;
-            x = u; fx = fu; dx = du;
-        } else {
-            if (u < x) a = u; else b = u;
-            if (fu <= fw || w == x) {
-                v = w; fv = fw; dv = dw;
-                w = u; fw = fu; dw = du;
-            } else if (fu < fv || v == x || v == w) {
-                v = u; fv = fu; dv = du;
+            case S_BR_SHIFT: {
+                const double fu = r0; if (r0 != r0) saw_nan = true;
+                ax = bx; bx = cx; cx = u;
+                fa = fb; fb = fc; fc = fu;
+                st = S_BR_HEAD;
+                break;
+            }
+
+            // ---- Brent with derivatives on the bracket ------------------------------
+            case S_DB_START:
+                a = (ax < cx ? ax : cx);
+                b = (ax > cx ? ax : cx);
+                x = w = v = bx;
+                d = 0.0; e = 0.0; it = 0;
+                st = S_DB_FIRST;
+                return want_fd(x);
+            case S_DB_FIRST:
+                fx = r0; dx = r1; if (r0 != r0) saw_nan = true;
+                ++ngeval;
+                fw = fv = fx;
+                dw = dv = dx;
+                st = S_DB_HEAD;
+                break;
+            case S_DB_HEAD: {
+                if (it >= DB_ITMAX) { reason = EXIT_DBRENT_ITMAX; st = S_FINISH; break; }  // nrc :403 throws
+                const double xm = 0.5 * (a + b);
+                const double tol1 = TOL * fabs(x) + ZEPS;
+                const double tol2 = 2.0 * tol1;
+                if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) {
+                    st = S_AFTER_LINMIN;
+                    return traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0);
+                }
+                bool bisect = true;
+                if (fabs(e) > tol1) {
+                    double d1 = 2.0 * (b - a), d2 = d1;
+                    if (dw != dx) d1 = (w - x) * dx / (dx - dw);
+                    if (dv != dx) d2 = (v - x) * dx / (dx - dv);
+                    const double u1 = x + d1, u2 = x + d2;
+                    const bool ok1 = (a - u1) * (u1 - b) > 0.0 && dx * d1 <= 0.0;
+                    const bool ok2 = (a - u2) * (u2 - b) > 0.0 && dx * d2 <= 0.0;
+                    const double olde = e;
+                    e = d;
+                    if (ok1 || ok2) {
+                        if (ok1 && ok2) d = (fabs(d1) < fabs(d2) ? d1 : d2);
+                        else if (ok1) d = d1;
+                        else d = d2;
+                        if (fabs(d) <= fabs(0.5 * olde)) {
+                            const double ut = x + d;
+                            if (ut - a < tol2 || b - ut < tol2) d = copysign(tol1, xm - x);
+                            bisect = false;
+                        }
+                    }
+                }
+                if (bisect) { e = (dx >= 0.0 ? a - x : b - x); d = 0.5 * e; }
+                if (fabs(d) >= tol1) { uu = x + d; tiny = false; }
+                else { uu = x + copysign(tol1, d); tiny = true; }
+                st = S_DB_EVAL;
+                return want_fd(uu);
+            }
+            case S_DB_EVAL: {
+                const double fu = r0, du = r1; if (r0 != r0) saw_nan = true;
+                if (tiny && fu > fx) {  // the minimal downhill step goes uphill: done (no df call, nrc :369-376)
+                    st = S_AFTER_LINMIN;
+                    return traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0);
+                }
+                ++ngeval;
+                if (fu <= fx) {
+                    if (uu >= x) a = x; else b = x;
+                    v = w; fv = fw; dv = dw;
+                    w = x; fw = fx; dw = dx;
+                    x = uu; fx = fu; dx = du;
+                } else {
+                    if (uu < x) a = uu; else b = uu;
+                    if (fu <= fw || w == x) {
+                        v = w; fv = fw; dv = dw;
+                        w = uu; fw = fu; dw = du;
+                    } else if (fu < fv || v == x || v == w) {
+                        v = uu; fv = fu; dv = du;
+                    }
+                }
+                ++it;
+                st = S_DB_HEAD;
+                break;
+            }
+
+            // ---- Frprmn's loop body after linmin --------------------------------------
+            case S_AFTER_LINMIN:
+                fret = fx;
+                if (2.0 * fabs(fret - fp) <= ftol * (fabs(fret) + fabs(fp) + EPS)) { reason = EXIT_FTOL; st = S_FINISH; break; }
+                fp = fret;
+                ++ngeval;
+                st = S_GRAD_ITER;
+                return req(REQ_GRAD);
+            case S_GRAD_ITER:
+                st = S_REDUCED;
+                return req(REQ_CG_REDUCE, fp);
+            case S_REDUCED: {
+                const double test = r0, gg = r1, dgg = r2;
+                Request nx;
+                if (test < GTOL) { reason = EXIT_GTOL; st = S_FINISH; nx = req(REQ_DONE); }
+                else if (gg == 0.0) { reason = EXIT_GGZERO; st = S_FINISH; nx = req(REQ_DONE); }
+                else if (its + 1 >= maxiters) { reason = EXIT_ITMAX; st = S_FINISH; nx = req(REQ_DONE); }  // the final
+                    // direction update of the reference has no observable effect: skipped
+                else { ++its; st = S_ITER_BEGIN; nx = req(REQ_CG_UPDATE, dgg / gg); }
+                if (nx.kind == REQ_DONE) { nx = finish_request(); }
+                return traced(nx, TR_ITER, test, gg, dgg);
+            }
+
+            // ---- CGD wrapper: rollback on negative progress (.cpp:61-80) -----------------
+            case S_FINISH: {
+                Request nx = finish_request();
+                return nx;
+            }
+            case S_ROLLED:
+                fret = r0;
+                st = S_DONE;
+                return req(REQ_DONE);
+            default:
+                return req(REQ_DONE);
             }
         }
     }
-    return false;
-}
 
-struct SolveOut { double fret; int iter; int reason; };
+    __device__ Request finish_request() {
+        if (saw_nan) { reason = EXIT_NAN; fret = DBL_MAX; }
+        if (fret > finit || saw_nan) {
+            rolled_back = true;
+            st = S_ROLLED;
+            Request r = want_f(0.0, false);
+            r.restore = true;
+            return r;
+        }
+        st = S_DONE;
+        return req(REQ_DONE);
+    }
+};
 
-// Frprmn::minimize (nrc :619-691) around Dlinemethod::linmin (nrc :492-513)
+// The driver: the single place where each heavy operation is instantiated.
+// Env provides eval_value / eval_value_slope / gradient_to_xi / cg_start /
+// line_begin / line_end / cg_reduce / cg_update / trace / aborted.
 template <class Env>
-__device__ SolveOut frprmn(Env& E, int maxiters, double ftol) {
-#pragma clang fp contract(off)
-    const double EPS = 1.0e-18, GTOL = 1.0e-8;
-    SolveOut out{DBL_MAX, 0, EXIT_ITMAX};
-    double fp = E.start_point();
-    E.gradient_to_xi();
-    E.cg_start();
-    E.trace(TR_START, fp, 0.0, 0.0);
-    for (int its = 0; its < maxiters; ++its) {
-        out.iter = its;
-        Bracket B;
-        double amin, fmin;
-        E.line_begin();
-        bracket_min(E, B, 0.0, 1.0);
-        if (!dbrent_min(E, B, amin, fmin)) { out.reason = EXIT_DBRENT_ITMAX; return out; }
-        E.line_end(amin);
-        E.trace(TR_LINMIN, amin, fmin, 0.0);
-        out.fret = fmin;
-        if (2.0 * fabs(out.fret - fp) <= ftol * (fabs(out.fret) + fabs(fp) + EPS)) {
-            out.reason = EXIT_FTOL; return out;
+__device__ __forceinline__ void run_machine(Env& E, CgdMachine& M) {
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    for (;;) {
+        const Request q = M.next(r0, r1, r2);
+        if (q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
+        if (q.kind == REQ_DONE || E.aborted()) break;
+        switch (q.kind) {
+        case REQ_F:
+            r0 = E.eval_value(q.a, q.restore);
+            if (q.line) E.trace(TR_F, q.a, r0, 0.0);
+            break;
+        case REQ_FD:
+            E.eval_value_slope(q.a, r0, r1);
+            E.trace(TR_FD, q.a, r0, r1);
+            break;
+        case REQ_GRAD: E.gradient_to_xi(); break;
+        case REQ_CG_START: E.cg_start(); break;
+        case REQ_LINE_BEGIN: E.line_begin(); break;
+        case REQ_LINE_END: E.line_end(q.a); break;
+        case REQ_CG_REDUCE: E.cg_reduce(q.a, r0, r1, r2); break;
+        case REQ_CG_UPDATE: E.cg_update(q.a); break;
+        default: break;
         }
-        fp = out.fret;
-        E.gradient_to_xi();
-        double test, gg, dgg;
-        E.cg_reduce(fp, test, gg, dgg);
-        E.trace(TR_ITER, test, gg, dgg);
-        if (test < GTOL) { out.reason = EXIT_GTOL; return out; }
-        if (gg == 0.0) { out.reason = EXIT_GGZERO; return out; }
-        E.cg_update(dgg / gg);
     }
-    return out;
 }
 
 }  // namespace rdis_hip

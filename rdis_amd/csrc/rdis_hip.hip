@@ -102,18 +102,31 @@ struct rdis_hip_problem {
     int slot_of(int f, int k) const { return kind == KIND_BA ? 12 * f + k : h_rowptr[f] + k; }
 };
 
+struct CoopItem {
+    int comp = 0, nwg = 0;
+    DevBuf slot_li;   // [12 * m] local free index of each factor slot, -1 = constant
+    DevBuf lane_var;  // [nwg * threads] free variable owned by a lane, -1 = none
+    DevBuf wave_var;  // [nwg * threads / 64] free variable owned by a whole wave, -1 = none
+};
+
 struct rdis_hip_plan {
     rdis_hip_problem* prob = nullptr;
     int64_t ncomp = 0, nfree = 0, nfac = 0;
     int64_t max_fac = 0, max_free = 0;
-    DevBuf order, free_ptr, free_vid, fac_ptr, fac_id, v2s_ptr, v2s_idx;
+    DevBuf order, free_ptr, free_vid, fac_ptr, fac_id, v2s_ptr, slot_pos;
     DevBuf ws, dir, gfac, xstart, xout, fret, delta, iters, status, nfeval, ngeval, objective;
     DevBuf trace, trace_n, coop_state, vdump;
-    std::vector<int> h_order, h_fac_ptr, h_free_ptr;
+    std::vector<int> h_order, h_fac_ptr, h_free_ptr, h_free_vid, h_fac_id, h_v2s_ptr;
     bool have_start = false;
+    // which components go where (rebuilt when an option changes)
+    bool partition_dirty = true;
+    std::vector<CoopItem> coop;
+    std::vector<int> h_rest;
+    DevBuf rest_order, xi_glob, coop_timing;
     // options
     int block_threads = 0;
-    int64_t coop_min_factors = 0;
+    int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
+    int coop_max_components = 8;      // ... for at most this many components per plan
     int coop_workgroups = 0, coop_threads = 256;
     int trace_records = 0;
     int dump_iters = 0;
@@ -125,10 +138,10 @@ struct rdis_hip_plan {
     PlanView view() const {
         PlanView v{};
         v.ncomp = (int)ncomp;
-        v.order = order.as<int>();
+        v.order = rest_order.as<int>();
         v.free_ptr = free_ptr.as<int>(); v.free_vid = free_vid.as<int>();
         v.fac_ptr = fac_ptr.as<int>(); v.fac_id = fac_id.as<int>();
-        v.v2s_ptr = v2s_ptr.as<int>(); v.v2s_idx = v2s_idx.as<int>();
+        v.v2s_ptr = v2s_ptr.as<int>(); v.slot_pos = slot_pos.as<int>();
         v.ws = ws.as<double>(); v.dir = dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>(); v.xout = xout.as<double>();
         v.fret = fret.as<double>(); v.delta = delta.as<double>();
@@ -555,7 +568,8 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
             }
         }
     for (int64_t i = 0; i < nfree; ++i) v2s_ptr[(size_t)i + 1] += v2s_ptr[(size_t)i];
-    std::vector<int> v2s_idx((size_t)v2s_ptr[(size_t)nfree]);
+    // gfac is variable-major: slot_pos[s] = where factor slot s lands in it (-1: not free here)
+    std::vector<int> slot_pos((size_t)p->nslots(), -1);
     {
         std::vector<int> fill(v2s_ptr.begin(), v2s_ptr.end() - 1);
         for (int64_t cc = 0; cc < ncomp; ++cc)
@@ -564,7 +578,7 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
                 for (int k = 0, a = p->arity(f); k < a; ++k) {
                     const int v = p->var_of(f, k);
                     if (owner[(size_t)v] != (int)cc) continue;
-                    v2s_idx[(size_t)fill[(size_t)(free_ptr[cc] + local[(size_t)v])]++] = p->slot_of(f, k);
+                    slot_pos[(size_t)p->slot_of(f, k)] = fill[(size_t)(free_ptr[cc] + local[(size_t)v])]++;
                 }
             }
     }
@@ -579,6 +593,7 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
         L->max_free = std::max(L->max_free, free_ptr[cc + 1] - free_ptr[cc]);
     }
     L->h_fac_ptr = h_fac_ptr; L->h_free_ptr = h_free_ptr;
+    L->h_free_vid = h_free_vid; L->h_fac_id = h_fac_id; L->h_v2s_ptr = v2s_ptr;
 
     int rc = 0;
     if (!rc) rc = upload(c, L->order, L->h_order);
@@ -587,10 +602,10 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
     if (!rc) rc = upload(c, L->fac_ptr, h_fac_ptr);
     if (!rc) rc = upload(c, L->fac_id, h_fac_id);
     if (!rc) rc = upload(c, L->v2s_ptr, v2s_ptr);
-    if (!rc) rc = upload(c, L->v2s_idx, v2s_idx);
+    if (!rc) rc = upload(c, L->slot_pos, slot_pos);
     if (!rc) rc = dalloc(c, L->ws, (size_t)(5 * nfree) * sizeof(double));
     if (!rc) rc = dalloc(c, L->dir, (size_t)p->N * sizeof(double));
-    if (!rc) rc = dalloc(c, L->gfac, (size_t)p->nslots() * sizeof(double));
+    if (!rc) rc = dalloc(c, L->gfac, (size_t)v2s_ptr[(size_t)nfree] * sizeof(double));
     if (!rc) rc = dalloc(c, L->xstart, (size_t)nfree * sizeof(double));
     if (!rc) rc = dalloc(c, L->xout, (size_t)nfree * sizeof(double));
     if (!rc) rc = dalloc(c, L->fret, (size_t)ncomp * sizeof(double));
@@ -602,6 +617,7 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
     if (!rc) rc = dalloc(c, L->trace_n, (size_t)ncomp * sizeof(int));
     if (!rc) rc = dalloc(c, L->objective, 64);
     if (!rc) rc = dalloc(c, L->coop_state, coop_state_bytes());
+    if (!rc) rc = dalloc(c, L->coop_timing, 256);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(L->dir.p, 0, L->dir.bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(L->coop_state.p, 0, L->coop_state.bytes, c->stream));
@@ -647,11 +663,14 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_min_factors") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "coop_min_factors < 0");
         L->coop_min_factors = value;
+    } else if (n == "coop_max_components") {
+        if (value < 0 || value > 4096) return fail(c, RDIS_HIP_EINVAL, "coop_max_components out of range");
+        L->coop_max_components = (int)value;
     } else if (n == "coop_workgroups") {
         if (value < 0 || value > COOP_MAX_WG) return fail(c, RDIS_HIP_EINVAL, "coop_workgroups out of range");
         L->coop_workgroups = (int)value;
     } else if (n == "coop_threads") {
-        if (value != 64 && value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 64..512");
+        if (value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 128, 256 or 512");
         L->coop_threads = (int)value;
     } else if (n == "trace_records") {
         if (value < 0 || value > (1 << 22)) return fail(c, RDIS_HIP_EINVAL, "trace_records out of range");
@@ -671,16 +690,74 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else {
         return fail(c, RDIS_HIP_EINVAL, "unknown option " + n);
     }
+    L->partition_dirty = true;
     return 0;
 }
 
 namespace {
+// decide which components the cooperative solver takes and build what it needs
+int prepare_partition(rdis_hip_plan* L) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    rdis_hip_problem* p = L->prob;
+    L->coop.clear();
+    L->h_rest.clear();
+    int cap = 0;
+    if (p->kind == KIND_BA && L->coop_min_factors > 0 && L->coop_max_components > 0)
+        cap = coop_max_workgroups(L->coop_threads, c->num_cus);
+    if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
+    int64_t max_n = 0;
+    std::vector<int> local((size_t)p->N, -1);
+    for (int cc : L->h_order) {  // heaviest first
+        const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
+        const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
+        const int64_t need = (std::max(m, n) + L->coop_threads - 1) / L->coop_threads;
+        const bool take = cap > 0 && m >= L->coop_min_factors && (int)L->coop.size() < L->coop_max_components && need <= cap;
+        if (!take) { L->h_rest.push_back(cc); continue; }
+        L->coop.emplace_back();
+        CoopItem& it = L->coop.back();
+        it.comp = cc;
+        it.nwg = (int)std::max<int64_t>(need, 1);
+        const int f0 = L->h_free_ptr[(size_t)cc], c0 = L->h_fac_ptr[(size_t)cc];
+        for (int64_t i = 0; i < n; ++i) local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = (int)i;
+        std::vector<int> sl((size_t)(12 * m));
+        for (int64_t j = 0; j < m; ++j) {
+            const int f = L->h_fac_id[(size_t)(c0 + j)];
+            for (int k = 0; k < 12; ++k) sl[(size_t)(12 * j + k)] = local[(size_t)p->var_of(f, k)];
+        }
+        for (int64_t i = 0; i < n; ++i) local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = -1;
+        // owners of the CG recurrence: a lane per variable, a whole wave for variables fed by
+        // many partials (longest first), see solver_coop.hpp
+        const int lanes = it.nwg * L->coop_threads, waves = lanes / 64;
+        std::vector<int> lane_var((size_t)lanes, -1), wave_var((size_t)waves, -1), longv;
+        for (int64_t i = 0; i < n; ++i)
+            if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) longv.push_back((int)i);
+        std::stable_sort(longv.begin(), longv.end(), [&](int a, int b) {
+            return (L->h_v2s_ptr[(size_t)(f0 + a) + 1] - L->h_v2s_ptr[(size_t)(f0 + a)]) >
+                   (L->h_v2s_ptr[(size_t)(f0 + b) + 1] - L->h_v2s_ptr[(size_t)(f0 + b)]);
+        });
+        std::vector<char> wave_owned((size_t)n, 0);
+        for (size_t k = 0; k < longv.size() && (int)k < waves; ++k) { wave_var[k] = longv[k]; wave_owned[(size_t)longv[k]] = 1; }
+        for (int64_t i = 0; i < n; ++i) if (!wave_owned[(size_t)i]) lane_var[(size_t)i] = (int)i;
+        int rc = upload(c, it.slot_li, sl);
+        if (!rc) rc = upload(c, it.lane_var, lane_var);
+        if (!rc) rc = upload(c, it.wave_var, wave_var);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        max_n = std::max(max_n, n);
+    }
+    int rc = upload(c, L->rest_order, L->h_rest);
+    if (!rc && max_n > 0) rc = dalloc(c, L->xi_glob, (size_t)max_n * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    L->partition_dirty = false;
+    return 0;
+}
+
 template <int KIND>
-int launch_wg(rdis_hip_plan* L, int threads, int grid, int order_offset, int maxiters, double ftol) {
+int launch_wg(rdis_hip_plan* L, int threads, int grid, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;
     ProblemView P = L->prob->view();
     PlanView V = L->view();
-    V.order += order_offset;
     switch (threads) {
         case 64: cgd_wg_kernel<KIND, 64><<<grid, 64, 0, c->stream>>>(P, V, maxiters, ftol); break;
         case 128: cgd_wg_kernel<KIND, 128><<<grid, 128, 0, c->stream>>>(P, V, maxiters, ftol); break;
@@ -702,35 +779,29 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     L->timed = false;
     if (L->ncomp == 0) return 0;
 
-    // components at the head of the (heaviest-first) order that are big enough go
-    // to the cooperative multi-workgroup solver, one launch each; the rest are one
-    // batched launch with one workgroup per component
-    int ncoop = 0;
-    if (L->coop_min_factors > 0)
-        while (ncoop < (int)L->ncomp) {
-            const int cc = L->h_order[(size_t)ncoop];
-            if (L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc] < L->coop_min_factors) break;
-            ++ncoop;
-        }
+    // a few very large components go to the cooperative multi-workgroup solver, one
+    // launch each; everything else is one batched launch, one workgroup per component
+    if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
+    PlanView V = L->view();
     HIPCHK(c, hipEventRecord(L->ev0, c->stream));
-    for (int i = 0; i < ncoop; ++i) {
-        int rc = launch_coop(c->stream, c->num_cus, L->prob->kind, L->prob->view(), L->view(), L->h_order[(size_t)i],
-                             L->coop_workgroups, L->coop_threads, L->coop_state.p, maxiters, ftol);
+    for (size_t i = 0; i < L->coop.size(); ++i) {
+        const CoopItem& it = L->coop[i];
+        CoopArgs ca{L->coop_timing.as<long long>(), L->coop_state.as<CoopState>(), it.slot_li.as<int>(),
+                    it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp};
+        int rc = launch_coop(c->stream, L->prob->kind, L->prob->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
-    const int rest = (int)L->ncomp - ncoop;
+    const int rest = (int)L->h_rest.size();
     if (rest > 0) {
         int64_t mf = 0;
-        for (int i = ncoop; i < (int)L->ncomp; ++i) {
-            const int cc = L->h_order[(size_t)i];
+        for (int cc : L->h_rest)
             mf = std::max<int64_t>(mf, std::max(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
                                                 (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
-        }
         int threads = L->block_threads;
         if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 2048 ? 512 : 1024;
-        int rc = L->prob->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, ncoop, maxiters, ftol)
-                                          : launch_wg<KIND_NLP>(L, threads, rest, ncoop, maxiters, ftol);
+        int rc = L->prob->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
+                                          : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
     }
@@ -791,6 +862,14 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
         HIPCHK(c, hipMemcpyAsync(rec4, L->trace.as<double>() + 4ll * L->trace_records * comp, (size_t)k * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out8) {
+    if (!L || !out8) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    HIPCHK(c, hipMemcpyAsync(out8, L->coop_timing.p, 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

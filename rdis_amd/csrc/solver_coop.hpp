@@ -1,13 +1,431 @@
-// solver_coop.hpp -- cooperative multi-workgroup solver for one large component
-// (placeholder until the grid-wide variant lands; the single-workgroup solver
-// handles every component meanwhile).
+// solver_coop.hpp -- a whole grid solves ONE large bundle-adjustment component.
+//
+// ladybug-49-7776 as a single component is 31843 factors over 23769 free
+// variables: ~1 MB of state and ~800 dependent objective evaluations per solve.
+// That is a latency problem, not a bandwidth problem, so the design removes
+// memory traffic and launches from the evaluation loop altogether:
+//
+//  * one persistent launch runs the entire CGDSubspaceOptimizer::optimize call
+//    (reference src/optimizers/CGDSubspaceOptimizer.cpp:19-98); every lane of
+//    every workgroup steps the scalar control logic (minimizer.hpp) redundantly
+//    on identical reduced values, so nothing is ever broadcast;
+//  * lane j owns factor j: for the duration of a line minimisation the point and
+//    direction of its 12 variables, their bounds and its observation live in
+//    registers; a trial step a costs clamp(base + a*dir), ~500 flops, and zero
+//    memory traffic;
+//  * the CG recurrence (p, xi, g, h) of free variable i lives in the registers of
+//    its owner: lane i for variables fed by few factors (points), a whole wave for
+//    variables fed by many (cameras: up to 906 partials) so that the per-variable
+//    sum of partials is one coalesced sweep + butterfly instead of a serial chain.
+//    Only xi is published (once per CG iteration) for the factor lanes to re-read;
+//  * the per-factor partials of a full gradient are scattered straight into
+//    variable-major order (PlanView::slot_pos), so every owner reads one
+//    contiguous run;
+//  * workgroups exchange partial sums through 8-byte granules in HBM (relaxed
+//    agent-scope atomics, written through to memory): the data is the flag.  A
+//    granule holds an all-ones NaN until its owner publishes; three buffers
+//    rotate and each workgroup re-arms its own granules two exchanges ahead.
+//    One wave per workgroup sweeps the granules and reduces them in a fixed
+//    order, so every workgroup obtains bit-identical sums.  When an exchange also
+//    has to order memory (per-factor partials -> per-variable sums, new xi ->
+//    factor lanes) it is bracketed by an agent-scope release / acquire
+//    (cdna_hip_programming.md, Guideline 16); placement-independent, spins bounded.
+//
+// Launched with hipLaunchCooperativeKernel so that an oversized grid is rejected
+// instead of deadlocking.  Bundle adjustment only (fixed arity 12).
 #pragma once
 #include "solver_wg.hpp"
 
 namespace rdis_hip {
-constexpr int COOP_MAX_WG = 256;
-inline size_t coop_state_bytes() { return 4096; }
-inline int launch_coop(hipStream_t, int, int, const ProblemView&, const PlanView&, int, int, int, void*, int, double) {
-    return (int)hipErrorNotSupported;
+
+constexpr int COOP_MAX_WG = 512;
+constexpr int COOP_K = 3;  // values per exchange
+constexpr int COOP_LONG_LIST = 48;  // variables fed by more partials than this are wave-owned
+constexpr unsigned long long COOP_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long COOP_CANON_NAN = 0x7FF8000000000000ull;
+constexpr unsigned COOP_SPIN_LIMIT = 1u << 22;
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+struct CoopState {
+    // [3 buffers][COOP_K][COOP_MAX_WG] granules, then an abort word
+    unsigned long long granule[3][COOP_K][COOP_MAX_WG];
+    unsigned int abort_flag;
+    unsigned int pad[15];
+};
+inline size_t coop_state_bytes() { return sizeof(CoopState); }
+
+struct CoopArgs {
+    long long* timing;     // [8] cycle accumulators written by lane 0 (profiling aid)
+    CoopState* st;
+    const int* slot_li;    // [12 * m]: local free index of each factor slot or -1 (constant)
+    const int* lane_var;   // [nwg * threads]: free variable owned by this lane or -1
+    const int* wave_var;   // [nwg * threads / 64]: free variable owned by this wave or -1
+    double* xi_glob;       // [n] published search direction
+    int comp;
+};
+
+// the CG recurrence of one free variable
+struct VarState {
+    int li;  // local free index, -1 = none
+    double p, xi, g, h, xinit, lo, hi;
+};
+
+struct CoopEnv {
+    const ProblemView& P;
+    const PlanView& L;
+    const CoopArgs& A;
+    int n, m, f0;
+    int gt, tid, nwg, wg;     // global lane, lane in workgroup, #workgroups, my workgroup
+    double (*red)[COOP_K][MAX_WAVES];  // LDS block-reduce scratch [2][K][waves]
+    double* bcast;                     // LDS [2][4]
+    int parity;
+    unsigned epoch;
+    bool dead;                         // a spin gave up: unwind quickly
+    double* tr;
+    int trn, lm_count;
+    // factor lane state
+    bool has_fac;
+    int fid;
+    double base[12], dirv[12], lov[12], hiv[12];
+    double ox, oy;
+    VarState lv;   // lane-owned variable
+    VarState wv;   // wave-owned variable (identical in all 64 lanes)
+    long long tm[8];  // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
+                      // 5 #exchanges, 6 #sweeps, 7 whole kernel
+
+    // ---- inter-workgroup exchange ------------------------------------------------
+    __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&A.st->granule[buf][k][w]; }
+
+    // Sum (k = 0,1) / max (k = 2) of one value per workgroup, delivered to every lane
+    // of every workgroup, bit-identical everywhere.  `order` additionally makes all
+    // plain global stores issued before the call visible to all lanes after it.
+    __device__ void exchange(double& a, double& b, double& mx, bool order) {
+        const long long t0 = clock64();
+        long long t1 = t0, t2 = t0, t3 = t0;
+        a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
+        const int w = tid >> 6, lane = tid & 63;
+        if (lane == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
+        if (order) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+        __syncthreads();
+        const int buf = epoch % 3u;
+        t1 = clock64();
+        if (w == 0) {
+            double ra = 0.0, rb = 0.0, rm = 0.0;
+            const int nwv = blockDim.x >> 6;
+            for (int i = 0; i < nwv; ++i) { ra += red[parity][0][i]; rb += red[parity][1][i]; rm = fmax(rm, red[parity][2][i]); }
+            if (lane == 0) {
+                if (order) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // re-arm stores + payload are out
+                unsigned long long ua = __double_as_longlong(ra), ub = __double_as_longlong(rb), um = __double_as_longlong(rm);
+                if (ua == COOP_SENTINEL) ua = COOP_CANON_NAN;
+                if (ub == COOP_SENTINEL) ub = COOP_CANON_NAN;
+                if (um == COOP_SENTINEL) um = COOP_CANON_NAN;
+                __hip_atomic_store(gran(buf, 0, wg), ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gran(buf, 1, wg), ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gran(buf, 2, wg), um, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // sweep: lane l looks after workgroups l, l+64, ...
+            t2 = clock64();
+            double sa = 0.0, sb = 0.0, sm = 0.0;
+            unsigned spins = 0;
+            bool ok = !dead;
+            const int per = (nwg + 63) >> 6;
+            while (!dead) {
+                ok = true;
+                ++tm[6];
+                sa = 0.0; sb = 0.0; sm = 0.0;
+                for (int j = 0; j < per; ++j) {
+                    const int ww = lane + (j << 6);
+                    if (ww < nwg) {
+                        const unsigned long long va = __hip_atomic_load(gran(buf, 0, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long vb = __hip_atomic_load(gran(buf, 1, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long vm = __hip_atomic_load(gran(buf, 2, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && va != COOP_SENTINEL && vb != COOP_SENTINEL && vm != COOP_SENTINEL;
+                        sa += __longlong_as_double(va); sb += __longlong_as_double(vb);
+                        sm = fmax(sm, __longlong_as_double(vm));
+                    }
+                }
+                if (__all(ok)) break;
+                if (++spins > COOP_SPIN_LIMIT ||
+                    __hip_atomic_load((gu32*)&A.st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (lane == 0) __hip_atomic_store((gu32*)&A.st->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = __all(ok);
+            t3 = clock64();
+            sa = wave_sum(sa); sb = wave_sum(sb); sm = wave_max(sm);
+            if (lane == 0) {
+                bcast[parity * 4 + 0] = sa; bcast[parity * 4 + 1] = sb; bcast[parity * 4 + 2] = sm;
+                bcast[parity * 4 + 3] = ok ? 1.0 : 0.0;
+                if (order) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // re-arm my granules two exchanges ahead (safe: everybody has consumed that buffer)
+                const int nb = (epoch + 2u) % 3u;
+                __hip_atomic_store(gran(nb, 0, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gran(nb, 1, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gran(nb, 2, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        a = bcast[parity * 4 + 0]; b = bcast[parity * 4 + 1]; mx = bcast[parity * 4 + 2];
+        if (bcast[parity * 4 + 3] == 0.0) dead = true;
+        parity ^= 1;
+        ++epoch;
+        const long long t4 = clock64();
+        tm[1] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; tm[4] += t4 - t3; ++tm[5];
+    }
+    __device__ void barrier_ordered() {
+        double a = 0.0, b = 0.0, c = 0.0;
+        exchange(a, b, c, true);
+    }
+
+    __device__ void trace(int tag, double a, double b, double c) {
+        if (tr != nullptr && gt == 0) {
+            if (trn < L.trace_cap) { double* r = tr + 4ll * trn; r[0] = (double)tag; r[1] = a; r[2] = b; r[3] = c; }
+            ++trn;
+        }
+    }
+    __device__ bool aborted() const { return dead; }
+
+    // ---- evaluation at clamp(base + a*dir), straight from registers ---------------
+    template <bool SLOPE>
+    __device__ void eval_line(double a, double& f, double& s) {
+        double fj = 0.0, sj = 0.0, dummy = 0.0;
+        const long long tc0 = clock64();
+        if (has_fac) {
+            double v[12];
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const double t = a * dirv[k];
+                    v[k] = clampd(base[k] + t, lov[k], hiv[k]);
+                }
+            }
+            if constexpr (SLOPE) {
+                double g[12];
+                fj = ba_eval_grad(v, ox, oy, g);
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) acc += g[k] * dirv[k];
+                sj = acc;
+            } else {
+                fj = ba_eval(v, ox, oy);
+            }
+        }
+        tm[0] += clock64() - tc0;
+        exchange(fj, sj, dummy, false);
+        f = fj; s = sj;
+    }
+    __device__ double eval_value(double a, bool restore) {
+        if (restore) load_base(L.xstart + f0);  // objective at clamp(x_init) for the rollback
+        double f, s;
+        eval_line<false>(restore ? 0.0 : a, f, s);
+        return f;
+    }
+    __device__ void eval_value_slope(double a, double& f, double& s) { eval_line<true>(a, f, s); }
+
+    // load the factor lane's 12 (point, bounds) from a free-variable-ordered vector
+    __device__ void load_base(const double* vec) {
+        if (has_fac) {
+            const int c = P.cam[fid], q = P.pt[fid];
+            const int* sl = A.slot_li + 12ll * gt;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int v = k < 9 ? c + k : q + (k - 9);
+                const int li = sl[k];
+                if (li >= 0) { base[k] = vec[li]; lov[k] = P.lo[v]; hiv[k] = P.hi[v]; }
+                else { base[k] = P.x[v]; lov[k] = -__builtin_inf(); hiv[k] = __builtin_inf(); }
+                dirv[k] = 0.0;
+            }
+        }
+    }
+
+    // ---- the CG vectors, one variable per owner ----------------------------------------
+    __device__ void var_init(VarState& V, int li) {
+        V.li = li;
+        V.p = V.xi = V.g = V.h = V.xinit = 0.0; V.lo = V.hi = 0.0;
+        if (li >= 0) {
+            const int vid = L.free_vid[f0 + li];
+            V.p = L.xstart[f0 + li]; V.xinit = V.p;
+            V.lo = P.lo[vid]; V.hi = P.hi[vid];
+        }
+    }
+    __device__ void init_vectors() {
+        var_init(lv, gt < nwg * (int)blockDim.x ? A.lane_var[gt] : -1);
+        var_init(wv, A.wave_var[gt >> 6]);
+        load_base(L.xstart + f0);
+    }
+
+    __device__ void gradient_to_xi() {
+        if (has_fac) {
+            double v[12], g[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
+            ba_eval_grad(v, ox, oy, g);
+            const int* sp = L.slot_pos + 12ll * fid;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) L.gfac[t] = g[k]; }
+        }
+        barrier_ordered();
+        const int* vp = L.v2s_ptr + f0;
+        if (lv.li >= 0) {  // few partials: serial, in factor-list order (src/State.h:157-210)
+            const int b = vp[lv.li], e = vp[lv.li + 1];
+            double s = 0.0;
+            if (b < e) {
+                s = L.gfac[b];
+                for (int k = b + 1; k < e; ++k) s += L.gfac[k];
+            }
+            lv.xi = s;
+        }
+        if (wv.li >= 0) {  // many partials: the wave strides over the run, then a butterfly (fixed order)
+            const int b = vp[wv.li], e = vp[wv.li + 1];
+            double s = 0.0;
+            for (int k = b + (tid & 63); k < e; k += 64) s += L.gfac[k];
+            wv.xi = wave_sum(s);
+        }
+    }
+    __device__ void publish_xi() {
+        if (lv.li >= 0) A.xi_glob[lv.li] = lv.xi;
+        if (wv.li >= 0 && (tid & 63) == 0) A.xi_glob[wv.li] = wv.xi;
+        barrier_ordered();
+    }
+    __device__ void cg_start() {
+        { const double t = -lv.xi; lv.g = t; lv.h = t; lv.xi = t; }
+        { const double t = -wv.xi; wv.g = t; wv.h = t; wv.xi = t; }
+        publish_xi();
+    }
+    __device__ void line_begin() {
+        if (has_fac) {
+            const int* sl = A.slot_li + 12ll * gt;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int li = sl[k]; dirv[k] = li >= 0 ? A.xi_glob[li] : 0.0; }
+        }
+        if (L.vdump != nullptr && lm_count < L.dump_iters) {
+            double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;
+            if (lv.li >= 0) { d[lv.li] = lv.p; d[n + lv.li] = lv.xi; }
+            if (wv.li >= 0 && (tid & 63) == 0) { d[wv.li] = wv.p; d[n + wv.li] = wv.xi; }
+        }
+        ++lm_count;
+    }
+    __device__ void line_end(double amin) {
+#pragma clang fp contract(off)
+        { const double t = lv.xi * amin; lv.xi = t; lv.p = lv.p + t; }
+        { const double t = wv.xi * amin; wv.xi = t; wv.p = wv.p + t; }
+        if (has_fac) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const double t = dirv[k] * amin; base[k] = base[k] + t; }
+        }
+    }
+    __device__ void cg_reduce(double fp, double& test, double& gg, double& dgg) {
+#pragma clang fp contract(off)
+        const double den = fmax(fabs(fp), 1.0);
+        double a = 0.0, b = 0.0, t = 0.0;
+        if (lv.li >= 0) {
+            t = fabs(lv.xi) * fmax(fabs(lv.p), 1.0) / den;
+            a = lv.g * lv.g;
+            b = (lv.xi + lv.g) * lv.xi;
+        }
+        if (wv.li >= 0 && (tid & 63) == 0) {
+            t = fmax(t, fabs(wv.xi) * fmax(fabs(wv.p), 1.0) / den);
+            a = a + wv.g * wv.g;
+            b = b + (wv.xi + wv.g) * wv.xi;
+        }
+        exchange(a, b, t, false);
+        gg = a; dgg = b; test = t;
+    }
+    __device__ void cg_update(double gam) {
+        {
+#pragma clang fp contract(off)
+            { const double gn = -lv.xi; const double hn = gn + gam * lv.h; lv.g = gn; lv.h = hn; lv.xi = hn; }
+            { const double gn = -wv.xi; const double hn = gn + gam * wv.h; wv.g = gn; wv.h = hn; wv.xi = hn; }
+        }
+        publish_xi();
+    }
+    __device__ void write_back(const VarState& V, bool restore, bool writer) {
+        if (V.li >= 0 && writer) {
+            const double xf = clampd(restore ? V.xinit : V.p, V.lo, V.hi);
+            P.x[L.free_vid[f0 + V.li]] = xf;   // variables are left assigned (.cpp:61, :84-86)
+            L.xout[f0 + V.li] = xf;
+        }
+    }
+};
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol) {
+    __shared__ double red[2][COOP_K][MAX_WAVES];
+    __shared__ double bcast[8];
+    const long long tk0 = clock64();
+    const int comp = A.comp;
+    const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
+    const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+
+    CoopEnv E{P, L, A, n, m, f0, gt, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x,
+              red, bcast, 0, 0u, false,
+              L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
+              gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}, {}};
+    if (E.has_fac) {
+        E.fid = L.fac_id[c0 + gt];
+        const double2 o = P.obs[E.fid];
+        E.ox = o.x; E.oy = o.y;
+    }
+
+    CgdMachine M;
+    M.init(maxiters, ftol);
+    E.init_vectors();
+    run_machine(E, M);
+    int status = M.status();
+    if (E.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
+    const bool restore = M.rolled_back || E.dead;
+    E.write_back(E.lv, restore, true);
+    E.write_back(E.wv, restore, (threadIdx.x & 63) == 0);
+    if (gt == 0) {
+        L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
+        L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
+        if (L.trace_n) L.trace_n[comp] = E.trn;
+        E.tm[7] = clock64() - tk0;
+        if (A.timing) for (int i = 0; i < 8; ++i) A.timing[i] = E.tm[i];
+    }
 }
+
+// host side: returns hipSuccess (0) or a hipError_t
+inline int launch_coop(hipStream_t stream, int kind, const ProblemView& P, const PlanView& V, const CoopArgs& a_in,
+                       int nwg, int threads, int maxiters, double ftol) {
+    if (kind != KIND_BA) return (int)hipErrorNotSupported;
+    hipError_t e = hipMemsetAsync(a_in.st, 0xFF, sizeof(CoopState) - 64, stream);  // arm every granule
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync((char*)a_in.st + offsetof(CoopState, abort_flag), 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    ProblemView p = P;
+    PlanView v = V;
+    CoopArgs a = a_in;
+    int mi = maxiters;
+    double ft = ftol;
+    void* args[] = {&p, &v, &a, &mi, &ft};
+    const void* fn = threads == 512 ? (const void*)cgd_coop_kernel<512>
+                   : threads == 128 ? (const void*)cgd_coop_kernel<128>
+                                    : (const void*)cgd_coop_kernel<256>;
+    e = hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(threads), args, 0, stream);
+    return (int)e;
+}
+
+inline int coop_max_workgroups(int threads, int num_cus) {
+    int per_cu = 0;
+    const void* fn = threads == 512 ? (const void*)cgd_coop_kernel<512>
+                   : threads == 128 ? (const void*)cgd_coop_kernel<128>
+                                    : (const void*)cgd_coop_kernel<256>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess) return 0;
+    // stay one block per CU below what the API reports when it reports more than one
+    // (MI355X_MICROARCH.md: the query can be one high for SGPR-heavy kernels)
+    if (per_cu > 1) per_cu -= 1;
+    const long long cap = (long long)per_cu * num_cus;
+    return (int)(cap > COOP_MAX_WG ? COOP_MAX_WG : cap);
+}
+
 }  // namespace rdis_hip

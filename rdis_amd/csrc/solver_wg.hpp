@@ -88,9 +88,12 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
     }
 }
 
-// per-factor partials into their gradient slots (BA: 12*fid + k, NLP: CSR position)
+// per-factor partials into their gradient slots.  Slot id: BA 12*fid + k, NLP the CSR
+// position; with slot_pos the partial of slot s goes to gfac[slot_pos[s]] (variable-major,
+// skipped when negative), without it to gfac[s].
 template <int KIND>
-__device__ __forceinline__ void factor_partials(const ProblemView& P, double* __restrict__ gfac, int fid) {
+__device__ __forceinline__ void factor_partials(const ProblemView& P, double* __restrict__ gfac,
+                                                const int* __restrict__ slot_pos, int fid) {
     if constexpr (KIND == KIND_BA) {
         const int c = P.cam[fid], q = P.pt[fid];
         const double2 o = P.obs[fid];
@@ -100,9 +103,15 @@ __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
         ba_eval_grad(v, o.x, o.y, g);
-        double* dst = gfac + 12ll * fid;
+        if (slot_pos) {
+            const int* sp = slot_pos + 12ll * fid;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) dst[k] = g[k];
+            for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) gfac[t] = g[k]; }
+        } else {
+            double* dst = gfac + 12ll * fid;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dst[k] = g[k];
+        }
     } else {
         const int b = P.rowptr[fid], e = P.rowptr[fid + 1];
         for (int k = b; k < e; ++k) {
@@ -116,7 +125,8 @@ __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __
                     d *= nlp_term(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
                 }
             }
-            gfac[k] = d * P.coeff[fid];
+            const int t = slot_pos ? slot_pos[k] : k;
+            if (t >= 0) gfac[t] = d * P.coeff[fid];
         }
     }
 }
@@ -133,8 +143,6 @@ struct WgEnv {
     double *p, *xi, *g, *h, *xinit;
     double (*red)[3][MAX_WAVES];  // LDS [2][3][MAX_WAVES]
     int parity;
-    long long nfeval, ngeval;
-    bool saw_nan;
     double* tr;
     int trn;
     int lm_count;  // line minimisations started
@@ -192,66 +200,40 @@ struct WgEnv {
         }
         sum3(af, as, dummy);
         f = af; s = as;
-        if (f != f) saw_nan = true;
     }
 
-    __device__ double line_f(double a) {
-        ++nfeval;
-        assign_line(a);
+    __device__ bool aborted() const { return false; }
+    // value at clamp(p + a*xi), or at clamp(x_init) for the rollback (CGD .cpp:71)
+    __device__ double eval_value(double a, bool restore) {
+        if (restore) assign_vec(xinit); else assign_line(a);
         double f, s;
         eval_sum<false>(f, s);
-        trace(TR_F, a, f, 0.0);
         return f;
     }
-    __device__ void line_fd(double a, double& f, double& s) {
-        ++nfeval;
+    __device__ void eval_value_slope(double a, double& f, double& s) {
         assign_line(a);
         eval_sum<true>(f, s);
-        trace(TR_FD, a, f, s);
     }
-    __device__ void count_slope() { ++ngeval; }
-
-    __device__ double first_eval() {  // CGD .cpp:34-39
+    __device__ void init_vectors() {  // CGD .cpp:34-39: p = x0 (unclamped), keep x0 for the rollback
         const double* xs = L.xstart + (fv - L.free_vid);
         for (int i = tid; i < n; i += nt) { p[i] = xs[i]; xinit[i] = xs[i]; xi[i] = 0.0; }
         __syncthreads();
-        ++nfeval;
-        assign_vec(p);
-        double f, s;
-        eval_sum<false>(f, s);
-        return f;
-    }
-    __device__ double start_point() {  // nrc :628
-        ++nfeval;
-        assign_vec(p);
-        double f, s;
-        eval_sum<false>(f, s);
-        return f;
-    }
-    __device__ double eval_at(const double* src) {
-        ++nfeval;
-        assign_vec(src);
-        double f, s;
-        eval_sum<false>(f, s);
-        return f;
     }
 
     // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p)
     __device__ void gradient_to_xi() {
-        ++ngeval;
         assign_vec(p);
         for (int j = tid; j < m; j += nt) {
             const int fid = fl[j];
-            if constexpr (KIND == KIND_BA) factor_partials<KIND>(P, L.gfac, fid);
-            else factor_partials<KIND>(P, L.gfac, fid);
+            factor_partials<KIND>(P, L.gfac, L.slot_pos, fid);
         }
         __syncthreads();
         for (int i = tid; i < n; i += nt) {
             const int b = vptr[i], e = vptr[i + 1];
             double s = 0.0;
             if (b < e) {
-                s = L.gfac[L.v2s_idx[b]];
-                for (int k = b + 1; k < e; ++k) s += L.gfac[L.v2s_idx[k]];
+                s = L.gfac[b];
+                for (int k = b + 1; k < e; ++k) s += L.gfac[k];
             }
             xi[i] = s;
         }
@@ -327,23 +309,19 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
     WgEnv<KIND> E{P, L, comp, n, m, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
                   L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                   ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
-                  red, 0, 0, 0, false,
+                  red, 0,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
 
-    const double finit = E.first_eval();
-    SolveOut r = frprmn(E, maxiters, ftol);
-    int status = r.reason;
-    double fret = r.fret;
-    E.assign_vec(E.p);  // assign gdmin.p with sanitisation (.cpp:61)
-    if (E.saw_nan) { status = EXIT_NAN; fret = DBL_MAX; }
-    if (fret > finit || E.saw_nan) {  // negative progress: restore the start (.cpp:66-80)
-        status |= STATUS_ROLLED_BACK;
-        fret = E.eval_at(E.xinit);
-    }
+    CgdMachine M;
+    M.init(maxiters, ftol);
+    E.init_vectors();
+    run_machine(E, M);
+    // assign gdmin.p with sanitisation (.cpp:61); after a rollback x already holds clamp(x_init)
+    if (!M.rolled_back) E.assign_vec(E.p);
     for (int i = E.tid; i < n; i += E.nt) L.xout[f0 + i] = P.x[E.fv[i]];
     if (E.tid == 0) {
-        L.fret[comp] = fret; L.delta[comp] = fret - finit; L.iters[comp] = r.iter;
-        L.status[comp] = status; L.nfeval[comp] = E.nfeval; L.ngeval[comp] = E.ngeval;
+        L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
+        L.status[comp] = M.status(); L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
     }
 }
