@@ -33,7 +33,7 @@ enum : int {
 };
 constexpr int STATUS_ROLLED_BACK = 0x100;
 
-// trace record tags (oracle/rdis_oracle.c ro_cgd_replay reads the same)
+// trace record tags (the replay check in tests/ reads the same tags)
 enum : int { TR_NONE = 0, TR_F = 1, TR_FD = 2, TR_ITER = 3, TR_START = 4, TR_LINMIN = 5 };
 
 enum : int {

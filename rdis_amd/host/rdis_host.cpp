@@ -1,0 +1,483 @@
+// rdis_host.cpp -- see rdis_host.h.  Host bookkeeping only; all arithmetic on the
+// path goes through include/rdis_hip.h.
+#include "rdis_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../include/rdis_hip.h"
+
+namespace rdis {
+
+namespace {
+void check(rdis_hip_ctx* ctx, int rc, const char* where) {
+    if (rc != 0) throw HipError(rc, std::string(where) + ": " + (ctx ? rdis_hip_last_error(ctx) : "no context"));
+}
+// split on " \t,;" with token compression (OptimizableFunction::readAndSplit,
+// src/OptimizableFunction.cpp:354-371); skips blank and '#' lines
+bool readAndSplit(std::istream& in, std::vector<std::string>& out) {
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        out.clear();
+        std::string cur;
+        for (char ch : line) {
+            if (ch == ' ' || ch == '\t' || ch == ',' || ch == ';' || ch == '\r') {
+                if (!cur.empty()) { out.push_back(cur); cur.clear(); }
+            } else cur.push_back(ch);
+        }
+        if (!cur.empty()) out.push_back(cur);
+        if (out.empty()) continue;
+        return true;
+    }
+    return false;
+}
+std::string trim(const std::string& s) {
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+std::string lower(std::string s) {
+    for (char& c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+}
+bool parseNumber(const std::string& s, double& v) {
+    char* end = nullptr;
+    v = std::strtod(s.c_str(), &end);
+    return !s.empty() && end && *end == '\0';
+}
+}  // namespace
+
+// ------------------------------------------------------------------ VariableDomain
+VariableDomain::VariableDomain(const std::string& domain) : lo_(0), hi_(0) {
+    std::vector<double> v;
+    std::string cur;
+    for (char ch : domain + " ") {
+        if (ch == ' ' || ch == '~' || ch == ':' || ch == ',') {
+            double d;
+            if (!cur.empty() && parseNumber(cur, d)) v.push_back(d);
+            cur.clear();
+        } else cur.push_back(ch);
+    }
+    if (v.size() < 2) throw std::invalid_argument("VariableDomain: cannot parse '" + domain + "'");
+    lo_ = v.front(); hi_ = v.back();
+}
+
+// ------------------------------------------------------------------ Variable
+void Variable::assign(Numeric newval) {
+    assigned_ = true;
+    value_ = newval;
+    if (owner_) owner_->markDirty(id_);
+}
+Numeric Variable::eval() const {
+    if (!assigned_) throw std::logic_error("Variable::eval: variable " + name_ + " is not assigned");
+    return value_;
+}
+
+// ------------------------------------------------------------------ Factor
+bool Factor::areAllVarsAssigned() const {
+    for (const Variable* v : variables_) if (!v->isAssigned()) return false;
+    return true;
+}
+Numeric Factor::eval() const {
+    if (!owner_) throw std::logic_error("Factor::eval: factor is not part of a function");
+    double out = 0;
+    int64_t id = id_;
+    rdis_hip_problem* p = owner_->deviceProblem();
+    check(owner_->deviceContext(), rdis_hip_eval_each(p, 1, &id, &out), "Factor::eval");
+    return out;
+}
+void Factor::computeGradient(PartialGradient& g) const {
+    FactorPtrVec one(1, const_cast<Factor*>(this));
+    owner_->computeGradient(one, g);
+}
+
+void NonlinearProductFactor::addVariable(Variable* v, Numeric exponent, Numeric constant, bool useSine) {
+    if (exponent == 0.0) return;
+    for (const Variable* u : variables_) if (u == v) return;
+    variables_.push_back(v);
+    terms_.push_back(Term{exponent, constant, useSine});
+    v->getFactors().push_back(this);
+}
+
+// ------------------------------------------------------------------ OptimizableFunction
+OptimizableFunction::OptimizableFunction() : defaultDomain(0, 0), ctx_(nullptr), prob_(nullptr), device_(0) {}
+
+OptimizableFunction::~OptimizableFunction() {
+    if (prob_) rdis_hip_free_problem(prob_);
+    if (ctx_) rdis_hip_destroy(ctx_);
+    for (Variable* v : variables) delete v;
+    for (Factor* f : factors) delete f;
+}
+
+Variable* OptimizableFunction::addVariable(const std::string& name, const VariableDomain& dom, VariableID& id) {
+    for (Variable* v : variables) if (v->getName() == name) return v;  // src/OptimizableFunction.cpp:61-63
+    Variable* v = new Variable(id, name, dom, this);
+    variables.push_back(v);
+    ++id;
+    return v;
+}
+void OptimizableFunction::addFactor(Factor* f) {
+    f->owner_ = this;
+    factors.push_back(f);
+}
+
+const OptimizableFunction::Packed& OptimizableFunction::packed() const {
+    if (packed_) return *packed_;
+    std::unique_ptr<Packed> P(new Packed);
+    const size_t N = variables.size(), F = factors.size();
+    P->lo.resize(N); P->hi.resize(N);
+    for (size_t i = 0; i < N; ++i) { P->lo[i] = variables[i]->getDomain().min(); P->hi[i] = variables[i]->getDomain().max(); }
+    const bool ba = F > 0 && dynamic_cast<const BundleAdjustmentFactor*>(factors[0]) != nullptr;
+    P->kind = ba ? 0 : 1;
+    if (ba) {
+        P->cam_vid0.resize(F); P->pt_vid0.resize(F); P->obs.resize(2 * F);
+        for (size_t i = 0; i < F; ++i) {
+            const BundleAdjustmentFactor* bf = dynamic_cast<const BundleAdjustmentFactor*>(factors[i]);
+            if (!bf || bf->getVariables().size() != 12) throw std::logic_error("packed: mixed factor kinds");
+            const VariablePtrVec& v = bf->getVariables();
+            for (int k = 1; k < 9; ++k) if (v[k]->getID() != v[0]->getID() + k) throw std::logic_error("packed: camera block not contiguous");
+            for (int k = 1; k < 3; ++k) if (v[9 + k]->getID() != v[9]->getID() + k) throw std::logic_error("packed: point block not contiguous");
+            P->cam_vid0[i] = v[0]->getID(); P->pt_vid0[i] = v[9]->getID();
+            bf->getObservation(P->obs[2 * i], P->obs[2 * i + 1]);
+        }
+    } else {
+        P->rowptr.assign(1, 0);
+        for (size_t i = 0; i < F; ++i) {
+            const NonlinearProductFactor* nf = dynamic_cast<const NonlinearProductFactor*>(factors[i]);
+            if (!nf) throw std::logic_error("packed: unsupported factor kind (no device descriptor)");
+            P->coeff.push_back(nf->getCoeff());
+            for (size_t k = 0; k < nf->terms().size(); ++k) {
+                P->vid.push_back(nf->getVariables()[k]->getID());
+                P->expo.push_back(nf->terms()[k].exponent);
+                P->cons.push_back(nf->terms()[k].constant);
+                P->sine.push_back(nf->terms()[k].useSine ? 1 : 0);
+            }
+            P->rowptr.push_back((int64_t)P->vid.size());
+        }
+    }
+    packed_ = std::move(P);
+    return *packed_;
+}
+
+void OptimizableFunction::initDevice(int device) { device_ = device; ensureUploaded(); }
+
+void OptimizableFunction::ensureUploaded() const {
+    if (prob_) return;
+    const Packed& P = packed();
+    if (!ctx_) {
+        int rc = rdis_hip_create(device_, &ctx_);
+        if (rc != 0) throw HipError(rc, "rdis_hip_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)");
+    }
+    const size_t N = variables.size();
+    std::vector<double> x0(N, 0.0);
+    for (size_t i = 0; i < N; ++i) if (variables[i]->assigned_) x0[i] = variables[i]->value_;
+    int rc;
+    if (P.kind == 0)
+        rc = rdis_hip_upload_ba(ctx_, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
+                                P.cam_vid0.data(), P.pt_vid0.data(), P.obs.data(), &prob_);
+    else
+        rc = rdis_hip_upload_nlp(ctx_, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
+                                 P.coeff.data(), P.rowptr.data(), P.vid.data(), P.expo.data(), P.cons.data(),
+                                 P.sine.data(), &prob_);
+    check(ctx_, rc, "upload");
+    dirty_.clear();
+    is_dirty_.assign(N, 0);
+}
+
+void OptimizableFunction::markDirty(VariableID id) const {
+    if (!prob_) return;  // everything is uploaded at first use
+    if (!is_dirty_[(size_t)id]) { is_dirty_[(size_t)id] = 1; dirty_.push_back(id); }
+}
+
+void OptimizableFunction::pushAssignments() const {
+    if (dirty_.empty()) return;
+    std::vector<int64_t> ids(dirty_.begin(), dirty_.end());
+    std::vector<double> vals(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) { vals[i] = variables[(size_t)ids[i]]->value_; is_dirty_[(size_t)ids[i]] = 0; }
+    dirty_.clear();
+    check(ctx_, rdis_hip_set_x(prob_, (int64_t)ids.size(), ids.data(), vals.data()), "set_x");
+}
+
+rdis_hip_problem* OptimizableFunction::deviceProblem() const { ensureUploaded(); pushAssignments(); return prob_; }
+rdis_hip_ctx* OptimizableFunction::deviceContext() const { ensureUploaded(); return ctx_; }
+
+void OptimizableFunction::assignAll(const NumericVec& x) {
+    if (x.size() != variables.size()) throw std::invalid_argument("assignAll: size mismatch");
+    for (size_t i = 0; i < x.size(); ++i) { variables[i]->assign(x[i]); onVarAssigned((VariableID)i, x[i]); }
+}
+
+void OptimizableFunction::fillIds(const FactorPtrVec& fs, std::vector<int64_t>& ids) const {
+    ids.resize(fs.size());
+    for (size_t i = 0; i < fs.size(); ++i) {
+        if (!fs[i]->areAllVarsAssigned()) throw std::logic_error("factor with unassigned variables handed to the device path");
+        ids[i] = fs[i]->getID();
+    }
+}
+
+Numeric OptimizableFunction::eval() const {
+    Numeric ferr = 0;
+    return evalFactors(factors, ferr, true);
+}
+Numeric OptimizableFunction::evalFactors(const FactorPtrVec& fctrs, Numeric& ferr, bool) const {
+    ferr = 0.0;
+    if (fctrs.empty()) return 0.0;
+    std::vector<int64_t> ids;
+    fillIds(fctrs, ids);
+    double f = 0;
+    rdis_hip_problem* p = deviceProblem();
+    check(ctx_, rdis_hip_eval(p, (int64_t)ids.size(), ids.data(), &f), "evalFactors");
+    return f;
+}
+void OptimizableFunction::computeGradient(const FactorPtrVec& facs, PartialGradient& gradient, bool) const {
+    gradient.clear();
+    if (facs.empty()) return;
+    std::vector<int64_t> ids;
+    fillIds(facs, ids);
+    std::vector<double> g(variables.size());
+    double f = 0;
+    rdis_hip_problem* p = deviceProblem();
+    check(ctx_, rdis_hip_eval_grad(p, (int64_t)ids.size(), ids.data(), &f, g.data()), "computeGradient");
+    std::vector<char> touched(variables.size(), 0);
+    for (const Factor* fa : facs) for (const Variable* v : fa->getVariables()) touched[(size_t)v->getID()] = 1;
+    for (size_t i = 0; i < g.size(); ++i) if (touched[i]) gradient.push_back(std::make_pair((VariableID)i, g[i]));
+}
+void OptimizableFunction::computeGradient(NumericVec& gradient, bool) const {
+    PartialGradient pg;
+    computeGradient(factors, pg);
+    gradient.assign(variables.size(), 0.0);
+    for (const auto& kv : pg) gradient[(size_t)kv.first] = kv.second;
+}
+
+// ------------------------------------------------------------------ BundleAdjustmentFunction
+void BundleAdjustmentFunction::getBlockRangeByBlkId(VariableCount b, VariableID& lo, VariableID& hi) const {
+    if (b < ncams_) { lo = getCamVID(b, 0); hi = getCamVID(b, 8); }
+    else { lo = getPointVID(b - ncams_, 0); hi = getPointVID(b - ncams_, 2); }
+}
+
+void BundleAdjustmentFunction::setDomain(VariableID vid, Numeric init) {
+    const long long ncv = ncams_ * 9;
+    const int type = vid < ncv ? (int)(vid % 9) : 9 + (int)((vid - ncv) % 3);
+    const double dsf = 1000.0, pi = 3.14159265358979323846;
+    double slo, shi, dlo, dhi;
+    if (type < 3) { slo = -1.0 * pi; shi = 1.0 * pi; dlo = slo * dsf; dhi = shi * dsf; }
+    else if (type <= 5 || type >= 9) { slo = init + -100.0; shi = init + 100.0; dlo = slo * dsf; dhi = shi * dsf; }
+    else if (type == 6) {
+        slo = init + -100.0; shi = init + 100.0;
+        dlo = std::max(std::min(slo, slo * dsf), 0.0);
+        dhi = shi * dsf;
+    } else if (type == 7) { slo = init + -1e-4; shi = init + 1e-4; dlo = -1e-1; dhi = 1e-1; }
+    else { slo = init + -1e-6; shi = init + 1e-6; dlo = -1e-3; dhi = 1e-3; }
+    variables[(size_t)vid]->setDomain(VariableDomain(std::min(dlo, slo), std::max(dhi, shi)));  // hull
+}
+
+bool BundleAdjustmentFunction::load(const std::string& file, VariableCount numcams, VariableCount numpoints) {
+    std::ifstream in(file.c_str());
+    if (!in.is_open()) { std::cerr << "BundleAdjustmentFunction::load: cannot open " << file << std::endl; return false; }
+    std::vector<std::string> sv;
+    if (!readAndSplit(in, sv) || sv.size() != 3) return false;
+    const long long fc = std::atoll(sv[0].c_str()), fp = std::atoll(sv[1].c_str()), nobs = std::atoll(sv[2].c_str());
+    ncams_ = numcams <= 0 ? fc : numcams;
+    npts_ = numpoints <= 0 ? fp : numpoints;
+    if (ncams_ > fc || npts_ > fp) return false;
+    VariableID id = 0;
+    char name[64];
+    for (long long c = 0; c < ncams_; ++c)
+        for (int k = 0; k < 9; ++k) { std::snprintf(name, sizeof name, "C%lld.%d", c, k); addVariable(name, VariableDomain(0, 0), id); }
+    for (long long p = 0; p < npts_; ++p)
+        for (int k = 0; k < 3; ++k) { std::snprintf(name, sizeof name, "x%lld.%c", p, (char)('x' + k)); addVariable(name, VariableDomain(0, 0), id); }
+    for (long long i = 0; i < nobs; ++i) {
+        if (!readAndSplit(in, sv) || sv.size() != 4) return false;
+        const long long cam = std::atoll(sv[0].c_str()), pt = std::atoll(sv[1].c_str());
+        if (cam >= ncams_ || pt >= npts_) continue;
+        BundleAdjustmentFactor* f = new BundleAdjustmentFactor((FactorID)factors.size(), cam, pt,
+                                                               std::strtod(sv[2].c_str(), nullptr), std::strtod(sv[3].c_str(), nullptr));
+        addFactor(f);
+        for (int k = 0; k < 9; ++k) f->addVariable(variables[(size_t)getCamVID(cam, k)]);
+        for (int k = 0; k < 3; ++k) f->addVariable(variables[(size_t)getPointVID(pt, k)]);
+    }
+    xinit.assign(variables.size(), 0.0);
+    for (long long c = 0; c < fc; ++c)
+        for (int k = 0; k < 9; ++k) {
+            if (!readAndSplit(in, sv) || sv.size() != 1) return false;
+            if (c >= ncams_) continue;
+            const double v = std::strtod(sv[0].c_str(), nullptr);
+            xinit[(size_t)getCamVID(c, k)] = v;
+            setDomain(getCamVID(c, k), v);
+        }
+    for (long long p = 0; p < fp; ++p)
+        for (int k = 0; k < 3; ++k) {
+            if (!readAndSplit(in, sv) || sv.size() != 1) return false;
+            if (p >= npts_) continue;
+            const double v = std::strtod(sv[0].c_str(), nullptr);
+            xinit[(size_t)getPointVID(p, k)] = v;
+            setDomain(getPointVID(p, k), v);
+        }
+    return !variables.empty() && !factors.empty();
+}
+
+// ------------------------------------------------------------------ PolynomialFunction
+Variable* PolynomialFunction::varByName(const std::string& name, VariableID& next_id) {
+    return addVariable(name, defaultDomain, next_id);
+}
+
+bool PolynomialFunction::load(const std::string& file) {
+    std::ifstream in(file.c_str());
+    if (!in.is_open()) { std::cerr << "PolynomialFunction::load: cannot open " << file << std::endl; return false; }
+    VariableID next_id = 0;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+        if (line.empty() || line[0] == '#') continue;
+        const size_t eq = line.find('=');
+        if (eq != std::string::npos) {  // "<name> = <lo>:<hi>", "default" sets the default domain
+            const std::string name = trim(line.substr(0, eq));
+            const VariableDomain dom(trim(line.substr(eq + 1)));
+            if (lower(name) == "default") defaultDomain = dom;
+            else addVariable(name, dom, next_id);
+            continue;
+        }
+        NonlinearProductFactor* f = new NonlinearProductFactor((FactorID)factors.size());
+        addFactor(f);
+        std::stringstream ss(line);
+        std::string part;
+        while (std::getline(ss, part, ',')) {  // "[coeff][, var^exp ...]"
+            const size_t hat = part.find('^');
+            const std::string name = lower(trim(part.substr(0, hat)));
+            double num;
+            if (hat == std::string::npos) {
+                if (parseNumber(name, num)) { f->setCoeff(num); continue; }
+                f->addVariable(varByName(name, next_id), 1.0, 0, false);
+            } else {
+                double e = 1.0;
+                if (!parseNumber(trim(part.substr(hat + 1)), e)) throw std::invalid_argument("PolynomialFunction: bad exponent in '" + line + "'");
+                f->addVariable(varByName(name, next_id), e, 0, false);
+            }
+        }
+    }
+    return !variables.empty() && !factors.empty();
+}
+
+std::unique_ptr<PolynomialFunction> PolynomialFunction::makeHighDimSinusoid(VariableCount h, VariableCount k,
+        VariableCount maxArity, bool allowOdd) {
+    const double twopi = 2.000001 * 3.141592653;
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%g", 10 * twopi);  // boost::format("%1%") prints 6 significant digits
+    const double bound = std::strtod(buf, nullptr);
+    std::unique_ptr<PolynomialFunction> poly(new PolynomialFunction(VariableDomain(-bound, bound)));
+    maxArity = std::min(maxArity, h + 1);
+    const VariableCount nvars = k == 1 ? h + 1 : (VariableCount)((std::llround(std::pow((double)k, (double)h + 1)) - 1) / (k - 1));
+    VariableID id = 0;
+    for (VariableCount i = 0; i < nvars; ++i) { std::snprintf(buf, sizeof buf, "x%lld", (long long)i); poly->addVariable(buf, poly->defaultDomain, id); }
+    for (VariableCount ar = 1; ar <= maxArity; ++ar) {
+        if (ar > 1 && (ar & 1) && !allowOdd) continue;
+        VariableCount lasth = h;
+        for (VariableID vid = nvars - 1; vid >= 0; --vid) {
+            const VariableID lastAtNext = k == 1 ? lasth - 1
+                : (VariableID)((std::round(std::pow((double)k, (double)lasth)) - 1.0) / (k - 1.0) - 1.0);
+            const VariableCount varheight = vid > lastAtNext ? lasth : --lasth;
+            if (varheight + 1 < ar) continue;
+            std::vector<VariableID> chain;
+            VariableID cur = vid;
+            for (VariableCount c = 0; c < ar; ++c) { chain.push_back(cur); cur = (VariableID)std::floor(((double)cur - 1.0) / (double)k); }
+            NonlinearProductFactor* f = new NonlinearProductFactor((FactorID)poly->factors.size(), ar > 1 ? 12 : 0.6);
+            poly->addFactor(f);
+            for (size_t c = chain.size(); c-- > 0;) f->addVariable(poly->variables[(size_t)chain[c]], 1, 0, ar > 1);
+        }
+    }
+    for (VariableID vid = 0; vid < nvars; ++vid) {
+        NonlinearProductFactor* f = new NonlinearProductFactor((FactorID)poly->factors.size(), 0.1);
+        poly->addFactor(f);
+        f->addVariable(poly->variables[(size_t)vid], 2, 0, false);
+    }
+    return poly;
+}
+
+// ------------------------------------------------------------------ SubspaceOptimizer
+SubspaceOptimizer::SubspaceOptimizer(OptimizableFunction& f_)
+    : f(f_), doAscent(!f_.isMinSum()), maxiters(50), ftol(3.0e-8) {}  // src/SubspaceOptimizer.cpp:12-17
+
+void SubspaceOptimizer::setParameters(const Options& options) {
+    if (options.count("SSmaxit")) maxiters = options.as<size_t>("SSmaxit");
+    if (options.count("SSftol")) ftol = options.as<Numeric>("SSftol");
+    if (maxiters == 0) throw std::invalid_argument("SSmaxit must be > 0");
+}
+
+// ------------------------------------------------------------------ HipCGDSubspaceOptimizer
+HipCGDSubspaceOptimizer::HipCGDSubspaceOptimizer(OptimizableFunction& f_)
+    : SubspaceOptimizer(f_), last_iters_(0), last_status_(0), last_nfeval_(0), last_ngeval_(0) {
+    if (doAscent) throw std::invalid_argument("HipCGDSubspaceOptimizer: only the MinSum (descent) semiring is supported");
+}
+
+Numeric HipCGDSubspaceOptimizer::optimize(const VariablePtrVec& vars, const FactorPtrVec& gdfs, NumericVec& xval,
+                                          Numeric& deltaFval, const bool printdbg) {
+    std::vector<Component> one(1);
+    one[0].vars = vars; one[0].factors = gdfs; one[0].xval = xval;
+    if (xval.size() != vars.size()) throw std::invalid_argument("optimize: xval.size() != vars.size()");
+    optimizeBatch(one, printdbg);
+    if (!gdfs.empty()) xval = one[0].xval;  // an empty factor list leaves xval as it was (.cpp:26-29)
+    deltaFval = one[0].deltaFval;
+    last_iters_ = one[0].iters; last_status_ = one[0].status;
+    last_nfeval_ = one[0].nfeval; last_ngeval_ = one[0].ngeval;
+    return one[0].fret;
+}
+
+Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, const bool printdbg) {
+    const size_t nc = comps.size();
+    std::vector<int64_t> free_ptr(nc + 1, 0), fac_ptr(nc + 1, 0), free_vid, fac_id;
+    std::vector<double> x;
+    for (size_t c = 0; c < nc; ++c) {
+        Component& C = comps[c];
+        if (C.xval.size() != C.vars.size()) throw std::invalid_argument("optimizeBatch: xval.size() != vars.size()");
+        // every variable of every listed factor must be assigned or free in this call
+        // (the caller guarantees it, src/RDISOptimizer.cpp:1042, :1049-1059)
+        std::vector<char> is_free;
+        for (const Factor* fa : C.factors)
+            for (const Variable* v : fa->getVariables())
+                if (!v->isAssigned()) {
+                    bool fr = false;
+                    for (const Variable* u : C.vars) if (u == v) { fr = true; break; }
+                    if (!fr) throw std::logic_error("optimize: factor " + std::to_string(fa->getID()) + " reads the unassigned variable " + v->getName());
+                }
+        for (size_t i = 0; i < C.vars.size(); ++i) { free_vid.push_back(C.vars[i]->getID()); x.push_back(C.xval[i]); }
+        for (const Factor* fa : C.factors) fac_id.push_back(fa->getID());
+        free_ptr[c + 1] = (int64_t)free_vid.size();
+        fac_ptr[c + 1] = (int64_t)fac_id.size();
+    }
+    std::vector<double> fret(nc), delta(nc);
+    std::vector<int32_t> iters(nc), status(nc);
+    std::vector<int64_t> nfe(nc), nge(nc);
+    rdis_hip_problem* p = f.deviceProblem();
+    const int rc = rdis_hip_cgd_batch(p, (int64_t)nc, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data(),
+                                      x.data(), (int32_t)maxiters, ftol, fret.data(), delta.data(), iters.data(),
+                                      status.data(), nfe.data(), nge.data());
+    check(f.deviceContext(), rc, "rdis_hip_cgd_batch");
+    Numeric total = 0;
+    for (size_t c = 0; c < nc; ++c) {
+        Component& C = comps[c];
+        C.fret = fret[c]; C.deltaFval = delta[c]; C.iters = iters[c]; C.status = status[c];
+        C.nfeval = nfe[c]; C.ngeval = nge[c];
+        total += fret[c];
+        if ((status[c] & 0xff) == RDIS_HIP_EXIT_NAN) std::cerr << "HipCGD: NaN objective in component " << c << ", start restored" << std::endl;
+        if ((status[c] & 0xff) == RDIS_HIP_EXIT_EMPTY) continue;  // nothing touched
+        // the variables are left assigned to the final, clamped values (.cpp:84-86); the
+        // device already holds them, so they are not marked for re-upload
+        for (size_t i = 0; i < C.vars.size(); ++i) {
+            Variable* v = C.vars[i];
+            const double val = x[(size_t)free_ptr[c] + i];
+            C.xval[i] = val;
+            v->assigned_ = true; v->value_ = val;
+            f.onVarAssigned(v->getID(), val);
+        }
+        if (printdbg)
+            std::cout << "CGD subspace result (steps " << iters[c] << "): " << fret[c] << ", diff: " << delta[c]
+                      << ", init: " << fret[c] - delta[c] << ((status[c] & RDIS_HIP_STATUS_ROLLED_BACK) ? " [restored]" : "") << std::endl;
+    }
+    return total;
+}
+
+}  // namespace rdis

@@ -1,0 +1,301 @@
+// rdis_host.h -- host side of the drop-in: the reference's plugin surface for the
+// subspace-solver path, mirrored class for class, over the C ABI of
+// include/rdis_hip.h.  No factor arithmetic lives here: every evaluation goes to the
+// HIP kernels, and there is no CPU fallback.
+//
+// Mirrored interfaces (reference file:line):
+//   SubspaceOptimizer                 src/SubspaceOptimizer.h:24-60
+//   CGDSubspaceOptimizer              src/optimizers/CGDSubspaceOptimizer.h:21-38
+//       -> HipCGDSubspaceOptimizer    (same virtual, same pre/post-conditions)
+//   OptimizableFunction               src/OptimizableFunction.h:26-230 (the parts the path uses)
+//   Factor / Variable / VariableDomain  src/Factor.h, src/Variable.h, src/VariableDomain.h
+//   BundleAdjustmentFactor / Function src/bundleadjust/BundleAdjustmentFactor.h, ...Function.h
+//   NonlinearProductFactor            src/NonlinearProductFactor.h
+//   PolynomialFunction + makeHighDimSinusoid  src/PolynomialFunction.h,
+//                                     src/OptimizableFunctionGenerator.cpp:660-760
+// Deliberate differences:
+//   * Factor gains pack(): the descriptor the device needs (the reference exposes only
+//     eval / computeGradient / getVariables; SURVEY.md section 7, hard part 7).
+//   * setParameters takes rdis::Options (a string->value map) because Boost
+//     program_options is not available here; INTEGRATION.md shows the one-line adapter.
+//   * HipCGDSubspaceOptimizer::optimizeBatch solves sibling components in one launch.
+#ifndef RDIS_HOST_H_
+#define RDIS_HOST_H_
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct rdis_hip_ctx;
+struct rdis_hip_problem;
+
+namespace rdis {
+
+typedef double Numeric;                 // src/common.h:25
+typedef long long int VariableCount;    // src/common.h:30-32
+typedef long long int VariableID;
+typedef long long int FactorID;
+typedef std::vector<Numeric> NumericVec;
+typedef std::vector<VariableID> VariableIDVec;
+// sorted (vid, value) pairs, like the reference's flat_map (src/State.h:30)
+typedef std::vector<std::pair<VariableID, Numeric> > PartialGradient;
+
+class Factor;
+class OptimizableFunction;
+
+// SSmaxit / SSftol carrier (stands in for boost::program_options::variables_map)
+class Options {
+public:
+    void set(const std::string& name, double v) { vals_[name] = v; }
+    size_t count(const std::string& name) const { return vals_.count(name); }
+    template <class T> T as(const std::string& name) const { return static_cast<T>(vals_.at(name)); }
+private:
+    std::map<std::string, double> vals_;
+};
+
+// single-interval domain (CGD asserts exactly one sub-interval, CGDSubspaceOptimizer.cpp:119)
+class VariableDomain {
+public:
+    VariableDomain() : lo_(0), hi_(0) {}
+    VariableDomain(Numeric lower, Numeric upper) : lo_(lower), hi_(upper) {}
+    explicit VariableDomain(const std::string& domain);  // "lo:hi" (src/VariableDomain.cpp:63-72)
+    Numeric min() const { return lo_; }
+    Numeric max() const { return hi_; }
+    Numeric closestVal(Numeric val) const {  // src/VariableDomain.cpp:158-163
+        if (lo_ <= val && val <= hi_) return val;
+        return val < lo_ ? lo_ : hi_;
+    }
+private:
+    Numeric lo_, hi_;
+};
+
+class Variable {
+public:
+    Variable(VariableID id, const std::string& name, const VariableDomain& dom, OptimizableFunction* owner)
+        : id_(id), name_(name), dom_(dom), assigned_(false), value_(0), owner_(owner) {}
+    void assign(Numeric newval);            // src/Variable.cpp:66-88
+    void unassign() { assigned_ = false; }
+    Numeric eval() const;                   // throws if unassigned (the reference asserts)
+    bool isAssigned() const { return assigned_; }
+    const VariableID& getID() const { return id_; }
+    const std::string& getName() const { return name_; }
+    const VariableDomain& getDomain() const { return dom_; }
+    void setDomain(const VariableDomain& d) { dom_ = d; }
+    std::vector<Factor*>& getFactors() { return factors_; }
+private:
+    friend class OptimizableFunction;
+    friend class HipCGDSubspaceOptimizer;
+    VariableID id_;
+    std::string name_;
+    VariableDomain dom_;
+    bool assigned_;
+    Numeric value_;
+    OptimizableFunction* owner_;
+    std::vector<Factor*> factors_;
+};
+typedef std::vector<Variable*> VariablePtrVec;
+
+class Factor {
+public:
+    explicit Factor(FactorID id) : id_(id), owner_(nullptr) {}
+    virtual ~Factor() {}
+    FactorID getID() const { return id_; }
+    const VariablePtrVec& getVariables() const { return variables_; }
+    bool areAllVarsAssigned() const;
+    // Factor::eval / computeGradient (src/Factor.h:72, :92-93), evaluated on the device
+    Numeric eval() const;
+    void computeGradient(PartialGradient& g) const;
+protected:
+    friend class OptimizableFunction;
+    FactorID id_;
+    VariablePtrVec variables_;
+    OptimizableFunction* owner_;
+};
+typedef std::vector<Factor*> FactorPtrVec;
+
+// vals = [rx ry rz tx ty tz f k1 k2 X Y Z] (BundleAdjustmentCommon.h:36-59)
+class BundleAdjustmentFactor : public Factor {
+public:
+    BundleAdjustmentFactor(FactorID id, long long cameraID, long long pointID, Numeric obsX, Numeric obsY)
+        : Factor(id), cam_(cameraID), pt_(pointID), ox_(obsX), oy_(obsY) {}
+    void addVariable(Variable* v) { variables_.push_back(v); v->getFactors().push_back(this); }
+    long long getCameraID() const { return cam_; }
+    long long getPointID() const { return pt_; }
+    void getObservation(Numeric& x, Numeric& y) const { x = ox_; y = oy_; }
+private:
+    long long cam_, pt_;
+    Numeric ox_, oy_;
+};
+
+// coeff * prod_i g((x_i - k_i)^e_i), g = id or sin (src/NonlinearProductFactor.h:15-20)
+class NonlinearProductFactor : public Factor {
+public:
+    struct Term { Numeric exponent, constant; bool useSine; };
+    explicit NonlinearProductFactor(FactorID id, Numeric coefficient = 1) : Factor(id), coeff_(coefficient) {}
+    // exponent 0 is dropped and a repeated variable ignored (src/NonlinearProductFactor.cpp:27-52)
+    void addVariable(Variable* v, Numeric exponent = 1, Numeric constant = 0, bool useSine = false);
+    void setCoeff(Numeric c) { coeff_ = c; }
+    Numeric getCoeff() const { return coeff_; }
+    const std::vector<Term>& terms() const { return terms_; }
+private:
+    Numeric coeff_;
+    std::vector<Term> terms_;
+};
+
+class OptimizableFunction {
+public:
+    OptimizableFunction();
+    virtual ~OptimizableFunction();
+    OptimizableFunction(const OptimizableFunction&) = delete;
+    OptimizableFunction& operator=(const OptimizableFunction&) = delete;
+
+    virtual VariableCount getNumVars() const { return (VariableCount)variables.size(); }
+    virtual VariablePtrVec& getVariables() { return variables; }
+    virtual const FactorPtrVec& getFactors() const { return factors; }
+    // hooks the solver calls after (un)assigning a variable (src/OptimizableFunction.h:65-69)
+    virtual void onVarAssigned(const VariableID, const Numeric) const {}
+    virtual void onVarUnassigned(const VariableID) const {}
+    // MinSum semiring: product is +, sum is min => descent (src/Semiring.h:97-106)
+    bool isMinSum() const { return true; }
+
+    // src/OptimizableFunction.h:82-88, :109-110 -- evaluated by the HIP kernels
+    virtual Numeric eval() const;
+    virtual Numeric evalFactors(const FactorPtrVec& fctrs, Numeric& ferr, bool useCached = true) const;
+    virtual void computeGradient(const FactorPtrVec& facs, PartialGradient& gradient, bool checkGrad = false) const;
+    virtual void computeGradient(NumericVec& gradient, bool checkGrad = false) const;
+
+    // assign every variable (State x) -- optBA's "assign the initial state"
+    void assignAll(const NumericVec& x);
+    void initDevice(int device = 0);          // upload the packed function (done lazily otherwise)
+    rdis_hip_problem* deviceProblem() const;  // uploads + pushes pending assignments
+    rdis_hip_ctx* deviceContext() const;
+
+    // packed (structure-of-arrays) view of the function; what rdis_hip_upload_* takes
+    struct Packed {
+        int kind;  // 0 = bundle adjustment, 1 = nonlinear product
+        std::vector<double> lo, hi;
+        std::vector<int64_t> cam_vid0, pt_vid0;
+        std::vector<double> obs;
+        std::vector<double> coeff, expo, cons;
+        std::vector<int64_t> rowptr, vid;
+        std::vector<uint8_t> sine;
+    };
+    const Packed& packed() const;
+
+protected:
+    Variable* addVariable(const std::string& name, const VariableDomain& dom, VariableID& id);
+    void addFactor(Factor* f);
+    VariablePtrVec variables;  // indexed by id (creation order, src/OptimizableFunction.cpp:57-76)
+    FactorPtrVec factors;      // indexed by id
+    VariableDomain defaultDomain;
+
+private:
+    friend class Variable;
+    friend class Factor;
+    friend class HipCGDSubspaceOptimizer;
+    void markDirty(VariableID id) const;
+    void pushAssignments() const;
+    void ensureUploaded() const;
+    void fillIds(const FactorPtrVec& f, std::vector<int64_t>& ids) const;
+    mutable std::unique_ptr<Packed> packed_;
+    mutable rdis_hip_ctx* ctx_;
+    mutable rdis_hip_problem* prob_;
+    mutable int device_;
+    mutable std::vector<VariableID> dirty_;
+    mutable std::vector<char> is_dirty_;
+};
+
+class BundleAdjustmentFunction : public OptimizableFunction {
+public:
+    BundleAdjustmentFunction() : ncams_(0), npts_(0) {}
+    // BAL text (src/bundleadjust/BundleAdjustmentFunction.cpp:50-250); numcams / numpoints > 0
+    // keep the first k cameras / points
+    bool load(const std::string& file, VariableCount numcams = 0, VariableCount numpoints = 0);
+    long long getNumCameras() const { return ncams_; }
+    long long getNumPoints() const { return npts_; }
+    VariableID getCamVID(long long cid, unsigned k) const { return cid * 9 + k; }                 // .h:88-96
+    VariableID getPointVID(long long pid, unsigned k) const { return ncams_ * 9 + pid * 3 + k; }
+    // blocks = camera (9) / point (3) (.h:51-78)
+    VariableCount getNumBlocks() const { return ncams_ + npts_; }
+    void getBlockRangeByBlkId(VariableCount b, VariableID& lo, VariableID& hi) const;
+    const NumericVec& getInitialState() const { return xinit; }
+private:
+    void setDomain(VariableID vid, Numeric initialVal);  // .cpp:402-477
+    long long ncams_, npts_;
+    NumericVec xinit;
+};
+
+class PolynomialFunction : public OptimizableFunction {
+public:
+    PolynomialFunction() {}
+    explicit PolynomialFunction(const VariableDomain& dflt) { defaultDomain = dflt; }
+    bool load(const std::string& file);  // src/PolynomialFunction.cpp:60-215
+    // OptimizableFunctionGenerator::makeHighDimSinusoid (src/OptimizableFunctionGenerator.cpp:660-760)
+    static std::unique_ptr<PolynomialFunction> makeHighDimSinusoid(VariableCount treeHeight = 4,
+            VariableCount branches = 3, VariableCount maxArity = 3, bool allowOddArityFactors = false);
+private:
+    Variable* varByName(const std::string& name, VariableID& next_id);
+};
+
+// src/SubspaceOptimizer.h:24-60
+class SubspaceOptimizer {
+public:
+    explicit SubspaceOptimizer(OptimizableFunction& f_);
+    virtual ~SubspaceOptimizer() {}
+    virtual void setParameters(const Options& options);  // SSmaxit, SSftol (src/SubspaceOptimizer.cpp:26-32)
+    // vars / factors define the sub-function; xval: start values in the order of vars, overwritten
+    // with the final (clamped) values; deltaFval = f(x_end) - f(x_init); returns f(x_end)
+    virtual Numeric optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xval,
+                             Numeric& deltaFval, const bool printdbg) = 0;
+protected:
+    OptimizableFunction& f;
+    const bool doAscent;
+    size_t maxiters;
+    Numeric ftol;
+};
+
+// The drop-in for CGDSubspaceOptimizer: same contract, solved on the MI355X.
+class HipCGDSubspaceOptimizer : public SubspaceOptimizer {
+public:
+    explicit HipCGDSubspaceOptimizer(OptimizableFunction& f_);
+    virtual ~HipCGDSubspaceOptimizer() {}
+    virtual Numeric optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xinit,
+                             Numeric& deltaFval, const bool printdbg);
+
+    // sibling components of one recursion level in one launch (they share no free variable
+    // and no factor, src/Component.cpp:508-549).  Returns the sum of the components' values.
+    struct Component {
+        VariablePtrVec vars;
+        FactorPtrVec factors;
+        NumericVec xval;      // in: start, out: final clamped values
+        Numeric fret, deltaFval;
+        int iters, status;
+        long long nfeval, ngeval;
+    };
+    Numeric optimizeBatch(std::vector<Component>& comps, const bool printdbg);
+
+    // results of the last optimize() beyond what the reference returns
+    int lastIters() const { return last_iters_; }
+    int lastStatus() const { return last_status_; }
+    long long lastFEvals() const { return last_nfeval_; }
+    long long lastGEvals() const { return last_ngeval_; }
+private:
+    int last_iters_, last_status_;
+    long long last_nfeval_, last_ngeval_;
+};
+
+// error raised when the HIP library reports a failure (no silent fallback)
+class HipError : public std::runtime_error {
+public:
+    HipError(int code, const std::string& what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }
+private:
+    int code_;
+};
+
+}  // namespace rdis
+#endif  // RDIS_HOST_H_

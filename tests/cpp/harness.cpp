@@ -1,0 +1,156 @@
+// Test harness for the C++ drop-in surface (rdis_amd/host): small C entry points that
+// use the mirrored classes exactly the way the reference's callers do
+// (BCDOptimizer with one block = all variables, src/optimizers/BCDOptimizer.cpp:149;
+//  RDISOptimizer::getValueFromDomain, src/RDISOptimizer.cpp:1039-1083).
+#include <cstring>
+#include <iostream>
+#include <memory>
+
+#include "../../rdis_amd/host/rdis_host.h"
+
+using namespace rdis;
+
+extern "C" {
+
+// ---- host-only: what the loaders build (no GPU needed) --------------------------------
+// out_sizes = {nvars, nfac, kind}; arrays may be NULL to query sizes
+int harness_pack_bal(const char* path, long long ncams, long long npts, long long* out_sizes, double* xinit,
+                     double* lo, double* hi, long long* cam_vid0, long long* pt_vid0, double* obs) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        const OptimizableFunction::Packed& P = f.packed();
+        out_sizes[0] = f.getNumVars(); out_sizes[1] = (long long)f.getFactors().size(); out_sizes[2] = P.kind;
+        if (xinit) std::memcpy(xinit, f.getInitialState().data(), sizeof(double) * f.getInitialState().size());
+        if (lo) std::memcpy(lo, P.lo.data(), sizeof(double) * P.lo.size());
+        if (hi) std::memcpy(hi, P.hi.data(), sizeof(double) * P.hi.size());
+        if (cam_vid0) for (size_t i = 0; i < P.cam_vid0.size(); ++i) { cam_vid0[i] = P.cam_vid0[i]; pt_vid0[i] = P.pt_vid0[i]; }
+        if (obs) std::memcpy(obs, P.obs.data(), sizeof(double) * P.obs.size());
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_pack_bal: " << e.what() << std::endl; return -2; }
+}
+
+// which = 0: polynomial file, 1: default high-dimensional sinusoid. out_sizes = {nvars, nfac, nnz}
+int harness_pack_nlp(int which, const char* path, long long* out_sizes, double* lo, double* hi, double* coeff,
+                     long long* rowptr, long long* vid, double* expo, double* cons, unsigned char* sine) {
+    try {
+        std::unique_ptr<PolynomialFunction> f;
+        if (which == 0) { f.reset(new PolynomialFunction()); if (!f->load(path)) return -1; }
+        else f = PolynomialFunction::makeHighDimSinusoid();
+        const OptimizableFunction::Packed& P = f->packed();
+        out_sizes[0] = f->getNumVars(); out_sizes[1] = (long long)f->getFactors().size(); out_sizes[2] = (long long)P.vid.size();
+        if (lo) {
+            std::memcpy(lo, P.lo.data(), sizeof(double) * P.lo.size());
+            std::memcpy(hi, P.hi.data(), sizeof(double) * P.hi.size());
+            std::memcpy(coeff, P.coeff.data(), sizeof(double) * P.coeff.size());
+            for (size_t i = 0; i < P.rowptr.size(); ++i) rowptr[i] = P.rowptr[i];
+            for (size_t i = 0; i < P.vid.size(); ++i) { vid[i] = P.vid[i]; expo[i] = P.expo[i]; cons[i] = P.cons[i]; sine[i] = P.sine[i]; }
+        }
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_pack_nlp: " << e.what() << std::endl; return -2; }
+}
+
+// ---- GPU: the reference's call pattern through the plugin surface ------------------------
+// mode 0: all variables, all factors (BCD, one block).  mode 1: block = camera 0 + point 0 free,
+// the other variables assigned to the file values, factors = those touching the block
+// (getValueFromDomain).  out = {fret, deltaFval, f_before, f_after(eval of the same factor list),
+// iters, status, nfeval, ngeval, post_ok}
+int harness_ba_cgd(const char* path, long long ncams, long long npts, int mode, int maxit, double ftol,
+                   double* out, double* xval_out, long long* nfree_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        f.assignAll(f.getInitialState());
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit); o.set("SSftol", ftol);
+        ssopt.setParameters(o);
+        VariablePtrVec vars;
+        FactorPtrVec facs;
+        if (mode == 0) { vars = f.getVariables(); facs = f.getFactors(); }
+        else {
+            VariableID lo, hi;
+            f.getBlockRangeByBlkId(0, lo, hi);
+            for (VariableID v = lo; v <= hi; ++v) vars.push_back(f.getVariables()[(size_t)v]);
+            f.getBlockRangeByBlkId(f.getNumCameras(), lo, hi);
+            for (VariableID v = lo; v <= hi; ++v) vars.push_back(f.getVariables()[(size_t)v]);
+            for (Factor* fa : f.getFactors()) {
+                const BundleAdjustmentFactor* b = static_cast<const BundleAdjustmentFactor*>(fa);
+                if (b->getCameraID() == 0 || b->getPointID() == 0) facs.push_back(fa);
+            }
+        }
+        NumericVec xval(vars.size());
+        for (size_t i = 0; i < vars.size(); ++i) xval[i] = vars[i]->eval();
+        Numeric ferr = 0;
+        const Numeric before = f.evalFactors(facs, ferr);
+        Numeric delta = 0;
+        const Numeric fret = ssopt.optimize(vars, facs, xval, delta, false);
+        // post-conditions of optimize(): vars assigned to xval (clamped), others untouched
+        bool ok = true;
+        for (size_t i = 0; i < vars.size(); ++i) {
+            ok = ok && vars[i]->isAssigned() && vars[i]->eval() == xval[i];
+            ok = ok && xval[i] >= vars[i]->getDomain().min() && xval[i] <= vars[i]->getDomain().max();
+        }
+        if (mode == 1)
+            for (size_t v = 9; v < (size_t)f.getNumCameras() * 9; ++v) ok = ok && f.getVariables()[v]->eval() == f.getInitialState()[v];
+        const Numeric after = f.evalFactors(facs, ferr);
+        out[0] = fret; out[1] = delta; out[2] = before; out[3] = after; out[4] = ssopt.lastIters();
+        out[5] = ssopt.lastStatus(); out[6] = (double)ssopt.lastFEvals(); out[7] = (double)ssopt.lastGEvals(); out[8] = ok ? 1 : 0;
+        *nfree_out = (long long)vars.size();
+        if (xval_out) std::memcpy(xval_out, xval.data(), sizeof(double) * xval.size());
+        // empty factor list: returns 0, delta 0, xval untouched (CGDSubspaceOptimizer.cpp:26-29)
+        NumericVec keep = xval;
+        Numeric d2 = 1;
+        if (ssopt.optimize(vars, FactorPtrVec(), keep, d2, false) != 0 || d2 != 0 || keep != xval) out[8] = 0;
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_ba_cgd: " << e.what() << std::endl; return -2; }
+}
+
+// polynomial file, start (x0, x1); out = {fret, delta, x0, x1, iters, status}
+int harness_poly_cgd(const char* path, double x0, double x1, int maxit, double* out) {
+    try {
+        PolynomialFunction f;
+        if (!f.load(path)) return -1;
+        NumericVec xval(2); xval[0] = x0; xval[1] = x1;
+        f.assignAll(xval);
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        Numeric delta = 0;
+        const Numeric fret = ssopt.optimize(f.getVariables(), f.getFactors(), xval, delta, false);
+        out[0] = fret; out[1] = delta; out[2] = xval[0]; out[3] = xval[1]; out[4] = ssopt.lastIters(); out[5] = ssopt.lastStatus();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_poly_cgd: " << e.what() << std::endl; return -2; }
+}
+
+// sibling components in one launch: every point of a BAL problem is its own component once the
+// cameras are fixed (the shape RDIS produces on ladybug).  out = {sum fret, sum
+// delta, ncomp, total iterations, f_before, f_after}
+int harness_ba_points_batch(const char* path, long long ncams, long long npts, int maxit, double* out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        f.assignAll(f.getInitialState());
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        std::vector<HipCGDSubspaceOptimizer::Component> comps((size_t)f.getNumPoints());
+        for (Factor* fa : f.getFactors()) comps[(size_t)static_cast<BundleAdjustmentFactor*>(fa)->getPointID()].factors.push_back(fa);
+        for (long long p = 0; p < f.getNumPoints(); ++p) {
+            VariableID lo, hi;
+            f.getBlockRangeByBlkId(f.getNumCameras() + p, lo, hi);
+            for (VariableID v = lo; v <= hi; ++v) {
+                comps[(size_t)p].vars.push_back(f.getVariables()[(size_t)v]);
+                comps[(size_t)p].xval.push_back(f.getVariables()[(size_t)v]->eval());
+            }
+        }
+        const Numeric before = f.eval();
+        const Numeric total = ssopt.optimizeBatch(comps, false);
+        const Numeric after = f.eval();
+        double sd = 0, its = 0;
+        for (const auto& c : comps) { sd += c.deltaFval; its += c.iters + 1; }
+        out[0] = total; out[1] = sd; out[2] = (double)comps.size(); out[3] = its; out[4] = before; out[5] = after;
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_ba_points_batch: " << e.what() << std::endl; return -2; }
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""The C++ plugin surface (rdis_amd/host): rdis::HipCGDSubspaceOptimizer used the way
+the reference's callers use CGDSubspaceOptimizer, through tests/cpp/harness.cpp.
+
+CPU part: the loaders build exactly the packed function the Python builders build
+(ids, domains, factor order) -- index work is bit-exact.  GPU part: optimize() over
+all variables (BCD one-block shape), over one camera+point block with constants
+(RDIS getValueFromDomain shape), on the polynomial file, and sibling components in
+one launch."""
+import ctypes as C
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rdis_amd import problems as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "rdis_amd", "host")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    return C.CDLL(os.path.join(ROOT, "tests", "cpp", "libharness.so"))
+
+
+@pytest.fixture(scope="module")
+def bal_path(tmp_path_factory):
+    dst = tmp_path_factory.mktemp("bal") / "ladybug.txt"
+    with gzip.open(P.LADYBUG_PATH, "rb") as src, open(dst, "wb") as out:
+        shutil.copyfileobj(src, out)
+    return str(dst).encode()
+
+
+def _pack_bal(h, path, nc, npnt):
+    sizes = np.zeros(3, dtype=np.int64)
+    assert h.harness_pack_bal(path, nc, npnt, sizes.ctypes.data_as(C.c_void_p), None, None, None, None, None, None) == 0
+    n, f = int(sizes[0]), int(sizes[1])
+    x, lo, hi = np.empty(n), np.empty(n), np.empty(n)
+    cam, pt, obs = np.empty(f, np.int64), np.empty(f, np.int64), np.empty(2 * f)
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert h.harness_pack_bal(path, nc, npnt, v(sizes), v(x), v(lo), v(hi), v(cam), v(pt), v(obs)) == 0
+    return sizes, x, lo, hi, cam, pt, obs
+
+
+@pytest.mark.parametrize("nc,npnt", [(5, 30), (49, 500), (0, 0)])
+def test_bal_loader_matches_python_builder(harness, bal_path, nc, npnt):
+    sizes, x, lo, hi, cam, pt, obs = _pack_bal(harness, bal_path, nc, npnt)
+    pp = P.load_bal(ncams=nc, npts=npnt)
+    assert (sizes[0], sizes[1], sizes[2]) == (pp.nvars, pp.nfac, 0)
+    assert np.array_equal(cam, pp.cam_vid0) and np.array_equal(pt, pp.pt_vid0)     # indexing: bit-exact
+    assert np.array_equal(x, pp.x0) and np.array_equal(obs, pp.obs.reshape(-1))
+    assert np.array_equal(lo, pp.lo) and np.array_equal(hi, pp.hi)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_nlp_builders_match_python(harness, which):
+    pp = P.load_poly() if which == 0 else P.make_high_dim_sinusoid()
+    sizes = np.zeros(3, dtype=np.int64)
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    path = P.TESTPOLY_PATH.encode()
+    assert harness.harness_pack_nlp(which, path, v(sizes), None, None, None, None, None, None, None, None) == 0
+    n, f, nnz = (int(s) for s in sizes)
+    assert (n, f, nnz) == (pp.nvars, pp.nfac, len(pp.vid))
+    lo, hi, coeff = np.empty(n), np.empty(n), np.empty(f)
+    rowptr, vid = np.empty(f + 1, np.int64), np.empty(nnz, np.int64)
+    expo, cons, sine = np.empty(nnz), np.empty(nnz), np.empty(nnz, np.uint8)
+    assert harness.harness_pack_nlp(which, path, v(sizes), v(lo), v(hi), v(coeff), v(rowptr), v(vid), v(expo), v(cons), v(sine)) == 0
+    assert np.array_equal(lo, pp.lo) and np.array_equal(hi, pp.hi) and np.array_equal(coeff, pp.coeff)
+    assert np.array_equal(rowptr, pp.rowptr) and np.array_equal(vid, pp.vid)
+    assert np.array_equal(expo, pp.expo) and np.array_equal(cons, pp.cons) and np.array_equal(sine, pp.sine)
+
+
+def _ba_cgd(h, path, nc, npnt, mode, maxit):
+    out = np.zeros(9)
+    nfree = C.c_longlong()
+    x = np.zeros(9 * 49 + 3 * 7776)
+    rc = h.harness_ba_cgd(path, nc, npnt, mode, maxit, C.c_double(3e-8), out.ctypes.data_as(C.c_void_p),
+                          x.ctypes.data_as(C.c_void_p), C.byref(nfree))
+    assert rc == 0
+    return out, x[:nfree.value]
+
+
+@pytest.mark.gpu
+def test_optimize_all_variables_like_bcd(harness, bal_path, gctx):
+    from rdis_amd import capi
+    out, x = _ba_cgd(harness, bal_path, 5, 30, 0, 25)
+    fret, delta, before, after, iters, status, nfe, nge, ok = out
+    pp = P.load_bal(ncams=5, npts=30).single_component()
+    o = O.OracleProblem(pp)
+    assert ok == 1.0 and abs(before - o.eval()) <= 1e-12 * before           # f(x_init)
+    assert abs((fret - delta) - before) <= 1e-12 * before                  # deltaFval = f_end - f_init
+    assert abs(after - fret) <= 1e-12 * fret                               # vars left assigned to the result
+    # identical to driving the C ABI directly (same kernels, same inputs): bit-exact
+    plan = capi.Plan(capi.Problem(gctx, pp))
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert fret == r.fret[0] and np.array_equal(x, r.x) and iters == r.iters[0] and nfe == r.nfeval[0]
+    o.assign(None, x)
+    assert abs(o.eval() - fret) <= 1e-12 * fret                            # oracle's objective at the returned point
+
+
+@pytest.mark.gpu
+def test_optimize_block_with_constants_like_rdis(harness, bal_path):
+    out, x = _ba_cgd(harness, bal_path, 5, 30, 1, 25)
+    fret, delta, before, after, iters, status, nfe, nge, ok = out
+    assert ok == 1.0 and len(x) == 12 and delta < 0
+    pp = P.load_bal(ncams=5, npts=30)
+    free = np.concatenate([np.arange(9), np.arange(45, 48)]).astype(np.int64)
+    fac = np.where((pp.cam_vid0 == 0) | (pp.pt_vid0 == 45))[0].astype(np.int64)
+    o = O.OracleProblem(pp)
+    assert abs(before - o.eval(fac)) <= 1e-12 * before
+    o.assign(free, x)
+    assert abs(o.eval(fac) - fret) <= 1e-12 * fret and abs(after - fret) <= 1e-12 * fret
+    r1 = O.OracleProblem(pp).cgd(free_vid=free, fac=fac, x=pp.x0[free], maxiters=1)
+    out1, _ = _ba_cgd(harness, bal_path, 5, 30, 1, 1)
+    assert abs(out1[0] - r1.fret) <= 1e-6 * r1.fret                        # one line minimisation: Brent's tolerance
+
+
+@pytest.mark.gpu
+def test_optimize_full_ladybug_through_plugin(harness, bal_path, golden):
+    out, x = _ba_cgd(harness, bal_path, 0, 0, 0, 25)
+    c = golden["cgd"]["ladybug_full"]
+    assert out[8] == 1.0 and int(out[5]) & 0xFF == 3 and out[4] == 24
+    assert abs(out[0] - c["fret"]) <= 0.08 * c["fret"]                      # chaos band, see test_gpu_solver.py
+    assert abs(out[2] - 850912.46068083902) <= 1e-12 * out[2]
+    assert abs(out[3] - out[0]) <= 1e-12 * out[0]
+
+
+@pytest.mark.gpu
+def test_polynomial_through_plugin(harness, golden):
+    t = golden["testpoly"]
+    for case in t["cgd"]:
+        out = np.zeros(6)
+        assert harness.harness_poly_cgd(P.TESTPOLY_PATH.encode(), C.c_double(case["start"][0]), C.c_double(case["start"][1]),
+                                        50, out.ctypes.data_as(C.c_void_p)) == 0
+        assert abs(out[0] - case["fret"]) <= 1e-10 * abs(case["fret"])
+        if "x" in case:
+            assert abs(out[2] - case["x"][0]) <= 1e-5 and abs(out[3] - case["x"][1]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_sibling_components_in_one_launch(harness, bal_path):
+    # cameras fixed => every point is an independent component
+    out = np.zeros(6)
+    assert harness.harness_ba_points_batch(bal_path, 49, 500, 25, out.ctypes.data_as(C.c_void_p)) == 0
+    total, sum_delta, ncomp, its, before, after = out
+    assert ncomp == 500 and its >= 500 and sum_delta < 0
+    assert abs(total - after) <= 1e-12 * after                              # sum of component values = objective
+    assert abs((before + sum_delta) - after) <= 1e-10 * before
+    # the same components one at a time on the oracle: converged 3-variable problems agree
+    pp = P.load_bal(ncams=49, npts=500)
+    o = O.OracleProblem(pp)
+    tot = 0.0
+    for p in range(500):
+        fv = np.arange(441 + 3 * p, 441 + 3 * p + 3, dtype=np.int64)
+        fc = np.where(pp.pt_vid0 == 441 + 3 * p)[0].astype(np.int64)
+        tot += o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25).fret
+    assert abs(tot - total) <= 1e-6 * tot
