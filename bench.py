@@ -209,9 +209,12 @@ def main():
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
         print(json.dumps(line))
+    plan.close()
+    prob.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

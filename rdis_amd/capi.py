@@ -68,6 +68,29 @@ SYMBOLS = {
 }
 
 _lib: Optional[C.CDLL] = None
+_live = []  # weak references to open handles, closed in order (plans, problems, contexts) at exit
+
+
+def _register(obj):
+    import weakref
+    _live.append(weakref.ref(obj))
+
+
+def _close_all():
+    # the HIP runtime must still be loaded when device memory and streams are released
+    objs = [r() for r in _live]
+    for cls in ("Plan", "Problem", "Context"):
+        for o in objs:
+            if o is not None and type(o).__name__ == cls:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_all)
 
 
 def load_library() -> C.CDLL:
@@ -118,6 +141,7 @@ class Context:
                                    f"({self.lib.rdis_hip_device_count()} HIP devices visible)")
         self.h = h
         self.device = device
+        _register(self)
 
     def check(self, rc: int):
         if rc:
@@ -185,6 +209,7 @@ class Problem:
         ctx.check(rc)
         self.h = h
         self.nvars, self.nfac = pp.nvars, pp.nfac
+        _register(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -267,6 +292,7 @@ class Plan:
         self.ctx.check(self.ctx.lib.rdis_hip_plan_create(prob.h, self.ncomp, _ptr(self.free_ptr), _ptr(self.free_vid),
                                                          _ptr(self.fac_ptr), _ptr(self.fac_id), C.byref(h)))
         self.h = h
+        _register(self)
 
     def close(self):
         if getattr(self, "h", None):

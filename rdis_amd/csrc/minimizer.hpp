@@ -324,11 +324,24 @@ struct CgdMachine {
 // The driver: the single place where each heavy operation is instantiated.
 // Env provides eval_value / eval_value_slope / gradient_to_xi / cg_start /
 // line_begin / line_end / cg_reduce / cg_update / trace / aborted.
+//
+// The machine's ~40 doubles of state live in LDS and only wave 0 of a workgroup
+// steps it (the other waves would compute the same thing); the request is handed to
+// the other waves through a double-buffered LDS slot.  Nothing of the control logic
+// is therefore live in registers across the factor arithmetic.
 template <class Env>
-__device__ __forceinline__ void run_machine(Env& E, CgdMachine& M) {
+__device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Request (&Q)[2] /* LDS */,
+                                            int maxiters, double ftol) {
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-    for (;;) {
-        const Request q = M.next(r0, r1, r2);
+    const bool stepper = threadIdx.x < 64;
+    if (stepper) M.init(maxiters, ftol);
+    for (int round = 0;; ++round) {
+        if (stepper) {
+            const Request nq = M.next(r0, r1, r2);
+            if (threadIdx.x == 0) Q[round & 1] = nq;
+        }
+        __syncthreads();
+        const Request q = Q[round & 1];
         if (q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
         if (q.kind == REQ_DONE || E.aborted()) break;
         switch (q.kind) {
@@ -349,6 +362,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M) {
         default: break;
         }
     }
+    __syncthreads();  // M is final and visible to every lane
 }
 
 }  // namespace rdis_hip

@@ -376,10 +376,10 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
         E.ox = o.x; E.oy = o.y;
     }
 
-    CgdMachine M;
-    M.init(maxiters, ftol);
+    __shared__ CgdMachine M;
+    __shared__ Request Q[2];
     E.init_vectors();
-    run_machine(E, M);
+    run_machine(E, M, Q, maxiters, ftol);
     int status = M.status();
     if (E.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
     const bool restore = M.rolled_back || E.dead;

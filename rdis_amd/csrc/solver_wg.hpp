@@ -312,10 +312,10 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
                   red, 0,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
 
-    CgdMachine M;
-    M.init(maxiters, ftol);
+    __shared__ CgdMachine M;
+    __shared__ Request Q[2];
     E.init_vectors();
-    run_machine(E, M);
+    run_machine(E, M, Q, maxiters, ftol);
     // assign gdmin.p with sanitisation (.cpp:61); after a rollback x already holds clamp(x_init)
     if (!M.rolled_back) E.assign_vec(E.p);
     for (int i = E.tid; i < n; i += E.nt) L.xout[f0 + i] = P.x[E.fv[i]];

@@ -1,0 +1,95 @@
+"""N > 1 plumbing on CPU: two processes over gloo shard the components of a synthetic
+decomposable problem (LPT, identical on every rank), "solve" their shards (here with
+the oracle -- the checker stands in for the GPU solver, this test is about the
+sharding and the objective all-reduce), and the reduced objective equals the
+unsharded one."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from rdis_amd import problems as P
+from rdis_amd.dist import rank_decomposition
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lpt_partition_is_a_partition_and_balanced():
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 1000, 1000)
+    for world in (1, 2, 4, 8):
+        parts = P.shard_components(1000, w, world)
+        allc = np.sort(np.concatenate(parts))
+        assert np.array_equal(allc, np.arange(1000))                 # every component exactly once
+        loads = np.array([w[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= w.max()                  # LPT bound
+        assert all(np.all(np.diff(p) > 0) for p in parts)            # ascending ids within a rank
+
+
+def test_rank_decomposition_matches_components():
+    pp = P.make_synthetic_ba(10, 2, 6)
+    seen = []
+    for r in range(3):
+        free_ptr, free_vid, fac_ptr, fac_id, mine = rank_decomposition(pp, r, 3)
+        seen.extend(mine.tolist())
+        for k, c in enumerate(mine):
+            fv, fc = pp.component(int(c))
+            assert np.array_equal(free_vid[free_ptr[k]:free_ptr[k + 1]], fv)    # indexing: bit-exact
+            assert np.array_equal(fac_id[fac_ptr[k]:fac_ptr[k + 1]], fc)
+    assert sorted(seen) == list(range(10))
+
+
+_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch, torch.distributed as dist
+    from rdis_amd import problems as P
+    from rdis_amd.dist import rank_decomposition, allreduce_objective, gather_deterministic_sum
+    from oracle import oracle as O
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pp = P.make_synthetic_ba(12, 2, 8)
+    free_ptr, free_vid, fac_ptr, fac_id, mine = rank_decomposition(pp, rank, world)
+    o = O.OracleProblem(pp)
+    local, iters = 0.0, 0
+    for k in range(len(mine)):
+        fv = free_vid[free_ptr[k]:free_ptr[k + 1]]; fc = fac_id[fac_ptr[k]:fac_ptr[k + 1]]
+        r = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=10)
+        local += r.fret; iters += r.iters + 1
+    total = allreduce_objective(local, dist)
+    total2 = gather_deterministic_sum(local, dist)
+    it = torch.tensor([float(iters)], dtype=torch.float64); dist.all_reduce(it)
+    if rank == 0:
+        print(json.dumps({{"total": total, "total2": total2, "iters": it.item(), "ncomp_rank0": len(mine)}}))
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_two_ranks_gloo_objective_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    # the unsharded reference: all components on one rank
+    from oracle import oracle as O
+    pp = P.make_synthetic_ba(12, 2, 8)
+    o = O.OracleProblem(pp)
+    tot, its = 0.0, 0
+    for c in range(12):
+        fv, fc = pp.component(c)
+        r = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=10)
+        tot += r.fret
+        its += r.iters + 1
+    assert abs(res["total"] - tot) <= 1e-12 * abs(tot) and abs(res["total2"] - tot) <= 1e-12 * abs(tot)
+    assert res["iters"] == its and res["ncomp_rank0"] == 6
