@@ -53,13 +53,15 @@ struct Request {
     double a;
     bool restore;
     bool line;           // an evaluation on the current line (recorded in the trace)
+    int pre_tag;         // optional trace record of an evaluation whose value was already known
+    double pre_a, pre_b, pre_c;  //   (emitted first)
     int tr_tag;          // optional trace record emitted before the request is served
     double tr_a, tr_b, tr_c;
 };
 
 struct CgdMachine {
     enum : int {
-        S_BEGIN, S_FIRST, S_GRAD0, S_ITER_BEGIN, S_BR_START, S_BR_FA, S_BR_FB, S_BR_FC, S_BR_HEAD,
+        S_BEGIN, S_FIRST, S_GRAD0, S_ITER_BEGIN, S_BR_START, S_BR_FB, S_BR_FC, S_BR_HEAD,
         S_BR_CASE1, S_BR_CASE2, S_BR_SHIFT, S_DB_START, S_DB_FIRST, S_DB_HEAD, S_DB_EVAL,
         S_AFTER_LINMIN, S_GRAD_ITER, S_REDUCED, S_FINISH, S_ROLLED, S_DONE
     };
@@ -69,8 +71,13 @@ struct CgdMachine {
     double finit, fp, fret;
     bool saw_nan, rolled_back;
     long long nfeval, ngeval;
-    // bracket (nrc :80-151)
+    // bracket (nrc :80-151); every trial also yields the slope along the line (it costs no extra
+    // exchange), remembered so that Dbrent's first evaluation at bx need not be repeated
     double ax, bx, cx, fa, fb, fc, u;
+    double sa, sb, sc;
+    bool va, vb, vc;      // slope known at ax / bx / cx
+    int pp_tag;           // pending "value already known" trace record
+    double pp_a, pp_b, pp_c;
     // Brent with derivatives (nrc :284-404)
     double a, b, x, w, v, fx, fw, fv, dx, dw, dv, d, e, uu;
     int it;
@@ -82,13 +89,22 @@ struct CgdMachine {
         finit = 0.0; fp = 0.0; fret = DBL_MAX;
         saw_nan = false; rolled_back = false; nfeval = 0; ngeval = 0;
         ax = bx = cx = fa = fb = fc = u = 0.0;
+        sa = sb = sc = 0.0; va = vb = vc = false;
+        pp_tag = TR_NONE; pp_a = pp_b = pp_c = 0.0;
         a = b = x = w = v = fx = fw = fv = dx = dw = dv = d = e = uu = 0.0;
         it = 0; tiny = false;
     }
     __device__ int status() const { return reason | (rolled_back ? STATUS_ROLLED_BACK : 0); }
 
     __device__ static Request req(int kind, double a = 0.0) {
-        Request r; r.kind = kind; r.a = a; r.restore = false; r.line = false; r.tr_tag = TR_NONE; r.tr_a = r.tr_b = r.tr_c = 0.0;
+        Request r; r.kind = kind; r.a = a; r.restore = false; r.line = false;
+        r.pre_tag = TR_NONE; r.pre_a = r.pre_b = r.pre_c = 0.0;
+        r.tr_tag = TR_NONE; r.tr_a = r.tr_b = r.tr_c = 0.0;
+        return r;
+    }
+    __device__ Request with_pending(Request r) {
+        r.pre_tag = pp_tag; r.pre_a = pp_a; r.pre_b = pp_b; r.pre_c = pp_c;
+        pp_tag = TR_NONE;
         return r;
     }
     __device__ static Request traced(Request r, int tag, double ta, double tb, double tc) {
@@ -131,21 +147,26 @@ struct CgdMachine {
 
             // ---- bracket from (0, 1) ------------------------------------------------
             case S_BR_START:
+                // f at a = 0 is the value the previous line search ended on (or f(x0)): the same
+                // point, hence the same bits -- counted and traced like the reference's call
+                // (nrc :87) but not evaluated again.  Its slope is not known.
                 ax = 0.0; bx = 1.0;
-                st = S_BR_FA;
-                return want_f(ax);
-            case S_BR_FA:
-                fa = r0; if (r0 != r0) saw_nan = true;
+                fa = fp; sa = 0.0; va = false;
+                ++nfeval;
+                pp_tag = TR_F; pp_a = 0.0; pp_b = fp; pp_c = 0.0;
                 st = S_BR_FB;
-                return want_f(bx);
+                return with_pending(want_fd(bx));
             case S_BR_FB:
-                fb = r0; if (r0 != r0) saw_nan = true;
-                if (fb > fa) { double t = ax; ax = bx; bx = t; t = fa; fa = fb; fb = t; }
+                fb = r0; sb = r1; vb = true; if (r0 != r0) saw_nan = true;
+                if (fb > fa) {
+                    double t = ax; ax = bx; bx = t; t = fa; fa = fb; fb = t;
+                    t = sa; sa = sb; sb = t; const bool tv = va; va = vb; vb = tv;
+                }
                 cx = bx + GOLD * (bx - ax);
                 st = S_BR_FC;
-                return want_f(cx);
+                return want_fd(cx);
             case S_BR_FC:
-                fc = r0; if (r0 != r0) saw_nan = true;
+                fc = r0; sc = r1; vc = true; if (r0 != r0) saw_nan = true;
                 st = S_BR_HEAD;
                 break;
             case S_BR_HEAD: {
@@ -155,39 +176,42 @@ struct CgdMachine {
                 const double qr = q - r;
                 u = bx - ((bx - cx) * q - (bx - ax) * r) / (2.0 * copysign(fmax(fabs(qr), TINY), qr));
                 const double ulim = bx + GLIMIT * (cx - bx);
-                if ((bx - u) * (u - cx) > 0.0) { st = S_BR_CASE1; return want_f(u); }
-                if ((cx - u) * (u - ulim) > 0.0) { st = S_BR_CASE2; return want_f(u); }
+                if ((bx - u) * (u - cx) > 0.0) { st = S_BR_CASE1; return want_fd(u); }
+                if ((cx - u) * (u - ulim) > 0.0) { st = S_BR_CASE2; return want_fd(u); }
                 if ((u - ulim) * (ulim - cx) >= 0.0) u = ulim;
                 else u = cx + GOLD * (cx - bx);
                 st = S_BR_SHIFT;
-                return want_f(u);
+                return want_fd(u);
             }
             case S_BR_CASE1: {  // parabolic u between b and c
-                const double fu = r0; if (r0 != r0) saw_nan = true;
-                if (fu < fc) { ax = bx; bx = u; fa = fb; fb = fu; st = S_DB_START; break; }
-                if (fu > fb) { cx = u; fc = fu; st = S_DB_START; break; }
+                const double fu = r0, su = r1; if (r0 != r0) saw_nan = true;
+                if (fu < fc) { ax = bx; bx = u; fa = fb; fb = fu; sa = sb; va = vb; sb = su; vb = true; st = S_DB_START; break; }
+                if (fu > fb) { cx = u; fc = fu; sc = su; vc = true; st = S_DB_START; break; }
                 u = cx + GOLD * (cx - bx);
                 st = S_BR_SHIFT;
-                return want_f(u);
+                return want_fd(u);
             }
             case S_BR_CASE2: {  // parabolic u between c and its limit
-                const double fu = r0; if (r0 != r0) saw_nan = true;
+                const double fu = r0, su = r1; if (r0 != r0) saw_nan = true;
                 if (fu < fc) {
                     const double unew = u + GOLD * (u - cx);
                     bx = cx; cx = u; u = unew;
                     fb = fc; fc = fu;
+                    sb = sc; vb = vc; sc = su; vc = true;
                     st = S_BR_SHIFT;
-                    return want_f(u);
+                    return want_fd(u);
                 }
                 ax = bx; bx = cx; cx = u;
                 fa = fb; fb = fc; fc = fu;
+                sa = sb; va = vb; sb = sc; vb = vc; sc = su; vc = true;
                 st = S_BR_HEAD;
                 break;
             }
             case S_BR_SHIFT: {
-                const double fu = r0; if (r0 != r0) saw_nan = true;
+                const double fu = r0, su = r1; if (r0 != r0) saw_nan = true;
                 ax = bx; bx = cx; cx = u;
                 fa = fb; fb = fc; fc = fu;
+                sa = sb; va = vb; sb = sc; vb = vc; sc = su; vc = true;
                 st = S_BR_HEAD;
                 break;
             }
@@ -198,6 +222,14 @@ struct CgdMachine {
                 b = (ax > cx ? ax : cx);
                 x = w = v = bx;
                 d = 0.0; e = 0.0; it = 0;
+                if (vb) {  // value and slope at bx are known from the bracketing: same point, same bits
+                    ++nfeval; ++ngeval;  // the reference's funcd(x), funcd.df(x) (nrc :314-315)
+                    fx = fb; dx = sb;
+                    fw = fv = fx; dw = dv = dx;
+                    pp_tag = TR_FD; pp_a = x; pp_b = fx; pp_c = dx;
+                    st = S_DB_HEAD;
+                    break;
+                }
                 st = S_DB_FIRST;
                 return want_fd(x);
             case S_DB_FIRST:
@@ -214,7 +246,7 @@ struct CgdMachine {
                 const double tol2 = 2.0 * tol1;
                 if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) {
                     st = S_AFTER_LINMIN;
-                    return traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0);
+                    return with_pending(traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0));
                 }
                 bool bisect = true;
                 if (fabs(e) > tol1) {
@@ -241,7 +273,7 @@ struct CgdMachine {
                 if (fabs(d) >= tol1) { uu = x + d; tiny = false; }
                 else { uu = x + copysign(tol1, d); tiny = true; }
                 st = S_DB_EVAL;
-                return want_fd(uu);
+                return with_pending(want_fd(uu));
             }
             case S_DB_EVAL: {
                 const double fu = r0, du = r1; if (r0 != r0) saw_nan = true;
@@ -329,6 +361,19 @@ struct CgdMachine {
 // steps it (the other waves would compute the same thing); the request is handed to
 // the other waves through a double-buffered LDS slot.  Nothing of the control logic
 // is therefore live in registers across the factor arithmetic.
+// one step of the machine (wave 0 only); the request goes to the other waves through LDS
+__device__ __forceinline__ void step_machine(CgdMachine* M, Request* out, double r0, double r1, double r2) {
+    const Request nq = M->next(r0, r1, r2);
+    if ((threadIdx.x & 63) == 0) *out = nq;
+}
+
+__device__ __forceinline__ double uniform(double v) {  // a wave-uniform value into scalar registers
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <class Env>
 __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Request (&Q)[2] /* LDS */,
                                             int maxiters, double ftol) {
@@ -336,29 +381,35 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
     const bool stepper = threadIdx.x < 64;
     if (stepper) M.init(maxiters, ftol);
     for (int round = 0;; ++round) {
-        if (stepper) {
-            const Request nq = M.next(r0, r1, r2);
-            if (threadIdx.x == 0) Q[round & 1] = nq;
-        }
+        if (stepper) step_machine(&M, &Q[round & 1], r0, r1, r2);
         __syncthreads();
-        const Request q = Q[round & 1];
-        if (q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
-        if (q.kind == REQ_DONE || E.aborted()) break;
-        switch (q.kind) {
+        const Request& q = Q[round & 1];
+        if (E.tracing()) {
+            if (q.pre_tag != TR_NONE) E.trace(q.pre_tag, q.pre_a, q.pre_b, q.pre_c);
+            if (q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
+        }
+        const int kind = __builtin_amdgcn_readfirstlane(q.kind);
+        const double qa = uniform(q.a);
+        if (kind == REQ_DONE || E.aborted()) break;
+        switch (kind) {
         case REQ_F:
-            r0 = E.eval_value(q.a, q.restore);
-            if (q.line) E.trace(TR_F, q.a, r0, 0.0);
+            r0 = uniform(E.eval_value(qa, q.restore));
+            if (q.line) E.trace(TR_F, qa, r0, 0.0);
             break;
         case REQ_FD:
-            E.eval_value_slope(q.a, r0, r1);
-            E.trace(TR_FD, q.a, r0, r1);
+            E.eval_value_slope(qa, r0, r1);
+            r0 = uniform(r0); r1 = uniform(r1);
+            E.trace(TR_FD, qa, r0, r1);
             break;
         case REQ_GRAD: E.gradient_to_xi(); break;
         case REQ_CG_START: E.cg_start(); break;
         case REQ_LINE_BEGIN: E.line_begin(); break;
-        case REQ_LINE_END: E.line_end(q.a); break;
-        case REQ_CG_REDUCE: E.cg_reduce(q.a, r0, r1, r2); break;
-        case REQ_CG_UPDATE: E.cg_update(q.a); break;
+        case REQ_LINE_END: E.line_end(qa); break;
+        case REQ_CG_REDUCE:
+            E.cg_reduce(qa, r0, r1, r2);
+            r0 = uniform(r0); r1 = uniform(r1); r2 = uniform(r2);
+            break;
+        case REQ_CG_UPDATE: E.cg_update(qa); break;
         default: break;
         }
     }

@@ -189,6 +189,7 @@ struct CoopEnv {
             ++trn;
         }
     }
+    __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return dead; }
 
     // ---- evaluation at clamp(base + a*dir), straight from registers ---------------

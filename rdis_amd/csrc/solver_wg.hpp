@@ -202,6 +202,7 @@ struct WgEnv {
         f = af; s = as;
     }
 
+    __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return false; }
     // value at clamp(p + a*xi), or at clamp(x_init) for the rollback (CGD .cpp:71)
     __device__ double eval_value(double a, bool restore) {
