@@ -36,6 +36,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per solver launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE and,
+    in a separate pass, --pmc WRITE_SIZE; KiB units; FETCH doubled per MI355X_MICROARCH.md
+    section HBM), as recorded in profiles/traffic.json by tools/collect_traffic.py for the
+    same bench command.  None when no such record exists for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            rec = json.load(fh).get(workload)
+        return None if rec is None else float(rec["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +215,7 @@ def main():
             "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in
                                       zip(*np.unique(r.status & 0xFF, return_counts=True))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload),
                          "kernel": "cgd solver kernel(s)", "kernel_ms_avg": kms / max(klaunch, 1),
                          "algorithmic_bytes_per_launch": abytes / max(klaunch, 1)},
         }
