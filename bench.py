@@ -130,7 +130,7 @@ def main():
                  f"--nproc-per-node {a.gpus} (WORLD_SIZE is {world})")
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("RDIS_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path on one GPU
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch  # before the HIP library: one HIP runtime per process
         import torch.distributed as dist
@@ -138,7 +138,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rdis_amd import capi
-    ctx = capi.Context(local_rank if world > 1 else 0)
+    ctx = capi.Context(local_rank)
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
 
@@ -221,13 +221,15 @@ def main():
         }
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
-        print(json.dumps(line))
     plan.close()
     prob.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)  # the last line of stdout
 
 
 if __name__ == "__main__":
