@@ -53,7 +53,8 @@ struct PlanView {
     const int* fac_ptr;
     const int* fac_id;
     const int* v2s_ptr;   // [nfree_total + 1]
-    const int* slot_pos;  // [12F | nnz] factor slot -> position in gfac (variable-major), -1 = not a free variable
+    const int* slot_base; // [nfac_total + 1] first slot of each LISTED factor (plan-local: 12 per BA factor, arity per NLP factor)
+    const int* slot_pos;  // [slot_base[nfac_total]] listed factor's slot -> position in gfac (variable-major), -1 = not a free variable
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]
     double* gfac;         // [v2s_ptr[nfree_total]] per-factor partials, variable-major

@@ -31,8 +31,13 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = true;  // false: a slice of the problem's arena
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; }
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -53,6 +58,7 @@ int dalloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 8;
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
+    b.owned = true;
     return 0;
 }
 template <class T>
@@ -83,6 +89,15 @@ struct rdis_hip_problem {
     DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
     DevBuf all_v2s_ptr, all_v2s_idx;  // gather lists for "all factors"
     bool have_all_v2s = false;
+    // shared by the plans of this problem (solves on a context are serialised)
+    DevBuf dir, coop_state, coop_timing;   // search direction by variable id (kept zero between solves), ...
+    DevBuf arena;                          // memory of the transient plan of rdis_hip_cgd_batch
+    size_t arena_used = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct rdis_hip_plan* last_timed_plan = nullptr;
+    std::vector<int> h_owner, h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
+    int stamp = 0;
+    ~rdis_hip_problem() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 
     ProblemView view() const {
         ProblemView v{};
@@ -102,6 +117,7 @@ struct rdis_hip_problem {
     int slot_of(int f, int k) const { return kind == KIND_BA ? 12 * f + k : h_rowptr[f] + k; }
 };
 
+
 struct CoopItem {
     int comp = 0, nwg = 0;
     DevBuf slot_li;   // [12 * m] local free index of each factor slot, -1 = constant
@@ -111,18 +127,24 @@ struct CoopItem {
 
 struct rdis_hip_plan {
     rdis_hip_problem* prob = nullptr;
-    int64_t ncomp = 0, nfree = 0, nfac = 0;
-    int64_t max_fac = 0, max_free = 0;
-    DevBuf order, free_ptr, free_vid, fac_ptr, fac_id, v2s_ptr, slot_pos;
-    DevBuf ws, dir, gfac, xstart, xout, fret, delta, iters, status, nfeval, ngeval, objective;
-    DevBuf trace, trace_n, coop_state, vdump;
+    bool transient = false;  // lives in the problem's arena (rdis_hip_cgd_batch): one at a time
+    int64_t ncomp = 0, nfree = 0, nfac = 0, nslots = 0, ngfac = 0;
+    // one device block of int32 (order | free_ptr | free_vid | fac_ptr | fac_id | v2s_ptr |
+    // slot_base | slot_pos) and one of results (see out_layout)
+    DevBuf ints, ws, gfac, xstart, outbuf, objective, trace, vdump;
+    size_t off_order = 0, off_free_ptr = 0, off_free_vid = 0, off_fac_ptr = 0, off_fac_id = 0, off_v2s_ptr = 0,
+           off_slot_base = 0, off_slot_pos = 0;
+    // results block: xout[nfree] fret[nc] delta[nc] (f64) | nfeval[nc] ngeval[nc] (i64) | iters[nc] status[nc] trace_n[nc] (i32)
+    size_t out_bytes = 0;
+    std::vector<char> h_out;
+    std::vector<int> h_blk;   // host image of `ints` (kept alive: its upload is asynchronous)
     std::vector<int> h_order, h_fac_ptr, h_free_ptr, h_free_vid, h_fac_id, h_v2s_ptr;
     bool have_start = false;
     // which components go where (rebuilt when an option changes)
     bool partition_dirty = true;
     std::vector<CoopItem> coop;
     std::vector<int> h_rest;
-    DevBuf rest_order, xi_glob, coop_timing;
+    DevBuf rest_order, xi_glob;
     // options
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
@@ -130,31 +152,35 @@ struct rdis_hip_plan {
     int coop_workgroups = 0, coop_threads = 256;
     int trace_records = 0;
     int dump_iters = 0;
-    // timing of the last solve
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_launches = 0;
     bool timed = false;
 
+    const int* ip(size_t off) const { return ints.as<int>() + off; }
+    double* out_f64(size_t idx) const { return outbuf.as<double>() + idx; }
     PlanView view() const {
         PlanView v{};
+        const size_t nc = (size_t)ncomp;
         v.ncomp = (int)ncomp;
         v.order = rest_order.as<int>();
-        v.free_ptr = free_ptr.as<int>(); v.free_vid = free_vid.as<int>();
-        v.fac_ptr = fac_ptr.as<int>(); v.fac_id = fac_id.as<int>();
-        v.v2s_ptr = v2s_ptr.as<int>(); v.slot_pos = slot_pos.as<int>();
-        v.ws = ws.as<double>(); v.dir = dir.as<double>(); v.gfac = gfac.as<double>();
-        v.xstart = xstart.as<double>(); v.xout = xout.as<double>();
-        v.fret = fret.as<double>(); v.delta = delta.as<double>();
-        v.iters = iters.as<int>(); v.status = status.as<int>();
-        v.nfeval = nfeval.as<long long>(); v.ngeval = ngeval.as<long long>();
+        v.free_ptr = ip(off_free_ptr); v.free_vid = ip(off_free_vid);
+        v.fac_ptr = ip(off_fac_ptr); v.fac_id = ip(off_fac_id);
+        v.v2s_ptr = ip(off_v2s_ptr); v.slot_base = ip(off_slot_base); v.slot_pos = ip(off_slot_pos);
+        v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
+        v.xstart = xstart.as<double>();
+        v.xout = out_f64(0);
+        v.fret = out_f64((size_t)nfree); v.delta = out_f64((size_t)nfree + nc);
+        long long* i64 = reinterpret_cast<long long*>(out_f64((size_t)nfree + 2 * nc));
+        v.nfeval = i64; v.ngeval = i64 + nc;
+        int* i32 = reinterpret_cast<int*>(i64 + 2 * nc);
+        v.iters = i32; v.status = i32 + nc; v.trace_n = i32 + 2 * nc;
         v.trace = trace_records > 0 ? trace.as<double>() : nullptr;
-        v.trace_n = trace_n.as<int>();
         v.trace_cap = trace_records;
         v.vdump = dump_iters > 0 ? vdump.as<double>() : nullptr;
         v.dump_iters = dump_iters;
         return v;
     }
 };
+
 
 // =====================================================================================
 // context
@@ -513,72 +539,126 @@ extern "C" int rdis_hip_grad_each_ba(rdis_hip_problem* p, int64_t nf, const int6
 // =====================================================================================
 // plans
 // =====================================================================================
-extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const int64_t* free_ptr,
-                                    const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
-                                    rdis_hip_plan** out) {
+
+// =====================================================================================
+// plans
+// =====================================================================================
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// plan memory: a persistent plan owns hipMalloc'ed buffers; a transient one (cgd_batch, i.e.
+// one optimize() call) carves them out of the problem's arena so that a call costs no
+// hipMalloc / hipFree (each of which synchronises the device)
+int plan_alloc(rdis_hip_plan* L, DevBuf& b, size_t bytes) {
+    rdis_hip_problem* p = L->prob;
+    if (!L->transient) return dalloc(p->ctx, b, bytes);
+    b.release();
+    bytes = align_up(std::max<size_t>(bytes, 8), 256);
+    if (p->arena_used + bytes > p->arena.bytes) return fail(p->ctx, RDIS_HIP_ENOMEM, "plan arena exhausted (internal sizing error)");
+    b.p = static_cast<char*>(p->arena.p) + p->arena_used;
+    b.bytes = bytes;
+    b.owned = false;
+    p->arena_used += bytes;
+    return 0;
+}
+
+int ensure_problem_scratch(rdis_hip_problem* p) {
+    rdis_hip_ctx* c = p->ctx;
+    if (!p->dir.p) {
+        int rc = dalloc(c, p->dir, (size_t)p->N * sizeof(double));
+        if (!rc) rc = dalloc(c, p->coop_state, coop_state_bytes());
+        if (!rc) rc = dalloc(c, p->coop_timing, 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(p->dir.p, 0, p->dir.bytes, c->stream));
+        HIPCHK(c, hipEventCreate(&p->ev0));
+        HIPCHK(c, hipEventCreate(&p->ev1));
+        p->h_owner.assign((size_t)p->N, -1);
+        p->h_local.assign((size_t)p->N, -1);
+        p->h_owner_stamp.assign((size_t)p->N, 0);
+        p->h_fac_stamp.assign((size_t)p->F, 0);
+    }
+    return 0;
+}
+
+}  // namespace
+
+static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, const int64_t* free_ptr,
+                            const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
+                            rdis_hip_plan** out) {
     if (!p || !out || ncomp < 0 || !free_ptr || !fac_ptr) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
     *out = nullptr;
     const int64_t nfree = free_ptr[ncomp], nfac = fac_ptr[ncomp];
     if (free_ptr[0] != 0 || fac_ptr[0] != 0 || nfree < 0 || nfac < 0 || (nfree && !free_vid) || (nfac && !fac_id))
         return fail(c, RDIS_HIP_EINVAL, "plan_create: bad CSR");
-    if (nfree >= (1ll << 31) / 5 || nfac >= (1ll << 31) - 16) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
+    if (nfree >= (1ll << 31) / 5 || nfac >= ((1ll << 31) - 16) / 12) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_problem_scratch(p);
+    if (rc) return rc;
 
     rdis_hip_plan* L = new (std::nothrow) rdis_hip_plan;
     if (!L) return fail(c, RDIS_HIP_ENOMEM, "plan_create: host allocation");
     struct Guard { rdis_hip_plan* l; ~Guard() { if (l) rdis_hip_plan_destroy(l); } } guard{L};
-    L->prob = p; L->ncomp = ncomp; L->nfree = nfree; L->nfac = nfac;
+    L->prob = p; L->transient = transient; L->ncomp = ncomp; L->nfree = nfree; L->nfac = nfac;
 
-    // --- validate independence: free sets disjoint, factors owned once, and no
-    // factor of one component reads a free variable of another
-    std::vector<int> owner((size_t)p->N, -1), local((size_t)p->N, -1);
-    std::vector<int> h_free_ptr((size_t)ncomp + 1), h_fac_ptr((size_t)ncomp + 1);
-    std::vector<int> h_free_vid((size_t)nfree), h_fac_id((size_t)nfac);
+    // --- validate independence (free sets disjoint, factors owned once, no factor of one
+    // component reading a free variable of another); owner / local are persistent per-problem
+    // arrays validated by a stamp, so a call costs O(its own size), not O(N)
+    const int stamp = ++p->stamp;
+    auto owner_of = [&](int v) { return p->h_owner_stamp[(size_t)v] == stamp ? p->h_owner[(size_t)v] : -1; };
+    L->h_free_ptr.resize((size_t)ncomp + 1); L->h_fac_ptr.resize((size_t)ncomp + 1);
+    L->h_free_vid.resize((size_t)nfree); L->h_fac_id.resize((size_t)nfac);
     for (int64_t cc = 0; cc <= ncomp; ++cc) {
-        if ((cc && (free_ptr[cc] < free_ptr[cc - 1] || fac_ptr[cc] < fac_ptr[cc - 1])))
+        if (cc && (free_ptr[cc] < free_ptr[cc - 1] || fac_ptr[cc] < fac_ptr[cc - 1]))
             return fail(c, RDIS_HIP_EINVAL, "plan_create: ptr not monotone");
-        h_free_ptr[(size_t)cc] = (int)free_ptr[cc];
-        h_fac_ptr[(size_t)cc] = (int)fac_ptr[cc];
+        L->h_free_ptr[(size_t)cc] = (int)free_ptr[cc];
+        L->h_fac_ptr[(size_t)cc] = (int)fac_ptr[cc];
     }
     for (int64_t cc = 0; cc < ncomp; ++cc)
         for (int64_t i = free_ptr[cc]; i < free_ptr[cc + 1]; ++i) {
             const int64_t v = free_vid[i];
             if (v < 0 || v >= p->N) return fail(c, RDIS_HIP_EINVAL, "plan_create: free variable id out of range");
-            if (owner[(size_t)v] != -1) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: variable " + std::to_string(v) + " is free in two components (or listed twice)");
-            owner[(size_t)v] = (int)cc;
-            local[(size_t)v] = (int)(i - free_ptr[cc]);
-            h_free_vid[(size_t)i] = (int)v;
+            if (owner_of((int)v) != -1) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: variable " + std::to_string(v) + " is free in two components (or listed twice)");
+            p->h_owner_stamp[(size_t)v] = stamp;
+            p->h_owner[(size_t)v] = (int)cc;
+            p->h_local[(size_t)v] = (int)(i - free_ptr[cc]);
+            L->h_free_vid[(size_t)i] = (int)v;
         }
-    std::vector<char> fac_seen((size_t)p->F, 0);
-    std::vector<int> v2s_ptr((size_t)nfree + 1, 0);
+    std::vector<int>& v2s_ptr = L->h_v2s_ptr;
+    v2s_ptr.assign((size_t)nfree + 1, 0);
+    std::vector<int> slot_base((size_t)nfac + 1, 0);
     for (int64_t cc = 0; cc < ncomp; ++cc)
         for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
             const int64_t f = fac_id[j];
             if (f < 0 || f >= p->F) return fail(c, RDIS_HIP_EINVAL, "plan_create: factor id out of range");
-            if (fac_seen[(size_t)f]) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " listed twice");
-            fac_seen[(size_t)f] = 1;
-            h_fac_id[(size_t)j] = (int)f;
-            for (int k = 0, a = p->arity((int)f); k < a; ++k) {
+            if (p->h_fac_stamp[(size_t)f] == stamp) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " listed twice");
+            p->h_fac_stamp[(size_t)f] = stamp;
+            L->h_fac_id[(size_t)j] = (int)f;
+            const int a = p->arity((int)f);
+            slot_base[(size_t)j + 1] = slot_base[(size_t)j] + a;
+            for (int k = 0; k < a; ++k) {
                 const int v = p->var_of((int)f, k);
-                const int o = owner[(size_t)v];
+                const int o = owner_of(v);
                 if (o == -1) continue;  // a constant for this solve
                 if (o != (int)cc) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " of component " + std::to_string(cc) + " reads a free variable of component " + std::to_string(o));
-                ++v2s_ptr[(size_t)(free_ptr[cc] + local[(size_t)v]) + 1];
+                ++v2s_ptr[(size_t)(free_ptr[cc] + p->h_local[(size_t)v]) + 1];
             }
         }
     for (int64_t i = 0; i < nfree; ++i) v2s_ptr[(size_t)i + 1] += v2s_ptr[(size_t)i];
-    // gfac is variable-major: slot_pos[s] = where factor slot s lands in it (-1: not free here)
-    std::vector<int> slot_pos((size_t)p->nslots(), -1);
+    L->nslots = slot_base[(size_t)nfac];
+    L->ngfac = v2s_ptr[(size_t)nfree];
+    // gfac is variable-major: slot_pos[s] = where listed factor slot s lands in it (-1: not free here)
+    std::vector<int> slot_pos((size_t)L->nslots, -1);
     {
         std::vector<int> fill(v2s_ptr.begin(), v2s_ptr.end() - 1);
         for (int64_t cc = 0; cc < ncomp; ++cc)
             for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
-                const int f = h_fac_id[(size_t)j];
+                const int f = L->h_fac_id[(size_t)j];
                 for (int k = 0, a = p->arity(f); k < a; ++k) {
                     const int v = p->var_of(f, k);
-                    if (owner[(size_t)v] != (int)cc) continue;
-                    slot_pos[(size_t)p->slot_of(f, k)] = fill[(size_t)(free_ptr[cc] + local[(size_t)v])]++;
+                    if (owner_of(v) != (int)cc) continue;
+                    slot_pos[(size_t)slot_base[(size_t)j] + k] = fill[(size_t)(free_ptr[cc] + p->h_local[(size_t)v])]++;
                 }
             }
     }
@@ -588,52 +668,56 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
     std::stable_sort(L->h_order.begin(), L->h_order.end(), [&](int a, int b) {
         return (fac_ptr[a + 1] - fac_ptr[a]) > (fac_ptr[b + 1] - fac_ptr[b]);
     });
-    for (int64_t cc = 0; cc < ncomp; ++cc) {
-        L->max_fac = std::max(L->max_fac, fac_ptr[cc + 1] - fac_ptr[cc]);
-        L->max_free = std::max(L->max_free, free_ptr[cc + 1] - free_ptr[cc]);
-    }
-    L->h_fac_ptr = h_fac_ptr; L->h_free_ptr = h_free_ptr;
-    L->h_free_vid = h_free_vid; L->h_fac_id = h_fac_id; L->h_v2s_ptr = v2s_ptr;
 
-    int rc = 0;
-    if (!rc) rc = upload(c, L->order, L->h_order);
-    if (!rc) rc = upload(c, L->free_ptr, h_free_ptr);
-    if (!rc) rc = upload(c, L->free_vid, h_free_vid);
-    if (!rc) rc = upload(c, L->fac_ptr, h_fac_ptr);
-    if (!rc) rc = upload(c, L->fac_id, h_fac_id);
-    if (!rc) rc = upload(c, L->v2s_ptr, v2s_ptr);
-    if (!rc) rc = upload(c, L->slot_pos, slot_pos);
-    if (!rc) rc = dalloc(c, L->ws, (size_t)(5 * nfree) * sizeof(double));
-    if (!rc) rc = dalloc(c, L->dir, (size_t)p->N * sizeof(double));
-    if (!rc) rc = dalloc(c, L->gfac, (size_t)v2s_ptr[(size_t)nfree] * sizeof(double));
-    if (!rc) rc = dalloc(c, L->xstart, (size_t)nfree * sizeof(double));
-    if (!rc) rc = dalloc(c, L->xout, (size_t)nfree * sizeof(double));
-    if (!rc) rc = dalloc(c, L->fret, (size_t)ncomp * sizeof(double));
-    if (!rc) rc = dalloc(c, L->delta, (size_t)ncomp * sizeof(double));
-    if (!rc) rc = dalloc(c, L->iters, (size_t)ncomp * sizeof(int));
-    if (!rc) rc = dalloc(c, L->status, (size_t)ncomp * sizeof(int));
-    if (!rc) rc = dalloc(c, L->nfeval, (size_t)ncomp * sizeof(long long));
-    if (!rc) rc = dalloc(c, L->ngeval, (size_t)ncomp * sizeof(long long));
-    if (!rc) rc = dalloc(c, L->trace_n, (size_t)ncomp * sizeof(int));
-    if (!rc) rc = dalloc(c, L->objective, 64);
-    if (!rc) rc = dalloc(c, L->coop_state, coop_state_bytes());
-    if (!rc) rc = dalloc(c, L->coop_timing, 256);
+    // --- one int32 block, one H2D copy
+    std::vector<int>& blk = L->h_blk;
+    auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
+    L->off_order = put(L->h_order);
+    L->off_free_ptr = put(L->h_free_ptr); L->off_free_vid = put(L->h_free_vid);
+    L->off_fac_ptr = put(L->h_fac_ptr); L->off_fac_id = put(L->h_fac_id);
+    L->off_v2s_ptr = put(v2s_ptr); L->off_slot_base = put(slot_base); L->off_slot_pos = put(slot_pos);
+
+    const size_t nc = (size_t)ncomp;
+    L->out_bytes = ((size_t)nfree + 2 * nc) * 8 + 2 * nc * 8 + 3 * nc * 4;
+    if (transient) {
+        // everything this call can need, including what prepare_partition adds for the cooperative solver
+        const size_t lanes_max = (size_t)COOP_MAX_WG * 512;
+        size_t need = 4096 + 16 * 256;
+        need += align_up(blk.size() * 4, 256) + align_up((size_t)(5 * nfree) * 8, 256) + align_up((size_t)L->ngfac * 8, 256);
+        need += align_up((size_t)nfree * 8, 256) + align_up(L->out_bytes, 256) + 256;
+        need += align_up(nc * 4, 256) + align_up((size_t)nfree * 8, 256);                       // rest_order, xi_glob
+        need += (size_t)std::min<int64_t>(ncomp, 8) * (align_up(lanes_max * 4, 256) + align_up(lanes_max / 64 * 4, 256));
+        need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
+        if (p->arena.bytes < need) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rc = dalloc(c, p->arena, std::max(need, 2 * p->arena.bytes));
+            if (rc) return rc;
+        }
+        p->arena_used = 0;
+    }
+    rc = plan_alloc(L, L->ints, blk.size() * sizeof(int));
+    if (!rc) rc = plan_alloc(L, L->ws, (size_t)(5 * nfree) * sizeof(double));
+    if (!rc) rc = plan_alloc(L, L->gfac, (size_t)L->ngfac * sizeof(double));
+    if (!rc) rc = plan_alloc(L, L->xstart, (size_t)nfree * sizeof(double));
+    if (!rc) rc = plan_alloc(L, L->outbuf, L->out_bytes);
+    if (!rc) rc = plan_alloc(L, L->objective, 64);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(L->dir.p, 0, L->dir.bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(L->coop_state.p, 0, L->coop_state.bytes, c->stream));
-    HIPCHK(c, hipEventCreate(&L->ev0));
-    HIPCHK(c, hipEventCreate(&L->ev1));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    L->h_out.resize(L->out_bytes);
+    if (!blk.empty()) HIPCHK(c, hipMemcpyAsync(L->ints.p, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     guard.l = nullptr;
     *out = L;
     return 0;
 }
 
+extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const int64_t* free_ptr,
+                                    const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
+                                    rdis_hip_plan** out) {
+    return plan_create_impl(p, false, ncomp, free_ptr, free_vid, fac_ptr, fac_id, out);
+}
+
 extern "C" void rdis_hip_plan_destroy(rdis_hip_plan* L) {
     if (!L) return;
-    if (L->prob) (void)hipStreamSynchronize(L->prob->ctx->stream);
-    if (L->ev0) (void)hipEventDestroy(L->ev0);
-    if (L->ev1) (void)hipEventDestroy(L->ev1);
+    if (L->prob && !L->transient) (void)hipStreamSynchronize(L->prob->ctx->stream);
     delete L;
 }
 
@@ -642,10 +726,11 @@ extern "C" int rdis_hip_plan_set_start(rdis_hip_plan* L, const double* xs) {
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->nfree == 0) { L->have_start = true; return 0; }
     if (xs) {
+        // pageable source: the copy is staged by the runtime before the call returns
         HIPCHK(c, hipMemcpyAsync(L->xstart.p, xs, (size_t)L->nfree * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!L->transient) HIPCHK(c, hipStreamSynchronize(c->stream));
     } else {
-        gather_x_kernel<<<grid_for(c, L->nfree, 256), 256, 0, c->stream>>>((int)L->nfree, L->free_vid.as<int>(), L->prob->x.as<double>(), L->xstart.as<double>());
+        gather_x_kernel<<<grid_for(c, L->nfree, 256), 256, 0, c->stream>>>((int)L->nfree, L->ip(L->off_free_vid), L->prob->x.as<double>(), L->xstart.as<double>());
         HIPCHK(c, hipGetLastError());
     }
     L->have_start = true;
@@ -674,6 +759,7 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->coop_threads = (int)value;
     } else if (n == "trace_records") {
         if (value < 0 || value > (1 << 22)) return fail(c, RDIS_HIP_EINVAL, "trace_records out of range");
+        if (L->transient && value) return fail(c, RDIS_HIP_EINVAL, "tracing needs a persistent plan");
         L->trace_records = (int)value;
         if (value > 0) {
             int rc = dalloc(c, L->trace, (size_t)L->ncomp * (size_t)value * 4 * sizeof(double));
@@ -681,6 +767,7 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         }
     } else if (n == "dump_iters") {
         if (value < 0 || value > 4096 || (double)value * 2.0 * (double)L->nfree > 4e9) return fail(c, RDIS_HIP_EINVAL, "dump_iters out of range");
+        if (L->transient && value) return fail(c, RDIS_HIP_EINVAL, "vector dumps need a persistent plan");
         L->dump_iters = (int)value;
         if (value > 0) {
             int rc = dalloc(c, L->vdump, (size_t)value * 2 * (size_t)L->nfree * sizeof(double));
@@ -702,11 +789,11 @@ int prepare_partition(rdis_hip_plan* L) {
     L->coop.clear();
     L->h_rest.clear();
     int cap = 0;
-    if (p->kind == KIND_BA && L->coop_min_factors > 0 && L->coop_max_components > 0)
+    if (p->kind == KIND_BA && L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors)
         cap = coop_max_workgroups(L->coop_threads, c->num_cus);
     if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
     int64_t max_n = 0;
-    std::vector<int> local((size_t)p->N, -1);
+    std::vector<int> blk_all;
     for (int cc : L->h_order) {  // heaviest first
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
@@ -718,13 +805,20 @@ int prepare_partition(rdis_hip_plan* L) {
         it.comp = cc;
         it.nwg = (int)std::max<int64_t>(need, 1);
         const int f0 = L->h_free_ptr[(size_t)cc], c0 = L->h_fac_ptr[(size_t)cc];
-        for (int64_t i = 0; i < n; ++i) local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = (int)i;
+        // local free index of each factor slot (h_local is still valid for this plan's stamp only
+        // while no other plan was created in between: rebuild it for the component)
+        for (int64_t i = 0; i < n; ++i) p->h_local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = (int)i;
+        std::vector<char> is_free_here;  // via a per-call marker: stamp the component's variables
+        const int stamp = ++p->stamp;
+        for (int64_t i = 0; i < n; ++i) p->h_owner_stamp[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = stamp;
         std::vector<int> sl((size_t)(12 * m));
         for (int64_t j = 0; j < m; ++j) {
             const int f = L->h_fac_id[(size_t)(c0 + j)];
-            for (int k = 0; k < 12; ++k) sl[(size_t)(12 * j + k)] = local[(size_t)p->var_of(f, k)];
+            for (int k = 0; k < 12; ++k) {
+                const int v = p->var_of(f, k);
+                sl[(size_t)(12 * j + k)] = p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1;
+            }
         }
-        for (int64_t i = 0; i < n; ++i) local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = -1;
         // owners of the CG recurrence: a lane per variable, a whole wave for variables fed by
         // many partials (longest first), see solver_coop.hpp
         const int lanes = it.nwg * L->coop_threads, waves = lanes / 64;
@@ -738,17 +832,20 @@ int prepare_partition(rdis_hip_plan* L) {
         std::vector<char> wave_owned((size_t)n, 0);
         for (size_t k = 0; k < longv.size() && (int)k < waves; ++k) { wave_var[k] = longv[k]; wave_owned[(size_t)longv[k]] = 1; }
         for (int64_t i = 0; i < n; ++i) if (!wave_owned[(size_t)i]) lane_var[(size_t)i] = (int)i;
-        int rc = upload(c, it.slot_li, sl);
-        if (!rc) rc = upload(c, it.lane_var, lane_var);
-        if (!rc) rc = upload(c, it.wave_var, wave_var);
+        int rc = plan_alloc(L, it.slot_li, sl.size() * sizeof(int));
+        if (!rc) rc = plan_alloc(L, it.lane_var, lane_var.size() * sizeof(int));
+        if (!rc) rc = plan_alloc(L, it.wave_var, wave_var.size() * sizeof(int));
         if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpyAsync(it.slot_li.p, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(it.lane_var.p, lane_var.data(), lane_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(it.wave_var.p, wave_var.data(), wave_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // locals
         max_n = std::max(max_n, n);
     }
-    int rc = upload(c, L->rest_order, L->h_rest);
-    if (!rc && max_n > 0) rc = dalloc(c, L->xi_glob, (size_t)max_n * sizeof(double));
+    int rc = plan_alloc(L, L->rest_order, std::max<size_t>(L->h_rest.size(), 1) * sizeof(int));
+    if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!L->h_rest.empty()) HIPCHK(c, hipMemcpyAsync(L->rest_order.p, L->h_rest.data(), L->h_rest.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     L->partition_dirty = false;
     return 0;
 }
@@ -772,7 +869,8 @@ int launch_wg(rdis_hip_plan* L, int threads, int grid, int maxiters, double ftol
 
 extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ftol) {
     if (!L || maxiters <= 0) return RDIS_HIP_EINVAL;
-    rdis_hip_ctx* c = L->prob->ctx;
+    rdis_hip_problem* p = L->prob;
+    rdis_hip_ctx* c = p->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (!L->have_start) { int rc = rdis_hip_plan_set_start(L, nullptr); if (rc) return rc; }
     L->last_launches = 0;
@@ -783,12 +881,12 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     // launch each; everything else is one batched launch, one workgroup per component
     if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
     PlanView V = L->view();
-    HIPCHK(c, hipEventRecord(L->ev0, c->stream));
+    HIPCHK(c, hipEventRecord(p->ev0, c->stream));
     for (size_t i = 0; i < L->coop.size(); ++i) {
         const CoopItem& it = L->coop[i];
-        CoopArgs ca{L->coop_timing.as<long long>(), L->coop_state.as<CoopState>(), it.slot_li.as<int>(),
+        CoopArgs ca{p->coop_timing.as<long long>(), p->coop_state.as<CoopState>(), it.slot_li.as<int>(),
                     it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp};
-        int rc = launch_coop(c->stream, L->prob->kind, L->prob->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
+        int rc = launch_coop(c->stream, p->kind, p->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
@@ -800,14 +898,15 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
                                                 (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
         int threads = L->block_threads;
         if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 2048 ? 512 : 1024;
-        int rc = L->prob->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
-                                          : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
+        int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
+                                    : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
     }
-    HIPCHK(c, hipEventRecord(L->ev1, c->stream));
+    HIPCHK(c, hipEventRecord(p->ev1, c->stream));
     L->timed = true;
-    objective_sum_kernel<<<1, 256, 0, c->stream>>>((int)L->ncomp, L->fret.as<double>(), L->objective.as<double>());
+    p->last_timed_plan = L;
+    objective_sum_kernel<<<1, 256, 0, c->stream>>>((int)L->ncomp, V.fret, L->objective.as<double>());
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -816,17 +915,23 @@ extern "C" int rdis_hip_plan_fetch(rdis_hip_plan* L, double* x_out, double* fret
                                    int32_t* status, int64_t* nfeval, int64_t* ngeval) {
     if (!L) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
-    auto cp = [&](void* dst, const DevBuf& b, size_t bytes) -> hipError_t {
-        return (dst && bytes) ? hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
-    };
-    HIPCHK(c, cp(x_out, L->xout, (size_t)L->nfree * sizeof(double)));
-    HIPCHK(c, cp(fret, L->fret, (size_t)L->ncomp * sizeof(double)));
-    HIPCHK(c, cp(delta, L->delta, (size_t)L->ncomp * sizeof(double)));
-    HIPCHK(c, cp(iters, L->iters, (size_t)L->ncomp * sizeof(int)));
-    HIPCHK(c, cp(status, L->status, (size_t)L->ncomp * sizeof(int)));
-    HIPCHK(c, cp(nfeval, L->nfeval, (size_t)L->ncomp * sizeof(long long)));
-    HIPCHK(c, cp(ngeval, L->ngeval, (size_t)L->ncomp * sizeof(long long)));
+    const size_t nc = (size_t)L->ncomp, nf = (size_t)L->nfree;
+    if (L->out_bytes == 0) return 0;
+    // one D2H copy of the whole results block (x first: skipped when not wanted)
+    const size_t skip = x_out ? 0 : nf * 8;
+    HIPCHK(c, hipMemcpyAsync(L->h_out.data() + skip, static_cast<char*>(L->outbuf.p) + skip, L->out_bytes - skip,
+                             hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char* h = L->h_out.data();
+    if (x_out) std::memcpy(x_out, h, nf * 8);
+    if (fret) std::memcpy(fret, h + nf * 8, nc * 8);
+    if (delta) std::memcpy(delta, h + (nf + nc) * 8, nc * 8);
+    const char* i64 = h + (nf + 2 * nc) * 8;
+    if (nfeval) std::memcpy(nfeval, i64, nc * 8);
+    if (ngeval) std::memcpy(ngeval, i64 + nc * 8, nc * 8);
+    const char* i32 = i64 + 2 * nc * 8;
+    if (iters) std::memcpy(iters, i32, nc * 4);
+    if (status) std::memcpy(status, i32 + nc * 4, nc * 4);
     return 0;
 }
 
@@ -838,13 +943,14 @@ extern "C" int rdis_hip_plan_objective_device(rdis_hip_plan* L, void** dev_ptr) 
 
 extern "C" int rdis_hip_plan_last_kernel_ms(rdis_hip_plan* L, double* ms, int32_t* launches) {
     if (!L || !ms) return RDIS_HIP_EINVAL;
-    rdis_hip_ctx* c = L->prob->ctx;
+    rdis_hip_problem* p = L->prob;
+    rdis_hip_ctx* c = p->ctx;
     *ms = 0.0;
     if (launches) *launches = L->last_launches;
-    if (!L->timed) return 0;
-    HIPCHK(c, hipEventSynchronize(L->ev1));
+    if (!L->timed || p->last_timed_plan != L) return 0;  // the events belong to the problem's last solve
+    HIPCHK(c, hipEventSynchronize(p->ev1));
     float t = 0.f;
-    HIPCHK(c, hipEventElapsedTime(&t, L->ev0, L->ev1));
+    HIPCHK(c, hipEventElapsedTime(&t, p->ev0, p->ev1));
     *ms = t;
     return 0;
 }
@@ -854,7 +960,7 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->trace_records <= 0) { *nrec = 0; return 0; }
     int n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, L->trace_n.as<int>() + comp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n, L->view().trace_n + comp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nrec = n;
     const int64_t k = std::min<int64_t>(std::min<int64_t>(n, L->trace_records), cap);
@@ -868,7 +974,7 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
 extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out8) {
     if (!L || !out8) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
-    HIPCHK(c, hipMemcpyAsync(out8, L->coop_timing.p, 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out8, L->prob->coop_timing.p, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -887,12 +993,14 @@ extern "C" int rdis_hip_plan_get_vectors(rdis_hip_plan* L, int64_t comp, double*
     return 0;
 }
 
+// one optimize() call: a transient plan in the problem's arena -- no hipMalloc / hipFree, one
+// H2D copy of the decomposition, one of the start, the launch(es), one D2H copy of the results
 extern "C" int rdis_hip_cgd_batch(rdis_hip_problem* p, int64_t ncomp, const int64_t* free_ptr,
                                   const int64_t* free_vid, const int64_t* fac_ptr, const int64_t* fac_id,
                                   double* x_inout, int32_t maxiters, double ftol, double* fret, double* delta,
                                   int32_t* iters, int32_t* status, int64_t* nfeval, int64_t* ngeval) {
     rdis_hip_plan* L = nullptr;
-    int rc = rdis_hip_plan_create(p, ncomp, free_ptr, free_vid, fac_ptr, fac_id, &L);
+    int rc = plan_create_impl(p, true, ncomp, free_ptr, free_vid, fac_ptr, fac_id, &L);
     if (rc) return rc;
     rc = rdis_hip_plan_set_start(L, x_inout);
     if (!rc) rc = rdis_hip_plan_solve(L, maxiters, ftol);

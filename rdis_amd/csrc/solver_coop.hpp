@@ -76,7 +76,7 @@ struct CoopEnv {
     const ProblemView& P;
     const PlanView& L;
     const CoopArgs& A;
-    int n, m, f0;
+    int n, m, f0, c0;
     int gt, tid, nwg, wg;     // global lane, lane in workgroup, #workgroups, my workgroup
     double (*red)[COOP_K][MAX_WAVES];  // LDS block-reduce scratch [2][K][waves]
     double* bcast;                     // LDS [2][4]
@@ -268,7 +268,7 @@ struct CoopEnv {
 #pragma unroll
             for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
             ba_eval_grad(v, ox, oy, g);
-            const int* sp = L.slot_pos + 12ll * fid;
+            const int* sp = L.slot_pos + L.slot_base[c0 + gt];
 #pragma unroll
             for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) L.gfac[t] = g[k]; }
         }
@@ -367,7 +367,7 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
 
-    CoopEnv E{P, L, A, n, m, f0, gt, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x,
+    CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x,
               red, bcast, 0, 0u, false,
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
               gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}, {}};

@@ -89,11 +89,11 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
 }
 
 // per-factor partials into their gradient slots.  Slot id: BA 12*fid + k, NLP the CSR
-// position; with slot_pos the partial of slot s goes to gfac[slot_pos[s]] (variable-major,
-// skipped when negative), without it to gfac[s].
+// position.  With sp (this factor's row of PlanView::slot_pos) partial k goes to gfac[sp[k]]
+// (variable-major, skipped when negative); without it to gfac[global slot id].
 template <int KIND>
 __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __restrict__ gfac,
-                                                const int* __restrict__ slot_pos, int fid) {
+                                                const int* __restrict__ sp, int fid) {
     if constexpr (KIND == KIND_BA) {
         const int c = P.cam[fid], q = P.pt[fid];
         const double2 o = P.obs[fid];
@@ -103,8 +103,7 @@ __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
         ba_eval_grad(v, o.x, o.y, g);
-        if (slot_pos) {
-            const int* sp = slot_pos + 12ll * fid;
+        if (sp) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) gfac[t] = g[k]; }
         } else {
@@ -125,7 +124,7 @@ __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __
                     d *= nlp_term(xv, P.expo[j], P.cons[j], P.sine[j] != 0);
                 }
             }
-            const int t = slot_pos ? slot_pos[k] : k;
+            const int t = sp ? sp[k - b] : k;
             if (t >= 0) gfac[t] = d * P.coeff[fid];
         }
     }
@@ -136,7 +135,7 @@ template <int KIND>
 struct WgEnv {
     const ProblemView& P;
     const PlanView& L;
-    int comp, n, m, tid, nt, nwaves;
+    int comp, n, m, fac0, tid, nt, nwaves;
     const int* fv;    // free variable ids of this component
     const int* fl;    // factor ids of this component
     const int* vptr;  // v2s_ptr + free offset
@@ -226,7 +225,7 @@ struct WgEnv {
         assign_vec(p);
         for (int j = tid; j < m; j += nt) {
             const int fid = fl[j];
-            factor_partials<KIND>(P, L.gfac, L.slot_pos, fid);
+            factor_partials<KIND>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
         }
         __syncthreads();
         for (int i = tid; i < n; i += nt) {
@@ -307,7 +306,7 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
     }
 
     double* ws = L.ws + 5ll * f0;
-    WgEnv<KIND> E{P, L, comp, n, m, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
+    WgEnv<KIND> E{P, L, comp, n, m, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
                   L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                   ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
                   red, 0,
@@ -319,7 +318,10 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
     run_machine(E, M, Q, maxiters, ftol);
     // assign gdmin.p with sanitisation (.cpp:61); after a rollback x already holds clamp(x_init)
     if (!M.rolled_back) E.assign_vec(E.p);
-    for (int i = E.tid; i < n; i += E.nt) L.xout[f0 + i] = P.x[E.fv[i]];
+    for (int i = E.tid; i < n; i += E.nt) {
+        L.xout[f0 + i] = P.x[E.fv[i]];
+        L.dir[E.fv[i]] = 0.0;  // dir is shared by all plans of the problem: leave it zero
+    }
     if (E.tid == 0) {
         L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
         L.status[comp] = M.status(); L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
