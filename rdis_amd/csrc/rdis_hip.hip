@@ -149,7 +149,7 @@ struct rdis_hip_plan {
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
     int coop_max_components = 8;      // ... for at most this many components per plan
-    int coop_workgroups = 0, coop_threads = 256;
+    int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     int trace_records = 0;
     int dump_iters = 0;
     int last_launches = 0;
@@ -568,7 +568,7 @@ int ensure_problem_scratch(rdis_hip_problem* p) {
     if (!p->dir.p) {
         int rc = dalloc(c, p->dir, (size_t)p->N * sizeof(double));
         if (!rc) rc = dalloc(c, p->coop_state, coop_state_bytes());
-        if (!rc) rc = dalloc(c, p->coop_timing, 64);
+        if (!rc) rc = dalloc(c, p->coop_timing, 128);
         if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(p->dir.p, 0, p->dir.bytes, c->stream));
         HIPCHK(c, hipEventCreate(&p->ev0));
@@ -757,6 +757,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_threads") {
         if (value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 128, 256 or 512");
         L->coop_threads = (int)value;
+    } else if (n == "coop_poll_delay") {
+        if (value < 0 || value > 1024) return fail(c, RDIS_HIP_EINVAL, "coop_poll_delay out of range");
+        L->coop_poll_delay = (int)value;
     } else if (n == "trace_records") {
         if (value < 0 || value > (1 << 22)) return fail(c, RDIS_HIP_EINVAL, "trace_records out of range");
         if (L->transient && value) return fail(c, RDIS_HIP_EINVAL, "tracing needs a persistent plan");
@@ -885,7 +888,7 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     for (size_t i = 0; i < L->coop.size(); ++i) {
         const CoopItem& it = L->coop[i];
         CoopArgs ca{p->coop_timing.as<long long>(), p->coop_state.as<CoopState>(), it.slot_li.as<int>(),
-                    it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp};
+                    it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp, L->coop_poll_delay};
         int rc = launch_coop(c->stream, p->kind, p->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
@@ -974,7 +977,7 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
 extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out8) {
     if (!L || !out8) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
-    HIPCHK(c, hipMemcpyAsync(out8, L->prob->coop_timing.p, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out8, L->prob->coop_timing.p, 96, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

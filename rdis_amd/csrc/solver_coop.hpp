@@ -64,6 +64,7 @@ struct CoopArgs {
     const int* wave_var;   // [nwg * threads / 64]: free variable owned by this wave or -1
     double* xi_glob;       // [n] published search direction
     int comp;
+    int poll_delay;        // x64 cycles between publishing and the first sweep (a store needs about that long to land)
 };
 
 // the CG recurrence of one free variable
@@ -92,7 +93,7 @@ struct CoopEnv {
     double ox, oy;
     VarState lv;   // lane-owned variable
     VarState wv;   // wave-owned variable (identical in all 64 lanes)
-    long long tm[8];  // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
+    long long tm[12]; // cycles (8: state-machine step, 9: hand-over of the request): 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
                       // 5 #exchanges, 6 #sweeps, 7 whole kernel
 
     // ---- inter-workgroup exchange ------------------------------------------------
@@ -132,24 +133,40 @@ struct CoopEnv {
             unsigned spins = 0;
             bool ok = !dead;
             const int per = (nwg + 63) >> 6;
+            for (int d = 0; d < A.poll_delay; d += 8) __builtin_amdgcn_s_sleep(8);
             while (!dead) {
-                ok = true;
                 ++tm[6];
+                // every load of the sweep is in flight before the first one is looked at: one
+                // memory round trip per sweep (a lane's out-of-range slots read granule 0)
+                constexpr int PER = COOP_MAX_WG / 64;
+                unsigned long long va[PER], vb[PER], vm[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    if (j < per) {
+                        const int ww = lane + (j << 6);
+                        const int wc = ww < nwg ? ww : 0;
+                        va[j] = __hip_atomic_load(gran(buf, 0, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vb[j] = __hip_atomic_load(gran(buf, 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vm[j] = __hip_atomic_load(gran(buf, 2, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                ok = true;
                 sa = 0.0; sb = 0.0; sm = 0.0;
-                for (int j = 0; j < per; ++j) {
-                    const int ww = lane + (j << 6);
-                    if (ww < nwg) {
-                        const unsigned long long va = __hip_atomic_load(gran(buf, 0, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long vb = __hip_atomic_load(gran(buf, 1, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long vm = __hip_atomic_load(gran(buf, 2, ww), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && va != COOP_SENTINEL && vb != COOP_SENTINEL && vm != COOP_SENTINEL;
-                        sa += __longlong_as_double(va); sb += __longlong_as_double(vb);
-                        sm = fmax(sm, __longlong_as_double(vm));
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    if (j < per) {
+                        ok = ok && va[j] != COOP_SENTINEL && vb[j] != COOP_SENTINEL && vm[j] != COOP_SENTINEL;
+                        if (lane + (j << 6) < nwg) {
+                            sa += __longlong_as_double(va[j]); sb += __longlong_as_double(vb[j]);
+                            sm = fmax(sm, __longlong_as_double(vm[j]));
+                        }
                     }
                 }
                 if (__all(ok)) break;
-                if (++spins > COOP_SPIN_LIMIT ||
-                    __hip_atomic_load((gu32*)&A.st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ++spins;
+                if (spins > COOP_SPIN_LIMIT ||
+                    ((spins & 255u) == 0u &&
+                     __hip_atomic_load((gu32*)&A.st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     if (lane == 0) __hip_atomic_store((gu32*)&A.st->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = false;
                     break;
@@ -191,6 +208,7 @@ struct CoopEnv {
     }
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return dead; }
+    __device__ void tick(int slot, long long dt) { tm[slot] += dt; }
 
     // ---- evaluation at clamp(base + a*dir), straight from registers ---------------
     template <bool SLOPE>
@@ -391,7 +409,7 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
         L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
         E.tm[7] = clock64() - tk0;
-        if (A.timing) for (int i = 0; i < 8; ++i) A.timing[i] = E.tm[i];
+        if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.tm[i];
     }
 }
 

@@ -7,7 +7,7 @@ from oracle import oracle as O
 ctx = capi.Context(0)
 pp = P.load_bal().single_component()
 g = capi.Problem(ctx, pp)
-for opts in [{"coop_threads": 256}, {"coop_threads": 512}, {"coop_threads": 128}, {"coop_min_factors": 0}]:
+for opts in [{"coop_poll_delay": d} for d in (12, 16, 20)]:
     plan = capi.Plan(g)
     for k, v in opts.items():
         plan.set_option(k, v)
@@ -21,6 +21,7 @@ for opts in [{"coop_threads": 256}, {"coop_threads": 512}, {"coop_threads": 128}
         tm = plan.debug_counters()
         nx = max(int(tm[5]), 1)
         print("   total ticks %d => %.1f MHz tick rate; accounted %.0f%%" % (tm[7], tm[7] / (ms * 1e3), 100.0 * tm[:5].sum() / max(tm[7], 1)))
+        print("   state machine step %.0f, hand-over %.0f cycles per exchange" % (tm[8] / nx, tm[9] / nx))
         print("   cycles/exchange: compute %.0f local-reduce %.0f publish %.0f sweep %.0f tail %.0f | exchanges %d sweeps %d (%.1f per exchange)" % (
             tm[0] / nx, tm[1] / nx, tm[2] / nx, tm[3] / nx, tm[4] / nx, tm[5], tm[6], tm[6] / nx))
     plan.close()
