@@ -430,9 +430,9 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
     const bool stepper = threadIdx.x < 64;
     if (stepper) M.init(maxiters, ftol);
     for (int round = 0;; ++round) {
-        const long long ts0 = clock64();
+        const long long ts0 = E.clock();
         if (stepper) step_machine(&M, &Q[round & 1], r0, r1, r2);
-        const long long ts1 = clock64();
+        const long long ts1 = E.clock();
         __syncthreads();
         const Request& q = Q[round & 1];
         if (E.tracing()) {
@@ -441,7 +441,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         }
         const int kind = __builtin_amdgcn_readfirstlane(q.kind);
         const double qa = uniform(q.a);
-        E.tick(8, ts1 - ts0); E.tick(9, clock64() - ts1);
+        E.tick(8, ts1 - ts0); E.tick(9, E.clock() - ts1);
         if (kind == REQ_DONE || E.aborted()) break;
         switch (kind) {
         case REQ_F:

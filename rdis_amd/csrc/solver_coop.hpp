@@ -45,6 +45,17 @@ constexpr unsigned long long COOP_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 constexpr unsigned long long COOP_CANON_NAN = 0x7FF8000000000000ull;
 constexpr unsigned COOP_SPIN_LIMIT = 1u << 22;
 
+// shader-clock stamps for the per-phase breakdown (rdis_hip_plan_debug_counters).  Each stamp
+// is a scalar memory read (~150 cycles on the critical path), so they are compiled in only
+// with -DRDIS_COOP_TIMING (make -C rdis_amd/csrc EXTRA=-DRDIS_COOP_TIMING).
+__device__ __forceinline__ long long coop_clock() {
+#ifdef RDIS_COOP_TIMING
+    return clock64();
+#else
+    return 0;
+#endif
+}
+
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
@@ -103,7 +114,7 @@ struct CoopEnv {
     // of every workgroup, bit-identical everywhere.  `order` additionally makes all
     // plain global stores issued before the call visible to all lanes after it.
     __device__ void exchange(double& a, double& b, double& mx, bool order) {
-        const long long t0 = clock64();
+        const long long t0 = coop_clock();
         long long t1 = t0, t2 = t0, t3 = t0;
         a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
         const int w = tid >> 6, lane = tid & 63;
@@ -111,7 +122,7 @@ struct CoopEnv {
         if (order) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
         __syncthreads();
         const int buf = epoch % 3u;
-        t1 = clock64();
+        t1 = coop_clock();
         if (w == 0) {
             double ra = 0.0, rb = 0.0, rm = 0.0;
             const int nwv = blockDim.x >> 6;
@@ -128,7 +139,7 @@ struct CoopEnv {
                 __hip_atomic_store(gran(buf, 2, wg), um, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // sweep: lane l looks after workgroups l, l+64, ...
-            t2 = clock64();
+            t2 = coop_clock();
             double sa = 0.0, sb = 0.0, sm = 0.0;
             unsigned spins = 0;
             bool ok = !dead;
@@ -174,7 +185,7 @@ struct CoopEnv {
                 __builtin_amdgcn_s_sleep(1);
             }
             ok = __all(ok);
-            t3 = clock64();
+            t3 = coop_clock();
             sa = wave_sum(sa); sb = wave_sum(sb); sm = wave_max(sm);
             if (lane == 0) {
                 bcast[parity * 4 + 0] = sa; bcast[parity * 4 + 1] = sb; bcast[parity * 4 + 2] = sm;
@@ -192,7 +203,7 @@ struct CoopEnv {
         if (bcast[parity * 4 + 3] == 0.0) dead = true;
         parity ^= 1;
         ++epoch;
-        const long long t4 = clock64();
+        const long long t4 = coop_clock();
         tm[1] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; tm[4] += t4 - t3; ++tm[5];
     }
     __device__ void barrier_ordered() {
@@ -209,12 +220,13 @@ struct CoopEnv {
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return dead; }
     __device__ void tick(int slot, long long dt) { tm[slot] += dt; }
+    __device__ long long clock() const { return coop_clock(); }
 
     // ---- evaluation at clamp(base + a*dir), straight from registers ---------------
     template <bool SLOPE>
     __device__ void eval_line(double a, double& f, double& s) {
         double fj = 0.0, sj = 0.0, dummy = 0.0;
-        const long long tc0 = clock64();
+        const long long tc0 = coop_clock();
         if (has_fac) {
             double v[12];
             {
@@ -236,7 +248,7 @@ struct CoopEnv {
                 fj = ba_eval(v, ox, oy);
             }
         }
-        tm[0] += clock64() - tc0;
+        tm[0] += coop_clock() - tc0;
         exchange(fj, sj, dummy, false);
         f = fj; s = sj;
     }
@@ -379,7 +391,7 @@ __global__ void __launch_bounds__(THREADS)
 cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol) {
     __shared__ double red[2][COOP_K][MAX_WAVES];
     __shared__ double bcast[8];
-    const long long tk0 = clock64();
+    const long long tk0 = coop_clock();
     const int comp = A.comp;
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
@@ -408,7 +420,7 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
         L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
         L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
-        E.tm[7] = clock64() - tk0;
+        E.tm[7] = coop_clock() - tk0;
         if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.tm[i];
     }
 }

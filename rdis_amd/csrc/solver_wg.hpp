@@ -204,6 +204,7 @@ struct WgEnv {
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return false; }
     __device__ void tick(int, long long) {}
+    __device__ long long clock() const { return 0; }
     // value at clamp(p + a*xi), or at clamp(x_init) for the rollback (CGD .cpp:71)
     __device__ double eval_value(double a, bool restore) {
         if (restore) assign_vec(xinit); else assign_line(a);

@@ -7,7 +7,7 @@ from oracle import oracle as O
 ctx = capi.Context(0)
 pp = P.load_bal().single_component()
 g = capi.Problem(ctx, pp)
-for opts in [{"coop_poll_delay": d} for d in (12, 16, 20)]:
+for opts in [{"coop_poll_delay": d} for d in (12, 13)]:
     plan = capi.Plan(g)
     for k, v in opts.items():
         plan.set_option(k, v)
