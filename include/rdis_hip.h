@@ -168,7 +168,10 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * solved by the multi-workgroup cooperative kernel, one launch each; 0 = never; default
  * 4096), "coop_max_components" (at most this many per plan, default 8; further large
  * components stay in the batched launch), "coop_workgroups" (cap, 0 = what fits),
- * "coop_threads" (128, 256 or 512),
+ * "coop_threads" (128, 256 or 512), "coop_poll_delay" (x64 cycles between publishing and the
+ * first granule sweep), "force_stream" (send large components to the streaming grid solver even
+ * when they fit the register-resident one; large components that do not fit, and large
+ * nonlinear-product components, always go there),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

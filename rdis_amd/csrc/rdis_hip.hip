@@ -15,6 +15,7 @@
 
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
+#include "solver_stream.hpp"
 
 using namespace rdis_hip;
 
@@ -125,6 +126,11 @@ struct CoopItem {
     DevBuf wave_var;  // [nwg * threads / 64] free variable owned by a whole wave, -1 = none
 };
 
+struct StreamItem {
+    int comp = 0, nwg = 0, nlong = 0;
+    DevBuf long_vars;  // local indices of the variables fed by many partials
+};
+
 struct rdis_hip_plan {
     rdis_hip_problem* prob = nullptr;
     bool transient = false;  // lives in the problem's arena (rdis_hip_cgd_batch): one at a time
@@ -143,6 +149,7 @@ struct rdis_hip_plan {
     // which components go where (rebuilt when an option changes)
     bool partition_dirty = true;
     std::vector<CoopItem> coop;
+    std::vector<StreamItem> stream;
     std::vector<int> h_rest;
     DevBuf rest_order, xi_glob;
     // options
@@ -150,6 +157,7 @@ struct rdis_hip_plan {
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
     int coop_max_components = 8;      // ... for at most this many components per plan
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
+    bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
     int dump_iters = 0;
     int last_launches = 0;
@@ -686,6 +694,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         need += align_up(blk.size() * 4, 256) + align_up((size_t)(5 * nfree) * 8, 256) + align_up((size_t)L->ngfac * 8, 256);
         need += align_up((size_t)nfree * 8, 256) + align_up(L->out_bytes, 256) + 256;
         need += align_up(nc * 4, 256) + align_up((size_t)nfree * 8, 256);                       // rest_order, xi_glob
+        need += align_up((size_t)nfree * 4, 256) + 8 * 256;                                      // long_vars of streaming components
         need += (size_t)std::min<int64_t>(ncomp, 8) * (align_up(lanes_max * 4, 256) + align_up(lanes_max / 64 * 4, 256));
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
         if (p->arena.bytes < need) {
@@ -757,6 +766,8 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_threads") {
         if (value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 128, 256 or 512");
         L->coop_threads = (int)value;
+    } else if (n == "force_stream") {
+        L->force_stream = value != 0;
     } else if (n == "coop_poll_delay") {
         if (value < 0 || value > 1024) return fail(c, RDIS_HIP_EINVAL, "coop_poll_delay out of range");
         L->coop_poll_delay = (int)value;
@@ -790,18 +801,41 @@ int prepare_partition(rdis_hip_plan* L) {
     rdis_hip_ctx* c = L->prob->ctx;
     rdis_hip_problem* p = L->prob;
     L->coop.clear();
+    L->stream.clear();
     L->h_rest.clear();
-    int cap = 0;
-    if (p->kind == KIND_BA && L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors)
-        cap = coop_max_workgroups(L->coop_threads, c->num_cus);
-    if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
+    int cap = 0, scap = 0;
+    const bool any_big = L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors;
+    if (any_big && p->kind == KIND_BA) cap = coop_max_workgroups(L->coop_threads, c->num_cus);
+    if (any_big) scap = stream_max_workgroups(p->kind, c->num_cus);
+    if (L->coop_workgroups > 0) { cap = std::min(cap, L->coop_workgroups); scap = std::min(scap, L->coop_workgroups); }
     int64_t max_n = 0;
     std::vector<int> blk_all;
     for (int cc : L->h_order) {  // heaviest first
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
         const int64_t need = (std::max(m, n) + L->coop_threads - 1) / L->coop_threads;
-        const bool take = cap > 0 && m >= L->coop_min_factors && (int)L->coop.size() < L->coop_max_components && need <= cap;
+        const bool big = m >= L->coop_min_factors && (int)(L->coop.size() + L->stream.size()) < L->coop_max_components;
+        const bool take = big && cap > 0 && need <= cap && !L->force_stream;
+        if (!take && big && scap > 0) {
+            // too large for the register-resident solver (or not bundle adjustment): the streaming
+            // grid solver; about two factors per lane and trial point, at most what is resident
+            L->stream.emplace_back();
+            StreamItem& st = L->stream.back();
+            st.comp = cc;
+            st.nwg = (int)std::max<int64_t>(1, std::min<int64_t>(scap, (std::max(m, n) + 2 * STREAM_THREADS - 1) / (2 * STREAM_THREADS)));
+            const int f0s = L->h_free_ptr[(size_t)cc];
+            std::vector<int> longv;
+            for (int64_t i = 0; i < n; ++i)
+                if (L->h_v2s_ptr[(size_t)(f0s + i) + 1] - L->h_v2s_ptr[(size_t)(f0s + i)] > STREAM_LONG_LIST) longv.push_back((int)i);
+            st.nlong = (int)longv.size();
+            int rcs = plan_alloc(L, st.long_vars, std::max<size_t>(longv.size(), 1) * sizeof(int));
+            if (rcs) return rcs;
+            if (!longv.empty()) {
+                HIPCHK(c, hipMemcpyAsync(st.long_vars.p, longv.data(), longv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));  // local
+            }
+            continue;
+        }
         if (!take) { L->h_rest.push_back(cc); continue; }
         L->coop.emplace_back();
         CoopItem& it = L->coop.back();
@@ -891,6 +925,14 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
                     it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp, L->coop_poll_delay};
         int rc = launch_coop(c->stream, p->kind, p->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
+        ++L->last_launches;
+    }
+    for (size_t i = 0; i < L->stream.size(); ++i) {
+        const StreamItem& it = L->stream[i];
+        StreamArgs sa{p->coop_timing.as<long long>(), p->coop_state.as<CoopState>(), it.long_vars.as<int>(), it.nlong,
+                      it.comp, L->coop_poll_delay};
+        int rc = launch_stream(c->stream, p->kind, p->view(), V, sa, it.nwg, maxiters, ftol);
+        if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
     const int rest = (int)L->h_rest.size();

@@ -34,38 +34,9 @@
 // Launched with hipLaunchCooperativeKernel so that an oversized grid is rejected
 // instead of deadlocking.  Bundle adjustment only (fixed arity 12).
 #pragma once
-#include "solver_wg.hpp"
+#include "grid_sync.hpp"
 
 namespace rdis_hip {
-
-constexpr int COOP_MAX_WG = 512;
-constexpr int COOP_K = 3;  // values per exchange
-constexpr int COOP_LONG_LIST = 48;  // variables fed by more partials than this are wave-owned
-constexpr unsigned long long COOP_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
-constexpr unsigned long long COOP_CANON_NAN = 0x7FF8000000000000ull;
-constexpr unsigned COOP_SPIN_LIMIT = 1u << 22;
-
-// shader-clock stamps for the per-phase breakdown (rdis_hip_plan_debug_counters).  Each stamp
-// is a scalar memory read (~150 cycles on the critical path), so they are compiled in only
-// with -DRDIS_COOP_TIMING (make -C rdis_amd/csrc EXTRA=-DRDIS_COOP_TIMING).
-__device__ __forceinline__ long long coop_clock() {
-#ifdef RDIS_COOP_TIMING
-    return clock64();
-#else
-    return 0;
-#endif
-}
-
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-struct CoopState {
-    // [3 buffers][COOP_K][COOP_MAX_WG] granules, then an abort word
-    unsigned long long granule[3][COOP_K][COOP_MAX_WG];
-    unsigned int abort_flag;
-    unsigned int pad[15];
-};
-inline size_t coop_state_bytes() { return sizeof(CoopState); }
 
 struct CoopArgs {
     long long* timing;     // [8] cycle accumulators written by lane 0 (profiling aid)
@@ -89,12 +60,8 @@ struct CoopEnv {
     const PlanView& L;
     const CoopArgs& A;
     int n, m, f0, c0;
-    int gt, tid, nwg, wg;     // global lane, lane in workgroup, #workgroups, my workgroup
-    double (*red)[COOP_K][MAX_WAVES];  // LDS block-reduce scratch [2][K][waves]
-    double* bcast;                     // LDS [2][4]
-    int parity;
-    unsigned epoch;
-    bool dead;                         // a spin gave up: unwind quickly
+    int gt, tid;              // global lane, lane in workgroup
+    GridSync X;
     double* tr;
     int trn, lm_count;
     // factor lane state
@@ -104,112 +71,6 @@ struct CoopEnv {
     double ox, oy;
     VarState lv;   // lane-owned variable
     VarState wv;   // wave-owned variable (identical in all 64 lanes)
-    long long tm[12]; // cycles (8: state-machine step, 9: hand-over of the request): 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
-                      // 5 #exchanges, 6 #sweeps, 7 whole kernel
-
-    // ---- inter-workgroup exchange ------------------------------------------------
-    __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&A.st->granule[buf][k][w]; }
-
-    // Sum (k = 0,1) / max (k = 2) of one value per workgroup, delivered to every lane
-    // of every workgroup, bit-identical everywhere.  `order` additionally makes all
-    // plain global stores issued before the call visible to all lanes after it.
-    __device__ void exchange(double& a, double& b, double& mx, bool order) {
-        const long long t0 = coop_clock();
-        long long t1 = t0, t2 = t0, t3 = t0;
-        a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
-        const int w = tid >> 6, lane = tid & 63;
-        if (lane == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
-        if (order) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
-        __syncthreads();
-        const int buf = epoch % 3u;
-        t1 = coop_clock();
-        if (w == 0) {
-            double ra = 0.0, rb = 0.0, rm = 0.0;
-            const int nwv = blockDim.x >> 6;
-            for (int i = 0; i < nwv; ++i) { ra += red[parity][0][i]; rb += red[parity][1][i]; rm = fmax(rm, red[parity][2][i]); }
-            if (lane == 0) {
-                if (order) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // re-arm stores + payload are out
-                unsigned long long ua = __double_as_longlong(ra), ub = __double_as_longlong(rb), um = __double_as_longlong(rm);
-                if (ua == COOP_SENTINEL) ua = COOP_CANON_NAN;
-                if (ub == COOP_SENTINEL) ub = COOP_CANON_NAN;
-                if (um == COOP_SENTINEL) um = COOP_CANON_NAN;
-                __hip_atomic_store(gran(buf, 0, wg), ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(buf, 1, wg), ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(buf, 2, wg), um, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // sweep: lane l looks after workgroups l, l+64, ...
-            t2 = coop_clock();
-            double sa = 0.0, sb = 0.0, sm = 0.0;
-            unsigned spins = 0;
-            bool ok = !dead;
-            const int per = (nwg + 63) >> 6;
-            for (int d = 0; d < A.poll_delay; d += 8) __builtin_amdgcn_s_sleep(8);
-            while (!dead) {
-                ++tm[6];
-                // every load of the sweep is in flight before the first one is looked at: one
-                // memory round trip per sweep (a lane's out-of-range slots read granule 0)
-                constexpr int PER = COOP_MAX_WG / 64;
-                unsigned long long va[PER], vb[PER], vm[PER];
-#pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    if (j < per) {
-                        const int ww = lane + (j << 6);
-                        const int wc = ww < nwg ? ww : 0;
-                        va[j] = __hip_atomic_load(gran(buf, 0, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vb[j] = __hip_atomic_load(gran(buf, 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vm[j] = __hip_atomic_load(gran(buf, 2, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                ok = true;
-                sa = 0.0; sb = 0.0; sm = 0.0;
-#pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    if (j < per) {
-                        ok = ok && va[j] != COOP_SENTINEL && vb[j] != COOP_SENTINEL && vm[j] != COOP_SENTINEL;
-                        if (lane + (j << 6) < nwg) {
-                            sa += __longlong_as_double(va[j]); sb += __longlong_as_double(vb[j]);
-                            sm = fmax(sm, __longlong_as_double(vm[j]));
-                        }
-                    }
-                }
-                if (__all(ok)) break;
-                ++spins;
-                if (spins > COOP_SPIN_LIMIT ||
-                    ((spins & 255u) == 0u &&
-                     __hip_atomic_load((gu32*)&A.st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    if (lane == 0) __hip_atomic_store((gu32*)&A.st->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            ok = __all(ok);
-            t3 = coop_clock();
-            sa = wave_sum(sa); sb = wave_sum(sb); sm = wave_max(sm);
-            if (lane == 0) {
-                bcast[parity * 4 + 0] = sa; bcast[parity * 4 + 1] = sb; bcast[parity * 4 + 2] = sm;
-                bcast[parity * 4 + 3] = ok ? 1.0 : 0.0;
-                if (order) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // re-arm my granules two exchanges ahead (safe: everybody has consumed that buffer)
-                const int nb = (epoch + 2u) % 3u;
-                __hip_atomic_store(gran(nb, 0, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(nb, 1, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(nb, 2, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        a = bcast[parity * 4 + 0]; b = bcast[parity * 4 + 1]; mx = bcast[parity * 4 + 2];
-        if (bcast[parity * 4 + 3] == 0.0) dead = true;
-        parity ^= 1;
-        ++epoch;
-        const long long t4 = coop_clock();
-        tm[1] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; tm[4] += t4 - t3; ++tm[5];
-    }
-    __device__ void barrier_ordered() {
-        double a = 0.0, b = 0.0, c = 0.0;
-        exchange(a, b, c, true);
-    }
 
     __device__ void trace(int tag, double a, double b, double c) {
         if (tr != nullptr && gt == 0) {
@@ -218,8 +79,8 @@ struct CoopEnv {
         }
     }
     __device__ bool tracing() const { return tr != nullptr; }
-    __device__ bool aborted() const { return dead; }
-    __device__ void tick(int slot, long long dt) { tm[slot] += dt; }
+    __device__ bool aborted() const { return X.dead; }
+    __device__ void tick(int slot, long long dt) { X.tm[slot] += dt; }
     __device__ long long clock() const { return coop_clock(); }
 
     // ---- evaluation at clamp(base + a*dir), straight from registers ---------------
@@ -248,8 +109,8 @@ struct CoopEnv {
                 fj = ba_eval(v, ox, oy);
             }
         }
-        tm[0] += coop_clock() - tc0;
-        exchange(fj, sj, dummy, false);
+        X.tm[0] += coop_clock() - tc0;
+        X.exchange(fj, sj, dummy, false);
         f = fj; s = sj;
     }
     __device__ double eval_value(double a, bool restore) {
@@ -287,7 +148,7 @@ struct CoopEnv {
         }
     }
     __device__ void init_vectors() {
-        var_init(lv, gt < nwg * (int)blockDim.x ? A.lane_var[gt] : -1);
+        var_init(lv, A.lane_var[gt]);
         var_init(wv, A.wave_var[gt >> 6]);
         load_base(L.xstart + f0);
     }
@@ -302,7 +163,7 @@ struct CoopEnv {
 #pragma unroll
             for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) L.gfac[t] = g[k]; }
         }
-        barrier_ordered();
+        X.barrier_ordered();
         const int* vp = L.v2s_ptr + f0;
         if (lv.li >= 0) {  // few partials: serial, in factor-list order (src/State.h:157-210)
             const int b = vp[lv.li], e = vp[lv.li + 1];
@@ -323,7 +184,7 @@ struct CoopEnv {
     __device__ void publish_xi() {
         if (lv.li >= 0) A.xi_glob[lv.li] = lv.xi;
         if (wv.li >= 0 && (tid & 63) == 0) A.xi_glob[wv.li] = wv.xi;
-        barrier_ordered();
+        X.barrier_ordered();
     }
     __device__ void cg_start() {
         { const double t = -lv.xi; lv.g = t; lv.h = t; lv.xi = t; }
@@ -366,7 +227,7 @@ struct CoopEnv {
             a = a + wv.g * wv.g;
             b = b + (wv.xi + wv.g) * wv.xi;
         }
-        exchange(a, b, t, false);
+        X.exchange(a, b, t, false);
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {
@@ -397,10 +258,10 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
 
-    CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x,
-              red, bcast, 0, 0u, false,
+    CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x,
+              GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, red, bcast, A.poll_delay, 0, 0u, false, {}},
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
-              gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}, {}};
+              gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
     if (E.has_fac) {
         E.fid = L.fac_id[c0 + gt];
         const double2 o = P.obs[E.fid];
@@ -412,16 +273,16 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     E.init_vectors();
     run_machine(E, M, Q, maxiters, ftol);
     int status = M.status();
-    if (E.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
-    const bool restore = M.rolled_back || E.dead;
+    if (E.X.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
+    const bool restore = M.rolled_back || E.X.dead;
     E.write_back(E.lv, restore, true);
     E.write_back(E.wv, restore, (threadIdx.x & 63) == 0);
     if (gt == 0) {
         L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
         L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
-        E.tm[7] = coop_clock() - tk0;
-        if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.tm[i];
+        E.X.tm[7] = coop_clock() - tk0;
+        if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.X.tm[i];
     }
 }
 

@@ -273,3 +273,38 @@ def test_workgroup_size_does_not_change_the_algorithm(threads, gctx):
     pp = P.load_bal(ncams=5, npts=30)
     _, r, trv = solve(gctx, pp, maxiters=6, trace=4096, opts={"block_threads": threads})
     check_replay(pp, trv, r, 6)
+
+
+STREAM_CASES = {
+    "ladybug_49_500": (lambda: P.load_bal(ncams=49, npts=500), 6, {"coop_min_factors": 1000, "force_stream": 1}),
+    "ladybug_full": (lambda: P.load_bal(), 4, {"force_stream": 1}),
+    "sinusoid_nlp": (lambda: _with_x0(P.make_high_dim_sinusoid(), np.random.default_rng(4).uniform(-6, 6, 121)), 12,
+                     {"coop_min_factors": 100}),
+}
+
+
+@pytest.mark.parametrize("name", list(STREAM_CASES))
+def test_streaming_grid_solver_replays_against_oracle(name, gctx):
+    """components too large for the register-resident solver (or not bundle adjustment) are solved
+    by the streaming multi-workgroup kernel: same algorithm, checked the same way"""
+    make, mit, opts = STREAM_CASES[name]
+    pp = make()
+    g, r, trv = solve(gctx, pp, maxiters=mit, trace=1 << 13, opts=opts)
+    check_replay(pp, trv, r, mit)
+    assert np.array_equal(g.get_x(), r.x)
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    o.assign(None, r.x)
+    assert abs(o.eval() - r.fret[0]) <= 1e-12 * abs(r.fret[0])
+    # dir is shared by the plans of a problem and must be left zero: a second, different solve on the
+    # same problem still replays
+    _, r2, trv2 = solve(gctx, pp, maxiters=2, trace=4096, opts={"coop_min_factors": 0})
+    check_replay(pp, trv2, r2, 2)
+
+
+def test_component_beyond_register_capacity_uses_streaming(gctx):
+    # one synthetic component with more factors than the register-resident solver has lanes (65536)
+    pp = P.make_synthetic_ba(1, 12, 20000, obs_per_pt=4)
+    assert pp.nfac == 80000
+    _, r, trv = solve(gctx, pp, maxiters=3, trace=4096)
+    check_replay(pp, trv, r, 3)
+    assert r.delta[0] < 0 and (r.status[0] & 0xFF) in (0, 3)
