@@ -19,6 +19,9 @@ Workloads (--workload):
                  top-level objective is summed with an RCCL all-reduce.
   synthetic-S    BASELINE config 5: 1000 independent 3-camera x 40-point components
                  per rank (one workgroup each, one launch).
+  ladybug-components  the component mix RDIS reaches on ladybug once a separator is assigned
+                 (SURVEY.md 3.2b): 7776 single-point components (3 variables, 2-29 factors,
+                 cameras fixed), one launch.
 """
 from __future__ import annotations
 
@@ -54,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S"])
+    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "ladybug-components"])
     ap.add_argument("--maxiters", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
@@ -65,6 +68,11 @@ def build_problem(workload: str, rank: int):
     from rdis_amd import problems as P
     if workload == "ladybug-full":
         return P.load_bal().single_component()
+    if workload == "ladybug-components":
+        pp = P.load_bal()
+        _, pts = P.ba_alternation_plans(pp)
+        pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id = pts
+        return pp
     return P.make_synthetic_ba(1000, 3, 40, first_comp=1000 * rank)
 
 
@@ -87,8 +95,8 @@ def cpu_baseline(pp, maxiters: int):
     single-threaded like the reference; bounded to a few tens of seconds"""
     from oracle import oracle as O
     ncores = 1
-    if pp.meta.get("generator") == "synthetic_ba":
-        ncomp = 100
+    if pp.ncomp > 1:
+        ncomp = min(pp.ncomp, 100 if pp.meta.get("generator") == "synthetic_ba" else 1000)
         o = O.OracleProblem(pp)
         t = time.perf_counter()
         its = 0
@@ -97,7 +105,7 @@ def cpu_baseline(pp, maxiters: int):
             r = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=maxiters)
             its += r.iters + 1
         dt = time.perf_counter() - t
-        sample = f"first {ncomp} of 1000 components, dense gradient accumulation"
+        sample = f"first {ncomp} of {pp.ncomp} components, dense gradient accumulation"
         extra = {}
     else:
         o = O.OracleProblem(pp)
@@ -148,7 +156,7 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         plan.set_option(k, int(v))
-    plan.set_start(pp.x0)
+    plan.set_start(pp.x0[pp.comp_free_vid])
 
     class _DevObjective:  # torch view of the device-side objective sum
         def __init__(self, ptr):
@@ -204,9 +212,10 @@ def main():
             "metric": "subspace-solver iters/sec (all components), ladybug BA",
             "value": total_iters / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "ladybug-49-7776 (BAL file)" if a.workload == "ladybug-full" else "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.workload == "synthetic-S" else "ladybug-49-7776 (BAL file)",
             "config": {"workload": ("ladybug-49-7776 full, CGD over all 23769 variables / 31843 factors, SSmaxit 25, ftol 3e-8; "
                                     "one such component per GPU") if a.workload == "ladybug-full" else
+                       "ladybug-49-7776 with the cameras fixed: 7776 single-point components per GPU, SSmaxit 25" if a.workload == "ladybug-components" else
                        "synthetic decomposable BA: 1000 components x (3 cameras, 40 points, 120 observations) per GPU, SSmaxit 25",
                        "components_per_gpu": pp.ncomp, "factors_per_gpu": pp.nfac, "variables_per_gpu": pp.nvars,
                        "parallelism": f"{world} x independent components, all-reduce of the objective"},

@@ -320,6 +320,26 @@ bool BundleAdjustmentFunction::load(const std::string& file, VariableCount numca
     return !variables.empty() && !factors.empty();
 }
 
+bool BundleAdjustmentFunction::save(const std::string& file, const NumericVec* state) const {
+    std::ofstream out(file.c_str());
+    if (!out.is_open()) { std::cerr << "BundleAdjustmentFunction::save: cannot open " << file << std::endl; return false; }
+    if (state && state->size() != variables.size()) return false;
+    char buf[128];
+    out << ncams_ << " " << npts_ << " " << factors.size() << "\n";
+    for (const Factor* f : factors) {
+        const BundleAdjustmentFactor* b = static_cast<const BundleAdjustmentFactor*>(f);
+        Numeric ox, oy;
+        b->getObservation(ox, oy);
+        std::snprintf(buf, sizeof buf, "%lld %lld     %.17e %.17e\n", b->getCameraID(), b->getPointID(), ox, oy);
+        out << buf;
+    }
+    for (size_t i = 0; i < variables.size(); ++i) {
+        std::snprintf(buf, sizeof buf, "%.17e\n", state ? (*state)[i] : variables[i]->eval());
+        out << buf;
+    }
+    return out.good();
+}
+
 // ------------------------------------------------------------------ PolynomialFunction
 Variable* PolynomialFunction::varByName(const std::string& name, VariableID& next_id) {
     return addVariable(name, defaultDomain, next_id);

@@ -215,6 +215,9 @@ public:
     // BAL text (src/bundleadjust/BundleAdjustmentFunction.cpp:50-250); numcams / numpoints > 0
     // keep the first k cameras / points
     bool load(const std::string& file, VariableCount numcams = 0, VariableCount numpoints = 0);
+    // BAL file with the currently assigned values (or the given state) in place of the parameters
+    // (src/bundleadjust/BundleAdjustmentFunction.cpp:253-320)
+    bool save(const std::string& file, const NumericVec* state = nullptr) const;
     long long getNumCameras() const { return ncams_; }
     long long getNumPoints() const { return npts_; }
     VariableID getCamVID(long long cid, unsigned k) const { return cid * 9 + k; }                 // .h:88-96

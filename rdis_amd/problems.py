@@ -144,6 +144,41 @@ def load_bal(path: str = LADYBUG_PATH, ncams: int = 0, npts: int = 0) -> PackedP
     )
 
 
+def save_bal(pp: PackedProblem, path: str, x: Optional[np.ndarray] = None) -> None:
+    """Write a packed BA problem (with state x, default x0) in BAL format -- what
+    BundleAdjustmentFunction::save does (src/bundleadjust/BundleAdjustmentFunction.cpp:253-320)."""
+    assert pp.kind == KIND_BA
+    x = pp.x0 if x is None else np.asarray(x, dtype=np.float64)
+    nc = int(pp.meta.get("ncams", int(pp.pt_vid0.min()) // 9 if pp.nfac else 0))
+    npnt = (pp.nvars - 9 * nc) // 3
+    with open(path, "w") as fh:
+        fh.write(f"{nc} {npnt} {pp.nfac}\n")
+        for c, q, (ox, oy) in zip(pp.cam_vid0 // 9, (pp.pt_vid0 - 9 * nc) // 3, pp.obs):
+            fh.write(f"{int(c)} {int(q)}     {ox:.17e} {oy:.17e}\n")
+        for v in x:
+            fh.write(f"{v:.17e}\n")
+
+
+def ba_alternation_plans(pp: PackedProblem):
+    """The decomposition RDIS reaches on a BAL problem once a separator is assigned (SURVEY.md
+    3.2b): with the points fixed every camera is an independent 9-variable component (its factors
+    = its observations), with the cameras fixed every point is an independent 3-variable
+    component.  Returns two CSR decompositions (free_ptr, free_vid, fac_ptr, fac_id): cameras, points.
+    Factor lists are in ascending factor id, like Component's (src/Component.cpp:78-79,103,116)."""
+    assert pp.kind == KIND_BA
+    nc = int(pp.meta["ncams"])
+    npnt = (pp.nvars - 9 * nc) // 3
+    fid = np.arange(pp.nfac, dtype=np.int64)
+    cam_of, pt_of = pp.cam_vid0 // 9, (pp.pt_vid0 - 9 * nc) // 3
+    oc = np.argsort(cam_of, kind="stable")
+    op = np.argsort(pt_of, kind="stable")
+    cams = (np.arange(nc + 1, dtype=np.int64) * 9, np.arange(9 * nc, dtype=np.int64),
+            np.concatenate([[0], np.cumsum(np.bincount(cam_of, minlength=nc))]).astype(np.int64), fid[oc])
+    pts = (np.arange(npnt + 1, dtype=np.int64) * 3, 9 * nc + np.arange(3 * npnt, dtype=np.int64),
+           np.concatenate([[0], np.cumsum(np.bincount(pt_of, minlength=npnt))]).astype(np.int64), fid[op])
+    return cams, pts
+
+
 # ---------------------------------------------------------------------------
 # nonlinear product factors: polynomial file and the sinusoid generator
 # ---------------------------------------------------------------------------

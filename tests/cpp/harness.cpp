@@ -30,6 +30,22 @@ int harness_pack_bal(const char* path, long long ncams, long long npts, long lon
     } catch (const std::exception& e) { std::cerr << "harness_pack_bal: " << e.what() << std::endl; return -2; }
 }
 
+// load -> assign the initial state -> save -> load again: sizes and values survive
+int harness_bal_round_trip(const char* path, long long ncams, long long npts, const char* out_path) {
+    try {
+        BundleAdjustmentFunction f, g;
+        if (!f.load(path, ncams, npts)) return -1;
+        f.assignAll(f.getInitialState());
+        if (!f.save(out_path)) return -3;
+        if (!g.load(out_path)) return -4;
+        if (g.getNumVars() != f.getNumVars() || g.getFactors().size() != f.getFactors().size()) return 1;
+        if (g.getInitialState() != f.getInitialState()) return 2;
+        const OptimizableFunction::Packed &a = f.packed(), &b = g.packed();
+        if (a.cam_vid0 != b.cam_vid0 || a.pt_vid0 != b.pt_vid0 || a.obs != b.obs || a.lo != b.lo || a.hi != b.hi) return 3;
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_bal_round_trip: " << e.what() << std::endl; return -2; }
+}
+
 // which = 0: polynomial file, 1: default high-dimensional sinusoid. out_sizes = {nvars, nfac, nnz}
 int harness_pack_nlp(int which, const char* path, long long* out_sizes, double* lo, double* hi, double* coeff,
                      long long* rowptr, long long* vid, double* expo, double* cons, unsigned char* sine) {

@@ -308,3 +308,34 @@ def test_component_beyond_register_capacity_uses_streaming(gctx):
     _, r, trv = solve(gctx, pp, maxiters=3, trace=4096)
     check_replay(pp, trv, r, 3)
     assert r.delta[0] < 0 and (r.status[0] & 0xFF) in (0, 3)
+
+
+def test_camera_and_point_component_batches(gctx):
+    """the component mix RDIS reaches on a BAL problem: all cameras (points fixed) in one launch,
+    then all points (cameras fixed) in one launch; members replay against the oracle"""
+    pp = P.load_bal(ncams=49, npts=500)
+    g = capi.Problem(gctx, pp)
+    obj = g.eval()
+    for name, (free_ptr, free_vid, fac_ptr, fac_id) in zip(("cameras", "points"), P.ba_alternation_plans(pp)):
+        plan = capi.Plan(g, free_ptr, free_vid, fac_ptr, fac_id)
+        plan.set_option("trace_records", 4096)
+        plan.set_option("dump_iters", 25)
+        plan.set_start(None)                      # start from the currently assigned values
+        x_before = g.get_x()
+        plan.solve(25, 3e-8)
+        r = plan.fetch()
+        assert np.all(r.delta <= 0) and np.all((r.status & 0xFF) != 5)
+        new_obj = g.eval()
+        assert abs(new_obj - np.sum(r.fret)) <= 1e-12 * new_obj          # every factor is in exactly one component
+        assert abs((obj + np.sum(r.delta)) - new_obj) <= 1e-10 * obj
+        obj = new_obj
+        ncomp = len(free_ptr) - 1
+        for c in (0, ncomp // 3, ncomp - 1):
+            fv, fc = free_vid[free_ptr[c]:free_ptr[c + 1]], fac_id[fac_ptr[c]:fac_ptr[c + 1]]
+            q = P.load_bal(ncams=49, npts=500)
+            q.x0 = x_before                                               # the oracle sees the same constants
+            tr, n = plan.get_trace(c, 4096)
+            rep = O.OracleProblem(q).replay(tr, free_vid=fv, fac=fc, x=x_before[fv], maxiters=25,
+                                            vdump=plan.get_vectors(c, 25)[:int(r.iters[c]) + 1])
+            assert rep.step_mismatches == 0 and rep.tag_mismatches == 0 and rep.underrun == 0 and rep.consumed == n, (name, c, rep)
+            assert rep.max_f_rel_near <= 1e-12 and rep.max_slope_rel_near <= 1e-11 and rep.fret == r.fret[c], (name, c, rep)

@@ -59,6 +59,13 @@ def test_bal_loader_matches_python_builder(harness, bal_path, nc, npnt):
     assert np.array_equal(lo, pp.lo) and np.array_equal(hi, pp.hi)
 
 
+def test_bal_save_round_trip(harness, bal_path, tmp_path):
+    assert harness.harness_bal_round_trip(bal_path, 5, 30, str(tmp_path / "out.txt").encode()) == 0
+    q = P.load_bal(str(tmp_path / "out.txt"))           # and the Python loader reads what the C++ saver wrote
+    pp = P.load_bal(ncams=5, npts=30)
+    assert np.array_equal(q.x0, pp.x0) and np.array_equal(q.obs, pp.obs) and np.array_equal(q.cam_vid0, pp.cam_vid0)
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_nlp_builders_match_python(harness, which):
     pp = P.load_poly() if which == 0 else P.make_high_dim_sinusoid()

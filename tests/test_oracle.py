@@ -223,3 +223,26 @@ def test_cgd_contract_details():
     o3.assign(None, np.array([0.0, 2.0]))
     r = o3.cgd(free_vid=np.array([0]), fac=fac, x=np.array([0.0]), maxiters=50)
     assert abs(r.x[0] - (-4.6601175)) < 1e-5 and o3.get_x()[1] == 2.0
+
+
+# ---------------------------------------------------------------- data formats either side of the path
+def test_bal_save_load_round_trip(tmp_path):
+    pp = P.load_bal(ncams=5, npts=30)
+    x = pp.x0 * (1 + 1e-3 * np.random.default_rng(0).standard_normal(pp.nvars))
+    f = str(tmp_path / "state.txt")
+    P.save_bal(pp, f, x)
+    q = P.load_bal(f)
+    assert np.array_equal(q.x0, x) and np.array_equal(q.obs, pp.obs)
+    assert np.array_equal(q.cam_vid0, pp.cam_vid0) and np.array_equal(q.pt_vid0, pp.pt_vid0)
+
+
+def test_alternation_decompositions_are_independent_components():
+    pp = P.load_bal(ncams=49, npts=500)
+    for (free_ptr, free_vid, fac_ptr, fac_id), block, nblk in zip(P.ba_alternation_plans(pp), (9, 3), (49, 500)):
+        assert len(free_ptr) == nblk + 1 and np.array_equal(np.sort(fac_id), np.arange(pp.nfac))   # every factor once
+        owner = np.repeat(np.arange(nblk), np.diff(fac_ptr))
+        blk_of = (pp.cam_vid0[fac_id] // 9) if block == 9 else ((pp.pt_vid0[fac_id] - 441) // 3)
+        assert np.array_equal(owner, blk_of)                       # a factor belongs to the component of its block
+        for c in (0, nblk // 2, nblk - 1):
+            assert np.all(np.diff(fac_id[fac_ptr[c]:fac_ptr[c + 1]]) > 0)   # ascending factor ids (Component.cpp:78-79)
+            assert np.array_equal(free_vid[free_ptr[c]:free_ptr[c + 1]], (0 if block == 9 else 441) + block * c + np.arange(block))
