@@ -26,13 +26,10 @@ __device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, d
     const double th2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     t.theta = sqrt(th2);
     const bool rot = t.theta > 0.0;
-    const double inv = rot ? 1.0 / t.theta : 1.0;
-    // the reference divides each component by theta; multiply by the reciprocal
-    // only where that is exact enough: keep the division for parity of v.
+    // unit axis by division, like the reference (BundleAdjustmentCommon.h:81-93)
     t.v0 = rot ? x[0] / t.theta : x[0];
     t.v1 = rot ? x[1] / t.theta : x[1];
     t.v2 = rot ? x[2] / t.theta : x[2];
-    (void)inv;
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     t.w0 = t.v1 * q2 - t.v2 * q1;
     t.w1 = t.v2 * q0 - t.v0 * q2;

@@ -339,3 +339,26 @@ def test_camera_and_point_component_batches(gctx):
                                             vdump=plan.get_vectors(c, 25)[:int(r.iters[c]) + 1])
             assert rep.step_mismatches == 0 and rep.tag_mismatches == 0 and rep.underrun == 0 and rep.consumed == n, (name, c, rep)
             assert rep.max_f_rel_near <= 1e-12 and rep.max_slope_rel_near <= 1e-11 and rep.fret == r.fret[c], (name, c, rep)
+
+
+def test_cooperative_exchange_is_bit_reproducible(gctx):
+    """a stale or torn read in the inter-workgroup exchange would change a sum and, through the
+    chaotic trajectory, the whole result: 12 repeated solves (register-resident and streaming
+    grid solvers, two workgroup counts) must agree to the last bit"""
+    pp = P.load_bal().single_component()
+    g = capi.Problem(gctx, pp)
+    for opts in ({}, {"coop_threads": 128}, {"force_stream": 1}):
+        plan = capi.Plan(g)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        ref = None
+        for rep in range(4):
+            plan.set_start(pp.x0)
+            plan.solve(10, 3e-8)
+            r = plan.fetch()
+            assert (r.status[0] & 0xFF) == 3, r.status                     # never a sync timeout
+            if ref is None:
+                ref = r
+            else:
+                assert r.fret[0] == ref.fret[0] and np.array_equal(r.x, ref.x) and r.nfeval[0] == ref.nfeval[0], opts
+        plan.close()
