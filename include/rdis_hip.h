@@ -183,10 +183,12 @@ int rdis_hip_plan_last_kernel_ms(rdis_hip_plan *plan, double *ms, int32_t *launc
 int rdis_hip_plan_get_trace(rdis_hip_plan *plan, int64_t comp, double *rec4, int64_t cap,
                             int64_t *nrec);
 
-/* shader-cycle accumulators of the last cooperative solve, as seen by lane 0 of
+/* 32 shader-cycle accumulators of the last cooperative solve, as seen by lane 0 of
  * workgroup 0: {factor arithmetic, workgroup reduce, publish, granule sweep, tail,
- * #exchanges, #sweeps, 0} (profiling aid) */
-int rdis_hip_plan_debug_counters(rdis_hip_plan *plan, int64_t *out8);
+ * #exchanges, #sweeps, whole kernel, control step, request hand-over, combine, release,
+ * [12..20] cycles per request kind, [22..30] requests per kind}.  All zero unless the
+ * library was built with -DRDIS_COOP_TIMING (profiling aid) */
+int rdis_hip_plan_debug_counters(rdis_hip_plan *plan, int64_t *out32);
 /* p and search direction at the start of each of the first dump_iters line
  * minimisations of component c: out[dump_iters][2][nfree_c] (dump_iters > 0) */
 int rdis_hip_plan_get_vectors(rdis_hip_plan *plan, int64_t comp, double *out, int64_t cap_doubles);

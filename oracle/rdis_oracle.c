@@ -860,6 +860,24 @@ static double replay_on_f(void *ctx, double a, double f_own)
     track(&R->rep->max_f_rel, f_own, r[2], sabs);
     R->rep->last_near = fabs(f_own) <= 4.0 * fabs(R->rep->finit) + 1.0;
     if (R->rep->last_near) track(&R->rep->max_f_rel_near, f_own, r[2], sabs);
+    else {
+        /* a far-out trial point: how much does the objective move when every free variable
+         * moves by one unit in the last place?  The device's value is expected within a small
+         * multiple of that (plus the ordinary rounding of the sum). */
+        sub_t *S = R->S;
+        ro_problem *p = S->p;
+        double *save = malloc((size_t)(S->nfree > 0 ? S->nfree : 1) * sizeof(double));
+        for (int64_t i = 0; i < S->nfree; ++i) {
+            const int64_t v = S->free_vid[i];
+            save[i] = p->x[v];
+            p->x[v] = nextafter(p->x[v], (i & 1) ? INFINITY : -INFINITY);
+        }
+        double fpert = 0.0;
+        for (int64_t i = 0; i < S->nf; ++i) fpert = fpert + factor_value_nocache(p, S->fac ? S->fac[i] : i);
+        for (int64_t i = 0; i < S->nfree; ++i) p->x[S->free_vid[i]] = save[i];
+        free(save);
+        track(&R->rep->max_f_far_ulps, f_own, r[2], fabs(fpert - f_own) + DBL_EPSILON * sabs);
+    }
     R->rep->pending_slope = ((int)r[0] == 2) ? r[3] : NAN;
     return r[2];
 }

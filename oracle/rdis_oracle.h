@@ -136,6 +136,8 @@ typedef struct {
     int32_t last_near;       /* internal */
     int64_t synced_iters;    /* line searches started from the device's dumped p, xi */
     double pending_slope;    /* internal */
+    double max_f_far_ulps;   /* far-out trial points: worst |f_own - f_dev| in units of (the change of f
+                                under a one-ulp move of every free variable + eps * sum|factor values|) */
 } ro_replay_report;
 
 /* vdump (may be NULL): the device's p and xi at the start of each of the first

@@ -1,13 +1,28 @@
 // grid_sync.hpp -- exchange of partial sums between the workgroups of one cooperative launch.
 //
 // 8-byte granules in HBM (relaxed agent-scope atomics, written through to memory): the data is
-// the flag.  A granule holds an all-ones NaN until its owner publishes; three buffers rotate and
-// each workgroup re-arms its own granules two exchanges ahead (drained with s_waitcnt vmcnt(0)
-// before its next publish).  One wave per workgroup sweeps all granules and reduces them in a
+// the flag.  A granule holds an all-ones NaN until its owner publishes; four buffers rotate.
+// After exchange e a workgroup re-arms its granules of buffer e+3 (= e-1: everybody has consumed
+// it, or this workgroup could not have completed e) and, before that, waits for the re-arming
+// stores it issued after exchange e-1.  Those are therefore complete before it publishes in
+// e+1, which every other workgroup must see before it can look at buffer e+2: nobody can read a
+// granule of an earlier use of a buffer.  One wave per workgroup sweeps all granules and reduces them in a
 // fixed order, so every workgroup obtains bit-identical results and takes identical branches.
-// `order` brackets the exchange with an agent-scope release / acquire (cdna_hip_programming.md
-// Guideline 16) so that plain stores issued before it are visible to every lane after it.
+// An exchange can also order memory (`sync`): SYNC_DRAIN makes every wave wait for its own
+// outstanding stores first -- enough when the data handed over is itself written and read with
+// coherent accesses (store_f64<true> / load_f64<true>); SYNC_FENCE additionally brackets the
+// exchange with an agent-scope release / acquire (cdna_hip_programming.md Guideline 16: L2
+// write-back and invalidate) so that plain stores issued before it are visible to plain loads
+// after it.
 // Placement-independent; every spin is bounded and raises `dead`.
+//
+// Two forms:
+//   to_wave0 + finish_wave0   the sums are delivered to wave 0 of every workgroup only -- the
+//                             wave that steps the solver's state machine is the only consumer of
+//                             a line-search value, so the other waves go straight to the barrier
+//                             that hands them the next request (one barrier per round saved);
+//   exchange / barrier_ordered   delivered to every lane (used inside operations that continue
+//                             with the result, e.g. partials -> per-variable sums).
 #pragma once
 #include "solver_wg.hpp"
 
@@ -15,6 +30,9 @@ namespace rdis_hip {
 
 constexpr int COOP_MAX_WG = 512;
 constexpr int COOP_K = 3;  // values per exchange
+constexpr int COOP_NBUF = 4;
+enum : int { SYNC_NONE = 0, SYNC_DRAIN = 1, SYNC_FENCE = 2 };
+constexpr int COOP_TM = 32;  // debug counters (rdis_hip_plan_debug_counters)
 constexpr int COOP_LONG_LIST = 48;  // variables fed by more partials than this are wave-owned
 constexpr unsigned long long COOP_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 constexpr unsigned long long COOP_CANON_NAN = 0x7FF8000000000000ull;
@@ -35,8 +53,8 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 struct CoopState {
-    // [3 buffers][COOP_K][COOP_MAX_WG] granules, then an abort word
-    unsigned long long granule[3][COOP_K][COOP_MAX_WG];
+    // [COOP_NBUF buffers][COOP_K][COOP_MAX_WG] granules, then an abort word
+    unsigned long long granule[COOP_NBUF][COOP_K][COOP_MAX_WG];
     unsigned int abort_flag;
     unsigned int pad[15];
 };
@@ -51,39 +69,46 @@ struct GridSync {
     int parity;
     unsigned epoch;
     bool dead;                          // a spin gave up: unwind quickly
-    long long tm[12]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
-                      // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over
+    long long tm[COOP_TM]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
+                      // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over,
+                      // 10 combine waves, 11 release, 12.. per request kind (REQ_F ..): handler cycles, 22.. their counts
 
     // ---- inter-workgroup exchange ------------------------------------------------
     __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][k][w]; }
 
-    // Sum (k = 0,1) / max (k = 2) of one value per workgroup, delivered to every lane
-    // of every workgroup, bit-identical everywhere.  `order` additionally makes all
-    // plain global stores issued before the call visible to all lanes after it.
-    __device__ void exchange(double& a, double& b, double& mx, bool order) {
+    // All lanes call.  On return wave 0 of every workgroup holds the first K of (sum a, sum b,
+    // max mx) over the whole grid, bit-identical in every workgroup; the other waves hold
+    // garbage.  Must be paired with finish_wave0(sync) before the workgroup's next barrier.
+    template <int K>
+    __device__ void to_wave0(double& a, double& b, double& mx, int sync) {
         const long long t0 = coop_clock();
-        long long t1 = t0, t2 = t0, t3 = t0;
-        a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
+        long long t1 = t0, t2 = t0;
         const int w = tid >> 6, lane = tid & 63;
-        if (lane == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
-        if (order) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+        a = wave_sum(a);
+        if constexpr (K >= 2) b = wave_sum(b);
+        if constexpr (K >= 3) mx = wave_max(mx);
+        if (lane == 0) {
+            red[parity][0][w] = a;
+            if constexpr (K >= 2) red[parity][1][w] = b;
+            if constexpr (K >= 3) red[parity][2][w] = mx;
+        }
+        if (sync != SYNC_NONE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
         __syncthreads();
-        const int buf = epoch % 3u;
+        const int buf = epoch & (COOP_NBUF - 1);
         t1 = coop_clock();
         if (w == 0) {
             double ra = 0.0, rb = 0.0, rm = 0.0;
-            const int nwv = blockDim.x >> 6;
-            for (int i = 0; i < nwv; ++i) { ra += red[parity][0][i]; rb += red[parity][1][i]; rm = fmax(rm, red[parity][2][i]); }
+            combine_waves<K>(red[parity], blockDim.x >> 6, ra, rb, rm);
+            const long long t1a = coop_clock();
+            tm[10] += t1a - t1;
             if (lane == 0) {
-                if (order) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // re-arm stores + payload are out
-                unsigned long long ua = __double_as_longlong(ra), ub = __double_as_longlong(rb), um = __double_as_longlong(rm);
-                if (ua == COOP_SENTINEL) ua = COOP_CANON_NAN;
-                if (ub == COOP_SENTINEL) ub = COOP_CANON_NAN;
-                if (um == COOP_SENTINEL) um = COOP_CANON_NAN;
-                __hip_atomic_store(gran(buf, 0, wg), ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(buf, 1, wg), ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(buf, 2, wg), um, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (this lane's re-arming stores to these granules were issued three exchanges
+                // ago and have been waited for, see finish_wave0)
+                if (sync == SYNC_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                tm[11] += coop_clock() - t1a;
+                publish(gran(buf, 0, wg), ra);
+                if constexpr (K >= 2) publish(gran(buf, 1, wg), rb);
+                if constexpr (K >= 3) publish(gran(buf, 2, wg), rm);
             }
             // sweep: lane l looks after workgroups l, l+64, ...
             t2 = coop_clock();
@@ -91,6 +116,7 @@ struct GridSync {
             unsigned spins = 0;
             bool ok = !dead;
             const int per = (nwg + 63) >> 6;
+            // a store needs about this long to land; polling earlier only slows it down
             for (int d = 0; d < poll_delay; d += 8) __builtin_amdgcn_s_sleep(8);
             while (!dead) {
                 ++tm[6];
@@ -104,8 +130,8 @@ struct GridSync {
                         const int ww = lane + (j << 6);
                         const int wc = ww < nwg ? ww : 0;
                         va[j] = __hip_atomic_load(gran(buf, 0, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vb[j] = __hip_atomic_load(gran(buf, 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vm[j] = __hip_atomic_load(gran(buf, 2, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (K >= 2) vb[j] = __hip_atomic_load(gran(buf, 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (K >= 3) vm[j] = __hip_atomic_load(gran(buf, 2, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 ok = true;
@@ -113,10 +139,13 @@ struct GridSync {
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
                     if (j < per) {
-                        ok = ok && va[j] != COOP_SENTINEL && vb[j] != COOP_SENTINEL && vm[j] != COOP_SENTINEL;
+                        ok = ok && va[j] != COOP_SENTINEL;
+                        if constexpr (K >= 2) ok = ok && vb[j] != COOP_SENTINEL;
+                        if constexpr (K >= 3) ok = ok && vm[j] != COOP_SENTINEL;
                         if (lane + (j << 6) < nwg) {
-                            sa += __longlong_as_double(va[j]); sb += __longlong_as_double(vb[j]);
-                            sm = fmax(sm, __longlong_as_double(vm[j]));
+                            sa += __longlong_as_double(va[j]);
+                            if constexpr (K >= 2) sb += __longlong_as_double(vb[j]);
+                            if constexpr (K >= 3) sm = fmax(sm, __longlong_as_double(vm[j]));
                         }
                     }
                 }
@@ -131,32 +160,64 @@ struct GridSync {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            ok = __all(ok);
-            t3 = coop_clock();
-            sa = wave_sum(sa); sb = wave_sum(sb); sm = wave_max(sm);
-            if (lane == 0) {
-                bcast[parity * 4 + 0] = sa; bcast[parity * 4 + 1] = sb; bcast[parity * 4 + 2] = sm;
-                bcast[parity * 4 + 3] = ok ? 1.0 : 0.0;
-                if (order) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // re-arm my granules two exchanges ahead (safe: everybody has consumed that buffer)
-                const int nb = (epoch + 2u) % 3u;
-                __hip_atomic_store(gran(nb, 0, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(nb, 1, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gran(nb, 2, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (!__all(ok)) dead = true;
+            a = wave_sum(sa);
+            if constexpr (K >= 2) b = wave_sum(sb);
+            if constexpr (K >= 3) mx = wave_max(sm);
         }
-        __syncthreads();
-        a = bcast[parity * 4 + 0]; b = bcast[parity * 4 + 1]; mx = bcast[parity * 4 + 2];
-        if (bcast[parity * 4 + 3] == 0.0) dead = true;
+        const long long t3 = coop_clock();
+        tm[1] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; ++tm[5];
+    }
+    __device__ static void publish(gu64* g, double v) {
+        unsigned long long u = __double_as_longlong(v);
+        if (u == COOP_SENTINEL) u = COOP_CANON_NAN;   // the one NaN pattern that means "not yet"
+        __hip_atomic_store(g, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // Acquire side of an ordered exchange, and re-arming of this workgroup's granules three
+    // exchanges ahead (see the header).  All lanes advance epoch / parity.
+    __device__ void finish_wave0(int sync) {
+        if (tid == 0) {
+            if (sync == SYNC_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous re-arming stores: an exchange old
+            const int nb = (epoch + 3u) & (COOP_NBUF - 1);
+            __hip_atomic_store(gran(nb, 0, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gran(nb, 1, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gran(nb, 2, wg), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         parity ^= 1;
         ++epoch;
-        const long long t4 = coop_clock();
-        tm[1] += t1 - t0; tm[2] += t2 - t1; tm[3] += t3 - t2; tm[4] += t4 - t3; ++tm[5];
     }
-    __device__ void barrier_ordered() {
+
+    // Sum (k = 0,1) / max (k = 2) of one value per workgroup, delivered to every lane of every
+    // workgroup.
+    __device__ void exchange(double& a, double& b, double& mx, int sync) {
+        const long long t3 = coop_clock();
+        to_wave0<3>(a, b, mx, sync);
+        if (tid == 0) {
+            bcast[parity * 4 + 0] = a; bcast[parity * 4 + 1] = b; bcast[parity * 4 + 2] = mx;
+            bcast[parity * 4 + 3] = dead ? 0.0 : 1.0;
+        }
+        const int par = parity;
+        finish_wave0(sync);
+        __syncthreads();
+        a = bcast[par * 4 + 0]; b = bcast[par * 4 + 1]; mx = bcast[par * 4 + 2];
+        if (bcast[par * 4 + 3] == 0.0) dead = true;
+        tm[4] += coop_clock() - t3;
+    }
+    // a grid-wide barrier that orders memory as `sync` says; no payload
+    __device__ void barrier(int sync) {
         double a = 0.0, b = 0.0, c = 0.0;
-        exchange(a, b, c, true);
+        const long long t3 = coop_clock();
+        to_wave0<1>(a, b, c, sync);
+        if (tid == 0) bcast[parity * 4 + 3] = dead ? 0.0 : 1.0;
+        const int par = parity;
+        finish_wave0(sync);
+        __syncthreads();
+        if (bcast[par * 4 + 3] == 0.0) dead = true;
+        tm[4] += coop_clock() - t3;
     }
+    __device__ void barrier_ordered() { barrier(SYNC_FENCE); }
 
 };
 

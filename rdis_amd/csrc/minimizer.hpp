@@ -50,14 +50,17 @@ enum : int {
 
 struct Request {
     int kind;
-    double a;
     bool restore;
     bool line;           // an evaluation on the current line (recorded in the trace)
     int pre_tag;         // optional trace record of an evaluation whose value was already known
-    double pre_a, pre_b, pre_c;  //   (emitted first)
     int tr_tag;          // optional trace record emitted before the request is served
-    double tr_a, tr_b, tr_c;
+    double a;
+    double pre_a, pre_b, pre_c;  // (emitted first; meaningful only when pre_tag is set)
+    double tr_a, tr_b, tr_c;     // (meaningful only when tr_tag is set)
 };
+
+// keeps a value in a vector register, hides its origin from the optimiser
+__device__ __forceinline__ void opaque(double& v) { asm("" : "+v"(v)); }
 
 struct CgdMachine {
     enum : int {
@@ -126,50 +129,60 @@ struct CgdMachine {
         // next trial point), ~85 % of all steps.  Written with selects instead of branches -- a
         // taken branch costs this single in-order wave more than the arithmetic it skips -- and
         // with exactly the operations of the branchy form below (S_DB_EVAL / S_DB_HEAD).
-        if (st == S_DB_EVAL && !(tiny && r0 > fx) && it + 1 < DB_ITMAX) {
-            const double fu = r0, du = r1;
-            saw_nan = saw_nan || (r0 != r0);
-            ++ngeval;
-            const bool le = fu <= fx;
-            const bool right = uu >= x, left = uu < x;
-            const double a1 = le ? (right ? x : a) : (left ? uu : a);
-            const double b1 = le ? (right ? b : x) : (left ? b : uu);
-            const bool c1 = !le && (fu <= fw || w == x);
-            const bool c2 = !le && !c1 && (fu < fv || v == x || v == w);
-            const bool vw = le || c1;           // v <- w
-            const double v1 = vw ? w : (c2 ? uu : v), fv1 = vw ? fw : (c2 ? fu : fv), dv1 = vw ? dw : (c2 ? du : dv);
-            const double w1 = le ? x : (c1 ? uu : w), fw1 = le ? fx : (c1 ? fu : fw), dw1 = le ? dx : (c1 ? du : dw);
-            const double x1 = le ? uu : x, fx1 = le ? fu : fx, dx1 = le ? du : dx;
-            a = a1; b = b1; v = v1; fv = fv1; dv = dv1; w = w1; fw = fw1; dw = dw1; x = x1; fx = fx1; dx = dx1;
-            ++it;
-            // S_DB_HEAD
-            const double xm = 0.5 * (a + b);
-            const double tol1 = TOL * fabs(x) + ZEPS;
-            const double tol2 = 2.0 * tol1;
-            if (!(fabs(x - xm) <= (tol2 - 0.5 * (b - a)))) {
-                const bool big = fabs(e) > tol1;
-                const double dflt = 2.0 * (b - a);
-                const double q1 = (w - x) * dx / (dx - dw);
-                const double q2 = (v - x) * dx / (dx - dv);
-                const double d1 = (dw != dx) ? q1 : dflt;
-                const double d2 = (dv != dx) ? q2 : dflt;
-                const double u1 = x + d1, u2 = x + d2;
-                const bool ok1 = (a - u1) * (u1 - b) > 0.0 && dx * d1 <= 0.0;
-                const bool ok2 = (a - u2) * (u2 - b) > 0.0 && dx * d2 <= 0.0;
-                const double dsel = (ok1 && ok2) ? (fabs(d1) < fabs(d2) ? d1 : d2) : (ok1 ? d1 : d2);
-                const bool accept = big && (ok1 || ok2) && (fabs(dsel) <= fabs(0.5 * e));
-                const double ut = x + dsel;
-                const double dacc = (ut - a < tol2 || b - ut < tol2) ? copysign(tol1, xm - x) : dsel;
-                const double ebis = (dx >= 0.0 ? a - x : b - x);
-                const double enew = accept ? d : ebis;
-                const double dnew = accept ? dacc : 0.5 * ebis;
-                e = enew; d = dnew;
-                tiny = !(fabs(d) >= tol1);
-                uu = tiny ? x + copysign(tol1, d) : x + d;
-                st = S_DB_EVAL;
-                return with_pending(want_fd(uu));
+        if (st == S_DB_EVAL) {
+            // the whole Brent state is loaded once, up front (the loads overlap) and made opaque:
+            // left to itself the compiler turns every select between two fields into a select
+            // between two LDS addresses followed by a dependent load
+            double a_ = a, b_ = b, x_ = x, w_ = w, v_ = v, fx_ = fx, fw_ = fw, fv_ = fv;
+            double dx_ = dx, dw_ = dw, dv_ = dv, d_ = d, e_ = e, uu_ = uu;
+            opaque(a_); opaque(b_); opaque(x_); opaque(w_); opaque(v_); opaque(fx_); opaque(fw_); opaque(fv_);
+            opaque(dx_); opaque(dw_); opaque(dv_); opaque(d_); opaque(e_); opaque(uu_);
+            const bool tiny_ = tiny;
+            const int it_ = it;
+            if (!(tiny_ && r0 > fx_) && it_ + 1 < DB_ITMAX) {
+                const double fu = r0, du = r1;
+                if (r0 != r0) saw_nan = true;
+                ++ngeval;
+                const bool le = fu <= fx_;
+                const bool right = uu_ >= x_, left = uu_ < x_;
+                const double a1 = le ? (right ? x_ : a_) : (left ? uu_ : a_);
+                const double b1 = le ? (right ? b_ : x_) : (left ? b_ : uu_);
+                const bool c1 = !le && (fu <= fw_ || w_ == x_);
+                const bool c2 = !le && !c1 && (fu < fv_ || v_ == x_ || v_ == w_);
+                const bool vw = le || c1;           // v <- w
+                const double v1 = vw ? w_ : (c2 ? uu_ : v_), fv1 = vw ? fw_ : (c2 ? fu : fv_), dv1 = vw ? dw_ : (c2 ? du : dv_);
+                const double w1 = le ? x_ : (c1 ? uu_ : w_), fw1 = le ? fx_ : (c1 ? fu : fw_), dw1 = le ? dx_ : (c1 ? du : dw_);
+                const double x1 = le ? uu_ : x_, fx1 = le ? fu : fx_, dx1 = le ? du : dx_;
+                a = a1; b = b1; v = v1; fv = fv1; dv = dv1; w = w1; fw = fw1; dw = dw1; x = x1; fx = fx1; dx = dx1;
+                it = it_ + 1;
+                // S_DB_HEAD
+                const double xm = 0.5 * (a1 + b1);
+                const double tol1 = TOL * fabs(x1) + ZEPS;
+                const double tol2 = 2.0 * tol1;
+                if (!(fabs(x1 - xm) <= (tol2 - 0.5 * (b1 - a1)))) {
+                    const bool big = fabs(e_) > tol1;
+                    const double dflt = 2.0 * (b1 - a1);
+                    const double q1 = (w1 - x1) * dx1 / (dx1 - dw1);
+                    const double q2 = (v1 - x1) * dx1 / (dx1 - dv1);
+                    const double d1 = (dw1 != dx1) ? q1 : dflt;
+                    const double d2 = (dv1 != dx1) ? q2 : dflt;
+                    const double u1 = x1 + d1, u2 = x1 + d2;
+                    const bool ok1 = (a1 - u1) * (u1 - b1) > 0.0 && dx1 * d1 <= 0.0;
+                    const bool ok2 = (a1 - u2) * (u2 - b1) > 0.0 && dx1 * d2 <= 0.0;
+                    const double dsel = (ok1 && ok2) ? (fabs(d1) < fabs(d2) ? d1 : d2) : (ok1 ? d1 : d2);
+                    const bool accept = big && (ok1 || ok2) && (fabs(dsel) <= fabs(0.5 * e_));
+                    const double ut = x1 + dsel;
+                    const double dacc = (ut - a1 < tol2 || b1 - ut < tol2) ? copysign(tol1, xm - x1) : dsel;
+                    const double ebis = (dx1 >= 0.0 ? a1 - x1 : b1 - x1);
+                    const double enew = accept ? d_ : ebis;
+                    const double dnew = accept ? dacc : 0.5 * ebis;
+                    const bool tn = !(fabs(dnew) >= tol1);
+                    const double un = tn ? x1 + copysign(tol1, dnew) : x1 + dnew;
+                    e = enew; d = dnew; tiny = tn; uu = un;
+                    return with_pending(want_fd(un));   // st stays S_DB_EVAL
+                }
+                st = S_DB_HEAD;  // converged: the generic code below finishes the line search
             }
-            st = S_DB_HEAD;  // converged: the generic code below finishes the line search
         }
         for (;;) {
             switch (st) {
@@ -404,7 +417,8 @@ struct CgdMachine {
 
 // The driver: the single place where each heavy operation is instantiated.
 // Env provides eval_value / eval_value_slope / gradient_to_xi / cg_start /
-// line_begin / line_end / cg_reduce / cg_update / trace / aborted.
+// line_begin / line_end / cg_reduce / cg_update / trace / aborted.  Replies (values, slopes,
+// reductions) and aborted() need only be valid in wave 0, the one wave that consumes them.
 //
 // The machine's ~40 doubles of state live in LDS and only wave 0 of a workgroup
 // steps it (the other waves would compute the same thing); the request is handed to
@@ -413,7 +427,12 @@ struct CgdMachine {
 // one step of the machine (wave 0 only); the request goes to the other waves through LDS
 __device__ __forceinline__ void step_machine(CgdMachine* __restrict__ M, Request* __restrict__ out, double r0, double r1, double r2) {
     const Request nq = M->next(r0, r1, r2);
-    if ((threadIdx.x & 63) == 0) *out = nq;
+    if ((threadIdx.x & 63) == 0) {
+        out->kind = nq.kind; out->restore = nq.restore; out->line = nq.line;
+        out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a;
+        if (nq.pre_tag != TR_NONE) { out->pre_a = nq.pre_a; out->pre_b = nq.pre_b; out->pre_c = nq.pre_c; }
+        if (nq.tr_tag != TR_NONE) { out->tr_a = nq.tr_a; out->tr_b = nq.tr_b; out->tr_c = nq.tr_c; }
+    }
 }
 
 __device__ __forceinline__ double uniform(double v) {  // a wave-uniform value into scalar registers
@@ -431,7 +450,13 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
     if (stepper) M.init(maxiters, ftol);
     for (int round = 0;; ++round) {
         const long long ts0 = E.clock();
-        if (stepper) step_machine(&M, &Q[round & 1], r0, r1, r2);
+        if (stepper) {
+            step_machine(&M, &Q[round & 1], r0, r1, r2);
+            if (E.aborted() && (threadIdx.x & 63) == 0) {  // only this wave is certain to know
+                Q[round & 1].kind = REQ_DONE;
+                M.reason = EXIT_SYNC_TIMEOUT; M.rolled_back = true;
+            }
+        }
         const long long ts1 = E.clock();
         __syncthreads();
         const Request& q = Q[round & 1];
@@ -442,28 +467,34 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         const int kind = __builtin_amdgcn_readfirstlane(q.kind);
         const double qa = uniform(q.a);
         E.tick(8, ts1 - ts0); E.tick(9, E.clock() - ts1);
-        if (kind == REQ_DONE || E.aborted()) break;
+        if (kind == REQ_DONE) break;
+        const long long th0 = E.clock();
+#define RDIS_TICK_KIND(K) E.tick(12 + K, E.clock() - th0); E.tick(22 + K, 1)
         switch (kind) {
         case REQ_F:
             r0 = uniform(E.eval_value(qa, q.restore));
             if (q.line) E.trace(TR_F, qa, r0, 0.0);
+            RDIS_TICK_KIND(REQ_F);
             break;
         case REQ_FD:
             E.eval_value_slope(qa, r0, r1);
             r0 = uniform(r0); r1 = uniform(r1);
             E.trace(TR_FD, qa, r0, r1);
+            RDIS_TICK_KIND(REQ_FD);
             break;
-        case REQ_GRAD: E.gradient_to_xi(); break;
-        case REQ_CG_START: E.cg_start(); break;
-        case REQ_LINE_BEGIN: E.line_begin(); break;
-        case REQ_LINE_END: E.line_end(qa); break;
+        case REQ_GRAD: E.gradient_to_xi(); RDIS_TICK_KIND(REQ_GRAD); break;
+        case REQ_CG_START: E.cg_start(); RDIS_TICK_KIND(REQ_CG_START); break;
+        case REQ_LINE_BEGIN: E.line_begin(); RDIS_TICK_KIND(REQ_LINE_BEGIN); break;
+        case REQ_LINE_END: E.line_end(qa); RDIS_TICK_KIND(REQ_LINE_END); break;
         case REQ_CG_REDUCE:
             E.cg_reduce(qa, r0, r1, r2);
             r0 = uniform(r0); r1 = uniform(r1); r2 = uniform(r2);
+            RDIS_TICK_KIND(REQ_CG_REDUCE);
             break;
-        case REQ_CG_UPDATE: E.cg_update(qa); break;
+        case REQ_CG_UPDATE: E.cg_update(qa); RDIS_TICK_KIND(REQ_CG_UPDATE); break;
         default: break;
         }
+#undef RDIS_TICK_KIND
     }
     __syncthreads();  // M is final and visible to every lane
 }

@@ -576,7 +576,7 @@ int ensure_problem_scratch(rdis_hip_problem* p) {
     if (!p->dir.p) {
         int rc = dalloc(c, p->dir, (size_t)p->N * sizeof(double));
         if (!rc) rc = dalloc(c, p->coop_state, coop_state_bytes());
-        if (!rc) rc = dalloc(c, p->coop_timing, 128);
+        if (!rc) rc = dalloc(c, p->coop_timing, COOP_TM * sizeof(long long));
         if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(p->dir.p, 0, p->dir.bytes, c->stream));
         HIPCHK(c, hipEventCreate(&p->ev0));
@@ -1016,10 +1016,10 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
     return 0;
 }
 
-extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out8) {
-    if (!L || !out8) return RDIS_HIP_EINVAL;
+extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out32) {
+    if (!L || !out32) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
-    HIPCHK(c, hipMemcpyAsync(out8, L->prob->coop_timing.p, 96, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out32, L->prob->coop_timing.p, COOP_TM * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -80,7 +80,11 @@ struct CoopEnv {
     }
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return X.dead; }
-    __device__ void tick(int slot, long long dt) { X.tm[slot] += dt; }
+    __device__ void tick(int slot, long long dt) {
+#ifdef RDIS_COOP_TIMING
+        X.tm[slot] += dt;
+#endif
+    }
     __device__ long long clock() const { return coop_clock(); }
 
     // ---- evaluation at clamp(base + a*dir), straight from registers ---------------
@@ -110,7 +114,8 @@ struct CoopEnv {
             }
         }
         X.tm[0] += coop_clock() - tc0;
-        X.exchange(fj, sj, dummy, false);
+        X.to_wave0<SLOPE ? 2 : 1>(fj, sj, dummy, SYNC_NONE);  // only the stepping wave consumes a line-search value
+        X.finish_wave0(SYNC_NONE);
         f = fj; s = sj;
     }
     __device__ double eval_value(double a, bool restore) {
@@ -154,6 +159,7 @@ struct CoopEnv {
     }
 
     __device__ void gradient_to_xi() {
+        const long long tg0 = coop_clock();
         if (has_fac) {
             double v[12], g[12];
 #pragma unroll
@@ -161,30 +167,27 @@ struct CoopEnv {
             ba_eval_grad(v, ox, oy, g);
             const int* sp = L.slot_pos + L.slot_base[c0 + gt];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) L.gfac[t] = g[k]; }
+            for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) store_f64<true>(L.gfac + t, g[k]); }
         }
-        X.barrier_ordered();
+        const long long tg1 = coop_clock();
+        X.barrier(SYNC_DRAIN);   // the partials are written and read with coherent accesses
+        const long long tg2 = coop_clock();
         const int* vp = L.v2s_ptr + f0;
         if (lv.li >= 0) {  // few partials: serial, in factor-list order (src/State.h:157-210)
-            const int b = vp[lv.li], e = vp[lv.li + 1];
-            double s = 0.0;
-            if (b < e) {
-                s = L.gfac[b];
-                for (int k = b + 1; k < e; ++k) s += L.gfac[k];
-            }
-            lv.xi = s;
+            lv.xi = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         }
         if (wv.li >= 0) {  // many partials: the wave strides over the run, then a butterfly (fixed order)
-            const int b = vp[wv.li], e = vp[wv.li + 1];
-            double s = 0.0;
-            for (int k = b + (tid & 63); k < e; k += 64) s += L.gfac[k];
-            wv.xi = wave_sum(s);
+            wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
         }
+        tick(20, tg1 - tg0); tick(21, tg2 - tg1); tick(30, coop_clock() - tg2);
     }
     __device__ void publish_xi() {
-        if (lv.li >= 0) A.xi_glob[lv.li] = lv.xi;
-        if (wv.li >= 0 && (tid & 63) == 0) A.xi_glob[wv.li] = wv.xi;
-        X.barrier_ordered();
+        if (lv.li >= 0) store_f64<true>(A.xi_glob + lv.li, lv.xi);
+        if (wv.li >= 0 && (tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, wv.xi);
+        // no payload; the workgroup barrier that hands out the next request closes it
+        double a = 0.0, b = 0.0, c = 0.0;
+        X.to_wave0<1>(a, b, c, SYNC_DRAIN);
+        X.finish_wave0(SYNC_DRAIN);
     }
     __device__ void cg_start() {
         { const double t = -lv.xi; lv.g = t; lv.h = t; lv.xi = t; }
@@ -195,7 +198,7 @@ struct CoopEnv {
         if (has_fac) {
             const int* sl = A.slot_li + 12ll * gt;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int li = sl[k]; dirv[k] = li >= 0 ? A.xi_glob[li] : 0.0; }
+            for (int k = 0; k < 12; ++k) { const int li = sl[k]; dirv[k] = li >= 0 ? load_f64<true>(A.xi_glob + li) : 0.0; }
         }
         if (L.vdump != nullptr && lm_count < L.dump_iters) {
             double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;
@@ -227,7 +230,8 @@ struct CoopEnv {
             a = a + wv.g * wv.g;
             b = b + (wv.xi + wv.g) * wv.xi;
         }
-        X.exchange(a, b, t, false);
+        X.to_wave0<3>(a, b, t, SYNC_NONE);
+        X.finish_wave0(SYNC_NONE);
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {
@@ -272,9 +276,8 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     __shared__ Request Q[2];
     E.init_vectors();
     run_machine(E, M, Q, maxiters, ftol);
-    int status = M.status();
-    if (E.X.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
-    const bool restore = M.rolled_back || E.X.dead;
+    const int status = M.status();   // a failed exchange is recorded in M by the stepping wave
+    const bool restore = M.rolled_back;
     E.write_back(E.lv, restore, true);
     E.write_back(E.wv, restore, (threadIdx.x & 63) == 0);
     if (gt == 0) {
@@ -282,7 +285,7 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
         L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
         E.X.tm[7] = coop_clock() - tk0;
-        if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.X.tm[i];
+        if (A.timing) for (int i = 0; i < COOP_TM; ++i) A.timing[i] = E.X.tm[i];
     }
 }
 

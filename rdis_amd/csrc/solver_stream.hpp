@@ -52,7 +52,11 @@ struct StreamEnv {
     }
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return X.dead; }
-    __device__ void tick(int slot, long long dt) { X.tm[slot] += dt; }
+    __device__ void tick(int slot, long long dt) {
+#ifdef RDIS_COOP_TIMING
+        X.tm[slot] += dt;
+#endif
+    }
     __device__ long long clock() const { return coop_clock(); }
 
     // SubfunctionFD::quickAssignVals (reference CGDSubspaceOptimizer.cpp:160-184) across the grid
@@ -85,7 +89,7 @@ struct StreamEnv {
             if constexpr (SLOPE) as += sj;
         }
         X.tm[0] += coop_clock() - tc0;
-        X.exchange(af, as, dummy, false);
+        X.exchange(af, as, dummy, SYNC_NONE);
         f = af; s = as;
     }
     __device__ double eval_value(double a, bool restore) {
@@ -112,8 +116,7 @@ struct StreamEnv {
             if (e - b > STREAM_LONG_LIST) continue;
             double s = 0.0;
             if (b < e) {
-                s = L.gfac[b];
-                for (int k = b + 1; k < e; ++k) s += L.gfac[k];
+                s = run_sum_ordered(L.gfac, b, e);
             }
             xi[i] = s;
         }
@@ -121,9 +124,7 @@ struct StreamEnv {
         for (int q = gw; q < A.nlong; q += nw) {  // long runs: a wave strides over the run, then a butterfly
             const int i = A.long_vars[q];
             const int b = vptr[i], e = vptr[i + 1];
-            double s = 0.0;
-            for (int k = b + lane; k < e; k += 64) s += L.gfac[k];
-            s = wave_sum(s);
+            const double s = wave_sum(run_sum_strided(L.gfac, b, e, lane));
             if (lane == 0) xi[i] = s;
         }
         X.barrier_ordered();  // the long runs were summed by other lanes than their owners
@@ -161,7 +162,7 @@ struct StreamEnv {
                 b = b + (x + gi) * x;
             }
         }
-        X.exchange(a, b, t, false);
+        X.exchange(a, b, t, SYNC_NONE);
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {
@@ -196,8 +197,7 @@ cgd_stream_kernel(ProblemView P, PlanView L, StreamArgs A, int maxiters, double 
     E.init_vectors();
     run_machine(E, M, Q, maxiters, ftol);
     int status = M.status();
-    if (E.X.dead) status = EXIT_SYNC_TIMEOUT | STATUS_ROLLED_BACK;
-    const bool restore = M.rolled_back || E.X.dead;
+    const bool restore = M.rolled_back;
     for (int i = gt; i < n; i += gsz) {
         const int v = E.fv[i];
         const double xf = clampd(restore ? E.xinit[i] : E.p[i], P.lo[v], P.hi[v]);
@@ -210,7 +210,7 @@ cgd_stream_kernel(ProblemView P, PlanView L, StreamArgs A, int maxiters, double 
         L.status[comp] = status; L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
         E.X.tm[7] = coop_clock() - tk0;
-        if (A.timing) for (int i = 0; i < 12; ++i) A.timing[i] = E.X.tm[i];
+        if (A.timing) for (int i = 0; i < COOP_TM; ++i) A.timing[i] = E.X.tm[i];
     }
 }
 

@@ -8,7 +8,7 @@
 //   phase B  every factor: gather 12 values of x, evaluate; for Brent also the 12
 //            partials dotted with the search direction -> the slope along the line
 //            needs no scatter at all
-//   reduce   wave butterfly + LDS, fixed order => bit-reproducible run to run
+//   reduce   wave reduction (DPP) + LDS, fixed order => bit-reproducible run to run
 // The full gradient is needed once per CG iteration only: per-factor partials go
 // to gfac[], then each free variable sums its slots in factor-list order (the same
 // order the reference's PartialGradient merge produces, src/State.h:157-210).
@@ -21,15 +21,106 @@ namespace rdis_hip {
 
 constexpr int MAX_WAVES = 16;
 
+// Wave-wide reductions; every lane of a full wave returns the same bits.  Within a row of 16
+// lanes the partner comes through DPP (quad_perm / row_half_mirror / row_mirror: an ALU-speed
+// move, where a ds_bpermute shuffle costs an LDS round trip per step); the four row sums are
+// then read as scalars and combined in a fixed order.  Must be called with all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;            // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;  // lane i <-> 7-i, i <-> 15-i in its row
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_move<DPP_XOR1>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    v += dpp_move<DPP_HALF_MIRROR>(v);
+    v += dpp_move<DPP_MIRROR>(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_move<DPP_XOR1>(v));
+    v = fmax(v, dpp_move<DPP_XOR2>(v));
+    v = fmax(v, dpp_move<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_move<DPP_MIRROR>(v));
+    return fmax(fmax(read_lane(v, 0), read_lane(v, 16)), fmax(read_lane(v, 32), read_lane(v, 48)));
+}
+
+// Combines the per-wave partials a workgroup left in LDS (one entry per wave, red[k][wave]):
+// lane i fetches entry i -- one LDS round trip instead of one per wave -- and, as there are at
+// most 16 waves, a reduction over the first row of lanes finishes the job.  Every wave that
+// calls it obtains the same bits.  K: 1 = a, 2 = a and b, 3 = a, b and the maximum mx.
+template <int K>
+__device__ __forceinline__ void combine_waves(const double (*red)[16], int nwaves, double& a, double& b, double& mx) {
+    const int lane = threadIdx.x & 63;
+    const bool in = lane < nwaves;
+    double va = in ? red[0][lane] : 0.0, vb = 0.0, vm = 0.0;
+    if constexpr (K >= 2) vb = in ? red[1][lane] : 0.0;
+    if constexpr (K >= 3) vm = in ? red[2][lane] : 0.0;
+    va += dpp_move<DPP_XOR1>(va); if constexpr (K >= 2) vb += dpp_move<DPP_XOR1>(vb); if constexpr (K >= 3) vm = fmax(vm, dpp_move<DPP_XOR1>(vm));
+    va += dpp_move<DPP_XOR2>(va); if constexpr (K >= 2) vb += dpp_move<DPP_XOR2>(vb); if constexpr (K >= 3) vm = fmax(vm, dpp_move<DPP_XOR2>(vm));
+    if (nwaves > 4) {
+        va += dpp_move<DPP_HALF_MIRROR>(va); if constexpr (K >= 2) vb += dpp_move<DPP_HALF_MIRROR>(vb); if constexpr (K >= 3) vm = fmax(vm, dpp_move<DPP_HALF_MIRROR>(vm));
+        va += dpp_move<DPP_MIRROR>(va); if constexpr (K >= 2) vb += dpp_move<DPP_MIRROR>(vb); if constexpr (K >= 3) vm = fmax(vm, dpp_move<DPP_MIRROR>(vm));
+    }
+    a = read_lane(va, 0);
+    if constexpr (K >= 2) b = read_lane(vb, 0);
+    if constexpr (K >= 3) mx = read_lane(vm, 0);
+}
+
+// Loads / stores that are coherent across the whole device without cache maintenance: relaxed
+// agent-scope atomics (write-through stores, loads that do not hit a stale line of this XCD's L2).
+template <bool COHERENT>
+__device__ __forceinline__ double load_f64(const double* p) {
+    if constexpr (COHERENT)
+        return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else
+        return *p;
+}
+template <bool COHERENT>
+__device__ __forceinline__ void store_f64(double* p, double v) {
+    if constexpr (COHERENT)
+        __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// Sum of the contiguous run g[b..e) in index order (factor-list order, src/State.h:157-210).
+// Eight loads are in flight at a time -- after an exchange every one of them comes from memory,
+// and one round trip per element is what a plain loop pays -- while the additions stay strictly
+// sequential, so the result has the bits of the plain loop.
+template <bool COHERENT = false>
+__device__ __forceinline__ double run_sum_ordered(const double* __restrict__ g, int b, int e) {
+    double s = 0.0;
+    for (int k0 = b; k0 < e; k0 += 8) {
+        double t[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+        for (int j = 0; j < 8; ++j) t[j] = (k0 + j < e) ? load_f64<COHERENT>(g + k0 + j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < e) s = (k0 + j == b) ? t[j] : s + t[j];
+    }
+    return s;
+}
+// This lane's share of a long run: elements b + lane, b + lane + 64, ... (four loads in flight)
+template <bool COHERENT = false>
+__device__ __forceinline__ double run_sum_strided(const double* __restrict__ g, int b, int e, int lane) {
+    double s = 0.0;
+    for (int k0 = b + lane; k0 < e; k0 += 256) {
+        double t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (k0 + 64 * j < e) ? load_f64<COHERENT>(g + k0 + 64 * j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + 64 * j < e) s += t[j];
+    }
+    return s;
 }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) {
@@ -151,11 +242,7 @@ struct WgEnv {
         const int w = tid >> 6;
         if ((tid & 63) == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
         __syncthreads();
-        double ra = 0.0, rb = 0.0, rm = 0.0;
-        for (int i = 0; i < nwaves; ++i) {
-            ra += red[parity][0][i]; rb += red[parity][1][i]; rm = fmax(rm, red[parity][2][i]);
-        }
-        a = ra; b = rb; mx = rm;
+        if (nwaves > 1) combine_waves<3>(red[parity], nwaves, a, b, mx);
         parity ^= 1;
     }
 
@@ -234,8 +321,7 @@ struct WgEnv {
             const int b = vptr[i], e = vptr[i + 1];
             double s = 0.0;
             if (b < e) {
-                s = L.gfac[b];
-                for (int k = b + 1; k < e; ++k) s += L.gfac[k];
+                s = run_sum_ordered(L.gfac, b, e);
             }
             xi[i] = s;
         }

@@ -4,10 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O
+if os.environ.get("RDIS_PROBE_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["RDIS_PROBE_LIB"])  # A/B builds
+if os.environ.get("RDIS_PROBE_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["RDIS_PROBE_LIB"])  # A/B builds
 ctx = capi.Context(0)
 pp = P.load_bal().single_component()
 g = capi.Problem(ctx, pp)
-for opts in [{"coop_poll_delay": d} for d in (12, 13)]:
+for opts in [{"coop_poll_delay": d} for d in (12, 16)]:
     plan = capi.Plan(g)
     for k, v in opts.items():
         plan.set_option(k, v)
@@ -21,6 +25,11 @@ for opts in [{"coop_poll_delay": d} for d in (12, 13)]:
         tm = plan.debug_counters()
         nx = max(int(tm[5]), 1)
         print("   total ticks %d => %.1f MHz tick rate; accounted %.0f%%" % (tm[7], tm[7] / (ms * 1e3), 100.0 * tm[:5].sum() / max(tm[7], 1)))
+        print("   publish: combine waves %.0f, release %.0f cycles" % (tm[10] / nx, tm[11] / nx))
+        names = ["F", "FD", "GRAD", "CG_START", "LINE_BEGIN", "LINE_END", "CG_REDUCE", "CG_UPDATE"]
+        print("   handlers: " + "  ".join("%s %d x %.0f" % (nm, tm[22 + i], tm[12 + i] / max(int(tm[22 + i]), 1)) for i, nm in enumerate(names)))
+        ng = max(int(tm[24]), 1)
+        print("   gradient: partials+scatter %.0f, barrier %.0f, gather %.0f cycles" % (tm[20] / ng, tm[21] / ng, tm[30] / ng))
         print("   state machine step %.0f, hand-over %.0f cycles per exchange" % (tm[8] / nx, tm[9] / nx))
         print("   cycles/exchange: compute %.0f local-reduce %.0f publish %.0f sweep %.0f tail %.0f | exchanges %d sweeps %d (%.1f per exchange)" % (
             tm[0] / nx, tm[1] / nx, tm[2] / nx, tm[3] / nx, tm[4] / nx, tm[5], tm[6], tm[6] / nx))
