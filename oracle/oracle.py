@@ -32,7 +32,8 @@ class ReplayReport(C.Structure):
                 ("max_iter_rel", C.c_double), ("max_vec_rel", C.c_double),
                 ("max_f_rel_near", C.c_double), ("max_slope_rel_near", C.c_double), ("last_near", C.c_int32),
                 ("synced_iters", C.c_int64),
-                ("pending_slope", C.c_double), ("max_f_far_ulps", C.c_double)]
+                ("pending_slope", C.c_double), ("max_f_far_ulps", C.c_double),
+                ("max_f_bound", C.c_double), ("max_slope_bound", C.c_double)]
 
     def __repr__(self):
         return "ReplayReport(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_ if n != "pending_slope") + ")"

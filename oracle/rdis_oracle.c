@@ -350,6 +350,75 @@ static double nlp_deriv(const ro_problem *p, int64_t f, int64_t wrt)
     return prod * p->coeff[f];
 }
 
+/* First-order bounds, in units of the machine epsilon, on how far two correct fp64 evaluations
+ * of one factor can lie apart: what a difference between this oracle and another implementation
+ * of the same formulas is measured against (parity tests; not part of the reference).
+ *
+ * Bundle adjustment: the camera-frame point P is a sum of O(|q|) terms; an absolute error
+ * eps*T_i in P_i becomes a relative error a_i = T_i/|P_i| + T_2/|P_2| (+2 for the roundings
+ * that follow) in the projection pp_i = -P_i/P_2 and in the pixel, i.e. |pix_i| a_i in the
+ * residual and |res_i| |pix_i| a_i in E.  The partials are proportional to the residual, whose
+ * relative error is (|pix|/|res|) a, and carry one more power of 1/P_2.
+ *   vb = |E| + sum_i |res_i| |pix_i| a_i          (bound on the value, / eps)
+ *   gb = 1 + a (|pix|/|res| + 2)                  (relative bound on each partial, / eps) */
+static void ba_bounds(const double x[12], double ox, double oy, double *vb, double *gb)
+{
+    ba_fwd t;
+    const double E = ba_forward(x, ox, oy, &t);
+    const double *q = x + 9, *tr = x + 3, *v = t.v;
+    const double omc = 1 - t.c;
+    double a[2], T[3];
+    for (int i = 0; i < 3; ++i)
+        T[i] = fabs(q[i]) + fabs(t.w[i]) + fabs(v[i] * t.d) + fabs(tr[i])
+             + (fabs(v[0] * q[0]) + fabs(v[1] * q[1]) + fabs(v[2] * q[2])) * (fabs(t.s) + fabs(v[i] * omc));
+    /* the pixel is pp times a polynomial in |pp|^2: up to the fifth power of pp */
+    const double sens = 1.0 + 2.0 * fabs(t.r2 * (x[7] + 2.0 * x[8] * t.r2)) / fabs(t.dstn);
+    for (int i = 0; i < 2; ++i) a[i] = (T[i] / fabs(t.P[i]) + T[2] / fabs(t.P[2])) * sens + 2.0;
+    const double pix0 = t.res[0] + ox, pix1 = t.res[1] + oy;
+    *vb = fabs(E) + fabs(t.res[0]) * fabs(pix0) * a[0] + fabs(t.res[1]) * fabs(pix1) * a[1];
+    const double am = a[0] > a[1] ? a[0] : a[1];
+    const double rr = hypot(t.res[0], t.res[1]);
+    *gb = 1.0 + am * (hypot(pix0, pix1) / rr + 2.0);
+    if (!(*vb == *vb)) *vb = INFINITY;
+    if (!(*gb == *gb)) *gb = INFINITY;
+}
+
+/* Nonlinear product: each term (x-k)^e carries about e+1 roundings; under a sine the absolute
+ * error of its argument u becomes |u|(e+1)/|sin u| relative.  The value bound is |f| times the
+ * sum over terms (+1 per multiplication); a partial is a product of the same kind. */
+static void nlp_bounds(const ro_problem *p, int64_t f, double *vb, double *gb)
+{
+    double rel = 1.0;
+    for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) {
+        double val = p->x[p->vid[k]];
+        double r = 1.0 + p->expo[k];
+        if (p->cons[k] != 0) { const double d = val - p->cons[k]; r += (fabs(val) + fabs(p->cons[k])) / fabs(d); val = d; }
+        if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
+        if (p->sine[k]) {
+            const double sn = fabs(sin(val)), cs = fabs(cos(val));
+            const double m = sn < cs ? sn : cs;   /* the derivative has the cosine */
+            r = r * fabs(val) / (m > 0 ? m : DBL_MIN) + 2.0;
+        }
+        rel += r + 1.0;
+    }
+    *vb = fabs(nlp_eval(p, f)) * rel;
+    *gb = rel + 2.0;
+    if (!(*vb == *vb)) *vb = INFINITY;
+    if (!(*gb == *gb)) *gb = INFINITY;
+}
+
+static void gather_ba(const ro_problem *p, int64_t f, double vals[12]);
+static void factor_bounds(const ro_problem *p, int64_t f, double *vb, double *gb)
+{
+    if (p->kind == RO_KIND_BA) {
+        double vals[12];
+        gather_ba(p, f, vals);
+        ba_bounds(vals, p->obs[2 * f], p->obs[2 * f + 1], vb, gb);
+    } else {
+        nlp_bounds(p, f, vb, gb);
+    }
+}
+
 static double factor_value_nocache(const ro_problem *p, int64_t f)
 {
     if (p->kind == RO_KIND_BA) {
@@ -857,8 +926,13 @@ static double replay_on_f(void *ctx, double a, double f_own)
     double sabs = 0.0;
     for (int64_t i = 0; i < R->S->nf; ++i)
         sabs += fabs(factor_value_nocache(R->S->p, R->S->fac ? R->S->fac[i] : i));
+    {
+        double B = 0.0, vb, gb;
+        for (int64_t i = 0; i < R->S->nf; ++i) { factor_bounds(R->S->p, R->S->fac ? R->S->fac[i] : i, &vb, &gb); B += vb; }
+        track(&R->rep->max_f_bound, f_own, r[2], DBL_EPSILON * B);
+        R->rep->last_near = B <= RO_NEAR_AMPLIFICATION * sabs && fabs(f_own) <= 4.0 * fabs(R->rep->finit) + 1.0;
+    }
     track(&R->rep->max_f_rel, f_own, r[2], sabs);
-    R->rep->last_near = fabs(f_own) <= 4.0 * fabs(R->rep->finit) + 1.0;
     if (R->rep->last_near) track(&R->rep->max_f_rel_near, f_own, r[2], sabs);
     else {
         /* a far-out trial point: how much does the objective move when every free variable
@@ -895,15 +969,21 @@ static double replay_on_slope(void *ctx, double s_own, double s_abs, const doubl
         double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
         int64_t vids[64]; double vals[64];
         for (int i = 0; i < n; ++i) dir[S->free_vid[i]] = xi[i];
-        double sc = 0.0;
+        double sc = 0.0, sb = 0.0;
         for (int64_t i = 0; i < S->nf; ++i) {
             const int64_t f = S->fac ? S->fac[i] : i;
             if (fac_arity(p, f) > 64) continue;
             const int k = factor_partials(p, f, vids, vals);
-            for (int j = 0; j < k; ++j) sc += fabs(vals[j] * dir[vids[j]]);
+            double t = 0.0, vb, gb;
+            for (int j = 0; j < k; ++j) t += fabs(vals[j] * dir[vids[j]]);
+            factor_bounds(p, f, &vb, &gb);
+            sc += t;
+            sb += t * gb;
         }
         free(dir);
         if (sc > s_abs) s_abs = sc;
+        if (R->rep->pending_slope == R->rep->pending_slope)
+            track(&R->rep->max_slope_bound, s_own, R->rep->pending_slope, DBL_EPSILON * (sb > 0 ? sb : s_abs));
     }
     if (dev != dev) { /* the device recorded a value-only evaluation here */
         if (R->rep->first_mismatch < 0) R->rep->first_mismatch = R->pos - 1;

@@ -115,6 +115,8 @@ int ro_frprmn(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
               int maxiters, double ftol, double *fret, int *iter);
 
 /* ---- replay of a device trace (see rdis_oracle.c) ---------------------------*/
+#define RO_NEAR_AMPLIFICATION 1.0e5
+
 typedef struct {
     int64_t consumed;        /* trace records consumed */
     int64_t first_mismatch;  /* index of the first record that did not line up, or -1 */
@@ -129,15 +131,20 @@ typedef struct {
     double max_slope_rel;    /* worst |s_own - s_dev| / sum|g_j xi_j| */
     double max_iter_rel;     /* worst relative difference of test / gg / dgg */
     double max_vec_rel;      /* worst drift of p / xi (inf-norm relative) before each re-sync */
-    double max_f_rel_near;   /* max_f_rel / max_slope_rel restricted to trial points with
-                                |f| <= 4 |f(x0)| + 1: far-out bracketing steps (f up to 1e4 x f(x0))
-                                evaluate the projection near its pole and are ill-conditioned */
+    double max_f_rel_near;   /* max_f_rel / max_slope_rel restricted to the ordinary trial points:
+                                |f| <= 4 |f(x0)| + 1 and a first-order rounding bound of the sum of at most
+                                RO_NEAR_AMPLIFICATION x eps x sum|factor values| (typically 2e3..3e4).
+                                Far-out bracketing steps (f up to 1e4 x f(x0)) and steps that put a point
+                                next to a camera's pole (P_z -> 0) are ill-conditioned */
     double max_slope_rel_near;
     int32_t last_near;       /* internal */
     int64_t synced_iters;    /* line searches started from the device's dumped p, xi */
     double pending_slope;    /* internal */
     double max_f_far_ulps;   /* far-out trial points: worst |f_own - f_dev| in units of (the change of f
                                 under a one-ulp move of every free variable + eps * sum|factor values|) */
+    double max_f_bound;      /* worst |f_own - f_dev| / (eps * first-order rounding bound of the sum at that
+                                point), all trial points: the conditioning-aware form of max_f_rel */
+    double max_slope_bound;  /* the same for the slope along the line */
 } ro_replay_report;
 
 /* vdump (may be NULL): the device's p and xi at the start of each of the first

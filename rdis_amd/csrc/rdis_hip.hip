@@ -942,7 +942,10 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             mf = std::max<int64_t>(mf, std::max(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
                                                 (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
         int threads = L->block_threads;
-        if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 2048 ? 512 : 1024;
+        // 1024 lanes only pay when the components are too few to fill the device: that build of the
+        // kernel has half the registers (and spills), 512 lanes with twice the resident workgroups win
+        if (threads == 0)
+            threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : (mf <= 2048 || 2 * rest > c->num_cus) ? 512 : 1024;
         int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
                                     : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
         if (rc) return rc;

@@ -166,8 +166,13 @@ struct CoopEnv {
             for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
             ba_eval_grad(v, ox, oy, g);
             const int* sp = L.slot_pos + L.slot_base[c0 + gt];
+            int t[12];  // all twelve destinations first: the loads overlap (the coherent stores
+                        // below are atomics, across which the compiler does not move a load)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int t = sp[k]; if (t >= 0) store_f64<true>(L.gfac + t, g[k]); }
+            for (int k = 0; k < 12; ++k) t[k] = sp[k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (t[k] >= 0) store_f64<true>(L.gfac + t[k], g[k]);
         }
         const long long tg1 = coop_clock();
         X.barrier(SYNC_DRAIN);   // the partials are written and read with coherent accesses
@@ -197,8 +202,14 @@ struct CoopEnv {
     __device__ void line_begin() {
         if (has_fac) {
             const int* sl = A.slot_li + 12ll * gt;
+            int li[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { const int li = sl[k]; dirv[k] = li >= 0 ? load_f64<true>(A.xi_glob + li) : 0.0; }
+            for (int k = 0; k < 12; ++k) li[k] = sl[k];
+            double d[12];   // unconditional, so that the twelve loads are in flight together
+#pragma unroll
+            for (int k = 0; k < 12; ++k) d[k] = load_f64<true>(A.xi_glob + (li[k] >= 0 ? li[k] : 0));
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dirv[k] = li[k] >= 0 ? d[k] : 0.0;
         }
         if (L.vdump != nullptr && lm_count < L.dump_iters) {
             double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;

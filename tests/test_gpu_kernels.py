@@ -119,6 +119,35 @@ def test_theta_zero_and_nlp_edge_cases(gctx):
     assert abs(f - o.eval()) <= 1e-13 * 10 and np.max(np.abs(gg - o.gradient())) <= 1e-13 * 10
 
 
+def test_rotation_angles_over_the_whole_domain(gctx):
+    """The device evaluates sin/cos of the rotation angle with its own routine (factors.hpp
+    sincos_angle).  Rotation vectors from 1e-9 rad to the edge of their domain (1000 pi,
+    BundleAdjustmentFunction.cpp:419-471), all quadrants, and beyond the routine's exact range
+    where it defers to the library: per-factor values and partials against the oracle's libm."""
+    rng = np.random.default_rng(11)
+    pp = P.make_synthetic_ba(1, 40, 60, obs_per_pt=6)
+    ncam = 40
+    mags = np.concatenate([10.0 ** rng.uniform(-9, 0, 10), rng.uniform(0.0, 2 * np.pi, 14),
+                           np.arange(1, 9) * (np.pi / 4) + rng.uniform(-1e-9, 1e-9, 8),   # quadrant edges
+                           rng.uniform(6.0, 3141.0, 6), [3.0e6, 1.0e9]])
+    assert len(mags) == ncam
+    for c in range(ncam):
+        d = rng.normal(size=3)
+        pp.x0[9 * c:9 * c + 3] = mags[c] * d / np.linalg.norm(d)
+    pp.lo[:], pp.hi[:] = -np.inf, np.inf
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    idx = np.arange(pp.nfac)
+    e_dev, e_orc = g.eval_each(idx), o.eval_each(idx)
+    g_dev, g_orc = g.grad_each_ba(idx), o.grad_each_ba(idx)
+    # the residual is a difference of pixel-scale numbers: scale with E + |projection|^2 ~ E + |obs|^2
+    scale = e_orc + np.sum(pp.obs ** 2, axis=1) + 1.0
+    ok = np.isfinite(e_orc)
+    assert ok.sum() >= 0.9 * pp.nfac
+    assert np.all(np.abs(e_dev - e_orc)[ok] <= 1e-12 * scale[ok])
+    gs = np.max(np.abs(g_orc), axis=1, keepdims=True) + 1.0
+    assert np.all(np.abs(g_dev - g_orc)[ok] <= 1e-11 * gs[ok])
+
+
 def test_abi_error_codes(gctx):
     pp = CASES["ladybug_5_30"]
     g = capi.Problem(gctx, pp)
