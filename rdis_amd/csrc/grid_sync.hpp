@@ -71,7 +71,7 @@ struct GridSync {
     bool dead;                          // a spin gave up: unwind quickly
     long long tm[COOP_TM]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
                       // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over,
-                      // 10 combine waves, 11 release, 12.. per request kind (REQ_F ..): handler cycles, 22.. their counts
+                      // 10 combine waves, 11 release, 12.. handler cycles: 12 value, 13 value+slope, 14 gradient (+reduce), 17 line end; 22.. their counts
 
     // ---- inter-workgroup exchange ------------------------------------------------
     __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][k][w]; }

@@ -36,25 +36,31 @@ constexpr int STATUS_ROLLED_BACK = 0x100;
 // trace record tags (the replay check in tests/ reads the same tags)
 enum : int { TR_NONE = 0, TR_F = 1, TR_FD = 2, TR_ITER = 3, TR_START = 4, TR_LINMIN = 5 };
 
+// What the machine asks the solver's lanes to do next.  A request is one evaluation or one
+// full gradient, optionally wrapped in the vector updates that surround it in the algorithm and
+// need no decision in between (every request costs a step of the machine and a hand-over):
+//   REQ_EVAL      [PRE_START | PRE_UPDATE(b = gamma)] [PRE_BEGIN]  value (+ slope) at step a
+//   REQ_GRAD      [PRE_LINE_END(a = step)]  xi <- grad f(clamp(p))  [POST_REDUCE(b = fp)]
+//   REQ_LINE_END  xi *= a; p += xi                                  (nrc :508-511)
+enum : int { REQ_EVAL = 0, REQ_GRAD, REQ_LINE_END, REQ_DONE };
 enum : int {
-    REQ_F = 0,        // value at clamp(p + a*xi); restore: at clamp(x_init) instead   reply r0 = f
-    REQ_FD,           // value and slope d/da at clamp(p + a*xi)                        reply r0 = f, r1 = slope
-    REQ_GRAD,         // xi <- grad f(clamp(p))                       (nrc :629, :654)
-    REQ_CG_START,     // g = -xi; xi = h = g                          (nrc :631-635)
-    REQ_LINE_BEGIN,   // a new line p + a*xi starts                   (nrc :496-498)
-    REQ_LINE_END,     // xi *= a; p += xi                             (nrc :508-511)
-    REQ_CG_REDUCE,    // a = fp: reply r0 = test, r1 = gg, r2 = dgg   (nrc :655-672)
-    REQ_CG_UPDATE,    // a = gamma: g = -xi; xi = h = g + gamma*h     (nrc :679-683)
-    REQ_DONE
+    RF_SLOPE = 1,          // also the slope d/da; reply r0 = f, r1 = slope  (else r0 = f)
+    RF_RESTORE = 2,        // evaluate at clamp(x_init) instead (the rollback, CGD .cpp:71)
+    RF_LINE = 4,           // an evaluation on the current line (recorded in the trace)
+    RF_PRE_START = 8,      // first: g = -xi; xi = h = g                   (nrc :631-635)
+    RF_PRE_UPDATE = 16,    // first: g = -xi; xi = h = g + b*h             (nrc :679-683)
+    RF_PRE_BEGIN = 32,     // then: a new line p + a*xi starts             (nrc :496-498)
+    RF_PRE_LINE_END = 64,  // REQ_GRAD: first xi *= a; p += xi             (nrc :508-511)
+    RF_POST_REDUCE = 128,  // REQ_GRAD: then reply r0 = test, r1 = gg, r2 = dgg with fp = b (nrc :655-672)
+    RF_TR_FIRST = 256      // emit the tr_ trace record before the pre_ one
 };
 
 struct Request {
     int kind;
-    bool restore;
-    bool line;           // an evaluation on the current line (recorded in the trace)
+    int flags;
     int pre_tag;         // optional trace record of an evaluation whose value was already known
     int tr_tag;          // optional trace record emitted before the request is served
-    double a;
+    double a, b;
     double pre_a, pre_b, pre_c;  // (emitted first; meaningful only when pre_tag is set)
     double tr_a, tr_b, tr_c;     // (meaningful only when tr_tag is set)
 };
@@ -64,9 +70,9 @@ __device__ __forceinline__ void opaque(double& v) { asm("" : "+v"(v)); }
 
 struct CgdMachine {
     enum : int {
-        S_BEGIN, S_FIRST, S_GRAD0, S_ITER_BEGIN, S_BR_START, S_BR_FB, S_BR_FC, S_BR_HEAD,
+        S_BEGIN, S_FIRST, S_GRAD0, S_BR_FB, S_BR_FC, S_BR_HEAD,
         S_BR_CASE1, S_BR_CASE2, S_BR_SHIFT, S_DB_START, S_DB_FIRST, S_DB_HEAD, S_DB_EVAL,
-        S_AFTER_LINMIN, S_GRAD_ITER, S_REDUCED, S_FINISH, S_ROLLED, S_DONE
+        S_AFTER_LINMIN, S_REDUCED, S_FINISH, S_ROLLED, S_DONE
     };
     int maxiters;
     double ftol;
@@ -99,8 +105,8 @@ struct CgdMachine {
     }
     __device__ int status() const { return reason | (rolled_back ? STATUS_ROLLED_BACK : 0); }
 
-    __device__ static Request req(int kind, double a = 0.0) {
-        Request r; r.kind = kind; r.a = a; r.restore = false; r.line = false;
+    __device__ static Request req(int kind, double a = 0.0, int flags = 0) {
+        Request r; r.kind = kind; r.a = a; r.b = 0.0; r.flags = flags;
         r.pre_tag = TR_NONE; r.pre_a = r.pre_b = r.pre_c = 0.0;
         r.tr_tag = TR_NONE; r.tr_a = r.tr_b = r.tr_c = 0.0;
         return r;
@@ -114,8 +120,37 @@ struct CgdMachine {
         r.tr_tag = tag; r.tr_a = ta; r.tr_b = tb; r.tr_c = tc;
         return r;
     }
-    __device__ Request want_f(double at, bool line = true) { ++nfeval; Request r = req(REQ_F, at); r.line = line; return r; }
-    __device__ Request want_fd(double at) { ++nfeval; Request r = req(REQ_FD, at); r.line = true; return r; }
+    __device__ Request want_f(double at, bool line = true) { ++nfeval; return req(REQ_EVAL, at, line ? RF_LINE : 0); }
+    __device__ Request want_fd(double at, int extra = 0) { ++nfeval; return req(REQ_EVAL, at, RF_SLOPE | RF_LINE | extra); }
+    // the bracketing of a new line starts from (0, 1); f at a = 0 is the value the previous line
+    // search ended on (or f(x0)): the same point, hence the same bits -- counted and traced like
+    // the reference's call (nrc :87) but not evaluated again.  Its slope is not known.
+    __device__ Request start_line(int pre_ops, double gamma) {
+        iter = its;
+        ax = 0.0; bx = 1.0;
+        fa = fp; sa = 0.0; va = false;
+        ++nfeval;
+        pp_tag = TR_F; pp_a = 0.0; pp_b = fp; pp_c = 0.0;
+        st = S_BR_FB;
+        Request r = with_pending(want_fd(bx, pre_ops | RF_PRE_BEGIN));
+        r.b = gamma;
+        return r;
+    }
+    // a line minimisation ended at step x with value fx (nrc :646-654): unless converged, move
+    // there, take the gradient and reduce it for the next direction in one request
+    __device__ Request line_done() {
+        if (2.0 * fabs(fx - fp) <= ftol * (fabs(fx) + fabs(fp) + 1.0e-18)) {
+            st = S_AFTER_LINMIN;  // finds the same and finishes
+            return traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0);
+        }
+        fret = fx;
+        fp = fret;
+        ++ngeval;
+        st = S_REDUCED;
+        Request r = req(REQ_GRAD, x, RF_PRE_LINE_END | RF_POST_REDUCE);
+        r.b = fp;
+        return traced(r, TR_LINMIN, x, fx, 0.0);
+    }
 
     // r0, r1, r2: reply to the previous request
     __device__ Request next(double r0, double r1, double r2) {
@@ -199,25 +234,9 @@ struct CgdMachine {
                 return traced(req(REQ_GRAD), TR_START, fp, 0.0, 0.0);
             case S_GRAD0:
                 its = 0;
-                st = S_ITER_BEGIN;
-                return req(REQ_CG_START);
-            case S_ITER_BEGIN:
-                if (its >= maxiters) { reason = EXIT_ITMAX; st = S_FINISH; break; }
-                iter = its;
-                st = S_BR_START;
-                return req(REQ_LINE_BEGIN);
+                return start_line(RF_PRE_START, 0.0);
 
-            // ---- bracket from (0, 1) ------------------------------------------------
-            case S_BR_START:
-                // f at a = 0 is the value the previous line search ended on (or f(x0)): the same
-                // point, hence the same bits -- counted and traced like the reference's call
-                // (nrc :87) but not evaluated again.  Its slope is not known.
-                ax = 0.0; bx = 1.0;
-                fa = fp; sa = 0.0; va = false;
-                ++nfeval;
-                pp_tag = TR_F; pp_a = 0.0; pp_b = fp; pp_c = 0.0;
-                st = S_BR_FB;
-                return with_pending(want_fd(bx));
+            // ---- bracket from (0, 1) (start_line) -----------------------------------------
             case S_BR_FB:
                 fb = r0; sb = r1; vb = true; if (r0 != r0) saw_nan = true;
                 if (fb > fa) {
@@ -306,10 +325,7 @@ struct CgdMachine {
                 const double xm = 0.5 * (a + b);
                 const double tol1 = TOL * fabs(x) + ZEPS;
                 const double tol2 = 2.0 * tol1;
-                if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) {
-                    st = S_AFTER_LINMIN;
-                    return with_pending(traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0));
-                }
+                if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) return with_pending(line_done());
                 bool bisect = true;
                 if (fabs(e) > tol1) {
                     double d1 = 2.0 * (b - a), d2 = d1;
@@ -339,10 +355,7 @@ struct CgdMachine {
             }
             case S_DB_EVAL: {
                 const double fu = r0, du = r1; if (r0 != r0) saw_nan = true;
-                if (tiny && fu > fx) {  // the minimal downhill step goes uphill: done (no df call, nrc :369-376)
-                    st = S_AFTER_LINMIN;
-                    return traced(req(REQ_LINE_END, x), TR_LINMIN, x, fx, 0.0);
-                }
+                if (tiny && fu > fx) return line_done();  // the minimal downhill step goes uphill: done (no df call, nrc :369-376)
                 ++ngeval;
                 if (fu <= fx) {
                     if (uu >= x) a = x; else b = x;
@@ -364,25 +377,18 @@ struct CgdMachine {
             }
 
             // ---- Frprmn's loop body after linmin --------------------------------------
-            case S_AFTER_LINMIN:
+            case S_AFTER_LINMIN:  // only reached when line_done() found the ftol test satisfied
                 fret = fx;
-                if (2.0 * fabs(fret - fp) <= ftol * (fabs(fret) + fabs(fp) + EPS)) { reason = EXIT_FTOL; st = S_FINISH; break; }
-                fp = fret;
-                ++ngeval;
-                st = S_GRAD_ITER;
-                return req(REQ_GRAD);
-            case S_GRAD_ITER:
-                st = S_REDUCED;
-                return req(REQ_CG_REDUCE, fp);
+                reason = EXIT_FTOL; st = S_FINISH;
+                break;
             case S_REDUCED: {
                 const double test = r0, gg = r1, dgg = r2;
                 Request nx;
-                if (test < GTOL) { reason = EXIT_GTOL; st = S_FINISH; nx = req(REQ_DONE); }
-                else if (gg == 0.0) { reason = EXIT_GGZERO; st = S_FINISH; nx = req(REQ_DONE); }
-                else if (its + 1 >= maxiters) { reason = EXIT_ITMAX; st = S_FINISH; nx = req(REQ_DONE); }  // the final
+                if (test < GTOL) { reason = EXIT_GTOL; st = S_FINISH; nx = finish_request(); }
+                else if (gg == 0.0) { reason = EXIT_GGZERO; st = S_FINISH; nx = finish_request(); }
+                else if (its + 1 >= maxiters) { reason = EXIT_ITMAX; st = S_FINISH; nx = finish_request(); }  // the final
                     // direction update of the reference has no observable effect: skipped
-                else { ++its; st = S_ITER_BEGIN; nx = req(REQ_CG_UPDATE, dgg / gg); }
-                if (nx.kind == REQ_DONE) { nx = finish_request(); }
+                else { ++its; nx = start_line(RF_PRE_UPDATE, dgg / gg); nx.flags |= RF_TR_FIRST; }
                 return traced(nx, TR_ITER, test, gg, dgg);
             }
 
@@ -407,7 +413,7 @@ struct CgdMachine {
             rolled_back = true;
             st = S_ROLLED;
             Request r = want_f(0.0, false);
-            r.restore = true;
+            r.flags |= RF_RESTORE;
             return r;
         }
         st = S_DONE;
@@ -428,8 +434,8 @@ struct CgdMachine {
 __device__ __forceinline__ void step_machine(CgdMachine* __restrict__ M, Request* __restrict__ out, double r0, double r1, double r2) {
     const Request nq = M->next(r0, r1, r2);
     if ((threadIdx.x & 63) == 0) {
-        out->kind = nq.kind; out->restore = nq.restore; out->line = nq.line;
-        out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a;
+        out->kind = nq.kind; out->flags = nq.flags;
+        out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a; out->b = nq.b;
         if (nq.pre_tag != TR_NONE) { out->pre_a = nq.pre_a; out->pre_b = nq.pre_b; out->pre_c = nq.pre_c; }
         if (nq.tr_tag != TR_NONE) { out->tr_a = nq.tr_a; out->tr_b = nq.tr_b; out->tr_c = nq.tr_c; }
     }
@@ -460,38 +466,46 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         const long long ts1 = E.clock();
         __syncthreads();
         const Request& q = Q[round & 1];
-        if (E.tracing()) {
-            if (q.pre_tag != TR_NONE) E.trace(q.pre_tag, q.pre_a, q.pre_b, q.pre_c);
-            if (q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
-        }
         const int kind = __builtin_amdgcn_readfirstlane(q.kind);
+        const int flags = __builtin_amdgcn_readfirstlane(q.flags);
+        if (E.tracing()) {
+            if ((flags & RF_TR_FIRST) && q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
+            if (q.pre_tag != TR_NONE) E.trace(q.pre_tag, q.pre_a, q.pre_b, q.pre_c);
+            if (!(flags & RF_TR_FIRST) && q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
+        }
         const double qa = uniform(q.a);
         E.tick(8, ts1 - ts0); E.tick(9, E.clock() - ts1);
         if (kind == REQ_DONE) break;
         const long long th0 = E.clock();
 #define RDIS_TICK_KIND(K) E.tick(12 + K, E.clock() - th0); E.tick(22 + K, 1)
         switch (kind) {
-        case REQ_F:
-            r0 = uniform(E.eval_value(qa, q.restore));
-            if (q.line) E.trace(TR_F, qa, r0, 0.0);
-            RDIS_TICK_KIND(REQ_F);
+        case REQ_EVAL:
+            if (flags & (RF_PRE_START | RF_PRE_UPDATE | RF_PRE_BEGIN)) {
+                if (flags & RF_PRE_START) E.cg_start();
+                if (flags & RF_PRE_UPDATE) E.cg_update(uniform(q.b));
+                if (flags & RF_PRE_BEGIN) E.line_begin();
+            }
+            if (flags & RF_SLOPE) {
+                E.eval_value_slope(qa, r0, r1);
+                r0 = uniform(r0); r1 = uniform(r1);
+                E.trace(TR_FD, qa, r0, r1);
+                RDIS_TICK_KIND(1);
+            } else {
+                r0 = uniform(E.eval_value(qa, (flags & RF_RESTORE) != 0));
+                if (flags & RF_LINE) E.trace(TR_F, qa, r0, 0.0);
+                RDIS_TICK_KIND(0);
+            }
             break;
-        case REQ_FD:
-            E.eval_value_slope(qa, r0, r1);
-            r0 = uniform(r0); r1 = uniform(r1);
-            E.trace(TR_FD, qa, r0, r1);
-            RDIS_TICK_KIND(REQ_FD);
+        case REQ_GRAD:
+            if (flags & RF_PRE_LINE_END) E.line_end(qa);
+            E.gradient_to_xi();
+            if (flags & RF_POST_REDUCE) {
+                E.cg_reduce(uniform(q.b), r0, r1, r2);
+                r0 = uniform(r0); r1 = uniform(r1); r2 = uniform(r2);
+            }
+            RDIS_TICK_KIND(2);
             break;
-        case REQ_GRAD: E.gradient_to_xi(); RDIS_TICK_KIND(REQ_GRAD); break;
-        case REQ_CG_START: E.cg_start(); RDIS_TICK_KIND(REQ_CG_START); break;
-        case REQ_LINE_BEGIN: E.line_begin(); RDIS_TICK_KIND(REQ_LINE_BEGIN); break;
-        case REQ_LINE_END: E.line_end(qa); RDIS_TICK_KIND(REQ_LINE_END); break;
-        case REQ_CG_REDUCE:
-            E.cg_reduce(qa, r0, r1, r2);
-            r0 = uniform(r0); r1 = uniform(r1); r2 = uniform(r2);
-            RDIS_TICK_KIND(REQ_CG_REDUCE);
-            break;
-        case REQ_CG_UPDATE: E.cg_update(qa); RDIS_TICK_KIND(REQ_CG_UPDATE); break;
+        case REQ_LINE_END: E.line_end(qa); RDIS_TICK_KIND(5); break;
         default: break;
         }
 #undef RDIS_TICK_KIND

@@ -189,10 +189,7 @@ struct CoopEnv {
     __device__ void publish_xi() {
         if (lv.li >= 0) store_f64<true>(A.xi_glob + lv.li, lv.xi);
         if (wv.li >= 0 && (tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, wv.xi);
-        // no payload; the workgroup barrier that hands out the next request closes it
-        double a = 0.0, b = 0.0, c = 0.0;
-        X.to_wave0<1>(a, b, c, SYNC_DRAIN);
-        X.finish_wave0(SYNC_DRAIN);
+        X.barrier(SYNC_DRAIN);   // line_begin, which follows in the same request, reads it
     }
     __device__ void cg_start() {
         { const double t = -lv.xi; lv.g = t; lv.h = t; lv.xi = t; }

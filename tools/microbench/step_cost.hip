@@ -29,15 +29,15 @@ __global__ void __launch_bounds__(64) drive(long long* cyc, long long* cnt, doub
         const int kind = __builtin_amdgcn_readfirstlane(q.kind);
         const double a = uniform(q.a);
         if (kind == REQ_DONE) break;
-        if (kind == REQ_F || kind == REQ_FD) {
+        const int flags = __builtin_amdgcn_readfirstlane(q.flags);
+        if (kind == REQ_EVAL && (flags & RF_PRE_BEGIN)) { shift = 0.11 + 0.07 * (double)(round % 13); curv = 1.0 + 0.5 * (double)(round % 5); }
+        if (kind == REQ_EVAL) {
             // a quartic with a single minimum at `shift`
             const double u = a - shift;
             r0 = uniform(10.0 + curv * u * u + 0.3 * u * u * u * u + 0.05 * u * u * u);
             r1 = uniform(2.0 * curv * u + 1.2 * u * u * u + 0.15 * u * u);
-        } else if (kind == REQ_CG_REDUCE) {
+        } else if (kind == REQ_GRAD && (flags & RF_POST_REDUCE)) {
             r0 = 1.0; r1 = 1.0; r2 = 0.5;
-        } else if (kind == REQ_LINE_BEGIN) {
-            shift = 0.11 + 0.07 * (double)(round % 13); curv = 1.0 + 0.5 * (double)(round % 5);
         }
     }
     if (threadIdx.x == 0) {
