@@ -19,6 +19,9 @@ Workloads (--workload):
                  top-level objective is summed with an RCCL all-reduce.
   synthetic-S    BASELINE config 5: 1000 independent 3-camera x 40-point components
                  per rank (one workgroup each, one launch).
+  synthetic-L    the same generator at ladybug's size (the throughput point):
+                 --components (default 256) independent 49-camera x 7776-point components of
+                 31104 observations per rank -- 8.0e6 factors; one workgroup each, one launch.
   ladybug-components  the component mix RDIS reaches on ladybug once a separator is assigned
                  (SURVEY.md 3.2b): 7776 single-point components (3 variables, 2-29 factors,
                  cameras fixed), one launch.
@@ -57,15 +60,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "ladybug-components"])
+    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "synthetic-L", "ladybug-components"])
+    ap.add_argument("--components", type=int, default=256, help="synthetic-L: components per rank")
     ap.add_argument("--maxiters", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
     return ap.parse_args()
 
 
-def build_problem(workload: str, rank: int):
+def build_problem(workload: str, rank: int, components: int = 256):
     from rdis_amd import problems as P
+    if workload == "synthetic-L":
+        return P.make_synthetic_ba(components, 49, 7776, obs_per_pt=4, first_comp=components * rank)
     if workload == "ladybug-full":
         return P.load_bal().single_component()
     if workload == "ladybug-components":
@@ -96,7 +102,8 @@ def cpu_baseline(pp, maxiters: int):
     from oracle import oracle as O
     ncores = 1
     if pp.ncomp > 1:
-        ncomp = min(pp.ncomp, 100 if pp.meta.get("generator") == "synthetic_ba" else 1000)
+        # about 2e5 factors' worth of components (10-20 s): 1000 small ones, 6 of ladybug's size
+        ncomp = min(pp.ncomp, 1000, max(1, int(2e5 // max(pp.nfac // pp.ncomp, 1))))
         o = O.OracleProblem(pp)
         t = time.perf_counter()
         its = 0
@@ -150,7 +157,7 @@ def main():
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
 
-    pp = build_problem(a.workload, rank)
+    pp = build_problem(a.workload, rank, a.components)
     prob = capi.Problem(ctx, pp)
     plan = capi.Plan(prob)
     for kv in a.opt:
@@ -212,10 +219,11 @@ def main():
             "metric": "subspace-solver iters/sec (all components), ladybug BA",
             "value": total_iters / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.workload == "synthetic-S" else "ladybug-49-7776 (BAL file)",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.workload.startswith("synthetic") else "ladybug-49-7776 (BAL file)",
             "config": {"workload": ("ladybug-49-7776 full, CGD over all 23769 variables / 31843 factors, SSmaxit 25, ftol 3e-8; "
                                     "one such component per GPU") if a.workload == "ladybug-full" else
                        "ladybug-49-7776 with the cameras fixed: 7776 single-point components per GPU, SSmaxit 25" if a.workload == "ladybug-components" else
+                       f"synthetic decomposable BA: {pp.ncomp} components x (49 cameras, 7776 points, 31104 observations) per GPU, SSmaxit 25" if a.workload == "synthetic-L" else
                        "synthetic decomposable BA: 1000 components x (3 cameras, 40 points, 120 observations) per GPU, SSmaxit 25",
                        "components_per_gpu": pp.ncomp, "factors_per_gpu": pp.nfac, "variables_per_gpu": pp.nvars,
                        "parallelism": f"{world} x independent components, all-reduce of the objective"},

@@ -156,7 +156,7 @@ struct CgdMachine {
     __device__ Request next(double r0, double r1, double r2) {
 #pragma clang fp contract(off)
         const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;      // nrc :82
-        const double EPS = 1.0e-18, GTOL = 1.0e-8;                          // nrc :621-622
+        const double GTOL = 1.0e-8;                                         // nrc :622 (EPS = 1e-18, :621, is in line_done)
         const double TOL = 3.0e-8;  // Dbrent's own default, not the solver's ftol (nrc :288, :499)
         const double ZEPS = DBL_EPSILON * 1.0e-3;
         const int DB_ITMAX = 100;

@@ -275,7 +275,7 @@ def test_plan_rejects_dependent_components(gctx):
     assert e.value.code == -4
 
 
-@pytest.mark.parametrize("threads", [64, 256, 1024])
+@pytest.mark.parametrize("threads", [64, 256, 768, 1024])
 def test_workgroup_size_does_not_change_the_algorithm(threads, gctx):
     pp = P.load_bal(ncams=5, npts=30)
     _, r, trv = solve(gctx, pp, maxiters=6, trace=4096, opts={"block_threads": threads})

@@ -13,7 +13,7 @@ pp = P.make_synthetic_ba(ncomp, ncams, npts, obs_per_pt=4)
 print("built %d comps, %d factors, %d vars in %.1f s" % (pp.ncomp, pp.nfac, pp.nvars, time.time() - t))
 ctx = capi.Context(0)
 g = capi.Problem(ctx, pp)
-for threads in (256, 512, 1024):
+for threads in (512, 768, 1024):
     plan = capi.Plan(g)
     plan.set_option("coop_max_components", 0)
     plan.set_option("block_threads", threads)
