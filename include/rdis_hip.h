@@ -117,6 +117,24 @@ int rdis_hip_eval_grad(rdis_hip_problem *p, int64_t nf, const int64_t *fac, doub
 int rdis_hip_eval_each(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *fvals);
 int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *g12);
 
+/* ---- the step before the path: which independent sub-problems are there? -----
+ * Connected components of the factor graph once the variables with assigned[v] != 0 are fixed:
+ * what Component::createChildren (src/Component.cpp:508-549) obtains from the reference's dynamic
+ * connectivity structure (ConnectivityGraph.h:255-261), computed on the device by a lock-free
+ * union-find (rdis_amd/csrc/components.hip).  A component = unassigned variables connected
+ * through factors.  Lists come out the way Component::init leaves them (Component.cpp:60-79):
+ * variable ids ascending, factor ids ascending; components ordered by number of variables
+ * ascending (ComponentComparator, Component.cpp:603-608), equal sizes by smallest variable id.
+ * Factors all of whose variables are assigned are in no component; an unassigned variable that
+ * no factor reads is a component with an empty factor list.  The four arrays are exactly the
+ * arguments of rdis_hip_plan_create / rdis_hip_cgd_batch.
+ *   rdis_hip_components        computes; returns the sizes
+ *   rdis_hip_components_fetch  copies the lists of the last call (free_ptr, fac_ptr: ncomp + 1) */
+int rdis_hip_components(rdis_hip_problem *p, const uint8_t *assigned, int64_t *ncomp, int64_t *nfree,
+                        int64_t *nfac);
+int rdis_hip_components_fetch(rdis_hip_problem *p, int64_t *free_ptr, int64_t *free_vid, int64_t *fac_ptr,
+                              int64_t *fac_id);
+
 /* ---- the solver: CGDSubspaceOptimizer::optimize for a batch of independent
  * components --------------------------------------------------------------------
  * Component c optimises the free variables free_vid[free_ptr[c] .. free_ptr[c+1])

@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         L.ro_frprmn.restype = C.c_int
         L.ro_frprmn.argtypes = [C.c_int, _f64p, FUNC_CB, GRAD_CB, C.c_void_p, C.c_int, C.c_double,
                                 C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ro_components.restype = C.c_int64
+        L.ro_components.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -147,6 +149,17 @@ class OracleProblem:
         out = np.empty(n)
         lib().ro_get_x(self.h, n, vp, out)
         return out
+
+    def components(self, assigned):
+        """(free_ptr, free_vid, fac_ptr, fac_id) of the connected components left when the variables
+        with assigned[v] != 0 are fixed"""
+        a = np.ascontiguousarray(assigned, dtype=np.uint8)
+        n, f = self.pp.nvars, self.pp.nfac
+        fp, fv = np.zeros(n + 1, np.int64), np.zeros(max(n, 1), np.int64)
+        cp, ci = np.zeros(n + 1, np.int64), np.zeros(max(f, 1), np.int64)
+        v = lambda x: x.ctypes.data_as(C.c_void_p)
+        nc = int(lib().ro_components(self.h, v(a), v(fp), v(fv), v(cp), v(ci)))
+        return fp[:nc + 1].copy(), fv[:fp[nc]].copy(), cp[:nc + 1].copy(), ci[:cp[nc]].copy()
 
     def eval(self, fac=None) -> float:
         f, fp = _opt_i64(fac)

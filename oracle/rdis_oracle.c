@@ -1112,3 +1112,83 @@ int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int
     ro_set_emulate_stale_cache(p, emulate);
     return T.n;
 }
+
+/* ------------------------------------------------------------------------
+ * Connected components of the residual factor graph
+ *
+ * Component::createChildren (src/Component.cpp:508-549) asks the dynamic connectivity structure
+ * (ConnectivityGraph.h:255-261) for the component label of every unassigned variable of the
+ * parent and builds one child per label; Component::init (Component.cpp:60-79) fills a child
+ * with the variables and factors of that connected component and sorts both lists by id.
+ * Children are kept ordered by number of variables (ComponentComparator, :603-608).  The graph
+ * is bipartite: a factor is adjacent to each of its variables, edges of assigned variables are
+ * removed.  Restated as a static labelling: sequential union-find over the variables, one pass
+ * over the factors.  Ties between components of equal size are broken by the smallest variable
+ * id (the reference's order among them follows the internals of its Euler-tour forest).
+ * Returns the number of components; free_ptr / fac_ptr need nvars + 1 entries, free_vid nvars,
+ * fac_id nfac.
+ * ------------------------------------------------------------------------ */
+static int64_t cc_find(int64_t *parent, int64_t x)
+{
+    while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+    return x;
+}
+
+typedef struct { int64_t nvars, root; } cc_key;
+static int cc_key_cmp(const void *a, const void *b)
+{
+    const cc_key *x = a, *y = b;
+    if (x->nvars != y->nvars) return x->nvars < y->nvars ? -1 : 1;
+    return x->root < y->root ? -1 : (x->root > y->root ? 1 : 0);
+}
+
+int64_t ro_components(const ro_problem *p, const uint8_t *assigned, int64_t *free_ptr, int64_t *free_vid,
+                      int64_t *fac_ptr, int64_t *fac_id)
+{
+    const int64_t N = p->nvars, F = p->nfac;
+    int64_t *parent = malloc((size_t)(N + 1) * sizeof(int64_t));
+    int64_t *count = calloc((size_t)(N + 1), sizeof(int64_t));
+    int64_t *comp_of = malloc((size_t)(N + 1) * sizeof(int64_t));
+    for (int64_t v = 0; v < N; ++v) parent[v] = v;
+    for (int64_t f = 0; f < F; ++f) {
+        int64_t first = -1;
+        for (int64_t k = 0, a = fac_arity(p, f); k < a; ++k) {
+            const int64_t v = fac_var(p, f, k);
+            if (assigned[v]) continue;
+            if (first < 0) { first = v; continue; }
+            int64_t ra = cc_find(parent, first), rb = cc_find(parent, v);
+            if (ra == rb) continue;
+            if (ra < rb) parent[rb] = ra; else parent[ra] = rb;   /* the smaller id stays root */
+        }
+    }
+    int64_t ncomp = 0;
+    for (int64_t v = 0; v < N; ++v) if (!assigned[v]) count[cc_find(parent, v)]++;
+    cc_key *keys = malloc((size_t)(N + 1) * sizeof(cc_key));
+    for (int64_t v = 0; v < N; ++v)
+        if (!assigned[v] && parent[v] == v) { keys[ncomp].nvars = count[v]; keys[ncomp].root = v; ++ncomp; }
+    qsort(keys, (size_t)ncomp, sizeof(cc_key), cc_key_cmp);
+    free_ptr[0] = 0;
+    for (int64_t c = 0; c < ncomp; ++c) { comp_of[keys[c].root] = c; free_ptr[c + 1] = free_ptr[c] + keys[c].nvars; }
+    /* members in ascending id: a forward pass with per-component cursors */
+    int64_t *cur = malloc((size_t)(ncomp + 1) * sizeof(int64_t));
+    for (int64_t c = 0; c < ncomp; ++c) cur[c] = free_ptr[c];
+    for (int64_t v = 0; v < N; ++v) if (!assigned[v]) free_vid[cur[comp_of[cc_find(parent, v)]]++] = v;
+    for (int64_t c = 0; c <= ncomp; ++c) fac_ptr[c] = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            for (int64_t c = 0; c < ncomp; ++c) fac_ptr[c + 1] += fac_ptr[c];
+            for (int64_t c = 0; c < ncomp; ++c) cur[c] = fac_ptr[c];
+        }
+        for (int64_t f = 0; f < F; ++f) {
+            int64_t r = -1;
+            for (int64_t k = 0, a = fac_arity(p, f); k < a && r < 0; ++k) {
+                const int64_t v = fac_var(p, f, k);
+                if (!assigned[v]) r = cc_find(parent, v);
+            }
+            if (r < 0) continue;   /* every variable assigned: a constant, in no component */
+            if (pass == 0) fac_ptr[comp_of[r] + 1]++; else fac_id[cur[comp_of[r]]++] = f;
+        }
+    }
+    free(parent); free(count); free(comp_of); free(keys); free(cur);
+    return ncomp;
+}

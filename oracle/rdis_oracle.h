@@ -164,4 +164,11 @@ int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int
 #ifdef __cplusplus
 }
 #endif
+/* Connected components of the factor graph once the variables with assigned[v] != 0 are fixed
+ * (Component::createChildren / Component::init, src/Component.cpp:508-549, 60-79): variable and
+ * factor lists ascending, components by (number of variables, smallest variable id).  Returns
+ * the number of components; free_ptr / fac_ptr: nvars + 1 entries, free_vid: nvars, fac_id: nfac. */
+int64_t ro_components(const ro_problem *p, const uint8_t *assigned, int64_t *free_ptr, int64_t *free_vid,
+                      int64_t *fac_ptr, int64_t *fac_id);
+
 #endif /* RDIS_ORACLE_H_ */

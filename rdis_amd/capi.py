@@ -65,6 +65,8 @@ SYMBOLS = {
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
     "rdis_hip_plan_debug_counters": (C.c_int, [_vp, _vp]),
+    "rdis_hip_components": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "rdis_hip_components_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -225,6 +227,21 @@ class Problem:
     def set_x(self, val, vid=None):
         val, vid = _f(val), _i(vid)
         self.ctx.check(self.ctx.lib.rdis_hip_set_x(self.h, val.shape[0], _ptr(vid), _ptr(val)))
+
+    def components(self, assigned):
+        """(free_ptr, free_vid, fac_ptr, fac_id) of the connected components left when the variables
+        with assigned[v] != 0 are fixed (Component::createChildren); device union-find"""
+        a = np.ascontiguousarray(assigned, dtype=np.uint8)
+        if a.shape[0] != self.nvars:
+            raise ValueError("assigned must have one entry per variable")
+        sizes = np.zeros(3, dtype=np.int64)
+        sp = sizes.ctypes.data
+        self.ctx.check(self.ctx.lib.rdis_hip_components(self.h, _ptr(a), C.c_void_p(sp), C.c_void_p(sp + 8), C.c_void_p(sp + 16)))
+        nc, nfree, nfac = (int(v) for v in sizes)
+        free_ptr, fac_ptr = np.empty(nc + 1, np.int64), np.empty(nc + 1, np.int64)
+        free_vid, fac_id = np.empty(nfree, np.int64), np.empty(nfac, np.int64)
+        self.ctx.check(self.ctx.lib.rdis_hip_components_fetch(self.h, _ptr(free_ptr), _ptr(free_vid), _ptr(fac_ptr), _ptr(fac_id)))
+        return free_ptr, free_vid, fac_ptr, fac_id
 
     def get_x(self, vid=None) -> np.ndarray:
         vid = _i(vid)

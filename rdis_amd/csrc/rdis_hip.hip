@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "components.hpp"
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
 #include "solver_stream.hpp"
@@ -97,6 +98,8 @@ struct rdis_hip_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct rdis_hip_plan* last_timed_plan = nullptr;
     std::vector<int> h_owner, h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
+    ComponentLists comps;                  // result of the last rdis_hip_components call
+    DevBuf assigned;
     int stamp = 0;
     ~rdis_hip_problem() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 
@@ -1023,6 +1026,35 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
         HIPCHK(c, hipMemcpyAsync(rec4, L->trace.as<double>() + 4ll * L->trace_records * comp, (size_t)k * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int rdis_hip_components(rdis_hip_problem* p, const uint8_t* assigned, int64_t* ncomp, int64_t* nfree, int64_t* nfac) {
+    if (!p) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (!assigned && p->N > 0) return fail(c, RDIS_HIP_EINVAL, "components: assigned is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (p->N >= INT32_MAX || p->F >= INT32_MAX) return fail(c, RDIS_HIP_ERANGE, "components: problem too large for 32-bit ids");
+    int rc = dalloc(c, p->assigned, (size_t)std::max<int64_t>(p->N, 1));
+    if (rc) return rc;
+    if (p->N > 0) HIPCHK(c, hipMemcpyAsync(p->assigned.p, assigned, (size_t)p->N, hipMemcpyHostToDevice, c->stream));
+    const int e = device_components(c->stream, p->kind, (int)p->N, (int)p->F, p->cam.as<int>(), p->pt.as<int>(),
+                                    p->rowptr.as<int>(), p->vid.as<int>(), p->assigned.as<unsigned char>(), &p->comps);
+    if (e != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("components: ") + hipGetErrorString((hipError_t)e));
+    if (ncomp) *ncomp = p->comps.ncomp;
+    if (nfree) *nfree = p->comps.nfree;
+    if (nfac) *nfac = p->comps.nfac;
+    return 0;
+}
+
+extern "C" int rdis_hip_components_fetch(rdis_hip_problem* p, int64_t* free_ptr, int64_t* free_vid, int64_t* fac_ptr, int64_t* fac_id) {
+    if (!p) return RDIS_HIP_EINVAL;
+    const ComponentLists& L = p->comps;
+    if (L.free_ptr.empty()) return fail(p->ctx, RDIS_HIP_EINVAL, "components_fetch: call rdis_hip_components first");
+    if (free_ptr) std::memcpy(free_ptr, L.free_ptr.data(), L.free_ptr.size() * sizeof(int64_t));
+    if (fac_ptr) std::memcpy(fac_ptr, L.fac_ptr.data(), L.fac_ptr.size() * sizeof(int64_t));
+    if (free_vid && !L.free_vid.empty()) std::memcpy(free_vid, L.free_vid.data(), L.free_vid.size() * sizeof(int64_t));
+    if (fac_id && !L.fac_id.empty()) std::memcpy(fac_id, L.fac_id.data(), L.fac_id.size() * sizeof(int64_t));
     return 0;
 }
 

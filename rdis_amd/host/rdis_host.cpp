@@ -500,4 +500,25 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
     return total;
 }
 
+std::vector<HipCGDSubspaceOptimizer::Component> HipCGDSubspaceOptimizer::createChildren() {
+    const VariablePtrVec& vars = f.getVariables();
+    const FactorPtrVec& facs = f.getFactors();
+    std::vector<uint8_t> assigned(vars.size());
+    for (size_t i = 0; i < vars.size(); ++i) assigned[i] = vars[i]->isAssigned() ? 1 : 0;
+    rdis_hip_problem* p = f.deviceProblem();
+    int64_t nc = 0, nfree = 0, nfac = 0;
+    check(f.deviceContext(), rdis_hip_components(p, assigned.data(), &nc, &nfree, &nfac), "rdis_hip_components");
+    std::vector<int64_t> free_ptr((size_t)nc + 1), fac_ptr((size_t)nc + 1), free_vid((size_t)nfree), fac_id((size_t)nfac);
+    check(f.deviceContext(), rdis_hip_components_fetch(p, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data()),
+          "rdis_hip_components_fetch");
+    std::vector<Component> out((size_t)nc);
+    for (int64_t c = 0; c < nc; ++c) {
+        Component& C = out[(size_t)c];
+        for (int64_t i = free_ptr[(size_t)c]; i < free_ptr[(size_t)c + 1]; ++i) C.vars.push_back(vars[(size_t)free_vid[(size_t)i]]);
+        for (int64_t j = fac_ptr[(size_t)c]; j < fac_ptr[(size_t)c + 1]; ++j) C.factors.push_back(facs[(size_t)fac_id[(size_t)j]]);
+        C.fret = C.deltaFval = 0; C.iters = C.status = 0; C.nfeval = C.ngeval = 0;
+    }
+    return out;
+}
+
 }  // namespace rdis

@@ -281,6 +281,14 @@ public:
     };
     Numeric optimizeBatch(std::vector<Component>& comps, const bool printdbg);
 
+    // The sibling components themselves: connected components of the factor graph over the
+    // variables that are currently unassigned -- what Component::createChildren
+    // (src/Component.cpp:508-549) obtains from the reference's dynamic connectivity structure,
+    // labelled on the device (rdis_hip_components).  Variable and factor lists ascending by id,
+    // components by number of variables ascending (Component.cpp:60-79, 603-608); xval of each
+    // is left empty for the caller to fill with a start.
+    std::vector<Component> createChildren();
+
     // results of the last optimize() beyond what the reference returns
     int lastIters() const { return last_iters_; }
     int lastStatus() const { return last_status_; }

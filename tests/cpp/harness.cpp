@@ -169,4 +169,34 @@ int harness_ba_points_batch(const char* path, long long ncams, long long npts, i
     } catch (const std::exception& e) { std::cerr << "harness_ba_points_batch: " << e.what() << std::endl; return -2; }
 }
 
+// The RDIS step in full: with the cameras assigned, un-assign the points, let the optimizer find
+// the children (connected components on the device) and solve them in one launch.
+// out = {sum fret, sum delta, ncomp, total iterations, f_before, f_after, min #vars, max #vars}
+int harness_ba_children_batch(const char* path, long long ncams, long long npts, int maxit, double* out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        const NumericVec x0 = f.getInitialState();
+        f.assignAll(x0);
+        const Numeric before = f.eval();
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        for (VariableID v = 9 * f.getNumCameras(); v < (VariableID)f.getNumVars(); ++v) f.getVariables()[(size_t)v]->unassign();
+        std::vector<HipCGDSubspaceOptimizer::Component> comps = ssopt.createChildren();
+        size_t mn = (size_t)-1, mx = 0;
+        for (auto& c : comps) {
+            mn = std::min(mn, c.vars.size()); mx = std::max(mx, c.vars.size());
+            for (const Variable* v : c.vars) c.xval.push_back(x0[(size_t)v->getID()]);
+        }
+        const Numeric total = ssopt.optimizeBatch(comps, false);
+        const Numeric after = f.eval();
+        double sd = 0, its = 0;
+        for (const auto& c : comps) { sd += c.deltaFval; its += c.iters + 1; }
+        out[0] = total; out[1] = sd; out[2] = (double)comps.size(); out[3] = its; out[4] = before; out[5] = after;
+        out[6] = (double)mn; out[7] = (double)mx;
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_ba_children_batch: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

@@ -171,3 +171,14 @@ def test_sibling_components_in_one_launch(harness, bal_path):
         fc = np.where(pp.pt_vid0 == 441 + 3 * p)[0].astype(np.int64)
         tot += o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25).fret
     assert abs(tot - total) <= 1e-6 * tot
+
+
+@pytest.mark.gpu
+def test_children_found_on_the_device_then_solved(harness, bal_path):
+    # cameras assigned, points unassigned: createChildren() labels the 500 point components on the
+    # device and optimizeBatch solves them -- identical to the hand-built batch above
+    out, ref = np.zeros(8), np.zeros(6)
+    assert harness.harness_ba_children_batch(bal_path, 49, 500, 25, out.ctypes.data_as(C.c_void_p)) == 0
+    assert harness.harness_ba_points_batch(bal_path, 49, 500, 25, ref.ctypes.data_as(C.c_void_p)) == 0
+    assert out[2] == 500 and out[6] == 3 and out[7] == 3
+    assert np.array_equal(out[:6], ref)                                     # same components, same launch: bit-identical

@@ -246,3 +246,73 @@ def test_alternation_decompositions_are_independent_components():
         for c in (0, nblk // 2, nblk - 1):
             assert np.all(np.diff(fac_id[fac_ptr[c]:fac_ptr[c + 1]]) > 0)   # ascending factor ids (Component.cpp:78-79)
             assert np.array_equal(free_vid[free_ptr[c]:free_ptr[c + 1]], (0 if block == 9 else 441) + block * c + np.arange(block))
+
+
+# ---- connected components of the residual factor graph (Component::createChildren) -------------
+def _scipy_components(pp, assigned):
+    """independent implementation: scipy's connected_components on the bipartite variable-factor graph"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    n, f = pp.nvars, pp.nfac
+    if pp.kind == 0:
+        rows = np.repeat(np.arange(f), 12)
+        cols = np.concatenate([pp.cam_vid0[:, None] + np.arange(9), pp.pt_vid0[:, None] + np.arange(3)], axis=1).reshape(-1)
+    else:
+        rows = np.repeat(np.arange(f), np.diff(pp.rowptr))
+        cols = pp.vid
+    keep = assigned[cols] == 0
+    g = coo_matrix((np.ones(keep.sum()), (cols[keep], n + rows[keep])), shape=(n + f, n + f))
+    _, lab = connected_components(g, directed=False)
+    comps = {}
+    for v in np.where(assigned == 0)[0]:
+        comps.setdefault(lab[v], ([], []))[0].append(int(v))
+    has_edge = np.zeros(f, bool)
+    has_edge[rows[keep]] = True
+    for k in np.where(has_edge)[0]:                      # a factor without an unassigned variable is in no component
+        comps[lab[n + k]][1].append(int(k))
+    order = sorted(comps.values(), key=lambda c: (len(c[0]), c[0][0]))
+    return order
+
+
+@pytest.mark.parametrize("case", ["ladybug_cams", "ladybug_random", "synthetic", "sinusoid", "none", "all"])
+def test_components_match_scipy(case):
+    rng = np.random.default_rng(5)
+    if case.startswith("ladybug"):
+        pp = P.load_bal(ncams=49, npts=300)
+        a = np.zeros(pp.nvars, np.uint8)
+        if case == "ladybug_cams":
+            a[:9 * 46] = 1                               # 46 of 49 cameras assigned (the PaToH cut of SURVEY 3.2b)
+        else:
+            a[rng.random(pp.nvars) < 0.6] = 1
+    elif case == "synthetic":
+        pp = P.make_synthetic_ba(7, 3, 10)
+        a = np.zeros(pp.nvars, np.uint8); a[rng.random(pp.nvars) < 0.2] = 1
+    elif case == "sinusoid":
+        pp = P.make_high_dim_sinusoid()
+        a = np.zeros(pp.nvars, np.uint8); a[rng.random(pp.nvars) < 0.3] = 1
+    else:
+        pp = P.load_bal(ncams=5, npts=30)
+        a = np.full(pp.nvars, 1 if case == "all" else 0, np.uint8)
+    fp, fv, cp, ci = O.OracleProblem(pp).components(a)
+    ref = _scipy_components(pp, a)
+    assert len(fp) - 1 == len(ref)
+    for c, (vs, fs) in enumerate(ref):                   # index work: exact
+        assert list(fv[fp[c]:fp[c + 1]]) == vs
+        assert list(ci[cp[c]:cp[c + 1]]) == sorted(fs)
+    # every unassigned variable exactly once; factors with an unassigned variable exactly once
+    assert sorted(fv) == list(np.where(a == 0)[0])
+    assert len(set(ci)) == len(ci)
+    if case == "none":
+        assert len(fp) == 2 and fp[1] == pp.nvars and cp[1] == pp.nfac
+    if case == "all":
+        assert len(fp) == 1 and len(fv) == 0 and len(ci) == 0
+
+
+def test_components_isolated_variable_and_constant_factor():
+    # x2 appears in no factor; the last factor has no variables at all
+    terms = [(2.0, [(0, 1.0, 0.0, 0), (1, 1.0, 0.0, 0)]), (1.0, [(3, 2.0, 0.0, 0)]), (-7.0, [])]
+    q = P._pack_nlp(terms, np.zeros(4), np.full(4, -5.0), np.full(4, 5.0), {})
+    fp, fv, cp, ci = O.OracleProblem(q).components(np.zeros(4, np.uint8))
+    # by (size, smallest id): {2} (no factors), {3} (factor 1), {0,1} (factor 0)
+    assert list(fp) == [0, 1, 2, 4] and list(fv) == [2, 3, 0, 1]
+    assert list(cp) == [0, 0, 1, 2] and list(ci) == [1, 0]
