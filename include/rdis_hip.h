@@ -181,11 +181,12 @@ int rdis_hip_plan_fetch(rdis_hip_plan *plan, double *x_out, double *fret, double
 int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
 
 /* tuning / introspection ---------------------------------------------------------- */
-/* option names: "block_threads" (workgroup size of the per-component solver, 0 = auto),
- * "coop_min_factors" (bundle-adjustment components with at least this many factors are
- * solved by the multi-workgroup cooperative kernel, one launch each; 0 = never; default
- * 4096), "coop_max_components" (at most this many per plan, default 8; further large
- * components stay in the batched launch), "coop_workgroups" (cap, 0 = what fits),
+/* option names: "block_threads" (workgroup size of the per-component solver: 64, 128, 256, 512,
+ * 768 or 1024; 0 = auto), "coop_min_factors" (bundle-adjustment components with at least this
+ * many factors are solved by the multi-workgroup cooperative kernel, one launch each; 0 = never;
+ * default 4096), "coop_max_components" (only when the plan has at most this many such
+ * components, default 8; a plan with more of them is one batched launch, one workgroup per
+ * component), "coop_workgroups" (cap, 0 = what fits),
  * "coop_threads" (128, 256 or 512), "coop_poll_delay" (x64 cycles between publishing and the
  * first granule sweep), "force_stream" (send large components to the streaming grid solver even
  * when they fit the register-resident one; large components that do not fit, and large

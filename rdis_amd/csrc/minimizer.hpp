@@ -13,11 +13,11 @@
 // into one kernel (110 KB of code, more than the instruction cache: measured 69 %
 // of the solve stalled on instruction fetch).  Here the control logic is turned
 // inside out: `next()` consumes the reply to the previous request and returns
-// the next request -- "value at step a", "value and slope at step a", "gradient
-// at p", a vector update -- and the kernel's driver loop holds the ONE copy of
-// each heavy operation.  Every lane of the cooperating group runs the machine
-// redundantly on group-uniform replies, so all lanes take the same branches and
-// nothing is broadcast.  FP contraction is off in here: fed the same replies the
+// the next request -- an evaluation ("value (and slope) at step a") or a full
+// gradient, each with the vector updates that surround it -- and the kernel's
+// driver loop holds the ONE copy of each heavy operation.  The machine's state
+// lives in LDS; one wave per workgroup steps it and hands the request to the
+// others (run_machine).  FP contraction is off in here: fed the same replies the
 // device takes bit-identical decisions to the CPU oracle (tests/test_gpu_solver.py
 // replays the device's trace through the oracle to check exactly that).
 #pragma once

@@ -6,30 +6,26 @@
 // memory traffic and launches from the evaluation loop altogether:
 //
 //  * one persistent launch runs the entire CGDSubspaceOptimizer::optimize call
-//    (reference src/optimizers/CGDSubspaceOptimizer.cpp:19-98); every lane of
-//    every workgroup steps the scalar control logic (minimizer.hpp) redundantly
-//    on identical reduced values, so nothing is ever broadcast;
+//    (reference src/optimizers/CGDSubspaceOptimizer.cpp:19-98); wave 0 of every
+//    workgroup steps the scalar control logic (minimizer.hpp) on the same reduced
+//    values, so every workgroup takes the same branches and nothing is broadcast
+//    between workgroups;
 //  * lane j owns factor j: for the duration of a line minimisation the point and
 //    direction of its 12 variables, their bounds and its observation live in
-//    registers; a trial step a costs clamp(base + a*dir), ~500 flops, and zero
-//    memory traffic;
+//    registers; a trial step a costs clamp(base + a*dir), ~310 fp64 instructions,
+//    and zero memory traffic;
 //  * the CG recurrence (p, xi, g, h) of free variable i lives in the registers of
 //    its owner: lane i for variables fed by few factors (points), a whole wave for
 //    variables fed by many (cameras: up to 906 partials) so that the per-variable
-//    sum of partials is one coalesced sweep + butterfly instead of a serial chain.
-//    Only xi is published (once per CG iteration) for the factor lanes to re-read;
+//    sum of partials is one coalesced sweep + wave reduction instead of a serial
+//    chain.  Only xi is published (once per CG iteration) for the factor lanes;
 //  * the per-factor partials of a full gradient are scattered straight into
 //    variable-major order (PlanView::slot_pos), so every owner reads one
-//    contiguous run;
-//  * workgroups exchange partial sums through 8-byte granules in HBM (relaxed
-//    agent-scope atomics, written through to memory): the data is the flag.  A
-//    granule holds an all-ones NaN until its owner publishes; three buffers
-//    rotate and each workgroup re-arms its own granules two exchanges ahead.
-//    One wave per workgroup sweeps the granules and reduces them in a fixed
-//    order, so every workgroup obtains bit-identical sums.  When an exchange also
-//    has to order memory (per-factor partials -> per-variable sums, new xi ->
-//    factor lanes) it is bracketed by an agent-scope release / acquire
-//    (cdna_hip_programming.md, Guideline 16); placement-independent, spins bounded.
+//    contiguous run; partials and xi cross workgroups through agent-scope coherent
+//    stores / loads, the barrier in between only drains the stores;
+//  * workgroups exchange partial sums through 8-byte granules in HBM, the data
+//    being the flag (grid_sync.hpp); a line-search value is delivered to the
+//    stepping wave only.
 //
 // Launched with hipLaunchCooperativeKernel so that an oversized grid is rejected
 // instead of deadlocking.  Bundle adjustment only (fixed arity 12).
