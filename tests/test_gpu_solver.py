@@ -168,6 +168,26 @@ def test_ladybug_full_objective(golden, gctx):
     assert abs(ro.eval() - r.fret[0]) <= 1e-12 * r.fret[0]                      # oracle's objective at the device's point
 
 
+def test_rdis_separator_block_on_full_ladybug(gctx):
+    """the call RDIS spends its time in on ladybug: the separator block -- 46 cameras and
+    one point, 417 free variables -- against every factor of those cameras (30285), all other points
+    constants.  Cooperative kernel with mostly-constant factor slots; replayed by the oracle."""
+    pp = P.load_bal()
+    free = np.concatenate([np.arange(9 * 46), np.arange(441, 444)]).astype(np.int64)
+    fac = np.where((pp.cam_vid0 // 9 < 46) | (pp.pt_vid0 == 441))[0].astype(np.int64)
+    g, r, tr = solve(gctx, pp, maxiters=25, free_vid=free, fac_id=fac, trace=1 << 13)
+    assert (r.status[0] & 0xFF) == 3 and r.delta[0] < 0
+    o = O.OracleProblem(pp)
+    assert abs((r.fret[0] - r.delta[0]) - o.eval(fac)) <= 1e-12 * o.eval(fac)      # f(x_init) over the listed factors
+    x_all = g.get_x()
+    assert np.array_equal(x_all[free], r.x)                                         # block left assigned
+    rest = np.setdiff1d(np.arange(pp.nvars), free)
+    assert np.array_equal(x_all[rest], pp.x0[rest])                                 # constants untouched
+    o.assign(free, r.x)
+    assert abs(o.eval(fac) - r.fret[0]) <= 1e-12 * r.fret[0]
+    check_replay(pp, tr, r, 25, free_vid=free, fac_id=fac, x=pp.x0[free])
+
+
 def test_subfunction_with_constants_and_clamping(gctx):
     # only camera 0 and point 0 free; the other variables are constants of the listed factors
     pp = P.load_bal(ncams=5, npts=30)
