@@ -117,6 +117,25 @@ int rdis_hip_eval_grad(rdis_hip_problem *p, int64_t nf, const int64_t *fac, doub
 int rdis_hip_eval_each(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *fvals);
 int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *g12);
 
+/* ---- a second subspace solver: Levenberg-Marquardt (bundle adjustment) ---------------
+ * The least-squares problem LMSubspaceOptimizer::optimize hands to levmar
+ * (src/optimizers/LMSubspaceOptimizer.cpp:28-147, 176-278: residual sqrt(2 E_j) per factor,
+ * Jacobian row grad E_j / e_j, damping scale 1e-3, eps1 = eps2 = 1e-15, eps3 = ftol, itmax =
+ * maxiters, result clamped into the domains), solved on the device: normal equations in
+ * camera / point blocks, Schur complement onto the cameras, both contractions on the matrix
+ * cores (rdis_amd/csrc/lm_solver.hip).  levmar is not vendored by the reference: parity is
+ * unpinned, the iteration is checked step by step against oracle/lm_oracle.py.
+ * Same calling convention as one component of rdis_hip_cgd_batch; x_inout may be NULL (start at
+ * the currently assigned x; the result is left assigned either way).
+ * info[8] = {iterations, stop code (levmar's: 1 small gradient, 2 small step, 3 itmax,
+ * 4 singular, 5 no further reduction, 6 small error, 7 invalid values), residual evaluations,
+ * Jacobian evaluations, linear solves, final damping mu, camera blocks, point blocks};
+ * hist (may be NULL): up to hist_cap records {mu, |Dp|^2, f(trial), accepted} per linear solve. */
+int rdis_hip_lm_optimize(rdis_hip_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
+                         const int64_t *fac_id, double *x_inout, int32_t maxiters, double ftol,
+                         double *fret, double *delta, double *info8, double *hist4, int64_t hist_cap,
+                         int64_t *nhist);
+
 /* ---- the step before the path: which independent sub-problems are there? -----
  * Connected components of the factor graph once the variables with assigned[v] != 0 are fixed:
  * what Component::createChildren (src/Component.cpp:508-549) obtains from the reference's dynamic

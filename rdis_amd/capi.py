@@ -16,6 +16,22 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librdis_hip.so")
 
+@dataclass
+class LmResult:
+    x: np.ndarray
+    fret: float
+    delta: float
+    iters: int
+    stop: int
+    nfev: int
+    njev: int
+    nsolve: int
+    mu: float
+    camera_blocks: int
+    point_blocks: int
+    history: np.ndarray   # [nsolve, 4]: mu, |Dp|^2, f(trial), accepted
+
+
 EXIT_NAMES = {0: "ftol", 1: "gtol", 2: "gg==0", 3: "itmax", 4: "dbrent-itmax", 5: "nan",
               6: "empty", 7: "sync-timeout"}
 STATUS_ROLLED_BACK = 0x100
@@ -65,6 +81,8 @@ SYMBOLS = {
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
     "rdis_hip_plan_debug_counters": (C.c_int, [_vp, _vp]),
+    "rdis_hip_lm_optimize": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int32, C.c_double, _vp, _vp, _vp, _vp,
+                                       C.c_int64, _vp]),
     "rdis_hip_components": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "rdis_hip_components_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
@@ -227,6 +245,24 @@ class Problem:
     def set_x(self, val, vid=None):
         val, vid = _f(val), _i(vid)
         self.ctx.check(self.ctx.lib.rdis_hip_set_x(self.h, val.shape[0], _ptr(vid), _ptr(val)))
+
+    def lm_optimize(self, free_vid=None, fac_id=None, x=None, maxiters=25, ftol=3e-8, history=256):
+        """Levenberg-Marquardt over the listed free variables / factors (bundle adjustment; the
+        least-squares problem of LMSubspaceOptimizer).  Returns an LmResult; the variables are left
+        assigned to the result."""
+        fv = np.arange(self.nvars, dtype=np.int64) if free_vid is None else _i(free_vid)
+        fc = np.arange(self.nfac, dtype=np.int64) if fac_id is None else _i(fac_id)
+        xin = None if x is None else _f(x).copy()
+        out = np.zeros(2)
+        info = np.zeros(8)
+        hist = np.zeros((max(history, 1), 4))
+        nh = np.zeros(1, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.rdis_hip_lm_optimize(self.h, fv.shape[0], _ptr(fv), fc.shape[0], _ptr(fc), _ptr(xin), maxiters, ftol,
+                                                         C.c_void_p(out.ctypes.data), C.c_void_p(out.ctypes.data + 8), _ptr(info),
+                                                         _ptr(hist), hist.shape[0], _ptr(nh)))
+        return LmResult(x=self.get_x(fv), fret=float(out[0]), delta=float(out[1]), iters=int(info[0]), stop=int(info[1]),
+                        nfev=int(info[2]), njev=int(info[3]), nsolve=int(info[4]), mu=float(info[5]),
+                        camera_blocks=int(info[6]), point_blocks=int(info[7]), history=hist[:min(int(nh[0]), hist.shape[0])].copy())
 
     def components(self, assigned):
         """(free_ptr, free_vid, fac_ptr, fac_id) of the connected components left when the variables

@@ -1,0 +1,582 @@
+// lm_solver.hip -- Levenberg-Marquardt subspace solver for bundle adjustment on the device.
+//
+// What it solves is what the reference's LMSubspaceOptimizer hands to levmar
+// (src/optimizers/LMSubspaceOptimizer.cpp:28-147, 176-278): one residual per factor,
+// e_j = sqrt(2 E_j), Jacobian row grad E_j / e_j over the free variables, unconstrained, damping
+// scale 1e-3, eps1 = eps2 = 1e-15, eps3 = SSftol, itmax = SSmaxit; the result clamped into the
+// domains afterwards.  levmar itself is not vendored by the reference (parity unpinned, SURVEY.md
+// 8c): the iteration is the published Levenberg-Marquardt with Nielsen's damping update that
+// levmar's dlevmar_der implements, restated in oracle/lm_oracle.py, which checks this file step
+// by step.
+//
+// How: the reference builds a dense n x m Jacobian.  Here the normal equations keep the
+// camera / point block structure of bundle adjustment:
+//     [ U + mu I    W        ] [dc]   [bc]       U_c = sum_j Jc_j Jc_j^T   (9x9 per camera)
+//     [ W^T         V + mu I ] [dp] = [bp]       V_p = sum_j Jp_j Jp_j^T   (3x3 per point)
+// and are reduced to the cameras:  (U + mu I - Z Z^T) dc = bc - Z y,  with L_p L_p^T = V_p + mu I,
+// Z's block (c, p) = Jc_j (L_p^-1 Jp_j)^T for the factor j that joins camera c and point p,
+// y_p = L_p^-1 bp_p;  then dp_p = L_p^-T (y_p - Z_p^T dc).
+// The two contractions run on the matrix cores (v_mfma_f64_16x16x4_f64): U_c = A_c^T A_c over a
+// camera's few hundred Jacobian rows, and the rank-3P update Z Z^T (9C x 9C x 3P; dense, Z stored
+// k-major so that operand loads are contiguous).  Everything is summed in a fixed order.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "factors.hpp"
+#include "lm_solver.hpp"
+
+namespace rdis_hip {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Dev {            // everything the kernels need, by value
+    LmProblem P;
+    int nf, nca, npa, M, Mp, Kp, SK;
+    const int *lf, *fci, *fpi;               // listed factor id, local camera / point block (-1: not active)
+    const unsigned char* freem;              // [N]
+    const int *cam_ptr, *cam_list, *pt_ptr, *pt_list;
+    const int *cam_id, *pt_id;               // first variable id of each active block
+    double *Jc, *Jp, *e;                     // [nf*9], [nf*3], [nf]
+    double *U, *bc;                          // [nca*81], [Mp]
+    double *V, *bp, *Lp, *yp, *T;            // [npa*6], [npa*3], [npa*6], [npa*3], [nf*3]
+    double *Zt;                              // [Kp][Mp]   k-major
+    double *Spart, *S, *rhs, *dc, *dp;       // [SK][Mp*Mp], [Mp*Mp], [Mp], [Mp], [npa*3]
+    double *psave;                           // accepted point: [9*nca + 3*npa] by block slot
+    double *part, *sc;                       // block partials [4096*4], scalars [16]
+};
+
+__device__ __forceinline__ double wsum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- 1. linearisation: residual and Jacobian row of every listed factor --------------------
+__global__ void __launch_bounds__(256) k_lin(Dev D) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nf) return;
+    const int f = D.lf[j];
+    const int c = D.P.cam[f], q = D.P.pt[f];
+    double v[12], g[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = D.P.x[k < 9 ? c + k : q + (k - 9)];
+    const double2 o = D.P.obs[f];
+    const double E = ba_eval_grad(v, o.x, o.y, g);
+    const double e = sqrt(2.0 * E);
+    const double inv = e > 0.0 ? 1.0 / e : 0.0;
+    D.e[j] = e;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D.Jc[9ll * j + k] = D.freem[c + k] ? g[k] * inv : 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) D.Jp[3ll * j + k] = D.freem[q + k] ? g[9 + k] * inv : 0.0;
+}
+
+// objective of the listed factors at the current x: block partials of sum e^2 / 2
+__global__ void __launch_bounds__(256) k_obj(Dev D) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < D.nf; j += gridDim.x * blockDim.x) {
+        const int f = D.lf[j];
+        const int c = D.P.cam[f], q = D.P.pt[f];
+        double v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = D.P.x[k < 9 ? c + k : q + (k - 9)];
+        const double2 o = D.P.obs[f];
+        acc += ba_eval(v, o.x, o.y);
+    }
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) D.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) k_obj_final(Dev D, int nblocks, int slot) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += D.part[i];
+    acc = wsum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) D.sc[slot] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- 2. camera blocks on the matrix cores: U_c = A_c^T A_c, bc = -A_c^T e ---------------------
+// one wave per active camera.  v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][n = l & 15]; with A = B^T = (rows of Jc)^T both are the same number.  Result
+// register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+__global__ void __launch_bounds__(64) k_cam(Dev D) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    const int b0 = D.cam_ptr[c], cnt = D.cam_ptr[c + 1] - b0;
+    const int i = l & 15, kk = l >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double bsum = 0.0;
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+        double a = 0.0, ev = 0.0;
+        if (j0 + kk < cnt && i < 9) {
+            const int j = D.cam_list[b0 + j0 + kk];
+            a = D.Jc[9ll * j + i];
+            ev = D.e[j];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        bsum += a * ev;
+    }
+    // bc: lanes i, i+16, i+32, i+48 hold the four k-phases of row i
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (l < 9) D.bc[9 * c + l] = -bsum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r, col = i;
+        if (row < 9 && col < 9) D.U[81ll * c + 9 * row + col] = acc[r];
+    }
+}
+
+// ---- 3. point blocks: V_p (lower triangle, 6 numbers), bp ------------------------------------
+__global__ void __launch_bounds__(256) k_pt(Dev D) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.npa) return;
+    double v00 = 0, v10 = 0, v11 = 0, v20 = 0, v21 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int t = D.pt_ptr[p]; t < D.pt_ptr[p + 1]; ++t) {
+        const int j = D.pt_list[t];
+        const double a = D.Jp[3ll * j], b = D.Jp[3ll * j + 1], c = D.Jp[3ll * j + 2], ev = D.e[j];
+        v00 += a * a; v10 += b * a; v11 += b * b; v20 += c * a; v21 += c * b; v22 += c * c;
+        b0 += a * ev; b1 += b * ev; b2 += c * ev;
+    }
+    double* V = D.V + 6ll * p;
+    V[0] = v00; V[1] = v10; V[2] = v11; V[3] = v20; V[4] = v21; V[5] = v22;
+    D.bp[3ll * p] = -b0; D.bp[3ll * p + 1] = -b1; D.bp[3ll * p + 2] = -b2;
+}
+
+// ---- 4. scalars: max diag(J^T J), |J^T e|_inf, |p|^2 (one block) --------------------------------
+__global__ void __launch_bounds__(1024) k_scalars(Dev D) {
+    __shared__ double r0[16], r1[16], r2[16];
+    double md = 0.0, mb = 0.0, pl = 0.0;
+    for (int t = threadIdx.x; t < 9 * D.nca; t += 1024) {
+        const int c = t / 9, k = t - 9 * c;
+        md = fmax(md, D.U[81ll * c + 10 * k]);
+        mb = fmax(mb, fabs(D.bc[t]));
+        const int v = D.cam_id[c] + k;
+        if (D.freem[v]) { const double x = D.P.x[v]; pl += x * x; }
+    }
+    for (int t = threadIdx.x; t < 3 * D.npa; t += 1024) {
+        const int p = t / 3, k = t - 3 * p;
+        md = fmax(md, D.V[6ll * p + (k == 0 ? 0 : k == 1 ? 2 : 5)]);
+        mb = fmax(mb, fabs(D.bp[t]));
+        const int v = D.pt_id[p] + k;
+        if (D.freem[v]) { const double x = D.P.x[v]; pl += x * x; }
+    }
+    md = wmax(md); mb = wmax(mb); pl = wsum(pl);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = md; r1[threadIdx.x >> 6] = mb; r2[threadIdx.x >> 6] = pl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, s = 0.0;
+        for (int w = 0; w < 16; ++w) { a = fmax(a, r0[w]); b = fmax(b, r1[w]); s += r2[w]; }
+        D.sc[0] = a; D.sc[1] = b; D.sc[2] = s;
+    }
+}
+
+// ---- 5. per damping value: point Cholesky, T_j = L_p^-1 Jp_j, Z --------------------------------
+__global__ void __launch_bounds__(256) k_ptchol(Dev D, double mu) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.npa) return;
+    const double* V = D.V + 6ll * p;
+    const double l00 = sqrt(V[0] + mu);
+    const double l10 = V[1] / l00, l20 = V[3] / l00;
+    const double l11 = sqrt(V[2] + mu - l10 * l10);
+    const double l21 = (V[4] - l20 * l10) / l11;
+    const double l22 = sqrt(V[5] + mu - l20 * l20 - l21 * l21);
+    double* L = D.Lp + 6ll * p;
+    L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
+    const double y0 = D.bp[3ll * p] / l00;
+    const double y1 = (D.bp[3ll * p + 1] - l10 * y0) / l11;
+    const double y2 = (D.bp[3ll * p + 2] - l20 * y0 - l21 * y1) / l22;
+    D.yp[3ll * p] = y0; D.yp[3ll * p + 1] = y1; D.yp[3ll * p + 2] = y2;
+}
+__global__ void __launch_bounds__(256) k_z(Dev D) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D.nf) return;
+    const int ci = D.fci[j], pi = D.fpi[j];
+    if (pi < 0) return;
+    const double* L = D.Lp + 6ll * pi;
+    const double t0 = D.Jp[3ll * j] / L[0];
+    const double t1 = (D.Jp[3ll * j + 1] - L[1] * t0) / L[2];
+    const double t2 = (D.Jp[3ll * j + 2] - L[3] * t0 - L[4] * t1) / L[5];
+    D.T[3ll * j] = t0; D.T[3ll * j + 1] = t1; D.T[3ll * j + 2] = t2;
+    if (ci < 0) return;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const double jc = D.Jc[9ll * j + a];
+        double* z = D.Zt + (long long)(3 * pi) * D.Mp + 9 * ci + a;
+        z[0] = jc * t0; z[D.Mp] = jc * t1; z[2ll * D.Mp] = jc * t2;
+    }
+}
+
+// ---- 6. Z Z^T on the matrix cores ----------------------------------------------------------------
+// grid (tile pairs, K slices); one wave per 32 x 32 tile of the product and slice of K; partial
+// products per slice, summed in slice order by k_sfinish.
+__global__ void __launch_bounds__(64) k_syrk(Dev D) {
+    const int nt = D.Mp / 32;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    if (tj > ti) return;                       // lower triangle of tiles; mirrored by k_sfinish
+    const int l = threadIdx.x, i = l & 15, kk = l >> 4;
+    const int kslice = (D.Kp / 4 + D.SK - 1) / D.SK * 4;
+    const int k0 = blockIdx.y * kslice, k1 = min(D.Kp, k0 + kslice);
+    d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    const double* za = D.Zt + 32 * ti + i;
+    const double* zb = D.Zt + 32 * tj + i;
+    for (int k = k0; k < k1; k += 4) {
+        const long long off = (long long)(k + kk) * D.Mp;
+        const double a0 = za[off], a1 = za[off + 16], b0 = zb[off], b1 = zb[off + 16];
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+    }
+    double* out = D.Spart + (long long)blockIdx.y * D.Mp * D.Mp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r, col = i;
+        out[(long long)(32 * ti + row) * D.Mp + 32 * tj + col] = c00[r];
+        out[(long long)(32 * ti + row) * D.Mp + 32 * tj + 16 + col] = c01[r];
+        out[(long long)(32 * ti + 16 + row) * D.Mp + 32 * tj + col] = c10[r];
+        out[(long long)(32 * ti + 16 + row) * D.Mp + 32 * tj + 16 + col] = c11[r];
+    }
+}
+// S = U + mu I - sum over slices (lower triangle; padding rows get a unit diagonal); rhs = bc - Z y
+__global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)D.Mp * D.Mp) return;
+    const int row = (int)(t / D.Mp), col = (int)(t % D.Mp);
+    if (col > row) return;
+    double s = 0.0;
+    for (int sl = 0; sl < D.SK; ++sl) s += D.Spart[(long long)sl * D.Mp * D.Mp + t];
+    double v = -s;
+    if (row < D.M) {
+        if (row / 9 == col / 9) v += D.U[81ll * (row / 9) + 9 * (row % 9) + (col % 9)];
+        if (row == col) v += mu;
+    } else {
+        v = row == col ? 1.0 : 0.0;
+    }
+    D.S[t] = v;
+}
+__global__ void __launch_bounds__(64) k_rhs(Dev D) {
+    const int row = blockIdx.x, l = threadIdx.x;
+    double s = 0.0;
+    if (row < D.M)
+        for (int k = l; k < 3 * D.npa; k += 64) s += D.Zt[(long long)k * D.Mp + row] * D.yp[k];
+    s = wsum(s);
+    if (l == 0) D.rhs[row] = row < D.M ? D.bc[row] - s : 0.0;
+}
+
+// ---- 7. dense Cholesky of the reduced system and the two triangular solves (one workgroup) -----
+__global__ void __launch_bounds__(1024) k_chol_solve(Dev D) {
+    const int n = D.M, ld = D.Mp, tid = threadIdx.x;
+    double* S = D.S;
+    __shared__ int bad;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double d = S[(long long)k * ld + k];
+            if (!(d > 0.0)) bad = 1;
+            S[(long long)k * ld + k] = sqrt(d);
+        }
+        __syncthreads();
+        if (bad) break;
+        const double dk = S[(long long)k * ld + k];
+        for (int i = k + 1 + tid; i < n; i += 1024) S[(long long)i * ld + k] /= dk;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i > k, columns k < j <= i
+        const int m = n - k - 1;
+        for (long long t = tid; t < (long long)m * m; t += 1024) {
+            const int i = k + 1 + (int)(t / m), j = k + 1 + (int)(t % m);
+            if (j <= i) S[(long long)i * ld + j] -= S[(long long)i * ld + k] * S[(long long)j * ld + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) D.sc[8] = bad ? 1.0 : 0.0;
+    if (bad) return;
+    // L z = rhs (column sweeps), then L^T dc = z
+    double* z = D.dc;
+    for (int i = tid; i < D.Mp; i += 1024) z[i] = D.rhs[i];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) z[k] /= S[(long long)k * ld + k];
+        __syncthreads();
+        const double zk = z[k];
+        for (int i = k + 1 + tid; i < n; i += 1024) z[i] -= S[(long long)i * ld + k] * zk;
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        if (tid == 0) z[k] /= S[(long long)k * ld + k];
+        __syncthreads();
+        const double zk = z[k];
+        for (int i = tid; i < k; i += 1024) z[i] -= S[(long long)k * ld + i] * zk;
+        __syncthreads();
+    }
+}
+// no free points at all: the camera blocks are independent 9 x 9 systems -- same kernel, S is
+// block diagonal; no free cameras: k_back alone.
+
+// ---- 8. back-substitution for the points ------------------------------------------------------
+__global__ void __launch_bounds__(256) k_back(Dev D) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.npa) return;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int t = D.pt_ptr[p]; t < D.pt_ptr[p + 1]; ++t) {
+        const int j = D.pt_list[t];
+        const int ci = D.fci[j];
+        if (ci < 0) continue;
+        double w = 0.0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) w += D.Jc[9ll * j + a] * D.dc[9 * ci + a];
+        s0 += D.T[3ll * j] * w; s1 += D.T[3ll * j + 1] * w; s2 += D.T[3ll * j + 2] * w;
+    }
+    const double* L = D.Lp + 6ll * p;
+    const double r0 = D.yp[3ll * p] - s0, r1 = D.yp[3ll * p + 1] - s1, r2 = D.yp[3ll * p + 2] - s2;
+    const double d2 = r2 / L[5];
+    const double d1 = (r1 - L[4] * d2) / L[2];
+    const double d0 = (r0 - L[1] * d1 - L[3] * d2) / L[0];
+    D.dp[3ll * p] = d0; D.dp[3ll * p + 1] = d1; D.dp[3ll * p + 2] = d2;
+}
+
+// ---- 9. trial point, |Dp|^2, dL = Dp . (mu Dp + J^T e) (one block) --------------------------------
+// mode 0: x = psave + Dp;  mode 1: psave = x (accept);  mode 2: x = psave (restore);
+// mode 3: x = clamp(psave) (final, LMSubspaceOptimizer.cpp:104-108)
+__global__ void __launch_bounds__(1024) k_apply(Dev D, double mu, int mode) {
+    __shared__ double r0[16], r1[16];
+    double dl2 = 0.0, dL = 0.0;
+    const int nc9 = 9 * D.nca, ntot = nc9 + 3 * D.npa;
+    for (int t = threadIdx.x; t < ntot; t += 1024) {
+        int v; double dpv, b;
+        if (t < nc9) { v = D.cam_id[t / 9] + t % 9; dpv = D.nca ? D.dc[t] : 0.0; b = D.bc[t]; }
+        else { const int u = t - nc9; v = D.pt_id[u / 3] + u % 3; dpv = D.dp[u]; b = D.bp[u]; }
+        if (!D.freem[v]) continue;
+        if (mode == 0) {
+            D.P.x[v] = D.psave[t] + dpv;
+            dl2 += dpv * dpv;
+            dL += dpv * (mu * dpv + b);
+        } else if (mode == 1) {
+            D.psave[t] = D.P.x[v];
+        } else if (mode == 2) {
+            D.P.x[v] = D.psave[t];
+        } else {
+            const double x = D.psave[t], lo = D.P.lo[v], hi = D.P.hi[v];
+            D.P.x[v] = (lo <= x && x <= hi) ? x : (x < lo ? lo : hi);
+        }
+    }
+    if (mode != 0) return;
+    dl2 = wsum(dl2); dL = wsum(dL);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = dl2; r1[threadIdx.x >> 6] = dL; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 16; ++w) { a += r0[w]; b += r1[w]; }
+        D.sc[3] = a; D.sc[4] = b;
+    }
+}
+
+struct Buf {
+    void* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+#define LM_CHK(expr)                                   \
+    do {                                               \
+        const hipError_t e_ = (expr);                  \
+        if (e_ != hipSuccess) return (int)e_;          \
+    } while (0)
+
+template <class T>
+int up(Buf& b, const std::vector<T>& h, hipStream_t s) {
+    LM_CHK(b.alloc(h.size() * sizeof(T)));
+    if (!h.empty()) LM_CHK(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+}  // namespace
+
+int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const int64_t* free_vid, int64_t nf,
+                 const int64_t* fac, const LmOptions& opt, LmResult* out, std::string* err) {
+    *out = LmResult();
+    auto fail = [&](const std::string& m) { if (err) *err = m; return -1; };
+    if (nfree <= 0 || nf <= 0) return fail("lm: empty variable or factor list");
+    // ---- host: which camera / point blocks are active, factor lists per block --------------------
+    std::vector<unsigned char> freem((size_t)P.N, 0);
+    for (int64_t i = 0; i < nfree; ++i) {
+        if (free_vid[i] < 0 || free_vid[i] >= P.N) return fail("lm: variable id out of range");
+        freem[(size_t)free_vid[i]] = 1;
+    }
+    const int *h_cam = P.h_cam, *h_pt = P.h_pt;
+    const int npts_all = (P.N - 9 * P.ncams) / 3;
+    std::vector<int> cam_local((size_t)std::max(P.ncams, 1), -1), pt_local((size_t)std::max(npts_all, 1), -1);
+    auto block_free = [&](int v0, int len) { for (int k = 0; k < len; ++k) if (freem[(size_t)(v0 + k)]) return true; return false; };
+    std::vector<int> lf((size_t)nf), fci((size_t)nf, -1), fpi((size_t)nf, -1), cam_id, pt_id;
+    for (int64_t j = 0; j < nf; ++j) {
+        if (fac[j] < 0 || fac[j] >= P.F) return fail("lm: factor id out of range");
+        lf[(size_t)j] = (int)fac[j];
+    }
+    // active blocks (those with a free variable) in ascending id order; a free variable that no
+    // listed factor reads has a zero column: its step is 0, like in the dense formulation
+    for (int c = 0; c < P.ncams; ++c) if (block_free(9 * c, 9)) { cam_local[(size_t)c] = (int)cam_id.size(); cam_id.push_back(9 * c); }
+    for (int p = 0; p < npts_all; ++p) if (block_free(9 * P.ncams + 3 * p, 3)) { pt_local[(size_t)p] = (int)pt_id.size(); pt_id.push_back(9 * P.ncams + 3 * p); }
+    const int nca = (int)cam_id.size(), npa = (int)pt_id.size();
+    std::vector<int> cam_ptr((size_t)nca + 1, 0), pt_ptr((size_t)npa + 1, 0);
+    for (int64_t j = 0; j < nf; ++j) {
+        const int f = lf[(size_t)j];
+        fci[(size_t)j] = cam_local[(size_t)(h_cam[(size_t)f] / 9)];
+        fpi[(size_t)j] = pt_local[(size_t)((h_pt[(size_t)f] - 9 * P.ncams) / 3)];
+        if (fci[(size_t)j] >= 0) ++cam_ptr[(size_t)fci[(size_t)j] + 1];
+        if (fpi[(size_t)j] >= 0) ++pt_ptr[(size_t)fpi[(size_t)j] + 1];
+    }
+    for (int c = 0; c < nca; ++c) cam_ptr[(size_t)c + 1] += cam_ptr[(size_t)c];
+    for (int p = 0; p < npa; ++p) pt_ptr[(size_t)p + 1] += pt_ptr[(size_t)p];
+    std::vector<int> cam_list((size_t)cam_ptr[(size_t)nca]), pt_list((size_t)pt_ptr[(size_t)npa]);
+    {
+        std::vector<int> cc(cam_ptr.begin(), cam_ptr.end() - 1), pc(pt_ptr.begin(), pt_ptr.end() - 1);
+        for (int64_t j = 0; j < nf; ++j) {   // listed order = summation order
+            if (fci[(size_t)j] >= 0) cam_list[(size_t)cc[(size_t)fci[(size_t)j]]++] = (int)j;
+            if (fpi[(size_t)j] >= 0) pt_list[(size_t)pc[(size_t)fpi[(size_t)j]]++] = (int)j;
+        }
+    }
+    // two factors joining the same camera and point would need their Z blocks added: not the BAL model
+    {
+        std::vector<int> seen((size_t)std::max(nca, 1), -1);
+        for (int p = 0; p < npa; ++p)
+            for (int t = pt_ptr[(size_t)p]; t < pt_ptr[(size_t)p + 1]; ++t) {
+                const int ci = fci[(size_t)pt_list[(size_t)t]];
+                if (ci < 0) continue;
+                if (seen[(size_t)ci] == p) return fail("lm: two listed factors join the same camera and point");
+                seen[(size_t)ci] = p;
+            }
+    }
+    Dev D{};
+    D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa;
+    D.M = 9 * nca; D.Mp = std::max(32, (D.M + 31) / 32 * 32); D.Kp = std::max(4, (3 * npa + 3) / 4 * 4);
+    const int ntile = D.Mp / 32;
+    D.SK = std::max(1, std::min(64, 2048 / std::max(1, ntile * (ntile + 1) / 2)));
+    D.SK = std::min(D.SK, std::max(1, D.Kp / 64));
+    if ((double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
+
+    Buf b_lf, b_fci, b_fpi, b_free, b_cptr, b_clist, b_pptr, b_plist, b_cid, b_pid;
+    int rc;
+    if ((rc = up(b_lf, lf, stream)) || (rc = up(b_fci, fci, stream)) || (rc = up(b_fpi, fpi, stream)) || (rc = up(b_free, freem, stream)) ||
+        (rc = up(b_cptr, cam_ptr, stream)) || (rc = up(b_clist, cam_list, stream)) || (rc = up(b_pptr, pt_ptr, stream)) ||
+        (rc = up(b_plist, pt_list, stream)) || (rc = up(b_cid, cam_id, stream)) || (rc = up(b_pid, pt_id, stream))) return rc;
+    D.lf = b_lf.as<int>(); D.fci = b_fci.as<int>(); D.fpi = b_fpi.as<int>(); D.freem = b_free.as<unsigned char>();
+    D.cam_ptr = b_cptr.as<int>(); D.cam_list = b_clist.as<int>(); D.pt_ptr = b_pptr.as<int>(); D.pt_list = b_plist.as<int>();
+    D.cam_id = b_cid.as<int>(); D.pt_id = b_pid.as<int>();
+    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Spart, S, rhs, dc, dp, psave, part, sc;
+    const size_t MM = (size_t)D.Mp * D.Mp;
+    LM_CHK(Jc.alloc((size_t)nf * 72)); LM_CHK(Jp.alloc((size_t)nf * 24)); LM_CHK(e.alloc((size_t)nf * 8));
+    LM_CHK(U.alloc((size_t)std::max(nca, 1) * 81 * 8)); LM_CHK(bc.alloc((size_t)D.Mp * 8));
+    LM_CHK(V.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(bp.alloc((size_t)std::max(npa, 1) * 24));
+    LM_CHK(Lp.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(yp.alloc((size_t)D.Kp * 8)); LM_CHK(T.alloc((size_t)nf * 24));
+    LM_CHK(Zt.alloc((size_t)D.Kp * D.Mp * 8)); LM_CHK(Spart.alloc(MM * 8 * (size_t)D.SK)); LM_CHK(S.alloc(MM * 8));
+    LM_CHK(rhs.alloc((size_t)D.Mp * 8)); LM_CHK(dc.alloc((size_t)D.Mp * 8)); LM_CHK(dp.alloc((size_t)D.Kp * 8));
+    LM_CHK(psave.alloc((size_t)(9 * nca + 3 * npa + 1) * 8)); LM_CHK(part.alloc(4096 * 8)); LM_CHK(sc.alloc(16 * 8));
+    D.Jc = Jc.as<double>(); D.Jp = Jp.as<double>(); D.e = e.as<double>(); D.U = U.as<double>(); D.bc = bc.as<double>();
+    D.V = V.as<double>(); D.bp = bp.as<double>(); D.Lp = Lp.as<double>(); D.yp = yp.as<double>(); D.T = T.as<double>();
+    D.Zt = Zt.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
+    D.dc = dc.as<double>(); D.dp = dp.as<double>(); D.psave = psave.as<double>(); D.part = part.as<double>(); D.sc = sc.as<double>();
+    LM_CHK(hipMemsetAsync(D.Zt, 0, (size_t)D.Kp * D.Mp * 8, stream));   // the block pattern of Z is fixed: zero once
+    LM_CHK(hipMemsetAsync(D.bc, 0, (size_t)D.Mp * 8, stream));
+    LM_CHK(hipMemsetAsync(D.yp, 0, (size_t)D.Kp * 8, stream));
+    LM_CHK(hipMemsetAsync(D.dc, 0, (size_t)D.Mp * 8, stream));
+    LM_CHK(hipMemsetAsync(D.dp, 0, (size_t)D.Kp * 8, stream));
+
+    const int gf = (int)((nf + 255) / 256), gp = (npa + 255) / 256, gobj = (int)std::min<int64_t>(gf, 2048);
+    double h[16];
+    auto scalars = [&]() -> int { LM_CHK(hipMemcpyAsync(h, D.sc, sizeof(h), hipMemcpyDeviceToHost, stream)); LM_CHK(hipStreamSynchronize(stream)); return 0; };
+    auto objective = [&](int slot) -> int {
+        k_obj<<<gobj, 256, 0, stream>>>(D);
+        k_obj_final<<<1, 256, 0, stream>>>(D, gobj, slot);
+        LM_CHK(hipGetLastError());
+        return 0;
+    };
+    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 1);   // psave = x
+    if ((rc = objective(5)) || (rc = scalars())) return rc;
+    double p_eL2 = 2.0 * h[5];
+    out->finit = h[5];
+    out->ncam_blocks = nca; out->npt_blocks = npa;
+    out->nfev = 1;
+    double mu = 0.0;
+    long long nu = 2;
+    int stop = 0, k = 0;
+    const double EPSILON = 1e-12, ONE_THIRD = 0.3333333334;
+    while (k < opt.maxiters && !stop) {
+        if (p_eL2 <= opt.eps3) { stop = 6; break; }
+        k_lin<<<gf, 256, 0, stream>>>(D);
+        if (nca) k_cam<<<nca, 64, 0, stream>>>(D);
+        if (npa) k_pt<<<gp, 256, 0, stream>>>(D);
+        k_scalars<<<1, 1024, 0, stream>>>(D);
+        LM_CHK(hipGetLastError());
+        if ((rc = scalars())) return rc;
+        ++out->njev;
+        const double maxdiag = h[0], jte_inf = h[1], p_L2 = h[2];
+        if (jte_inf <= opt.eps1) { stop = 1; break; }
+        if (k == 0) mu = opt.tau * maxdiag;
+        for (;;) {
+            if (npa) {
+                k_ptchol<<<gp, 256, 0, stream>>>(D, mu);
+                k_z<<<gf, 256, 0, stream>>>(D);
+            }
+            if (nca) {
+                const int nt = D.Mp / 32;
+                k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
+                k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D, mu);
+                k_rhs<<<D.Mp, 64, 0, stream>>>(D);
+                k_chol_solve<<<1, 1024, 0, stream>>>(D);
+            }
+            if (npa) k_back<<<gp, 256, 0, stream>>>(D);
+            k_apply<<<1, 1024, 0, stream>>>(D, mu, 0);
+            LM_CHK(hipGetLastError());
+            if ((rc = objective(5)) || (rc = scalars())) return rc;
+            ++out->nsolve;
+            const bool solved = !(nca && h[8] != 0.0);
+            if (solved) {
+                const double Dp_L2 = h[3], dL = h[4];
+                if (Dp_L2 <= opt.eps2 * opt.eps2 * p_L2) { stop = 2; break; }
+                if (Dp_L2 >= (p_L2 + opt.eps2) / (EPSILON * EPSILON)) { stop = 4; break; }
+                ++out->nfev;
+                const double pDp_eL2 = 2.0 * h[5];
+                if (!std::isfinite(pDp_eL2)) { stop = 7; break; }
+                const double dF = p_eL2 - pDp_eL2;
+                const bool ok = dL > 0.0 && dF > 0.0;
+                out->history.push_back(LmStep{mu, Dp_L2, h[5], ok ? 1 : 0});
+                if (ok) {
+                    double tmp = 2.0 * dF / dL - 1.0;
+                    tmp = 1.0 - tmp * tmp * tmp;
+                    mu = mu * (tmp >= ONE_THIRD ? tmp : ONE_THIRD);
+                    nu = 2;
+                    p_eL2 = pDp_eL2;
+                    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 1);   // accept: psave = x
+                    break;
+                }
+            }
+            mu *= (double)nu;
+            const long long nu2 = nu << 1;
+            if (nu2 >= (1ll << 31)) { stop = 5; break; }
+            nu = nu2;
+        }
+        ++k;
+    }
+    if (!stop) stop = 3;
+    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 3);   // x = clamp(accepted point)
+    if ((rc = objective(5)) || (rc = scalars())) return rc;
+    out->fret = h[5];
+    out->mu = mu; out->iters = k; out->stop = stop;
+    return 0;
+}
+
+}  // namespace rdis_hip

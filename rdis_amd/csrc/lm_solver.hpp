@@ -1,0 +1,39 @@
+// lm_solver.hpp -- interface of lm_solver.hip: Levenberg-Marquardt for a bundle-adjustment
+// sub-problem, normal equations reduced to the cameras by a Schur complement, on the device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rdis_hip {
+
+struct LmProblem {          // device arrays of an uploaded bundle-adjustment problem
+    int N, F, ncams;        // ncams: variables 0 .. 9*ncams-1 are cameras, the rest points (3 each)
+    double* x;
+    const double *lo, *hi;
+    const int *cam, *pt;    // first variable id of each factor's camera / point block (device)
+    const int *h_cam, *h_pt; // the same on the host
+    const double2* obs;
+};
+
+struct LmOptions {
+    int maxiters;           // SSmaxit
+    double tau, eps1, eps2, eps3;   // levmar opts[0..3] (reference: 1e-3, 1e-15, 1e-15, SSftol)
+};
+
+struct LmStep { double mu, dp_l2, f_trial; int accepted; };
+
+struct LmResult {
+    double fret = 0, finit = 0, mu = 0;
+    int iters = 0, stop = 0, nfev = 0, njev = 0, nsolve = 0;
+    int ncam_blocks = 0, npt_blocks = 0;
+    std::vector<LmStep> history;    // one entry per linear solve
+};
+
+// free_vid / fac: host arrays (sorted ascending not required).  x is updated in place: the free
+// variables end at the clamped result.  Returns 0, a hipError_t (> 0), or -1 with *err set.
+int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const int64_t* free_vid, int64_t nf,
+                 const int64_t* fac, const LmOptions& opt, LmResult* out, std::string* err);
+
+}  // namespace rdis_hip

@@ -164,12 +164,14 @@ struct CgdMachine {
         // next trial point), ~85 % of all steps.  Written with selects instead of branches -- a
         // taken branch costs this single in-order wave more than the arithmetic it skips -- and
         // with exactly the operations of the branchy form below (S_DB_EVAL / S_DB_HEAD).
-        if (st == S_DB_EVAL) {
-            // the whole Brent state is loaded once, up front (the loads overlap) and made opaque:
-            // left to itself the compiler turns every select between two fields into a select
-            // between two LDS addresses followed by a dependent load
-            double a_ = a, b_ = b, x_ = x, w_ = w, v_ = v, fx_ = fx, fw_ = fw, fv_ = fv;
-            double dx_ = dx, dw_ = dw, dv_ = dv, d_ = d, e_ = e, uu_ = uu;
+        // The whole Brent state is loaded once, up front and before the state is even looked at
+        // (the loads overlap; an LDS round trip is ~130 cycles for this lone wave), and made
+        // opaque: left to itself the compiler turns every select between two fields into a select
+        // between two LDS addresses followed by a dependent load.
+        double a_ = a, b_ = b, x_ = x, w_ = w, v_ = v, fx_ = fx, fw_ = fw, fv_ = fv;
+        double dx_ = dx, dw_ = dw, dv_ = dv, d_ = d, e_ = e, uu_ = uu;
+        const int st_ = st;
+        if (st_ == S_DB_EVAL) {
             opaque(a_); opaque(b_); opaque(x_); opaque(w_); opaque(v_); opaque(fx_); opaque(fw_); opaque(fv_);
             opaque(dx_); opaque(dw_); opaque(dv_); opaque(d_); opaque(e_); opaque(uu_);
             const bool tiny_ = tiny;

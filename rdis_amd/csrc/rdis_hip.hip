@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "components.hpp"
+#include "lm_solver.hpp"
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
 #include "solver_stream.hpp"
@@ -1026,6 +1027,53 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
         HIPCHK(c, hipMemcpyAsync(rec4, L->trace.as<double>() + 4ll * L->trace_records * comp, (size_t)k * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const int64_t* free_vid, int64_t nf, const int64_t* fac_id,
+                                    double* x_inout, int32_t maxiters, double ftol, double* fret, double* delta, double* info8,
+                                    double* hist4, int64_t hist_cap, int64_t* nhist) {
+    if (!p) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (p->kind != KIND_BA) return fail(c, RDIS_HIP_EINVAL, "lm_optimize: bundle adjustment problems only");
+    if (nfree <= 0 || nf <= 0 || !free_vid || !fac_id || maxiters < 1) return fail(c, RDIS_HIP_EINVAL, "lm_optimize: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    // cameras occupy the ids below the first point block (BundleAdjustmentFunction.h:88-96)
+    int minpt = INT32_MAX;
+    for (int64_t f = 0; f < p->F; ++f) minpt = std::min(minpt, p->h_pt[(size_t)f]);
+    const int ncams = p->F > 0 ? minpt / 9 : 0;
+    for (int64_t f = 0; f < p->F; ++f)
+        if (p->h_cam[(size_t)f] % 9 != 0 || p->h_cam[(size_t)f] >= 9 * ncams || (p->h_pt[(size_t)f] - 9 * ncams) % 3 != 0)
+            return fail(c, RDIS_HIP_EINVAL, "lm_optimize: variables are not laid out as camera blocks of 9 followed by point blocks of 3");
+    if (x_inout) {
+        std::vector<int64_t> ids(free_vid, free_vid + nfree);
+        int rc = rdis_hip_set_x(p, nfree, ids.data(), x_inout);
+        if (rc) return rc;
+    }
+    LmProblem P{(int)p->N, (int)p->F, ncams, p->x.as<double>(), p->lo.as<double>(), p->hi.as<double>(),
+                p->cam.as<int>(), p->pt.as<int>(), p->h_cam.data(), p->h_pt.data(), p->obs.as<double2>()};
+    LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol};
+    LmResult r;
+    std::string err;
+    const int e = device_lm_ba(c->stream, P, nfree, free_vid, nf, fac_id, o, &r, &err);
+    if (e < 0) return fail(c, RDIS_HIP_EINVAL, err);
+    if (e > 0) return fail(c, RDIS_HIP_EDEVICE, std::string("lm_optimize: ") + hipGetErrorString((hipError_t)e));
+    if (x_inout) {
+        int rc = rdis_hip_get_x(p, nfree, free_vid, x_inout);
+        if (rc) return rc;
+    }
+    if (fret) *fret = r.fret;
+    if (delta) *delta = r.fret - r.finit;
+    if (info8) {
+        info8[0] = r.iters; info8[1] = r.stop; info8[2] = r.nfev; info8[3] = r.njev; info8[4] = r.nsolve; info8[5] = r.mu;
+        info8[6] = r.ncam_blocks; info8[7] = r.npt_blocks;
+    }
+    if (nhist) *nhist = (int64_t)r.history.size();
+    if (hist4)
+        for (size_t i = 0; i < r.history.size() && (int64_t)i < hist_cap; ++i) {
+            hist4[4 * i] = r.history[i].mu; hist4[4 * i + 1] = r.history[i].dp_l2;
+            hist4[4 * i + 2] = r.history[i].f_trial; hist4[4 * i + 3] = r.history[i].accepted;
+        }
     return 0;
 }
 
