@@ -267,64 +267,161 @@ __global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu) {
     }
     D.S[t] = v;
 }
+// rhs = bc - Z y, one wave per active camera over its factor list: Z's block of factor j times y_p
+// is Jc_j (T_j . y_p)
 __global__ void __launch_bounds__(64) k_rhs(Dev D) {
-    const int row = blockIdx.x, l = threadIdx.x;
-    double s = 0.0;
-    if (row < D.M)
-        for (int k = l; k < 3 * D.npa; k += 64) s += D.Zt[(long long)k * D.Mp + row] * D.yp[k];
-    s = wsum(s);
-    if (l == 0) D.rhs[row] = row < D.M ? D.bc[row] - s : 0.0;
+    const int c = blockIdx.x, l = threadIdx.x;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = D.cam_ptr[c] + l; t < D.cam_ptr[c + 1]; t += 64) {
+        const int j = D.cam_list[t], pi = D.fpi[j];
+        if (pi < 0) continue;
+        const double w = D.T[3ll * j] * D.yp[3ll * pi] + D.T[3ll * j + 1] * D.yp[3ll * pi + 1] + D.T[3ll * j + 2] * D.yp[3ll * pi + 2];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) acc[a] += D.Jc[9ll * j + a] * w;
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const double s = wsum(acc[a]);
+        if (l == 0) D.rhs[9 * c + a] = D.bc[9 * c + a] - s;
+    }
 }
 
-// ---- 7. dense Cholesky of the reduced system and the two triangular solves (one workgroup) -----
-__global__ void __launch_bounds__(1024) k_chol_solve(Dev D) {
-    const int n = D.M, ld = D.Mp, tid = threadIdx.x;
-    double* S = D.S;
+// ---- 7. dense Cholesky of the reduced system, blocked (panel width 32), and the solves ----------
+// The padded matrix (order Mp, a multiple of 32, unit diagonal in the padding) is factored in
+// place, right-looking: per panel  k_potf2 (32 x 32 diagonal block, in LDS)  ->  k_trsm (rows below:
+// X = A L^-T, one lane per row)  ->  k_trail (trailing matrix -= X X^T on the matrix cores).
+__global__ void __launch_bounds__(1024) k_potf2(Dev D, int kb) {
+    __shared__ double A[32][33];
+    const int ld = D.Mp, i = threadIdx.x >> 5, j = threadIdx.x & 31;
+    A[i][j] = j <= i ? D.S[(long long)(kb + i) * ld + kb + j] : 0.0;
     __shared__ int bad;
-    if (tid == 0) bad = 0;
+    if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            const double d = S[(long long)k * ld + k];
+    for (int k = 0; k < 32; ++k) {
+        if (threadIdx.x == 0) {
+            const double d = A[k][k];
             if (!(d > 0.0)) bad = 1;
-            S[(long long)k * ld + k] = sqrt(d);
+            A[k][k] = sqrt(d);
         }
         __syncthreads();
-        if (bad) break;
-        const double dk = S[(long long)k * ld + k];
-        for (int i = k + 1 + tid; i < n; i += 1024) S[(long long)i * ld + k] /= dk;
+        if (j == k && i > k) A[i][k] /= A[k][k];
         __syncthreads();
-        // trailing update of the lower triangle: rows i > k, columns k < j <= i
-        const int m = n - k - 1;
-        for (long long t = tid; t < (long long)m * m; t += 1024) {
-            const int i = k + 1 + (int)(t / m), j = k + 1 + (int)(t % m);
-            if (j <= i) S[(long long)i * ld + j] -= S[(long long)i * ld + k] * S[(long long)j * ld + k];
-        }
+        if (j > k && i >= j) A[i][j] -= A[i][k] * A[j][k];
         __syncthreads();
     }
-    if (tid == 0) D.sc[8] = bad ? 1.0 : 0.0;
-    if (bad) return;
-    // L z = rhs (column sweeps), then L^T dc = z
-    double* z = D.dc;
-    for (int i = tid; i < D.Mp; i += 1024) z[i] = D.rhs[i];
+    if (j <= i) D.S[(long long)(kb + i) * ld + kb + j] = A[i][j];
+    if (threadIdx.x == 0 && bad) D.sc[8] = 1.0;
+}
+__global__ void __launch_bounds__(256) k_trsm(Dev D, int kb) {
+    __shared__ double L[32][33];
+    const int ld = D.Mp;
+    for (int t = threadIdx.x; t < 1024; t += 256) L[t >> 5][t & 31] = D.S[(long long)(kb + (t >> 5)) * ld + kb + (t & 31)];
     __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        if (tid == 0) z[k] /= S[(long long)k * ld + k];
+    const int row = kb + 32 + blockIdx.x * 256 + threadIdx.x;
+    if (row >= D.Mp) return;
+    double* a = D.S + (long long)row * ld + kb;
+    double x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = a[c];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        double v = x[c];
+#pragma unroll
+        for (int t = 0; t < c; ++t) v -= x[t] * L[c][t];
+        x[c] = v / L[c][c];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = x[c];
+}
+__global__ void __launch_bounds__(64) k_trail(Dev D, int kb) {
+    const int r0 = kb + 32, nt = (D.Mp - r0) / 32;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    if (tj > ti) return;
+    const int l = threadIdx.x, i = l & 15, kk = l >> 4, ld = D.Mp;
+    d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    const double* xa = D.S + (long long)(r0 + 32 * ti + i) * ld + kb + kk;
+    const double* xb = D.S + (long long)(r0 + 32 * tj + i) * ld + kb + kk;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        const double a0 = xa[k], a1 = xa[16ll * ld + k], b0 = xb[k], b1 = xb[16ll * ld + k];
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r, col = i;
+        double* o = D.S + (long long)(r0 + 32 * ti + row) * ld + r0 + 32 * tj + col;
+        o[0] -= c00[r];
+        o[16] -= c01[r];
+        o[16ll * ld] -= c10[r];
+        o[16ll * ld + 16] -= c11[r];
+    }
+}
+// L z = rhs, then L^T dc = z, blocked like the factorisation (one workgroup): a 32 x 32 triangular
+// solve inside one wave (values exchanged by shuffles), then every other row takes its update.
+__global__ void __launch_bounds__(1024) k_trsv(Dev D) {
+    const int n = D.Mp, ld = D.Mp, tid = threadIdx.x;
+    const double* S = D.S;
+    double* z = D.dc;
+    if (D.sc[8] != 0.0) return;
+    for (int i = tid; i < n; i += 1024) z[i] = D.rhs[i];
+    __syncthreads();
+    for (int kb = 0; kb < n; kb += 32) {
+        if (tid < 64) {
+            const int i = tid & 31;
+            double row[32];   // this lane's row of the diagonal block, fetched before the serial part
+#pragma unroll
+            for (int c = 0; c < 32; ++c) row[c] = S[(long long)(kb + i) * ld + kb + c];
+            double zi = z[kb + i], dinv = 1.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c == i) dinv = 1.0 / row[c];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const double xc = __shfl(zi * dinv, c);
+                if (i == c) zi = xc;
+                else if (i > c) zi -= row[c] * xc;
+            }
+            if (tid < 32) z[kb + i] = zi;
+        }
         __syncthreads();
-        const double zk = z[k];
-        for (int i = k + 1 + tid; i < n; i += 1024) z[i] -= S[(long long)i * ld + k] * zk;
+        for (int i = kb + 32 + tid; i < n; i += 1024) {
+            const double* row = S + (long long)i * ld + kb;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc += row[c] * z[kb + c];
+            z[i] -= acc;
+        }
         __syncthreads();
     }
-    for (int k = n - 1; k >= 0; --k) {
-        if (tid == 0) z[k] /= S[(long long)k * ld + k];
+    for (int kb = n - 32; kb >= 0; kb -= 32) {
+        if (tid < 64) {
+            const int i = tid & 31;
+            double col[32];   // this lane's column of the diagonal block
+#pragma unroll
+            for (int c = 0; c < 32; ++c) col[c] = S[(long long)(kb + c) * ld + kb + i];
+            double zi = z[kb + i], dinv = 1.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c == i) dinv = 1.0 / col[c];
+#pragma unroll
+            for (int c = 31; c >= 0; --c) {
+                const double xc = __shfl(zi * dinv, c);
+                if (i == c) zi = xc;
+                else if (i < c) zi -= col[c] * xc;
+            }
+            if (tid < 32) z[kb + i] = zi;
+        }
         __syncthreads();
-        const double zk = z[k];
-        for (int i = tid; i < k; i += 1024) z[i] -= S[(long long)k * ld + i] * zk;
+        for (int j = tid; j < kb; j += 1024) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc += S[(long long)(kb + c) * ld + j] * z[kb + c];
+            z[j] -= acc;
+        }
         __syncthreads();
     }
 }
-// no free points at all: the camera blocks are independent 9 x 9 systems -- same kernel, S is
-// block diagonal; no free cameras: k_back alone.
 
 // ---- 8. back-substitution for the points ------------------------------------------------------
 __global__ void __launch_bounds__(256) k_back(Dev D) {
@@ -494,6 +591,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     LM_CHK(hipMemsetAsync(D.yp, 0, (size_t)D.Kp * 8, stream));
     LM_CHK(hipMemsetAsync(D.dc, 0, (size_t)D.Mp * 8, stream));
     LM_CHK(hipMemsetAsync(D.dp, 0, (size_t)D.Kp * 8, stream));
+    LM_CHK(hipMemsetAsync(D.rhs, 0, (size_t)D.Mp * 8, stream));
 
     const int gf = (int)((nf + 255) / 256), gp = (npa + 255) / 256, gobj = (int)std::min<int64_t>(gf, 2048);
     double h[16];
@@ -535,8 +633,18 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                 const int nt = D.Mp / 32;
                 k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
                 k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D, mu);
-                k_rhs<<<D.Mp, 64, 0, stream>>>(D);
-                k_chol_solve<<<1, 1024, 0, stream>>>(D);
+                k_rhs<<<nca, 64, 0, stream>>>(D);
+                LM_CHK(hipMemsetAsync(D.sc + 8, 0, 8, stream));
+                for (int kb = 0; kb < D.Mp; kb += 32) {
+                    k_potf2<<<1, 1024, 0, stream>>>(D, kb);
+                    const int rem = D.Mp - kb - 32;
+                    if (rem > 0) {
+                        k_trsm<<<(rem + 255) / 256, 256, 0, stream>>>(D, kb);
+                        const int ntr = rem / 32;
+                        k_trail<<<ntr * ntr, 64, 0, stream>>>(D, kb);
+                    }
+                }
+                k_trsv<<<1, 1024, 0, stream>>>(D);
             }
             if (npa) k_back<<<gp, 256, 0, stream>>>(D);
             k_apply<<<1, 1024, 0, stream>>>(D, mu, 0);

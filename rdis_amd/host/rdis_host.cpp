@@ -500,6 +500,35 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
     return total;
 }
 
+HipLMSubspaceOptimizer::HipLMSubspaceOptimizer(OptimizableFunction& f_)
+    : SubspaceOptimizer(f_), last_iters_(0), last_stop_(0), last_nsolve_(0) {}
+
+Numeric HipLMSubspaceOptimizer::optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xval,
+                                         Numeric& deltaFval, const bool printdbg) {
+    if (xval.size() != vars.size()) throw std::invalid_argument("optimize: xval.size() != vars.size()");
+    if (factors.empty() || vars.empty()) { deltaFval = 0; return 0; }
+    std::vector<int64_t> free_vid, fac_id;
+    for (const Variable* v : vars) free_vid.push_back(v->getID());
+    for (const Factor* fa : factors) fac_id.push_back(fa->getID());
+    rdis_hip_problem* p = f.deviceProblem();
+    double fret = 0, delta = 0, info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    check(f.deviceContext(), rdis_hip_lm_optimize(p, (int64_t)free_vid.size(), free_vid.data(), (int64_t)fac_id.size(), fac_id.data(),
+                                                  xval.data(), (int32_t)maxiters, ftol, &fret, &delta, info, nullptr, 0, nullptr),
+          "rdis_hip_lm_optimize");
+    // the variables are left assigned to the final, clamped values (LMSubspaceOptimizer.cpp:104-108)
+    for (size_t i = 0; i < vars.size(); ++i) {
+        Variable* v = vars[i];
+        v->assigned_ = true; v->value_ = xval[i];
+        f.onVarAssigned(v->getID(), xval[i]);
+    }
+    deltaFval = delta;
+    last_iters_ = (int)info[0]; last_stop_ = (int)info[1]; last_nsolve_ = (int)info[4];
+    if (printdbg)
+        std::cout << "LM SS opt returned " << fret << " (init " << fret - delta << ", diff " << delta << ") after "
+                  << last_iters_ << " iterations -- termination: " << last_stop_ << ", #linsolves " << last_nsolve_ << std::endl;
+    return fret;
+}
+
 std::vector<HipCGDSubspaceOptimizer::Component> HipCGDSubspaceOptimizer::createChildren() {
     const VariablePtrVec& vars = f.getVariables();
     const FactorPtrVec& facs = f.getFactors();

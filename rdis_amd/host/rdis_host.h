@@ -89,6 +89,7 @@ public:
 private:
     friend class OptimizableFunction;
     friend class HipCGDSubspaceOptimizer;
+    friend class HipLMSubspaceOptimizer;
     VariableID id_;
     std::string name_;
     VariableDomain dom_;
@@ -197,6 +198,7 @@ private:
     friend class Variable;
     friend class Factor;
     friend class HipCGDSubspaceOptimizer;
+    friend class HipLMSubspaceOptimizer;
     void markDirty(VariableID id) const;
     void pushAssignments() const;
     void ensureUploaded() const;
@@ -297,6 +299,24 @@ public:
 private:
     int last_iters_, last_status_;
     long long last_nfeval_, last_ngeval_;
+};
+
+// The drop-in for LMSubspaceOptimizer (src/optimizers/LMSubspaceOptimizer.h): same contract and
+// the same least-squares problem (one residual sqrt(2 E_j) per factor, levmar's options as set at
+// LMSubspaceOptimizer.cpp:84-101), solved on the MI355X by rdis_hip_lm_optimize -- block normal
+// equations, Schur complement onto the cameras, matrix-core contractions.  Bundle adjustment
+// functions only.  levmar is not part of the reference tree: parity is unpinned (oracle/lm_oracle.py).
+class HipLMSubspaceOptimizer : public SubspaceOptimizer {
+public:
+    explicit HipLMSubspaceOptimizer(OptimizableFunction& f_);
+    virtual ~HipLMSubspaceOptimizer() {}
+    virtual Numeric optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xinit,
+                             Numeric& deltaFval, const bool printdbg);
+    int lastIters() const { return last_iters_; }
+    int lastStop() const { return last_stop_; }          // levmar's termination code (info[6])
+    int lastLinearSolves() const { return last_nsolve_; }
+private:
+    int last_iters_, last_stop_, last_nsolve_;
 };
 
 // error raised when the HIP library reports a failure (no silent fallback)

@@ -199,4 +199,25 @@ int harness_ba_children_batch(const char* path, long long ncams, long long npts,
     } catch (const std::exception& e) { std::cerr << "harness_ba_children_batch: " << e.what() << std::endl; return -2; }
 }
 
+// LMSubspaceOptimizer's place taken by HipLMSubspaceOptimizer: all variables of a BAL subset.
+// out = {fret, delta, f_before, f_after, iterations, stop, linear solves}
+int harness_ba_lm(const char* path, long long ncams, long long npts, int maxit, double* out, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        NumericVec x = f.getInitialState();
+        f.assignAll(x);
+        const Numeric before = f.eval();
+        HipLMSubspaceOptimizer lm(f);
+        Options o; o.set("SSmaxit", maxit);
+        lm.setParameters(o);
+        Numeric delta = 0;
+        const Numeric fret = lm.optimize(f.getVariables(), f.getFactors(), x, delta, false);
+        const Numeric after = f.eval();
+        out[0] = fret; out[1] = delta; out[2] = before; out[3] = after; out[4] = lm.lastIters(); out[5] = lm.lastStop(); out[6] = lm.lastLinearSolves();
+        for (size_t i = 0; i < x.size(); ++i) x_out[i] = x[i];
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_ba_lm: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

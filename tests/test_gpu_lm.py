@@ -1,0 +1,95 @@
+"""The second subspace solver, Levenberg-Marquardt for bundle adjustment (rdis_hip_lm_optimize;
+reference shape: LMSubspaceOptimizer + levmar).  levmar is not vendored by the reference, so parity
+is UNPINNED; the device solver (block normal equations, Schur complement, fp64 matrix-core
+contractions) is checked step by step against the dense numpy restatement in oracle/lm_oracle.py,
+and by properties at full size."""
+import numpy as np
+import pytest
+
+from oracle import lm_oracle as LM
+from oracle import oracle as O
+from rdis_amd import capi, problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(r, ro, tol_hist=1e-7):
+    assert (r.iters, r.stop, r.nsolve, r.nfev, r.njev) == (ro.iters, ro.stop, ro.nsolve, ro.nfev, ro.njev)
+    assert len(r.history) == len(ro.history)
+    for (mu, dp, ft, ok), (omu, odp, oft, ook) in zip(r.history, ro.history):
+        assert bool(ok) == bool(ook)                                    # same accept / reject decisions
+        assert abs(mu - omu) <= tol_hist * omu and abs(dp - odp) <= tol_hist * odp and abs(ft - oft) <= tol_hist * abs(oft)
+    assert abs(r.fret - ro.fret) <= 1e-8 * abs(ro.fret) and abs(r.mu - ro.mu) <= 1e-6 * ro.mu
+    assert np.max(np.abs(r.x - ro.x)) <= 1e-7 * (1.0 + np.max(np.abs(ro.x)))
+
+
+@pytest.mark.parametrize("nc,npt,iters", [(5, 30, 25), (49, 300, 12)])
+def test_lm_steps_equal_dense_oracle(nc, npt, iters, gctx):
+    pp = P.load_bal(ncams=nc, npts=npt)
+    r = capi.Problem(gctx, pp).lm_optimize(maxiters=iters)
+    ro = LM.lm_optimize(O.OracleProblem(pp, emulate_stale_cache=False), maxiters=iters)
+    _compare(r, ro)
+    assert r.camera_blocks == nc and r.point_blocks == npt and r.delta < 0
+
+
+def test_lm_sub_block_with_constants(gctx):
+    """free: camera 0's rotation and translation (not its intrinsics), camera 3, points 0..9; only the
+    factors of those points listed; everything else constant"""
+    pp = P.load_bal(ncams=5, npts=30)
+    free = np.concatenate([np.arange(0, 6), np.arange(27, 36), np.arange(45, 75)]).astype(np.int64)
+    fac = np.where(pp.pt_vid0 < 75)[0].astype(np.int64)
+    g = capi.Problem(gctx, pp)
+    r = g.lm_optimize(free, fac, maxiters=15)
+    ro = LM.lm_optimize(O.OracleProblem(pp, emulate_stale_cache=False), free, fac, maxiters=15)
+    _compare(r, ro)
+    x_all = g.get_x()
+    rest = np.setdiff1d(np.arange(pp.nvars), free)
+    assert np.array_equal(x_all[rest], pp.x0[rest]) and np.array_equal(x_all[free], r.x)   # constants untouched, block left assigned
+    # cameras only (no free point: the reduced system is the whole system) and points only (no dense solve)
+    for fr in (np.arange(0, 45, dtype=np.int64), np.arange(45, 135, dtype=np.int64)):
+        g.set_x(pp.x0)
+        r = g.lm_optimize(fr, None, maxiters=8)
+        ro = LM.lm_optimize(O.OracleProblem(pp, emulate_stale_cache=False), fr, None, maxiters=8)
+        _compare(r, ro)
+
+
+def test_lm_full_ladybug_properties(gctx):
+    pp = P.load_bal()
+    g = capi.Problem(gctx, pp)
+    f0 = g.eval()
+    r = g.lm_optimize(maxiters=10)
+    assert r.camera_blocks == 49 and r.point_blocks == 7776 and r.iters == 10 and r.stop == 3
+    assert abs((r.fret - r.delta) - f0) <= 1e-12 * f0 and r.fret < 0.6 * f0
+    accepted = r.history[r.history[:, 3] == 1]
+    assert len(accepted) == 10 and np.all(np.diff(accepted[:, 2]) < 0)     # every accepted step lowers the objective
+    assert np.array_equal(g.get_x(), r.x) and abs(g.eval() - r.fret) <= 1e-12 * r.fret
+    assert np.all(r.x >= pp.lo) and np.all(r.x <= pp.hi)
+    o = O.OracleProblem(pp)
+    o.assign(None, r.x)
+    assert abs(o.eval() - r.fret) <= 1e-12 * r.fret                         # oracle's objective at the device's point
+    # the first step solves the damped normal equations: check the residual of that linear system on the CPU
+    # (domains removed: the final clamp -- 36 intrinsics here -- is not part of the linear step)
+    pp = P.load_bal()
+    pp.lo[:], pp.hi[:] = -np.inf, np.inf
+    r1 = capi.Problem(gctx, pp).lm_optimize(maxiters=1)
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    grad = o.gradient()
+    dp = r1.x - pp.x0
+    assert r1.history[-1, 3] == 1
+    mu = r1.history[-1, 0]                                                   # the damping of the accepted solve
+    E, G = o.eval_each(np.arange(pp.nfac)), o.grad_each_ba(np.arange(pp.nfac))
+    Jd = np.zeros(pp.nvars)                                                  # (J^T J + mu I) dp + grad, matrix-free
+    vids = np.concatenate([pp.cam_vid0[:, None] + np.arange(9), pp.pt_vid0[:, None] + np.arange(3)], axis=1)
+    rows = G / np.sqrt(2.0 * E)[:, None]
+    np.add.at(Jd, vids.reshape(-1), (rows * np.sum(rows * dp[vids], axis=1)[:, None]).reshape(-1))
+    res = Jd + mu * dp + grad
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(grad)
+
+
+def test_lm_argument_errors(gctx):
+    q = P.load_poly()
+    with pytest.raises(capi.RdisHipError):
+        capi.Problem(gctx, q).lm_optimize()
+    pp = P.load_bal(ncams=5, npts=30)
+    with pytest.raises(capi.RdisHipError):
+        capi.Problem(gctx, pp).lm_optimize(np.array([0, 99999]), None)

@@ -182,3 +182,16 @@ def test_children_found_on_the_device_then_solved(harness, bal_path):
     assert harness.harness_ba_points_batch(bal_path, 49, 500, 25, ref.ctypes.data_as(C.c_void_p)) == 0
     assert out[2] == 500 and out[6] == 3 and out[7] == 3
     assert np.array_equal(out[:6], ref)                                     # same components, same launch: bit-identical
+
+
+@pytest.mark.gpu
+def test_lm_optimizer_through_plugin(harness, bal_path, gctx):
+    from rdis_amd import capi
+    out, x = np.zeros(7), np.zeros(135)
+    assert harness.harness_ba_lm(bal_path, 5, 30, 25, out.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p)) == 0
+    fret, delta, before, after, iters, stop, nsolve = out
+    pp = P.load_bal(ncams=5, npts=30)
+    r = capi.Problem(gctx, pp).lm_optimize(maxiters=25)                     # the C ABI directly: same kernels, same inputs
+    assert fret == r.fret and np.array_equal(x, r.x) and (iters, stop, nsolve) == (r.iters, r.stop, r.nsolve)
+    assert abs(before - 2111.5030158718296) <= 1e-12 * before and abs((fret - delta) - before) <= 1e-12 * before
+    assert abs(after - fret) <= 1e-12 * fret and delta < 0                  # variables left assigned to the result

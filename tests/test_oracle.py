@@ -316,3 +316,19 @@ def test_components_isolated_variable_and_constant_factor():
     # by (size, smallest id): {2} (no factors), {3} (factor 1), {0,1} (factor 0)
     assert list(fp) == [0, 1, 2, 4] and list(fv) == [2, 3, 0, 1]
     assert list(cp) == [0, 0, 1, 2] and list(ci) == [1, 0]
+
+
+# ---- Levenberg-Marquardt restatement (parity unpinned, oracle/lm_oracle.py) ----------------------
+def test_lm_oracle_least_squares_problem_and_descent():
+    from oracle import lm_oracle as LM
+    pp = P.load_bal(ncams=5, npts=30)
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    fv, fc = np.arange(pp.nvars), np.arange(pp.nfac)
+    e, J = LM.residuals_and_jacobian(o, fv, fc)
+    assert abs(0.5 * e @ e - o.eval()) <= 1e-12 * o.eval()              # sum e_j^2 / 2 is the objective (LMSubspaceOptimizer.cpp:196-200)
+    assert np.max(np.abs(J.T @ e - o.gradient())) <= 1e-10 * np.max(np.abs(o.gradient()))   # J^T e is its gradient (:258-275)
+    r = LM.lm_optimize(o, maxiters=25)
+    acc = [h for h in r.history if h[3]]
+    assert r.stop == 3 and r.iters == 25 and len(acc) == 25
+    assert all(b[2] < a[2] for a, b in zip(acc, acc[1:])) and r.fret < 0.05 * r.finit
+    assert np.all(r.x >= pp.lo) and np.all(r.x <= pp.hi)
