@@ -220,35 +220,41 @@ __global__ void __launch_bounds__(256) k_z(Dev D) {
 }
 
 // ---- 6. Z Z^T on the matrix cores ----------------------------------------------------------------
-// grid (tile pairs, K slices); one wave per 32 x 32 tile of the product and slice of K; partial
+// grid (tile pairs, K slices); one wave per 64 x 64 tile of the product (sixteen accumulators:
+// eight operand loads feed sixteen MFMAs) and slice of K; partial
 // products per slice, summed in slice order by k_sfinish.
 __global__ void __launch_bounds__(64) k_syrk(Dev D) {
-    const int nt = D.Mp / 32;
+    const int nt = D.Mp / 64;
     const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
     if (tj > ti) return;                       // lower triangle of tiles; mirrored by k_sfinish
     const int l = threadIdx.x, i = l & 15, kk = l >> 4;
     const int kslice = (D.Kp / 4 + D.SK - 1) / D.SK * 4;
     const int k0 = blockIdx.y * kslice, k1 = min(D.Kp, k0 + kslice);
-    d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-    const double* za = D.Zt + 32 * ti + i;
-    const double* zb = D.Zt + 32 * tj + i;
+    d4 c[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c[a][b] = d4{0, 0, 0, 0};
+    const double* za = D.Zt + 64 * ti + i;
+    const double* zb = D.Zt + 64 * tj + i;
     for (int k = k0; k < k1; k += 4) {
         const long long off = (long long)(k + kk) * D.Mp;
-        const double a0 = za[off], a1 = za[off + 16], b0 = zb[off], b1 = zb[off + 16];
-        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { av[a] = za[off + 16 * a]; bv[a] = zb[off + 16 * a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) c[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], c[a][b], 0, 0, 0);
     }
     double* out = D.Spart + (long long)blockIdx.y * D.Mp * D.Mp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = kk + 4 * r, col = i;
-        out[(long long)(32 * ti + row) * D.Mp + 32 * tj + col] = c00[r];
-        out[(long long)(32 * ti + row) * D.Mp + 32 * tj + 16 + col] = c01[r];
-        out[(long long)(32 * ti + 16 + row) * D.Mp + 32 * tj + col] = c10[r];
-        out[(long long)(32 * ti + 16 + row) * D.Mp + 32 * tj + 16 + col] = c11[r];
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(long long)(64 * ti + 16 * a + kk + 4 * r) * D.Mp + 64 * tj + 16 * b + i] = c[a][b][r];
 }
 // S = U + mu I - sum over slices (lower triangle; padding rows get a unit diagonal); rhs = bc - Z y
 __global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu) {
@@ -559,8 +565,8 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     }
     Dev D{};
     D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa;
-    D.M = 9 * nca; D.Mp = std::max(32, (D.M + 31) / 32 * 32); D.Kp = std::max(4, (3 * npa + 3) / 4 * 4);
-    const int ntile = D.Mp / 32;
+    D.M = 9 * nca; D.Mp = std::max(64, (D.M + 63) / 64 * 64); D.Kp = std::max(4, (3 * npa + 3) / 4 * 4);
+    const int ntile = D.Mp / 64;
     D.SK = std::max(1, std::min(64, 2048 / std::max(1, ntile * (ntile + 1) / 2)));
     D.SK = std::min(D.SK, std::max(1, D.Kp / 64));
     if ((double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
@@ -630,7 +636,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                 k_z<<<gf, 256, 0, stream>>>(D);
             }
             if (nca) {
-                const int nt = D.Mp / 32;
+                const int nt = D.Mp / 64;
                 k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
                 k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D, mu);
                 k_rhs<<<nca, 64, 0, stream>>>(D);
