@@ -125,6 +125,9 @@ int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, d
  * camera / point blocks, Schur complement onto the cameras, both contractions on the matrix
  * cores (rdis_amd/csrc/lm_solver.hip).  levmar is not vendored by the reference: parity is
  * unpinned, the iteration is checked step by step against oracle/lm_oracle.py.
+ * residual_model 1 is that formulation; 2 replaces it by the two pixel residuals of every
+ * observation (the usual bundle-adjustment Gauss-Newton model: J^T J of rank 2 per factor instead
+ * of 1, same machinery) -- not something the reference offers, far faster convergence.
  * Same calling convention as one component of rdis_hip_cgd_batch; x_inout may be NULL (start at
  * the currently assigned x; the result is left assigned either way).
  * info[8] = {iterations, stop code (levmar's: 1 small gradient, 2 small step, 3 itmax,
@@ -133,7 +136,7 @@ int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, d
  * hist (may be NULL): up to hist_cap records {mu, |Dp|^2, f(trial), accepted} per linear solve. */
 int rdis_hip_lm_optimize(rdis_hip_problem *p, int64_t nfree, const int64_t *free_vid, int64_t nf,
                          const int64_t *fac_id, double *x_inout, int32_t maxiters, double ftol,
-                         double *fret, double *delta, double *info8, double *hist4, int64_t hist_cap,
+                         int32_t residual_model, double *fret, double *delta, double *info8, double *hist4, int64_t hist_cap,
                          int64_t *nhist);
 
 /* ---- the step before the path: which independent sub-problems are there? -----

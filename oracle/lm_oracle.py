@@ -38,10 +38,28 @@ class LMResult:
     history: list = field(default_factory=list)   # per linear solve: (mu, |Dp|^2, f_trial, accepted)
 
 
-def residuals_and_jacobian(o, free_vid, fac, want_jac=True):
-    """e_j = sqrt(2 E_j) per listed factor and the dense Jacobian over the free variables
-    (rows grad E_j / e_j; a zero row where E_j == 0)."""
+def residuals_and_jacobian(o, free_vid, fac, want_jac=True, model=1):
+    """model 1: e_j = sqrt(2 E_j) per listed factor and the dense Jacobian over the free variables
+    (rows grad E_j / e_j; a zero row where E_j == 0) -- the reference's formulation.
+    model 2: the two pixel residuals per factor and their Jacobian rows (not in the reference;
+    lm_optimize then also projects every trial point into the variables' domains, where the
+    reference's formulation clamps once at the end)."""
     pp = o.pp
+    if model == 2:
+        res, Jr = o.resjac_each_ba(fac)
+        e = res.reshape(-1)
+        if not want_jac:
+            return e, None
+        col = -np.ones(pp.nvars, dtype=np.int64)
+        col[free_vid] = np.arange(len(free_vid))
+        vids = np.concatenate([pp.cam_vid0[fac][:, None] + np.arange(9), pp.pt_vid0[fac][:, None] + np.arange(3)], axis=1)
+        J = np.zeros((2 * len(fac), len(free_vid)))
+        for r in range(2):
+            for k in range(12):
+                c = col[vids[:, k]]
+                m = c >= 0
+                J[2 * np.where(m)[0] + r, c[m]] += Jr[m, r, k]
+        return e, J
     E = o.eval_each(fac)
     e = np.sqrt(2.0 * E)
     if not want_jac:
@@ -64,7 +82,7 @@ def residuals_and_jacobian(o, free_vid, fac, want_jac=True):
 
 
 def lm_optimize(o, free_vid=None, fac=None, x=None, maxiters=25, ftol=3e-8, tau=1e-3, eps1=1e-15, eps2=1e-15,
-                clamp=True) -> LMResult:
+                clamp=True, model=1) -> LMResult:
     """o: oracle.OracleProblem.  Leaves the free variables assigned to the result."""
     pp = o.pp
     free_vid = np.arange(pp.nvars, dtype=np.int64) if free_vid is None else np.asarray(free_vid, dtype=np.int64)
@@ -72,7 +90,7 @@ def lm_optimize(o, free_vid=None, fac=None, x=None, maxiters=25, ftol=3e-8, tau=
     p = np.array(pp.x0[free_vid] if x is None else x, dtype=np.float64)
     m = len(p)
     o.assign(free_vid, p)
-    e, _ = residuals_and_jacobian(o, free_vid, fac, want_jac=False)
+    e, _ = residuals_and_jacobian(o, free_vid, fac, want_jac=False, model=model)
     p_eL2 = float(e @ e)
     finit = 0.5 * p_eL2
     eps3 = ftol
@@ -84,7 +102,7 @@ def lm_optimize(o, free_vid=None, fac=None, x=None, maxiters=25, ftol=3e-8, tau=
             stop = 6
             break
         o.assign(free_vid, p)
-        e, J = residuals_and_jacobian(o, free_vid, fac)
+        e, J = residuals_and_jacobian(o, free_vid, fac, model=model)
         njev += 1
         JtJ = J.T @ J
         Jte = -(J.T @ e)                      # levmar: e = x - hx with x = 0
@@ -92,10 +110,13 @@ def lm_optimize(o, free_vid=None, fac=None, x=None, maxiters=25, ftol=3e-8, tau=
         if np.max(np.abs(Jte)) <= eps1:
             stop = 1
             break
+        dg = np.diag(JtJ)
+        # model 2 damps with Marquardt's scaling, mu * diag(J^T J) (floored at 1e-9 of the largest entry)
+        damp = np.maximum(dg, 1e-9 * float(np.max(dg))) if model == 2 else np.ones(m)
         if k == 0:
-            mu = tau * float(np.max(np.diag(JtJ)))
+            mu = tau if model == 2 else tau * float(np.max(dg))
         while True:
-            A = JtJ + mu * np.eye(m)
+            A = JtJ + mu * np.diag(damp)
             solved = True
             try:
                 L = np.linalg.cholesky(A)
@@ -112,14 +133,16 @@ def lm_optimize(o, free_vid=None, fac=None, x=None, maxiters=25, ftol=3e-8, tau=
                     stop = 4
                     break
                 pDp = p + Dp
+                if model == 2:                  # trial points stay inside the domains (projected step)
+                    pDp = np.minimum(np.maximum(pDp, pp.lo[free_vid]), pp.hi[free_vid])
                 o.assign(free_vid, pDp)
-                e_new, _ = residuals_and_jacobian(o, free_vid, fac, want_jac=False)
+                e_new, _ = residuals_and_jacobian(o, free_vid, fac, want_jac=False, model=model)
                 nfev += 1
                 pDp_eL2 = float(e_new @ e_new)
                 if not np.isfinite(pDp_eL2):
                     stop = 7
                     break
-                dL = float(Dp @ (mu * Dp + Jte))
+                dL = float(Dp @ (mu * damp * Dp + Jte))
                 dF = p_eL2 - pDp_eL2
                 ok = dL > 0.0 and dF > 0.0
                 hist.append((mu, Dp_L2, 0.5 * pDp_eL2, ok))

@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         L.ro_frprmn.restype = C.c_int
         L.ro_frprmn.argtypes = [C.c_int, _f64p, FUNC_CB, GRAD_CB, C.c_void_p, C.c_int, C.c_double,
                                 C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ro_resjac_each_ba.restype = None
+        L.ro_resjac_each_ba.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ro_components.restype = C.c_int64
         L.ro_components.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -149,6 +151,14 @@ class OracleProblem:
         out = np.empty(n)
         lib().ro_get_x(self.h, n, vp, out)
         return out
+
+    def resjac_each_ba(self, fac=None):
+        """(res [nf, 2], J [nf, 2, 12]): pixel residuals and their Jacobian rows per listed factor"""
+        f, fp = _opt_i64(fac)
+        n = self.pp.nfac if f is None else f.shape[0]
+        res, J = np.empty((n, 2)), np.empty((n, 2, 12))
+        lib().ro_resjac_each_ba(self.h, n, fp, res.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p))
+        return res, J
 
     def components(self, assigned):
         """(free_ptr, free_vid, fac_ptr, fac_id) of the connected components left when the variables

@@ -87,22 +87,23 @@ double ro_ba_factor_eval(const double vals[12], double obsx, double obsy)
  * variable at a time; this oracle back-propagates adjoints through the same
  * forward model instead (derived from the mathematics, SURVEY.md 8a note 8).
  * Both are the exact derivative; they differ only in rounding. */
-double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
+/* adjoint sweep for the seed (s0, s1): g = d(s0 pix_x + s1 pix_y)/dx at the forward state t.  With
+ * the residual as seed this is grad E; with unit seeds the two rows of the residual's Jacobian. */
+static void ba_adjoint(const ba_fwd *tp, const double x[12], double s0, double s1, double g[12])
 {
-    ba_fwd t;
-    const double E = ba_forward(x, ox, oy, &t);
+    const ba_fwd t = *tp;
     const double *q = x + 9, *v = t.v;
     const double f = x[6], k1 = x[7], k2 = x[8];
 
     /* pix = f * dstn * pp ; E = |pix - obs|^2 / 2 */
-    const double rp = t.res[0] * t.pp[0] + t.res[1] * t.pp[1];
+    const double rp = s0 * t.pp[0] + s1 * t.pp[1];
     g[6] = t.dstn * rp;                 /* dE/df    */
     const double adst = f * rp;         /* dE/ddstn */
     g[7] = adst * t.r2;                 /* dE/dk1   */
     g[8] = adst * t.r2 * t.r2;          /* dE/dk2   */
     const double ar2 = adst * (k1 + 2.0 * k2 * t.r2);
-    const double app0 = f * t.dstn * t.res[0] + 2.0 * ar2 * t.pp[0];
-    const double app1 = f * t.dstn * t.res[1] + 2.0 * ar2 * t.pp[1];
+    const double app0 = f * t.dstn * s0 + 2.0 * ar2 * t.pp[0];
+    const double app1 = f * t.dstn * s1 + 2.0 * ar2 * t.pp[1];
 
     /* pp = -P.xy / P.z */
     double a[3];
@@ -142,7 +143,24 @@ double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
             g[i] = qxa[i];
         }
     }
+}
+
+double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
+{
+    ba_fwd t;
+    const double E = ba_forward(x, ox, oy, &t);
+    ba_adjoint(&t, x, t.res[0], t.res[1], g);
     return E;
+}
+
+/* the two pixel residuals of one factor and their Jacobian rows J[0..11] (x), J[12..23] (y) */
+void ro_ba_factor_resjac(const double x[12], double ox, double oy, double res[2], double J[24])
+{
+    ba_fwd t;
+    ba_forward(x, ox, oy, &t);
+    res[0] = t.res[0]; res[1] = t.res[1];
+    ba_adjoint(&t, x, 1.0, 0.0, J);
+    ba_adjoint(&t, x, 0.0, 1.0, J + 12);
 }
 
 /* ===========================================================================
@@ -1111,6 +1129,16 @@ int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int
     free(S.gdense); free(xw);
     ro_set_emulate_stale_cache(p, emulate);
     return T.n;
+}
+
+void ro_resjac_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *res2, double *J24)
+{
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i;
+        double vals[12];
+        gather_ba(p, f, vals);
+        ro_ba_factor_resjac(vals, p->obs[2 * f], p->obs[2 * f + 1], res2 + 2 * i, J24 + 24 * i);
+    }
 }
 
 /* ------------------------------------------------------------------------

@@ -85,6 +85,10 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac,
 /* per-factor values and 12 (BA) / arity (NLP, CSR order) partials */
 void ro_eval_each(ro_problem *p, int64_t nf, const int64_t *fac, double *fvals);
 void ro_grad_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g12);
+/* pixel residuals (2 per factor) and their Jacobian rows (2 x 12 per factor): the usual
+ * bundle-adjustment least-squares model, used by the LM oracle's residual model 2 */
+void ro_ba_factor_resjac(const double vals[12], double obsx, double obsy, double res[2], double J[24]);
+void ro_resjac_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *res2, double *J24);
 
 /* ---- the solver ------------------------------------------------------------*/
 typedef struct {

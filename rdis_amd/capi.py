@@ -81,7 +81,7 @@ SYMBOLS = {
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
     "rdis_hip_plan_debug_counters": (C.c_int, [_vp, _vp]),
-    "rdis_hip_lm_optimize": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int32, C.c_double, _vp, _vp, _vp, _vp,
+    "rdis_hip_lm_optimize": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int32, C.c_double, C.c_int32, _vp, _vp, _vp, _vp,
                                        C.c_int64, _vp]),
     "rdis_hip_components": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "rdis_hip_components_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -246,7 +246,7 @@ class Problem:
         val, vid = _f(val), _i(vid)
         self.ctx.check(self.ctx.lib.rdis_hip_set_x(self.h, val.shape[0], _ptr(vid), _ptr(val)))
 
-    def lm_optimize(self, free_vid=None, fac_id=None, x=None, maxiters=25, ftol=3e-8, history=256):
+    def lm_optimize(self, free_vid=None, fac_id=None, x=None, maxiters=25, ftol=3e-8, history=256, model=1):
         """Levenberg-Marquardt over the listed free variables / factors (bundle adjustment; the
         least-squares problem of LMSubspaceOptimizer).  Returns an LmResult; the variables are left
         assigned to the result."""
@@ -257,7 +257,7 @@ class Problem:
         info = np.zeros(8)
         hist = np.zeros((max(history, 1), 4))
         nh = np.zeros(1, dtype=np.int64)
-        self.ctx.check(self.ctx.lib.rdis_hip_lm_optimize(self.h, fv.shape[0], _ptr(fv), fc.shape[0], _ptr(fc), _ptr(xin), maxiters, ftol,
+        self.ctx.check(self.ctx.lib.rdis_hip_lm_optimize(self.h, fv.shape[0], _ptr(fv), fc.shape[0], _ptr(fc), _ptr(xin), maxiters, ftol, model,
                                                          C.c_void_p(out.ctypes.data), C.c_void_p(out.ctypes.data + 8), _ptr(info),
                                                          _ptr(hist), hist.shape[0], _ptr(nh)))
         return LmResult(x=self.get_x(fv), fret=float(out[0]), delta=float(out[1]), iters=int(info[0]), stop=int(info[1]),

@@ -95,22 +95,21 @@ __device__ __forceinline__ double ba_eval(const double (&x)[12], double ox, doub
     return ba_forward(x, ox, oy, t);
 }
 
-// value + the 12 partials
-__device__ __forceinline__ double ba_eval_grad(const double (&x)[12], double ox, double oy,
-                                               double (&g)[12]) {
-    BaFwd t;
-    const double E = ba_forward(x, ox, oy, t);
+// Adjoint (reverse) sweep of the projection: g = d(s0 * pix_x + s1 * pix_y) / dx for the forward
+// state t.  With (s0, s1) = the residual this is the gradient of E = |res|^2 / 2; with unit
+// seeds it yields the two rows of the residual's Jacobian.
+__device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12], double s0, double s1, double (&g)[12]) {
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double f = x[6];
-    const double rp = t.res0 * t.pp0 + t.res1 * t.pp1;
+    const double rp = s0 * t.pp0 + s1 * t.pp1;
     g[6] = t.dstn * rp;
     const double adst = f * rp;
     g[7] = adst * t.r2;
     g[8] = adst * t.r2 * t.r2;
     const double ar2 = adst * (x[7] + 2.0 * x[8] * t.r2);
     const double fd = f * t.dstn;
-    const double app0 = fd * t.res0 + 2.0 * ar2 * t.pp0;
-    const double app1 = fd * t.res1 + 2.0 * ar2 * t.pp1;
+    const double app0 = fd * s0 + 2.0 * ar2 * t.pp0;
+    const double app1 = fd * s1 + 2.0 * ar2 * t.pp1;
     const double a0 = -app0 * t.iz, a1 = -app1 * t.iz;
     const double a2 = -(app0 * t.pp0 + app1 * t.pp1) * t.iz;
     g[3] = a0; g[4] = a1; g[5] = a2;
@@ -137,7 +136,25 @@ __device__ __forceinline__ double ba_eval_grad(const double (&x)[12], double ox,
         g[9] = a0 - vxa0; g[10] = a1 - vxa1; g[11] = a2 - vxa2;
         g[0] = qxa0; g[1] = qxa1; g[2] = qxa2;
     }
+}
+
+// value + the 12 partials
+__device__ __forceinline__ double ba_eval_grad(const double (&x)[12], double ox, double oy,
+                                               double (&g)[12]) {
+    BaFwd t;
+    const double E = ba_forward(x, ox, oy, t);
+    ba_adjoint(t, x, t.res0, t.res1, g);
     return E;
+}
+
+// the two pixel residuals and their Jacobian rows
+__device__ __forceinline__ void ba_residual_jacobian(const double (&x)[12], double ox, double oy, double (&res)[2],
+                                                     double (&jx)[12], double (&jy)[12]) {
+    BaFwd t;
+    ba_forward(x, ox, oy, t);
+    res[0] = t.res0; res[1] = t.res1;
+    ba_adjoint(t, x, 1.0, 0.0, jx);
+    ba_adjoint(t, x, 0.0, 1.0, jy);
 }
 
 // ---- nonlinear product factor -------------------------------------------------

@@ -37,14 +37,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct Dev {            // everything the kernels need, by value
     LmProblem P;
-    int nf, nca, npa, M, Mp, Kp, SK;
+    int nf, nca, npa, M, Mp, Kp, SK, R;       // R: residual rows per factor (1 or 2)
     const int *lf, *fci, *fpi;               // listed factor id, local camera / point block (-1: not active)
     const unsigned char* freem;              // [N]
     const int *cam_ptr, *cam_list, *pt_ptr, *pt_list;
     const int *cam_id, *pt_id;               // first variable id of each active block
-    double *Jc, *Jp, *e;                     // [nf*9], [nf*3], [nf]
+    double *Jc, *Jp, *e;                     // [nf*R*9], [nf*R*3], [nf*R]  (row jr = j*R + r)
     double *U, *bc;                          // [nca*81], [Mp]
-    double *V, *bp, *Lp, *yp, *T;            // [npa*6], [npa*3], [npa*6], [npa*3], [nf*3]
+    double *V, *bp, *Lp, *yp, *T;            // [npa*6], [npa*3], [npa*6], [npa*3], [nf*R*3]
     double *Zt;                              // [Kp][Mp]   k-major
     double *Spart, *S, *rhs, *dc, *dp;       // [SK][Mp*Mp], [Mp*Mp], [Mp], [Mp], [npa*3]
     double *psave;                           // accepted point: [9*nca + 3*npa] by block slot
@@ -70,14 +70,30 @@ __global__ void __launch_bounds__(256) k_lin(Dev D) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) v[k] = D.P.x[k < 9 ? c + k : q + (k - 9)];
     const double2 o = D.P.obs[f];
-    const double E = ba_eval_grad(v, o.x, o.y, g);
-    const double e = sqrt(2.0 * E);
-    const double inv = e > 0.0 ? 1.0 / e : 0.0;
-    D.e[j] = e;
+    if (D.R == 1) {   // the reference's formulation: one residual sqrt(2 E), row grad E / e
+        const double E = ba_eval_grad(v, o.x, o.y, g);
+        const double e = sqrt(2.0 * E);
+        const double inv = e > 0.0 ? 1.0 / e : 0.0;
+        D.e[j] = e;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) D.Jc[9ll * j + k] = D.freem[c + k] ? g[k] * inv : 0.0;
+        for (int k = 0; k < 9; ++k) D.Jc[9ll * j + k] = D.freem[c + k] ? g[k] * inv : 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) D.Jp[3ll * j + k] = D.freem[q + k] ? g[9 + k] * inv : 0.0;
+        for (int k = 0; k < 3; ++k) D.Jp[3ll * j + k] = D.freem[q + k] ? g[9 + k] * inv : 0.0;
+    } else {          // the two pixel residuals and their Jacobian rows
+        double res[2], g2[12];
+        ba_residual_jacobian(v, o.x, o.y, res, g, g2);
+        D.e[2ll * j] = res[0]; D.e[2ll * j + 1] = res[1];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const bool fr = D.freem[c + k];
+            D.Jc[18ll * j + k] = fr ? g[k] : 0.0; D.Jc[18ll * j + 9 + k] = fr ? g2[k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool fr = D.freem[q + k];
+            D.Jp[6ll * j + k] = fr ? g[9 + k] : 0.0; D.Jp[6ll * j + 3 + k] = fr ? g2[9 + k] : 0.0;
+        }
+    }
 }
 
 // objective of the listed factors at the current x: block partials of sum e^2 / 2
@@ -114,16 +130,17 @@ __global__ void __launch_bounds__(256) k_obj_final(Dev D, int nblocks, int slot)
 // register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
 __global__ void __launch_bounds__(64) k_cam(Dev D) {
     const int c = blockIdx.x, l = threadIdx.x;
-    const int b0 = D.cam_ptr[c], cnt = D.cam_ptr[c + 1] - b0;
+    const int b0 = D.cam_ptr[c], cnt = (D.cam_ptr[c + 1] - b0) * D.R;   // Jacobian rows of this camera
     const int i = l & 15, kk = l >> 4;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     double bsum = 0.0;
     for (int j0 = 0; j0 < cnt; j0 += 4) {
         double a = 0.0, ev = 0.0;
         if (j0 + kk < cnt && i < 9) {
-            const int j = D.cam_list[b0 + j0 + kk];
-            a = D.Jc[9ll * j + i];
-            ev = D.e[j];
+            const int rr = j0 + kk;
+            const long long jr = (long long)D.cam_list[b0 + rr / D.R] * D.R + rr % D.R;
+            a = D.Jc[9 * jr + i];
+            ev = D.e[jr];
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
         bsum += a * ev;
@@ -145,10 +162,12 @@ __global__ void __launch_bounds__(256) k_pt(Dev D) {
     if (p >= D.npa) return;
     double v00 = 0, v10 = 0, v11 = 0, v20 = 0, v21 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (int t = D.pt_ptr[p]; t < D.pt_ptr[p + 1]; ++t) {
-        const int j = D.pt_list[t];
-        const double a = D.Jp[3ll * j], b = D.Jp[3ll * j + 1], c = D.Jp[3ll * j + 2], ev = D.e[j];
-        v00 += a * a; v10 += b * a; v11 += b * b; v20 += c * a; v21 += c * b; v22 += c * c;
-        b0 += a * ev; b1 += b * ev; b2 += c * ev;
+        for (int r = 0; r < D.R; ++r) {
+            const long long jr = (long long)D.pt_list[t] * D.R + r;
+            const double a = D.Jp[3 * jr], b = D.Jp[3 * jr + 1], c = D.Jp[3 * jr + 2], ev = D.e[jr];
+            v00 += a * a; v10 += b * a; v11 += b * b; v20 += c * a; v21 += c * b; v22 += c * c;
+            b0 += a * ev; b1 += b * ev; b2 += c * ev;
+        }
     }
     double* V = D.V + 6ll * p;
     V[0] = v00; V[1] = v10; V[2] = v11; V[3] = v20; V[4] = v21; V[5] = v22;
@@ -184,15 +203,20 @@ __global__ void __launch_bounds__(1024) k_scalars(Dev D) {
 }
 
 // ---- 5. per damping value: point Cholesky, T_j = L_p^-1 Jp_j, Z --------------------------------
-__global__ void __launch_bounds__(256) k_ptchol(Dev D, double mu) {
+// damping added to a diagonal entry d of J^T J: mu (Levenberg, what levmar does: model 1) or
+// mu * max(d, floor) (Marquardt's scaling by the diagonal: model 2)
+__device__ __forceinline__ double damp(const Dev& D, double mu, double floor_, double d) {
+    return D.R == 2 ? mu * fmax(d, floor_) : mu;
+}
+__global__ void __launch_bounds__(256) k_ptchol(Dev D, double mu, double floor_) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.npa) return;
     const double* V = D.V + 6ll * p;
-    const double l00 = sqrt(V[0] + mu);
+    const double l00 = sqrt(V[0] + damp(D, mu, floor_, V[0]));
     const double l10 = V[1] / l00, l20 = V[3] / l00;
-    const double l11 = sqrt(V[2] + mu - l10 * l10);
+    const double l11 = sqrt(V[2] + damp(D, mu, floor_, V[2]) - l10 * l10);
     const double l21 = (V[4] - l20 * l10) / l11;
-    const double l22 = sqrt(V[5] + mu - l20 * l20 - l21 * l21);
+    const double l22 = sqrt(V[5] + damp(D, mu, floor_, V[5]) - l20 * l20 - l21 * l21);
     double* L = D.Lp + 6ll * p;
     L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
     const double y0 = D.bp[3ll * p] / l00;
@@ -206,16 +230,20 @@ __global__ void __launch_bounds__(256) k_z(Dev D) {
     const int ci = D.fci[j], pi = D.fpi[j];
     if (pi < 0) return;
     const double* L = D.Lp + 6ll * pi;
-    const double t0 = D.Jp[3ll * j] / L[0];
-    const double t1 = (D.Jp[3ll * j + 1] - L[1] * t0) / L[2];
-    const double t2 = (D.Jp[3ll * j + 2] - L[3] * t0 - L[4] * t1) / L[5];
-    D.T[3ll * j] = t0; D.T[3ll * j + 1] = t1; D.T[3ll * j + 2] = t2;
+    double t0[2] = {0, 0}, t1[2] = {0, 0}, t2[2] = {0, 0};
+    for (int r = 0; r < D.R; ++r) {
+        const long long jr = (long long)j * D.R + r;
+        t0[r] = D.Jp[3 * jr] / L[0];
+        t1[r] = (D.Jp[3 * jr + 1] - L[1] * t0[r]) / L[2];
+        t2[r] = (D.Jp[3 * jr + 2] - L[3] * t0[r] - L[4] * t1[r]) / L[5];
+        D.T[3 * jr] = t0[r]; D.T[3 * jr + 1] = t1[r]; D.T[3 * jr + 2] = t2[r];
+    }
     if (ci < 0) return;
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
-        const double jc = D.Jc[9ll * j + a];
+        const double jc0 = D.Jc[9ll * j * D.R + a], jc1 = D.R == 2 ? D.Jc[9ll * (2 * j + 1) + a] : 0.0;
         double* z = D.Zt + (long long)(3 * pi) * D.Mp + 9 * ci + a;
-        z[0] = jc * t0; z[D.Mp] = jc * t1; z[2ll * D.Mp] = jc * t2;
+        z[0] = jc0 * t0[0] + jc1 * t0[1]; z[D.Mp] = jc0 * t1[0] + jc1 * t1[1]; z[2ll * D.Mp] = jc0 * t2[0] + jc1 * t2[1];
     }
 }
 
@@ -257,7 +285,7 @@ __global__ void __launch_bounds__(64) k_syrk(Dev D) {
                 out[(long long)(64 * ti + 16 * a + kk + 4 * r) * D.Mp + 64 * tj + 16 * b + i] = c[a][b][r];
 }
 // S = U + mu I - sum over slices (lower triangle; padding rows get a unit diagonal); rhs = bc - Z y
-__global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu) {
+__global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu, double floor_) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)D.Mp * D.Mp) return;
     const int row = (int)(t / D.Mp), col = (int)(t % D.Mp);
@@ -267,7 +295,7 @@ __global__ void __launch_bounds__(256) k_sfinish(Dev D, double mu) {
     double v = -s;
     if (row < D.M) {
         if (row / 9 == col / 9) v += D.U[81ll * (row / 9) + 9 * (row % 9) + (col % 9)];
-        if (row == col) v += mu;
+        if (row == col) v += damp(D, mu, floor_, D.U[81ll * (row / 9) + 10 * (row % 9)]);
     } else {
         v = row == col ? 1.0 : 0.0;
     }
@@ -281,9 +309,12 @@ __global__ void __launch_bounds__(64) k_rhs(Dev D) {
     for (int t = D.cam_ptr[c] + l; t < D.cam_ptr[c + 1]; t += 64) {
         const int j = D.cam_list[t], pi = D.fpi[j];
         if (pi < 0) continue;
-        const double w = D.T[3ll * j] * D.yp[3ll * pi] + D.T[3ll * j + 1] * D.yp[3ll * pi + 1] + D.T[3ll * j + 2] * D.yp[3ll * pi + 2];
+        for (int r = 0; r < D.R; ++r) {
+            const long long jr = (long long)j * D.R + r;
+            const double w = D.T[3 * jr] * D.yp[3ll * pi] + D.T[3 * jr + 1] * D.yp[3ll * pi + 1] + D.T[3 * jr + 2] * D.yp[3ll * pi + 2];
 #pragma unroll
-        for (int a = 0; a < 9; ++a) acc[a] += D.Jc[9ll * j + a] * w;
+            for (int a = 0; a < 9; ++a) acc[a] += D.Jc[9 * jr + a] * w;
+        }
     }
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
@@ -438,10 +469,13 @@ __global__ void __launch_bounds__(256) k_back(Dev D) {
         const int j = D.pt_list[t];
         const int ci = D.fci[j];
         if (ci < 0) continue;
-        double w = 0.0;
+        for (int r = 0; r < D.R; ++r) {
+            const long long jr = (long long)j * D.R + r;
+            double w = 0.0;
 #pragma unroll
-        for (int a = 0; a < 9; ++a) w += D.Jc[9ll * j + a] * D.dc[9 * ci + a];
-        s0 += D.T[3ll * j] * w; s1 += D.T[3ll * j + 1] * w; s2 += D.T[3ll * j + 2] * w;
+            for (int a = 0; a < 9; ++a) w += D.Jc[9 * jr + a] * D.dc[9 * ci + a];
+            s0 += D.T[3 * jr] * w; s1 += D.T[3 * jr + 1] * w; s2 += D.T[3 * jr + 2] * w;
+        }
     }
     const double* L = D.Lp + 6ll * p;
     const double r0 = D.yp[3ll * p] - s0, r1 = D.yp[3ll * p + 1] - s1, r2 = D.yp[3ll * p + 2] - s2;
@@ -452,21 +486,26 @@ __global__ void __launch_bounds__(256) k_back(Dev D) {
 }
 
 // ---- 9. trial point, |Dp|^2, dL = Dp . (mu Dp + J^T e) (one block) --------------------------------
-// mode 0: x = psave + Dp;  mode 1: psave = x (accept);  mode 2: x = psave (restore);
+// mode 0: x = psave + Dp (model 2: clamped into the domain);  mode 1: psave = x (accept);  mode 2: x = psave (restore);
 // mode 3: x = clamp(psave) (final, LMSubspaceOptimizer.cpp:104-108)
-__global__ void __launch_bounds__(1024) k_apply(Dev D, double mu, int mode) {
+__global__ void __launch_bounds__(1024) k_apply(Dev D, double mu, double floor_, int mode) {
     __shared__ double r0[16], r1[16];
     double dl2 = 0.0, dL = 0.0;
     const int nc9 = 9 * D.nca, ntot = nc9 + 3 * D.npa;
     for (int t = threadIdx.x; t < ntot; t += 1024) {
-        int v; double dpv, b;
-        if (t < nc9) { v = D.cam_id[t / 9] + t % 9; dpv = D.nca ? D.dc[t] : 0.0; b = D.bc[t]; }
-        else { const int u = t - nc9; v = D.pt_id[u / 3] + u % 3; dpv = D.dp[u]; b = D.bp[u]; }
+        int v; double dpv, b, dg;
+        if (t < nc9) { v = D.cam_id[t / 9] + t % 9; dpv = D.nca ? D.dc[t] : 0.0; b = D.bc[t]; dg = D.U[81ll * (t / 9) + 10 * (t % 9)]; }
+        else { const int u = t - nc9, k = u % 3; v = D.pt_id[u / 3] + k; dpv = D.dp[u]; b = D.bp[u]; dg = D.V[6ll * (u / 3) + (k == 0 ? 0 : k == 1 ? 2 : 5)]; }
         if (!D.freem[v]) continue;
         if (mode == 0) {
-            D.P.x[v] = D.psave[t] + dpv;
+            double xn = D.psave[t] + dpv;
+            if (D.R == 2) {   // the pixel-residual model keeps every trial point inside the domains
+                const double lo = D.P.lo[v], hi = D.P.hi[v];
+                xn = (lo <= xn && xn <= hi) ? xn : (xn < lo ? lo : hi);
+            }
+            D.P.x[v] = xn;
             dl2 += dpv * dpv;
-            dL += dpv * (mu * dpv + b);
+            dL += dpv * (damp(D, mu, floor_, dg) * dpv + b);
         } else if (mode == 1) {
             D.psave[t] = D.P.x[v];
         } else if (mode == 2) {
@@ -564,7 +603,8 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             }
     }
     Dev D{};
-    D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa;
+    if (opt.model != 1 && opt.model != 2) return fail("lm: residual model must be 1 or 2");
+    D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa; D.R = opt.model;
     D.M = 9 * nca; D.Mp = std::max(64, (D.M + 63) / 64 * 64); D.Kp = std::max(4, (3 * npa + 3) / 4 * 4);
     const int ntile = D.Mp / 64;
     D.SK = std::max(1, std::min(64, 2048 / std::max(1, ntile * (ntile + 1) / 2)));
@@ -581,10 +621,10 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     D.cam_id = b_cid.as<int>(); D.pt_id = b_pid.as<int>();
     Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Spart, S, rhs, dc, dp, psave, part, sc;
     const size_t MM = (size_t)D.Mp * D.Mp;
-    LM_CHK(Jc.alloc((size_t)nf * 72)); LM_CHK(Jp.alloc((size_t)nf * 24)); LM_CHK(e.alloc((size_t)nf * 8));
+    LM_CHK(Jc.alloc((size_t)nf * 72 * D.R)); LM_CHK(Jp.alloc((size_t)nf * 24 * D.R)); LM_CHK(e.alloc((size_t)nf * 8 * D.R));
     LM_CHK(U.alloc((size_t)std::max(nca, 1) * 81 * 8)); LM_CHK(bc.alloc((size_t)D.Mp * 8));
     LM_CHK(V.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(bp.alloc((size_t)std::max(npa, 1) * 24));
-    LM_CHK(Lp.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(yp.alloc((size_t)D.Kp * 8)); LM_CHK(T.alloc((size_t)nf * 24));
+    LM_CHK(Lp.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(yp.alloc((size_t)D.Kp * 8)); LM_CHK(T.alloc((size_t)nf * 24 * D.R));
     LM_CHK(Zt.alloc((size_t)D.Kp * D.Mp * 8)); LM_CHK(Spart.alloc(MM * 8 * (size_t)D.SK)); LM_CHK(S.alloc(MM * 8));
     LM_CHK(rhs.alloc((size_t)D.Mp * 8)); LM_CHK(dc.alloc((size_t)D.Mp * 8)); LM_CHK(dp.alloc((size_t)D.Kp * 8));
     LM_CHK(psave.alloc((size_t)(9 * nca + 3 * npa + 1) * 8)); LM_CHK(part.alloc(4096 * 8)); LM_CHK(sc.alloc(16 * 8));
@@ -608,7 +648,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         LM_CHK(hipGetLastError());
         return 0;
     };
-    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 1);   // psave = x
+    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 0.0, 1);   // psave = x
     if ((rc = objective(5)) || (rc = scalars())) return rc;
     double p_eL2 = 2.0 * h[5];
     out->finit = h[5];
@@ -629,16 +669,19 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         ++out->njev;
         const double maxdiag = h[0], jte_inf = h[1], p_L2 = h[2];
         if (jte_inf <= opt.eps1) { stop = 1; break; }
-        if (k == 0) mu = opt.tau * maxdiag;
+        // Marquardt scaling (model 2): mu is relative to the diagonal; entries below 1e-9 of the largest
+        // (a free variable nothing reads) are damped as if they were that large
+        const double floor_ = 1e-9 * maxdiag;
+        if (k == 0) mu = D.R == 2 ? opt.tau : opt.tau * maxdiag;
         for (;;) {
             if (npa) {
-                k_ptchol<<<gp, 256, 0, stream>>>(D, mu);
+                k_ptchol<<<gp, 256, 0, stream>>>(D, mu, floor_);
                 k_z<<<gf, 256, 0, stream>>>(D);
             }
             if (nca) {
                 const int nt = D.Mp / 64;
                 k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
-                k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D, mu);
+                k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D, mu, floor_);
                 k_rhs<<<nca, 64, 0, stream>>>(D);
                 LM_CHK(hipMemsetAsync(D.sc + 8, 0, 8, stream));
                 for (int kb = 0; kb < D.Mp; kb += 32) {
@@ -653,7 +696,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                 k_trsv<<<1, 1024, 0, stream>>>(D);
             }
             if (npa) k_back<<<gp, 256, 0, stream>>>(D);
-            k_apply<<<1, 1024, 0, stream>>>(D, mu, 0);
+            k_apply<<<1, 1024, 0, stream>>>(D, mu, floor_, 0);
             LM_CHK(hipGetLastError());
             if ((rc = objective(5)) || (rc = scalars())) return rc;
             ++out->nsolve;
@@ -674,7 +717,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                     mu = mu * (tmp >= ONE_THIRD ? tmp : ONE_THIRD);
                     nu = 2;
                     p_eL2 = pDp_eL2;
-                    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 1);   // accept: psave = x
+                    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 0.0, 1);   // accept: psave = x
                     break;
                 }
             }
@@ -686,7 +729,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         ++k;
     }
     if (!stop) stop = 3;
-    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 3);   // x = clamp(accepted point)
+    k_apply<<<1, 1024, 0, stream>>>(D, 0.0, 0.0, 3);   // x = clamp(accepted point)
     if ((rc = objective(5)) || (rc = scalars())) return rc;
     out->fret = h[5];
     out->mu = mu; out->iters = k; out->stop = stop;

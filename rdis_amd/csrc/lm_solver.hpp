@@ -20,6 +20,7 @@ struct LmProblem {          // device arrays of an uploaded bundle-adjustment pr
 struct LmOptions {
     int maxiters;           // SSmaxit
     double tau, eps1, eps2, eps3;   // levmar opts[0..3] (reference: 1e-3, 1e-15, 1e-15, SSftol)
+    int model;              // residual rows per factor: 1 = sqrt(2 E_j) (the reference's), 2 = the two pixel residuals
 };
 
 struct LmStep { double mu, dp_l2, f_trial; int accepted; };

@@ -1031,7 +1031,7 @@ extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* r
 }
 
 extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const int64_t* free_vid, int64_t nf, const int64_t* fac_id,
-                                    double* x_inout, int32_t maxiters, double ftol, double* fret, double* delta, double* info8,
+                                    double* x_inout, int32_t maxiters, double ftol, int32_t model, double* fret, double* delta, double* info8,
                                     double* hist4, int64_t hist_cap, int64_t* nhist) {
     if (!p) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
@@ -1052,7 +1052,7 @@ extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const in
     }
     LmProblem P{(int)p->N, (int)p->F, ncams, p->x.as<double>(), p->lo.as<double>(), p->hi.as<double>(),
                 p->cam.as<int>(), p->pt.as<int>(), p->h_cam.data(), p->h_pt.data(), p->obs.as<double2>()};
-    LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol};
+    LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol, model};
     LmResult r;
     std::string err;
     const int e = device_lm_ba(c->stream, P, nfree, free_vid, nf, fac_id, o, &r, &err);

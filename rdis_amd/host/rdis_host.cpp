@@ -501,7 +501,7 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
 }
 
 HipLMSubspaceOptimizer::HipLMSubspaceOptimizer(OptimizableFunction& f_)
-    : SubspaceOptimizer(f_), last_iters_(0), last_stop_(0), last_nsolve_(0) {}
+    : SubspaceOptimizer(f_), model_(1), last_iters_(0), last_stop_(0), last_nsolve_(0) {}
 
 Numeric HipLMSubspaceOptimizer::optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xval,
                                          Numeric& deltaFval, const bool printdbg) {
@@ -513,7 +513,7 @@ Numeric HipLMSubspaceOptimizer::optimize(const VariablePtrVec& vars, const Facto
     rdis_hip_problem* p = f.deviceProblem();
     double fret = 0, delta = 0, info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     check(f.deviceContext(), rdis_hip_lm_optimize(p, (int64_t)free_vid.size(), free_vid.data(), (int64_t)fac_id.size(), fac_id.data(),
-                                                  xval.data(), (int32_t)maxiters, ftol, &fret, &delta, info, nullptr, 0, nullptr),
+                                                  xval.data(), (int32_t)maxiters, ftol, (int32_t)model_, &fret, &delta, info, nullptr, 0, nullptr),
           "rdis_hip_lm_optimize");
     // the variables are left assigned to the final, clamped values (LMSubspaceOptimizer.cpp:104-108)
     for (size_t i = 0; i < vars.size(); ++i) {

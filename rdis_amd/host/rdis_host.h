@@ -315,8 +315,10 @@ public:
     int lastIters() const { return last_iters_; }
     int lastStop() const { return last_stop_; }          // levmar's termination code (info[6])
     int lastLinearSolves() const { return last_nsolve_; }
+    // 1 (default): the reference's residual sqrt(2 E_j) per factor; 2: the two pixel residuals
+    void setResidualModel(int m) { model_ = m; }
 private:
-    int last_iters_, last_stop_, last_nsolve_;
+    int model_, last_iters_, last_stop_, last_nsolve_;
 };
 
 // error raised when the HIP library reports a failure (no silent fallback)

@@ -22,3 +22,7 @@ for rep in range(2):
     t = time.time(); r = g.lm_optimize(maxiters=25); dt = time.time() - t
 print("full ladybug: f %.9g -> %.9g iters %d stop %d nsolve %d mu %.4g blocks %d/%d wall %.1f ms" % (r.fret - r.delta, r.fret, r.iters, r.stop, r.nsolve, r.mu, r.camera_blocks, r.point_blocks, dt * 1e3))
 print("   oracle objective at the device's point: %.9g" % (lambda o: (o.assign(None, r.x), o.eval())[1])(O.OracleProblem(pp)))
+for rep in range(2):
+    g.set_x(pp.x0)
+    t = time.time(); r = g.lm_optimize(maxiters=25, model=2); dt = time.time() - t
+print("full ladybug, pixel residuals: f %.9g -> %.9g iters %d stop %d nsolve %d wall %.1f ms; trial objectives %s" % (r.fret - r.delta, r.fret, r.iters, r.stop, r.nsolve, dt * 1e3, ["%.5g" % h[2] for h in r.history[:12]]))
