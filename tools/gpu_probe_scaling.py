@@ -9,10 +9,6 @@ ctx = capi.Context(0)
 pp = P.load_bal().single_component()
 g = capi.Problem(ctx, pp)
 plan = capi.Plan(g)
-try:
-    plan.set_option("coop_two_level", int(os.environ.get("TWO_LEVEL", "0")))
-except Exception:
-    pass
 rows = []
 for mi in (1, 2, 3, 5, 8, 12, 16, 20, 25):
     plan.set_start(pp.x0)
