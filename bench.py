@@ -245,6 +245,10 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     if rank == 0:
+        # RCCL prints a version banner through C stdio, which is flushed at exit when stdout is a
+        # pipe: push it out now, so that the JSON really is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(line), flush=True)  # the last line of stdout
 
