@@ -240,6 +240,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
     plan.close()
     prob.close()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)   # every rank: nothing buffered (RCCL's banner) may surface after rank 0's JSON
+    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -247,7 +250,6 @@ def main():
     if rank == 0:
         # RCCL prints a version banner through C stdio, which is flushed at exit when stdout is a
         # pipe: push it out now, so that the JSON really is the last line of stdout
-        import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(line), flush=True)  # the last line of stdout
