@@ -236,7 +236,7 @@ def main():
                          "kernel": "cgd solver kernel(s)", "kernel_ms_avg": kms / max(klaunch, 1),
                          "algorithmic_bytes_per_launch": abytes / max(klaunch, 1)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
     plan.close()
     prob.close()
