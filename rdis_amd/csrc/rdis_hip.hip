@@ -954,9 +954,10 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             mf = std::max<int64_t>(mf, std::max(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
                                                 (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
         int threads = L->block_threads;
-        // Large components: 768 lanes = three waves per SIMD at 168 registers (a few spills) beat
-        // two waves at 250 and four at 128 (heavy spills) by 20 % and 40 % in throughput.
-        if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 2048 ? 512 : 768;
+        // More than 512 factors: 768 lanes = three waves per SIMD at 168 registers (a few spills) beat
+        // two waves at 250 and four at 128 (heavy spills): +20 % / +40 % throughput on large components,
+        // and 5 % on the 361..906-factor camera components of ladybug.
+        if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 512 ? 512 : 768;
         int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
                                     : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
         if (rc) return rc;

@@ -20,6 +20,7 @@
 namespace rdis_hip {
 
 constexpr int MAX_WAVES = 16;
+constexpr int WG_LONG_LIST = 64;   // batch solver: variables fed by more partials than this are summed by a whole wave
 
 // Wave-wide reductions; every lane of a full wave returns the same bits.  Within a row of 16
 // lanes the partner comes through DPP (quad_perm / row_half_mirror / row_mirror: an ALU-speed
@@ -318,13 +319,22 @@ struct WgEnv {
             factor_partials<KIND>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
         }
         __syncthreads();
+        // variables fed by few partials: one lane each, in factor-list order (src/State.h:157-210)
         for (int i = tid; i < n; i += nt) {
             const int b = vptr[i], e = vptr[i + 1];
+            if (e - b > WG_LONG_LIST) continue;
             double s = 0.0;
             if (b < e) {
                 s = run_sum_ordered(L.gfac, b, e);
             }
             xi[i] = s;
+        }
+        // fed by many (a camera against fixed points: hundreds): one wave each, strided + reduction
+        for (int i = tid >> 6; i < n; i += nwaves) {
+            const int b = vptr[i], e = vptr[i + 1];
+            if (e - b <= WG_LONG_LIST) continue;
+            const double s = wave_sum(run_sum_strided(L.gfac, b, e, tid & 63));
+            if ((tid & 63) == 0) xi[i] = s;
         }
         __syncthreads();
     }

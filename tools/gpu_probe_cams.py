@@ -9,7 +9,7 @@ ctx = capi.Context(0)
 pp = P.load_bal()
 cams, pts = P.ba_alternation_plans(pp)
 g = capi.Problem(ctx, pp)
-for threads in (0, 256, 512, 1024):
+for threads in (0, 512, 768):
     plan = capi.Plan(g, *cams)
     if threads: plan.set_option("block_threads", threads)
     rows = []
