@@ -213,6 +213,9 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * first granule sweep), "force_stream" (send large components to the streaming grid solver even
  * when they fit the register-resident one; large components that do not fit, and large
  * nonlinear-product components, always go there),
+ * "quad_max_vars" / "quad_min_components" (bundle-adjustment components with at most that many
+ * free variables, default and maximum 4, are solved by groups of four lanes, sixteen per wave,
+ * when the plan has at least that many of them, default 16384; 0 variables = never),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

@@ -433,9 +433,10 @@ struct CgdMachine {
 // the other waves through a double-buffered LDS slot.  Nothing of the control logic
 // is therefore live in registers across the factor arithmetic.
 // one step of the machine (wave 0 only); the request goes to the other waves through LDS
-__device__ __forceinline__ void step_machine(CgdMachine* __restrict__ M, Request* __restrict__ out, double r0, double r1, double r2) {
+__device__ __forceinline__ void step_machine(CgdMachine* __restrict__ M, Request* __restrict__ out, double r0, double r1, double r2,
+                                             bool writer) {
     const Request nq = M->next(r0, r1, r2);
-    if ((threadIdx.x & 63) == 0) {
+    if (writer) {
         out->kind = nq.kind; out->flags = nq.flags;
         out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a; out->b = nq.b;
         if (nq.pre_tag != TR_NONE) { out->pre_a = nq.pre_a; out->pre_b = nq.pre_b; out->pre_c = nq.pre_c; }
@@ -450,32 +451,46 @@ __device__ __forceinline__ double uniform(double v) {  // a wave-uniform value i
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// The cooperating group is normally a workgroup whose wave 0 steps the machine (Env::UNIFORM: the
+// request is the same for every lane of a wave and is moved to scalar registers).  The quad solver
+// (solver_quad.hpp) runs sixteen independent machines per wave instead: requests differ between
+// lanes, the stepper is the first lane of each group of four.  Env supplies stepper(), writer()
+// (the one lane that stores the request) and sync() (what orders that store before the reads).
+template <class Env>
+__device__ __forceinline__ double uni(double v) {
+    if constexpr (Env::UNIFORM) return uniform(v); else return v;
+}
+template <class Env>
+__device__ __forceinline__ int uni(int v) {
+    if constexpr (Env::UNIFORM) return __builtin_amdgcn_readfirstlane(v); else return v;
+}
+
 template <class Env>
 __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Request (&Q)[2] /* LDS */,
                                             int maxiters, double ftol) {
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-    const bool stepper = threadIdx.x < 64;
+    const bool stepper = E.stepper();
     if (stepper) M.init(maxiters, ftol);
     for (int round = 0;; ++round) {
         const long long ts0 = E.clock();
         if (stepper) {
-            step_machine(&M, &Q[round & 1], r0, r1, r2);
-            if (E.aborted() && (threadIdx.x & 63) == 0) {  // only this wave is certain to know
+            step_machine(&M, &Q[round & 1], r0, r1, r2, E.writer());
+            if (E.aborted() && E.writer()) {  // only this wave is certain to know
                 Q[round & 1].kind = REQ_DONE;
                 M.reason = EXIT_SYNC_TIMEOUT; M.rolled_back = true;
             }
         }
         const long long ts1 = E.clock();
-        __syncthreads();
+        E.sync();
         const Request& q = Q[round & 1];
-        const int kind = __builtin_amdgcn_readfirstlane(q.kind);
-        const int flags = __builtin_amdgcn_readfirstlane(q.flags);
+        const int kind = uni<Env>(q.kind);
+        const int flags = uni<Env>(q.flags);
         if (E.tracing()) {
             if ((flags & RF_TR_FIRST) && q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
             if (q.pre_tag != TR_NONE) E.trace(q.pre_tag, q.pre_a, q.pre_b, q.pre_c);
             if (!(flags & RF_TR_FIRST) && q.tr_tag != TR_NONE) E.trace(q.tr_tag, q.tr_a, q.tr_b, q.tr_c);
         }
-        const double qa = uniform(q.a);
+        const double qa = uni<Env>(q.a);
         E.tick(8, ts1 - ts0); E.tick(9, E.clock() - ts1);
         if (kind == REQ_DONE) break;
         const long long th0 = E.clock();
@@ -484,16 +499,16 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         case REQ_EVAL:
             if (flags & (RF_PRE_START | RF_PRE_UPDATE | RF_PRE_BEGIN)) {
                 if (flags & RF_PRE_START) E.cg_start();
-                if (flags & RF_PRE_UPDATE) E.cg_update(uniform(q.b));
+                if (flags & RF_PRE_UPDATE) E.cg_update(uni<Env>(q.b));
                 if (flags & RF_PRE_BEGIN) E.line_begin();
             }
             if (flags & RF_SLOPE) {
                 E.eval_value_slope(qa, r0, r1);
-                r0 = uniform(r0); r1 = uniform(r1);
+                r0 = uni<Env>(r0); r1 = uni<Env>(r1);
                 E.trace(TR_FD, qa, r0, r1);
                 RDIS_TICK_KIND(1);
             } else {
-                r0 = uniform(E.eval_value(qa, (flags & RF_RESTORE) != 0));
+                r0 = uni<Env>(E.eval_value(qa, (flags & RF_RESTORE) != 0));
                 if (flags & RF_LINE) E.trace(TR_F, qa, r0, 0.0);
                 RDIS_TICK_KIND(0);
             }
@@ -502,8 +517,8 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
             if (flags & RF_PRE_LINE_END) E.line_end(qa);
             E.gradient_to_xi();
             if (flags & RF_POST_REDUCE) {
-                E.cg_reduce(uniform(q.b), r0, r1, r2);
-                r0 = uniform(r0); r1 = uniform(r1); r2 = uniform(r2);
+                E.cg_reduce(uni<Env>(q.b), r0, r1, r2);
+                r0 = uni<Env>(r0); r1 = uni<Env>(r1); r2 = uni<Env>(r2);
             }
             RDIS_TICK_KIND(2);
             break;
@@ -512,7 +527,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         }
 #undef RDIS_TICK_KIND
     }
-    __syncthreads();  // M is final and visible to every lane
+    E.sync();  // M is final and visible to every lane of the group
 }
 
 }  // namespace rdis_hip

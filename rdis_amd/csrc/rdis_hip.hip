@@ -17,6 +17,7 @@
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
+#include "solver_quad.hpp"
 #include "solver_stream.hpp"
 
 using namespace rdis_hip;
@@ -160,6 +161,9 @@ struct rdis_hip_plan {
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
     int coop_max_components = 8;      // ... for at most this many components per plan
+    int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad solver
+    int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
+    int64_t quad_min_components = 16384;  // ... and only for at least this many tiny components
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
@@ -761,6 +765,12 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_min_factors") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "coop_min_factors < 0");
         L->coop_min_factors = value;
+    } else if (n == "quad_min_components") {
+        if (value < 0) return fail(c, RDIS_HIP_EINVAL, "quad_min_components < 0");
+        L->quad_min_components = value;
+    } else if (n == "quad_max_vars") {
+        if (value < 0 || value > QUAD_MAX_VARS) return fail(c, RDIS_HIP_EINVAL, "quad_max_vars out of range");
+        L->quad_max_vars = (int)value;
     } else if (n == "coop_max_components") {
         if (value < 0 || value > 4096) return fail(c, RDIS_HIP_EINVAL, "coop_max_components out of range");
         L->coop_max_components = (int)value;
@@ -890,6 +900,24 @@ int prepare_partition(rdis_hip_plan* L) {
         HIPCHK(c, hipStreamSynchronize(c->stream));  // locals
         max_n = std::max(max_n, n);
     }
+    // tiny bundle-adjustment components (at most QUAD_MAX_VARS free variables: a point against fixed
+    // cameras) go first in the batch list: four lanes each (solver_quad.hpp) instead of a workgroup
+    {
+        auto tiny = [&](int cc) {
+            return p->kind == KIND_BA && L->quad_max_vars > 0 &&
+                   L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc] <= std::min(L->quad_max_vars, QUAD_MAX_VARS);
+        };
+        // ... when there are enough of them to fill the device: below that a wave's sixteen components
+        // finish at different times and the wave runs as long as its slowest (measured: ladybug's 7776
+        // points 2.8 ms with a workgroup each, 4.2 ms as quads; 31104 synthetic points 4.5 vs 2.3 ms)
+        int64_t ntiny = 0;
+        for (int cc : L->h_rest) ntiny += tiny(cc) ? 1 : 0;
+        L->rest_tiny = 0;
+        if (ntiny >= L->quad_min_components) {
+            auto mid = std::stable_partition(L->h_rest.begin(), L->h_rest.end(), tiny);
+            L->rest_tiny = (int)(mid - L->h_rest.begin());
+        }
+    }
     int rc = plan_alloc(L, L->rest_order, std::max<size_t>(L->h_rest.size(), 1) * sizeof(int));
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
@@ -899,10 +927,11 @@ int prepare_partition(rdis_hip_plan* L) {
 }
 
 template <int KIND>
-int launch_wg(rdis_hip_plan* L, int threads, int grid, int maxiters, double ftol) {
+int launch_wg(rdis_hip_plan* L, int threads, int first, int grid, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;
     ProblemView P = L->prob->view();
     PlanView V = L->view();
+    V.order += first;   // components [first, first + grid) of the batch list
     switch (threads) {
         case 64: cgd_wg_kernel<KIND, 64><<<grid, 64, 0, c->stream>>>(P, V, maxiters, ftol); break;
         case 128: cgd_wg_kernel<KIND, 128><<<grid, 128, 0, c->stream>>>(P, V, maxiters, ftol); break;
@@ -947,19 +976,27 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
-    const int rest = (int)L->h_rest.size();
+    if (L->rest_tiny > 0) {
+        cgd_quad_kernel<<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, c->stream>>>(
+            p->view(), V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
+        HIPCHK(c, hipGetLastError());
+        ++L->last_launches;
+    }
+    const int rest = (int)L->h_rest.size() - L->rest_tiny;
     if (rest > 0) {
         int64_t mf = 0;
-        for (int cc : L->h_rest)
-            mf = std::max<int64_t>(mf, std::max(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
-                                                (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
+        for (size_t i = (size_t)L->rest_tiny; i < L->h_rest.size(); ++i) {
+            const int cc = L->h_rest[i];
+            mf = std::max<int64_t>(mf, std::max<int64_t>(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
+                                                         (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));
+        }
         int threads = L->block_threads;
         // More than 512 factors: 768 lanes = three waves per SIMD at 168 registers (a few spills) beat
         // two waves at 250 and four at 128 (heavy spills): +20 % / +40 % throughput on large components,
         // and 5 % on the 361..906-factor camera components of ladybug.
         if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 512 ? 512 : 768;
-        int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, rest, maxiters, ftol)
-                                    : launch_wg<KIND_NLP>(L, threads, rest, maxiters, ftol);
+        int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, L->rest_tiny, rest, maxiters, ftol)
+                                    : launch_wg<KIND_NLP>(L, threads, L->rest_tiny, rest, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
     }

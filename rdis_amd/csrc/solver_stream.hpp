@@ -50,6 +50,10 @@ struct StreamEnv {
             ++trn;
         }
     }
+    static constexpr bool UNIFORM = true;
+    __device__ bool stepper() const { return threadIdx.x < 64; }
+    __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
+    __device__ void sync() const { __syncthreads(); }
     __device__ bool tracing() const { return tr != nullptr; }
     __device__ bool aborted() const { return X.dead; }
     __device__ void tick(int slot, long long dt) {

@@ -392,3 +392,46 @@ def test_cooperative_exchange_is_bit_reproducible(gctx):
             else:
                 assert r.fret[0] == ref.fret[0] and np.array_equal(r.x, ref.x) and r.nfeval[0] == ref.nfeval[0], opts
         plan.close()
+
+
+def test_quad_solver_point_components(gctx):
+    """four lanes per tiny component, sixteen machines per wave (solver_quad.hpp), forced on for
+    ladybug's point components: same contract, members replay against the oracle, empty and
+    single-factor components included"""
+    pp = P.load_bal(ncams=49, npts=700)
+    g = capi.Problem(gctx, pp)
+    a = np.zeros(pp.nvars, np.uint8); a[:441] = 1
+    comps = g.components(a)
+    free_ptr, free_vid, fac_ptr, fac_id = comps
+    results = {}
+    for quad in (1, 0):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *comps)
+        plan.set_option("quad_min_components", 1 if quad else 1 << 40)
+        plan.set_option("trace_records", 2048)
+        plan.set_option("dump_iters", 25)
+        plan.set_start(None)
+        plan.solve(25, 3e-8)
+        r = plan.fetch()
+        results[quad] = r
+        if not quad:
+            continue
+        assert plan.last_kernel_ms()[1] == 1                                 # one launch, the quad kernel
+        assert np.all(r.delta <= 0) and np.all((r.status & 0xFF) != 5)
+        new_obj = g.eval()
+        assert abs(new_obj - np.sum(r.fret)) <= 1e-12 * new_obj              # every factor in exactly one component
+        assert np.array_equal(g.get_x()[free_vid], r.x)                      # variables left assigned
+        ncomp = len(free_ptr) - 1
+        for c in (0, 1, ncomp // 2, ncomp - 2, ncomp - 1):                   # first / last: lightest and heaviest
+            fv, fc = free_vid[free_ptr[c]:free_ptr[c + 1]], fac_id[fac_ptr[c]:fac_ptr[c + 1]]
+            tr, n = plan.get_trace(c, 2048)
+            rep = O.OracleProblem(pp).replay(tr, free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25,
+                                             vdump=plan.get_vectors(c, 25)[:int(r.iters[c]) + 1])
+            assert rep.step_mismatches == 0 and rep.tag_mismatches == 0 and rep.underrun == 0 and rep.consumed == n, (c, rep)
+            assert rep.max_f_rel_near <= 1e-11 and rep.max_slope_rel_near <= 1e-11 and rep.fret == r.fret[c], (c, rep)
+            assert rep.iters == r.iters[c] and rep.reason == (r.status[c] & 0xFF)
+    # against one workgroup per component: same algorithm, sums in a different order
+    rq, rw = results[1], results[0]
+    assert np.array_equal(rq.status & 0xFF, rw.status & 0xFF) or np.mean((rq.status & 0xFF) == (rw.status & 0xFF)) > 0.98
+    conv = ((rq.status & 0xFF) != 3) & ((rw.status & 0xFF) != 3)
+    assert np.max(np.abs(rq.fret[conv] - rw.fret[conv]) / (1.0 + np.abs(rw.fret[conv]))) <= 1e-6   # converged members agree

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64) drive(long long* cyc, long long* cnt, doub
     for (int round = 0; round < 100000; ++round) {
         const int st0 = __builtin_amdgcn_readfirstlane(M.st);
         const long long t0 = clock64();
-        step_machine(&M, &Q[round & 1], r0, r1, r2);
+        step_machine(&M, &Q[round & 1], r0, r1, r2, (threadIdx.x & 63) == 0);
         const long long t1 = clock64();
         __syncthreads();
         if (st0 == CgdMachine::S_DB_EVAL) { c_hot += t1 - t0; ++n_hot; } else { c_other += t1 - t0; ++n_other; }
