@@ -21,6 +21,7 @@ namespace rdis_hip {
 
 constexpr int MAX_WAVES = 16;
 constexpr int WG_LONG_LIST = 64;   // batch solver: variables fed by more partials than this are summed by a whole wave
+constexpr int WG_LONG_QUEUE = 512; // ... up to this many per component (LDS queue)
 
 // Wave-wide reductions; every lane of a full wave returns the same bits.  Within a row of 16
 // lanes the partner comes through DPP (quad_perm / row_half_mirror / row_mirror: an ALU-speed
@@ -235,6 +236,7 @@ struct WgEnv {
     double *p, *xi, *g, *h, *xinit;
     double (*red)[3][MAX_WAVES];  // LDS [2][3][MAX_WAVES]
     int parity;
+    int *long_q, *long_n;         // LDS queue of the variables with long runs (gradient_to_xi)
     double* tr;
     int trn;
     int lm_count;  // line minimisations started
@@ -323,24 +325,32 @@ struct WgEnv {
             factor_partials<KIND>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
         }
         __syncthreads();
-        // variables fed by few partials: one lane each, in factor-list order (src/State.h:157-210)
+        // variables fed by few partials: one lane each, in factor-list order (src/State.h:157-210);
+        // those fed by many (a camera against fixed points: hundreds) are queued for a whole wave each
+        if (tid == 0) *long_n = 0;
+        __syncthreads();
         for (int i = tid; i < n; i += nt) {
             const int b = vptr[i], e = vptr[i + 1];
-            if (e - b > WG_LONG_LIST) continue;
+            if (e - b > WG_LONG_LIST) {
+                const int k = atomicAdd(long_n, 1);
+                if (k < WG_LONG_QUEUE) { long_q[k] = i; continue; }   // (queue full: summed right here)
+            }
             double s = 0.0;
             if (b < e) {
                 s = run_sum_ordered(L.gfac, b, e);
             }
             xi[i] = s;
         }
-        // fed by many (a camera against fixed points: hundreds): one wave each, strided + reduction
-        for (int i = tid >> 6; i < n; i += nwaves) {
-            const int b = vptr[i], e = vptr[i + 1];
-            if (e - b <= WG_LONG_LIST) continue;
-            const double s = wave_sum(run_sum_strided(L.gfac, b, e, tid & 63));
-            if ((tid & 63) == 0) xi[i] = s;
-        }
         __syncthreads();
+        const int nq = min(*long_n, WG_LONG_QUEUE);
+        if (nq > 0) {
+            for (int k = tid >> 6; k < nq; k += nwaves) {   // strided over the run + wave reduction
+                const int i = long_q[k];
+                const double s = wave_sum(run_sum_strided(L.gfac, vptr[i], vptr[i + 1], tid & 63));
+                if ((tid & 63) == 0) xi[i] = s;
+            }
+            __syncthreads();
+        }
     }
 
     __device__ void cg_start() {
@@ -389,10 +399,14 @@ struct WgEnv {
     }
 };
 
+// (second launch-bounds argument, HIP: minimum waves per SIMD.  Two waves of small workgroups must
+// fit: without it the allocator takes a handful of registers more than 256 and halves the occupancy)
 template <int KIND, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
     __shared__ double red[2][3][MAX_WAVES];
+    __shared__ int long_q[WG_LONG_QUEUE];
+    __shared__ int long_n;
     const int comp = L.order[blockIdx.x];
     const int f0 = L.free_ptr[comp], f1 = L.free_ptr[comp + 1];
     const int c0 = L.fac_ptr[comp], c1 = L.fac_ptr[comp + 1];
@@ -412,7 +426,7 @@ cgd_wg_kernel(ProblemView P, PlanView L, int maxiters, double ftol) {
     WgEnv<KIND> E{P, L, comp, n, m, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
                   L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                   ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
-                  red, 0,
+                  red, 0, long_q, &long_n,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
 
     __shared__ CgdMachine M;
