@@ -262,7 +262,6 @@ struct CoopEnv {
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
 cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol) {
-    __shared__ double red[2][COOP_K][MAX_WAVES];
     __shared__ double bcast[8];
     const long long tk0 = coop_clock();
     const int comp = A.comp;
@@ -271,7 +270,7 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
 
     CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x,
-              GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, red, bcast, A.poll_delay, 0, 0u, false, {}},
+              GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, bcast, A.poll_delay, 0, 0u, false, {}},
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
               gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
     if (E.has_fac) {

@@ -182,7 +182,6 @@ struct StreamEnv {
 template <int KIND, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 cgd_stream_kernel(ProblemView P, PlanView L, StreamArgs A, int maxiters, double ftol) {
-    __shared__ double red[2][COOP_K][MAX_WAVES];
     __shared__ double bcast[8];
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
@@ -194,7 +193,7 @@ cgd_stream_kernel(ProblemView P, PlanView L, StreamArgs A, int maxiters, double 
     double* ws = L.ws + 5ll * f0;
 
     StreamEnv<KIND> E{P, L, A, n, m, f0, c0, gt, gsz, (int)threadIdx.x,
-                      GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, red, bcast, A.poll_delay, 0, 0u, false, {}},
+                      GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, bcast, A.poll_delay, 0, 0u, false, {}},
                       L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                       ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
                       L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};

@@ -11,7 +11,7 @@ if os.environ.get("RDIS_PROBE_LIB"):
 ctx = capi.Context(0)
 pp = P.load_bal().single_component()
 g = capi.Problem(ctx, pp)
-for opts in [{"coop_poll_delay": 8}, {"coop_poll_delay": 12}, {"coop_poll_delay": 16}, {"coop_poll_delay": 24}, {"coop_threads": 128}, {"coop_threads": 512}]:
+for opts in [{"coop_poll_delay": 8}, {"coop_poll_delay": 12}, {"coop_poll_delay": 16}, {"coop_poll_delay": 20}, {"coop_poll_delay": 24}, {"coop_threads": 128}]:
     plan = capi.Plan(g)
     for k, v in opts.items():
         plan.set_option(k, v)
