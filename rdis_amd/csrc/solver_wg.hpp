@@ -110,17 +110,17 @@ __device__ __forceinline__ double run_sum_ordered(const double* __restrict__ g, 
     }
     return s;
 }
-// This lane's share of a long run: elements b + lane, b + lane + 64, ... (four loads in flight);
+// This lane's share of a long run: elements b + lane, b + lane + 64, ... (eight loads in flight);
 // element k lives at g[k * pitch]
 template <bool COHERENT = false>
 __device__ __forceinline__ double run_sum_strided(const double* __restrict__ g, int b, int e, int lane, int pitch = 1) {
     double s = 0.0;
-    for (int k0 = b + lane; k0 < e; k0 += 256) {
-        double t[4];
+    for (int k0 = b + lane; k0 < e; k0 += 512) {
+        double t[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (k0 + 64 * j < e) ? load_f64<COHERENT>(g + (long long)(k0 + 64 * j) * pitch) : 0.0;
+        for (int j = 0; j < 8; ++j) t[j] = (k0 + 64 * j < e) ? load_f64<COHERENT>(g + (long long)(k0 + 64 * j) * pitch) : 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
             if (k0 + 64 * j < e) s += t[j];
     }
     return s;
