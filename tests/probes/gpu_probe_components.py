@@ -1,6 +1,6 @@
 """exploratory: connected-components labelling, device vs CPU oracle, wall time per call"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """exploratory: cooperative solver timing vs configuration + replay report on ladybug full"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """exploratory: the tiny-component regime (every point of ladybug a component, cameras fixed)"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O

@@ -2,7 +2,7 @@
 free, every factor of those cameras (the reference spends 113 s per such call), (ii) 3 cameras + their
 points, (iii) the single-point components, in one launch."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O
