@@ -94,18 +94,18 @@ __device__ __forceinline__ void store_f64(double* p, double v) {
 }
 
 // Sum of the contiguous run g[b..e) in index order (factor-list order, src/State.h:157-210).
-// Eight loads are in flight at a time -- after an exchange every one of them comes from memory,
+// BATCH loads are in flight at a time -- after an exchange every one of them comes from memory,
 // and one round trip per element is what a plain loop pays -- while the additions stay strictly
 // sequential, so the result has the bits of the plain loop.
-template <bool COHERENT = false>
+template <bool COHERENT = false, int BATCH = 8>
 __device__ __forceinline__ double run_sum_ordered(const double* __restrict__ g, int b, int e) {
     double s = 0.0;
-    for (int k0 = b; k0 < e; k0 += 8) {
-        double t[8];
+    for (int k0 = b; k0 < e; k0 += BATCH) {
+        double t[BATCH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = (k0 + j < e) ? load_f64<COHERENT>(g + k0 + j) : 0.0;
+        for (int j = 0; j < BATCH; ++j) t[j] = (k0 + j < e) ? load_f64<COHERENT>(g + k0 + j) : 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < BATCH; ++j)
             if (k0 + j < e) s = (k0 + j == b) ? t[j] : s + t[j];
     }
     return s;
