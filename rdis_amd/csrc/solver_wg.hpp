@@ -241,13 +241,23 @@ struct WgEnv {
     int trn;
     int lm_count;  // line minimisations started
 
-    __device__ void sum3(double& a, double& b, double& mx) {
-        a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
-        const int w = tid >> 6;
-        if ((tid & 63) == 0) { red[parity][0][w] = a; red[parity][1][w] = b; red[parity][2][w] = mx; }
-        __syncthreads();
-        if (nwaves > 1) combine_waves<3>(red[parity], nwaves, a, b, mx);
-        parity ^= 1;
+    // workgroup-wide sums of the first K of (a, b, max mx), the same bits in every lane
+    template <int K>
+    __device__ void sumk(double& a, double& b, double& mx) {
+        a = wave_sum(a);
+        if constexpr (K >= 2) b = wave_sum(b);
+        if constexpr (K >= 3) mx = wave_max(mx);
+        if (nwaves > 1) {
+            const int w = tid >> 6;
+            if ((tid & 63) == 0) {
+                red[parity][0][w] = a;
+                if constexpr (K >= 2) red[parity][1][w] = b;
+                if constexpr (K >= 3) red[parity][2][w] = mx;
+            }
+            __syncthreads();
+            combine_waves<K>(red[parity], nwaves, a, b, mx);
+            parity ^= 1;
+        }
     }
 
     __device__ void trace(int tag, double a, double b, double c) {
@@ -288,7 +298,7 @@ struct WgEnv {
             af += fj;
             if constexpr (SLOPE) as += sj;
         }
-        sum3(af, as, dummy);
+        sumk<SLOPE ? 2 : 1>(af, as, dummy);
         f = af; s = as;
     }
 
@@ -385,7 +395,7 @@ struct WgEnv {
             a = a + gi * gi;
             b = b + (x + gi) * x;
         }
-        sum3(a, b, t);
+        sumk<3>(a, b, t);
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {
