@@ -435,3 +435,41 @@ def test_quad_solver_point_components(gctx):
     assert np.array_equal(rq.status & 0xFF, rw.status & 0xFF) or np.mean((rq.status & 0xFF) == (rw.status & 0xFF)) > 0.98
     conv = ((rq.status & 0xFF) != 3) & ((rw.status & 0xFF) != 3)
     assert np.max(np.abs(rq.fret[conv] - rw.fret[conv]) / (1.0 + np.abs(rw.fret[conv]))) <= 1e-6   # converged members agree
+
+
+def test_quad_solver_partial_blocks_and_active_bounds(gctx):
+    """quad solver on components that are not whole point blocks (1 or 2 free coordinates, the rest
+    constants) and with domains tight enough that the clamp is active during the line searches"""
+    rng = np.random.default_rng(23)
+    pp = P.load_bal(ncams=49, npts=300)
+    pp.lo[441:] = pp.x0[441:] - rng.uniform(0.002, 0.05, pp.nvars - 441)
+    pp.hi[441:] = pp.x0[441:] + rng.uniform(0.002, 0.05, pp.nvars - 441)
+    g = capi.Problem(gctx, pp)
+    a = np.ones(pp.nvars, np.uint8)
+    keep = rng.random(300) < 0.7
+    for p in np.where(keep)[0]:                      # free 1..3 coordinates of 70 % of the points
+        k = rng.integers(1, 4)
+        a[441 + 3 * p + rng.choice(3, size=k, replace=False)] = 0
+    comps = g.components(a)
+    free_ptr, free_vid, fac_ptr, fac_id = comps
+    assert set(np.diff(free_ptr)) <= {1, 2, 3} and len(set(np.diff(free_ptr))) == 3
+    plan = capi.Plan(g, *comps)
+    plan.set_option("quad_min_components", 1)
+    plan.set_option("trace_records", 2048)
+    plan.set_option("dump_iters", 25)
+    plan.set_start(None)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.last_kernel_ms()[1] == 1
+    assert np.all(r.x >= pp.lo[free_vid]) and np.all(r.x <= pp.hi[free_vid])
+    assert np.any((r.x == pp.lo[free_vid]) | (r.x == pp.hi[free_vid]))          # some results sit on their bounds
+    ncomp = len(free_ptr) - 1
+    for c in rng.choice(ncomp, size=12, replace=False):
+        fv, fc = free_vid[free_ptr[c]:free_ptr[c + 1]], fac_id[fac_ptr[c]:fac_ptr[c + 1]]
+        tr, n = plan.get_trace(c, 2048)
+        rep = O.OracleProblem(pp).replay(tr, free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25,
+                                         vdump=plan.get_vectors(c, 25)[:int(r.iters[c]) + 1])
+        assert rep.step_mismatches == 0 and rep.tag_mismatches == 0 and rep.underrun == 0 and rep.consumed == n, (c, rep)
+        assert rep.max_f_rel_near <= 1e-11 and rep.max_slope_rel_near <= 1e-11, (c, rep)
+        if not (r.status[c] & capi.STATUS_ROLLED_BACK):
+            assert rep.fret == r.fret[c], (c, rep)
