@@ -155,7 +155,8 @@ def test_ladybug_full_objective(golden, gctx):
     pp = P.load_bal()
     g, r, tr = solve(gctx, pp, maxiters=25, trace=1 << 13)
     assert (r.status[0] & 0xFF) == 3 and r.iters[0] == 24
-    assert abs(r.fret[0] - c["fret"]) <= 0.08 * c["fret"]                       # chaos band around 83227.6
+    # chaos band: the oracle itself ends anywhere in 83189 .. 92367 when x0 is perturbed by 1e-15 relative
+    assert 0.96 * c["fret"] <= r.fret[0] <= 1.14 * c["fret"]
     assert abs(int(r.nfeval[0]) - c["nfeval"]) <= 0.15 * c["nfeval"]
     # the returned value IS the objective at the returned point (size-independent check)
     assert np.array_equal(g.get_x(), r.x)                                       # variables left assigned

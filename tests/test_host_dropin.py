@@ -136,7 +136,7 @@ def test_optimize_full_ladybug_through_plugin(harness, bal_path, golden):
     out, x = _ba_cgd(harness, bal_path, 0, 0, 0, 25)
     c = golden["cgd"]["ladybug_full"]
     assert out[8] == 1.0 and int(out[5]) & 0xFF == 3 and out[4] == 24
-    assert abs(out[0] - c["fret"]) <= 0.08 * c["fret"]                      # chaos band, see test_gpu_solver.py
+    assert 0.96 * c["fret"] <= out[0] <= 1.14 * c["fret"]                   # chaos band, see test_gpu_solver.py
     assert abs(out[2] - 850912.46068083902) <= 1e-12 * out[2]
     assert abs(out[3] - out[0]) <= 1e-12 * out[0]
 
