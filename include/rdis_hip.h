@@ -216,6 +216,12 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * "quad_max_vars" / "quad_min_components" (bundle-adjustment components with at most that many
  * free variables, default and maximum 4, are solved by groups of four lanes, sixteen per wave,
  * when the plan has at least that many of them, default 16384; 0 variables = never),
+ * "camera_records" (bundle adjustment, batched launches: 1 = default -- when no camera variable is
+ * free in the launch its factors read per-camera rotation records (angle, axis, sine, cosine,
+ * computed once per camera) and form only the point partials; with free cameras and more than 2048
+ * factors in a component the component rewrites the records of its cameras at every trial point;
+ * 2 = records wherever possible; 0 = every factor forms its camera's rotation itself.  Results
+ * are bit-identical in all three settings),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

@@ -96,6 +96,27 @@ def _register(obj):
     _live.append(weakref.ref(obj))
 
 
+class _Cell:
+    """A native handle and the handles that depend on it (context <- problems <- plans).  Closing a
+    cell closes its dependents first, so the order in which Python finalises the wrapper objects
+    (arbitrary inside a garbage cycle, e.g. the frames of a failed test) never leaves the library
+    with a dangling pointer."""
+    __slots__ = ("h", "kids", "destroy")
+
+    def __init__(self, h, destroy, owner=None):
+        self.h, self.kids, self.destroy = h, [], destroy
+        if owner is not None:
+            owner.kids = [k for k in owner.kids if k.h] + [self]
+
+    def close(self):
+        if self.h:
+            for k in self.kids:
+                k.close()
+            self.kids = []
+            self.destroy(self.h)
+            self.h = None
+
+
 def _close_all():
     # the HIP runtime must still be loaded when device memory and streams are released
     objs = [r() for r in _live]
@@ -159,7 +180,7 @@ class Context:
         if rc:
             raise RdisHipError(rc, f"rdis_hip_create(device={device}) failed "
                                    f"({self.lib.rdis_hip_device_count()} HIP devices visible)")
-        self.h = h
+        self._cell = _Cell(h, self.lib.rdis_hip_destroy)
         self.device = device
         _register(self)
 
@@ -178,10 +199,13 @@ class Context:
         self.check(self.lib.rdis_hip_copy_to_host(self.h, buf, _vp(dev_ptr), nbytes))
         return buf.raw
 
+    @property
+    def h(self):
+        return self._cell.h
+
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.rdis_hip_destroy(self.h)
-            self.h = None
+        if getattr(self, "_cell", None):
+            self._cell.close()
 
     def __del__(self):
         try:
@@ -227,14 +251,17 @@ class Problem:
                                          _ptr(_f(pp.expo)), _ptr(_f(pp.cons)),
                                          _ptr(np.ascontiguousarray(pp.sine, dtype=np.uint8)), C.byref(h))
         ctx.check(rc)
-        self.h = h
+        self._cell = _Cell(h, lib.rdis_hip_free_problem, ctx._cell)
         self.nvars, self.nfac = pp.nvars, pp.nfac
         _register(self)
 
+    @property
+    def h(self):
+        return self._cell.h
+
     def close(self):
-        if getattr(self, "h", None):
-            self.ctx.lib.rdis_hip_free_problem(self.h)
-            self.h = None
+        if getattr(self, "_cell", None):
+            self._cell.close()
 
     def __del__(self):
         try:
@@ -344,13 +371,16 @@ class Plan:
         h = _vp()
         self.ctx.check(self.ctx.lib.rdis_hip_plan_create(prob.h, self.ncomp, _ptr(self.free_ptr), _ptr(self.free_vid),
                                                          _ptr(self.fac_ptr), _ptr(self.fac_id), C.byref(h)))
-        self.h = h
+        self._cell = _Cell(h, self.ctx.lib.rdis_hip_plan_destroy, prob._cell)
         _register(self)
 
+    @property
+    def h(self):
+        return self._cell.h
+
     def close(self):
-        if getattr(self, "h", None):
-            self.ctx.lib.rdis_hip_plan_destroy(self.h)
-            self.h = None
+        if getattr(self, "_cell", None):
+            self._cell.close()
 
     def __del__(self):
         try:

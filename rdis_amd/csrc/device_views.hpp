@@ -7,7 +7,8 @@
 //                 during a solve the free entries hold the clamped trial point
 //   lo[N], hi[N]  single-interval domain (VariableDomain::interval())
 //   BA  factors:  cam[F], pt[F] first variable id of the camera / point block,
-//                 obs[F] (double2, one 16-byte load per factor)
+//                 obs[F] (double2, one 16-byte load per factor);
+//                 cam_blocks[] the distinct camera blocks, xrot[N] their rotation records
 //   NLP factors:  coeff[F], rowptr[F+1], vid/expo/cons/sine[nnz]   (CSR)
 //   plan:         order[ncomp] (heaviest component first), free_ptr/free_vid,
 //                 fac_ptr/fac_id, v2s_ptr + slot_pos (gfac is variable-major: the
@@ -27,6 +28,7 @@ namespace rdis_hip {
 
 constexpr int KIND_BA = 0;
 constexpr int KIND_NLP = 1;
+constexpr int ROT_PER_FACTOR = 0, ROT_RECORDS = 1, ROT_CAMFIX = 2;
 
 struct ProblemView {
     int kind;
@@ -37,6 +39,11 @@ struct ProblemView {
     const int* cam;
     const int* pt;
     const double2* obs;
+    double* xrot;         // null, or a shadow of x holding at every camera block's first id the camera's
+                          // rotation record (7 doubles, factors.hpp), current for the assigned x at launch
+    int rot_mode;         // ROT_PER_FACTOR: not used; ROT_RECORDS: factors read the records and a component rewrites
+                          // those of its free cameras (PlanView::cb) at every trial point; ROT_CAMFIX: no camera
+                          // variable is free in the launch -- records only read, point partials only
     const double* coeff;
     const int* rowptr;
     const int* vid;
@@ -54,6 +61,8 @@ struct PlanView {
     const int* fac_id;
     const int* v2s_ptr;   // [nfree_total + 1]
     const int* slot_base; // [nfac_total + 1] first slot of each LISTED factor (plan-local: 12 per BA factor, arity per NLP factor)
+    const int* cb_ptr;    // [ncomp + 1] ...
+    const int* cb;        // ... camera blocks (first variable id) with a free rotation variable, per component
     const int* slot_pos;  // [slot_base[nfac_total]] listed factor's slot -> position in gfac (variable-major), -1 = not a free variable
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

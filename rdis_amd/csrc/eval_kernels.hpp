@@ -30,6 +30,16 @@ partials_kernel(ProblemView P, int nf, const int* __restrict__ fac, double* __re
         factor_partials<KIND>(P, gfac, nullptr, fac ? fac[i] : i);
 }
 
+// rotation record of every camera block at the assigned x (one lane per camera): what the factors of
+// a launch without free camera variables read instead of redoing ba_rotation per trial point
+__global__ void __launch_bounds__(256)
+camera_rotations_kernel(const double* __restrict__ x, const int* __restrict__ cam_blocks, int nblocks,
+                        double* __restrict__ xrot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    store_rotation(x, cam_blocks[i], xrot);
+}
+
 __global__ void __launch_bounds__(256)
 gather_rows12_kernel(int nf, const int* __restrict__ fac, const double* __restrict__ gfac,
                      double* __restrict__ out) {

@@ -21,6 +21,7 @@ namespace rdis_hip {
 // below 1 ulp, like the library routine it replaces, at about a third of its instructions and
 // without its large-argument branch.  Beyond the exact range the library is used.
 __device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
+#pragma clang fp contract(on)
     if (!(x < 1.0e6)) { sincos(x, sn, cs); return; }
     const double fn = rint(x * 6.36619772367581382433e-01);
     const int n = (int)fn;
@@ -55,28 +56,43 @@ struct BaFwd {
     double P0, P1, P2, iz, pp0, pp1, r2, dstn, res0, res1;
 };
 
-__device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, double oy, BaFwd& t) {
-    const double th2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+// The rotation part of the forward pass: angle, unit axis, sine and cosine of a camera's
+// angle-axis vector.  It depends on the camera alone, so a launch whose components leave every
+// camera constant computes it once per camera (camera_rotations_kernel) instead of once per
+// factor and trial point; the arithmetic is the same either way.
+__device__ __forceinline__ void ba_rotation(double r0, double r1, double r2, BaFwd& t) {
+#pragma clang fp contract(on)
+    const double th2 = r0 * r0 + r1 * r1 + r2 * r2;
     t.theta = sqrt(th2);
     const bool rot = t.theta > 0.0;
     // unit axis (reference BundleAdjustmentCommon.h:81-93); one reciprocal instead of three quotients
     t.itheta = 1.0 / t.theta;
-    t.v0 = rot ? x[0] * t.itheta : x[0];
-    t.v1 = rot ? x[1] * t.itheta : x[1];
-    t.v2 = rot ? x[2] * t.itheta : x[2];
+    t.v0 = rot ? r0 * t.itheta : r0;
+    t.v1 = rot ? r1 * t.itheta : r1;
+    t.v2 = rot ? r2 * t.itheta : r2;
+    if (rot) {
+        sincos_angle(t.theta, &t.s, &t.c);
+    } else {
+        t.s = 0.0; t.c = 1.0;
+    }
+}
+
+// ... and the rest, given the rotation fields of t: rotate, translate, project, distort, residual.
+// x[0..2] are not read.
+__device__ __forceinline__ double ba_project(const double (&x)[12], double ox, double oy, BaFwd& t) {
+#pragma clang fp contract(on)
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     t.w0 = t.v1 * q2 - t.v2 * q1;
     t.w1 = t.v2 * q0 - t.v0 * q2;
     t.w2 = t.v0 * q1 - t.v1 * q0;
-    if (rot) {
-        sincos_angle(t.theta, &t.s, &t.c);
+    if (t.theta > 0.0) {
         const double omc = 1.0 - t.c;
         t.d = t.v0 * q0 + t.v1 * q1 + t.v2 * q2;
         t.P0 = q0 * t.c + t.w0 * t.s + t.v0 * omc * t.d;
         t.P1 = q1 * t.c + t.w1 * t.s + t.v1 * omc * t.d;
         t.P2 = q2 * t.c + t.w2 * t.s + t.v2 * omc * t.d;
     } else {  // first-order rotation at theta == 0 (reference .cpp:304-329)
-        t.s = 0.0; t.c = 1.0; t.d = 0.0;
+        t.d = 0.0;
         t.P0 = q0 + t.w0; t.P1 = q1 + t.w1; t.P2 = q2 + t.w2;
     }
     t.P0 += x[3]; t.P1 += x[4]; t.P2 += x[5];
@@ -90,6 +106,26 @@ __device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, d
     return (t.res0 * t.res0 + t.res1 * t.res1) * 0.5;
 }
 
+__device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, double oy, BaFwd& t) {
+    ba_rotation(x[0], x[1], x[2], t);
+    return ba_project(x, ox, oy, t);
+}
+
+// Rotation record of a camera block as camera_rotations_kernel leaves it: seven doubles at the
+// block's first variable id in a shadow array of x.
+constexpr int ROT_V0 = 0, ROT_THETA = 3, ROT_ITHETA = 4, ROT_SIN = 5, ROT_COS = 6;
+__device__ __forceinline__ void store_rotation(const double* __restrict__ x, int c, double* __restrict__ xrot) {
+    BaFwd t;
+    ba_rotation(x[c], x[c + 1], x[c + 2], t);
+    double* r = xrot + c;
+    r[ROT_V0] = t.v0; r[ROT_V0 + 1] = t.v1; r[ROT_V0 + 2] = t.v2;
+    r[ROT_THETA] = t.theta; r[ROT_ITHETA] = t.itheta; r[ROT_SIN] = t.s; r[ROT_COS] = t.c;
+}
+__device__ __forceinline__ void ba_load_rotation(const double* __restrict__ r, BaFwd& t) {
+    t.v0 = r[ROT_V0]; t.v1 = r[ROT_V0 + 1]; t.v2 = r[ROT_V0 + 2];
+    t.theta = r[ROT_THETA]; t.itheta = r[ROT_ITHETA]; t.s = r[ROT_SIN]; t.c = r[ROT_COS];
+}
+
 __device__ __forceinline__ double ba_eval(const double (&x)[12], double ox, double oy) {
     BaFwd t;
     return ba_forward(x, ox, oy, t);
@@ -99,6 +135,7 @@ __device__ __forceinline__ double ba_eval(const double (&x)[12], double ox, doub
 // state t.  With (s0, s1) = the residual this is the gradient of E = |res|^2 / 2; with unit
 // seeds it yields the two rows of the residual's Jacobian.
 __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12], double s0, double s1, double (&g)[12]) {
+#pragma clang fp contract(on)
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double f = x[6];
     const double rp = s0 * t.pp0 + s1 * t.pp1;

@@ -88,6 +88,9 @@ struct rdis_hip_problem {
     int kind = KIND_BA;
     int64_t N = 0, F = 0, nnz = 0;
     DevBuf x, lo, hi, cam, pt, obs, coeff, rowptr, vid, expo, cons, sine;
+    DevBuf cam_blocks, xrot;                        // distinct camera blocks; their rotation records (shadow of x)
+    int64_t ncam_blocks = 0;
+    std::vector<int> h_block_of;                    // [N] first variable id of the camera block a variable belongs to, -1 = none
     std::vector<int> h_cam, h_pt, h_rowptr, h_vid;  // host copies for plan building
     // scratch for the eval entry points
     DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
@@ -110,6 +113,7 @@ struct rdis_hip_problem {
         v.kind = kind; v.N = (int)N; v.F = (int)F;
         v.x = x.as<double>(); v.lo = lo.as<double>(); v.hi = hi.as<double>();
         v.cam = cam.as<int>(); v.pt = pt.as<int>(); v.obs = obs.as<double2>();
+        v.xrot = nullptr; v.rot_mode = ROT_PER_FACTOR;
         v.coeff = coeff.as<double>(); v.rowptr = rowptr.as<int>(); v.vid = vid.as<int>();
         v.expo = expo.as<double>(); v.cons = cons.as<double>(); v.sine = sine.as<uint8_t>();
         return v;
@@ -164,6 +168,9 @@ struct rdis_hip_plan {
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad solver
     int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
     int64_t quad_min_components = 16384;  // ... and only for at least this many tiny components
+    int rest_rot_mode = ROT_PER_FACTOR; // how the factors of the batch list get their camera rotations (device_views.hpp)
+    int camera_records = 1;           // option "camera_records": 0 = every factor forms its rotation itself, 1 = auto, 2 = records wherever possible
+    size_t off_cb_ptr = 0, off_cb = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
@@ -181,6 +188,7 @@ struct rdis_hip_plan {
         v.free_ptr = ip(off_free_ptr); v.free_vid = ip(off_free_vid);
         v.fac_ptr = ip(off_fac_ptr); v.fac_id = ip(off_fac_id);
         v.v2s_ptr = ip(off_v2s_ptr); v.slot_base = ip(off_slot_base); v.slot_pos = ip(off_slot_pos);
+        v.cb_ptr = ip(off_cb_ptr); v.cb = ip(off_cb);
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
         v.xout = out_f64(0);
@@ -301,6 +309,25 @@ extern "C" int rdis_hip_upload_ba(rdis_hip_ctx* c, int64_t nvars, const double* 
     if (!rc) rc = upload(c, p->cam, p->h_cam);
     if (!rc) rc = upload(c, p->pt, p->h_pt);
     if (!rc) rc = upload(c, p->obs, obs, (size_t)(2 * nfac));
+    std::vector<int> blocks;   // (alive until the copies below have completed)
+    {   // the distinct camera blocks, for the rotation records of launches that leave the cameras constant
+        p->h_block_of.assign((size_t)nvars, -1);
+        blocks = p->h_cam;
+        std::sort(blocks.begin(), blocks.end());
+        blocks.erase(std::unique(blocks.begin(), blocks.end()), blocks.end());
+        // blocks that overlap without coinciding would share record slots: no records then
+        bool disjoint = true;
+        for (size_t i = 1; i < blocks.size(); ++i) disjoint = disjoint && blocks[i] - blocks[i - 1] >= 9;
+        for (int cb : blocks)
+            for (int k = 0; k < 9; ++k) p->h_block_of[(size_t)cb + k] = cb;
+        for (int64_t i = 0; i < nfac && disjoint; ++i)   // a point block inside a camera block: likewise
+            for (int k = 0; k < 3; ++k) disjoint = disjoint && p->h_block_of[(size_t)p->h_pt[(size_t)i] + k] < 0;
+        p->ncam_blocks = disjoint ? (int64_t)blocks.size() : 0;
+        if (!rc && p->ncam_blocks > 0) {
+            rc = upload(c, p->cam_blocks, blocks);
+            if (!rc) rc = dalloc(c, p->xrot, (size_t)nvars * sizeof(double));
+        }
+    }
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, RDIS_HIP_EDEVICE, "upload_ba: sync");
     if (rc) { delete p; return rc; }
     *out = p;
@@ -692,6 +719,22 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     L->off_free_ptr = put(L->h_free_ptr); L->off_free_vid = put(L->h_free_vid);
     L->off_fac_ptr = put(L->h_fac_ptr); L->off_fac_id = put(L->h_fac_id);
     L->off_v2s_ptr = put(v2s_ptr); L->off_slot_base = put(slot_base); L->off_slot_pos = put(slot_pos);
+    {   // per component: the camera blocks with a free rotation variable (their records follow the trial point)
+        std::vector<int> cb_ptr((size_t)ncomp + 1, 0), cb;
+        if (p->kind == KIND_BA && p->ncam_blocks > 0)
+            for (int64_t cc = 0; cc < ncomp; ++cc) {
+                const size_t first = cb.size();
+                for (int64_t i = free_ptr[cc]; i < free_ptr[cc + 1]; ++i) {
+                    const int v = L->h_free_vid[(size_t)i], b = p->h_block_of[(size_t)v];
+                    if (b < 0) continue;
+                    if (v - b < 3) cb.push_back(b);
+                }
+                std::sort(cb.begin() + (long)first, cb.end());
+                cb.erase(std::unique(cb.begin() + (long)first, cb.end()), cb.end());
+                cb_ptr[(size_t)cc + 1] = (int)cb.size();
+            }
+        L->off_cb_ptr = put(cb_ptr); L->off_cb = put(cb);
+    }
 
     const size_t nc = (size_t)ncomp;
     L->out_bytes = ((size_t)nfree + 2 * nc) * 8 + 2 * nc * 8 + 3 * nc * 4;
@@ -768,6 +811,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "quad_min_components") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "quad_min_components < 0");
         L->quad_min_components = value;
+    } else if (n == "camera_records") {
+        if (value < 0 || value > 2) return fail(c, RDIS_HIP_EINVAL, "camera_records must be 0, 1 or 2");
+        L->camera_records = (int)value;
     } else if (n == "quad_max_vars") {
         if (value < 0 || value > QUAD_MAX_VARS) return fail(c, RDIS_HIP_EINVAL, "quad_max_vars out of range");
         L->quad_max_vars = (int)value;
@@ -918,6 +964,22 @@ int prepare_partition(rdis_hip_plan* L) {
             L->rest_tiny = (int)(mid - L->h_rest.begin());
         }
     }
+    L->rest_rot_mode = ROT_PER_FACTOR;
+    if (p->kind == KIND_BA && L->camera_records != 0 && p->ncam_blocks > 0 && !L->h_rest.empty()) {
+        bool camfix = true;
+        for (size_t i = 0; i < L->h_rest.size() && camfix; ++i) {
+            const int cc = L->h_rest[i];
+            for (int k = L->h_free_ptr[(size_t)cc]; k < L->h_free_ptr[(size_t)cc + 1] && camfix; ++k)
+                camfix = p->h_block_of[(size_t)L->h_free_vid[(size_t)k]] < 0;
+        }
+        // Free cameras: rewriting their records at every trial point costs a barrier and one lane's
+        // rotation latency per evaluation, and saves the rotation in every factor -- a gain only where a
+        // lane has many factors per camera (64 components of 31843 factors: 70 against 76 ms; ladybug's
+        // 49 camera components 6.9 against 6.5 ms, 1000 small components 2.2 against 2.0 ms).
+        int64_t mf = 0;
+        for (int cc : L->h_rest) mf = std::max<int64_t>(mf, L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc]);
+        L->rest_rot_mode = camfix ? ROT_CAMFIX : (L->camera_records == 2 || mf > 2048) ? ROT_RECORDS : ROT_PER_FACTOR;
+    }
     int rc = plan_alloc(L, L->rest_order, std::max<size_t>(L->h_rest.size(), 1) * sizeof(int));
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
@@ -930,6 +992,7 @@ template <int KIND>
 int launch_wg(rdis_hip_plan* L, int threads, int first, int grid, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;
     ProblemView P = L->prob->view();
+    P.xrot = L->prob->xrot.as<double>(); P.rot_mode = L->rest_rot_mode;
     PlanView V = L->view();
     V.order += first;   // components [first, first + grid) of the batch list
     switch (threads) {
@@ -976,9 +1039,17 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
+    if (L->rest_rot_mode != ROT_PER_FACTOR) {   // after the launches above, which may have moved cameras
+        camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, c->stream>>>(
+            p->x.as<double>(), p->cam_blocks.as<int>(), (int)p->ncam_blocks, p->xrot.as<double>());
+        HIPCHK(c, hipGetLastError());
+    }
     if (L->rest_tiny > 0) {
+        ProblemView PV = p->view();
+        PV.xrot = p->xrot.as<double>();
+        PV.rot_mode = L->rest_rot_mode == ROT_CAMFIX ? ROT_CAMFIX : ROT_PER_FACTOR;   // (the quad solver has no refresh)
         cgd_quad_kernel<<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, c->stream>>>(
-            p->view(), V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
+            PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
         HIPCHK(c, hipGetLastError());
         ++L->last_launches;
     }

@@ -59,6 +59,42 @@ struct QuadEnv {
     template <bool SLOPE>
     __device__ void eval_at(double& f, double& s) {
         double af = 0.0, as = 0.0;
+        if (P.rot_mode == ROT_CAMFIX) {   // cameras constant in this launch: rotation records, point partials only
+            for (int j = sub; j < m; j += 4) {
+                const int fid = L.fac_id[c0 + j];
+                const int c = P.cam[fid], q = P.pt[fid];
+                const double2 o = P.obs[fid];
+                double v[12], d[3];
+                BaFwd t;
+                ba_load_rotation(P.xrot + c, t);
+                v[0] = v[1] = v[2] = 0.0;
+#pragma unroll
+                for (int k = 3; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int vid = q + k;
+                    double val = 0.0, dv = 0.0;
+                    bool fr = false;
+#pragma unroll
+                    for (int u = 0; u < QUAD_MAX_VARS; ++u)
+                        if (u < n && vid == fv[u]) { val = xt[u]; dv = xi[u]; fr = true; }
+                    v[9 + k] = fr ? val : P.x[vid];
+                    d[k] = dv;
+                }
+                af += ba_project(v, o.x, o.y, t);
+                if constexpr (SLOPE) {
+                    double gg[12];
+                    ba_adjoint(t, v, t.res0, t.res1, gg);
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += gg[9 + k] * d[k];
+                    as += acc;
+                }
+            }
+            f = quad_sum(af);
+            s = SLOPE ? quad_sum(as) : 0.0;
+            return;
+        }
         for (int j = sub; j < m; j += 4) {
             const int fid = L.fac_id[c0 + j];
             const int c = P.cam[fid], q = P.pt[fid];
@@ -117,6 +153,41 @@ struct QuadEnv {
         double acc[QUAD_MAX_VARS];
 #pragma unroll
         for (int t = 0; t < QUAD_MAX_VARS; ++t) { xt[t] = clampd(p[t], lo[t], hi[t]); acc[t] = 0.0; }
+        if (P.rot_mode == ROT_CAMFIX) {
+            for (int j = sub; j < m; j += 4) {
+                const int fid = L.fac_id[c0 + j];
+                const int c = P.cam[fid], q = P.pt[fid];
+                const double2 o = P.obs[fid];
+                double v[12], gg[12];
+                int li[3];
+                BaFwd t;
+                ba_load_rotation(P.xrot + c, t);
+                v[0] = v[1] = v[2] = 0.0;
+#pragma unroll
+                for (int k = 3; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int vid = q + k;
+                    double val = 0.0;
+                    int l = -1;
+#pragma unroll
+                    for (int u = 0; u < QUAD_MAX_VARS; ++u)
+                        if (u < n && vid == fv[u]) { val = xt[u]; l = u; }
+                    v[9 + k] = l >= 0 ? val : P.x[vid];
+                    li[k] = l;
+                }
+                ba_project(v, o.x, o.y, t);
+                ba_adjoint(t, v, t.res0, t.res1, gg);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int u = 0; u < QUAD_MAX_VARS; ++u)
+                        if (li[k] == u) acc[u] += gg[9 + k];
+            }
+#pragma unroll
+            for (int t = 0; t < QUAD_MAX_VARS; ++t) xi[t] = quad_sum(acc[t]);
+            return;
+        }
         for (int j = sub; j < m; j += 4) {
             const int fid = L.fac_id[c0 + j];
             const int c = P.cam[fid], q = P.pt[fid];

@@ -133,10 +133,39 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) {
 }
 
 // ---- factor evaluation shared by all solver variants ---------------------------
-template <int KIND, bool SLOPE>
+// ROT (device_views.hpp): with ROT_RECORDS / ROT_CAMFIX the factor reads its camera's rotation
+// record from P.xrot instead of forming angle, axis, sine and cosine itself (same arithmetic, done
+// once per camera and trial point instead of once per factor); ROT_CAMFIX also forms only the
+// point's three partials.
+template <int KIND, bool SLOPE, int ROT = ROT_PER_FACTOR>
 __device__ __forceinline__ void factor_value(const ProblemView& P, const double* __restrict__ dir,
                                              int fid, double& f, double& s) {
-    if constexpr (KIND == KIND_BA) {
+    if constexpr (KIND == KIND_BA && ROT != ROT_PER_FACTOR) {
+        const int c = P.cam[fid], q = P.pt[fid];
+        const double2 o = P.obs[fid];
+        double v[12];
+        BaFwd t;
+        ba_load_rotation(P.xrot + c, t);
+        v[0] = v[1] = v[2] = 0.0;
+#pragma unroll
+        for (int k = 3; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
+        f = ba_project(v, o.x, o.y, t);
+        s = 0.0;
+        if constexpr (SLOPE) {
+            double g[12];
+            ba_adjoint(t, v, t.res0, t.res1, g);
+            double acc = 0.0;
+            if constexpr (ROT == ROT_RECORDS) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += g[k] * dir[c + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc += g[9 + k] * dir[q + k];
+            s = acc;
+        }
+    } else if constexpr (KIND == KIND_BA) {
         const int c = P.cam[fid], q = P.pt[fid];
         const double2 o = P.obs[fid];
         double v[12];
@@ -185,10 +214,25 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
 // per-factor partials into their gradient slots.  Slot id: BA 12*fid + k, NLP the CSR
 // position.  With sp (this factor's row of PlanView::slot_pos) partial k goes to gfac[sp[k]]
 // (variable-major, skipped when negative); without it to gfac[global slot id].
-template <int KIND>
+template <int KIND, int ROT = ROT_PER_FACTOR>
 __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __restrict__ gfac,
                                                 const int* __restrict__ sp, int fid) {
-    if constexpr (KIND == KIND_BA) {
+    if constexpr (KIND == KIND_BA && ROT != ROT_PER_FACTOR) {   // (sp given: the batch solvers)
+        const int c = P.cam[fid], q = P.pt[fid];
+        const double2 o = P.obs[fid];
+        double v[12], g[12];
+        BaFwd t;
+        ba_load_rotation(P.xrot + c, t);
+        v[0] = v[1] = v[2] = 0.0;
+#pragma unroll
+        for (int k = 3; k < 9; ++k) v[k] = P.x[c + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
+        ba_project(v, o.x, o.y, t);
+        ba_adjoint(t, v, t.res0, t.res1, g);
+#pragma unroll
+        for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) { const int u = sp[k]; if (u >= 0) gfac[u] = g[k]; }
+    } else if constexpr (KIND == KIND_BA) {
         const int c = P.cam[fid], q = P.pt[fid];
         const double2 o = P.obs[fid];
         double v[12], g[12];
@@ -280,6 +324,7 @@ struct WgEnv {
             P.x[v] = clampd(p[i] + t, P.lo[v], P.hi[v]);
         }
         __syncthreads();
+        refresh_rotations();
     }
     __device__ void assign_vec(const double* src) {
         for (int i = tid; i < n; i += nt) {
@@ -287,6 +332,17 @@ struct WgEnv {
             P.x[v] = clampd(src[i], P.lo[v], P.hi[v]);
         }
         __syncthreads();
+        refresh_rotations();
+    }
+    // the rotation records of this component's free cameras at the point just assigned
+    __device__ void refresh_rotations() {
+        if constexpr (KIND == KIND_BA) {
+            if (P.rot_mode != ROT_RECORDS) return;
+            const int b = L.cb_ptr[comp], e = L.cb_ptr[comp + 1];
+            if (b == e) return;
+            for (int i = b + tid; i < e; i += nt) store_rotation(P.x, L.cb[i], P.xrot);
+            __syncthreads();
+        }
     }
 
     template <bool SLOPE>
@@ -294,7 +350,9 @@ struct WgEnv {
         double af = 0.0, as = 0.0, dummy = 0.0;
         for (int j = tid; j < m; j += nt) {
             double fj, sj;
-            factor_value<KIND, SLOPE>(P, L.dir, fl[j], fj, sj);
+            if (KIND == KIND_BA && P.rot_mode == ROT_CAMFIX) factor_value<KIND, SLOPE, ROT_CAMFIX>(P, L.dir, fl[j], fj, sj);
+            else if (KIND == KIND_BA && P.rot_mode == ROT_RECORDS) factor_value<KIND, SLOPE, ROT_RECORDS>(P, L.dir, fl[j], fj, sj);
+            else factor_value<KIND, SLOPE>(P, L.dir, fl[j], fj, sj);
             af += fj;
             if constexpr (SLOPE) as += sj;
         }
@@ -332,7 +390,9 @@ struct WgEnv {
         assign_vec(p);
         for (int j = tid; j < m; j += nt) {
             const int fid = fl[j];
-            factor_partials<KIND>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
+            if (KIND == KIND_BA && P.rot_mode == ROT_CAMFIX) factor_partials<KIND, ROT_CAMFIX>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
+            else if (KIND == KIND_BA && P.rot_mode == ROT_RECORDS) factor_partials<KIND, ROT_RECORDS>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
+            else factor_partials<KIND>(P, L.gfac, L.slot_pos + L.slot_base[fac0 + j], fid);
         }
         __syncthreads();
         // variables fed by few partials: one lane each, in factor-list order (src/State.h:157-210);

@@ -58,7 +58,17 @@ def test_sum_gradient_and_per_factor_parity(name, gctx):
         scale = eo + np.sum(pp.obs ** 2, axis=1)
         assert np.all(np.abs(eg - eo) <= 1e-13 * scale)
         a, b = o.grad_each_ba(), g.grad_each_ba()
-        assert np.max(np.abs(a - b) / np.max(np.abs(a), axis=1, keepdims=True)) <= 1e-9
+        # 12 partials per factor: 1e-12 of the row's largest entry, or -- for the few badly conditioned
+        # rows (near-cancelling terms of the rotation derivative) -- a few times what one-ulp changes of
+        # the inputs do to the oracle's own row (up to 8e-9 on ladybug's factor 30771)
+        rng, allv, noise = np.random.default_rng(1), np.arange(pp.nvars, dtype=np.int64), np.zeros(len(a))
+        rowmax = np.max(np.abs(a), axis=1)
+        for _ in range(6):
+            o.assign(allv, pp.x0 * (1.0 + rng.choice([-1.0, 0.0, 1.0], pp.nvars) * 2.0 ** -52))
+            noise = np.maximum(noise, np.max(np.abs(a - o.grad_each_ba()), axis=1) / rowmax)
+        o.assign(allv, pp.x0)
+        dev = np.max(np.abs(a - b), axis=1) / rowmax
+        assert np.all(dev <= np.maximum(1e-12, 8.0 * noise)), (np.argmax(dev / np.maximum(1e-12, 8.0 * noise)), np.max(dev))
     else:
         assert np.max(np.abs(eg - eo)) <= 1e-13 * max(np.max(np.abs(eo)), 1.0)
 

