@@ -213,9 +213,11 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * first granule sweep), "force_stream" (send large components to the streaming grid solver even
  * when they fit the register-resident one; large components that do not fit, and large
  * nonlinear-product components, always go there),
- * "quad_max_vars" / "quad_min_components" (bundle-adjustment components with at most that many
- * free variables, default and maximum 4, are solved by groups of four lanes, sixteen per wave,
- * when the plan has at least that many of them, default 16384; 0 variables = never),
+ * "quad_max_vars" / "quad_min_components" / "row_min_components" (bundle-adjustment components
+ * with at most quad_max_vars free variables, default and maximum 4, are solved by groups of four
+ * lanes, sixteen per wave, when the plan has at least quad_min_components of them, default 16384;
+ * by groups of sixteen lanes from row_min_components, default 4096; below that by a workgroup
+ * each; 0 variables = never),
  * "camera_records" (bundle adjustment, batched launches: 1 = default -- when no camera variable is
  * free in the launch its factors read per-camera rotation records (angle, axis, sine, cosine,
  * computed once per camera) and form only the point partials; with free cameras and more than 2048

@@ -165,7 +165,9 @@ struct rdis_hip_plan {
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
     int coop_max_components = 8;      // ... for at most this many components per plan
-    int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad solver
+    int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
+    int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
+    int64_t row_min_components = 4096; // option: sixteen lanes each from this many tiny components (below: a workgroup each)
     int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
     int64_t quad_min_components = 16384;  // ... and only for at least this many tiny components
     int rest_rot_mode = ROT_PER_FACTOR; // how the factors of the batch list get their camera rotations (device_views.hpp)
@@ -811,6 +813,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "quad_min_components") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "quad_min_components < 0");
         L->quad_min_components = value;
+    } else if (n == "row_min_components") {
+        if (value < 0) return fail(c, RDIS_HIP_EINVAL, "row_min_components < 0");
+        L->row_min_components = value;
     } else if (n == "camera_records") {
         if (value < 0 || value > 2) return fail(c, RDIS_HIP_EINVAL, "camera_records must be 0, 1 or 2");
         L->camera_records = (int)value;
@@ -959,7 +964,8 @@ int prepare_partition(rdis_hip_plan* L) {
         int64_t ntiny = 0;
         for (int cc : L->h_rest) ntiny += tiny(cc) ? 1 : 0;
         L->rest_tiny = 0;
-        if (ntiny >= L->quad_min_components) {
+        L->tiny_group = ntiny >= L->quad_min_components ? 4 : ntiny >= L->row_min_components ? 16 : 0;
+        if (L->tiny_group != 0) {
             auto mid = std::stable_partition(L->h_rest.begin(), L->h_rest.end(), tiny);
             L->rest_tiny = (int)(mid - L->h_rest.begin());
         }
@@ -1048,8 +1054,12 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         ProblemView PV = p->view();
         PV.xrot = p->xrot.as<double>();
         PV.rot_mode = L->rest_rot_mode == ROT_CAMFIX ? ROT_CAMFIX : ROT_PER_FACTOR;   // (the quad solver has no refresh)
-        cgd_quad_kernel<<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, c->stream>>>(
-            PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
+        if (L->tiny_group == 4)
+            cgd_group_kernel<4, QUAD_THREADS><<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, c->stream>>>(
+                PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
+        else
+            cgd_group_kernel<16, 64><<<(L->rest_tiny + 3) / 4, 64, 0, c->stream>>>(
+                PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
         HIPCHK(c, hipGetLastError());
         ++L->last_launches;
     }

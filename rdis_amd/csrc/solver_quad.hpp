@@ -1,4 +1,5 @@
-// solver_quad.hpp -- four lanes solve one tiny component; sixteen components per wave.
+// solver_quad.hpp -- a few lanes solve one tiny component out of registers: four lanes each,
+// sixteen components per wave (many components), or one wave each (fewer, latency matters).
 //
 // With the cameras assigned, every point of a bundle-adjustment problem is a component of its
 // own: 3 free variables, 2..29 factors (SURVEY.md 3.2b -- by count this is what RDIS asks the
@@ -14,6 +15,14 @@
 //     steps it.  Groups of one wave are at different points of their solves: the wave runs the
 //     union of their paths under execution masks (run_machine with Env::UNIFORM = false).
 // Same CgdMachine, same requests, same trace records as the other solvers.
+//
+// GroupEnv<16> gives a component a DPP row of sixteen lanes (four machines per wave): between a
+// workgroup each and the quad solver when there are some thousands of components -- ladybug's
+// 7776 points: 2.05 ms against 2.46 (workgroups) and 2.9 (quads).  A whole wave per component out
+// of registers (G = 64, with each lane keeping its factor's constants for the whole solve) was
+// built and measured too: no better than a 64-lane workgroup (2.36 against 2.46 ms) -- a trial
+// point costs about 6000 cycles either way, most of it the control step and the reductions, and
+// with two waves per SIMD the vector unit is saturated by lanes that are mostly idle.
 #pragma once
 #include "solver_wg.hpp"
 
@@ -22,13 +31,23 @@ namespace rdis_hip {
 constexpr int QUAD_MAX_VARS = 4;
 constexpr int QUAD_THREADS = 256;   // 64 groups per workgroup
 
-__device__ __forceinline__ double quad_sum(double v) {
-    v += dpp_move<DPP_XOR1>(v);
-    v += dpp_move<DPP_XOR2>(v);
-    return v;
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    if constexpr (G == 4) {
+        v += dpp_move<DPP_XOR1>(v);
+        v += dpp_move<DPP_XOR2>(v);
+        return v;
+    } else {   // 16: one DPP row
+        v += dpp_move<DPP_XOR1>(v);
+        v += dpp_move<DPP_XOR2>(v);
+        v += dpp_move<DPP_HALF_MIRROR>(v);
+        v += dpp_move<DPP_MIRROR>(v);
+        return v;
+    }
 }
 
-struct QuadEnv {
+template <int G>   // lanes per component: 4 or 16
+struct GroupEnv {
     static constexpr bool UNIFORM = false;
     const ProblemView& P;
     const PlanView& L;
@@ -60,7 +79,7 @@ struct QuadEnv {
     __device__ void eval_at(double& f, double& s) {
         double af = 0.0, as = 0.0;
         if (P.rot_mode == ROT_CAMFIX) {   // cameras constant in this launch: rotation records, point partials only
-            for (int j = sub; j < m; j += 4) {
+            for (int j = sub; j < m; j += G) {
                 const int fid = L.fac_id[c0 + j];
                 const int c = P.cam[fid], q = P.pt[fid];
                 const double2 o = P.obs[fid];
@@ -91,11 +110,11 @@ struct QuadEnv {
                     as += acc;
                 }
             }
-            f = quad_sum(af);
-            s = SLOPE ? quad_sum(as) : 0.0;
+            f = group_sum<G>(af);
+            s = SLOPE ? group_sum<G>(as) : 0.0;
             return;
         }
-        for (int j = sub; j < m; j += 4) {
+        for (int j = sub; j < m; j += G) {
             const int fid = L.fac_id[c0 + j];
             const int c = P.cam[fid], q = P.pt[fid];
             const double2 o = P.obs[fid];
@@ -122,8 +141,8 @@ struct QuadEnv {
                 af += ba_eval(v, o.x, o.y);
             }
         }
-        f = quad_sum(af);
-        s = SLOPE ? quad_sum(as) : 0.0;
+        f = group_sum<G>(af);
+        s = SLOPE ? group_sum<G>(as) : 0.0;
     }
     __device__ void assign_line(double a) {
 #pragma clang fp contract(off)
@@ -154,7 +173,7 @@ struct QuadEnv {
 #pragma unroll
         for (int t = 0; t < QUAD_MAX_VARS; ++t) { xt[t] = clampd(p[t], lo[t], hi[t]); acc[t] = 0.0; }
         if (P.rot_mode == ROT_CAMFIX) {
-            for (int j = sub; j < m; j += 4) {
+            for (int j = sub; j < m; j += G) {
                 const int fid = L.fac_id[c0 + j];
                 const int c = P.cam[fid], q = P.pt[fid];
                 const double2 o = P.obs[fid];
@@ -185,10 +204,10 @@ struct QuadEnv {
                         if (li[k] == u) acc[u] += gg[9 + k];
             }
 #pragma unroll
-            for (int t = 0; t < QUAD_MAX_VARS; ++t) xi[t] = quad_sum(acc[t]);
+            for (int t = 0; t < QUAD_MAX_VARS; ++t) xi[t] = group_sum<G>(acc[t]);
             return;
         }
-        for (int j = sub; j < m; j += 4) {
+        for (int j = sub; j < m; j += G) {
             const int fid = L.fac_id[c0 + j];
             const int c = P.cam[fid], q = P.pt[fid];
             const double2 o = P.obs[fid];
@@ -213,7 +232,7 @@ struct QuadEnv {
                     if (li[k] == t) acc[t] += gg[k];
         }
 #pragma unroll
-        for (int t = 0; t < QUAD_MAX_VARS; ++t) xi[t] = quad_sum(acc[t]);
+        for (int t = 0; t < QUAD_MAX_VARS; ++t) xi[t] = group_sum<G>(acc[t]);
     }
     __device__ void cg_start() {
 #pragma unroll
@@ -259,19 +278,20 @@ struct QuadEnv {
 };
 
 // list[0 .. ncomp): the components of this launch (each with at most QUAD_MAX_VARS free variables)
-__global__ void __launch_bounds__(QUAD_THREADS)
-cgd_quad_kernel(ProblemView P, PlanView L, const int* __restrict__ list, int ncomp, int maxiters, double ftol) {
-    __shared__ CgdMachine Ms[QUAD_THREADS / 4];
-    __shared__ Request Qs[QUAD_THREADS / 4][2];
-    const int grp = threadIdx.x >> 2;
-    const int ci = blockIdx.x * (QUAD_THREADS / 4) + grp;
+template <int G, int THREADS>
+__global__ void __launch_bounds__(THREADS, G == 4 ? 1 : 2)
+cgd_group_kernel(ProblemView P, PlanView L, const int* __restrict__ list, int ncomp, int maxiters, double ftol) {
+    __shared__ CgdMachine Ms[THREADS / G];
+    __shared__ Request Qs[THREADS / G][2];
+    const int grp = threadIdx.x / G;
+    const int ci = blockIdx.x * (THREADS / G) + grp;
     const bool active = ci < ncomp;
     const int comp = list[active ? ci : 0];
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
-    QuadEnv E{P, L, comp, n, m, f0, c0, (int)(threadIdx.x & 3), active && m > 0,
-              {}, {}, {}, {}, {}, {}, {}, {}, {},
-              L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
+    GroupEnv<G> E{P, L, comp, n, m, f0, c0, (int)(threadIdx.x % G), active && m > 0,
+                  {}, {}, {}, {}, {}, {}, {}, {}, {},
+                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
 #pragma unroll
     for (int t = 0; t < QUAD_MAX_VARS; ++t) {
         const bool in = t < n;

@@ -396,7 +396,7 @@ def test_cooperative_exchange_is_bit_reproducible(gctx):
 
 
 def test_quad_solver_point_components(gctx):
-    """four lanes per tiny component, sixteen machines per wave (solver_quad.hpp), forced on for
+    """four (or sixteen) lanes per tiny component, sixteen (four) machines per wave (solver_quad.hpp), forced on for
     ladybug's point components: same contract, members replay against the oracle, empty and
     single-factor components included"""
     pp = P.load_bal(ncams=49, npts=700)
@@ -405,10 +405,11 @@ def test_quad_solver_point_components(gctx):
     comps = g.components(a)
     free_ptr, free_vid, fac_ptr, fac_id = comps
     results = {}
-    for quad in (1, 0):
+    for quad in (4, 16, 0):                       # lanes per component; 0: a workgroup each
         g.set_x(pp.x0)
         plan = capi.Plan(g, *comps)
-        plan.set_option("quad_min_components", 1 if quad else 1 << 40)
+        plan.set_option("quad_min_components", 1 if quad == 4 else 1 << 40)
+        plan.set_option("row_min_components", 1 if quad == 16 else 1 << 40)
         plan.set_option("trace_records", 2048)
         plan.set_option("dump_iters", 25)
         plan.set_start(None)
@@ -417,7 +418,7 @@ def test_quad_solver_point_components(gctx):
         results[quad] = r
         if not quad:
             continue
-        assert plan.last_kernel_ms()[1] == 1                                 # one launch, the quad kernel
+        assert plan.last_kernel_ms()[1] == 1                                 # one launch, the group kernel
         assert np.all(r.delta <= 0) and np.all((r.status & 0xFF) != 5)
         new_obj = g.eval()
         assert abs(new_obj - np.sum(r.fret)) <= 1e-12 * new_obj              # every factor in exactly one component
@@ -432,7 +433,11 @@ def test_quad_solver_point_components(gctx):
             assert rep.max_f_rel_near <= 1e-11 and rep.max_slope_rel_near <= 1e-11 and rep.fret == r.fret[c], (c, rep)
             assert rep.iters == r.iters[c] and rep.reason == (r.status[c] & 0xFF)
     # against one workgroup per component: same algorithm, sums in a different order
-    rq, rw = results[1], results[0]
+    for lanes in (4, 16):
+        _agree(results[lanes], results[0])
+
+
+def _agree(rq, rw):
     assert np.array_equal(rq.status & 0xFF, rw.status & 0xFF) or np.mean((rq.status & 0xFF) == (rw.status & 0xFF)) > 0.98
     conv = ((rq.status & 0xFF) != 3) & ((rw.status & 0xFF) != 3)
     dev = np.abs(rq.fret[conv] - rw.fret[conv]) / (1.0 + np.abs(rw.fret[conv]))
@@ -477,8 +482,8 @@ def test_quad_solver_partial_blocks_and_active_bounds(gctx):
             assert rep.fret == r.fret[c], (c, rep)
 
 
-@pytest.mark.parametrize("quad", [0, 1])
-def test_camera_rotation_records_change_nothing(gctx, quad):
+@pytest.mark.parametrize("solver", ["workgroup", "row", "quad"])
+def test_camera_rotation_records_change_nothing(gctx, solver):
     """launches whose components leave every camera constant read per-camera rotation records
     (camera_rotations_kernel) instead of redoing the angle / axis / sine / cosine per factor and
     trial point: the arithmetic is the same, so every output is bit-identical with the records off"""
@@ -490,7 +495,8 @@ def test_camera_rotation_records_change_nothing(gctx, quad):
     for rec in (1, 0):
         g.set_x(pp.x0)
         plan = capi.Plan(g, *comps)
-        plan.set_option("quad_min_components", 1 if quad else 1 << 40)
+        plan.set_option("quad_min_components", 1 if solver == "quad" else 1 << 40)
+        plan.set_option("row_min_components", 1 if solver == "row" else 1 << 40)
         plan.set_option("camera_records", rec)
         plan.set_option("trace_records", 1024)
         plan.set_start(None)

@@ -25,7 +25,8 @@ def run(name, g, pp, comps, opts, reps=3):
 pp = P.load_bal()
 g = capi.Problem(ctx, pp)
 cams, pts = P.ba_alternation_plans(pp)
-run("ladybug points", g, pp, pts, {"quad_min_components": 1 << 40})
+run("ladybug points", g, pp, pts, {"quad_min_components": 1 << 40, "row_min_components": 1 << 40})
+run("ladybug points", g, pp, pts, {"quad_min_components": 1 << 40, "row_min_components": 1})
 run("ladybug points", g, pp, pts, {"quad_min_components": 1})
 run("ladybug cameras", g, pp, cams, {})
 g.close()
@@ -38,7 +39,8 @@ for nblk in (4, 64):
     g = capi.Problem(ctx, pp)
     a = np.zeros(pp.nvars, np.uint8); a[np.arange(pp.nvars) % 23769 < 441] = 1
     comps = g.components(a)
-    run("synthetic x%d points" % nblk, g, pp, comps, {"quad_min_components": 1 << 40})
+    run("synthetic x%d points" % nblk, g, pp, comps, {"quad_min_components": 1 << 40, "row_min_components": 1 << 40})
+    run("synthetic x%d points" % nblk, g, pp, comps, {"quad_min_components": 1 << 40, "row_min_components": 1})
     run("synthetic x%d points" % nblk, g, pp, comps, {"quad_min_components": 1})
     if nblk == 64:
         g.set_x(pp.x0)
