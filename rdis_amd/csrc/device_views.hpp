@@ -63,6 +63,7 @@ struct PlanView {
     const int* slot_base; // [nfac_total + 1] first slot of each LISTED factor (plan-local: 12 per BA factor, arity per NLP factor)
     const int* cb_ptr;    // [ncomp + 1] ...
     const int* cb;        // ... camera blocks (first variable id) with a free rotation variable, per component
+    const int* cb_li;     // [3 per block] local index of the block's three rotation variables, -1 = constant
     const int* slot_pos;  // [slot_base[nfac_total]] listed factor's slot -> position in gfac (variable-major), -1 = not a free variable
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

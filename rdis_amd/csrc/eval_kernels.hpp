@@ -37,7 +37,8 @@ camera_rotations_kernel(const double* __restrict__ x, const int* __restrict__ ca
                         double* __restrict__ xrot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
-    store_rotation(x, cam_blocks[i], xrot);
+    const int c = cam_blocks[i];
+    store_rotation(x[c], x[c + 1], x[c + 2], xrot + c);
 }
 
 __global__ void __launch_bounds__(256)

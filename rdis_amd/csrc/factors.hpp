@@ -114,10 +114,9 @@ __device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, d
 // Rotation record of a camera block as camera_rotations_kernel leaves it: seven doubles at the
 // block's first variable id in a shadow array of x.
 constexpr int ROT_V0 = 0, ROT_THETA = 3, ROT_ITHETA = 4, ROT_SIN = 5, ROT_COS = 6;
-__device__ __forceinline__ void store_rotation(const double* __restrict__ x, int c, double* __restrict__ xrot) {
+__device__ __forceinline__ void store_rotation(double r0, double r1, double r2, double* __restrict__ r) {
     BaFwd t;
-    ba_rotation(x[c], x[c + 1], x[c + 2], t);
-    double* r = xrot + c;
+    ba_rotation(r0, r1, r2, t);
     r[ROT_V0] = t.v0; r[ROT_V0 + 1] = t.v1; r[ROT_V0 + 2] = t.v2;
     r[ROT_THETA] = t.theta; r[ROT_ITHETA] = t.itheta; r[ROT_SIN] = t.s; r[ROT_COS] = t.c;
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -172,7 +173,7 @@ struct rdis_hip_plan {
     int64_t quad_min_components = 16384;  // ... and only for at least this many tiny components
     int rest_rot_mode = ROT_PER_FACTOR; // how the factors of the batch list get their camera rotations (device_views.hpp)
     int camera_records = 1;           // option "camera_records": 0 = every factor forms its rotation itself, 1 = auto, 2 = records wherever possible
-    size_t off_cb_ptr = 0, off_cb = 0;
+    size_t off_cb_ptr = 0, off_cb = 0, off_cb_li = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
@@ -190,7 +191,7 @@ struct rdis_hip_plan {
         v.free_ptr = ip(off_free_ptr); v.free_vid = ip(off_free_vid);
         v.fac_ptr = ip(off_fac_ptr); v.fac_id = ip(off_fac_id);
         v.v2s_ptr = ip(off_v2s_ptr); v.slot_base = ip(off_slot_base); v.slot_pos = ip(off_slot_pos);
-        v.cb_ptr = ip(off_cb_ptr); v.cb = ip(off_cb);
+        v.cb_ptr = ip(off_cb_ptr); v.cb = ip(off_cb); v.cb_li = ip(off_cb_li);
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
         v.xout = out_f64(0);
@@ -721,21 +722,30 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     L->off_free_ptr = put(L->h_free_ptr); L->off_free_vid = put(L->h_free_vid);
     L->off_fac_ptr = put(L->h_fac_ptr); L->off_fac_id = put(L->h_fac_id);
     L->off_v2s_ptr = put(v2s_ptr); L->off_slot_base = put(slot_base); L->off_slot_pos = put(slot_pos);
-    {   // per component: the camera blocks with a free rotation variable (their records follow the trial point)
-        std::vector<int> cb_ptr((size_t)ncomp + 1, 0), cb;
-        if (p->kind == KIND_BA && p->ncam_blocks > 0)
+    {   // per component: the camera blocks with a free rotation variable (their records follow the trial
+        // point) and where in the component's vectors their three rotation variables are (-1: constant)
+        std::vector<int> cb_ptr((size_t)ncomp + 1, 0), cb, cb_li;
+        if (p->kind == KIND_BA && p->ncam_blocks > 0) {
+            std::vector<std::array<int, 3>> ent;   // (block, which of the three, local index)
             for (int64_t cc = 0; cc < ncomp; ++cc) {
-                const size_t first = cb.size();
+                ent.clear();
                 for (int64_t i = free_ptr[cc]; i < free_ptr[cc + 1]; ++i) {
                     const int v = L->h_free_vid[(size_t)i], b = p->h_block_of[(size_t)v];
-                    if (b < 0) continue;
-                    if (v - b < 3) cb.push_back(b);
+                    if (b >= 0 && v - b < 3) ent.push_back({b, v - b, (int)(i - free_ptr[cc])});
                 }
-                std::sort(cb.begin() + (long)first, cb.end());
-                cb.erase(std::unique(cb.begin() + (long)first, cb.end()), cb.end());
+                std::sort(ent.begin(), ent.end());
+                for (const auto& e : ent) {
+                    if (cb.size() == (size_t)cb_ptr[(size_t)cc] || cb.back() != e[0]) {
+                        cb.push_back(e[0]);
+                        cb_li.insert(cb_li.end(), {-1, -1, -1});
+                    }
+                    cb_li[cb_li.size() - 3 + (size_t)e[1]] = e[2];
+                }
                 cb_ptr[(size_t)cc + 1] = (int)cb.size();
             }
-        L->off_cb_ptr = put(cb_ptr); L->off_cb = put(cb);
+        }
+        for (int64_t cc = 0; cc < ncomp; ++cc) cb_ptr[(size_t)cc + 1] = std::max(cb_ptr[(size_t)cc + 1], cb_ptr[(size_t)cc]);
+        L->off_cb_ptr = put(cb_ptr); L->off_cb = put(cb); L->off_cb_li = put(cb_li);
     }
 
     const size_t nc = (size_t)ncomp;
@@ -978,10 +988,10 @@ int prepare_partition(rdis_hip_plan* L) {
             for (int k = L->h_free_ptr[(size_t)cc]; k < L->h_free_ptr[(size_t)cc + 1] && camfix; ++k)
                 camfix = p->h_block_of[(size_t)L->h_free_vid[(size_t)k]] < 0;
         }
-        // Free cameras: rewriting their records at every trial point costs a barrier and one lane's
-        // rotation latency per evaluation, and saves the rotation in every factor -- a gain only where a
-        // lane has many factors per camera (64 components of 31843 factors: 70 against 76 ms; ladybug's
-        // 49 camera components 6.9 against 6.5 ms, 1000 small components 2.2 against 2.0 ms).
+        // Free cameras: rewriting their records at every trial point puts one lane's rotation latency in
+        // front of the evaluation and takes the rotation out of every factor -- a gain only where a lane
+        // has many factors per camera (64 components of 31843 factors: 74 against 79 ms; no difference
+        // for ladybug's 49 camera components or 1000 small components).
         int64_t mf = 0;
         for (int cc : L->h_rest) mf = std::max<int64_t>(mf, L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc]);
         L->rest_rot_mode = camfix ? ROT_CAMFIX : (L->camera_records == 2 || mf > 2048) ? ROT_RECORDS : ROT_PER_FACTOR;

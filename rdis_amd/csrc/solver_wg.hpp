@@ -268,6 +268,28 @@ __device__ __forceinline__ void factor_partials(const ProblemView& P, double* __
     }
 }
 
+// With ROT_RECORDS a component rewrites the rotation records of its free cameras whenever it
+// assigns a point: lanes first, first + stride, ... take a camera each and form its three rotation
+// variables the way the assignment does (at(i): the clamped value given to free variable i; a
+// constant where the index is negative) -- no need to wait for x, the records become visible with it.
+// (at() reads vector entries other lanes wrote: the caller's vector updates end with a barrier.  The
+// streaming grid solver has none there -- and measured only 2.5 % with records -- so it forms its
+// rotations per factor.)
+template <class At>
+__device__ __forceinline__ void refresh_rotation_records(const ProblemView& P, const PlanView& L, int comp,
+                                                         int first, int stride, At at) {
+    if (P.rot_mode != ROT_RECORDS) return;
+    const int b = L.cb_ptr[comp], e = L.cb_ptr[comp + 1];
+    for (int i = b + first; i < e; i += stride) {
+        const int c = L.cb[i];
+        const int* li = L.cb_li + 3 * i;
+        double r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = li[k] >= 0 ? at(li[k]) : P.x[c + k];
+        store_rotation(r[0], r[1], r[2], P.xrot + c);
+    }
+}
+
 // ---- the single-workgroup environment ---------------------------------------------
 template <int KIND>
 struct WgEnv {
@@ -323,26 +345,23 @@ struct WgEnv {
             const double t = a * xi[i];
             P.x[v] = clampd(p[i] + t, P.lo[v], P.hi[v]);
         }
+        if constexpr (KIND == KIND_BA)
+            refresh_rotation_records(P, L, comp, tid, nt, [&](int i) {
+#pragma clang fp contract(off)
+                const int v = fv[i];
+                const double t = a * xi[i];
+                return clampd(p[i] + t, P.lo[v], P.hi[v]);
+            });
         __syncthreads();
-        refresh_rotations();
     }
     __device__ void assign_vec(const double* src) {
         for (int i = tid; i < n; i += nt) {
             const int v = fv[i];
             P.x[v] = clampd(src[i], P.lo[v], P.hi[v]);
         }
+        if constexpr (KIND == KIND_BA)
+            refresh_rotation_records(P, L, comp, tid, nt, [&](int i) { const int v = fv[i]; return clampd(src[i], P.lo[v], P.hi[v]); });
         __syncthreads();
-        refresh_rotations();
-    }
-    // the rotation records of this component's free cameras at the point just assigned
-    __device__ void refresh_rotations() {
-        if constexpr (KIND == KIND_BA) {
-            if (P.rot_mode != ROT_RECORDS) return;
-            const int b = L.cb_ptr[comp], e = L.cb_ptr[comp + 1];
-            if (b == e) return;
-            for (int i = b + tid; i < e; i += nt) store_rotation(P.x, L.cb[i], P.xrot);
-            __syncthreads();
-        }
     }
 
     template <bool SLOPE>

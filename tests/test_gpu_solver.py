@@ -539,14 +539,16 @@ def test_camera_rotation_records_with_free_cameras(gctx):
     cams, _ = P.ba_alternation_plans(lb)
     rot_only = (np.arange(0, 3 * 49 + 1, 3), np.concatenate([np.arange(9 * c, 9 * c + 3) for c in range(49)]),
                 cams[2], cams[3])
-    for prob, comps in ((pp, whole), (lb, cams), (lb, rot_only)):
+    for prob, comps, opts in ((pp, whole, {"coop_min_factors": 0}), (lb, cams, {"coop_min_factors": 0}),
+                              (lb, rot_only, {"coop_min_factors": 0})):
         g = capi.Problem(gctx, prob)
         out = {}
         for rec in (2, 0):
             g.set_x(prob.x0)
             plan = capi.Plan(g, *comps)
             plan.set_option("camera_records", rec)
-            plan.set_option("coop_min_factors", 0)
+            for k, v in opts.items():
+                plan.set_option(k, v)
             plan.set_option("trace_records", 1024)
             plan.set_start(None)
             plan.solve(12, 3e-8)
