@@ -224,6 +224,8 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * factors in a component the component rewrites the records of its cameras at every trial point;
  * 2 = records wherever possible; 0 = every factor forms its camera's rotation itself.  Results
  * are bit-identical in all three settings),
+ * "overlap_batch" (default 1: the batched launch of a plan runs on a second stream, concurrently
+ * with its cooperative launches),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

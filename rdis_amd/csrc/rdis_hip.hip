@@ -29,6 +29,9 @@ struct rdis_hip_ctx {
     bool own_stream = false;
     int num_cus = 0;
     std::string err;
+    // second stream for the batched launch of a plan that also has cooperative launches (they overlap)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -172,6 +175,7 @@ struct rdis_hip_plan {
     int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
     int64_t quad_min_components = 16384;  // ... and only for at least this many tiny components
     int rest_rot_mode = ROT_PER_FACTOR; // how the factors of the batch list get their camera rotations (device_views.hpp)
+    int overlap_batch = 1;            // option: run the batched launch concurrently with cooperative launches
     int camera_records = 1;           // option "camera_records": 0 = every factor forms its rotation itself, 1 = auto, 2 = records wherever possible
     size_t off_cb_ptr = 0, off_cb = 0, off_cb_li = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
@@ -243,6 +247,9 @@ extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
 extern "C" void rdis_hip_destroy(rdis_hip_ctx* c) {
     if (!c) return;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -823,6 +830,8 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "quad_min_components") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "quad_min_components < 0");
         L->quad_min_components = value;
+    } else if (n == "overlap_batch") {
+        L->overlap_batch = value != 0;
     } else if (n == "row_min_components") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "row_min_components < 0");
         L->row_min_components = value;
@@ -1005,19 +1014,19 @@ int prepare_partition(rdis_hip_plan* L) {
 }
 
 template <int KIND>
-int launch_wg(rdis_hip_plan* L, int threads, int first, int grid, int maxiters, double ftol) {
+int launch_wg(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;
     ProblemView P = L->prob->view();
     P.xrot = L->prob->xrot.as<double>(); P.rot_mode = L->rest_rot_mode;
     PlanView V = L->view();
     V.order += first;   // components [first, first + grid) of the batch list
     switch (threads) {
-        case 64: cgd_wg_kernel<KIND, 64><<<grid, 64, 0, c->stream>>>(P, V, maxiters, ftol); break;
-        case 128: cgd_wg_kernel<KIND, 128><<<grid, 128, 0, c->stream>>>(P, V, maxiters, ftol); break;
-        case 256: cgd_wg_kernel<KIND, 256><<<grid, 256, 0, c->stream>>>(P, V, maxiters, ftol); break;
-        case 512: cgd_wg_kernel<KIND, 512><<<grid, 512, 0, c->stream>>>(P, V, maxiters, ftol); break;
-        case 768: cgd_wg_kernel<KIND, 768><<<grid, 768, 0, c->stream>>>(P, V, maxiters, ftol); break;
-        default: cgd_wg_kernel<KIND, 1024><<<grid, 1024, 0, c->stream>>>(P, V, maxiters, ftol); break;
+        case 64: cgd_wg_kernel<KIND, 64><<<grid, 64, 0, stream>>>(P, V, maxiters, ftol); break;
+        case 128: cgd_wg_kernel<KIND, 128><<<grid, 128, 0, stream>>>(P, V, maxiters, ftol); break;
+        case 256: cgd_wg_kernel<KIND, 256><<<grid, 256, 0, stream>>>(P, V, maxiters, ftol); break;
+        case 512: cgd_wg_kernel<KIND, 512><<<grid, 512, 0, stream>>>(P, V, maxiters, ftol); break;
+        case 768: cgd_wg_kernel<KIND, 768><<<grid, 768, 0, stream>>>(P, V, maxiters, ftol); break;
+        default: cgd_wg_kernel<KIND, 1024><<<grid, 1024, 0, stream>>>(P, V, maxiters, ftol); break;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1039,6 +1048,22 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
     PlanView V = L->view();
     HIPCHK(c, hipEventRecord(p->ev0, c->stream));
+    // The batched launch is independent of the cooperative ones (disjoint components): it goes to a
+    // second stream and fills the CUs the few workgroups of a cooperative solve leave idle.  The
+    // cooperative kernels are enqueued first, so their workgroups are resident before the batch arrives.
+    // (not next to a streaming solve: that grid takes every CU and waits for all of its workgroups)
+    const bool overlap = L->overlap_batch && !L->h_rest.empty() && !L->coop.empty() && L->stream.empty();
+    hipStream_t bs = c->stream;
+    if (overlap) {
+        if (!c->aux) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        bs = c->aux;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(bs, c->ev_fork, 0));
+    }
     for (size_t i = 0; i < L->coop.size(); ++i) {
         const CoopItem& it = L->coop[i];
         CoopArgs ca{p->coop_timing.as<long long>(), p->coop_state.as<CoopState>(), it.slot_li.as<int>(),
@@ -1055,8 +1080,8 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
-    if (L->rest_rot_mode != ROT_PER_FACTOR) {   // after the launches above, which may have moved cameras
-        camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, c->stream>>>(
+    if (L->rest_rot_mode != ROT_PER_FACTOR) {   // (cameras the batch reads are not free in the launches above)
+        camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, bs>>>(
             p->x.as<double>(), p->cam_blocks.as<int>(), (int)p->ncam_blocks, p->xrot.as<double>());
         HIPCHK(c, hipGetLastError());
     }
@@ -1065,10 +1090,10 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         PV.xrot = p->xrot.as<double>();
         PV.rot_mode = L->rest_rot_mode == ROT_CAMFIX ? ROT_CAMFIX : ROT_PER_FACTOR;   // (the quad solver has no refresh)
         if (L->tiny_group == 4)
-            cgd_group_kernel<4, QUAD_THREADS><<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, c->stream>>>(
+            cgd_group_kernel<4, QUAD_THREADS><<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, bs>>>(
                 PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
         else
-            cgd_group_kernel<16, 64><<<(L->rest_tiny + 3) / 4, 64, 0, c->stream>>>(
+            cgd_group_kernel<16, 64><<<(L->rest_tiny + 3) / 4, 64, 0, bs>>>(
                 PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
         HIPCHK(c, hipGetLastError());
         ++L->last_launches;
@@ -1086,10 +1111,14 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         // two waves at 250 and four at 128 (heavy spills): +20 % / +40 % throughput on large components,
         // and 5 % on the 361..906-factor camera components of ladybug.
         if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : mf <= 512 ? 512 : 768;
-        int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, threads, L->rest_tiny, rest, maxiters, ftol)
-                                    : launch_wg<KIND_NLP>(L, threads, L->rest_tiny, rest, maxiters, ftol);
+        int rc = p->kind == KIND_BA ? launch_wg<KIND_BA>(L, bs, threads, L->rest_tiny, rest, maxiters, ftol)
+                                    : launch_wg<KIND_NLP>(L, bs, threads, L->rest_tiny, rest, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
+    }
+    if (overlap) {
+        HIPCHK(c, hipEventRecord(c->ev_join, bs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     HIPCHK(c, hipEventRecord(p->ev1, c->stream));
     L->timed = true;

@@ -34,11 +34,14 @@ print("    CPU oracle (dense gradient): %.2f s, fret %.6g" % (dto, ro.fret))
 a = np.zeros(pp.nvars, np.uint8); a[:9 * 46] = 1
 g.set_x(pp.x0)
 t = time.perf_counter(); comps = g.components(a); dtc = time.perf_counter() - t
-plan2 = capi.Plan(g, *comps)
-for rep in range(3):
-    g.set_x(pp.x0); plan2.set_start(None)
-    t = time.perf_counter(); plan2.solve(25, 3e-8); r2 = plan2.fetch(); dt = time.perf_counter() - t
-ms2, nl2 = plan2.last_kernel_ms()
 sizes = np.diff(comps[0])
-print("(ii+iii) 46 cameras fixed: %d components (labelling %.2f ms), largest %d vars / %d factors; solve kernel %.3f ms in %d launches, wall %.3f ms, sum f %.6g -> %.6g" % (
-    len(sizes), dtc * 1e3, sizes[-1], np.diff(comps[2])[-1], ms2, nl2, dt * 1e3, (r2.fret - r2.delta).sum(), r2.fret.sum()))
+for overlap in (0, 1):
+    plan2 = capi.Plan(g, *comps)
+    plan2.set_option("overlap_batch", overlap)
+    for rep in range(3):
+        g.set_x(pp.x0); plan2.set_start(None)
+        t = time.perf_counter(); plan2.solve(25, 3e-8); r2 = plan2.fetch(); dt = time.perf_counter() - t
+    ms2, nl2 = plan2.last_kernel_ms()
+    print("(ii+iii) 46 cameras fixed: %d components (labelling %.2f ms), largest %d vars / %d factors; overlap %d: solve kernel %.3f ms in %d launches, wall %.3f ms, sum f %.6g -> %.9g" % (
+        len(sizes), dtc * 1e3, sizes[-1], np.diff(comps[2])[-1], overlap, ms2, nl2, dt * 1e3, (r2.fret - r2.delta).sum(), r2.fret.sum()))
+    plan2.close()

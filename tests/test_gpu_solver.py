@@ -559,3 +559,27 @@ def test_camera_rotation_records_with_free_cameras(gctx):
         assert np.array_equal(r2.iters, r0.iters) and np.array_equal(r2.nfeval, r0.nfeval) and np.array_equal(r2.status, r0.status)
         assert n2 == n0 and np.array_equal(t2[:n2], t0[:n0])
         g.close()
+
+
+def test_batched_launch_overlaps_cooperative_launches(gctx):
+    """a plan with both kinds of components runs its batched launch on a second stream next to
+    the cooperative ones (disjoint components): same results as one after the other"""
+    pp = P.load_bal(ncams=49, npts=1500)
+    g = capi.Problem(gctx, pp)
+    a = np.zeros(pp.nvars, np.uint8); a[:9 * 46] = 1            # 3 cameras stay free: one large component + single points
+    comps = g.components(a)
+    assert np.diff(comps[2]).max() > 1000 and len(comps[0]) - 1 > 500
+    out = {}
+    for overlap in (1, 0):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *comps)
+        plan.set_option("coop_min_factors", 1000)
+        plan.set_option("overlap_batch", overlap)
+        plan.set_start(None)
+        plan.solve(25, 3e-8)
+        out[overlap] = (plan.fetch(), g.get_x(), plan.last_kernel_ms()[1])
+        plan.close()
+    (r1, x1, n1), (r0, x0, n0) = out[1], out[0]
+    assert n1 == n0 == 2                                         # one cooperative launch, one batched launch
+    assert np.array_equal(r1.fret, r0.fret) and np.array_equal(r1.x, r0.x) and np.array_equal(x1, x0)
+    assert np.array_equal(r1.iters, r0.iters) and np.array_equal(r1.status, r0.status) and np.all((r1.status & 0xFF) != 5)
