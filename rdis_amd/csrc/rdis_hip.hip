@@ -134,9 +134,15 @@ struct rdis_hip_problem {
 
 struct CoopItem {
     int comp = 0, nwg = 0;
+    size_t xi_off = 0;  // where its published search direction starts in the plan's xi_glob
     DevBuf slot_li;   // [12 * m] local free index of each factor slot, -1 = constant
     DevBuf lane_var;  // [nwg * threads] free variable owned by a lane, -1 = none
     DevBuf wave_var;  // [nwg * threads / 64] free variable owned by a whole wave, -1 = none
+};
+
+struct CoopLaunch {      // cooperative groups that run side by side in one launch
+    int first = 0, count = 0, total_wg = 0;   // items [first, first + count) of the plan's list
+    DevBuf groups, wg_group;
 };
 
 struct StreamItem {
@@ -162,13 +168,16 @@ struct rdis_hip_plan {
     // which components go where (rebuilt when an option changes)
     bool partition_dirty = true;
     std::vector<CoopItem> coop;
+    std::vector<CoopLaunch> coop_launches;
+    std::vector<std::vector<CoopGroup>> h_coop_groups;
     std::vector<StreamItem> stream;
     std::vector<int> h_rest;
     DevBuf rest_order, xi_glob;
     // options
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
-    int coop_max_components = 8;      // ... for at most this many components per plan
+    int coop_max_components = 8;      // ... for at most this many components per plan; or ...
+    int64_t coop_group_min_factors = 256;  // ... for every component of at least this many factors when all their groups fit the device at once
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
     int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
     int64_t row_min_components = 4096; // option: sixteen lanes each from this many tiny components (below: a workgroup each)
@@ -767,6 +776,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         need += align_up((size_t)nfree * 4, 256) + 8 * 256;                                      // long_vars of streaming components
         need += (size_t)std::min<int64_t>(ncomp, 8) * (align_up(lanes_max * 4, 256) + align_up(lanes_max / 64 * 4, 256));
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
+        need += (size_t)COOP_MAX_GROUPS * (4 * 256 + sizeof(CoopGroup)) + (size_t)COOP_MAX_WG * 4 + lanes_max * 4 + 64 * 256;  // groups, their alignment slack
         if (p->arena.bytes < need) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             rc = dalloc(c, p->arena, std::max(need, 2 * p->arena.bytes));
@@ -830,6 +840,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "quad_min_components") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "quad_min_components < 0");
         L->quad_min_components = value;
+    } else if (n == "coop_group_min_factors") {
+        if (value < 0) return fail(c, RDIS_HIP_EINVAL, "coop_group_min_factors < 0");
+        L->coop_group_min_factors = value;
     } else if (n == "overlap_batch") {
         L->overlap_batch = value != 0;
     } else if (n == "row_min_components") {
@@ -885,28 +898,59 @@ int prepare_partition(rdis_hip_plan* L) {
     rdis_hip_ctx* c = L->prob->ctx;
     rdis_hip_problem* p = L->prob;
     L->coop.clear();
+    L->coop_launches.clear();
+    L->h_coop_groups.clear();
     L->stream.clear();
     L->h_rest.clear();
     int cap = 0, scap = 0;
     // The grid solvers are for a few large components that would leave the device idle as single
     // workgroups, one launch each.  When there are more large components than that, the batch
     // kernel fills the device by itself (one workgroup per component) and is the better fit.
+    const int wpw = L->coop_threads / 64;
+    auto groups_of = [&](int cc) {   // workgroups of a component's cooperative group: a lane per factor / variable, a wave per long gradient run
+        const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
+        const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
+        const int f0 = L->h_free_ptr[(size_t)cc];
+        int64_t nlong = 0;
+        for (int64_t i = 0; i < n; ++i)
+            if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) ++nlong;
+        const int64_t need = (std::max(m, n) + L->coop_threads - 1) / L->coop_threads;
+        // (small groups only: a large one has its waves anyway, and more workgroups lengthen every sweep)
+        const int64_t for_long = need < 16 ? std::min<int64_t>((nlong + wpw - 1) / wpw, 2 * need + 2) : 0;
+        return std::max<int64_t>(1, std::max(need, for_long));
+    };
     int64_t nbig = 0;
     for (int64_t cc = 0; cc < L->ncomp; ++cc)
         if (L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc] >= L->coop_min_factors) ++nbig;
-    const bool any_big = L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors &&
-                         nbig <= L->coop_max_components;
-    if (any_big && p->kind == KIND_BA) cap = coop_max_workgroups(L->coop_threads, c->num_cus);
+    bool any_big = L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors &&
+                   nbig <= L->coop_max_components;
+    const bool coop_on = L->coop_min_factors > 0 && L->coop_max_components > 0 && p->kind == KIND_BA && !L->force_stream;
+    if (coop_on) cap = coop_max_workgroups(L->coop_threads, c->num_cus);
+    if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
+    // Group mode: every component of some size gets a cooperative group when all the groups are
+    // resident at once -- a device that the batch kernel would leave mostly idle (49 camera components
+    // of ladybug: 6.6 ms as one workgroup each).  Otherwise only the few very large ones do.
+    int64_t group_min = INT64_MAX;
+    if (coop_on && cap > 0 && L->coop_group_min_factors > 0) {
+        int64_t total = 0, count = 0;
+        for (int cc : L->h_order) {
+            if (L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc] < L->coop_group_min_factors) break;   // heaviest first
+            total += groups_of(cc);
+            ++count;
+        }
+        if (count > 0 && total <= cap && count <= COOP_MAX_GROUPS) { group_min = L->coop_group_min_factors; any_big = true; }
+    }
     if (any_big) scap = stream_max_workgroups(p->kind, c->num_cus);
-    if (L->coop_workgroups > 0) { cap = std::min(cap, L->coop_workgroups); scap = std::min(scap, L->coop_workgroups); }
+    if (L->coop_workgroups > 0) scap = std::min(scap, L->coop_workgroups);
     int64_t max_n = 0;
     std::vector<int> blk_all;
     for (int cc : L->h_order) {  // heaviest first
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
-        const int64_t need = (std::max(m, n) + L->coop_threads - 1) / L->coop_threads;
-        const bool big = any_big && m >= L->coop_min_factors && (int)(L->coop.size() + L->stream.size()) < L->coop_max_components;
-        const bool take = big && cap > 0 && need <= cap && !L->force_stream;
+        const int64_t need = groups_of(cc);
+        const bool grouped = m >= group_min;
+        const bool big = any_big && (grouped || (m >= L->coop_min_factors && (int)(L->coop.size() + L->stream.size()) < L->coop_max_components));
+        const bool take = big && cap > 0 && need <= cap && coop_on;
         if (!take && big && scap > 0) {
             // too large for the register-resident solver (or not bundle adjustment): the streaming
             // grid solver; about two factors per lane and trial point, at most what is resident
@@ -931,7 +975,8 @@ int prepare_partition(rdis_hip_plan* L) {
         L->coop.emplace_back();
         CoopItem& it = L->coop.back();
         it.comp = cc;
-        it.nwg = (int)std::max<int64_t>(need, 1);
+        it.nwg = (int)need;
+        it.xi_off = (size_t)max_n;   // (max_n: running total of the cooperative components' variables)
         const int f0 = L->h_free_ptr[(size_t)cc], c0 = L->h_fac_ptr[(size_t)cc];
         // local free index of each factor slot (h_local is still valid for this plan's stamp only
         // while no other plan was created in between: rebuild it for the component)
@@ -968,7 +1013,7 @@ int prepare_partition(rdis_hip_plan* L) {
         HIPCHK(c, hipMemcpyAsync(it.lane_var.p, lane_var.data(), lane_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(it.wave_var.p, wave_var.data(), wave_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // locals
-        max_n = std::max(max_n, n);
+        max_n += n;
     }
     // tiny bundle-adjustment components (at most QUAD_MAX_VARS free variables: a point against fixed
     // cameras) go first in the batch list: four lanes each (solver_quad.hpp) instead of a workgroup
@@ -1008,6 +1053,45 @@ int prepare_partition(rdis_hip_plan* L) {
     int rc = plan_alloc(L, L->rest_order, std::max<size_t>(L->h_rest.size(), 1) * sizeof(int));
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
+    // cooperative groups, packed into launches of at most `cap` workgroups
+    L->coop_launches.clear();
+    size_t max_groups = 1;
+    for (size_t i = 0; i < L->coop.size();) {
+        CoopLaunch cl;
+        cl.first = (int)i;
+        std::vector<CoopGroup> hg;
+        std::vector<int> hw;
+        while (i < L->coop.size() && (cl.count == 0 || cl.total_wg + L->coop[i].nwg <= cap) && cl.count < COOP_MAX_GROUPS) {
+            const CoopItem& it = L->coop[i];
+            CoopGroup g{};
+            g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, it.slot_li.as<int>(),
+                           it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>() + it.xi_off, it.comp, L->coop_poll_delay};
+            g.wg0 = cl.total_wg; g.nwg = it.nwg;
+            hg.push_back(g);
+            hw.insert(hw.end(), (size_t)it.nwg, cl.count);
+            cl.total_wg += it.nwg; ++cl.count; ++i;
+        }
+        max_groups = std::max(max_groups, hg.size());
+        if (p->coop_state.bytes < max_groups * sizeof(CoopState)) {   // one exchange state per concurrent group
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rc = dalloc(c, p->coop_state, max_groups * sizeof(CoopState));
+            if (rc) return rc;
+        }
+        rc = plan_alloc(L, cl.groups, hg.size() * sizeof(CoopGroup));
+        if (!rc) rc = plan_alloc(L, cl.wg_group, hw.size() * sizeof(int));
+        if (rc) return rc;
+        L->coop_launches.push_back(std::move(cl));
+        L->h_coop_groups.push_back(std::move(hg));
+        HIPCHK(c, hipMemcpyAsync(L->coop_launches.back().wg_group.p, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // hw is a local
+    }
+    // (the state pointers only now: the buffer may have moved while the launches were sized)
+    for (size_t l = 0; l < L->coop_launches.size(); ++l) {
+        std::vector<CoopGroup>& hg = L->h_coop_groups[l];
+        for (size_t g = 0; g < hg.size(); ++g) hg[g].a.st = p->coop_state.as<CoopState>() + g;
+        HIPCHK(c, hipMemcpyAsync(L->coop_launches[l].groups.p, hg.data(), hg.size() * sizeof(CoopGroup), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!L->h_rest.empty()) HIPCHK(c, hipMemcpyAsync(L->rest_order.p, L->h_rest.data(), L->h_rest.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     L->partition_dirty = false;
     return 0;
@@ -1064,11 +1148,9 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(bs, c->ev_fork, 0));
     }
-    for (size_t i = 0; i < L->coop.size(); ++i) {
-        const CoopItem& it = L->coop[i];
-        CoopArgs ca{p->coop_timing.as<long long>(), p->coop_state.as<CoopState>(), it.slot_li.as<int>(),
-                    it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>(), it.comp, L->coop_poll_delay};
-        int rc = launch_coop(c->stream, p->kind, p->view(), V, ca, it.nwg, L->coop_threads, maxiters, ftol);
+    for (const CoopLaunch& cl : L->coop_launches) {
+        int rc = launch_coop(c->stream, p->kind, p->view(), V, cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+                             cl.count, cl.total_wg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }

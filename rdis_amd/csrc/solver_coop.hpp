@@ -259,18 +259,30 @@ struct CoopEnv {
     }
 };
 
+// One launch solves several components side by side: workgroups [wg0, wg0 + nwg) of the grid form
+// the group of component a.comp, with its own exchange state; groups never talk to each other.
+constexpr int COOP_MAX_GROUPS = 256;
+struct CoopGroup {
+    CoopArgs a;
+    int wg0, nwg;
+};
+
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
-cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol) {
+cgd_coop_kernel(ProblemView P, PlanView L, const CoopGroup* __restrict__ groups, const int* __restrict__ wg_group,
+                int maxiters, double ftol) {
     __shared__ double bcast[8];
     const long long tk0 = coop_clock();
+    const CoopGroup G = groups[wg_group[blockIdx.x]];
+    const CoopArgs& A = G.a;
     const int comp = A.comp;
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wg = (int)blockIdx.x - G.wg0;
+    const int gt = wg * blockDim.x + threadIdx.x;
 
     CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x,
-              GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, bcast, A.poll_delay, 0, 0u, false, {}},
+              GridSync{A.st, (int)threadIdx.x, G.nwg, wg, bcast, A.poll_delay, 0, 0u, false, {}},
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
               gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
     if (E.has_fac) {
@@ -296,25 +308,37 @@ cgd_coop_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, double ftol
     }
 }
 
-// host side: returns hipSuccess (0) or a hipError_t
-inline int launch_coop(hipStream_t stream, int kind, const ProblemView& P, const PlanView& V, const CoopArgs& a_in,
-                       int nwg, int threads, int maxiters, double ftol) {
+// arms the granules the groups of a launch will use (one launch instead of two memsets per group)
+__global__ void __launch_bounds__(256) coop_arm_kernel(const CoopGroup* __restrict__ groups, int waves_per_wg) {
+    const CoopGroup G = groups[blockIdx.x];
+    CoopState* st = G.a.st;
+    const int entries = G.nwg * waves_per_wg;
+    for (int t = threadIdx.x; t < COOP_NBUF * COOP_K * entries; t += blockDim.x) {
+        const int e = t % entries, bk = t / entries;
+        st->granule[bk / COOP_K][bk % COOP_K][e] = ~0ull;
+    }
+    if (threadIdx.x == 0) st->abort_flag = 0u;
+}
+
+// host side: returns hipSuccess (0) or a hipError_t.  groups / wg_group: device arrays (ngroups
+// entries / one entry per workgroup of the launch)
+inline int launch_coop(hipStream_t stream, int kind, const ProblemView& P, const PlanView& V, const CoopGroup* groups,
+                       const int* wg_group, int ngroups, int total_wg, int threads, int maxiters, double ftol) {
     if (kind != KIND_BA) return (int)hipErrorNotSupported;
-    hipError_t e = hipMemsetAsync(a_in.st, 0xFF, sizeof(CoopState) - 64, stream);  // arm every granule
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync((char*)a_in.st + offsetof(CoopState, abort_flag), 0, 64, stream);
-    if (e != hipSuccess) return (int)e;
+    coop_arm_kernel<<<ngroups, 256, 0, stream>>>(groups, threads / 64);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return (int)e0;
     ProblemView p = P;
     PlanView v = V;
-    CoopArgs a = a_in;
+    const CoopGroup* gp = groups;
+    const int* wp = wg_group;
     int mi = maxiters;
     double ft = ftol;
-    void* args[] = {&p, &v, &a, &mi, &ft};
+    void* args[] = {&p, &v, &gp, &wp, &mi, &ft};
     const void* fn = threads == 512 ? (const void*)cgd_coop_kernel<512>
                    : threads == 128 ? (const void*)cgd_coop_kernel<128>
                                     : (const void*)cgd_coop_kernel<256>;
-    e = hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(threads), args, 0, stream);
-    return (int)e;
+    return (int)hipLaunchCooperativeKernel(fn, dim3(total_wg), dim3(threads), args, 0, stream);
 }
 
 inline int coop_max_workgroups(int threads, int num_cus) {

@@ -583,3 +583,45 @@ def test_batched_launch_overlaps_cooperative_launches(gctx):
     assert n1 == n0 == 2                                         # one cooperative launch, one batched launch
     assert np.array_equal(r1.fret, r0.fret) and np.array_equal(r1.x, r0.x) and np.array_equal(x1, x0)
     assert np.array_equal(r1.iters, r0.iters) and np.array_equal(r1.status, r0.status) and np.all((r1.status & 0xFF) != 5)
+
+
+def test_cooperative_groups_side_by_side(gctx):
+    """components of some size each get a cooperative group of workgroups, all groups in one launch
+    when they fit the device together (ladybug's 49 camera components: 361..906 factors, 9 variables,
+    every one of them a long gradient run): members replay against the oracle; packed into several
+    smaller launches the same groups give the same bits"""
+    pp = P.load_bal()
+    cams, _ = P.ba_alternation_plans(pp)
+    free_ptr, free_vid, fac_ptr, fac_id = cams
+    g = capi.Problem(gctx, pp)
+    out = {}
+    for mode in ("one launch", "chunks", "workgroup each"):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *cams)
+        if mode == "chunks":
+            plan.set_option("coop_workgroups", 16)             # group mode needs all groups resident: off ...
+            plan.set_option("coop_min_factors", 300)           # ... the few-large-components rule takes them instead
+            plan.set_option("coop_max_components", 49)
+        if mode == "workgroup each":
+            plan.set_option("coop_group_min_factors", 0)
+        plan.set_option("trace_records", 4096)
+        plan.set_option("dump_iters", 25)
+        plan.set_start(None)
+        plan.solve(25, 3e-8)
+        r = plan.fetch()
+        out[mode] = (r, g.get_x(), plan.last_kernel_ms()[1])
+        assert np.all(r.delta <= 0) and np.all((r.status & 0xFF) != 5), mode
+        assert np.array_equal(g.get_x()[free_vid], r.x)
+        if mode == "one launch":
+            for c in (0, 17, 48):
+                fv, fc = free_vid[free_ptr[c]:free_ptr[c + 1]], fac_id[fac_ptr[c]:fac_ptr[c + 1]]
+                tr, n = plan.get_trace(c, 4096)
+                rep = O.OracleProblem(pp).replay(tr, free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25,
+                                                 vdump=plan.get_vectors(c, 25)[:int(r.iters[c]) + 1])
+                assert rep.step_mismatches == 0 and rep.tag_mismatches == 0 and rep.underrun == 0 and rep.consumed == n, (c, rep)
+                assert rep.max_f_rel_near <= 1e-11 and rep.max_slope_rel_near <= 1e-11 and rep.fret == r.fret[c], (c, rep)
+        plan.close()
+    (r1, x1, n1), (rc, xc, nc), (rw, xw, nw) = out["one launch"], out["chunks"], out["workgroup each"]
+    assert n1 == 1 and nc > 4 and nw == 1
+    assert np.array_equal(r1.fret, rc.fret) and np.array_equal(r1.x, rc.x) and np.array_equal(x1, xc) and np.array_equal(r1.nfeval, rc.nfeval)
+    assert abs(np.sum(r1.fret) - np.sum(rw.fret)) <= 0.05 * np.sum(rw.fret)     # same algorithm, sums in another order, 25 unconverged iterations
