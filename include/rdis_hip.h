@@ -207,8 +207,8 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * 768 or 1024; 0 = auto), "coop_min_factors" (bundle-adjustment components with at least this
  * many factors are solved by the multi-workgroup cooperative kernel, one launch each; 0 = never;
  * default 4096), "coop_max_components" (only when the plan has at most this many such
- * components, default 8; a plan with more of them is one batched launch, one workgroup per
- * component), "coop_group_min_factors" (default 256: when the cooperative groups of ALL
+ * components, default 48 -- their groups are packed into launches of what is resident at once; a
+ * plan with more of them is one batched launch, one workgroup per component), "coop_group_min_factors" (default 256: when the cooperative groups of ALL
  * components with at least this many factors fit the device together, each of them gets one and
  * they run side by side in one launch; 0 = off), "coop_workgroups" (cap, 0 = what fits),
  * "coop_threads" (128, 256 or 512), "coop_poll_delay" (x64 cycles between publishing and the

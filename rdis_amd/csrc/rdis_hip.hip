@@ -176,7 +176,7 @@ struct rdis_hip_plan {
     // options
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
-    int coop_max_components = 8;      // ... for at most this many components per plan; or ...
+    int coop_max_components = 48;     // ... for at most this many components per plan (packed two or more to a launch); or ...
     int64_t coop_group_min_factors = 256;  // ... for every component of at least this many factors when all their groups fit the device at once
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
     int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
@@ -774,7 +774,8 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         need += align_up((size_t)nfree * 8, 256) + align_up(L->out_bytes, 256) + 256;
         need += align_up(nc * 4, 256) + align_up((size_t)nfree * 8, 256);                       // rest_order, xi_glob
         need += align_up((size_t)nfree * 4, 256) + 8 * 256;                                      // long_vars of streaming components
-        need += (size_t)std::min<int64_t>(ncomp, 8) * (align_up(lanes_max * 4, 256) + align_up(lanes_max / 64 * 4, 256));
+        // lane_var / wave_var of the cooperative groups: at most 3 x the lanes a component needs, rounded up to workgroups
+        need += 5 * (3 * (size_t)(nfac + nfree) + 2048 * (size_t)std::min<int64_t>(ncomp, 4096)) + align_up(lanes_max * 4, 256);
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
         need += (size_t)COOP_MAX_GROUPS * (4 * 256 + sizeof(CoopGroup)) + (size_t)COOP_MAX_WG * 4 + lanes_max * 4 + 64 * 256;  // groups, their alignment slack
         if (p->arena.bytes < need) {
