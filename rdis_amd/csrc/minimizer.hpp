@@ -492,7 +492,16 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
         }
         const double qa = uni<Env>(q.a);
         E.tick(8, ts1 - ts0); E.tick(9, E.clock() - ts1);
-        if (kind == REQ_DONE) break;
+        if (kind == REQ_DONE) {
+            // a group of the quad solver writes its results and carries on with the next component
+            if constexpr (Env::UNIFORM) break;
+            else {
+                if (!E.next_problem(M)) break;
+                if (stepper) M.init(maxiters, ftol);
+                r0 = r1 = r2 = 0.0;
+                continue;
+            }
+        }
         const long long th0 = E.clock();
 #define RDIS_TICK_KIND(K) E.tick(12 + K, E.clock() - th0); E.tick(22 + K, 1)
         switch (kind) {

@@ -172,7 +172,8 @@ struct rdis_hip_plan {
     std::vector<std::vector<CoopGroup>> h_coop_groups;
     std::vector<StreamItem> stream;
     std::vector<int> h_rest;
-    DevBuf rest_order, xi_glob;
+    DevBuf rest_order, xi_glob, queue;
+    int group_blocks4 = 0, group_blocks16 = 0;   // resident blocks of the tiny-component kernels
     // options
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
@@ -1051,7 +1052,15 @@ int prepare_partition(rdis_hip_plan* L) {
         for (int cc : L->h_rest) mf = std::max<int64_t>(mf, L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc]);
         L->rest_rot_mode = camfix ? ROT_CAMFIX : (L->camera_records == 2 || mf > 2048) ? ROT_RECORDS : ROT_PER_FACTOR;
     }
+    if (L->rest_tiny > 0 && L->group_blocks4 == 0) {
+        int b4 = 0, b16 = 0;
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cgd_group_kernel<4, QUAD_THREADS>, QUAD_THREADS, 0));
+        HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b16, cgd_group_kernel<16, 64>, 64, 0));
+        L->group_blocks4 = std::max(1, b4) * c->num_cus;
+        L->group_blocks16 = std::max(1, b16) * c->num_cus;
+    }
     int rc = plan_alloc(L, L->rest_order, std::max<size_t>(L->h_rest.size(), 1) * sizeof(int));
+    if (!rc) rc = plan_alloc(L, L->queue, 256);
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
     // cooperative groups, packed into launches of at most `cap` workgroups
@@ -1172,12 +1181,18 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         ProblemView PV = p->view();
         PV.xrot = p->xrot.as<double>();
         PV.rot_mode = L->rest_rot_mode == ROT_CAMFIX ? ROT_CAMFIX : ROT_PER_FACTOR;   // (the quad solver has no refresh)
-        if (L->tiny_group == 4)
-            cgd_group_kernel<4, QUAD_THREADS><<<(L->rest_tiny + QUAD_THREADS / 4 - 1) / (QUAD_THREADS / 4), QUAD_THREADS, 0, bs>>>(
-                PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
-        else
-            cgd_group_kernel<16, 64><<<(L->rest_tiny + 3) / 4, 64, 0, bs>>>(
-                PV, V, L->rest_order.as<int>(), L->rest_tiny, maxiters, ftol);
+        // persistent groups: as many blocks as are resident, every group draws components until the list is empty
+        HIPCHK(c, hipMemsetAsync(L->queue.p, 0, sizeof(int), bs));
+        if (L->tiny_group == 4) {
+            const int gpb = QUAD_THREADS / 4;
+            const int grid = std::min((L->rest_tiny + gpb - 1) / gpb, std::max(1, L->group_blocks4));
+            cgd_group_kernel<4, QUAD_THREADS><<<grid, QUAD_THREADS, 0, bs>>>(
+                PV, V, L->rest_order.as<int>(), L->rest_tiny, L->queue.as<int>(), maxiters, ftol);
+        } else {
+            const int grid = std::min((L->rest_tiny + 3) / 4, std::max(1, L->group_blocks16));
+            cgd_group_kernel<16, 64><<<grid, 64, 0, bs>>>(
+                PV, V, L->rest_order.as<int>(), L->rest_tiny, L->queue.as<int>(), maxiters, ftol);
+        }
         HIPCHK(c, hipGetLastError());
         ++L->last_launches;
     }

@@ -14,7 +14,9 @@
 //   * each group has its own control machine and request slot in LDS; the group's first lane
 //     steps it.  Groups of one wave are at different points of their solves: the wave runs the
 //     union of their paths under execution masks (run_machine with Env::UNIFORM = false).
-// Same CgdMachine, same requests, same trace records as the other solvers.
+// Same CgdMachine, same requests, same trace records as the other solvers.  The groups are
+// persistent: when a machine is done its group writes the results and takes the next component
+// of the launch's list (run_machine: next_problem), until the list is empty.
 //
 // GroupEnv<16> gives a component a DPP row of sixteen lanes (four machines per wave): between a
 // workgroup each and the quad solver when there are some thousands of components -- ladybug's
@@ -58,6 +60,66 @@ struct GroupEnv {
     int fv[QUAD_MAX_VARS];
     double* tr;
     int trn, lm_count;
+    // persistent groups: a group that finishes its component takes the next one off the launch's
+    // list (heaviest first), so a wave is busy until the list is empty, not until its slowest
+    // first component is done
+    const int* list;
+    int ncomp;
+    int* queue;        // components handed out beyond the first round
+    int first_round;   // = groups in the grid
+
+    // component number ci of the list (or the next non-empty one) into the registers of the group;
+    // false when the list is exhausted
+    __device__ bool load_next(int ci) {
+        for (;;) {
+            if (ci >= ncomp) return false;
+            comp = list[ci];
+            f0 = L.free_ptr[comp]; c0 = L.fac_ptr[comp];
+            n = L.free_ptr[comp + 1] - f0; m = L.fac_ptr[comp + 1] - c0;
+            if (m > 0) break;
+            if (sub == 0) {   // nothing to optimise: return 0, leave x as it was (.cpp:26-29)
+                for (int t = 0; t < n; ++t) L.xout[f0 + t] = L.xstart[f0 + t];
+                L.fret[comp] = 0.0; L.delta[comp] = 0.0; L.iters[comp] = 0;
+                L.status[comp] = EXIT_EMPTY; L.nfeval[comp] = 0; L.ngeval[comp] = 0;
+                if (L.trace_n) L.trace_n[comp] = 0;
+            }
+            ci = take();
+        }
+#pragma unroll
+        for (int t = 0; t < QUAD_MAX_VARS; ++t) {
+            const bool in = t < n;
+            const int v = in ? L.free_vid[f0 + t] : 0;
+            fv[t] = in ? v : -1;
+            const double x0 = in ? L.xstart[f0 + t] : 0.0;
+            p[t] = x0; xinit[t] = x0; xi[t] = 0.0; g[t] = 0.0; h[t] = 0.0; xt[t] = 0.0;
+            lo[t] = in ? P.lo[v] : 0.0; hi[t] = in ? P.hi[v] : 0.0;
+        }
+        tr = L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr;
+        trn = 0; lm_count = 0;
+        return true;
+    }
+    __device__ int take() {   // the group's first lane draws, the others get its number
+        int ci = 0;
+        if (sub == 0) ci = first_round + atomicAdd(queue, 1);
+        return __shfl(ci, 0, G);
+    }
+    // run_machine calls this when the machine is done: results out, next component in
+    __device__ bool next_problem(const CgdMachine& M) {
+        if (sub == 0) {
+#pragma unroll
+            for (int t = 0; t < QUAD_MAX_VARS; ++t) {
+                if (t < n) {
+                    const double xf = clampd(M.rolled_back ? xinit[t] : p[t], lo[t], hi[t]);
+                    P.x[fv[t]] = xf;   // variables are left assigned (.cpp:61, :84-86)
+                    L.xout[f0 + t] = xf;
+                }
+            }
+            L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
+            L.status[comp] = M.status(); L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
+            if (L.trace_n) L.trace_n[comp] = trn;
+        }
+        return load_next(take());
+    }
 
     __device__ bool stepper() const { return active && sub == 0; }
     __device__ bool writer() const { return active && sub == 0; }
@@ -280,52 +342,16 @@ struct GroupEnv {
 // list[0 .. ncomp): the components of this launch (each with at most QUAD_MAX_VARS free variables)
 template <int G, int THREADS>
 __global__ void __launch_bounds__(THREADS, G == 4 ? 1 : 2)
-cgd_group_kernel(ProblemView P, PlanView L, const int* __restrict__ list, int ncomp, int maxiters, double ftol) {
+cgd_group_kernel(ProblemView P, PlanView L, const int* __restrict__ list, int ncomp, int* __restrict__ queue,
+                 int maxiters, double ftol) {
     __shared__ CgdMachine Ms[THREADS / G];
     __shared__ Request Qs[THREADS / G][2];
     const int grp = threadIdx.x / G;
-    const int ci = blockIdx.x * (THREADS / G) + grp;
-    const bool active = ci < ncomp;
-    const int comp = list[active ? ci : 0];
-    const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
-    const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
-    GroupEnv<G> E{P, L, comp, n, m, f0, c0, (int)(threadIdx.x % G), active && m > 0,
+    GroupEnv<G> E{P, L, 0, 0, 0, 0, 0, (int)(threadIdx.x % G), false,
                   {}, {}, {}, {}, {}, {}, {}, {}, {},
-                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};
-#pragma unroll
-    for (int t = 0; t < QUAD_MAX_VARS; ++t) {
-        const bool in = t < n;
-        const int v = in ? L.free_vid[f0 + t] : 0;
-        E.fv[t] = in ? v : -1;
-        const double x0 = in ? L.xstart[f0 + t] : 0.0;
-        E.p[t] = x0; E.xinit[t] = x0; E.xi[t] = 0.0; E.g[t] = 0.0; E.h[t] = 0.0; E.xt[t] = 0.0;
-        E.lo[t] = in ? P.lo[v] : 0.0; E.hi[t] = in ? P.hi[v] : 0.0;
-    }
-    CgdMachine& M = Ms[grp];
-    if (active && m == 0) {  // nothing to optimise: return 0, leave x as it was (.cpp:26-29)
-        if (E.sub == 0) {
-            for (int t = 0; t < n; ++t) L.xout[f0 + t] = L.xstart[f0 + t];
-            L.fret[comp] = 0.0; L.delta[comp] = 0.0; L.iters[comp] = 0;
-            L.status[comp] = EXIT_EMPTY; L.nfeval[comp] = 0; L.ngeval[comp] = 0;
-            if (L.trace_n) L.trace_n[comp] = 0;
-        }
-    }
-    if (E.active) {
-        run_machine(E, M, Qs[grp], maxiters, ftol);
-        if (E.sub == 0) {
-#pragma unroll
-            for (int t = 0; t < QUAD_MAX_VARS; ++t) {
-                if (t < n) {
-                    const double xf = clampd(M.rolled_back ? E.xinit[t] : E.p[t], E.lo[t], E.hi[t]);
-                    P.x[E.fv[t]] = xf;   // variables are left assigned (.cpp:61, :84-86)
-                    L.xout[f0 + t] = xf;
-                }
-            }
-            L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
-            L.status[comp] = M.status(); L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
-            if (L.trace_n) L.trace_n[comp] = E.trn;
-        }
-    }
+                  nullptr, 0, 0, list, ncomp, queue, (int)(gridDim.x * (THREADS / G))};
+    E.active = E.load_next((int)blockIdx.x * (THREADS / G) + grp);   // the first component: by position
+    if (E.active) run_machine(E, Ms[grp], Qs[grp], maxiters, ftol);
 }
 
 }  // namespace rdis_hip
