@@ -19,6 +19,7 @@ Workloads (--workload):
                  top-level objective is summed with an RCCL all-reduce.
   synthetic-S    BASELINE config 5: 1000 independent 3-camera x 40-point components
                  per rank (one workgroup each, one launch).
+  (--scaling strong: the synthetic decompositions keep their total size and are sharded over the ranks)
   synthetic-L    the same generator at ladybug's size (the throughput point):
                  --components (default 256) independent 49-camera x 7776-point components of
                  31104 observations per rank -- 8.0e6 factors; one workgroup each, one launch.
@@ -61,15 +62,28 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "synthetic-L", "ladybug-components"])
-    ap.add_argument("--components", type=int, default=256, help="synthetic-L: components per rank")
+    ap.add_argument("--components", type=int, default=256, help="synthetic-L: components per rank (weak) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: the synthetic workloads keep their total size (synthetic-S: 1000 components, synthetic-L: "
+                         "--components) and every rank takes a contiguous share of the components")
     ap.add_argument("--maxiters", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
     return ap.parse_args()
 
 
-def build_problem(workload: str, rank: int, components: int = 256):
+def build_problem(workload: str, rank: int, components: int = 256, world: int = 1, strong: bool = False):
     from rdis_amd import problems as P
+    if strong:   # a fixed decomposition, sharded: components are generated from their ids, so a rank builds only its own
+        if workload not in ("synthetic-S", "synthetic-L"):
+            raise SystemExit("--scaling strong needs a decomposable workload (synthetic-S / synthetic-L)")
+        total = 1000 if workload == "synthetic-S" else components
+        lo, hi = rank * total // world, (rank + 1) * total // world
+        if hi <= lo:
+            raise SystemExit(f"--scaling strong: {total} components do not cover {world} ranks")
+        if workload == "synthetic-S":
+            return P.make_synthetic_ba(hi - lo, 3, 40, first_comp=lo)
+        return P.make_synthetic_ba(hi - lo, 49, 7776, obs_per_pt=4, first_comp=lo)
     if workload == "synthetic-L":
         return P.make_synthetic_ba(components, 49, 7776, obs_per_pt=4, first_comp=components * rank)
     if workload == "ladybug-full":
@@ -157,7 +171,7 @@ def main():
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
 
-    pp = build_problem(a.workload, rank, a.components)
+    pp = build_problem(a.workload, rank, a.components, world, a.scaling == "strong")
     prob = capi.Problem(ctx, pp)
     plan = capi.Plan(prob)
     for kv in a.opt:
@@ -206,11 +220,11 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        it = torch.tensor([iters_done], dtype=torch.float64, device=f"cuda:{local_rank}")
+        it = torch.tensor([iters_done, float(nfe.sum()), float(nge.sum())], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(it)
-        total_iters = float(it.item())
+        total_iters, total_nfe, total_nge = (float(v) for v in it.tolist())
     else:
-        total_iters = float(iters_done)
+        total_iters, total_nfe, total_nge = float(iters_done), float(nfe.sum()), float(nge.sum())
 
     if rank == 0:
         abytes = algorithmic_bytes(pp, nfe, nge)
@@ -218,17 +232,19 @@ def main():
         line = {
             "metric": "subspace-solver iters/sec (all components), ladybug BA",
             "value": total_iters / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.workload.startswith("synthetic") else "ladybug-49-7776 (BAL file)",
             "config": {"workload": ("ladybug-49-7776 full, CGD over all 23769 variables / 31843 factors, SSmaxit 25, ftol 3e-8; "
                                     "one such component per GPU") if a.workload == "ladybug-full" else
                        "ladybug-49-7776 with the cameras fixed: 7776 single-point components per GPU, SSmaxit 25" if a.workload == "ladybug-components" else
                        f"synthetic decomposable BA: {pp.ncomp} components x (49 cameras, 7776 points, 31104 observations) per GPU, SSmaxit 25" if a.workload == "synthetic-L" else
                        "synthetic decomposable BA: 1000 components x (3 cameras, 40 points, 120 observations) per GPU, SSmaxit 25",
+                       "decomposition": (f"strong scaling: the components of the whole decomposition are shared out over {world} rank(s); "
+                                         "rank 0's share is reported below") if a.scaling == "strong" else "weak scaling: the workload is per GPU",
                        "components_per_gpu": pp.ncomp, "factors_per_gpu": pp.nfac, "variables_per_gpu": pp.nvars,
                        "parallelism": f"{world} x independent components, all-reduce of the objective"},
             "final_objective": float(r.fret.sum()), "objective_sum_all_ranks": objective_sum,
-            "f_evals_per_s": float(nfe.sum()) * world / dt, "grad_evals_per_s": float(nge.sum()) * world / dt,
+            "f_evals_per_s": total_nfe / dt, "grad_evals_per_s": total_nge / dt,
             "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in
                                       zip(*np.unique(r.status & 0xFF, return_counts=True))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
