@@ -226,6 +226,8 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * factors in a component the component rewrites the records of its cameras at every trial point;
  * 2 = records wherever possible; 0 = every factor forms its camera's rotation itself.  Results
  * are bit-identical in all three settings),
+ * "tiny_max_blocks" (cap on the grid of the persistent tiny-component kernels, 0 = what is
+ * resident; for tests),
  * "overlap_batch" (default 1: the batched launch of a plan runs on a second stream, concurrently
  * with its cooperative launches),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and

@@ -174,6 +174,7 @@ struct rdis_hip_plan {
     std::vector<int> h_rest;
     DevBuf rest_order, xi_glob, queue;
     int group_blocks4 = 0, group_blocks16 = 0;   // resident blocks of the tiny-component kernels
+    int tiny_max_blocks = 0;                     // option (tests): cap on their grid, 0 = what is resident
     // options
     int block_threads = 0;
     int64_t coop_min_factors = 4096;  // cooperative solver from this many factors ...
@@ -845,6 +846,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_group_min_factors") {
         if (value < 0) return fail(c, RDIS_HIP_EINVAL, "coop_group_min_factors < 0");
         L->coop_group_min_factors = value;
+    } else if (n == "tiny_max_blocks") {
+        if (value < 0 || value > (1 << 20)) return fail(c, RDIS_HIP_EINVAL, "tiny_max_blocks out of range");
+        L->tiny_max_blocks = (int)value;
     } else if (n == "overlap_batch") {
         L->overlap_batch = value != 0;
     } else if (n == "row_min_components") {
@@ -1185,11 +1189,13 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         HIPCHK(c, hipMemsetAsync(L->queue.p, 0, sizeof(int), bs));
         if (L->tiny_group == 4) {
             const int gpb = QUAD_THREADS / 4;
-            const int grid = std::min((L->rest_tiny + gpb - 1) / gpb, std::max(1, L->group_blocks4));
+            int grid = std::min((L->rest_tiny + gpb - 1) / gpb, std::max(1, L->group_blocks4));
+            if (L->tiny_max_blocks > 0) grid = std::min(grid, L->tiny_max_blocks);
             cgd_group_kernel<4, QUAD_THREADS><<<grid, QUAD_THREADS, 0, bs>>>(
                 PV, V, L->rest_order.as<int>(), L->rest_tiny, L->queue.as<int>(), maxiters, ftol);
         } else {
-            const int grid = std::min((L->rest_tiny + 3) / 4, std::max(1, L->group_blocks16));
+            int grid = std::min((L->rest_tiny + 3) / 4, std::max(1, L->group_blocks16));
+            if (L->tiny_max_blocks > 0) grid = std::min(grid, L->tiny_max_blocks);
             cgd_group_kernel<16, 64><<<grid, 64, 0, bs>>>(
                 PV, V, L->rest_order.as<int>(), L->rest_tiny, L->queue.as<int>(), maxiters, ftol);
         }

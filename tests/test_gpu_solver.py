@@ -625,3 +625,55 @@ def test_cooperative_groups_side_by_side(gctx):
     assert n1 == 1 and nc > 4 and nw == 1
     assert np.array_equal(r1.fret, rc.fret) and np.array_equal(r1.x, rc.x) and np.array_equal(x1, xc) and np.array_equal(r1.nfeval, rc.nfeval)
     assert abs(np.sum(r1.fret) - np.sum(rw.fret)) <= 0.05 * np.sum(rw.fret)     # same algorithm, sums in another order, 25 unconverged iterations
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_persistent_groups_take_components_off_the_list(gctx, lanes):
+    """the tiny-component kernels are persistent: with the grid capped at one block (64 or 4
+    groups) every group works through many components, one after the other -- and gives each of
+    them the bits it gets when every component has a group of its own"""
+    pp = P.load_bal(ncams=49, npts=1200)
+    g = capi.Problem(gctx, pp)
+    a = np.zeros(pp.nvars, np.uint8); a[:441] = 1
+    comps = g.components(a)
+    out = {}
+    for cap in (0, 1):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *comps)
+        plan.set_option("quad_min_components", 1 if lanes == 4 else 1 << 40)
+        plan.set_option("row_min_components", 1 if lanes == 16 else 1 << 40)
+        plan.set_option("tiny_max_blocks", cap)
+        plan.set_option("trace_records", 256)
+        plan.set_start(None)
+        plan.solve(25, 3e-8)
+        out[cap] = (plan.fetch(), g.get_x(), [plan.get_trace(c, 256) for c in (0, 64, 65, 700, 1199)])
+        assert plan.last_kernel_ms()[1] == 1
+        plan.close()
+    (r0, x0, t0), (r1, x1, t1) = out[0], out[1]
+    assert np.array_equal(r0.fret, r1.fret) and np.array_equal(r0.x, r1.x) and np.array_equal(x0, x1)
+    assert np.array_equal(r0.iters, r1.iters) and np.array_equal(r0.status, r1.status) and np.array_equal(r0.nfeval, r1.nfeval)
+    for (ta, na), (tb, nb) in zip(t0, t1):
+        assert na == nb and np.array_equal(ta[:min(na, 256)], tb[:min(nb, 256)])
+
+
+def test_large_components_packed_into_one_cooperative_launch(gctx):
+    """a few large components share a cooperative launch (each its own group of workgroups and its
+    own exchange state): same bits as one launch per component"""
+    pp = P.make_synthetic_ba(5, 12, 700, obs_per_pt=4)           # 5 components of 2800 factors
+    comps = (pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id)
+    g = capi.Problem(gctx, pp)
+    out = {}
+    for label, opts in (("packed", {"coop_min_factors": 1000}), ("one each", {"coop_min_factors": 1000, "coop_workgroups": 24})):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *comps)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        plan.set_start(None)
+        plan.solve(10, 3e-8)
+        out[label] = (plan.fetch(), g.get_x(), plan.last_kernel_ms()[1])
+        plan.close()
+    (ra, xa, na), (rb, xb, nb) = out["packed"], out["one each"]
+    assert na == 1 and nb == 5
+    assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb)
+    assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.nfeval, rb.nfeval) and np.all((ra.status & 0xFF) != 5)
+    assert np.all(ra.delta < 0)
