@@ -10,6 +10,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from rdis_amd import problems as P
 from rdis_amd.dist import rank_decomposition
@@ -93,3 +94,24 @@ def test_two_ranks_gloo_objective_allreduce(tmp_path):
         its += r.iters + 1
     assert abs(res["total"] - tot) <= 1e-12 * abs(tot) and abs(res["total2"] - tot) <= 1e-12 * abs(tot)
     assert res["iters"] == its and res["ncomp_rank0"] == 6
+
+
+def test_strong_scaling_shards_of_the_bench_cover_the_decomposition():
+    """bench.py --scaling strong: every rank builds only its share of a fixed synthetic decomposition;
+    the shares are the components of the whole, each exactly once (they are generated from their ids)"""
+    import bench
+    whole = P.make_synthetic_ba(1000, 3, 40)
+    nv, nf = whole.nvars // 1000, whole.nfac // 1000
+    seen = 0
+    for world in (3, 8):
+        seen = 0
+        for rank in range(world):
+            part = bench.build_problem("synthetic-S", rank, world=world, strong=True)
+            lo = rank * 1000 // world
+            assert part.ncomp == (rank + 1) * 1000 // world - lo
+            assert np.array_equal(part.x0, whole.x0[lo * nv:(lo + part.ncomp) * nv])
+            assert np.array_equal(part.obs, whole.obs[lo * nf:(lo + part.ncomp) * nf])
+            seen += part.ncomp
+        assert seen == 1000
+    with pytest.raises(SystemExit):
+        bench.build_problem("ladybug-full", 0, world=2, strong=True)
