@@ -1,4 +1,5 @@
-// solver_coop.hpp -- a whole grid solves ONE large bundle-adjustment component.
+// solver_coop.hpp -- a group of workgroups solves ONE large bundle-adjustment component; a launch
+// runs one group or several side by side (CoopGroup, below).
 //
 // ladybug-49-7776 as a single component is 31843 factors over 23769 free
 // variables: ~1 MB of state and ~800 dependent objective evaluations per solve.
@@ -28,7 +29,8 @@
 //    stepping wave only.
 //
 // Launched with hipLaunchCooperativeKernel so that an oversized grid is rejected
-// instead of deadlocking.  Bundle adjustment only (fixed arity 12).
+// instead of deadlocking; every workgroup of a group must be resident, so the host packs groups
+// into launches of at most the resident capacity.  Bundle adjustment only (fixed arity 12).
 #pragma once
 #include "grid_sync.hpp"
 

@@ -1,5 +1,5 @@
 // solver_quad.hpp -- a few lanes solve one tiny component out of registers: four lanes each,
-// sixteen components per wave (many components), or one wave each (fewer, latency matters).
+// sixteen components per wave (very many components), or sixteen lanes each, four per wave (fewer).
 //
 // With the cameras assigned, every point of a bundle-adjustment problem is a component of its
 // own: 3 free variables, 2..29 factors (SURVEY.md 3.2b -- by count this is what RDIS asks the
