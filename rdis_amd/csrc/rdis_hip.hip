@@ -1079,7 +1079,9 @@ int prepare_partition(rdis_hip_plan* L) {
             const CoopItem& it = L->coop[i];
             CoopGroup g{};
             g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, it.slot_li.as<int>(),
-                           it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>() + it.xi_off, it.comp, L->coop_poll_delay};
+                           it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>() + it.xi_off, it.comp,
+                           // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
+                           it.nwg * (L->coop_threads / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
             hg.push_back(g);
             hw.insert(hw.end(), (size_t)it.nwg, cl.count);
