@@ -135,9 +135,10 @@ struct rdis_hip_problem {
 struct CoopItem {
     int comp = 0, nwg = 0;
     size_t xi_off = 0;  // where its published search direction starts in the plan's xi_glob
-    DevBuf slot_li;   // [12 * m] local free index of each factor slot, -1 = constant
-    DevBuf lane_var;  // [nwg * threads] free variable owned by a lane, -1 = none
-    DevBuf wave_var;  // [nwg * threads / 64] free variable owned by a whole wave, -1 = none
+    // offsets into the plan's coop_ints block (one upload for all cooperative components)
+    size_t slot_li = 0;   // [12 * m] local free index of each factor slot, -1 = constant
+    size_t lane_var = 0;  // [nwg * threads] free variable owned by a lane, -1 = none
+    size_t wave_var = 0;  // [nwg * threads / 64] free variable owned by a whole wave, -1 = none
 };
 
 struct CoopLaunch {      // cooperative groups that run side by side in one launch
@@ -169,7 +170,10 @@ struct rdis_hip_plan {
     bool partition_dirty = true;
     std::vector<CoopItem> coop;
     std::vector<CoopLaunch> coop_launches;
+    std::vector<int> h_coop_ints;   // host image of coop_ints (kept: the upload is asynchronous)
+    DevBuf coop_ints;
     std::vector<std::vector<CoopGroup>> h_coop_groups;
+    std::vector<std::vector<int>> h_coop_wg;
     std::vector<StreamItem> stream;
     std::vector<int> h_rest;
     DevBuf rest_order, xi_glob, queue;
@@ -904,8 +908,10 @@ int prepare_partition(rdis_hip_plan* L) {
     rdis_hip_ctx* c = L->prob->ctx;
     rdis_hip_problem* p = L->prob;
     L->coop.clear();
+    L->h_coop_ints.clear();
     L->coop_launches.clear();
     L->h_coop_groups.clear();
+    L->h_coop_wg.clear();
     L->stream.clear();
     L->h_rest.clear();
     int cap = 0, scap = 0;
@@ -950,6 +956,8 @@ int prepare_partition(rdis_hip_plan* L) {
     if (L->coop_workgroups > 0) scap = std::min(scap, L->coop_workgroups);
     int64_t max_n = 0;
     std::vector<int> blk_all;
+    // (one allocation: growing this by appending costs a transient call on ladybug 1.5 ms in page faults)
+    L->h_coop_ints.reserve((size_t)(any_big ? 12 * L->nfac + 4 * (L->nfac + L->nfree) + 4096 * (int64_t)std::min<int64_t>(L->ncomp, 64) : 0));
     for (int cc : L->h_order) {  // heaviest first
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
@@ -1011,14 +1019,13 @@ int prepare_partition(rdis_hip_plan* L) {
         std::vector<char> wave_owned((size_t)n, 0);
         for (size_t k = 0; k < longv.size() && (int)k < waves; ++k) { wave_var[k] = longv[k]; wave_owned[(size_t)longv[k]] = 1; }
         for (int64_t i = 0; i < n; ++i) if (!wave_owned[(size_t)i]) lane_var[(size_t)i] = (int)i;
-        int rc = plan_alloc(L, it.slot_li, sl.size() * sizeof(int));
-        if (!rc) rc = plan_alloc(L, it.lane_var, lane_var.size() * sizeof(int));
-        if (!rc) rc = plan_alloc(L, it.wave_var, wave_var.size() * sizeof(int));
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(it.slot_li.p, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(it.lane_var.p, lane_var.data(), lane_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(it.wave_var.p, wave_var.data(), wave_var.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // locals
+        auto append = [&](const std::vector<int>& v) {
+            const size_t off = L->h_coop_ints.size();
+            L->h_coop_ints.insert(L->h_coop_ints.end(), v.begin(), v.end());
+            L->h_coop_ints.resize((L->h_coop_ints.size() + 63) / 64 * 64, -1);
+            return off;
+        };
+        it.slot_li = append(sl); it.lane_var = append(lane_var); it.wave_var = append(wave_var);
         max_n += n;
     }
     // tiny bundle-adjustment components (at most QUAD_MAX_VARS free variables: a point against fixed
@@ -1067,6 +1074,11 @@ int prepare_partition(rdis_hip_plan* L) {
     if (!rc) rc = plan_alloc(L, L->queue, 256);
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
+    if (!L->coop.empty()) {
+        rc = plan_alloc(L, L->coop_ints, L->h_coop_ints.size() * sizeof(int));
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->coop_ints.p, L->h_coop_ints.data(), L->h_coop_ints.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     // cooperative groups, packed into launches of at most `cap` workgroups
     L->coop_launches.clear();
     size_t max_groups = 1;
@@ -1078,8 +1090,8 @@ int prepare_partition(rdis_hip_plan* L) {
         while (i < L->coop.size() && (cl.count == 0 || cl.total_wg + L->coop[i].nwg <= cap) && cl.count < COOP_MAX_GROUPS) {
             const CoopItem& it = L->coop[i];
             CoopGroup g{};
-            g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, it.slot_li.as<int>(),
-                           it.lane_var.as<int>(), it.wave_var.as<int>(), L->xi_glob.as<double>() + it.xi_off, it.comp,
+            g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, L->coop_ints.as<int>() + it.slot_li,
+                           L->coop_ints.as<int>() + it.lane_var, L->coop_ints.as<int>() + it.wave_var, L->xi_glob.as<double>() + it.xi_off, it.comp,
                            // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
                            it.nwg * (L->coop_threads / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
@@ -1098,8 +1110,9 @@ int prepare_partition(rdis_hip_plan* L) {
         if (rc) return rc;
         L->coop_launches.push_back(std::move(cl));
         L->h_coop_groups.push_back(std::move(hg));
-        HIPCHK(c, hipMemcpyAsync(L->coop_launches.back().wg_group.p, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // hw is a local
+        L->h_coop_wg.push_back(std::move(hw));   // (host images are kept: the uploads are asynchronous)
+        HIPCHK(c, hipMemcpyAsync(L->coop_launches.back().wg_group.p, L->h_coop_wg.back().data(),
+                                 L->h_coop_wg.back().size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
     // (the state pointers only now: the buffer may have moved while the launches were sized)
     for (size_t l = 0; l < L->coop_launches.size(); ++l) {
