@@ -556,16 +556,9 @@ __global__ void __launch_bounds__(1024) k_apply(Dev D, int mode) {
     }
 }
 
-struct Buf {
+struct Buf {   // a slice of the caller's workspace
     void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
     template <class T> T* as() { return static_cast<T*>(p); }
-};
-
-struct Pinned {
-    double* p = nullptr;
-    ~Pinned() { if (p) (void)hipHostFree(p); }
 };
 
 #define LM_CHK(expr)                                   \
@@ -576,15 +569,19 @@ struct Pinned {
 
 template <class T>
 int up(Buf& b, const std::vector<T>& h, hipStream_t s) {
-    LM_CHK(b.alloc(h.size() * sizeof(T)));
     if (!h.empty()) LM_CHK(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return 0;
 }
 
 }  // namespace
 
+LmWorkspace::~LmWorkspace() {
+    if (dev) (void)hipFree(dev);
+    if (pinned) (void)hipHostFree(pinned);
+}
+
 int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const int64_t* free_vid, int64_t nf,
-                 const int64_t* fac, const LmOptions& opt, LmResult* out, std::string* err) {
+                 const int64_t* fac, const LmOptions& opt, LmWorkspace* ws, LmResult* out, std::string* err) {
     *out = LmResult();
     auto fail = [&](const std::string& m) { if (err) *err = m; return -1; };
     if (nfree <= 0 || nf <= 0) return fail("lm: empty variable or factor list");
@@ -646,7 +643,34 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     D.SK = std::min(D.SK, std::max(1, D.Kp / 64));
     if ((double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
 
+    // Every device buffer of the solve is a slice of one workspace the caller keeps between solves
+    // (some thirty allocations and releases per call otherwise: 2 ms on ladybug).
     Buf b_lf, b_fci, b_fpi, b_free, b_cptr, b_clist, b_pptr, b_plist, b_cid, b_pid;
+    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Spart, S, rhs, dc, dp, psave, part, sc;
+    const size_t MM = (size_t)D.Mp * D.Mp;
+    {
+        const size_t n1c = (size_t)std::max(nca, 1), n1p = (size_t)std::max(npa, 1);
+        const std::pair<Buf*, size_t> want[] = {
+            {&b_lf, lf.size() * 4}, {&b_fci, fci.size() * 4}, {&b_fpi, fpi.size() * 4}, {&b_free, freem.size()},
+            {&b_cptr, cam_ptr.size() * 4}, {&b_clist, cam_list.size() * 4}, {&b_pptr, pt_ptr.size() * 4},
+            {&b_plist, pt_list.size() * 4}, {&b_cid, cam_id.size() * 4}, {&b_pid, pt_id.size() * 4},
+            {&Jc, (size_t)nf * 72 * D.R}, {&Jp, (size_t)nf * 24 * D.R}, {&e, (size_t)nf * 8 * D.R}, {&U, n1c * 81 * 8},
+            {&bc, (size_t)D.Mp * 8}, {&V, n1p * 48}, {&bp, n1p * 24}, {&Lp, n1p * 48}, {&yp, (size_t)D.Kp * 8},
+            {&T, (size_t)nf * 24 * D.R}, {&Zt, (size_t)D.Kp * D.Mp * 8}, {&Spart, MM * 8 * (size_t)D.SK}, {&S, MM * 8},
+            {&rhs, (size_t)D.Mp * 8}, {&dc, (size_t)D.Mp * 8}, {&dp, (size_t)D.Kp * 8},
+            {&psave, (size_t)(9 * nca + 3 * npa + 1) * 8}, {&part, 4096 * 8}, {&sc, 16 * 8}};
+        size_t total = 0;
+        for (const auto& w : want) total += (std::max<size_t>(w.second, 8) + 255) / 256 * 256;
+        if (ws->dev_bytes < total) {
+            LM_CHK(hipStreamSynchronize(stream));
+            if (ws->dev) { LM_CHK(hipFree(ws->dev)); ws->dev = nullptr; ws->dev_bytes = 0; }
+            LM_CHK(hipMalloc(&ws->dev, total + total / 4));
+            ws->dev_bytes = total + total / 4;
+        }
+        char* base = static_cast<char*>(ws->dev);
+        for (const auto& w : want) { w.first->p = base; base += (std::max<size_t>(w.second, 8) + 255) / 256 * 256; }
+        if (!ws->pinned) LM_CHK(hipHostMalloc((void**)&ws->pinned, 24 * sizeof(double), hipHostMallocDefault));
+    }
     int rc;
     if ((rc = up(b_lf, lf, stream)) || (rc = up(b_fci, fci, stream)) || (rc = up(b_fpi, fpi, stream)) || (rc = up(b_free, freem, stream)) ||
         (rc = up(b_cptr, cam_ptr, stream)) || (rc = up(b_clist, cam_list, stream)) || (rc = up(b_pptr, pt_ptr, stream)) ||
@@ -654,15 +678,6 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     D.lf = b_lf.as<int>(); D.fci = b_fci.as<int>(); D.fpi = b_fpi.as<int>(); D.freem = b_free.as<unsigned char>();
     D.cam_ptr = b_cptr.as<int>(); D.cam_list = b_clist.as<int>(); D.pt_ptr = b_pptr.as<int>(); D.pt_list = b_plist.as<int>();
     D.cam_id = b_cid.as<int>(); D.pt_id = b_pid.as<int>();
-    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Spart, S, rhs, dc, dp, psave, part, sc;
-    const size_t MM = (size_t)D.Mp * D.Mp;
-    LM_CHK(Jc.alloc((size_t)nf * 72 * D.R)); LM_CHK(Jp.alloc((size_t)nf * 24 * D.R)); LM_CHK(e.alloc((size_t)nf * 8 * D.R));
-    LM_CHK(U.alloc((size_t)std::max(nca, 1) * 81 * 8)); LM_CHK(bc.alloc((size_t)D.Mp * 8));
-    LM_CHK(V.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(bp.alloc((size_t)std::max(npa, 1) * 24));
-    LM_CHK(Lp.alloc((size_t)std::max(npa, 1) * 48)); LM_CHK(yp.alloc((size_t)D.Kp * 8)); LM_CHK(T.alloc((size_t)nf * 24 * D.R));
-    LM_CHK(Zt.alloc((size_t)D.Kp * D.Mp * 8)); LM_CHK(Spart.alloc(MM * 8 * (size_t)D.SK)); LM_CHK(S.alloc(MM * 8));
-    LM_CHK(rhs.alloc((size_t)D.Mp * 8)); LM_CHK(dc.alloc((size_t)D.Mp * 8)); LM_CHK(dp.alloc((size_t)D.Kp * 8));
-    LM_CHK(psave.alloc((size_t)(9 * nca + 3 * npa + 1) * 8)); LM_CHK(part.alloc(4096 * 8)); LM_CHK(sc.alloc(16 * 8));
     D.Jc = Jc.as<double>(); D.Jp = Jp.as<double>(); D.e = e.as<double>(); D.U = U.as<double>(); D.bc = bc.as<double>();
     D.V = V.as<double>(); D.bp = bp.as<double>(); D.Lp = Lp.as<double>(); D.yp = yp.as<double>(); D.T = T.as<double>();
     D.Zt = Zt.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
@@ -677,9 +692,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     const int gf = (int)((nf + 255) / 256), gp = (npa + 255) / 256, gobj = (int)std::min<int64_t>(gf, 2048);
     // Host <-> device scalars go through one pinned buffer: h[0..15] the device's D.sc, h[16..17] the
     // damping (mu, floor) of the next attempt.
-    Pinned hp;
-    LM_CHK(hipHostMalloc((void**)&hp.p, 24 * sizeof(double), hipHostMallocDefault));
-    double* h = hp.p;
+    double* h = ws->pinned;
     std::memset(h, 0, 24 * sizeof(double));
     auto fetch_scalars = [&]() -> int { LM_CHK(hipMemcpyAsync(h, D.sc, 16 * sizeof(double), hipMemcpyDeviceToHost, stream)); return 0; };
     auto objective = [&](int slot) -> int {

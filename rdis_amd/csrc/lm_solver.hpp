@@ -32,9 +32,20 @@ struct LmResult {
     std::vector<LmStep> history;    // one entry per linear solve
 };
 
+// device scratch and pinned host scalars of the solver, kept by the caller between solves (grown on demand)
+struct LmWorkspace {
+    void* dev = nullptr;
+    size_t dev_bytes = 0;
+    double* pinned = nullptr;
+    LmWorkspace() = default;
+    LmWorkspace(const LmWorkspace&) = delete;
+    LmWorkspace& operator=(const LmWorkspace&) = delete;
+    ~LmWorkspace();
+};
+
 // free_vid / fac: host arrays (sorted ascending not required).  x is updated in place: the free
 // variables end at the clamped result.  Returns 0, a hipError_t (> 0), or -1 with *err set.
 int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const int64_t* free_vid, int64_t nf,
-                 const int64_t* fac, const LmOptions& opt, LmResult* out, std::string* err);
+                 const int64_t* fac, const LmOptions& opt, LmWorkspace* ws, LmResult* out, std::string* err);
 
 }  // namespace rdis_hip

@@ -107,6 +107,7 @@ struct rdis_hip_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct rdis_hip_plan* last_timed_plan = nullptr;
     std::vector<int> h_owner, h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
+    LmWorkspace lm_ws;                     // scratch of rdis_hip_lm_optimize, kept between calls
     ComponentLists comps;                  // result of the last rdis_hip_components call
     DevBuf assigned;
     int stamp = 0;
@@ -1332,7 +1333,7 @@ extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const in
     LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol, model};
     LmResult r;
     std::string err;
-    const int e = device_lm_ba(c->stream, P, nfree, free_vid, nf, fac_id, o, &r, &err);
+    const int e = device_lm_ba(c->stream, P, nfree, free_vid, nf, fac_id, o, &p->lm_ws, &r, &err);
     if (e < 0) return fail(c, RDIS_HIP_EINVAL, err);
     if (e > 0) return fail(c, RDIS_HIP_EDEVICE, std::string("lm_optimize: ") + hipGetErrorString((hipError_t)e));
     if (x_inout) {
