@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a fresh checkout has no built libraries (they are git-ignored): build them once, the way the
+    # driver's build check does (hipcc cross-compiles without a GPU)
+    if not os.path.exists(os.path.join(ROOT, "rdis_amd", "lib", "librdis_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
