@@ -158,10 +158,8 @@ struct IsRoot {
     __host__ __device__ int operator()(int v) const { return label[v] == v ? 1 : 0; }
 };
 
-struct Buf {
+struct Buf {   // a slice of the caller's workspace
     void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -175,18 +173,46 @@ inline int grid_for(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>
 
 }  // namespace
 
+CcWorkspace::~CcWorkspace() { if (dev) (void)hipFree(dev); }
+
 int device_components(hipStream_t stream, int kind, int N, int F, const int* cam, const int* pt, const int* rowptr,
-                      const int* vid, const unsigned char* assigned_dev, ComponentLists* out) {
+                      const int* vid, const unsigned char* assigned_dev, CcWorkspace* ws, ComponentLists* out) {
     out->ncomp = out->nfree = out->nfac = 0;
     out->free_ptr.clear(); out->free_vid.clear(); out->fac_ptr.clear(); out->fac_id.clear();
     if (N <= 0) { out->free_ptr.assign(1, 0); out->fac_ptr.assign(1, 0); return 0; }
     const int M = std::max(N, std::max(F, 1));
-    Buf parent, count, label, key64, val, val2, key64b, key32, key32b, comp_of_root, comp_nvars, comp_nfac, tmp;
-    CC_CHK(parent.alloc((size_t)N * 4)); CC_CHK(count.alloc((size_t)N * 4)); CC_CHK(label.alloc((size_t)N * 4));
-    CC_CHK(key64.alloc((size_t)N * 8)); CC_CHK(key64b.alloc((size_t)N * 8));
-    CC_CHK(val.alloc((size_t)M * 4)); CC_CHK(val2.alloc((size_t)M * 4));
-    CC_CHK(key32.alloc((size_t)M * 4)); CC_CHK(key32b.alloc((size_t)M * 4));
-    CC_CHK(comp_of_root.alloc((size_t)N * 4)); CC_CHK(comp_nvars.alloc((size_t)N * 4)); CC_CHK(comp_nfac.alloc((size_t)N * 4));
+    // every device buffer is a slice of one workspace kept by the caller between calls (a dozen
+    // allocations and releases per labelling otherwise); the sizes of the library's scratch first
+    Buf parent, count, label, key64, val, val2, key64b, key32, key32b, comp_of_root, comp_nvars, comp_nfac, tmp, nsel, rtmp;
+    size_t tb = 0, tb2 = 0, tb3 = 0, rb = 0;
+    {
+        unsigned long long* k64 = nullptr;
+        int* i32 = nullptr;
+        CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k64, k64, i32, i32, N, 0, 64, stream));
+        CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, i32, i32, i32, i32, N, 0, 32, stream));
+        CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, i32, i32, i32, i32, std::max(F, 1), 0, 32, stream));
+        hipcub::CountingInputIterator<int> idx(0);
+        hipcub::TransformInputIterator<int, IsRoot, hipcub::CountingInputIterator<int>> it(idx, IsRoot{nullptr});
+        CC_CHK(hipcub::DeviceReduce::Sum(nullptr, rb, it, i32, N, stream));
+    }
+    const size_t tbytes = std::max(tb, std::max(tb2, tb3));
+    {
+        const std::pair<Buf*, size_t> want[] = {
+            {&parent, (size_t)N * 4}, {&count, (size_t)N * 4}, {&label, (size_t)N * 4}, {&key64, (size_t)N * 8}, {&key64b, (size_t)N * 8},
+            {&val, (size_t)M * 4}, {&val2, (size_t)M * 4}, {&key32, (size_t)M * 4}, {&key32b, (size_t)M * 4},
+            {&comp_of_root, (size_t)N * 4}, {&comp_nvars, (size_t)N * 4}, {&comp_nfac, (size_t)N * 4},
+            {&tmp, tbytes}, {&nsel, 8}, {&rtmp, rb}};
+        size_t total = 0;
+        for (const auto& w : want) total += (std::max<size_t>(w.second, 8) + 255) / 256 * 256;
+        if (ws->bytes < total) {
+            CC_CHK(hipStreamSynchronize(stream));
+            if (ws->dev) { CC_CHK(hipFree(ws->dev)); ws->dev = nullptr; ws->bytes = 0; }
+            CC_CHK(hipMalloc(&ws->dev, total + total / 4));
+            ws->bytes = total + total / 4;
+        }
+        char* base = static_cast<char*>(ws->dev);
+        for (const auto& w : want) { w.first->p = base; base += (std::max<size_t>(w.second, 8) + 255) / 256 * 256; }
+    }
 
     cc_init_kernel<<<grid_for(N), 256, 0, stream>>>(N, parent.as<int>(), count.as<int>());
     if (F > 0)
@@ -196,25 +222,14 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
                                                         key64.as<unsigned long long>(), val.as<int>());
     CC_CHK(hipGetLastError());
     // roots by (number of variables, id)
-    size_t tb = 0, tb2 = 0, tb3 = 0;
-    CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key64.as<unsigned long long>(), key64b.as<unsigned long long>(),
-                                             val.as<int>(), val2.as<int>(), N, 0, 64, stream));
-    CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), N, 0, 32, stream));
-    CC_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb3, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), std::max(F, 1), 0, 32, stream));
-    CC_CHK(tmp.alloc(std::max(tb, std::max(tb2, tb3))));
-    size_t tbytes = std::max(tb, std::max(tb2, tb3));
-    CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, key64.as<unsigned long long>(), key64b.as<unsigned long long>(),
+    size_t tbytes_ = tbytes;
+    CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key64.as<unsigned long long>(), key64b.as<unsigned long long>(),
                                              val.as<int>(), val2.as<int>(), N, 0, 64, stream));
     // number of components = number of roots
     int ncomp = 0;
     {
-        Buf nsel, rtmp;
-        CC_CHK(nsel.alloc(8));
         hipcub::CountingInputIterator<int> idx(0);
         hipcub::TransformInputIterator<int, IsRoot, hipcub::CountingInputIterator<int>> it(idx, IsRoot{label.as<int>()});
-        size_t rb = 0;
-        CC_CHK(hipcub::DeviceReduce::Sum(nullptr, rb, it, nsel.as<int>(), N, stream));
-        CC_CHK(rtmp.alloc(rb));
         CC_CHK(hipcub::DeviceReduce::Sum(rtmp.p, rb, it, nsel.as<int>(), N, stream));
         CC_CHK(hipMemcpyAsync(&ncomp, nsel.p, 4, hipMemcpyDeviceToHost, stream));
         CC_CHK(hipStreamSynchronize(stream));
@@ -229,7 +244,7 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
     // variables grouped by component (stable: ascending id inside a component)
     cc_var_keys_kernel<<<grid_for(N), 256, 0, stream>>>(N, label.as<int>(), comp_of_root.as<int>(), key32.as<int>(), val.as<int>());
     CC_CHK(hipGetLastError());
-    CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), N, 0, 32, stream));
+    CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), N, 0, 32, stream));
     std::vector<int> h_nvars((size_t)ncomp), h_nfac((size_t)ncomp);
     CC_CHK(hipMemcpyAsync(h_nvars.data(), comp_nvars.p, (size_t)ncomp * 4, hipMemcpyDeviceToHost, stream));
     CC_CHK(hipStreamSynchronize(stream));
@@ -248,7 +263,7 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
         cc_fac_keys_kernel<<<grid_for(F), 256, 0, stream>>>(kind, F, cam, pt, rowptr, vid, label.as<int>(), comp_of_root.as<int>(),
                                                            key32.as<int>(), val.as<int>(), comp_nfac.as<int>());
         CC_CHK(hipGetLastError());
-        CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), F, 0, 32, stream));
+        CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), F, 0, 32, stream));
     }
     CC_CHK(hipMemcpyAsync(h_nfac.data(), comp_nfac.p, (size_t)ncomp * 4, hipMemcpyDeviceToHost, stream));
     CC_CHK(hipStreamSynchronize(stream));

@@ -108,6 +108,7 @@ struct rdis_hip_problem {
     struct rdis_hip_plan* last_timed_plan = nullptr;
     std::vector<int> h_owner, h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
     LmWorkspace lm_ws;                     // scratch of rdis_hip_lm_optimize, kept between calls
+    CcWorkspace cc_ws;                     // ... and of rdis_hip_components
     ComponentLists comps;                  // result of the last rdis_hip_components call
     DevBuf assigned;
     int stamp = 0;
@@ -1365,7 +1366,7 @@ extern "C" int rdis_hip_components(rdis_hip_problem* p, const uint8_t* assigned,
     if (rc) return rc;
     if (p->N > 0) HIPCHK(c, hipMemcpyAsync(p->assigned.p, assigned, (size_t)p->N, hipMemcpyHostToDevice, c->stream));
     const int e = device_components(c->stream, p->kind, (int)p->N, (int)p->F, p->cam.as<int>(), p->pt.as<int>(),
-                                    p->rowptr.as<int>(), p->vid.as<int>(), p->assigned.as<unsigned char>(), &p->comps);
+                                    p->rowptr.as<int>(), p->vid.as<int>(), p->assigned.as<unsigned char>(), &p->cc_ws, &p->comps);
     if (e != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("components: ") + hipGetErrorString((hipError_t)e));
     if (ncomp) *ncomp = p->comps.ncomp;
     if (nfree) *nfree = p->comps.nfree;
