@@ -183,7 +183,7 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
     const int M = std::max(N, std::max(F, 1));
     // every device buffer is a slice of one workspace kept by the caller between calls (a dozen
     // allocations and releases per labelling otherwise); the sizes of the library's scratch first
-    Buf parent, count, label, key64, val, val2, key64b, key32, key32b, comp_of_root, comp_nvars, comp_nfac, tmp, nsel, rtmp;
+    Buf parent, count, label, key64, val, val2, val3, key64b, key32, key32b, comp_of_root, comp_nvars, comp_nfac, tmp, nsel, rtmp;
     size_t tb = 0, tb2 = 0, tb3 = 0, rb = 0;
     {
         unsigned long long* k64 = nullptr;
@@ -199,7 +199,7 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
     {
         const std::pair<Buf*, size_t> want[] = {
             {&parent, (size_t)N * 4}, {&count, (size_t)N * 4}, {&label, (size_t)N * 4}, {&key64, (size_t)N * 8}, {&key64b, (size_t)N * 8},
-            {&val, (size_t)M * 4}, {&val2, (size_t)M * 4}, {&key32, (size_t)M * 4}, {&key32b, (size_t)M * 4},
+            {&val, (size_t)M * 4}, {&val2, (size_t)M * 4}, {&val3, (size_t)M * 4}, {&key32, (size_t)M * 4}, {&key32b, (size_t)M * 4},
             {&comp_of_root, (size_t)N * 4}, {&comp_nvars, (size_t)N * 4}, {&comp_nfac, (size_t)N * 4},
             {&tmp, tbytes}, {&nsel, 8}, {&rtmp, rb}};
         size_t total = 0;
@@ -245,38 +245,31 @@ int device_components(hipStream_t stream, int kind, int N, int F, const int* cam
     cc_var_keys_kernel<<<grid_for(N), 256, 0, stream>>>(N, label.as<int>(), comp_of_root.as<int>(), key32.as<int>(), val.as<int>());
     CC_CHK(hipGetLastError());
     CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), N, 0, 32, stream));
-    std::vector<int> h_nvars((size_t)ncomp), h_nfac((size_t)ncomp);
-    CC_CHK(hipMemcpyAsync(h_nvars.data(), comp_nvars.p, (size_t)ncomp * 4, hipMemcpyDeviceToHost, stream));
-    CC_CHK(hipStreamSynchronize(stream));
-    int64_t nfree = 0;
-    for (int i = 0; i < ncomp; ++i) { out->free_ptr[(size_t)i] = nfree; nfree += h_nvars[(size_t)i]; }
-    out->free_ptr[(size_t)ncomp] = nfree;
-    out->nfree = nfree;
-    {
-        std::vector<int> h((size_t)nfree);
-        CC_CHK(hipMemcpyAsync(h.data(), val2.p, (size_t)nfree * 4, hipMemcpyDeviceToHost, stream));
-        CC_CHK(hipStreamSynchronize(stream));
-        out->free_vid.assign(h.begin(), h.end());
-    }
-    // factors grouped by component (stable: ascending id)
+    // factors grouped by component (stable: ascending id), into a buffer of their own so that both
+    // sorted lists can be fetched together
     if (F > 0) {
         cc_fac_keys_kernel<<<grid_for(F), 256, 0, stream>>>(kind, F, cam, pt, rowptr, vid, label.as<int>(), comp_of_root.as<int>(),
                                                            key32.as<int>(), val.as<int>(), comp_nfac.as<int>());
         CC_CHK(hipGetLastError());
-        CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key32.as<int>(), key32b.as<int>(), val.as<int>(), val2.as<int>(), F, 0, 32, stream));
+        CC_CHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes_, key32.as<int>(), key32b.as<int>(), val.as<int>(), val3.as<int>(), F, 0, 32, stream));
     }
+    std::vector<int> h_nvars((size_t)ncomp), h_nfac((size_t)ncomp);
+    CC_CHK(hipMemcpyAsync(h_nvars.data(), comp_nvars.p, (size_t)ncomp * 4, hipMemcpyDeviceToHost, stream));
     CC_CHK(hipMemcpyAsync(h_nfac.data(), comp_nfac.p, (size_t)ncomp * 4, hipMemcpyDeviceToHost, stream));
     CC_CHK(hipStreamSynchronize(stream));
-    int64_t nfac = 0;
-    for (int i = 0; i < ncomp; ++i) { out->fac_ptr[(size_t)i] = nfac; nfac += h_nfac[(size_t)i]; }
-    out->fac_ptr[(size_t)ncomp] = nfac;
-    out->nfac = nfac;
-    if (nfac > 0) {
-        std::vector<int> h((size_t)nfac);
-        CC_CHK(hipMemcpyAsync(h.data(), val2.p, (size_t)nfac * 4, hipMemcpyDeviceToHost, stream));
-        CC_CHK(hipStreamSynchronize(stream));
-        out->fac_id.assign(h.begin(), h.end());
+    int64_t nfree = 0, nfac = 0;
+    for (int i = 0; i < ncomp; ++i) {
+        out->free_ptr[(size_t)i] = nfree; nfree += h_nvars[(size_t)i];
+        out->fac_ptr[(size_t)i] = nfac; nfac += h_nfac[(size_t)i];
     }
+    out->free_ptr[(size_t)ncomp] = nfree; out->nfree = nfree;
+    out->fac_ptr[(size_t)ncomp] = nfac; out->nfac = nfac;
+    std::vector<int> hv((size_t)nfree), hf((size_t)nfac);
+    if (nfree > 0) CC_CHK(hipMemcpyAsync(hv.data(), val2.p, (size_t)nfree * 4, hipMemcpyDeviceToHost, stream));
+    if (nfac > 0) CC_CHK(hipMemcpyAsync(hf.data(), val3.p, (size_t)nfac * 4, hipMemcpyDeviceToHost, stream));
+    CC_CHK(hipStreamSynchronize(stream));
+    out->free_vid.assign(hv.begin(), hv.end());
+    out->fac_id.assign(hf.begin(), hf.end());
     return 0;
 }
 
