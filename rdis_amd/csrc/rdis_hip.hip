@@ -1179,8 +1179,9 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(bs, c->ev_fork, 0));
     }
-    for (const CoopLaunch& cl : L->coop_launches) {
-        int rc = launch_coop(c->stream, p->kind, p->view(), V, cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+    for (size_t l = 0; l < L->coop_launches.size(); ++l) {
+        const CoopLaunch& cl = L->coop_launches[l];
+        int rc = launch_coop(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
                              cl.count, cl.total_wg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;

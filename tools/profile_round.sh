@@ -14,7 +14,7 @@ for w in ladybug-full synthetic-S synthetic-L; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/$w -o fetch -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $D/err.txt
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/$w -o write -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $D/err.txt
 done
-python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_coop_kernel
+python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_coop_
 python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_wg_kernel
 python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_wg_kernel
 cp profiles/traffic.json $D/
