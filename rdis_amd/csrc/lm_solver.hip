@@ -514,15 +514,18 @@ __global__ void __launch_bounds__(256) k_back(Dev D) {
     D.dp[3ll * p] = d0; D.dp[3ll * p + 1] = d1; D.dp[3ll * p + 2] = d2;
 }
 
-// ---- 9. trial point, |Dp|^2, dL = Dp . (mu Dp + J^T e) (one block) --------------------------------
+// ---- 9. trial point, |Dp|^2, dL = Dp . (mu Dp + J^T e) -------------------------------------------
 // mode 0: x = psave + Dp (model 2: clamped into the domain);  mode 1: psave = x (accept);  mode 2: x = psave (restore);
-// mode 3: x = clamp(psave) (final, LMSubspaceOptimizer.cpp:104-108)
+// mode 3: x = clamp(psave) (final, LMSubspaceOptimizer.cpp:104-108).  Several blocks; for mode 0 the
+// block that finishes last adds the blocks' partial sums in block order.
+constexpr int APPLY_MAX_BLOCKS = 1024, SC_TICKET = 12;
 __global__ void __launch_bounds__(1024) k_apply(Dev D, int mode) {
     const double mu = D.sc[SC_MU], floor_ = D.sc[SC_FLOOR];
     __shared__ double r0[16], r1[16];
+    __shared__ bool last;
     double dl2 = 0.0, dL = 0.0;
     const int nc9 = 9 * D.nca, ntot = nc9 + 3 * D.npa;
-    for (int t = threadIdx.x; t < ntot; t += 1024) {
+    for (int t = blockIdx.x * 1024 + threadIdx.x; t < ntot; t += gridDim.x * 1024) {
         int v; double dpv, b, dg;
         if (t < nc9) { v = D.cam_id[t / 9] + t % 9; dpv = D.nca ? D.dc[t] : 0.0; b = D.bc[t]; dg = D.U[81ll * (t / 9) + 10 * (t % 9)]; }
         else { const int u = t - nc9, k = u % 3; v = D.pt_id[u / 3] + k; dpv = D.dp[u]; b = D.bp[u]; dg = D.V[6ll * (u / 3) + (k == 0 ? 0 : k == 1 ? 2 : 5)]; }
@@ -549,10 +552,24 @@ __global__ void __launch_bounds__(1024) k_apply(Dev D, int mode) {
     dl2 = wsum(dl2); dL = wsum(dL);
     if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = dl2; r1[threadIdx.x >> 6] = dL; }
     __syncthreads();
+    double* part = D.part + 2048;   // (k_obj's partials occupy the first half)
+    unsigned* ticket = reinterpret_cast<unsigned*>(D.sc + SC_TICKET);
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0;
         for (int w = 0; w < 16; ++w) { a += r0[w]; b += r1[w]; }
-        D.sc[3] = a; D.sc[4] = b;
+        part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        if (last) {
+            __threadfence();
+            double sa = 0.0, sb = 0.0;
+            for (unsigned q = 0; q < gridDim.x; ++q) {
+                sa += __hip_atomic_load(part + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sb += __hip_atomic_load(part + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            D.sc[3] = sa; D.sc[4] = sb;
+            *ticket = 0u;
+        }
     }
 }
 
@@ -682,6 +699,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     D.V = V.as<double>(); D.bp = bp.as<double>(); D.Lp = Lp.as<double>(); D.yp = yp.as<double>(); D.T = T.as<double>();
     D.Zt = Zt.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
     D.dc = dc.as<double>(); D.dp = dp.as<double>(); D.psave = psave.as<double>(); D.part = part.as<double>(); D.sc = sc.as<double>();
+    LM_CHK(hipMemsetAsync(D.sc, 0, 16 * 8, stream));                      // (the workspace is reused: k_apply's ticket starts at zero)
     LM_CHK(hipMemsetAsync(D.Zt, 0, (size_t)D.Kp * D.Mp * 8, stream));   // the block pattern of Z is fixed: zero once
     LM_CHK(hipMemsetAsync(D.bc, 0, (size_t)D.Mp * 8, stream));
     LM_CHK(hipMemsetAsync(D.yp, 0, (size_t)D.Kp * 8, stream));
@@ -690,6 +708,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     LM_CHK(hipMemsetAsync(D.rhs, 0, (size_t)D.Mp * 8, stream));
 
     const int gf = (int)((nf + 255) / 256), gp = (npa + 255) / 256, gobj = (int)std::min<int64_t>(gf, 2048);
+    const int gapply = std::max(1, std::min(APPLY_MAX_BLOCKS, (9 * nca + 3 * npa + 1023) / 1024));
     // Host <-> device scalars go through one pinned buffer: h[0..15] the device's D.sc, h[16..17] the
     // damping (mu, floor) of the next attempt.
     double* h = ws->pinned;
@@ -734,7 +753,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             k_trsv<<<1, 1024, 0, stream>>>(D);
         }
         if (npa) k_back<<<gp, 256, 0, stream>>>(D);
-        k_apply<<<1, 1024, 0, stream>>>(D, 0);
+        k_apply<<<gapply, 1024, 0, stream>>>(D, 0);
         LM_CHK(hipGetLastError());
         int rc_ = objective(5);
         return rc_ ? rc_ : fetch_scalars();
@@ -747,7 +766,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         return 0;
     };
 
-    k_apply<<<1, 1024, 0, stream>>>(D, 1);   // psave = x
+    k_apply<<<gapply, 1024, 0, stream>>>(D, 1);   // psave = x
     if ((rc = objective(5)) || (rc = fetch_scalars())) return rc;
     LM_CHK(hipStreamSynchronize(stream));
     double p_eL2 = 2.0 * h[5];
@@ -789,7 +808,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                     mu = mu * (tmp >= ONE_THIRD ? tmp : ONE_THIRD);
                     nu = 2;
                     p_eL2 = pDp_eL2;
-                    k_apply<<<1, 1024, 0, stream>>>(D, 1);   // accept: psave = x
+                    k_apply<<<gapply, 1024, 0, stream>>>(D, 1);   // accept: psave = x
                     break;
                 }
             }
@@ -801,7 +820,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         ++k;
     }
     if (!stop) stop = 3;
-    k_apply<<<1, 1024, 0, stream>>>(D, 3);   // x = clamp(accepted point)
+    k_apply<<<gapply, 1024, 0, stream>>>(D, 3);   // x = clamp(accepted point)
     if ((rc = objective(5)) || (rc = fetch_scalars())) return rc;
     LM_CHK(hipStreamSynchronize(stream));
     out->fret = h[5];
