@@ -171,21 +171,26 @@ __global__ void __launch_bounds__(64 * CAM_WAVES) k_cam(Dev D) {
 }
 
 // ---- 3. point blocks: V_p (lower triangle, 6 numbers), bp ------------------------------------
+// (sixteen lanes per point, like k_back)
 __global__ void __launch_bounds__(256) k_pt(Dev D) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
     if (p >= D.npa) return;
-    double v00 = 0, v10 = 0, v11 = 0, v20 = 0, v21 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
-    for (int t = D.pt_ptr[p]; t < D.pt_ptr[p + 1]; ++t) {
-        for (int r = 0; r < D.R; ++r) {
-            const long long jr = (long long)D.pt_list[t] * D.R + r;
-            const double a = D.Jp[3 * jr], b = D.Jp[3 * jr + 1], c = D.Jp[3 * jr + 2], ev = D.e[jr];
-            v00 += a * a; v10 += b * a; v11 += b * b; v20 += c * a; v21 += c * b; v22 += c * c;
-            b0 += a * ev; b1 += b * ev; b2 += c * ev;
-        }
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // v00 v10 v11 v20 v21 v22 b0 b1 b2
+    const int t0 = D.pt_ptr[p], nrows = (D.pt_ptr[p + 1] - t0) * D.R;
+    for (int rr = sub; rr < nrows; rr += 16) {
+        const long long jr = (long long)D.pt_list[t0 + rr / D.R] * D.R + rr % D.R;
+        const double a = D.Jp[3 * jr], b = D.Jp[3 * jr + 1], c = D.Jp[3 * jr + 2], ev = D.e[jr];
+        acc[0] += a * a; acc[1] += b * a; acc[2] += b * b; acc[3] += c * a; acc[4] += c * b; acc[5] += c * c;
+        acc[6] += a * ev; acc[7] += b * ev; acc[8] += c * ev;
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        for (int o = 8; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (sub != 0) return;
     double* V = D.V + 6ll * p;
-    V[0] = v00; V[1] = v10; V[2] = v11; V[3] = v20; V[4] = v21; V[5] = v22;
-    D.bp[3ll * p] = -b0; D.bp[3ll * p + 1] = -b1; D.bp[3ll * p + 2] = -b2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) V[k] = acc[k];
+    D.bp[3ll * p] = -acc[6]; D.bp[3ll * p + 1] = -acc[7]; D.bp[3ll * p + 2] = -acc[8];
 }
 
 // ---- 4. scalars: max diag(J^T J), |J^T e|_inf, |p|^2 (one block) --------------------------------
@@ -490,22 +495,24 @@ __global__ void __launch_bounds__(1024) k_trsv(Dev D) {
 }
 
 // ---- 8. back-substitution for the points ------------------------------------------------------
+// sixteen lanes per point: a point of ladybug has up to 29 factors (58 Jacobian rows), one lane each
 __global__ void __launch_bounds__(256) k_back(Dev D) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= D.npa) return;
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (p >= D.npa) return;   // (whole groups of sixteen leave together)
     double s0 = 0, s1 = 0, s2 = 0;
-    for (int t = D.pt_ptr[p]; t < D.pt_ptr[p + 1]; ++t) {
-        const int j = D.pt_list[t];
+    const int t0 = D.pt_ptr[p], nrows = (D.pt_ptr[p + 1] - t0) * D.R;
+    for (int rr = sub; rr < nrows; rr += 16) {
+        const int j = D.pt_list[t0 + rr / D.R];
         const int ci = D.fci[j];
         if (ci < 0) continue;
-        for (int r = 0; r < D.R; ++r) {
-            const long long jr = (long long)j * D.R + r;
-            double w = 0.0;
+        const long long jr = (long long)j * D.R + rr % D.R;
+        double w = 0.0;
 #pragma unroll
-            for (int a = 0; a < 9; ++a) w += D.Jc[9 * jr + a] * D.dc[9 * ci + a];
-            s0 += D.T[3 * jr] * w; s1 += D.T[3 * jr + 1] * w; s2 += D.T[3 * jr + 2] * w;
-        }
+        for (int a = 0; a < 9; ++a) w += D.Jc[9 * jr + a] * D.dc[9 * ci + a];
+        s0 += D.T[3 * jr] * w; s1 += D.T[3 * jr + 1] * w; s2 += D.T[3 * jr + 2] * w;
     }
+    for (int o = 8; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (sub != 0) return;
     const double* L = D.Lp + 6ll * p;
     const double r0 = D.yp[3ll * p] - s0, r1 = D.yp[3ll * p + 1] - s1, r2 = D.yp[3ll * p + 2] - s2;
     const double d2 = r2 / L[5];
@@ -725,7 +732,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     auto enqueue_linearise = [&]() -> int {
         k_lin<<<gf, 256, 0, stream>>>(D);
         if (nca) k_cam<<<nca, 64 * CAM_WAVES, 0, stream>>>(D);
-        if (npa) k_pt<<<gp, 256, 0, stream>>>(D);
+        if (npa) k_pt<<<(npa + 15) / 16, 256, 0, stream>>>(D);
         k_scalars<<<1, 1024, 0, stream>>>(D);
         LM_CHK(hipGetLastError());
         return fetch_scalars();
@@ -752,7 +759,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             }
             k_trsv<<<1, 1024, 0, stream>>>(D);
         }
-        if (npa) k_back<<<gp, 256, 0, stream>>>(D);
+        if (npa) k_back<<<(npa + 15) / 16, 256, 0, stream>>>(D);
         k_apply<<<gapply, 1024, 0, stream>>>(D, 0);
         LM_CHK(hipGetLastError());
         int rc_ = objective(5);
