@@ -326,24 +326,33 @@ __global__ void __launch_bounds__(256) k_sfinish(Dev D) {
 }
 // rhs = bc - Z y, one wave per active camera over its factor list: Z's block of factor j times y_p
 // is Jc_j (T_j . y_p)
-__global__ void __launch_bounds__(64) k_rhs(Dev D) {
-    const int c = blockIdx.x, l = threadIdx.x;
-    if (c == 0) for (int t = D.M + l; t < D.Mp; t += 64) D.dc[t] = 0.0;   // the padding, whatever a failed solve left there
+constexpr int RHS_WAVES = 8;   // (a camera of ladybug has 361-906 factors: eight waves share them)
+__global__ void __launch_bounds__(64 * RHS_WAVES) k_rhs(Dev D) {
+    __shared__ double part[RHS_WAVES][9];
+    const int c = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (c == 0) for (int t = D.M + (int)threadIdx.x; t < D.Mp; t += 64 * RHS_WAVES) D.dc[t] = 0.0;   // the padding, whatever a failed solve left there
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = D.cam_ptr[c] + l; t < D.cam_ptr[c + 1]; t += 64) {
+    for (int t = D.cam_ptr[c] + (int)threadIdx.x; t < D.cam_ptr[c + 1]; t += 64 * RHS_WAVES) {
         const int j = D.cam_list[t], pi = D.fpi[j];
         if (pi < 0) continue;
         for (int r = 0; r < D.R; ++r) {
             const long long jr = (long long)j * D.R + r;
-            const double w = D.T[3 * jr] * D.yp[3ll * pi] + D.T[3 * jr + 1] * D.yp[3ll * pi + 1] + D.T[3 * jr + 2] * D.yp[3ll * pi + 2];
+            const double wv = D.T[3 * jr] * D.yp[3ll * pi] + D.T[3 * jr + 1] * D.yp[3ll * pi + 1] + D.T[3 * jr + 2] * D.yp[3ll * pi + 2];
 #pragma unroll
-            for (int a = 0; a < 9; ++a) acc[a] += D.Jc[9 * jr + a] * w;
+            for (int a = 0; a < 9; ++a) acc[a] += D.Jc[9 * jr + a] * wv;
         }
     }
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         const double s = wsum(acc[a]);
-        if (l == 0) { const double v = D.bc[9 * c + a] - s; D.rhs[9 * c + a] = v; D.dc[9 * c + a] = v; }   // dc: the row the factorisation carries along
+        if (l == 0) part[w][a] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double s = 0.0;
+        for (int q = 0; q < RHS_WAVES; ++q) s += part[q][threadIdx.x];
+        const double v = D.bc[9 * c + threadIdx.x] - s;
+        D.rhs[9 * c + threadIdx.x] = v; D.dc[9 * c + threadIdx.x] = v;   // dc: the row the factorisation carries along
     }
 }
 
@@ -747,7 +756,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             const int nt = D.Mp / 64;
             k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
             k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D);
-            k_rhs<<<nca, 64, 0, stream>>>(D);
+            k_rhs<<<nca, 64 * RHS_WAVES, 0, stream>>>(D);
             LM_CHK(hipMemsetAsync(D.sc + 8, 0, 8, stream));
             for (int kb = 0; kb < D.Mp; kb += 32) {
                 const int rem = D.Mp - kb - 32;
