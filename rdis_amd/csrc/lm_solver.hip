@@ -375,8 +375,12 @@ __device__ __forceinline__ bool potf2_wave(double (&r)[32], int i) {
     for (int k = 0; k < 32; ++k) {
         const double dkk = bcast_lane(r[k], k);
         ok = ok && dkk > 0.0;
-        const double lkk = sqrt(dkk);
-        r[k] = i == k ? lkk : r[k] / lkk;          // (lanes above the diagonal carry values nobody reads)
+        // 1/sqrt(d) from the hardware estimate and two Newton steps (the square root and the division
+        // it replaces are a third of this loop's dependent chain); l_kk = d * rsqrt(d)
+        double y = __builtin_amdgcn_rsq(dkk);
+        y = y * (1.5 - 0.5 * dkk * y * y);
+        y = y * (1.5 - 0.5 * dkk * y * y);
+        r[k] = i == k ? dkk * y : r[k] * y;        // (lanes above the diagonal carry values nobody reads)
 #pragma unroll
         for (int c = k + 1; c < 32; ++c) r[c] -= r[k] * bcast_lane(r[k], c);
     }
