@@ -194,17 +194,20 @@ __global__ void __launch_bounds__(256) k_pt(Dev D) {
 }
 
 // ---- 4. scalars: max diag(J^T J), |J^T e|_inf, |p|^2 (one block) --------------------------------
+// several blocks; the block that finishes last combines the blocks' partials in block order
+constexpr int SCALARS_MAX_BLOCKS = 256, SC_TICKET2 = 13;
 __global__ void __launch_bounds__(1024) k_scalars(Dev D) {
     __shared__ double r0[16], r1[16], r2[16];
     double md = 0.0, mb = 0.0, pl = 0.0;
-    for (int t = threadIdx.x; t < 9 * D.nca; t += 1024) {
+    const int g0 = blockIdx.x * 1024 + threadIdx.x, gs = gridDim.x * 1024;
+    for (int t = g0; t < 9 * D.nca; t += gs) {
         const int c = t / 9, k = t - 9 * c;
         md = fmax(md, D.U[81ll * c + 10 * k]);
         mb = fmax(mb, fabs(D.bc[t]));
         const int v = D.cam_id[c] + k;
         if (D.freem[v]) { const double x = D.P.x[v]; pl += x * x; }
     }
-    for (int t = threadIdx.x; t < 3 * D.npa; t += 1024) {
+    for (int t = g0; t < 3 * D.npa; t += gs) {
         const int p = t / 3, k = t - 3 * p;
         md = fmax(md, D.V[6ll * p + (k == 0 ? 0 : k == 1 ? 2 : 5)]);
         mb = fmax(mb, fabs(D.bp[t]));
@@ -217,7 +220,21 @@ __global__ void __launch_bounds__(1024) k_scalars(Dev D) {
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0, s = 0.0;
         for (int w = 0; w < 16; ++w) { a = fmax(a, r0[w]); b = fmax(b, r1[w]); s += r2[w]; }
-        D.sc[0] = a; D.sc[1] = b; D.sc[2] = s;
+        double* part = D.part + 3072;   // (k_obj: [0, 2048), k_apply: [2048, 3072))
+        unsigned* ticket = reinterpret_cast<unsigned*>(D.sc + SC_TICKET2);
+        part[3 * blockIdx.x] = a; part[3 * blockIdx.x + 1] = b; part[3 * blockIdx.x + 2] = s;
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence();
+            a = 0.0; b = 0.0; s = 0.0;
+            for (unsigned q = 0; q < gridDim.x; ++q) {
+                a = fmax(a, __hip_atomic_load(part + 3 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b = fmax(b, __hip_atomic_load(part + 3 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                s += __hip_atomic_load(part + 3 * q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            D.sc[0] = a; D.sc[1] = b; D.sc[2] = s;
+            *ticket = 0u;
+        }
     }
 }
 
@@ -538,7 +555,7 @@ __global__ void __launch_bounds__(256) k_back(Dev D) {
 // mode 0: x = psave + Dp (model 2: clamped into the domain);  mode 1: psave = x (accept);  mode 2: x = psave (restore);
 // mode 3: x = clamp(psave) (final, LMSubspaceOptimizer.cpp:104-108).  Several blocks; for mode 0 the
 // block that finishes last adds the blocks' partial sums in block order.
-constexpr int APPLY_MAX_BLOCKS = 1024, SC_TICKET = 12;
+constexpr int APPLY_MAX_BLOCKS = 512, SC_TICKET = 12;
 __global__ void __launch_bounds__(1024) k_apply(Dev D, int mode) {
     const double mu = D.sc[SC_MU], floor_ = D.sc[SC_FLOOR];
     __shared__ double r0[16], r1[16];
@@ -746,7 +763,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
         k_lin<<<gf, 256, 0, stream>>>(D);
         if (nca) k_cam<<<nca, 64 * CAM_WAVES, 0, stream>>>(D);
         if (npa) k_pt<<<(npa + 15) / 16, 256, 0, stream>>>(D);
-        k_scalars<<<1, 1024, 0, stream>>>(D);
+        k_scalars<<<std::max(1, std::min(SCALARS_MAX_BLOCKS, (3 * npa + 9 * nca + 1023) / 1024)), 1024, 0, stream>>>(D);
         LM_CHK(hipGetLastError());
         return fetch_scalars();
     };
