@@ -77,6 +77,9 @@ def lib() -> C.CDLL:
         L.ro_ba_factor_eval.argtypes = [_f64p, C.c_double, C.c_double]
         L.ro_ba_factor_grad.restype = C.c_double
         L.ro_ba_factor_grad.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
+        L.ro_ba_factor_grad_ref.restype = C.c_double
+        L.ro_ba_factor_grad_ref.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
+        L.ro_set_ba_derivative.argtypes = [C.c_void_p, C.c_int]
         L.ro_create_ba.restype = C.c_void_p
         L.ro_create_ba.argtypes = [C.c_int64, _f64p, _f64p, _f64p, C.c_int64, _i64p, _i64p, _f64p]
         L.ro_create_nlp.restype = C.c_void_p
@@ -120,7 +123,10 @@ def _opt_i64(a):
 class OracleProblem:
     """CPU oracle instance for one rdis_amd.problems.PackedProblem."""
 
-    def __init__(self, pp, emulate_stale_cache: bool = True):
+    def __init__(self, pp, emulate_stale_cache: bool = True, derivative: str = "refchain"):
+        """derivative: "refchain" = the reference's forward chain operation by operation
+        (BundleAdjustmentFactor.cpp:351-554; reproduces the reference's recorded runs bit for bit),
+        "adjoint" = the independent reverse sweep (the derivation the device kernels use)"""
         L = lib()
         self.pp = pp
         x0 = np.ascontiguousarray(pp.x0, dtype=np.float64)
@@ -134,6 +140,10 @@ class OracleProblem:
             self.h = L.ro_create_nlp(pp.nvars, x0, lo, hi, pp.nfac, pp.coeff, pp.rowptr, pp.vid,
                                      pp.expo, pp.cons, pp.sine)
         L.ro_set_emulate_stale_cache(self.h, int(emulate_stale_cache))
+        self.set_derivative(derivative)
+
+    def set_derivative(self, derivative: str) -> None:
+        lib().ro_set_ba_derivative(self.h, {"refchain": 0, "adjoint": 1}[derivative])
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -251,6 +261,13 @@ def ba_factor_eval(vals, ox, oy) -> float:
 def ba_factor_grad(vals, ox, oy):
     g = np.empty(12)
     e = lib().ro_ba_factor_grad(np.ascontiguousarray(vals, dtype=np.float64), ox, oy, g)
+    return e, g
+
+
+def ba_factor_grad_ref(vals, ox, oy):
+    """the reference's forward-chain derivative (BundleAdjustmentFactor.cpp:351-554)"""
+    g = np.empty(12)
+    e = lib().ro_ba_factor_grad_ref(np.ascontiguousarray(vals, dtype=np.float64), ox, oy, g)
     return e, g
 
 

@@ -153,6 +153,84 @@ double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
     return E;
 }
 
+/* The reference's own derivative: the chain rule expanded forward, one variable at a time,
+ * every product and quotient in the order BundleAdjustmentFactor.cpp:351-554 forms it, so that
+ * an x86-64 build without FMA rounds every partial like the reference does.  This is what
+ * makes the oracle's CG trajectories reproduce the reference's recorded runs bit for bit
+ * (tests/test_oracle.py::test_reference_recorded_cgd_runs_*); the adjoint sweep above is an
+ * independent second derivation, compared with this one on every factor of ladybug.
+ *   col[0..2] = dP/d(that variable)  ->  dpp (quotient rule, .cpp:413-414)  ->  pixel  ->  E */
+static double chain_to_E(const ba_fwd *t, double f, const double dp[4], const double dP[3], double P22)
+{
+    /* dp = { dpixx/dppx, dpixx/dppy, dpixy/dppx, dpixy/dppy } */
+    const double dppx = (t->P[0] * dP[2] - t->P[2] * dP[0]) / P22;
+    const double dppy = (t->P[1] * dP[2] - t->P[2] * dP[1]) / P22;
+    const double drx = t->res[0] * (dp[0] * dppx + dp[1] * dppy);
+    const double dry = t->res[1] * (dp[2] * dppx + dp[3] * dppy);
+    return f * (drx + dry);
+}
+
+double ro_ba_factor_grad_ref(const double x[12], double ox, double oy, double g[12])
+{
+    ba_fwd t;
+    const double E = ba_forward(x, ox, oy, &t);
+    const double *q = x + 9, *v = t.v, *P = t.P, *pp = t.pp;
+    const double f = x[6], k1 = x[7], k2 = x[8];
+    const double r2 = t.r2, dstn = t.dstn, vdp = t.d;
+    const double *vxp = t.w;
+
+    const double tmp1 = 2.0 * (k1 + 2.0 * k2 * r2);                       /* .cpp:365 */
+    /* the reference evaluates sin/cos of theta again here (.cpp:368), also for theta == 0,
+     * where the forward pass above has the branch values 0 and 1: same numbers */
+    const double sinth = sin(t.theta), costh = cos(t.theta);
+    const double vnorm = t.theta;                                         /* .cpp:376 */
+    const double dEdpx = t.res[0], dEdpy = t.res[1];
+    const double P22 = P[2] * P[2];
+    const double pp00 = pp[0] * pp[0], pp01 = pp[0] * pp[1], pp11 = pp[1] * pp[1];
+    const double dp[4] = { dstn + tmp1 * pp00, tmp1 * pp01, tmp1 * pp01, dstn + tmp1 * pp11 };
+
+    /* dP/d(unit axis), dP/dtheta (.cpp:391-404) */
+    const double dPdvp[3][3] = {
+        { (vdp + v[0] * q[0]) * (1 - costh),  q[2] * sinth + v[0] * q[1] * (1 - costh), -q[1] * sinth + v[0] * q[2] * (1 - costh) },
+        { -q[2] * sinth + v[1] * q[0] * (1 - costh), (vdp + v[1] * q[1]) * (1 - costh),  q[0] * sinth + v[1] * q[2] * (1 - costh) },
+        {  q[1] * sinth + v[2] * q[0] * (1 - costh), -q[0] * sinth + v[2] * q[1] * (1 - costh), (vdp + v[2] * q[2]) * (1 - costh) } };
+    const double dPdth[3] = { -q[0] * sinth + vxp[0] * costh + v[0] * vdp * sinth,
+                              -q[1] * sinth + vxp[1] * costh + v[1] * vdp * sinth,
+                              -q[2] * sinth + vxp[2] * costh + v[2] * vdp * sinth };
+    /* d(unit axis)/d(rotation vector) (.cpp:407-409, 425-427, 443-445); dtheta/dr = v */
+    const double dvpdv[3][3] = {
+        { (v[1] * v[1] + v[2] * v[2]) / vnorm, -v[0] * v[1] / vnorm, -v[0] * v[2] / vnorm },
+        { -v[0] * v[1] / vnorm, (v[0] * v[0] + v[2] * v[2]) / vnorm, -v[1] * v[2] / vnorm },
+        { -v[0] * v[2] / vnorm, -v[1] * v[2] / vnorm, (v[0] * v[0] + v[1] * v[1]) / vnorm } };
+    for (int k = 0; k < 3; ++k) {
+        double dP[3];
+        for (int i = 0; i < 3; ++i)
+            dP[i] = dPdvp[i][0] * dvpdv[k][0] + dPdvp[i][1] * dvpdv[k][1] + dPdvp[i][2] * dvpdv[k][2] + dPdth[i] * v[k];
+        g[k] = chain_to_E(&t, f, dp, dP, P22);
+    }
+    /* point (.cpp:482-516) */
+    {
+        const double dPdq[3][3] = {
+            { costh * (1.0 - v[0] * v[0]) + v[0] * v[0], v[2] * sinth + v[0] * v[1] * (1.0 - costh), -v[1] * sinth + v[0] * v[2] * (1.0 - costh) },
+            { -v[2] * sinth + v[0] * v[1] * (1.0 - costh), costh * (1.0 - v[1] * v[1]) + v[1] * v[1], v[0] * sinth + v[1] * v[2] * (1.0 - costh) },
+            { v[1] * sinth + v[0] * v[2] * (1.0 - costh), -v[0] * sinth + v[1] * v[2] * (1.0 - costh), costh * (1.0 - v[2] * v[2]) + v[2] * v[2] } };
+        for (int k = 0; k < 3; ++k) g[9 + k] = chain_to_E(&t, f, dp, dPdq[k], P22);
+    }
+    /* translation (.cpp:518-530) */
+    g[3] = (dEdpx * dp[0] + dEdpy * dp[2]) * -f / P[2];
+    g[4] = (dEdpx * dp[1] + dEdpy * dp[3]) * -f / P[2];
+    {
+        const double dpxdtz = dp[0] * P[0] + dp[1] * P[1];
+        const double dpydtz = dp[2] * P[0] + dp[3] * P[1];
+        g[5] = (dEdpx * dpxdtz + dEdpy * dpydtz) * f / P22;
+    }
+    /* focal length and the two distortion coefficients (.cpp:532-543) */
+    g[6] = dEdpx * (dstn * pp[0]) + dEdpy * (dstn * pp[1]);
+    g[7] = dEdpx * (f * r2 * pp[0]) + dEdpy * (f * r2 * pp[1]);
+    g[8] = dEdpx * (f * r2 * r2 * pp[0]) + dEdpy * (f * r2 * r2 * pp[1]);
+    return E;
+}
+
 /* the two pixel residuals of one factor and their Jacobian rows J[0..11] (x), J[12..23] (y) */
 void ro_ba_factor_resjac(const double x[12], double ox, double oy, double res[2], double J[24])
 {
@@ -194,6 +272,7 @@ struct ro_problem {
     /* cached factor values + variable->factor adjacency (Factor.h:228-234,
      * Variable.cpp:66-88) */
     int emulate;
+    int ba_deriv;     /* RO_BA_DERIV_REFCHAIN (default) or RO_BA_DERIV_ADJOINT */
     double *fcache;
     uint8_t *fdirty;
     int64_t *v2f_ptr, *v2f_idx;
@@ -284,6 +363,17 @@ void ro_destroy(ro_problem *p)
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
     free(p->sine); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
     free(p);
+}
+
+void ro_set_ba_derivative(ro_problem *p, int which)
+{
+    p->ba_deriv = which;
+}
+
+static double ba_grad(const ro_problem *p, const double x[12], double ox, double oy, double g[12])
+{
+    return p->ba_deriv == RO_BA_DERIV_ADJOINT ? ro_ba_factor_grad(x, ox, oy, g)
+                                              : ro_ba_factor_grad_ref(x, ox, oy, g);
 }
 
 void ro_set_emulate_stale_cache(ro_problem *p, int on)
@@ -478,7 +568,7 @@ void ro_grad_each_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g12)
         const int64_t f = fac ? fac[i] : i;
         double vals[12];
         gather_ba(p, f, vals);
-        ro_ba_factor_grad(vals, p->obs[2 * f], p->obs[2 * f + 1], g12 + 12 * i);
+        ba_grad(p, vals, p->obs[2 * f], p->obs[2 * f + 1], g12 + 12 * i);
     }
 }
 
@@ -490,7 +580,7 @@ static int factor_partials(const ro_problem *p, int64_t f, int64_t *vids, double
     if (p->kind == RO_KIND_BA) {
         double x[12], g[12];
         gather_ba(p, f, x);
-        ro_ba_factor_grad(x, p->obs[2 * f], p->obs[2 * f + 1], g);
+        ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], g);
         for (int k = 0; k < 12; ++k) { vids[k] = fac_var(p, f, k); vals[k] = g[k]; }
         n = 12;
     } else {

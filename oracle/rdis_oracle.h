@@ -49,8 +49,14 @@ typedef struct ro_problem ro_problem;
 /* ---- single-factor arithmetic ------------------------------------------- */
 /* vals = [rx,ry,rz,tx,ty,tz,f,k1,k2,X,Y,Z] (BundleAdjustmentCommon.h:36-59) */
 double ro_ba_factor_eval(const double vals[12], double obsx, double obsy);
+/* two derivatives of the same factor: the reference's forward chain, operation by operation
+ * (BundleAdjustmentFactor.cpp:351-554; rounds like the reference), and an adjoint sweep derived
+ * independently from the camera model (the derivation the device kernels use) */
+double ro_ba_factor_grad_ref(const double vals[12], double obsx, double obsy,
+                             double grad[12]);
 double ro_ba_factor_grad(const double vals[12], double obsx, double obsy,
                          double grad[12]);
+enum { RO_BA_DERIV_REFCHAIN = 0, RO_BA_DERIV_ADJOINT = 1 };
 
 /* ---- problems -------------------------------------------------------------*/
 /* BA: factor i reads the 9 variables cam_vid0[i]..+8 and pt_vid0[i]..+2. */
@@ -70,6 +76,10 @@ void ro_destroy(ro_problem *p);
  * (src/Variable.cpp:70-76) together with the cached factor value
  * (src/Factor.h:228-234).  Default 1 (reference-faithful). */
 void ro_set_emulate_stale_cache(ro_problem *p, int on);
+
+/* which of the two derivatives the gradient / solver entry points use.  Default
+ * RO_BA_DERIV_REFCHAIN (reference-faithful rounding). */
+void ro_set_ba_derivative(ro_problem *p, int which);
 
 void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val);
 void ro_get_x(const ro_problem *p, int64_t nvid, const int64_t *vid, double *out);

@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/rdis_oracle.c) before anything is compared with it:
 
-* against the reference's golden values (tests/golden/reference_golden.json),
+* against the reference's golden values (tests/golden/reference_golden.json): per-factor values and
+  partials, the full objective and gradient, and the four recorded CGD runs -- all bit for bit,
 * against the reference's own documented minima of data/testpoly.txt,
 * bit for bit against the reference's minimize_nrc.h built as oracle/_ref.
 """
@@ -22,10 +23,44 @@ def test_ba_factor0_value_and_gradient(golden):
     vals = np.array(g0["cam"] + g0["pt"])
     e = O.ba_factor_eval(vals, *g0["obs"])
     assert e == g0["E"]                      # same expression order -> bit-exact
+    # the reference's forward chain restated operation by operation: bit-exact
+    e1, gref = O.ba_factor_grad_ref(vals, *g0["obs"])
+    assert e1 == g0["E"] and list(gref) == g0["grad"]
     e2, g = O.ba_factor_grad(vals, *g0["obs"])
     assert e2 == g0["E"]
     # adjoint-mode derivative vs the reference's forward chain rule: rounding only
     assert rel(g, g0["grad"]) < 1e-13
+
+
+def _seq_norm(g):
+    s = 0.0
+    for v in g:
+        s += float(v) * float(v)
+    return float(np.sqrt(s))
+
+
+def test_two_oracle_derivatives_agree_on_every_ladybug_factor():
+    """The oracle holds two derivatives of the reprojection factor: the reference's forward chain
+    (bit-exact against the reference's recorded partials and runs) and an adjoint sweep derived
+    independently from the camera model (the derivation the device kernels share).  They are
+    compared here on all 31843 factors of ladybug, at the BAL start and at a perturbed point, so a
+    derivation error in either would show."""
+    p = P.load_bal()
+    rng = np.random.default_rng(11)
+    for x in (p.x0, p.x0 * (1 + 1e-2 * rng.standard_normal(p.nvars))):
+        o = O.OracleProblem(p, derivative="refchain")
+        o.assign(None, x)
+        a = o.grad_each_ba()
+        o.set_derivative("adjoint")
+        b = o.grad_each_ba()
+        assert a.shape == b.shape == (31843, 12) and not np.array_equal(a, b)
+        d = np.max(np.abs(a - b), axis=1) / np.max(np.abs(a), axis=1)
+        assert d.max() < 2e-14, (d.max(), int(d.argmax()))
+        o.set_derivative("refchain")
+        ga = o.gradient()
+        o.set_derivative("adjoint")
+        gb = o.gradient()
+        assert np.max(np.abs(ga - gb)) < 1e-13 * np.max(np.abs(ga))
 
 
 def test_ba_gradient_matches_central_differences():
@@ -63,13 +98,16 @@ def test_ladybug_full_eval_and_gradient(golden):
     o = O.OracleProblem(p)
     each = o.eval_each()
     assert each[1] == gl["E_factor1"] and each[31842] == gl["E_factor31842"]
-    assert abs(o.eval() - gl["f_xinit"]) <= 1e-15 * gl["f_xinit"]
-    g = o.gradient()
+    assert o.eval() == gl["f_xinit"]
+    g = o.gradient()                       # reference-order derivative, factor-order sums: bit-exact
+    assert _seq_norm(g) == gl["grad_norm2"]
+    assert list(g[0:9]) == gl["grad_0_8"] and list(g[441:444]) == gl["grad_441_443"]
+    assert g[23768] == gl["grad_23768"]
+    o.set_derivative("adjoint")
+    g2 = o.gradient()
     gmax = np.max(np.abs(g))
-    assert abs(np.linalg.norm(g) - gl["grad_norm2"]) < 1e-13 * gl["grad_norm2"]
-    assert np.max(np.abs(g[0:9] - gl["grad_0_8"])) < 1e-14 * gmax
-    assert np.max(np.abs(g[441:444] - gl["grad_441_443"])) < 1e-14 * gmax
-    assert abs(g[23768] - gl["grad_23768"]) < 1e-14 * gmax
+    assert np.max(np.abs(g2 - g)) < 1e-13 * gmax
+    o.set_derivative("refchain")
     # the reference's sorted-vector merge and dense accumulation are the same sum
     sub = np.arange(0, 4000, dtype=np.int64)
     assert np.array_equal(o.gradient(sub, merge=True), o.gradient(sub, merge=False))
@@ -82,8 +120,7 @@ def test_bal_subsets_match_reference_sizes(golden):
         assert (p.nvars, p.nfac) == (c["nvars"], c["nfac"])
     c = golden["cgd"]["ladybug_5_30"]
     o = O.OracleProblem(P.load_bal(ncams=5, npts=30))
-    assert abs(o.eval() - c["f0"]) < 1e-14 * c["f0"]
-    assert abs(np.linalg.norm(o.gradient()) - c["grad_norm2"]) < 1e-13 * c["grad_norm2"]
+    assert o.eval() == c["f0"] and _seq_norm(o.gradient()) == c["grad_norm2"]
 
 
 # ---------------------------------------------------------------- NLP / poly
@@ -181,24 +218,51 @@ def test_minimiser_bit_exact_on_bundle_adjustment():
 
 
 # ---------------------------------------------------------------- CGD wrapper
-def test_cgd_chaos_band(golden):
-    """25 unconverged CG iterations are a chaotic map of the start point: the
-    oracle lands inside the band the reference's golden end points live in."""
+@pytest.mark.parametrize("key", ["ladybug_5_30", "ladybug_49_500", "ladybug_49_2000", "ladybug_full"])
+def test_reference_recorded_cgd_runs_bit_exact(golden, key):
+    """The four CGD runs the reference itself produced in this container (BASELINE.md 2:
+    unmodified reference sources, g++ -O2, glibc libm) are reproduced exactly: end value, evaluation
+    counts, end point.  25 unconverged CG iterations on bundle adjustment amplify a one-ulp
+    difference to percents (test_cgd_is_chaotic below), so equality of the end value after
+    500-800 dependent evaluations pins every rounding on the way: the forward-chain derivative
+    (BundleAdjustmentFactor.cpp:351-554), the factor-order sums (OptimizableFunction.cpp:118,
+    248-262; State.h:174-194), the stale-cache rule (Variable.cpp:70-76) and the minimiser."""
+    c = golden["cgd"][key]
+    p = P.load_bal(ncams=c["ncams"], npts=c["npts"])
+    r = O.OracleProblem(p).cgd(maxiters=c["maxiters"], ftol=3e-8)
+    assert r.fret == c["fret"] and r.nfeval == c["nfeval"]
+    assert r.status == 3 and r.iters == c["maxiters"] - 1          # "Too many iterations in frprmn"
+    if "ngeval" in c:
+        assert r.ngeval == c["ngeval"]
+    if "f0" in c:
+        assert r.finit == c["f0"]
+    if "delta" in c:
+        assert r.delta == c["delta"]
+    if "x_0_2" in c:
+        assert list(r.x[:3]) == c["x_0_2"]
+
+
+def test_recorded_runs_need_every_reference_detail(golden):
+    """drop any one of the reference's rounding-relevant details and the recorded end point is lost"""
     c = golden["cgd"]["ladybug_5_30"]
     p = P.load_bal(ncams=5, npts=30)
-    r = O.OracleProblem(p).cgd(maxiters=c["maxiters"])
-    assert r.finit == pytest.approx(c["f0"], rel=1e-14)
-    assert r.status == 3 and r.iters == 24
-    assert abs(r.fret - c["fret"]) < 0.05 * c["fret"]
-    assert abs(r.nfeval - c["nfeval"]) < 0.15 * c["nfeval"]
+    for kw in (dict(derivative="adjoint"), dict(emulate_stale_cache=False)):
+        r = O.OracleProblem(p, **kw).cgd(maxiters=25)
+        assert r.fret != c["fret"] and abs(r.fret - c["fret"]) < 0.05 * c["fret"]
+
+
+def test_cgd_is_chaotic():
+    """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
+    perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
+    is reproducible to Brent's own tolerance"""
+    p = P.load_bal(ncams=5, npts=30)
     frets = []
     rng = np.random.default_rng(0)
     for _ in range(5):
         q = P.load_bal(ncams=5, npts=30)
         q.x0 = q.x0 * (1 + 1e-15 * rng.standard_normal(q.nvars))
         frets.append(O.OracleProblem(q).cgd(maxiters=25).fret)
-    assert max(frets) - min(frets) > 1e-4 * c["fret"]        # the band is real
-    # ... while one line minimisation is reproducible to Brent's own tolerance
+    assert max(frets) - min(frets) > 1e-4 * np.mean(frets)
     a = O.OracleProblem(p).cgd(maxiters=1).fret
     q = P.load_bal(ncams=5, npts=30)
     q.x0 = q.x0 * (1 + 1e-15 * rng.standard_normal(q.nvars))
