@@ -35,7 +35,8 @@
 namespace rdis_hip {
 
 constexpr int COOP_MAX_WG = 512;
-constexpr int COOP_K = 3;  // values per exchange
+constexpr int COOP_SPEC = 1;  // line-search trial points evaluated per exchange (minimizer.hpp: speculation)
+constexpr int COOP_K = (2 * COOP_SPEC > 3 ? 2 * COOP_SPEC : 3);  // values per exchange
 constexpr int COOP_NBUF = 4;
 constexpr int COOP_MAX_WAVES = 8;  // waves per workgroup of the grid solvers (512 lanes)
 enum : int { SYNC_NONE = 0, SYNC_DRAIN = 1, SYNC_FENCE = 2 };
@@ -58,10 +59,16 @@ __device__ __forceinline__ long long coop_clock() {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) u64x2 gu64x2;
 
+constexpr int COOP_KP = (COOP_K + 1) / 2 * 2;   // granules per entry, padded to 16-byte pairs
 struct CoopState {
-    // [COOP_NBUF buffers][COOP_K][entries: workgroup * waves + wave] granules, then an abort word
-    unsigned long long granule[COOP_NBUF][COOP_K][COOP_MAX_WG * COOP_MAX_WAVES];
+    // [COOP_NBUF buffers][entries: workgroup * waves + wave][COOP_KP] granules -- the values an entry
+    // publishes in one exchange are neighbours, written and read two at a time (16 bytes: half the
+    // memory operations of a sweep; each half is still checked on its own, nothing relies on the
+    // pair arriving together) -- then an abort word
+    alignas(32) unsigned long long granule[COOP_NBUF][COOP_MAX_WG * COOP_MAX_WAVES][COOP_KP];
     unsigned int abort_flag;
     unsigned int pad[15];
 };
@@ -75,93 +82,161 @@ struct GridSync {
     int parity;
     unsigned epoch;
     bool dead;                          // a spin gave up: unwind quickly
+    unsigned kused;                     // byte b: how many granules per entry the last exchange in buffer b published
     long long tm[COOP_TM]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
                       // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over,
                       // 10 combine waves, 11 release, 12.. handler cycles: 12 value, 13 value+slope, 14 gradient (+reduce), 17 line end; 22.. their counts
 
     // ---- inter-workgroup exchange ------------------------------------------------
-    __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][k][w]; }
+    __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][w][k]; }
+    // granules k, k + 1 (k even) of an entry as one 16-byte access at agent scope (sc1: served by
+    // L2 / the fabric like the 8-byte agent-scope atomics; the compiler has no 16-byte form of those,
+    // and a volatile access is system scope -- measured twice as slow).  The load is asynchronous:
+    // its result may be used only after the s_waitcnt that follows the batch (to_wave0_n).
+    __device__ u64x2 load_pair(int buf, int k, int w) const {
+        u64x2 r;
+        const gu64* p = (const gu64*)&st->granule[buf][w][k];
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+        return r;
+    }
+    __device__ void store_pair(int buf, int k, int w, unsigned long long a, unsigned long long b) const {
+        u64x2 t; t.x = a; t.y = b;
+        gu64* p = (gu64*)&st->granule[buf][w][k];
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+    }
+    __device__ static unsigned long long bits_of(double v) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        return u == COOP_SENTINEL ? COOP_CANON_NAN : u;   // the one NaN pattern that means "not yet"
+    }
 
-    // All lanes call.  On return wave 0 of every workgroup holds the first K of (sum a, sum b,
-    // max mx) over the whole grid, bit-identical in every workgroup; the other waves hold
-    // garbage.  Must be paired with finish_wave0(sync) before the workgroup's next barrier.
-    // Every WAVE publishes its own partial sums (entry = workgroup * waves + wave): no LDS stage and
-    // no workgroup barrier between the arithmetic and the stores; wave 0 sweeps all entries.
-    template <int K>
-    __device__ void to_wave0(double& a, double& b, double& mx, int sync) {
+    // All lanes call.  On return wave 0 of every workgroup holds, for the N values of `v`, the sum
+    // (the last NMAX of them: the maximum) over the whole grid, bit-identical in every workgroup; the
+    // other waves hold garbage.  Must be paired with finish_wave0(sync) before the workgroup's next
+    // barrier.  Every WAVE publishes its own partial results (entry = workgroup * waves + wave): no
+    // LDS stage and no workgroup barrier between the arithmetic and the stores; wave 0 sweeps all
+    // entries.
+    template <int N, int NMAX>
+#ifdef RDIS_XCHG_NOINLINE
+    __device__ __attribute__((noinline)) void to_wave0_n(
+#else
+    __device__ void to_wave0_n(
+#endif
+        double (&v)[N], int sync) {
+        static_assert(N >= 1 && N <= COOP_K && NMAX >= 0 && NMAX <= N, "exchange width");
         const long long t0 = coop_clock();
         long long t2 = t0;
         const int w = tid >> 6, lane = tid & 63, nwv = blockDim.x >> 6;
-        a = wave_sum(a);
-        if constexpr (K >= 2) b = wave_sum(b);
-        if constexpr (K >= 3) mx = wave_max(mx);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(v[k]) : wave_max(v[k]);
         const int buf = epoch & (COOP_NBUF - 1);
+        kused = (kused & ~(0xFFu << (8 * buf))) | ((unsigned)N << (8 * buf));
         if (sync != SYNC_NONE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are out
         if (lane == 0) {
             // (this lane's re-arming stores to these granules were issued three exchanges
             // ago and have been waited for, see finish_wave0)
             if (sync == SYNC_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const int e = wg * nwv + w;
-            publish(gran(buf, 0, e), a);
-            if constexpr (K >= 2) publish(gran(buf, 1, e), b);
-            if constexpr (K >= 3) publish(gran(buf, 2, e), mx);
+#pragma unroll
+            for (int k = 0; k + 1 < N; k += 2) store_pair(buf, k, e, bits_of(v[k]), bits_of(v[k + 1]));
+            if constexpr (N & 1) publish(gran(buf, N - 1, e), v[N - 1]);
         }
         t2 = coop_clock();
         if (w == 0) {
-            // sweep: lane l looks after entries l, l+64, ...
+            // sweep: lane l looks after entries l, l+64, ..., CH of them in flight at a time (one memory
+            // round trip per chunk; a lane's out-of-range slots read entry 0).  A chunk is re-polled until
+            // all of it is there -- only the granules still missing are loaded again -- and then added
+            // up: chunks in order, entries in order, so every workgroup gets the same bits whatever
+            // the timing.
             const int nent = nwg * nwv;
-            double sa = 0.0, sb = 0.0, sm = 0.0;
+            double acc[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = 0.0;
             unsigned spins = 0;
             bool ok = !dead;
             const int per = (nent + 63) >> 6;
+            constexpr int CH = N <= 2 ? 8 : 4;
             // a store needs about this long to land; polling earlier only slows it down
             for (int d = 0; d < poll_delay; d += 8) __builtin_amdgcn_s_sleep(8);
-            while (!dead) {
-                ++tm[6];
-                ok = true;
-                sa = 0.0; sb = 0.0; sm = 0.0;
-                // eight entries (x K values) per lane in flight at a time: one memory round trip
-                // per chunk (a lane's out-of-range slots read entry 0)
-                for (int j0 = 0; j0 < per; j0 += 8) {
-                    unsigned long long va[8], vb[8], vm[8];
+            for (int j0 = 0; j0 < per && ok; j0 += CH) {
+                unsigned long long val[CH][N];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int k = 0; k < N; ++k) val[j][k] = COOP_SENTINEL;
+                for (;;) {
+                    ++tm[6];
+                    constexpr int NP = N / 2;
+                    u64x2 pr[CH][NP > 0 ? NP : 1];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
                         const int ww = lane + ((j0 + j) << 6);
                         const int wc = ww < nent ? ww : 0;
-                        va[j] = __hip_atomic_load(gran(buf, 0, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if constexpr (K >= 2) vb[j] = __hip_atomic_load(gran(buf, 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if constexpr (K >= 3) vm[j] = __hip_atomic_load(gran(buf, 2, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        ok = ok && va[j] != COOP_SENTINEL;
-                        if constexpr (K >= 2) ok = ok && vb[j] != COOP_SENTINEL;
-                        if constexpr (K >= 3) ok = ok && vm[j] != COOP_SENTINEL;
-                        if (lane + ((j0 + j) << 6) < nent) {
-                            sa += __longlong_as_double(va[j]);
-                            if constexpr (K >= 2) sb += __longlong_as_double(vb[j]);
-                            if constexpr (K >= 3) sm = fmax(sm, __longlong_as_double(vm[j]));
+                        for (int k = 0; k + 1 < N; k += 2) {
+                            pr[j][k / 2].x = val[j][k]; pr[j][k / 2].y = val[j][k + 1];
+                            if (val[j][k] == COOP_SENTINEL || val[j][k + 1] == COOP_SENTINEL) pr[j][k / 2] = load_pair(buf, k, wc);
+                        }
+                        if constexpr (N & 1) {
+                            if (val[j][N - 1] == COOP_SENTINEL)
+                                val[j][N - 1] = __hip_atomic_load(gran(buf, N - 1, wc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    if constexpr (NP > 0) {
+                        // (the 16-byte loads are invisible to the compiler's own wait counting: every
+                        // pair passes through these statements before it is looked at)
+#pragma unroll
+                        for (int j = 0; j < CH; ++j)
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) asm volatile("" : "+v"(pr[j][q]));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < CH; ++j)
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) {
+                                asm volatile("" : "+v"(pr[j][q]));
+                                val[j][2 * q] = pr[j][q].x; val[j][2 * q + 1] = pr[j][q].y;
+                            }
+                    }
+                    bool here = true;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int k = 0; k < N; ++k) here = here && val[j][k] != COOP_SENTINEL;
+                    if (__all(here)) break;
+                    ++spins;
+                    if (spins > COOP_SPIN_LIMIT ||
+                        ((spins & 255u) == 0u &&
+                         __hip_atomic_load((gu32*)&st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (lane == 0) __hip_atomic_store((gu32*)&st->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    if (lane + ((j0 + j) << 6) < nent) {
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const double x = __longlong_as_double(val[j][k]);
+                            if (k < N - NMAX) acc[k] += x; else acc[k] = fmax(acc[k], x);
                         }
                     }
                 }
-                if (__all(ok)) break;
-                ++spins;
-                if (spins > COOP_SPIN_LIMIT ||
-                    ((spins & 255u) == 0u &&
-                     __hip_atomic_load((gu32*)&st->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    if (lane == 0) __hip_atomic_store((gu32*)&st->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
             }
             if (!__all(ok)) dead = true;
-            a = wave_sum(sa);
-            if constexpr (K >= 2) b = wave_sum(sb);
-            if constexpr (K >= 3) mx = wave_max(sm);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(acc[k]) : wave_max(acc[k]);
         }
         const long long t3 = coop_clock();
         tm[2] += t2 - t0; tm[3] += t3 - t2; ++tm[5];
+    }
+    // the first K of (sum a, sum b, max mx)
+    template <int K>
+    __device__ void to_wave0(double& a, double& b, double& mx, int sync) {
+        if constexpr (K == 1) { double v[1] = {a}; to_wave0_n<1, 0>(v, sync); a = v[0]; }
+        else if constexpr (K == 2) { double v[2] = {a, b}; to_wave0_n<2, 0>(v, sync); a = v[0]; b = v[1]; }
+        else { double v[3] = {a, b, mx}; to_wave0_n<3, 1>(v, sync); a = v[0]; b = v[1]; mx = v[2]; }
     }
     __device__ static void publish(gu64* g, double v) {
         unsigned long long u = __double_as_longlong(v);
@@ -182,9 +257,10 @@ struct GridSync {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous re-arming stores: an exchange old
             const int nb = (epoch + 3u) & (COOP_NBUF - 1);
             const int e = wg * nwv + tid;
-            __hip_atomic_store(gran(nb, 0, e), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gran(nb, 1, e), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gran(nb, 2, e), COOP_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nk = (int)((kused >> (8 * nb)) & 0xFFu);   // what the buffer's last use published
+#pragma unroll
+            for (int k = 0; k < COOP_KP; k += 2)
+                if (k < nk) store_pair(nb, k, e, COOP_SENTINEL, COOP_SENTINEL);
         }
         parity ^= 1;
         ++epoch;

@@ -55,9 +55,24 @@ enum : int {
     RF_TR_FIRST = 256      // emit the tr_ trace record before the pre_ one
 };
 
+// Speculation.  An evaluation is a latency chain (arithmetic, reduction, exchange between
+// workgroups, a step of this machine), and in a line search every trial step depends on the reply to
+// the previous one.  But most steps of Brent's method on these problems are bisections towards the
+// best point (the bracket is [-1.6, 1] and the minimum lies at 1e-7..1e-3 of it), and the step a
+// bisection takes does not depend on the VALUE the pending trial returns, only on its being worse
+// than the best point.  So a solver environment may evaluate, together with the trial step a
+// request asks for, up to SPEC_MAX - 1 guesses at the following steps (Predictor, below).  When the
+// machine, stepped with the reply to the real trial, asks for exactly a step that was guessed (same
+// bits), the reply is already there and the machine is stepped again at once; otherwise the guess
+// is dropped.  The machine itself never sees a guess: its decisions, its trace and its f / df call
+// counts are those of the unspeculated run (the replay check holds with speculation on or off).
+constexpr int SPEC_MAX = 4;
+
 struct Request {
     int kind;
     int flags;
+    int ncand;                   // guesses at the following trial steps (evaluated with this one), 0 = none
+    double cand[SPEC_MAX - 1];
     int pre_tag;         // optional trace record of an evaluation whose value was already known
     int tr_tag;          // optional trace record emitted before the request is served
     double a, b;
@@ -65,8 +80,67 @@ struct Request {
     double tr_a, tr_b, tr_c;     // (meaningful only when tr_tag is set)
 };
 
+#ifdef RDIS_STEP_PROFILE   // tools/microbench/step_cost.hip: where inside a step do the cycles go?
+// [i]: cycles between mark i-1 (or the caller's start, [15]) and mark i; in LDS so that a mark costs little
+__device__ __forceinline__ long long* step_prof() { __shared__ long long a[16]; return a; }
+#define RDIS_SP(i) do { const long long n__ = clock64(); long long* sp__ = step_prof(); sp__[i] += n__ - sp__[15]; sp__[15] = clock64(); } while (0)
+#else
+#define RDIS_SP(i) do {} while (0)
+#endif
+
 // keeps a value in a vector register, hides its origin from the optimiser
 __device__ __forceinline__ void opaque(double& v) { asm("" : "+v"(v)); }
+
+// Guesses at the trial steps the line search will ask for after the request the machine has just
+// issued, from the machine's state alone: the pending trial (and every guess after it) is assumed
+// to come back WORSE than the best point, a new line to go the way the previous one went.  Same
+// operations as the machine's own (contraction off), so a guess that holds is the machine's next
+// request bit for bit; one that does not is only wasted arithmetic.
+struct Predictor {
+    enum : int { P_STOP = 0, P_BR_FC, P_DB };
+    int ph;
+    bool need_first;   // Brent's first evaluation (at bx, whose slope is unknown) comes before its first trial
+    double a, b, x, dx;
+    double ax, bx, cx;
+
+    // swapped: the previous bracketing found f(1) > f(0) and went to the other side of 0
+    __device__ void start(const struct CgdMachine& M, bool swapped);
+    __device__ void begin_brent(double ax_, double bx_, double cx_, bool slope_known, double slope) {
+        a = (ax_ < cx_ ? ax_ : cx_);
+        b = (ax_ > cx_ ? ax_ : cx_);
+        x = bx_;
+        need_first = !slope_known;
+        dx = slope_known ? slope : -1.0;   // the origin of a descent line: downhill to the right
+        ph = P_DB;
+    }
+    // the next guess; false = none
+    __device__ bool next(double& c) {
+#pragma clang fp contract(off)
+        const double GOLD = 1.618034, TOL = 3.0e-8, ZEPS = DBL_EPSILON * 1.0e-3;
+        if (ph == P_BR_FC) {
+            cx = bx + GOLD * (bx - ax);
+            c = cx;
+            // what follows a bracket that stands at once is known only when the search went back
+            // across the origin (bx = 0: Brent starts there); otherwise parabolic steps follow
+            if (bx == 0.0) begin_brent(ax, bx, cx, false, 0.0); else ph = P_STOP;
+            return true;
+        }
+        if (ph != P_DB) return false;
+        if (need_first) { need_first = false; c = x; return true; }
+        const double xm = 0.5 * (a + b);
+        const double tol1 = TOL * fabs(x) + ZEPS;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x - xm) <= (tol2 - 0.5 * (b - a))) { ph = P_STOP; return false; }
+        const double ebis = (dx >= 0.0 ? a - x : b - x);
+        const double d = 0.5 * ebis;
+        const bool tn = !(fabs(d) >= tol1);
+        const double u = tn ? x + copysign(tol1, d) : x + d;
+        c = u;
+        if (tn) ph = P_STOP;
+        else if (u < x) a = u; else b = u;
+        return true;
+    }
+};
 
 struct CgdMachine {
     enum : int {
@@ -107,6 +181,8 @@ struct CgdMachine {
 
     __device__ static Request req(int kind, double a = 0.0, int flags = 0) {
         Request r; r.kind = kind; r.a = a; r.b = 0.0; r.flags = flags;
+        r.ncand = 0;
+        for (int k = 0; k < SPEC_MAX - 1; ++k) r.cand[k] = 0.0;
         r.pre_tag = TR_NONE; r.pre_a = r.pre_b = r.pre_c = 0.0;
         r.tr_tag = TR_NONE; r.tr_a = r.tr_b = r.tr_c = 0.0;
         return r;
@@ -152,75 +228,109 @@ struct CgdMachine {
         return traced(r, TR_LINMIN, x, fx, 0.0);
     }
 
+    // Hot path: the reply to a Brent trial (nrc :380-401 housekeeping, then :319-376 for the next
+    // trial point) -- ~85 % of all steps -- as a routine of its own: straight-line code with selects
+    // instead of branches (a taken branch costs this single in-order wave more than the arithmetic
+    // it skips) and exactly the operations of the branchy form in next() (S_DB_EVAL / S_DB_HEAD).
+    // Everything it reads -- the Brent state, the two call counters, the pending trace record -- is
+    // loaded up front in one batch (one LDS round trip), everything it changes is stored at the end.
+    // Returns false, having changed nothing, when the generic code must take the step (not in a
+    // Brent iteration, the closing states of a line search, the iteration limit); otherwise `un` is
+    // the next trial step (request: value + slope on the line), pre_* the pending trace record to
+    // emit first, and G the state the Predictor continues from.
+    __device__ __forceinline__ bool hot(double r0, double r1, double& un, int& pre_tag, double& pre_a, double& pre_b,
+                                        double& pre_c, Predictor& G) {
+#pragma clang fp contract(off)
+        const double TOL = 3.0e-8, ZEPS = DBL_EPSILON * 1.0e-3;
+        const int DB_ITMAX = 100;
+        double a_ = a, b_ = b, x_ = x, w_ = w, v_ = v, fx_ = fx, fw_ = fw, fv_ = fv;
+        double dx_ = dx, dw_ = dw, dv_ = dv, d_ = d, e_ = e, uu_ = uu;
+        long long nfe_ = nfeval, nge_ = ngeval;
+        int ppt_ = pp_tag;
+        double ppa_ = pp_a, ppb_ = pp_b, ppc_ = pp_c;
+        const bool tiny_ = tiny;
+        const int it_ = it;
+        if (st != S_DB_EVAL) return false;
+        RDIS_SP(0);
+#ifndef RDIS_HOT_NO_OPAQUE
+        opaque(a_); opaque(b_); opaque(x_); opaque(w_); opaque(v_); opaque(fx_); opaque(fw_); opaque(fv_);
+        opaque(dx_); opaque(dw_); opaque(dv_); opaque(d_); opaque(e_); opaque(uu_);
+        opaque(ppa_); opaque(ppb_); opaque(ppc_);
+        asm("" : "+v"(nfe_), "+v"(nge_), "+v"(ppt_));
+#endif
+        if ((tiny_ && r0 > fx_) || !(it_ + 1 < DB_ITMAX)) return false;
+#if defined(RDIS_HOT_CUT) && RDIS_HOT_CUT == 1
+        un = uu_ * 0.5 + r0 * 1e-30; uu = un; pre_tag = TR_NONE; G.ph = 0; return true;
+#endif
+        RDIS_SP(1);
+        const double fu = r0, du = r1;
+        const bool le = fu <= fx_;
+        const bool right = uu_ >= x_, left = uu_ < x_;
+        const double a1 = le ? (right ? x_ : a_) : (left ? uu_ : a_);
+        const double b1 = le ? (right ? b_ : x_) : (left ? b_ : uu_);
+        const bool c1 = !le && (fu <= fw_ || w_ == x_);
+        const bool c2 = !le && !c1 && (fu < fv_ || v_ == x_ || v_ == w_);
+        const bool vw = le || c1;           // v <- w
+        const double v1 = vw ? w_ : (c2 ? uu_ : v_), fv1 = vw ? fw_ : (c2 ? fu : fv_), dv1 = vw ? dw_ : (c2 ? du : dv_);
+        const double w1 = le ? x_ : (c1 ? uu_ : w_), fw1 = le ? fx_ : (c1 ? fu : fw_), dw1 = le ? dx_ : (c1 ? du : dw_);
+        const double x1 = le ? uu_ : x_, fx1 = le ? fu : fx_, dx1 = le ? du : dx_;
+        // S_DB_HEAD
+        const double xm = 0.5 * (a1 + b1);
+        const double tol1 = TOL * fabs(x1) + ZEPS;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x1 - xm) <= (tol2 - 0.5 * (b1 - a1))) return false;   // converged: next() redoes the step and ends the line
+        const bool big = fabs(e_) > tol1;
+        const double dflt = 2.0 * (b1 - a1);
+        const double q1 = (w1 - x1) * dx1 / (dx1 - dw1);
+        const double q2 = (v1 - x1) * dx1 / (dx1 - dv1);
+        const double d1 = (dw1 != dx1) ? q1 : dflt;
+        const double d2 = (dv1 != dx1) ? q2 : dflt;
+        const double u1 = x1 + d1, u2 = x1 + d2;
+        const bool ok1 = (a1 - u1) * (u1 - b1) > 0.0 && dx1 * d1 <= 0.0;
+        const bool ok2 = (a1 - u2) * (u2 - b1) > 0.0 && dx1 * d2 <= 0.0;
+        const double dsel = (ok1 && ok2) ? (fabs(d1) < fabs(d2) ? d1 : d2) : (ok1 ? d1 : d2);
+        const bool accept = big && (ok1 || ok2) && (fabs(dsel) <= fabs(0.5 * e_));
+        const double ut = x1 + dsel;
+        const double dacc = (ut - a1 < tol2 || b1 - ut < tol2) ? copysign(tol1, xm - x1) : dsel;
+        const double ebis = (dx1 >= 0.0 ? a1 - x1 : b1 - x1);
+        const double enew = accept ? d_ : ebis;
+        const double dnew = accept ? dacc : 0.5 * ebis;
+        const bool tn = !(fabs(dnew) >= tol1);
+        un = tn ? x1 + copysign(tol1, dnew) : x1 + dnew;
+#if defined(RDIS_HOT_CUT) && RDIS_HOT_CUT == 2
+        uu = un; e = enew; pre_tag = TR_NONE; G.ph = 0; return true;
+#endif
+        RDIS_SP(2);
+        if (fu != fu) saw_nan = true;
+        a = a1; b = b1; v = v1; fv = fv1; dv = dv1; w = w1; fw = fw1; dw = dw1; x = x1; fx = fx1; dx = dx1;
+        e = enew; d = dnew; tiny = tn; uu = un;
+        it = it_ + 1;
+        ngeval = nge_ + 1;   // the reply's df call (nrc :378); the new trial's operator() call (:366/:369)
+        nfeval = nfe_ + 1;
+        pp_tag = TR_NONE;
+        pre_tag = ppt_; pre_a = ppa_; pre_b = ppb_; pre_c = ppc_;
+        // the Predictor continues from here: the new trial is assumed to come back worse
+        G.need_first = false;
+        G.a = (!tn && un < x1) ? un : a1;
+        G.b = (!tn && !(un < x1)) ? un : b1;
+        G.x = x1; G.dx = dx1;
+        G.ph = tn ? Predictor::P_STOP : Predictor::P_DB;
+        RDIS_SP(3);
+        return true;
+    }
+
     // r0, r1, r2: reply to the previous request
+#ifdef RDIS_NEXT_NOINLINE
+    __device__ __attribute__((noinline)) Request next(double r0, double r1, double r2) {
+#else
     __device__ Request next(double r0, double r1, double r2) {
+#endif
 #pragma clang fp contract(off)
         const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;      // nrc :82
         const double GTOL = 1.0e-8;                                         // nrc :622 (EPS = 1e-18, :621, is in line_done)
         const double TOL = 3.0e-8;  // Dbrent's own default, not the solver's ftol (nrc :288, :499)
         const double ZEPS = DBL_EPSILON * 1.0e-3;
         const int DB_ITMAX = 100;
-        // Hot path: the reply to a Brent trial (nrc :380-401 housekeeping, then :319-376 for the
-        // next trial point), ~85 % of all steps.  Written with selects instead of branches -- a
-        // taken branch costs this single in-order wave more than the arithmetic it skips -- and
-        // with exactly the operations of the branchy form below (S_DB_EVAL / S_DB_HEAD).
-        // The whole Brent state is loaded once, up front and before the state is even looked at
-        // (the loads overlap; an LDS round trip is ~130 cycles for this lone wave), and made
-        // opaque: left to itself the compiler turns every select between two fields into a select
-        // between two LDS addresses followed by a dependent load.
-        double a_ = a, b_ = b, x_ = x, w_ = w, v_ = v, fx_ = fx, fw_ = fw, fv_ = fv;
-        double dx_ = dx, dw_ = dw, dv_ = dv, d_ = d, e_ = e, uu_ = uu;
-        const int st_ = st;
-        if (st_ == S_DB_EVAL) {
-            opaque(a_); opaque(b_); opaque(x_); opaque(w_); opaque(v_); opaque(fx_); opaque(fw_); opaque(fv_);
-            opaque(dx_); opaque(dw_); opaque(dv_); opaque(d_); opaque(e_); opaque(uu_);
-            const bool tiny_ = tiny;
-            const int it_ = it;
-            if (!(tiny_ && r0 > fx_) && it_ + 1 < DB_ITMAX) {
-                const double fu = r0, du = r1;
-                if (r0 != r0) saw_nan = true;
-                ++ngeval;
-                const bool le = fu <= fx_;
-                const bool right = uu_ >= x_, left = uu_ < x_;
-                const double a1 = le ? (right ? x_ : a_) : (left ? uu_ : a_);
-                const double b1 = le ? (right ? b_ : x_) : (left ? b_ : uu_);
-                const bool c1 = !le && (fu <= fw_ || w_ == x_);
-                const bool c2 = !le && !c1 && (fu < fv_ || v_ == x_ || v_ == w_);
-                const bool vw = le || c1;           // v <- w
-                const double v1 = vw ? w_ : (c2 ? uu_ : v_), fv1 = vw ? fw_ : (c2 ? fu : fv_), dv1 = vw ? dw_ : (c2 ? du : dv_);
-                const double w1 = le ? x_ : (c1 ? uu_ : w_), fw1 = le ? fx_ : (c1 ? fu : fw_), dw1 = le ? dx_ : (c1 ? du : dw_);
-                const double x1 = le ? uu_ : x_, fx1 = le ? fu : fx_, dx1 = le ? du : dx_;
-                a = a1; b = b1; v = v1; fv = fv1; dv = dv1; w = w1; fw = fw1; dw = dw1; x = x1; fx = fx1; dx = dx1;
-                it = it_ + 1;
-                // S_DB_HEAD
-                const double xm = 0.5 * (a1 + b1);
-                const double tol1 = TOL * fabs(x1) + ZEPS;
-                const double tol2 = 2.0 * tol1;
-                if (!(fabs(x1 - xm) <= (tol2 - 0.5 * (b1 - a1)))) {
-                    const bool big = fabs(e_) > tol1;
-                    const double dflt = 2.0 * (b1 - a1);
-                    const double q1 = (w1 - x1) * dx1 / (dx1 - dw1);
-                    const double q2 = (v1 - x1) * dx1 / (dx1 - dv1);
-                    const double d1 = (dw1 != dx1) ? q1 : dflt;
-                    const double d2 = (dv1 != dx1) ? q2 : dflt;
-                    const double u1 = x1 + d1, u2 = x1 + d2;
-                    const bool ok1 = (a1 - u1) * (u1 - b1) > 0.0 && dx1 * d1 <= 0.0;
-                    const bool ok2 = (a1 - u2) * (u2 - b1) > 0.0 && dx1 * d2 <= 0.0;
-                    const double dsel = (ok1 && ok2) ? (fabs(d1) < fabs(d2) ? d1 : d2) : (ok1 ? d1 : d2);
-                    const bool accept = big && (ok1 || ok2) && (fabs(dsel) <= fabs(0.5 * e_));
-                    const double ut = x1 + dsel;
-                    const double dacc = (ut - a1 < tol2 || b1 - ut < tol2) ? copysign(tol1, xm - x1) : dsel;
-                    const double ebis = (dx1 >= 0.0 ? a1 - x1 : b1 - x1);
-                    const double enew = accept ? d_ : ebis;
-                    const double dnew = accept ? dacc : 0.5 * ebis;
-                    const bool tn = !(fabs(dnew) >= tol1);
-                    const double un = tn ? x1 + copysign(tol1, dnew) : x1 + dnew;
-                    e = enew; d = dnew; tiny = tn; uu = un;
-                    return with_pending(want_fd(un));   // st stays S_DB_EVAL
-                }
-                st = S_DB_HEAD;  // converged: the generic code below finishes the line search
-            }
-        }
         for (;;) {
             switch (st) {
             case S_BEGIN:  // CGD .cpp:34-37: assign clamp(x0), initialFval = sfd(xval)
@@ -423,6 +533,30 @@ struct CgdMachine {
     }
 };
 
+__device__ inline void Predictor::start(const CgdMachine& M, bool swapped) {
+#pragma clang fp contract(off)
+    ph = P_STOP; need_first = false;
+    a = b = x = dx = 0.0; ax = bx = cx = 0.0;
+    switch (M.st) {
+    case CgdMachine::S_BR_FB:   // pending: f at bx (= 1) of a new line from ax (= 0)
+        if (swapped) { ax = M.bx; bx = M.ax; ph = P_BR_FC; }
+        else { ax = M.ax; bx = M.bx; ph = P_BR_FC; }
+        break;
+    case CgdMachine::S_BR_FC:   // pending: f at cx; if it is no better than f(bx) the bracket stands
+        begin_brent(M.ax, M.bx, M.cx, M.vb, M.sb);
+        break;
+    case CgdMachine::S_DB_FIRST:  // pending: value and slope at x = bx (only ever the line's origin)
+        a = M.a; b = M.b; x = M.x; dx = -1.0; ph = P_DB;
+        break;
+    case CgdMachine::S_DB_EVAL:   // pending: a Brent trial at uu
+        if (M.tiny) break;        // worse after a minimal step ends the line search
+        a = M.a; b = M.b; x = M.x; dx = M.dx; ph = P_DB;
+        if (M.uu < x) a = M.uu; else b = M.uu;
+        break;
+    default: break;
+    }
+}
+
 // The driver: the single place where each heavy operation is instantiated.
 // Env provides eval_value / eval_value_slope / gradient_to_xi / cg_start /
 // line_begin / line_end / cg_reduce / cg_update / trace / aborted.  Replies (values, slopes,
@@ -435,9 +569,20 @@ struct CgdMachine {
 // one step of the machine (wave 0 only); the request goes to the other waves through LDS
 __device__ __forceinline__ void step_machine(CgdMachine* __restrict__ M, Request* __restrict__ out, double r0, double r1, double r2,
                                              bool writer) {
+    double un, pa, pb, pc;
+    int ptag;
+    Predictor G;
+    if (M->hot(r0, r1, un, ptag, pa, pb, pc, G)) {
+        if (writer) {
+            out->kind = REQ_EVAL; out->flags = RF_SLOPE | RF_LINE; out->ncand = 0;
+            out->pre_tag = ptag; out->tr_tag = TR_NONE; out->a = un;
+            if (ptag != TR_NONE) { out->pre_a = pa; out->pre_b = pb; out->pre_c = pc; }
+        }
+        return;
+    }
     const Request nq = M->next(r0, r1, r2);
     if (writer) {
-        out->kind = nq.kind; out->flags = nq.flags;
+        out->kind = nq.kind; out->flags = nq.flags; out->ncand = 0;
         out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a; out->b = nq.b;
         if (nq.pre_tag != TR_NONE) { out->pre_a = nq.pre_a; out->pre_b = nq.pre_b; out->pre_c = nq.pre_c; }
         if (nq.tr_tag != TR_NONE) { out->tr_a = nq.tr_a; out->tr_b = nq.tr_b; out->tr_c = nq.tr_c; }
@@ -465,21 +610,109 @@ __device__ __forceinline__ int uni(int v) {
     if constexpr (Env::UNIFORM) return __builtin_amdgcn_readfirstlane(v); else return v;
 }
 
+// entry j of a small register array (j wave-uniform; a dynamic index would go through scratch)
+template <int N>
+__device__ __forceinline__ double pick(const double (&v)[N], int j) {
+    double r = v[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) r = (j == k) ? v[k] : r;
+    return r;
+}
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// Env::SPEC: trial steps evaluated per value+slope request (1 = no speculation).  With SPEC > 1 Env
+// provides eval_value_slope_spec(steps, f, s) for SPEC steps at once and spec_hint() / spec_note().
 template <class Env>
 __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Request (&Q)[2] /* LDS */,
                                             int maxiters, double ftol) {
+    constexpr int K = Env::SPEC;
+    constexpr int KS = K > 1 ? K - 1 : 1;
+    static_assert(K >= 1 && K <= SPEC_MAX, "speculation depth");
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-    const bool stepper = E.stepper();
+    double sc[KS], sf[KS], ss[KS];   // guessed steps evaluated with the last request, their values and slopes
+    int ns = 0;                      // ... how many of them
+    bool swapped = true;             // did the last bracketing go to the other side of the origin?
+#pragma unroll
+    for (int k = 0; k < KS; ++k) sc[k] = sf[k] = ss[k] = 0.0;
+    // ONE lane steps the machine: its state is wave-uniform, and sixty-four lanes storing the same
+    // words to the same LDS addresses is a 64-way bank conflict on every store (measured: 1700 of the
+    // 2300 cycles of a step); the request reaches everybody, this lane's own wave included, through LDS
+    const bool stepper = E.stepper() && E.writer();
     if (stepper) M.init(maxiters, ftol);
     for (int round = 0;; ++round) {
         const long long ts0 = E.clock();
         if (stepper) {
-            step_machine(&M, &Q[round & 1], r0, r1, r2, E.writer());
+            if constexpr (K > 1) {
+                Request* out = &Q[round & 1];
+                const bool writer = E.writer();
+                for (int j = 0;; ++j) {
+                    Predictor G;
+                    Request nq;
+                    double un, pa, pb, pc;
+                    int ptag;
+                    const bool was_hot = M.hot(r0, r1, un, ptag, pa, pb, pc, G);
+                    if (was_hot) {
+                        if (j < ns && same_bits(un, pick(sc, j))) {
+                            // the step asked for was guessed and has been evaluated: reply at once
+                            if (ptag != TR_NONE) E.trace(ptag, pa, pb, pc);
+                            r0 = pick(sf, j); r1 = pick(ss, j);
+                            E.trace(TR_FD, un, r0, r1);
+                            E.tick(18, 1);
+                            continue;
+                        }
+                    } else {
+                        nq = M.next(r0, r1, r2);
+                        if (M.st == CgdMachine::S_BR_FC) swapped = M.ax == 1.0;
+                        if (j < ns && nq.kind == REQ_EVAL && nq.flags == (RF_SLOPE | RF_LINE) && same_bits(nq.a, pick(sc, j))) {
+                            if (nq.pre_tag != TR_NONE) E.trace(nq.pre_tag, nq.pre_a, nq.pre_b, nq.pre_c);
+                            if (nq.tr_tag != TR_NONE) E.trace(nq.tr_tag, nq.tr_a, nq.tr_b, nq.tr_c);
+                            r0 = pick(sf, j); r1 = pick(ss, j);
+                            E.trace(TR_FD, nq.a, r0, r1);
+                            E.tick(18, 1);
+                            continue;
+                        }
+                        G.start(M, swapped);
+                    }
+                    // hand the request over, with guesses at what follows a value+slope trial
+                    const bool slope_req = was_hot || (nq.kind == REQ_EVAL && (nq.flags & RF_SLOPE));
+                    int nc = 0;
+                    double cg[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) cg[k] = 0.0;
+                    if (slope_req && E.spec_on()) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            double c;
+                            if (nc == k && G.next(c)) { cg[k] = c; nc = k + 1; }
+                        }
+                    }
+                    if (writer) {
+                        out->ncand = nc;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) out->cand[k] = cg[k];
+                        if (was_hot) {
+                            out->kind = REQ_EVAL; out->flags = RF_SLOPE | RF_LINE;
+                            out->pre_tag = ptag; out->tr_tag = TR_NONE; out->a = un;
+                            if (ptag != TR_NONE) { out->pre_a = pa; out->pre_b = pb; out->pre_c = pc; }
+                        } else {
+                            out->kind = nq.kind; out->flags = nq.flags;
+                            out->pre_tag = nq.pre_tag; out->tr_tag = nq.tr_tag; out->a = nq.a; out->b = nq.b;
+                            if (nq.pre_tag != TR_NONE) { out->pre_a = nq.pre_a; out->pre_b = nq.pre_b; out->pre_c = nq.pre_c; }
+                            if (nq.tr_tag != TR_NONE) { out->tr_a = nq.tr_a; out->tr_b = nq.tr_b; out->tr_c = nq.tr_c; }
+                        }
+                    }
+                    break;
+                }
+            } else {
+                step_machine(&M, &Q[round & 1], r0, r1, r2, E.writer());
+            }
             if (E.aborted() && E.writer()) {  // only this wave is certain to know
                 Q[round & 1].kind = REQ_DONE;
-                M.reason = EXIT_SYNC_TIMEOUT; M.rolled_back = true;
+                // the restored start is what is returned: its value, no progress (CGD .cpp:66-80)
+                M.reason = EXIT_SYNC_TIMEOUT; M.rolled_back = true; M.fret = M.finit;
             }
         }
+        ns = 0;
         const long long ts1 = E.clock();
         E.sync();
         const Request& q = Q[round & 1];
@@ -503,7 +736,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
             }
         }
         const long long th0 = E.clock();
-#define RDIS_TICK_KIND(K) E.tick(12 + K, E.clock() - th0); E.tick(22 + K, 1)
+#define RDIS_TICK_KIND(K_) E.tick(12 + K_, E.clock() - th0); E.tick(22 + K_, 1)
         switch (kind) {
         case REQ_EVAL:
             if (flags & (RF_PRE_START | RF_PRE_UPDATE | RF_PRE_BEGIN)) {
@@ -512,8 +745,24 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
                 if (flags & RF_PRE_BEGIN) E.line_begin();
             }
             if (flags & RF_SLOPE) {
-                E.eval_value_slope(qa, r0, r1);
-                r0 = uni<Env>(r0); r1 = uni<Env>(r1);
+                if constexpr (K > 1) {
+                    // the step asked for and the guesses at the following ones, evaluated together
+                    // (a missing guess repeats the step: one code path, the value is not used)
+                    const int nc = uni<Env>(q.ncand);
+                    double ca[K], cf[K], cs[K];
+                    ca[0] = qa;
+#pragma unroll
+                    for (int k = 1; k < K; ++k) ca[k] = (k <= nc) ? uni<Env>(q.cand[k - 1]) : qa;
+                    E.eval_value_slope_spec(ca, cf, cs);
+                    r0 = uni<Env>(cf[0]); r1 = uni<Env>(cs[0]);
+#pragma unroll
+                    for (int k = 1; k < K; ++k) { sc[k - 1] = ca[k]; sf[k - 1] = uni<Env>(cf[k]); ss[k - 1] = uni<Env>(cs[k]); }
+                    ns = nc;
+                    E.tick(19, nc);
+                } else {
+                    E.eval_value_slope(qa, r0, r1);
+                    r0 = uni<Env>(r0); r1 = uni<Env>(r1);
+                }
                 E.trace(TR_FD, qa, r0, r1);
                 RDIS_TICK_KIND(1);
             } else {

@@ -102,6 +102,7 @@ struct rdis_hip_problem {
     bool have_all_v2s = false;
     // shared by the plans of this problem (solves on a context are serialised)
     DevBuf dir, coop_state, coop_timing;   // search direction by variable id (kept zero between solves), ...
+    int coop_state_gen = 0;                // bumped whenever coop_state moves: plans re-derive the pointers they baked in
     DevBuf arena;                          // memory of the transient plan of rdis_hip_cgd_batch
     size_t arena_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -170,6 +171,7 @@ struct rdis_hip_plan {
     bool have_start = false;
     // which components go where (rebuilt when an option changes)
     bool partition_dirty = true;
+    int coop_state_gen = -1;          // generation of the problem's exchange-state buffer this partition points into
     std::vector<CoopItem> coop;
     std::vector<CoopLaunch> coop_launches;
     std::vector<int> h_coop_ints;   // host image of coop_ints (kept: the upload is asynchronous)
@@ -196,6 +198,7 @@ struct rdis_hip_plan {
     int camera_records = 1;           // option "camera_records": 0 = every factor forms its rotation itself, 1 = auto, 2 = records wherever possible
     size_t off_cb_ptr = 0, off_cb = 0, off_cb_li = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
+    int coop_speculate = 1;           // option: guesses at the following trial steps ride along with every line-search trial
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
     int dump_iters = 0;
@@ -875,6 +878,8 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "coop_threads") {
         if (value != 128 && value != 256 && value != 512) return fail(c, RDIS_HIP_EINVAL, "coop_threads must be 128, 256 or 512");
         L->coop_threads = (int)value;
+    } else if (n == "coop_speculate") {
+        L->coop_speculate = value != 0;
     } else if (n == "force_stream") {
         L->force_stream = value != 0;
     } else if (n == "coop_poll_delay") {
@@ -1095,7 +1100,8 @@ int prepare_partition(rdis_hip_plan* L) {
             g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, L->coop_ints.as<int>() + it.slot_li,
                            L->coop_ints.as<int>() + it.lane_var, L->coop_ints.as<int>() + it.wave_var, L->xi_glob.as<double>() + it.xi_off, it.comp,
                            // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
-                           it.nwg * (L->coop_threads / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay};
+                           it.nwg * (L->coop_threads / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay,
+                           L->coop_speculate};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
             hg.push_back(g);
             hw.insert(hw.end(), (size_t)it.nwg, cl.count);
@@ -1103,9 +1109,13 @@ int prepare_partition(rdis_hip_plan* L) {
         }
         max_groups = std::max(max_groups, hg.size());
         if (p->coop_state.bytes < max_groups * sizeof(CoopState)) {   // one exchange state per concurrent group
+            // The buffer moves: every other plan of this problem has its address in its uploaded group
+            // tables.  The generation tells rdis_hip_plan_solve to rebuild theirs before they run again.
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            rc = dalloc(c, p->coop_state, max_groups * sizeof(CoopState));
+            if (c->aux) HIPCHK(c, hipStreamSynchronize(c->aux));
+            rc = dalloc(c, p->coop_state, std::max(max_groups, 2 * (p->coop_state.bytes / sizeof(CoopState))) * sizeof(CoopState));
             if (rc) return rc;
+            ++p->coop_state_gen;
         }
         rc = plan_alloc(L, cl.groups, hg.size() * sizeof(CoopGroup));
         if (!rc) rc = plan_alloc(L, cl.wg_group, hw.size() * sizeof(int));
@@ -1125,6 +1135,7 @@ int prepare_partition(rdis_hip_plan* L) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!L->h_rest.empty()) HIPCHK(c, hipMemcpyAsync(L->rest_order.p, L->h_rest.data(), L->h_rest.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     L->partition_dirty = false;
+    L->coop_state_gen = p->coop_state_gen;
     return 0;
 }
 
@@ -1160,7 +1171,9 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
 
     // a few very large components go to the cooperative multi-workgroup solver, one
     // launch each; everything else is one batched launch, one workgroup per component
-    if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
+    // (also when another plan of the problem has moved the exchange-state buffer this plan's
+    // cooperative group tables point into)
+    if (L->partition_dirty || (!L->coop.empty() && L->coop_state_gen != p->coop_state_gen)) { int rc = prepare_partition(L); if (rc) return rc; }
     PlanView V = L->view();
     HIPCHK(c, hipEventRecord(p->ev0, c->stream));
     // The batched launch is independent of the cooperative ones (disjoint components): it goes to a
@@ -1420,6 +1433,10 @@ extern "C" int rdis_hip_cgd_batch(rdis_hip_problem* p, int64_t ncomp, const int6
     rc = rdis_hip_plan_set_start(L, x_inout);
     if (!rc) rc = rdis_hip_plan_solve(L, maxiters, ftol);
     if (!rc) rc = rdis_hip_plan_fetch(L, x_inout, fret, delta, iters, status, nfeval, ngeval);
+    if (rc) {   // kernels or copies that use the plan's host staging vectors / arena slices may still be queued
+        (void)hipStreamSynchronize(p->ctx->stream);
+        if (p->ctx->aux) (void)hipStreamSynchronize(p->ctx->aux);
+    }
     rdis_hip_plan_destroy(L);
     return rc;
 }

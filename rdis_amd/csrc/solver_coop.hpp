@@ -45,6 +45,7 @@ struct CoopArgs {
     double* xi_glob;       // [n] published search direction
     int comp;
     int poll_delay;        // x64 cycles between publishing and the first sweep (a store needs about that long to land)
+    int speculate;         // evaluate guesses at the following trial steps with every line-search trial (minimizer.hpp)
 };
 
 // the CG recurrence of one free variable
@@ -77,6 +78,8 @@ struct CoopEnv {
         }
     }
     static constexpr bool UNIFORM = true;
+    static constexpr int SPEC = COOP_SPEC;   // trial steps per exchange (minimizer.hpp: speculation)
+    __device__ bool spec_on() const { return A.speculate != 0; }
     __device__ bool stepper() const { return threadIdx.x < 64; }
     __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
     __device__ void sync() const { __syncthreads(); }
@@ -119,6 +122,39 @@ struct CoopEnv {
         X.to_wave0<SLOPE ? 2 : 1>(fj, sj, dummy, SYNC_NONE);  // only the stepping wave consumes a line-search value
         X.finish_wave0(SYNC_NONE);
         f = fj; s = sj;
+    }
+    // SPEC trial steps at once: the evaluations are independent chains in one instruction stream
+    // (this wave is alone on its SIMD; a single evaluation is bound by instruction latency), and
+    // they share one exchange
+    __device__ void eval_value_slope_spec(const double (&ca)[SPEC], double (&cf)[SPEC], double (&cs)[SPEC]) {
+        double r[2 * SPEC];
+#pragma unroll
+        for (int k = 0; k < 2 * SPEC; ++k) r[k] = 0.0;
+        const long long tc0 = coop_clock();
+        if (has_fac) {
+#pragma unroll
+            for (int c = 0; c < SPEC; ++c) {
+                double v[12], g[12];
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const double t = ca[c] * dirv[k];
+                        v[k] = clampd(base[k] + t, lov[k], hiv[k]);
+                    }
+                }
+                r[2 * c] = ba_eval_grad(v, ox, oy, g);
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) acc += g[k] * dirv[k];
+                r[2 * c + 1] = acc;
+            }
+        }
+        X.tm[0] += coop_clock() - tc0;
+        X.to_wave0_n<2 * SPEC, 0>(r, SYNC_NONE);
+        X.finish_wave0(SYNC_NONE);
+#pragma unroll
+        for (int c = 0; c < SPEC; ++c) { cf[c] = r[2 * c]; cs[c] = r[2 * c + 1]; }
     }
     __device__ double eval_value(double a, bool restore) {
         if (restore) load_base(L.xstart + f0);  // objective at clamp(x_init) for the rollback
@@ -281,7 +317,7 @@ __device__ __forceinline__ void coop_solve(const ProblemView& P, const PlanView&
     const int gt = wg * blockDim.x + threadIdx.x;
 
     CoopEnv E{P, L, A, n, m, f0, c0, gt, (int)threadIdx.x,
-              GridSync{A.st, (int)threadIdx.x, nwg, wg, bcast, A.poll_delay, 0, 0u, false, {}},
+              GridSync{A.st, (int)threadIdx.x, nwg, wg, bcast, A.poll_delay, 0, 0u, false, 0u, {}},
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
               gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
     if (E.has_fac) {
@@ -327,9 +363,9 @@ __global__ void __launch_bounds__(256) coop_arm_kernel(const CoopGroup* __restri
     const CoopGroup G = groups[blockIdx.x];
     CoopState* st = G.a.st;
     const int entries = G.nwg * waves_per_wg;
-    for (int t = threadIdx.x; t < COOP_NBUF * COOP_K * entries; t += blockDim.x) {
-        const int e = t % entries, bk = t / entries;
-        st->granule[bk / COOP_K][bk % COOP_K][e] = ~0ull;
+    for (int t = threadIdx.x; t < COOP_NBUF * COOP_KP * entries; t += blockDim.x) {
+        const int k = t % COOP_KP, e = (t / COOP_KP) % entries, b = t / (COOP_KP * entries);
+        st->granule[b][e][k] = ~0ull;
     }
     if (threadIdx.x == 0) st->abort_flag = 0u;
 }

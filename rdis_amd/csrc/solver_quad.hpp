@@ -51,6 +51,7 @@ __device__ __forceinline__ double group_sum(double v) {
 template <int G>   // lanes per component: 4 or 16
 struct GroupEnv {
     static constexpr bool UNIFORM = false;
+    static constexpr int SPEC = 1;   // no speculative trial steps (minimizer.hpp)
     const ProblemView& P;
     const PlanView& L;
     int comp, n, m, f0, c0, sub;

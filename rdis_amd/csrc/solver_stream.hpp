@@ -51,6 +51,7 @@ struct StreamEnv {
         }
     }
     static constexpr bool UNIFORM = true;
+    static constexpr int SPEC = 1;   // no speculative trial steps (minimizer.hpp)
     __device__ bool stepper() const { return threadIdx.x < 64; }
     __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
     __device__ void sync() const { __syncthreads(); }
@@ -193,7 +194,7 @@ cgd_stream_kernel(ProblemView P, PlanView L, StreamArgs A, int maxiters, double 
     double* ws = L.ws + 5ll * f0;
 
     StreamEnv<KIND> E{P, L, A, n, m, f0, c0, gt, gsz, (int)threadIdx.x,
-                      GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, bcast, A.poll_delay, 0, 0u, false, {}},
+                      GridSync{A.st, (int)threadIdx.x, (int)gridDim.x, (int)blockIdx.x, bcast, A.poll_delay, 0, 0u, false, 0u, {}},
                       L.free_vid + f0, L.fac_id + c0, L.v2s_ptr + f0,
                       ws, ws + n, ws + 2ll * n, ws + 3ll * n, ws + 4ll * n,
                       L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0};

@@ -380,6 +380,7 @@ struct WgEnv {
     }
 
     static constexpr bool UNIFORM = true;
+    static constexpr int SPEC = 1;   // no speculative trial steps (minimizer.hpp)
     __device__ bool stepper() const { return threadIdx.x < 64; }
     __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
     __device__ void sync() const { __syncthreads(); }

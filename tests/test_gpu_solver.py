@@ -2,9 +2,14 @@
 oracle, i.e. with CGDSubspaceOptimizer::optimize of the reference.
 
 Why several kinds of check: 25 unconverged CG iterations are a chaotic map of
-the start point (tests/test_oracle.py::test_cgd_chaos_band -- a 1e-15 relative
+the start point (tests/test_oracle.py::test_cgd_is_chaotic -- a 1e-15 relative
 perturbation moves the end value by percents, for the reference itself too), so
 "end value equal to 1e-6" is only meaningful where the solve converges.  Hence:
+  * distribution: end values over one-ulp-perturbed starts, device against oracle
+               (configs 3 and 4); the oracle's unperturbed run IS the reference's
+               recorded one, bit for bit.
+  * converged: config 5 at its stated size (1000 components in one launch), every
+               converging component against an INDEPENDENT oracle run, 1e-6.
   * replay   : the device records every value its control logic saw; the oracle,
                fed those values, must ask for bit-identical step lengths, and
                its own evaluations at those points must agree to rounding.
@@ -139,14 +144,64 @@ def test_testpoly_converged_minima_match_golden(golden, gctx):
     assert abs(r.fret[0] - (-168.2721)) < 1e-4 and np.max(np.abs(r.x - (-4.6601))) < 1e-4
 
 
-def test_ladybug_golden_chaos_band(golden, gctx):
-    c = golden["cgd"]["ladybug_5_30"]
-    pp = P.load_bal(ncams=5, npts=30)
-    _, r, _ = solve(gctx, pp, maxiters=c["maxiters"])
-    assert (r.status[0] & 0xFF) == 3 and r.iters[0] == 24                       # exit by ITMAX like the reference
-    assert abs(r.fret[0] - c["fret"]) <= 0.05 * c["fret"]
-    assert abs(int(r.nfeval[0]) - c["nfeval"]) <= 0.15 * c["nfeval"]
-    assert abs((r.fret[0] - r.delta[0]) - c["f0"]) <= 1e-12 * c["f0"]           # initialFval
+def ulp_perturbed(x0, rng):
+    """every variable moved by one unit in the last place, up or down"""
+    return np.nextafter(x0, np.where(rng.random(x0.shape) < 0.5, -np.inf, np.inf))
+
+
+def oracle_end_values(pp, starts, maxiters, threads=8):
+    """independent oracle solves (reference-faithful rounding), in parallel: ctypes releases the GIL"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(x):
+        return O.OracleProblem(pp).cgd(x=x, maxiters=maxiters, ftol=3e-8).fret
+    with ThreadPoolExecutor(threads) as ex:
+        return np.array(list(ex.map(run, starts)))
+
+
+def device_end_values(gctx, pp, starts, maxiters):
+    g = capi.Problem(gctx, pp)
+    fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
+    plan = capi.Plan(g, np.array([0, len(fv)]), fv, np.array([0, len(fc)]), fc)
+    out = []
+    for x in starts:
+        plan.set_start(x)
+        plan.solve(maxiters, 3e-8)
+        r = plan.fetch()
+        assert (r.status[0] & 0xFF) == 3 and r.iters[0] == maxiters - 1      # exit by ITMAX like the reference
+        out.append(r.fret[0])
+    return np.array(out)
+
+
+BAND_MARGIN = 0.5   # the oracle's band [min, max] is widened by this fraction of its width on either side
+
+
+@pytest.mark.parametrize("key", ["ladybug_5_30", "ladybug_full"])
+def test_end_values_distribution_matches_oracle(key, golden, gctx):
+    """BASELINE configs 3 and 4.  25 unconverged CG iterations are a chaotic map of the start (a one-ulp
+    change of x0 moves the end value by percents, for the reference itself too), so the end value of ONE
+    run cannot be compared to 1e-6 between implementations that round differently.  What can: the
+    DISTRIBUTION of end values over one-ulp-perturbed starts.  16 such starts on the device, 8 on the
+    oracle (which reproduces the reference's recorded end value bit for bit from the unperturbed
+    start): the device's [min, median, max] must lie inside the oracle's band widened by BAND_MARGIN of
+    its width, and the reference's recorded value inside the device's band widened likewise."""
+    c = golden["cgd"][key]
+    pp = P.load_bal(ncams=c["ncams"], npts=c["npts"])
+    rng = np.random.default_rng(20260929)
+    ostarts = [pp.x0] + [ulp_perturbed(pp.x0, rng) for _ in range(7)]
+    dstarts = [pp.x0] + [ulp_perturbed(pp.x0, rng) for _ in range(15)]
+    oe = oracle_end_values(pp, ostarts, c["maxiters"])
+    assert oe[0] == c["fret"]                                      # the unperturbed oracle run IS the reference's
+    de = device_end_values(gctx, pp, dstarts, c["maxiters"])
+    olo, ohi, dlo, dhi = oe.min(), oe.max(), de.min(), de.max()
+    print("%s end values after %d iterations: oracle [%.6g, %.6g, %.6g] device [%.6g, %.6g, %.6g] (min, median, max), reference %.6g" % (
+        key, c["maxiters"], olo, np.median(oe), ohi, dlo, np.median(de), dhi, c["fret"]))
+    assert ohi - olo > 1e-4 * olo and dhi - dlo > 1e-4 * dlo       # the bands are real: chaos, on both sides
+    w = BAND_MARGIN * (ohi - olo)
+    assert olo - w <= dlo and dhi <= ohi + w, (oe, de)
+    assert olo - w <= np.median(de) <= ohi + w
+    wd = BAND_MARGIN * (dhi - dlo)
+    assert dlo - wd <= c["fret"] <= dhi + wd, (c["fret"], de)
 
 
 def test_ladybug_full_objective(golden, gctx):
@@ -155,8 +210,8 @@ def test_ladybug_full_objective(golden, gctx):
     pp = P.load_bal()
     g, r, tr = solve(gctx, pp, maxiters=25, trace=1 << 13)
     assert (r.status[0] & 0xFF) == 3 and r.iters[0] == 24
-    # chaos band: the oracle itself ends anywhere in 83189 .. 92367 when x0 is perturbed by 1e-15 relative
-    assert 0.96 * c["fret"] <= r.fret[0] <= 1.14 * c["fret"]
+    assert abs((r.fret[0] - r.delta[0]) - 850912.46068083902) <= 1e-12 * 850912.46068083902   # initialFval (golden)
+    # (end value: test_end_values_distribution_matches_oracle; evaluation counts vary with the trajectory)
     assert abs(int(r.nfeval[0]) - c["nfeval"]) <= 0.15 * c["nfeval"]
     # the returned value IS the objective at the returned point (size-independent check)
     assert np.array_equal(g.get_x(), r.x)                                       # variables left assigned
@@ -167,6 +222,67 @@ def test_ladybug_full_objective(golden, gctx):
     ro = O.OracleProblem(pp, emulate_stale_cache=False)
     ro.assign(None, r.x)
     assert abs(ro.eval() - r.fret[0]) <= 1e-12 * r.fret[0]                      # oracle's objective at the device's point
+
+
+def test_config5_synthetic_1000_components_converged_regime(gctx):
+    """BASELINE config 5 at its stated size: the 1000-component synthetic decomposition (3 cameras x 40
+    points each: 147 variables, 120 factors) in ONE launch.  These solves converge -- the regime where
+    north_star's "within 1e-6 relative" is attainable -- and every component is compared with an
+    INDEPENDENT oracle run of CGDSubspaceOptimizer::optimize (own trajectory, reference-faithful
+    rounding), not with a replay: exit reasons, and end values of every component that exits by the
+    function or gradient tolerance on both sides."""
+    pp = P.make_synthetic_ba(1000, 3, 40)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    ms, _ = plan.last_kernel_ms()
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(c):
+        fv, fc = pp.component(c)
+        return O.OracleProblem(pp).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25, ftol=3e-8)
+    with ThreadPoolExecutor(8) as ex:
+        ro = list(ex.map(run, range(1000)))
+    of = np.array([q.fret for q in ro]); ost = np.array([q.status & 0xFF for q in ro])
+    dst = r.status & 0xFF
+    conv = (dst <= 2) & (ost <= 2)
+    rel = np.abs(r.fret - of) / np.abs(of)
+    q = np.quantile(rel[conv], [0.5, 0.9, 0.99, 1.0])
+    print("config 5: %d of 1000 components converge on both sides (device %d, oracle %d); |f_dev - f_oracle| / |f| quantiles "
+          "50%% %.1e 90%% %.1e 99%% %.1e max %.1e; objective device %.9g oracle %.9g; %.2f ms on the device" % (
+              conv.sum(), (dst <= 2).sum(), (ost <= 2).sum(), q[0], q[1], q[2], q[3], r.fret.sum(), of.sum(), ms))
+    assert conv.sum() >= 900                                   # the converged regime is the rule here
+    assert np.all(rel[conv] <= 1e-6), np.sort(rel[conv])[-5:]  # north_star's bar, component by component
+    assert abs(r.fret.sum() - of.sum()) <= 1e-6 * of.sum()     # and for the top-level objective (what the all-reduce carries)
+    # components still on their way at the iteration limit are on the same slow plateau: percents
+    assert np.all(rel[~conv] <= 5e-2)
+    assert np.all(r.delta <= 0) and np.all((dst != 5) & (dst != 7))
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    o.assign(None, r.x)
+    assert abs(o.eval() - r.fret.sum()) <= 1e-12 * r.fret.sum()          # returned values are the objective at the returned point
+
+
+def test_plans_survive_a_move_of_the_exchange_state(gctx):
+    """a persistent plan with ONE cooperative group, then a call whose 49 groups make the problem's
+    exchange-state buffer grow (and move), then the first plan again: same bits, no timeout"""
+    pp = P.load_bal()
+    g = capi.Problem(gctx, pp)
+    fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
+    a = capi.Plan(g, np.array([0, len(fv)]), fv, np.array([0, len(fc)]), fc)
+    a.set_start(pp.x0)
+    a.solve(3, 3e-8)
+    r1 = a.fetch()
+    cams, _pts = P.ba_alternation_plans(pp)                     # 49 camera components: one group each
+    x = pp.x0[cams[1]]
+    rb = g.cgd_batch(cams[0], cams[1], cams[2], cams[3], x, 3, 3e-8)
+    assert np.all((rb.status & 0xFF) != 7)
+    g.set_x(pp.x0)
+    a.solve(3, 3e-8)
+    r2 = a.fetch()
+    assert (r2.status[0] & 0xFF) != 7
+    assert r2.fret[0] == r1.fret[0] and np.array_equal(r2.x, r1.x) and r2.nfeval[0] == r1.nfeval[0]
 
 
 def test_rdis_separator_block_on_full_ladybug(gctx):
