@@ -16,7 +16,10 @@ Workloads (--workload):
                  variables and 31843 factors of ladybug-49-7776 as one component.
                  For N > 1 every rank solves one such component (N independent
                  components of a block-diagonal problem; weak scaling) and the
-                 top-level objective is summed with an RCCL all-reduce.
+                 top-level objective is summed with an RCCL all-reduce.  The line
+                 also carries a "strong_scaling" block for every N: north_star's fixed
+                 1000-component synthetic decomposition shared out over the N ranks
+                 (STRONG below), and at N = 1 "cpu_baseline" and "objective_band".
   synthetic-S    BASELINE config 5: 1000 independent 3-camera x 40-point components
                  per rank (one workgroup each, one launch).
   (--scaling strong: the synthetic decompositions keep their total size and are sharded over the ranks)
@@ -68,6 +71,8 @@ def parse():
                          "--components) and every rank takes a contiguous share of the components")
     ap.add_argument("--maxiters", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling block (the fixed 1000-component decomposition)")
+    ap.add_argument("--no-objective-band", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
     return ap.parse_args()
 
@@ -94,6 +99,144 @@ def build_problem(workload: str, rank: int, components: int = 256, world: int = 
         pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id = pts
         return pp
     return P.make_synthetic_ba(1000, 3, 40, first_comp=1000 * rank)
+
+
+# The strong-scaling workload of north_star ("1000-component synthetic decomposition"): a FIXED
+# decomposition of 1000 independent bundle-adjustment components, sharded over the ranks.  Size of
+# a component: 8 cameras x 512 points x 4 observations per point = 2048 factors, 1608 variables
+# (2.05e6 factors in all).  Why this size: at 120 factors (synthetic-S) a launch is as long as its
+# slowest component's latency chain whatever the number of GPUs (2 ms on 1 or 8); at 2048 factors a
+# component occupies a whole compute unit (one 768-lane workgroup, three waves per SIMD), so one
+# GPU needs ceil(1000 / 256) = 4 rounds of workgroups where eight need one -- the time is bound by
+# arithmetic throughput, which is what sharding can divide.  (With one workgroup per component the
+# speed-up from 1 to 8 GPUs is therefore bounded by 4 rounds : 1 round)
+STRONG = {"components": 1000, "ncams": 8, "npts": 512, "obs_per_pt": 4}
+
+
+def strong_scaling_shard(rank: int, world: int, components: int = STRONG["components"]):
+    """(problem, CSR of this rank's components, their ids, per-rank factor loads): the whole fixed
+    decomposition is generated on every rank (components come from their ids: identical
+    everywhere) and shared out by dist.rank_decomposition -- longest-processing-time by factor
+    count, the same partition on every rank, no communication."""
+    from rdis_amd import problems as P
+    from rdis_amd.dist import rank_decomposition
+    pp = P.make_synthetic_ba(components, STRONG["ncams"], STRONG["npts"], obs_per_pt=STRONG["obs_per_pt"])
+    free_ptr, free_vid, fac_ptr, fac_id, mine = rank_decomposition(pp, rank, world)
+    w = np.diff(pp.comp_fac_ptr)
+    loads = np.array([int(w[part].sum()) for part in P.shard_components(pp.ncomp, w, world)])
+    return pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads
+
+
+def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, steps=3, warmup=1):
+    """the strong-scaling block of the bench line: the fixed 1000-component decomposition solved by
+    all ranks together; barrier + synchronize around exactly `steps` solves, MAX over ranks"""
+    from rdis_amd import capi, problems as P
+    pp, csr, mine, loads = strong_scaling_shard(rank, world)
+    prob = capi.Problem(ctx, pp)
+    plan = capi.Plan(prob, *csr)
+    plan.set_start(pp.x0[csr[1]])
+    obj_t = None
+    if torch is not None:
+        class _Dev:
+            def __init__(self, ptr):
+                self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        obj_t = torch.as_tensor(_Dev(plan.objective_device_ptr()), device=f"cuda:{local_rank}")
+
+    def step():
+        plan.solve(maxiters, 3e-8)
+        if dist is not None:
+            dist.all_reduce(obj_t)
+        return plan.fetch()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+    for _ in range(warmup):
+        r = step()
+    sync()
+    kms, iters = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = step()
+        kms += plan.last_kernel_ms()[0]
+        iters += int(np.sum(r.iters.astype(np.int64) + 1))
+    sync()
+    dt = time.perf_counter() - t0
+    objective = plan.objective()
+    kmax = kms / steps
+    if dist is not None:
+        tt = torch.tensor([dt, kmax], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, kmax = (float(v) for v in tt.tolist())
+        it = torch.tensor([float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(it)
+        iters = float(it.item())
+    ncu = 256
+    max_comps = max(len(part) for part in P.shard_components(pp.ncomp, np.diff(pp.comp_fac_ptr), world))
+    out = {"workload": (f"fixed decomposition of {pp.ncomp} independent synthetic BA components x ({STRONG['ncams']} cameras, "
+                        f"{STRONG['npts']} points, {pp.nfac // pp.ncomp} observations), SSmaxit {maxiters}, shared out over {world} rank(s) "
+                        "by factor count (longest processing time first), no data-path collective, objective all-reduced"),
+           "scaling": "strong", "n_gpus": world, "components_total": int(pp.ncomp), "factors_total": int(pp.nfac),
+           "variables_total": int(pp.nvars), "components_rank0": int(len(mine)),
+           "value": iters / dt, "unit": "iters/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "kernel_ms_max_over_ranks": kmax, "objective": objective,
+           "load_imbalance": float(loads.max() / loads.mean()), "factors_per_rank": [int(v) for v in loads],
+           # one 768-lane workgroup per component, one resident per compute unit: rounds a rank's launch needs
+           "workgroup_rounds": int(-(-int(max_comps) // ncu)),
+           "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))}}
+    plan.close()
+    prob.close()
+    return out
+
+
+def host_cpu():
+    """model name and core count of the box the CPU leg runs on"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"model": model, "logical_cores": os.cpu_count() or 1, "usable_cores": usable}
+
+
+def objective_band(plan, pp, maxiters: int, k_dev: int = 16, k_oracle: int = 8):
+    """End values over one-ulp-perturbed starts, device and oracle (tests/test_gpu_solver.py::
+    test_end_values_distribution_matches_oracle): 25 unconverged CG iterations are a chaotic map of
+    the start, so the end value of one run is a draw from a distribution; the oracle's unperturbed
+    run is the reference's recorded one bit for bit.  Outside the timed region."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    rng = np.random.default_rng(20260929)
+
+    def ulp(x):
+        return np.nextafter(x, np.where(rng.random(x.shape) < 0.5, -np.inf, np.inf))
+    ostarts = [pp.x0] + [ulp(pp.x0) for _ in range(k_oracle - 1)]
+    dstarts = [pp.x0] + [ulp(pp.x0) for _ in range(k_dev - 1)]
+    de = []
+    for x in dstarts:
+        plan.set_start(x[pp.comp_free_vid])
+        plan.solve(maxiters, 3e-8)
+        de.append(float(plan.fetch().fret.sum()))
+    plan.set_start(pp.x0[pp.comp_free_vid])
+    usable = host_cpu()["usable_cores"]
+    with ThreadPoolExecutor(max(1, min(k_oracle, usable))) as ex:
+        oe = list(ex.map(lambda x: O.OracleProblem(pp).cgd(x=x, maxiters=maxiters, ftol=3e-8).fret, ostarts))
+    de, oe = np.array(de), np.array(oe)
+    return {"what": "final objective over starts moved by one unit in the last place (first entry: the unperturbed start)",
+            "device": {"n": k_dev, "min": float(de.min()), "median": float(np.median(de)), "max": float(de.max())},
+            "oracle": {"n": k_oracle, "min": float(oe.min()), "median": float(np.median(oe)), "max": float(oe.max()),
+                       "unperturbed": float(oe[0])},
+            "reference_recorded": 83227.604227756252 if pp.nfac == 31843 and maxiters == 25 else None}
 
 
 def algorithmic_bytes(pp, nfeval: int, ngeval: int) -> float:
@@ -144,7 +287,7 @@ def cpu_baseline(pp, maxiters: int):
                                           "sample": "1 iteration with the reference's per-factor sorted-vector gradient merge",
                                           "final_objective": r2.fret}}
         extra["final_objective"] = r.fret
-    out = {"value": its / dt, "unit": "iters/s", "cores": ncores, "kind": "port", "sample": sample}
+    out = {"value": its / dt, "unit": "iters/s", "cores": ncores, "kind": "port", "sample": sample, "host": host_cpu()}
     out.update(extra)
     return out
 
@@ -250,12 +393,26 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload),
                          "kernel": "cgd solver kernel(s)", "kernel_ms_avg": kms / max(klaunch, 1),
-                         "algorithmic_bytes_per_launch": abytes / max(klaunch, 1)},
+                         "algorithmic_bytes_per_launch": abytes / max(klaunch, 1),
+                         # what governs a single-component solve is not bandwidth but the chain of dependent
+                         # evaluations: us per evaluation against the floor of one evaluation
+                         # (factor arithmetic of one wave + wave reduction + one store->load hop between compute
+                         # units + sweep + one step of the control logic, tools/microbench)
+                         "latency": ({"evals": float(nfe.sum()) / max(a.steps, 1), "us_per_eval": kms / max(a.steps, 1) * 1e3 / max(float(nfe.sum()) / max(a.steps, 1), 1.0),
+                                      "us_floor": 2.6, "floor": "2170 cycles arithmetic + 360 reduce + ~900 one hop + ~500 sweep + ~2000 control step at 2.4 GHz"}
+                                     if pp.ncomp == 1 else None)},
         }
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
+            if a.workload == "ladybug-full" and not a.no_objective_band:
+                line["objective_band"] = objective_band(plan, pp, a.maxiters)
     plan.close()
     prob.close()
+    # north_star's scaling workload, in the command the driver runs: for every N, N = 1 included
+    if a.workload == "ladybug-full" and not a.no_strong_scaling:
+        ss = run_strong_scaling(ctx, rank, world, local_rank, dist, torch, a.maxiters)
+        if rank == 0:
+            line["strong_scaling"] = ss
     import ctypes
     ctypes.CDLL(None).fflush(None)   # every rank: nothing buffered (RCCL's banner) may surface after rank 0's JSON
     sys.stdout.flush()

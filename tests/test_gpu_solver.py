@@ -8,8 +8,10 @@ perturbation moves the end value by percents, for the reference itself too), so
   * distribution: end values over one-ulp-perturbed starts, device against oracle
                (configs 3 and 4); the oracle's unperturbed run IS the reference's
                recorded one, bit for bit.
-  * converged: config 5 at its stated size (1000 components in one launch), every
-               converging component against an INDEPENDENT oracle run, 1e-6.
+  * config 5 : at its stated size (1000 components in one launch), every component
+               against an INDEPENDENT oracle run; measured: no converged regime exists
+               for BA under this algorithm (the oracle differs from itself by 11 %
+               after a one-ulp change), so populations are compared.
   * replay   : the device records every value its control logic saw; the oracle,
                fed those values, must ask for bit-identical step lengths, and
                its own evaluations at those points must agree to rounding.
@@ -224,13 +226,32 @@ def test_ladybug_full_objective(golden, gctx):
     assert abs(ro.eval() - r.fret[0]) <= 1e-12 * r.fret[0]                      # oracle's objective at the device's point
 
 
-def test_config5_synthetic_1000_components_converged_regime(gctx):
+def _ks(a, b):
+    """two-sample Kolmogorov-Smirnov statistic"""
+    allv = np.sort(np.concatenate([a, b]))
+    return float(np.max(np.abs(np.searchsorted(np.sort(a), allv, side="right") / len(a) -
+                               np.searchsorted(np.sort(b), allv, side="right") / len(b))))
+
+
+def test_config5_synthetic_1000_components(gctx):
     """BASELINE config 5 at its stated size: the 1000-component synthetic decomposition (3 cameras x 40
-    points each: 147 variables, 120 factors) in ONE launch.  These solves converge -- the regime where
-    north_star's "within 1e-6 relative" is attainable -- and every component is compared with an
+    points each: 147 variables, 120 factors) in ONE launch, every component compared with an
     INDEPENDENT oracle run of CGDSubspaceOptimizer::optimize (own trajectory, reference-faithful
-    rounding), not with a replay: exit reasons, and end values of every component that exits by the
-    function or gradient tolerance on both sides."""
+    rounding) -- not a replay.
+
+    What "the same result" can mean here was measured, not assumed: most components leave by the
+    function tolerance (2|df| <= 3e-8 (|f| + |fp|)) after 10-25 iterations, but that test fires on a
+    plateau of the CG descent, not at a minimum -- the ORACLE ITSELF, restarted from a start moved by
+    one unit in the last place, ends 11 % away (median over components; a quarter of them 23 % and
+    more).  There is no converged regime for bundle adjustment under this algorithm, with the
+    reference's own arithmetic; per-component end values are draws from a distribution.  So the test
+    compares distributions, with the oracle-against-perturbed-oracle spread as the yardstick:
+      * paired differences device / oracle are no larger than oracle / perturbed oracle,
+      * the two populations of 1000 end values are indistinguishable (Kolmogorov-Smirnov, quantiles),
+      * the top-level objective (the sum the all-reduce carries) agrees within the spread of such sums,
+      * exit reasons occur at the same rates.
+    The per-evaluation parity of these very solves is pinned bit for bit by the replay tests
+    (synthetic_3x40, test_batch_replay_of_members)."""
     pp = P.make_synthetic_ba(1000, 3, 40)
     g = capi.Problem(gctx, pp)
     plan = capi.Plan(g)
@@ -239,29 +260,55 @@ def test_config5_synthetic_1000_components_converged_regime(gctx):
     r = plan.fetch()
     ms, _ = plan.last_kernel_ms()
     from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(5)
+    x1 = ulp_perturbed(pp.x0, rng)
 
-    def run(c):
+    def run(args):
+        c, x, stale = args
         fv, fc = pp.component(c)
-        return O.OracleProblem(pp).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25, ftol=3e-8)
+        return O.OracleProblem(pp, emulate_stale_cache=stale).cgd(free_vid=fv, fac=fc, x=x[fv], maxiters=25, ftol=3e-8)
+    # The comparator recomputes every factor at every trial point, like the device.  The reference keeps
+    # a factor's cached value when none of its variables moved by 1e-12 (Variable.cpp:70-76), a quirk the
+    # device deliberately does not emulate: it changes values at the 1e-12 level, but on
+    # these plateaus that shifts how often the 3e-8 test fires -- 859 tolerance exits of 1000 with the
+    # quirk, 939 without (oracle against oracle) -- so the reference-faithful population is reported
+    # and bounded separately below.
     with ThreadPoolExecutor(8) as ex:
-        ro = list(ex.map(run, range(1000)))
-    of = np.array([q.fret for q in ro]); ost = np.array([q.status & 0xFF for q in ro])
-    dst = r.status & 0xFF
-    conv = (dst <= 2) & (ost <= 2)
-    rel = np.abs(r.fret - of) / np.abs(of)
-    q = np.quantile(rel[conv], [0.5, 0.9, 0.99, 1.0])
-    print("config 5: %d of 1000 components converge on both sides (device %d, oracle %d); |f_dev - f_oracle| / |f| quantiles "
-          "50%% %.1e 90%% %.1e 99%% %.1e max %.1e; objective device %.9g oracle %.9g; %.2f ms on the device" % (
-              conv.sum(), (dst <= 2).sum(), (ost <= 2).sum(), q[0], q[1], q[2], q[3], r.fret.sum(), of.sum(), ms))
-    assert conv.sum() >= 900                                   # the converged regime is the rule here
-    assert np.all(rel[conv] <= 1e-6), np.sort(rel[conv])[-5:]  # north_star's bar, component by component
-    assert abs(r.fret.sum() - of.sum()) <= 1e-6 * of.sum()     # and for the top-level objective (what the all-reduce carries)
-    # components still on their way at the iteration limit are on the same slow plateau: percents
-    assert np.all(rel[~conv] <= 5e-2)
-    assert np.all(r.delta <= 0) and np.all((dst != 5) & (dst != 7))
+        ro = list(ex.map(run, [(c, pp.x0, False) for c in range(1000)]))
+        rp = list(ex.map(run, [(c, x1, False) for c in range(1000)]))
+        rq = list(ex.map(run, [(c, pp.x0, True) for c in range(1000)]))
+    of, pf = np.array([q.fret for q in ro]), np.array([q.fret for q in rp])
+    ost, pst, dst = np.array([q.status & 0xFF for q in ro]), np.array([q.status & 0xFF for q in rp]), r.status & 0xFF
+    finit = np.array([q.finit for q in ro])
+    assert np.max(np.abs((r.fret - r.delta) - finit) / finit) <= 1e-12            # same initial values
+    d_do = np.abs(r.fret - of) / np.abs(of)          # device against oracle
+    d_oo = np.abs(pf - of) / np.abs(of)              # oracle against itself, start moved by one ulp
+    qs = [0.1, 0.25, 0.5, 0.75, 0.9]
+    qd, qo, qp = np.quantile(r.fret / finit, qs), np.quantile(of / finit, qs), np.quantile(pf / finit, qs)
+    ks_do, ks_oo = _ks(r.fret / finit, of / finit), _ks(pf / finit, of / finit)
+    print("config 5 (1000 components, %.2f ms on the device): paired |df|/f median / 75%% -- device:oracle %.3f / %.3f, oracle:oracle' %.3f / %.3f; "
+          "KS device:oracle %.3f oracle:oracle' %.3f; f_end/f_0 quantiles 10..90%% device %s oracle %s; objective device %.6g oracle %.6g oracle' %.6g; "
+          "tolerance exits device %d oracle %d oracle' %d" % (
+              ms, np.median(d_do), np.quantile(d_do, 0.75), np.median(d_oo), np.quantile(d_oo, 0.75), ks_do, ks_oo,
+              np.array2string(qd, precision=5), np.array2string(qo, precision=5), r.fret.sum(), of.sum(), pf.sum(),
+              (dst <= 2).sum(), (ost <= 2).sum(), (pst <= 2).sum()))
+    assert np.median(d_oo) > 1e-3                                   # the premise: the oracle does not agree with itself
+    assert np.median(d_do) <= 1.5 * np.median(d_oo) and np.quantile(d_do, 0.75) <= 1.5 * np.quantile(d_oo, 0.75)
+    assert ks_do <= 0.0872                                          # 1.95 sqrt(2 / 1000): alpha = 0.001
+    assert np.all(np.abs(qd - qo) <= 0.1 * qo + 3 * np.abs(qp - qo))
+    spread = abs(pf.sum() - of.sum())
+    assert abs(r.fret.sum() - of.sum()) <= max(3 * spread, 0.03 * of.sum())
+    assert abs(int((dst <= 2).sum()) - int((ost <= 2).sum())) <= 35 and np.all((dst != 5) & (dst != 7))   # 3 sigma of a binomial count
+    # against the reference-faithful population (stale factor cache emulated): same distribution up to
+    # the documented shift of the exit rate
+    qf, qfst = np.array([q.fret for q in rq]), np.array([q.status & 0xFF for q in rq])
+    print("   reference-faithful oracle (stale factor cache emulated): tolerance exits %d, objective %.6g, KS device:reference %.3f" % (
+        (qfst <= 2).sum(), qf.sum(), _ks(r.fret / finit, qf / finit)))
+    assert _ks(r.fret / finit, qf / finit) <= 0.0872 and abs(r.fret.sum() - qf.sum()) <= 0.05 * qf.sum()
+    assert np.all(r.delta <= 0)
     o = O.OracleProblem(pp, emulate_stale_cache=False)
     o.assign(None, r.x)
-    assert abs(o.eval() - r.fret.sum()) <= 1e-12 * r.fret.sum()          # returned values are the objective at the returned point
+    assert abs(o.eval() - r.fret.sum()) <= 1e-12 * r.fret.sum()          # returned values ARE the objective at the returned point
 
 
 def test_plans_survive_a_move_of_the_exchange_state(gctx):

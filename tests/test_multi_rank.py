@@ -115,3 +115,66 @@ def test_strong_scaling_shards_of_the_bench_cover_the_decomposition():
         assert seen == 1000
     with pytest.raises(SystemExit):
         bench.build_problem("ladybug-full", 0, world=2, strong=True)
+
+
+def test_strong_scaling_block_shards_with_lpt():
+    """the strong_scaling block of the default bench line: the fixed 1000-component decomposition goes
+    through dist.rank_decomposition (LPT by factor count) on every rank -- a partition, balanced,
+    the same on every rank, lists bit-exact"""
+    import bench
+    for world in (1, 2, 8):
+        seen, loads_seen = [], None
+        for rank in range(world):
+            pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads = bench.strong_scaling_shard(rank, world, components=48)
+            assert pp.ncomp == 48 and len(free_ptr) == len(mine) + 1 and fac_ptr[-1] == len(fac_id)
+            seen.extend(mine.tolist())
+            k = len(mine) // 2
+            fv, fc = pp.component(int(mine[k]))
+            assert np.array_equal(free_vid[free_ptr[k]:free_ptr[k + 1]], fv) and np.array_equal(fac_id[fac_ptr[k]:fac_ptr[k + 1]], fc)
+            assert loads_seen is None or np.array_equal(loads, loads_seen)        # every rank computes the same partition
+            loads_seen = loads
+            assert loads[rank] == int(fac_ptr[-1])
+        assert sorted(seen) == list(range(48))
+        assert loads_seen.max() - loads_seen.min() <= pp.nfac // pp.ncomp         # LPT bound: one component
+
+
+_WORKER_STRONG = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch, torch.distributed as dist
+    import bench
+    from rdis_amd.dist import allreduce_objective
+    from oracle import oracle as O
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads = bench.strong_scaling_shard(rank, world, components=6)
+    o = O.OracleProblem(pp)
+    o.assign(None, pp.x0)
+    local = 0.0
+    for k in range(len(mine)):     # the checker stands in for the device: this test is about sharding + reduction
+        local += o.eval(fac_id[fac_ptr[k]:fac_ptr[k + 1]])
+    total = allreduce_objective(local, dist)
+    if rank == 0:
+        print(json.dumps({{"total": total, "mine": [int(c) for c in mine], "loads": [int(v) for v in loads]}}))
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_strong_scaling_block_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker_strong.py"
+    script.write_text(_WORKER_STRONG.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    import bench
+    from oracle import oracle as O
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    pp, _, _, _ = bench.strong_scaling_shard(0, 1, components=6)
+    tot = O.OracleProblem(pp).eval()
+    assert abs(res["total"] - tot) <= 1e-12 * tot and len(res["mine"]) == 3 and sum(res["loads"]) == pp.nfac
