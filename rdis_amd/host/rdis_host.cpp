@@ -253,6 +253,14 @@ void OptimizableFunction::computeGradient(NumericVec& gradient, bool) const {
     for (const auto& kv : pg) gradient[(size_t)kv.first] = kv.second;
 }
 
+void OptimizableFunction::adoptDeviceValues(const std::vector<int64_t>& vids, const std::vector<double>& vals) {
+    for (size_t i = 0; i < vids.size(); ++i) {
+        Variable* v = variables[(size_t)vids[i]];
+        v->assigned_ = true; v->value_ = vals[i];
+        onVarAssigned(v->getID(), vals[i]);
+    }
+}
+
 // ------------------------------------------------------------------ BundleAdjustmentFunction
 void BundleAdjustmentFunction::getBlockRangeByBlkId(VariableCount b, VariableID& lo, VariableID& hi) const {
     if (b < ncams_) { lo = getCamVID(b, 0); hi = getCamVID(b, 8); }

@@ -169,8 +169,16 @@ public:
     virtual void computeGradient(const FactorPtrVec& facs, PartialGradient& gradient, bool checkGrad = false) const;
     virtual void computeGradient(NumericVec& gradient, bool checkGrad = false) const;
 
+    // variable blocks (src/OptimizableFunction.h:157-179): the variables an outer optimiser assigns
+    // together.  Default: every variable is its own block.
+    virtual bool hasBlockedVars() const { return false; }
+    virtual void getBlockRangeByVid(VariableID vid, VariableID& lower, VariableID& upper) const { lower = upper = vid; }
+
     // assign every variable (State x) -- optBA's "assign the initial state"
     void assignAll(const NumericVec& x);
+    // the device has assigned these values itself (a solve leaves its variables assigned there):
+    // mirror them on the host side without marking them for upload
+    void adoptDeviceValues(const std::vector<int64_t>& vids, const std::vector<double>& vals);
     void initDevice(int device = 0);          // upload the packed function (done lazily otherwise)
     rdis_hip_problem* deviceProblem() const;  // uploads + pushes pending assignments
     rdis_hip_ctx* deviceContext() const;
@@ -227,6 +235,11 @@ public:
     // blocks = camera (9) / point (3) (.h:51-78)
     VariableCount getNumBlocks() const { return ncams_ + npts_; }
     void getBlockRangeByBlkId(VariableCount b, VariableID& lo, VariableID& hi) const;
+    virtual bool hasBlockedVars() const { return true; }
+    virtual void getBlockRangeByVid(VariableID vid, VariableID& lower, VariableID& upper) const {
+        if (vid < ncams_ * 9) { lower = vid / 9 * 9; upper = lower + 8; }
+        else { lower = ncams_ * 9 + (vid - ncams_ * 9) / 3 * 3; upper = lower + 2; }
+    }
     const NumericVec& getInitialState() const { return xinit; }
 private:
     void setDomain(VariableID vid, Numeric initialVal);  // .cpp:402-477
@@ -252,6 +265,8 @@ public:
     explicit SubspaceOptimizer(OptimizableFunction& f_);
     virtual ~SubspaceOptimizer() {}
     virtual void setParameters(const Options& options);  // SSmaxit, SSftol (src/SubspaceOptimizer.cpp:26-32)
+    size_t getMaxIters() const { return maxiters; }
+    Numeric getFtol() const { return ftol; }
     // vars / factors define the sub-function; xval: start values in the order of vars, overwritten
     // with the final (clamped) values; deltaFval = f(x_end) - f(x_init); returns f(x_end)
     virtual Numeric optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xval,

@@ -1,0 +1,333 @@
+// rdis_levels.cpp -- see rdis_levels.h.  Host bookkeeping of the decomposition tree; the component
+// labelling and every solve go through include/rdis_hip.h.
+#include "rdis_levels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <iostream>
+#include <numeric>
+
+#include "../../include/rdis_hip.h"
+
+namespace rdis {
+
+namespace {
+void check(rdis_hip_ctx* ctx, int rc, const char* where) {
+    if (rc != 0) throw HipError(rc, std::string(where) + ": " + (ctx ? rdis_hip_last_error(ctx) : "no context"));
+}
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct UnionFind {
+    std::vector<int> parent, size;
+    explicit UnionFind(size_t n) : parent(n), size(n, 0) { std::iota(parent.begin(), parent.end(), 0); }
+    int find(int x) { while (parent[(size_t)x] != x) { parent[(size_t)x] = parent[(size_t)parent[(size_t)x]]; x = parent[(size_t)x]; } return x; }
+    int unite(int a, int b) {
+        a = find(a); b = find(b);
+        if (a == b) return a;
+        if (size[(size_t)a] < size[(size_t)b]) std::swap(a, b);
+        parent[(size_t)b] = a; size[(size_t)a] += size[(size_t)b];
+        return a;
+    }
+};
+}  // namespace
+
+struct HipRDISLevelOptimizer::LevelPlan {
+    int depth = 0, kind = 0;
+    std::vector<int> node;                  // node index of each component
+    std::vector<int64_t> free_ptr, free_vid, fac_ptr, fac_id;
+    rdis_hip_plan* plan = nullptr;
+    std::vector<double> x, fret, delta;
+    std::vector<int32_t> iters, status;
+};
+
+HipRDISLevelOptimizer::HipRDISLevelOptimizer(OptimizableFunction& f, HipCGDSubspaceOptimizer& ssopt)
+    : f_(f), ss_(ssopt), blkpct_(0.2), steptol_(1.0e-4), maxSweeps_(20), batch_(true),
+      ssmaxit_(ssopt.getMaxIters()), ssftol_(ssopt.getFtol()), sweeps_(0), decomp_ms_(0) {}
+
+HipRDISLevelOptimizer::~HipRDISLevelOptimizer() { releasePlans(); }
+
+void HipRDISLevelOptimizer::releasePlans() {
+    for (LevelPlan* lp : plans_) {
+        if (lp->plan) rdis_hip_plan_destroy(lp->plan);
+        delete lp;
+    }
+    plans_.clear();
+}
+
+void HipRDISLevelOptimizer::setParameters(const Options& o) {
+    if (o.count("AVblkpct")) blkpct_ = o.as<double>("AVblkpct");     // RDISOptimizer.cpp:95
+    if (o.count("steptol")) steptol_ = o.as<double>("steptol");      // :1089-1090
+    if (o.count("maxSweeps")) maxSweeps_ = o.as<int>("maxSweeps");
+    if (o.count("batch")) batch_ = o.as<int>("batch") != 0;
+    if (blkpct_ <= 0 || blkpct_ > 1 || maxSweeps_ < 1) throw std::invalid_argument("HipRDISLevelOptimizer: bad options");
+}
+
+void HipRDISLevelOptimizer::chooseSeparator(const OptimizableFunction& f, const std::vector<VariableID>& vars,
+                                            const std::vector<FactorID>& factors, size_t maxPiece,
+                                            std::vector<VariableID>& separator) {
+    separator.clear();
+    const FactorPtrVec& allf = f.getFactors();
+    // blocks of the component: local block index per variable
+    std::vector<VariableID> blk_lo;                 // first variable id of each block, ascending
+    std::vector<int> blk_nv;                        // variables of the block that are in the component
+    std::vector<std::pair<VariableID, int> > v2b;   // (vid, block) sorted by vid
+    v2b.reserve(vars.size());
+    for (VariableID v : vars) {
+        VariableID lo = v, hi = v;
+        f.getBlockRangeByVid(v, lo, hi);
+        if (blk_lo.empty() || blk_lo.back() != lo) { blk_lo.push_back(lo); blk_nv.push_back(0); }
+        ++blk_nv.back();
+        v2b.push_back(std::make_pair(v, (int)blk_lo.size() - 1));
+    }
+    const size_t nb = blk_lo.size();
+    auto block_of = [&](VariableID v) -> int {
+        auto it = std::lower_bound(v2b.begin(), v2b.end(), std::make_pair(v, -1));
+        return (it != v2b.end() && it->first == v) ? it->second : -1;
+    };
+    // per factor the distinct component blocks it reads; block degree
+    std::vector<std::vector<int> > fblk(factors.size());
+    std::vector<long long> deg(nb, 0);
+    for (size_t j = 0; j < factors.size(); ++j) {
+        for (const Variable* v : allf[(size_t)factors[j]]->getVariables()) {
+            const int b = block_of(v->getID());
+            if (b >= 0 && std::find(fblk[j].begin(), fblk[j].end(), b) == fblk[j].end()) fblk[j].push_back(b);
+        }
+        for (int b : fblk[j]) ++deg[(size_t)b];
+    }
+    std::vector<int> order(nb);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    // factors by block, to connect a block to the blocks already put back
+    std::vector<std::vector<int> > bfac(nb);
+    for (size_t j = 0; j < factors.size(); ++j) for (int b : fblk[j]) bfac[(size_t)b].push_back((int)j);
+    UnionFind uf(nb);
+    std::vector<char> in(nb, 0);
+    std::vector<int> seen_stamp(nb, -1);
+    bool closed = false;   // once a block does not fit, every block of higher degree is a separator block too
+    for (size_t k = 0; k < nb; ++k) {
+        const int b = order[k];
+        if (!closed) {
+            // size of the piece this block would create
+            long long total = blk_nv[(size_t)b];
+            for (int j : bfac[(size_t)b])
+                for (int o : fblk[(size_t)j]) {
+                    if (o == b || !in[(size_t)o]) continue;
+                    const int r = uf.find(o);
+                    if (seen_stamp[(size_t)r] == (int)k) continue;
+                    seen_stamp[(size_t)r] = (int)k;
+                    total += uf.size[(size_t)r];
+                }
+            if ((size_t)total <= maxPiece) {
+                in[(size_t)b] = 1;
+                uf.size[(size_t)uf.find(b)] = blk_nv[(size_t)b];
+                for (int j : bfac[(size_t)b])
+                    for (int o : fblk[(size_t)j])
+                        if (o != b && in[(size_t)o]) uf.unite(b, o);
+                continue;
+            }
+            closed = true;
+        }
+    }
+    std::vector<char> in_sep(nb, 0);
+    bool any = false;
+    for (size_t b = 0; b < nb; ++b) if (!in[b]) { in_sep[b] = 1; any = true; }
+    if (any) {
+        // ensureFactorWillBeAssigned: the first factor with the fewest variables outside the separator
+        long long best = -1; size_t bestj = 0;
+        for (size_t j = 0; j < factors.size(); ++j) {
+            bool touches = false; long long left = 0;
+            for (int b : fblk[j]) { if (in_sep[(size_t)b]) touches = true; else left += blk_nv[(size_t)b]; }
+            if (!touches || left == 0) { if (touches && left == 0) { best = 0; break; } continue; }
+            if (best < 0 || left < best) { best = left; bestj = j; }
+        }
+        if (best > 0) for (int b : fblk[bestj]) in_sep[(size_t)b] = 1;
+    }
+    for (const auto& vb : v2b) if (in_sep[(size_t)vb.second]) separator.push_back(vb.first);
+}
+
+void HipRDISLevelOptimizer::buildTree() {
+    const double t0 = now_ms();
+    nodes_.clear();
+    const VariablePtrVec& vars = f_.getVariables();
+    const FactorPtrVec& facs = f_.getFactors();
+    const size_t N = vars.size();
+    const size_t leafMax = std::max<size_t>(1, (size_t)std::llround(blkpct_ * (double)N));   // RDISOptimizer.cpp:342, :1761
+    rdis_hip_problem* p = f_.deviceProblem();
+    rdis_hip_ctx* ctx = f_.deviceContext();
+
+    // components of a set of free variables (everything else assigned), on the device
+    auto components = [&](const std::vector<uint8_t>& assigned, std::vector<int64_t>& free_ptr, std::vector<int64_t>& free_vid,
+                          std::vector<int64_t>& fac_ptr, std::vector<int64_t>& fac_id) {
+        int64_t nc = 0, nfree = 0, nfac = 0;
+        check(ctx, rdis_hip_components(p, assigned.data(), &nc, &nfree, &nfac), "rdis_hip_components");
+        free_ptr.assign((size_t)nc + 1, 0); fac_ptr.assign((size_t)nc + 1, 0);
+        free_vid.assign((size_t)nfree, 0); fac_id.assign((size_t)nfac, 0);
+        check(ctx, rdis_hip_components_fetch(p, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data()), "rdis_hip_components_fetch");
+        return (size_t)nc;
+    };
+
+    // depth 0: the connected components of the whole function (topccomp->decompose(), RDISOptimizer.cpp:173)
+    std::vector<uint8_t> assigned(N, 0);
+    std::vector<int64_t> fp, fv, cp, ci;
+    size_t nc = components(assigned, fp, fv, cp, ci);
+    std::vector<int> frontier;
+    for (size_t c = 0; c < nc; ++c) {
+        Node nd; nd.depth = 0; nd.parent = -1; nd.leaf = true;
+        nd.vars.assign(fv.begin() + fp[c], fv.begin() + fp[c + 1]);
+        nd.factors.assign(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
+        nodes_.push_back(nd);
+        frontier.push_back((int)nodes_.size() - 1);
+    }
+    std::vector<int> owner(N, -1);
+    for (int depth = 0; !frontier.empty(); ++depth) {
+        // split what is too large to be optimised as a whole
+        std::fill(assigned.begin(), assigned.end(), 1);
+        std::vector<int> split;
+        for (int ni : frontier) {
+            Node& nd = nodes_[(size_t)ni];
+            if (nd.factors.empty() || nd.vars.size() <= leafMax) continue;
+            chooseSeparator(f_, nd.vars, nd.factors, leafMax, nd.separator);
+            if (nd.separator.empty() || nd.separator.size() >= nd.vars.size()) { nd.separator.clear(); continue; }
+            nd.leaf = false;
+            std::vector<char> is_sep(N, 0);   // (only this node's entries are read)
+            for (VariableID v : nd.separator) is_sep[(size_t)v] = 1;
+            for (FactorID fid : nd.factors) {
+                for (const Variable* v : facs[(size_t)fid]->getVariables())
+                    if (is_sep[(size_t)v->getID()]) { nd.sepFactors.push_back(fid); break; }
+            }
+            for (VariableID v : nd.vars) if (!is_sep[(size_t)v]) { assigned[(size_t)v] = 0; owner[(size_t)v] = ni; }
+            split.push_back(ni);
+        }
+        frontier.clear();
+        if (split.empty()) break;
+        // the children of ALL nodes split at this depth: one labelling call (the nodes are disjoint)
+        nc = components(assigned, fp, fv, cp, ci);
+        for (size_t c = 0; c < nc; ++c) {
+            Node ch; ch.depth = depth + 1; ch.leaf = true;
+            ch.vars.assign(fv.begin() + fp[c], fv.begin() + fp[c + 1]);
+            ch.factors.assign(ci.begin() + cp[c], ci.begin() + cp[c + 1]);
+            ch.parent = owner[(size_t)ch.vars.front()];
+            nodes_.push_back(ch);
+            frontier.push_back((int)nodes_.size() - 1);
+        }
+    }
+    decomp_ms_ = now_ms() - t0;
+}
+
+void HipRDISLevelOptimizer::buildPlans() {
+    releasePlans();
+    int maxDepth = 0;
+    for (const Node& nd : nodes_) maxDepth = std::max(maxDepth, nd.depth);
+    rdis_hip_problem* p = f_.deviceProblem();
+    for (int d = 0; d <= maxDepth; ++d)
+        for (int kind = 0; kind < 2; ++kind) {   // a node's separator first, then (one level down) its children
+            LevelPlan* lp = new LevelPlan;
+            lp->depth = d; lp->kind = kind;
+            lp->free_ptr.push_back(0); lp->fac_ptr.push_back(0);
+            for (size_t i = 0; i < nodes_.size(); ++i) {
+                const Node& nd = nodes_[i];
+                if (nd.depth != d || nd.factors.empty()) continue;
+                if (kind == 0 && nd.leaf) continue;
+                if (kind == 1 && !nd.leaf) continue;
+                const std::vector<VariableID>& v = kind == 0 ? nd.separator : nd.vars;
+                const std::vector<FactorID>& fc = kind == 0 ? nd.sepFactors : nd.factors;
+                lp->node.push_back((int)i);
+                lp->free_vid.insert(lp->free_vid.end(), v.begin(), v.end());
+                lp->fac_id.insert(lp->fac_id.end(), fc.begin(), fc.end());
+                lp->free_ptr.push_back((int64_t)lp->free_vid.size());
+                lp->fac_ptr.push_back((int64_t)lp->fac_id.size());
+            }
+            if (lp->node.empty()) { delete lp; continue; }
+            const size_t ncomp = lp->node.size();
+            lp->x.resize(lp->free_vid.size()); lp->fret.resize(ncomp); lp->delta.resize(ncomp);
+            lp->iters.resize(ncomp); lp->status.resize(ncomp);
+            if (batch_)
+                check(f_.deviceContext(), rdis_hip_plan_create(p, (int64_t)ncomp, lp->free_ptr.data(), lp->free_vid.data(),
+                                                               lp->fac_ptr.data(), lp->fac_id.data(), &lp->plan), "rdis_hip_plan_create");
+            plans_.push_back(lp);
+        }
+}
+
+double HipRDISLevelOptimizer::runPlan(LevelPlan& lp, int sweep, double objective, bool printInfo) {
+    const double t0 = now_ms();
+    const VariablePtrVec& vars = f_.getVariables();
+    const FactorPtrVec& facs = f_.getFactors();
+    const size_t ncomp = lp.node.size();
+    long long iters = 0;
+    double dsum = 0.0;
+    if (batch_) {
+        rdis_hip_problem* p = f_.deviceProblem();   // (pushes pending host-side assignments)
+        (void)p;
+        rdis_hip_ctx* ctx = f_.deviceContext();
+        check(ctx, rdis_hip_plan_set_start(lp.plan, nullptr), "rdis_hip_plan_set_start");   // from the values assigned on the device
+        check(ctx, rdis_hip_plan_solve(lp.plan, (int32_t)ssmaxit_, ssftol_), "rdis_hip_plan_solve");
+        check(ctx, rdis_hip_plan_fetch(lp.plan, lp.x.data(), lp.fret.data(), lp.delta.data(), lp.iters.data(), lp.status.data(), nullptr, nullptr),
+              "rdis_hip_plan_fetch");
+        for (size_t c = 0; c < ncomp; ++c) {
+            const int st = lp.status[c] & 0xff;
+            if (st == RDIS_HIP_EXIT_SYNC_TIMEOUT) throw HipError(RDIS_HIP_EDEVICE, "level driver: device-side exchange timed out");
+            if (st == RDIS_HIP_EXIT_EMPTY) continue;
+            dsum += lp.delta[c];
+            iters += lp.iters[c] + 1;
+        }
+        // the variables are left assigned on the device; mirror the values on the host side
+        f_.adoptDeviceValues(lp.free_vid, lp.x);
+    } else {
+        // the same calls one at a time, in the order the reference visits siblings (Component.cpp:603-608:
+        // fewer variables first -- the order the labelling returns them in)
+        for (size_t c = 0; c < ncomp; ++c) {
+            VariablePtrVec cv; FactorPtrVec cf; NumericVec xv;
+            for (int64_t i = lp.free_ptr[c]; i < lp.free_ptr[c + 1]; ++i) {
+                Variable* v = vars[(size_t)lp.free_vid[(size_t)i]];
+                cv.push_back(v); xv.push_back(v->eval());
+            }
+            for (int64_t j = lp.fac_ptr[c]; j < lp.fac_ptr[c + 1]; ++j) cf.push_back(facs[(size_t)lp.fac_id[(size_t)j]]);
+            Numeric delta = 0;
+            lp.fret[c] = ss_.optimize(cv, cf, xv, delta, false);
+            lp.delta[c] = delta; lp.iters[c] = ss_.lastIters(); lp.status[c] = ss_.lastStatus();
+            for (size_t i = 0; i < xv.size(); ++i) lp.x[(size_t)lp.free_ptr[c] + i] = xv[i];
+            dsum += delta;
+            iters += ss_.lastIters() + 1;
+        }
+    }
+    objective += dsum;
+    Step s;
+    s.sweep = sweep; s.depth = lp.depth; s.kind = lp.kind; s.ncomp = (long long)ncomp;
+    s.nvars = (long long)lp.free_vid.size(); s.nfactors = (long long)lp.fac_id.size(); s.iters = iters;
+    s.objective = objective; s.ms = now_ms() - t0;
+    trace_.push_back(s);
+    if (printInfo)
+        std::cout << "sweep " << sweep << " depth " << lp.depth << (lp.kind == 0 ? " separators: " : " leaves: ") << ncomp << " component(s), "
+                  << lp.free_vid.size() << " variables, " << lp.fac_id.size() << " factors -> " << objective << " (" << s.ms << " ms)" << std::endl;
+    return objective;
+}
+
+Numeric HipRDISLevelOptimizer::optimize(bool printInfo) {
+    for (const Variable* v : f_.getVariables())
+        if (!v->isAssigned()) throw std::logic_error("HipRDISLevelOptimizer::optimize: assign an initial state first");
+    ssmaxit_ = ss_.getMaxIters(); ssftol_ = ss_.getFtol();
+    buildTree();
+    buildPlans();
+    trace_.clear();
+    double objective = f_.eval();
+    if (printInfo) {
+        size_t nleaf = 0, nsplit = 0;
+        for (const Node& nd : nodes_) (nd.leaf ? nleaf : nsplit)++;
+        std::cout << "level driver: " << nodes_.size() << " components (" << nsplit << " split by a separator, " << nleaf << " leaves) in "
+                  << plans_.size() << " launches per sweep; decomposition " << decomp_ms_ << " ms; initial value " << objective << std::endl;
+    }
+    sweeps_ = 0;
+    for (int sweep = 0; sweep < maxSweeps_; ++sweep) {
+        const double before = objective;
+        for (LevelPlan* lp : plans_) objective = runPlan(*lp, sweep, objective, printInfo);
+        ++sweeps_;
+        if (!(before - objective > steptol_)) break;   // no progress beyond steptol (RDISOptimizer.cpp:1089-1108)
+    }
+    const double check_f = f_.eval();   // the running sum of the launches' deltas IS the function value
+    if (printInfo) std::cout << "level driver: final value " << check_f << " (sum of deltas: " << objective << ") after " << sweeps_ << " sweep(s)" << std::endl;
+    return check_f;
+}
+
+}  // namespace rdis

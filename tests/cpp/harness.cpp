@@ -2,11 +2,14 @@
 // use the mirrored classes exactly the way the reference's callers do
 // (BCDOptimizer with one block = all variables, src/optimizers/BCDOptimizer.cpp:149;
 //  RDISOptimizer::getValueFromDomain, src/RDISOptimizer.cpp:1039-1083).
+#include <chrono>
+#include <cmath>
 #include <cstring>
 #include <iostream>
 #include <memory>
 
 #include "../../rdis_amd/host/rdis_host.h"
+#include "../../rdis_amd/host/rdis_levels.h"
 
 using namespace rdis;
 
@@ -218,6 +221,62 @@ int harness_ba_lm(const char* path, long long ncams, long long npts, int maxit, 
         for (size_t i = 0; i < x.size(); ++i) x_out[i] = x[i];
         return 0;
     } catch (const std::exception& e) { std::cerr << "harness_ba_lm: " << e.what() << std::endl; return -2; }
+}
+
+// ---- host-only: the separator the level driver chooses for the whole function (no GPU needed).
+// sep_out: capacity nvars; returns the number of separator variables (or < 0)
+long long harness_separator(const char* path, long long ncams, long long npts, double blkpct, long long* sep_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        std::vector<VariableID> vars((size_t)f.getNumVars()), sep;
+        std::vector<FactorID> facs(f.getFactors().size());
+        for (size_t i = 0; i < vars.size(); ++i) vars[i] = (VariableID)i;
+        for (size_t i = 0; i < facs.size(); ++i) facs[i] = (FactorID)i;
+        HipRDISLevelOptimizer::chooseSeparator(f, vars, facs, (size_t)std::llround(blkpct * (double)vars.size()), sep);
+        for (size_t i = 0; i < sep.size(); ++i) sep_out[i] = sep[i];
+        return (long long)sep.size();
+    } catch (const std::exception& e) { std::cerr << "harness_separator: " << e.what() << std::endl; return -2; }
+}
+
+// ---- GPU: the level driver (rdis_levels.h) on a BAL problem from the file's state.
+// out = {final value, initial value, sweeps, #nodes, #leaves, #split nodes, wall ms of optimize(), decomposition ms,
+//        largest separator, #trace steps, monotone (1/0), max |running sum - evaluated|};
+// trace_out (may be NULL): up to trace_cap rows {sweep, depth, kind, ncomp, nvars, nfactors, objective, ms};
+// x_out (may be NULL): final values of all variables
+int harness_level_driver(const char* path, long long ncams, long long npts, int maxit, int max_sweeps, double blkpct,
+                         int batch, double* out, double* trace_out, long long trace_cap, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        f.assignAll(f.getInitialState());
+        const Numeric before = f.eval();
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        HipRDISLevelOptimizer rdis(f, ssopt);
+        Options ro; ro.set("AVblkpct", blkpct); ro.set("maxSweeps", max_sweeps); ro.set("batch", batch);
+        rdis.setParameters(ro);
+        const auto t0 = std::chrono::steady_clock::now();
+        const Numeric fin = rdis.optimize(false);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        size_t nleaf = 0, nsplit = 0, maxsep = 0;
+        for (const auto& nd : rdis.nodes()) { (nd.leaf ? nleaf : nsplit)++; maxsep = std::max(maxsep, nd.separator.size()); }
+        bool mono = true; double prev = before;
+        for (const auto& st : rdis.trace()) { mono = mono && st.objective <= prev; prev = st.objective; }
+        out[0] = fin; out[1] = before; out[2] = rdis.sweepsDone(); out[3] = (double)rdis.nodes().size(); out[4] = (double)nleaf;
+        out[5] = (double)nsplit; out[6] = ms; out[7] = rdis.decompositionMs(); out[8] = (double)maxsep; out[9] = (double)rdis.trace().size();
+        out[10] = mono ? 1 : 0; out[11] = std::fabs(prev - fin);
+        if (trace_out)
+            for (size_t i = 0; i < rdis.trace().size() && (long long)i < trace_cap; ++i) {
+                const auto& st = rdis.trace()[i];
+                double* r = trace_out + 8 * i;
+                r[0] = st.sweep; r[1] = st.depth; r[2] = st.kind; r[3] = (double)st.ncomp; r[4] = (double)st.nvars; r[5] = (double)st.nfactors;
+                r[6] = st.objective; r[7] = st.ms;
+            }
+        if (x_out) for (size_t i = 0; i < f.getVariables().size(); ++i) x_out[i] = f.getVariables()[i]->eval();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_level_driver: " << e.what() << std::endl; return -2; }
 }
 
 }  // extern "C"

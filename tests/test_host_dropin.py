@@ -199,3 +199,87 @@ def test_lm_optimizer_through_plugin(harness, bal_path, gctx):
     assert fret == r.fret and np.array_equal(x, r.x) and (iters, stop, nsolve) == (r.iters, r.stop, r.nsolve)
     assert abs(before - 2111.5030158718296) <= 1e-12 * before and abs((fret - delta) - before) <= 1e-12 * before
     assert abs(after - fret) <= 1e-12 * fret and delta < 0                  # variables left assigned to the result
+
+
+# ---- the caller side: separator heuristic (N4) and level driver (N1), rdis_amd/host/rdis_levels.* -------------
+def _separator(h, path, nc, npnt, pct=0.2):
+    sizes, *_ = _pack_bal(h, path, nc, npnt)
+    sep = np.zeros(int(sizes[0]), dtype=np.int64)
+    h.harness_separator.restype = C.c_longlong
+    n = h.harness_separator(path, C.c_longlong(nc), C.c_longlong(npnt), C.c_double(pct), sep.ctypes.data_as(C.c_void_p))
+    assert n >= 0
+    return sep[:n], int(sizes[0])
+
+
+def test_separator_reproduces_the_shape_of_the_reference_cut(harness, bal_path):
+    """the reference's PaToH call (RDISOptimizer.cpp:779-865) cut ladybug-49-7776 at the 414 variables of
+    46 of the 49 cameras, and ensureFactorWillBeAssigned (:412-458) added one point: 417 variables
+    (SURVEY.md 3.2b).  The degree heuristic that stands in for the binary-only library finds the same
+    shape; on the 5-camera / 30-point subset all 5 cameras and one point (the reference's 48-variable
+    calls)."""
+    sep, n = _separator(harness, bal_path, 0, 0)
+    assert n == 23769 and len(sep) == 417
+    cams = np.unique(sep[sep < 441] // 9)
+    assert len(cams) == 46 and np.array_equal(np.sort(sep[sep < 441]), np.concatenate([9 * c + np.arange(9) for c in cams]))   # whole blocks
+    assert np.array_equal(sep[sep >= 441], [441, 442, 443])                      # the point of the first factor that reads a cut camera
+    # what is left decomposes: the 3 free cameras with the points they see, every other point on its own
+    pp = P.load_bal()
+    left = sorted(set(range(49)) - set(cams.tolist()))
+    deg = np.bincount(pp.cam_vid0 // 9, minlength=49)
+    assert sorted(np.argsort(deg, kind="stable")[:3].tolist()) == left           # the three cameras of lowest degree stay
+    assigned = np.ones(pp.nvars, np.uint8)
+    assigned[np.setdiff1d(np.arange(pp.nvars), sep)] = 0
+    fp, fv, cp, ci = O.OracleProblem(pp).components(assigned)
+    sizes = np.diff(fp)
+    assert sizes.max() <= round(0.2 * 23769) and sizes.max() > 3 and np.sum(sizes == 3) == len(sizes) - 1
+    sep, n = _separator(harness, bal_path, 5, 30)
+    assert n == 135 and len(sep) == 48 and np.array_equal(sep, np.arange(48))    # 5 cameras + point 0
+
+
+def _level_driver(h, path, nc, npnt, maxit=25, sweeps=20, pct=0.2, batch=1, nvars=0):
+    out, tr, x = np.zeros(12), np.zeros((4096, 8)), np.zeros(max(nvars, 1))
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = h.harness_level_driver(path, C.c_longlong(nc), C.c_longlong(npnt), maxit, sweeps, C.c_double(pct), batch, v(out), v(tr),
+                                C.c_longlong(4096), v(x) if nvars else None)
+    assert rc == 0
+    return out, tr[:int(out[9])], x
+
+
+@pytest.mark.gpu
+def test_level_driver_ladybug_5_30(harness, bal_path):
+    """BASELINE config 3 through the level driver: beats the reference's complete RDIS run (18.443091288282886
+    after 731 solver calls); monotone launch by launch; the running sum of the launches'
+    deltas is the function value; batched == the same calls made one at a time, bit for bit"""
+    out, tr, x = _level_driver(harness, bal_path, 5, 30, nvars=135)
+    print("ladybug 5/30: %.6f -> %.12f in %d sweeps, %d launches, %.1f ms (decomposition %.1f ms); reference RDIS: 18.443091288282886" % (
+        out[1], out[0], out[2], len(tr), out[6], out[7]))
+    assert out[1] == 2111.5030158718296 and out[10] == 1.0 and out[11] <= 1e-9 * out[0]
+    assert out[3] == 30 and out[5] == 1 and out[8] == 48                         # one split node (5 cameras + 1 point), 29 point leaves
+    assert out[0] <= 18.443091288282886
+    assert np.all(np.diff(tr[:, 6]) <= 0)
+    pp = P.load_bal(ncams=5, npts=30)
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    o.assign(None, x)
+    assert abs(o.eval() - out[0]) <= 1e-12 * out[0]                              # the value IS the objective at the returned point
+    assert np.all(x >= pp.lo) and np.all(x <= pp.hi)
+    out1, tr1, x1 = _level_driver(harness, bal_path, 5, 30, batch=0, nvars=135)
+    assert out1[0] == out[0] and np.array_equal(x1, x) and np.array_equal(tr1[:, 6], tr[:, 6])
+    print("   the same calls one at a time: %.1f ms" % out1[6])
+
+
+@pytest.mark.gpu
+def test_level_driver_full_ladybug(harness, bal_path):
+    """BASELINE config 4 through the level driver: the reference's RDIS run stood at 102978.259 when its
+    240 s budget ran out (13 850 solver calls)"""
+    out, tr, x = _level_driver(harness, bal_path, 0, 0, nvars=23769)
+    print("ladybug full: %.3f -> %.6f in %d sweeps, %d launches, %.1f ms (decomposition %.1f ms): %d components, largest separator %d; "
+          "reference RDIS: 102978.259 after 240 s" % (out[1], out[0], out[2], len(tr), out[6], out[7], out[3], out[8]))
+    for r in tr[:4]:
+        print("   sweep %d depth %d %s: %d components, %d variables, %d factors -> %.3f (%.2f ms)" % (
+            r[0], r[1], "separators" if r[2] == 0 else "leaves", r[3], r[4], r[5], r[6], r[7]))
+    assert out[10] == 1.0 and out[11] <= 1e-9 * out[0] and out[8] == 417
+    assert out[0] < 102978.259
+    pp = P.load_bal()
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    o.assign(None, x)
+    assert abs(o.eval() - out[0]) <= 1e-12 * out[0]

@@ -6,14 +6,16 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 D=gpurun_out/prof_$1
 mkdir -p $D
 python bench.py --steps 20 --warmup 3 > $D/bench_ladybug_full.json 2> $D/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ladybug -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $D/bench_ladybug.json 2>> $D/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o ladybug -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong-scaling > $D/bench_ladybug.json 2>> $D/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o synth -- python bench.py --workload synthetic-S --steps 10 --warmup 2 --no-cpu-baseline > $D/bench_synth.json 2>> $D/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o synthL -- python bench.py --workload synthetic-L --steps 3 --warmup 1 --no-cpu-baseline > $D/bench_synthL.json 2>> $D/err.txt
 for w in ladybug-full synthetic-S synthetic-L; do
   mkdir -p $D/$w
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/$w -o fetch -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $D/err.txt
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/$w -o write -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> $D/err.txt
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/$w -o fetch -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/$w -o write -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o strong -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_strong.json 2>> $D/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kernels -- python tools/profile_kernels.py > $D/kernels.txt 2>> $D/err.txt
 python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_coop_
 python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_wg_kernel
 python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_wg_kernel
