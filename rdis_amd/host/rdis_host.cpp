@@ -436,9 +436,61 @@ void SubspaceOptimizer::setParameters(const Options& options) {
 }
 
 // ------------------------------------------------------------------ HipCGDSubspaceOptimizer
+struct HipCGDSubspaceOptimizer::CachedPlan {
+    unsigned long long hash = 0, used = 0;
+    std::vector<int64_t> free_ptr, free_vid, fac_ptr, fac_id;
+    rdis_hip_plan* plan = nullptr;
+};
+
 HipCGDSubspaceOptimizer::HipCGDSubspaceOptimizer(OptimizableFunction& f_)
-    : SubspaceOptimizer(f_), last_iters_(0), last_status_(0), last_nfeval_(0), last_ngeval_(0) {
+    : SubspaceOptimizer(f_), last_iters_(0), last_status_(0), last_nfeval_(0), last_ngeval_(0),
+      cache_cap_(256), cache_hits_(0), cache_misses_(0), cache_tick_(0) {
     if (doAscent) throw std::invalid_argument("HipCGDSubspaceOptimizer: only the MinSum (descent) semiring is supported");
+}
+
+HipCGDSubspaceOptimizer::~HipCGDSubspaceOptimizer() { dropPlans(); }
+
+void HipCGDSubspaceOptimizer::dropPlans() {
+    for (CachedPlan* e : cache_) { if (e->plan) rdis_hip_plan_destroy(e->plan); delete e; }
+    cache_.clear();
+}
+
+void HipCGDSubspaceOptimizer::setPlanCache(size_t entries) {
+    cache_cap_ = entries;
+    if (cache_.size() > cache_cap_) dropPlans();
+}
+
+HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
+                                                                         const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id) {
+    if (cache_cap_ == 0) return nullptr;
+    unsigned long long h = 1469598103934665603ull;   // FNV-1a over the four lists
+    auto mix = [&](const std::vector<int64_t>& v) {
+        for (int64_t x : v) { h ^= (unsigned long long)x; h *= 1099511628211ull; }
+        h ^= 0x9e3779b97f4a7c15ull + v.size(); h *= 1099511628211ull;
+    };
+    mix(free_ptr); mix(free_vid); mix(fac_ptr); mix(fac_id);
+    for (CachedPlan* e : cache_)
+        if (e->hash == h && e->free_vid == free_vid && e->fac_id == fac_id && e->free_ptr == free_ptr && e->fac_ptr == fac_ptr) {
+            e->used = ++cache_tick_;
+            ++cache_hits_;
+            return e;
+        }
+    ++cache_misses_;
+    if (cache_.size() >= cache_cap_) {   // least recently used goes
+        size_t lru = 0;
+        for (size_t i = 1; i < cache_.size(); ++i) if (cache_[i]->used < cache_[lru]->used) lru = i;
+        if (cache_[lru]->plan) rdis_hip_plan_destroy(cache_[lru]->plan);
+        delete cache_[lru];
+        cache_.erase(cache_.begin() + (long)lru);
+    }
+    CachedPlan* e = new CachedPlan;
+    e->hash = h; e->used = ++cache_tick_;
+    e->free_ptr = free_ptr; e->free_vid = free_vid; e->fac_ptr = fac_ptr; e->fac_id = fac_id;
+    const int rc = rdis_hip_plan_create(f.deviceProblem(), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
+                                        fac_ptr.data(), fac_id.data(), &e->plan);
+    if (rc != 0) { delete e; check(f.deviceContext(), rc, "rdis_hip_plan_create"); }
+    cache_.push_back(e);
+    return e;
 }
 
 Numeric HipCGDSubspaceOptimizer::optimize(const VariablePtrVec& vars, const FactorPtrVec& gdfs, NumericVec& xval,
@@ -480,16 +532,27 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
     std::vector<int32_t> iters(nc), status(nc);
     std::vector<int64_t> nfe(nc), nge(nc);
     rdis_hip_problem* p = f.deviceProblem();
-    const int rc = rdis_hip_cgd_batch(p, (int64_t)nc, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data(),
-                                      x.data(), (int32_t)maxiters, ftol, fret.data(), delta.data(), iters.data(),
-                                      status.data(), nfe.data(), nge.data());
-    check(f.deviceContext(), rc, "rdis_hip_cgd_batch");
+    CachedPlan* cp = fac_id.empty() ? nullptr : cachedPlan(free_ptr, free_vid, fac_ptr, fac_id);
+    if (cp) {   // the decomposition is resident: start values in, launch, results out
+        rdis_hip_ctx* ctx = f.deviceContext();
+        check(ctx, rdis_hip_plan_set_start(cp->plan, x.data()), "rdis_hip_plan_set_start");
+        check(ctx, rdis_hip_plan_solve(cp->plan, (int32_t)maxiters, ftol), "rdis_hip_plan_solve");
+        check(ctx, rdis_hip_plan_fetch(cp->plan, x.data(), fret.data(), delta.data(), iters.data(), status.data(), nfe.data(), nge.data()),
+              "rdis_hip_plan_fetch");
+    } else {
+        const int rc = rdis_hip_cgd_batch(p, (int64_t)nc, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data(),
+                                          x.data(), (int32_t)maxiters, ftol, fret.data(), delta.data(), iters.data(),
+                                          status.data(), nfe.data(), nge.data());
+        check(f.deviceContext(), rc, "rdis_hip_cgd_batch");
+    }
     Numeric total = 0;
     for (size_t c = 0; c < nc; ++c) {
         Component& C = comps[c];
         C.fret = fret[c]; C.deltaFval = delta[c]; C.iters = iters[c]; C.status = status[c];
         C.nfeval = nfe[c]; C.ngeval = nge[c];
         total += fret[c];
+        if ((status[c] & 0xff) == RDIS_HIP_EXIT_SYNC_TIMEOUT)   // never expected; not a result the caller may build on
+            throw HipError(RDIS_HIP_EDEVICE, "HipCGD: the device-side exchange of component " + std::to_string(c) + " timed out (start restored)");
         if ((status[c] & 0xff) == RDIS_HIP_EXIT_NAN) std::cerr << "HipCGD: NaN objective in component " << c << ", start restored" << std::endl;
         if ((status[c] & 0xff) == RDIS_HIP_EXIT_EMPTY) continue;  // nothing touched
         // the variables are left assigned to the final, clamped values (.cpp:84-86); the

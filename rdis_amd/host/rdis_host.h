@@ -282,7 +282,7 @@ protected:
 class HipCGDSubspaceOptimizer : public SubspaceOptimizer {
 public:
     explicit HipCGDSubspaceOptimizer(OptimizableFunction& f_);
-    virtual ~HipCGDSubspaceOptimizer() {}
+    virtual ~HipCGDSubspaceOptimizer();
     virtual Numeric optimize(const VariablePtrVec& vars, const FactorPtrVec& factors, NumericVec& xinit,
                              Numeric& deltaFval, const bool printdbg);
 
@@ -306,14 +306,31 @@ public:
     // is left empty for the caller to fill with a start.
     std::vector<Component> createChildren();
 
+    // Callers like RDISOptimizer come back with the same (variables, factors) lists over and over
+    // (every revisit of a component, every restart).  The decomposition of such a call -- validated
+    // lists, gather tables, workspace -- is kept on the device as a persistent plan, keyed by the id
+    // lists, so a repeat pays for the start values, the launch and the results only.  At most
+    // `entries` plans are kept (least recently used goes first); 0 switches the cache off.  Results
+    // are bit-identical either way.
+    void setPlanCache(size_t entries);
+    size_t planCacheHits() const { return cache_hits_; }
+    size_t planCacheMisses() const { return cache_misses_; }
+
     // results of the last optimize() beyond what the reference returns
     int lastIters() const { return last_iters_; }
     int lastStatus() const { return last_status_; }
     long long lastFEvals() const { return last_nfeval_; }
     long long lastGEvals() const { return last_ngeval_; }
 private:
+    struct CachedPlan;
+    CachedPlan* cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
+                           const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id);
+    void dropPlans();
     int last_iters_, last_status_;
     long long last_nfeval_, last_ngeval_;
+    std::vector<CachedPlan*> cache_;
+    size_t cache_cap_, cache_hits_, cache_misses_;
+    unsigned long long cache_tick_;
 };
 
 // The drop-in for LMSubspaceOptimizer (src/optimizers/LMSubspaceOptimizer.h): same contract and

@@ -279,4 +279,49 @@ int harness_level_driver(const char* path, long long ncams, long long npts, int 
     } catch (const std::exception& e) { std::cerr << "harness_level_driver: " << e.what() << std::endl; return -2; }
 }
 
+// ---- GPU: the unchanged-caller path.  RDISOptimizer calls ssopt.optimize one component at a time
+// (src/RDISOptimizer.cpp:1067); on ladybug 5 cameras / 30 points its run makes 80 calls with the 48
+// variables of the 5 cameras and one point and 651 calls with the 3 variables of a single point
+// (SURVEY.md 3.2b).  The same call shapes, in rounds (one separator call, then the next few points in
+// turn), every call starting from the values the previous ones left.  cache: plan cache entries (0 = off).
+// out = {wall ms of all calls, #calls, final value of the function, sum of returned values, cache hits, cache misses}
+int harness_call_shapes(const char* path, int nsep, int npt_calls, int maxit, int cache, double* out, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, 5, 30)) return -1;
+        f.assignAll(f.getInitialState());
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        ssopt.setPlanCache((size_t)cache);
+        (void)f.eval();   // upload outside the timed region
+        const VariablePtrVec& V = f.getVariables();
+        VariablePtrVec sepv(V.begin(), V.begin() + 48);
+        FactorPtrVec sepf = f.getFactors();   // every factor reads a camera
+        std::vector<VariablePtrVec> pv(30); std::vector<FactorPtrVec> pf(30);
+        for (int p = 0; p < 30; ++p) for (int k = 0; k < 3; ++k) pv[(size_t)p].push_back(V[(size_t)(45 + 3 * p + k)]);
+        for (Factor* fa : f.getFactors()) pf[(size_t)static_cast<BundleAdjustmentFactor*>(fa)->getPointID()].push_back(fa);
+        double sum = 0; long long calls = 0; int next_pt = 1, pts_done = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < nsep; ++r) {
+            NumericVec x(48); Numeric d = 0;
+            for (size_t i = 0; i < 48; ++i) x[i] = sepv[i]->eval();
+            sum += ssopt.optimize(sepv, sepf, x, d, false); ++calls;
+            const int quota = (int)((long long)npt_calls * (r + 1) / nsep) - pts_done;
+            for (int q = 0; q < quota; ++q) {
+                NumericVec y(3);
+                for (size_t i = 0; i < 3; ++i) y[i] = pv[(size_t)next_pt][i]->eval();
+                sum += ssopt.optimize(pv[(size_t)next_pt], pf[(size_t)next_pt], y, d, false); ++calls;
+                next_pt = next_pt == 29 ? 1 : next_pt + 1;   // point 0 is part of the separator
+                ++pts_done;
+            }
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        out[0] = ms; out[1] = (double)calls; out[2] = f.eval(); out[3] = sum;
+        out[4] = (double)ssopt.planCacheHits(); out[5] = (double)ssopt.planCacheMisses();
+        if (x_out) for (size_t i = 0; i < V.size(); ++i) x_out[i] = V[i]->eval();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_call_shapes: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

@@ -283,3 +283,42 @@ def test_level_driver_full_ladybug(harness, bal_path):
     o = O.OracleProblem(pp, emulate_stale_cache=False)
     o.assign(None, x)
     assert abs(o.eval() - out[0]) <= 1e-12 * out[0]
+
+
+@pytest.mark.gpu
+def test_unchanged_caller_one_call_at_a_time(harness, bal_path):
+    """What an unmodified RDISOptimizer would do with the drop-in: 80 calls over (5 cameras + 1 point) and 651
+    calls over single points of ladybug 5/30 (the reference's own run), one optimize() at a
+    time.  The plan cache makes the sequence faster and changes no bit.  Measured on the GPU box (host: EPYC
+    9575F): 120 ms with the cache, 160 ms without, 87 ms for the CPU oracle on one core making the same calls --
+    a 3-variable call is 0.07 ms on that CPU, less than one kernel launch plus the latency chain of its ~70
+    dependent evaluations, so call-at-a-time cannot win on the tiny calls; the 80 large calls do (0.5 ms against
+    1 ms each).  The same work as sibling batches (test_level_driver_ladybug_5_30) takes 20 ms."""
+    import time
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    res = {}
+    for cache in (0, 256):
+        out, x = np.zeros(6), np.zeros(135)
+        assert harness.harness_call_shapes(bal_path, 80, 651, 25, cache, v(out), v(x)) == 0
+        res[cache] = (out.copy(), x.copy())
+    (o0, x0), (o1, x1) = res[0], res[256]
+    assert o0[1] == o1[1] == 731 and o1[4] == 731 - 30 and o1[5] == 30 and o0[4] == 0
+    assert o0[2] == o1[2] and o0[3] == o1[3] and np.array_equal(x0, x1)          # cached == uncached, bit for bit
+    # the same sequence of calls on the CPU oracle (its own trajectory), one core
+    pp = P.load_bal(ncams=5, npts=30)
+    orc = O.OracleProblem(pp)
+    sepv, sepf = np.arange(48, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
+    pf = [np.where(pp.pt_vid0 == 45 + 3 * p)[0].astype(np.int64) for p in range(30)]
+    t0 = time.perf_counter()
+    nxt, done = 1, 0
+    for r in range(80):
+        orc.cgd(free_vid=sepv, fac=sepf, maxiters=25)
+        quota = 651 * (r + 1) // 80 - done
+        for _ in range(quota):
+            orc.cgd(free_vid=np.arange(45 + 3 * nxt, 48 + 3 * nxt, dtype=np.int64), fac=pf[nxt], maxiters=25)
+            nxt = 1 if nxt == 29 else nxt + 1
+            done += 1
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    print("731 optimize() calls one at a time: %.1f ms with the plan cache, %.1f ms without; CPU oracle on one core %.1f ms; "
+          "function value %.6f (oracle's own trajectory: %.6f)" % (o1[0], o0[0], cpu_ms, o1[2], orc.eval()))
+    assert o1[0] < o0[0] and o1[0] < 2.5 * cpu_ms
