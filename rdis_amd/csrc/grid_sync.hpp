@@ -116,12 +116,7 @@ struct GridSync {
     // LDS stage and no workgroup barrier between the arithmetic and the stores; wave 0 sweeps all
     // entries.
     template <int N, int NMAX>
-#ifdef RDIS_XCHG_NOINLINE
-    __device__ __attribute__((noinline)) void to_wave0_n(
-#else
-    __device__ void to_wave0_n(
-#endif
-        double (&v)[N], int sync) {
+    __device__ void to_wave0_n(double (&v)[N], int sync) {
         static_assert(N >= 1 && N <= COOP_K && NMAX >= 0 && NMAX <= N, "exchange width");
         const long long t0 = coop_clock();
         long long t2 = t0;

@@ -80,14 +80,6 @@ struct Request {
     double tr_a, tr_b, tr_c;     // (meaningful only when tr_tag is set)
 };
 
-#ifdef RDIS_STEP_PROFILE   // tools/microbench/step_cost.hip: where inside a step do the cycles go?
-// [i]: cycles between mark i-1 (or the caller's start, [15]) and mark i; in LDS so that a mark costs little
-__device__ __forceinline__ long long* step_prof() { __shared__ long long a[16]; return a; }
-#define RDIS_SP(i) do { const long long n__ = clock64(); long long* sp__ = step_prof(); sp__[i] += n__ - sp__[15]; sp__[15] = clock64(); } while (0)
-#else
-#define RDIS_SP(i) do {} while (0)
-#endif
-
 // keeps a value in a vector register, hides its origin from the optimiser
 __device__ __forceinline__ void opaque(double& v) { asm("" : "+v"(v)); }
 
@@ -251,18 +243,11 @@ struct CgdMachine {
         const bool tiny_ = tiny;
         const int it_ = it;
         if (st != S_DB_EVAL) return false;
-        RDIS_SP(0);
-#ifndef RDIS_HOT_NO_OPAQUE
         opaque(a_); opaque(b_); opaque(x_); opaque(w_); opaque(v_); opaque(fx_); opaque(fw_); opaque(fv_);
         opaque(dx_); opaque(dw_); opaque(dv_); opaque(d_); opaque(e_); opaque(uu_);
         opaque(ppa_); opaque(ppb_); opaque(ppc_);
         asm("" : "+v"(nfe_), "+v"(nge_), "+v"(ppt_));
-#endif
         if ((tiny_ && r0 > fx_) || !(it_ + 1 < DB_ITMAX)) return false;
-#if defined(RDIS_HOT_CUT) && RDIS_HOT_CUT == 1
-        un = uu_ * 0.5 + r0 * 1e-30; uu = un; pre_tag = TR_NONE; G.ph = 0; return true;
-#endif
-        RDIS_SP(1);
         const double fu = r0, du = r1;
         const bool le = fu <= fx_;
         const bool right = uu_ >= x_, left = uu_ < x_;
@@ -297,10 +282,6 @@ struct CgdMachine {
         const double dnew = accept ? dacc : 0.5 * ebis;
         const bool tn = !(fabs(dnew) >= tol1);
         un = tn ? x1 + copysign(tol1, dnew) : x1 + dnew;
-#if defined(RDIS_HOT_CUT) && RDIS_HOT_CUT == 2
-        uu = un; e = enew; pre_tag = TR_NONE; G.ph = 0; return true;
-#endif
-        RDIS_SP(2);
         if (fu != fu) saw_nan = true;
         a = a1; b = b1; v = v1; fv = fv1; dv = dv1; w = w1; fw = fw1; dw = dw1; x = x1; fx = fx1; dx = dx1;
         e = enew; d = dnew; tiny = tn; uu = un;
@@ -315,16 +296,11 @@ struct CgdMachine {
         G.b = (!tn && !(un < x1)) ? un : b1;
         G.x = x1; G.dx = dx1;
         G.ph = tn ? Predictor::P_STOP : Predictor::P_DB;
-        RDIS_SP(3);
         return true;
     }
 
     // r0, r1, r2: reply to the previous request
-#ifdef RDIS_NEXT_NOINLINE
-    __device__ __attribute__((noinline)) Request next(double r0, double r1, double r2) {
-#else
     __device__ Request next(double r0, double r1, double r2) {
-#endif
 #pragma clang fp contract(off)
         const double GOLD = 1.618034, GLIMIT = 100.0, TINY = 1.0e-20;      // nrc :82
         const double GTOL = 1.0e-8;                                         // nrc :622 (EPS = 1e-18, :621, is in line_done)

@@ -14,9 +14,6 @@ __global__ void __launch_bounds__(64) drive(long long* cyc, long long* cnt, doub
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
     if (threadIdx.x == 0) M.init(maxiters, 3e-8);
-#ifdef RDIS_STEP_PROFILE
-    for (int i = 0; i < 16; ++i) step_prof()[i] = 0;
-#endif
     __syncthreads();
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
     long long c_hot = 0, n_hot = 0, c_other = 0, n_other = 0;
@@ -24,14 +21,8 @@ __global__ void __launch_bounds__(64) drive(long long* cyc, long long* cnt, doub
     for (int round = 0; round < 100000; ++round) {
         const int st0 = __builtin_amdgcn_readfirstlane(M.st);
         const long long t0 = clock64();
-#ifdef RDIS_STEP_PROFILE
-        step_prof()[15] = clock64();
-#endif
         if (threadIdx.x == 0) step_machine(&M, &Q[round & 1], r0, r1, r2, true);   // one lane: see run_machine
         const long long t1 = clock64();
-#ifdef RDIS_STEP_PROFILE
-        if (st0 == CgdMachine::S_DB_EVAL) step_prof()[5] += t1 - step_prof()[15];
-#endif
         __syncthreads();
         if (st0 == CgdMachine::S_DB_EVAL) { c_hot += t1 - t0; ++n_hot; } else { c_other += t1 - t0; ++n_other; }
         const Request& q = Q[round & 1];
@@ -49,9 +40,6 @@ __global__ void __launch_bounds__(64) drive(long long* cyc, long long* cnt, doub
             r0 = 1.0; r1 = 1.0; r2 = 0.5;
         }
     }
-#ifdef RDIS_STEP_PROFILE
-    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) cyc[2 + i] = step_prof()[i];
-#endif
     if (threadIdx.x == 0) {
         cyc[0] = c_hot; cnt[0] = n_hot; cyc[1] = c_other; cnt[1] = n_other;
         out[0] = M.fret; out[1] = (double)M.nfeval; out[2] = (double)M.iter;
@@ -69,11 +57,6 @@ int main() {
         hipMemcpy(ho, out, 24, hipMemcpyDeviceToHost);
         printf("run %d: Brent-reply steps %lld, %.0f cycles each; other steps %lld, %.0f cycles each (fret %.6f nfeval %.0f iters %.0f)\n",
                rep, hn[0], (double)hc[0] / (hn[0] ? hn[0] : 1), hn[1], (double)hc[1] / (hn[1] ? hn[1] : 1), ho[0], ho[1], ho[2]);
-#ifdef RDIS_STEP_PROFILE
-        // (each mark costs a clock read, ~100+ cycles: read the split, not the total)
-        printf("   profile (sums of stamps / hot steps): t0->load %.0f, load->branch %.0f, arithmetic %.0f, store+predictor %.0f, ->t1 %.0f\n",
-               (double)hc[2] / hn[0], (double)hc[3] / hn[0], (double)hc[4] / hn[0], (double)hc[5] / hn[0], (double)hc[7] / hn[0]);
-#endif
     }
     return 0;
 }
