@@ -103,7 +103,17 @@ REPLAY_CASES = {
     "testpoly": (lambda: _with_x0(P.load_poly(), [1.0, -2.0]), 50),
     "sinusoid": (lambda: _with_x0(P.make_high_dim_sinusoid(), np.random.default_rng(2).uniform(-6, 6, 121)), 25),
     "synthetic_3x40": (lambda: P.make_synthetic_ba(1, 3, 40), 25),
+    # BASELINE config 2 the way optSinusoid starts it: uniform over the FULL domain +-62.83
+    # (src/optimize_sinusoid.cpp:154-165); committed start vector, tests/golden/sinusoid_start.json
+    "sinusoid_full_domain": (lambda: _with_x0(P.make_high_dim_sinusoid(), _sinusoid_start()), 25),
 }
+
+
+def _sinusoid_start():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sinusoid_start.json")) as fh:
+        return np.array(json.load(fh)["x0"])
 
 
 def _with_x0(pp, x0):
@@ -119,6 +129,23 @@ def test_replay_device_decisions_equal_oracle(name, gctx):
     assert len(trv[0]) > 10
     check_replay(pp, trv, r, mit)
     check_prefix_endpoints(gctx, pp, [k for k in (1, 2, 3, 5, 10, 25) if k <= mit])
+
+
+def test_config2_sinusoid_from_the_full_domain_start(gctx):
+    """config 2 from the committed full-domain start: the first line searches take steps far beyond the
+    domain (a bound becomes active: the objective is evaluated at the clamped point while CG keeps
+    the unclamped iterate, CGDSubspaceOptimizer.cpp:165-168), the solve descends from 17126 by an
+    order of magnitude, and the returned point is inside the domain with a variable ON a bound"""
+    pp = _with_x0(P.make_high_dim_sinusoid(), _sinusoid_start())
+    assert np.max(np.abs(pp.x0)) > 50 and np.all(pp.x0 >= pp.lo) and np.all(pp.x0 <= pp.hi)
+    g, r, _ = solve(gctx, pp, maxiters=25)
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    finit = o.eval()
+    assert abs((r.fret[0] - r.delta[0]) - finit) <= 1e-12 * abs(finit) and abs(finit - 17126.136253546265) < 1e-6
+    assert r.fret[0] < 0.2 * finit and np.all(r.x >= pp.lo) and np.all(r.x <= pp.hi)
+    assert np.any((r.x == pp.lo) | (r.x == pp.hi))                     # a bound is active at the end
+    o.assign(None, r.x)
+    assert abs(o.eval() - r.fret[0]) <= 1e-12 * abs(r.fret[0])
 
 
 @pytest.mark.parametrize("name", ["ladybug_5_30", "ladybug_49_500", "sinusoid"])

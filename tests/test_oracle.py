@@ -170,6 +170,26 @@ def test_sinusoid_shape_and_derivative(golden):
         assert abs((fa - fb) / 2e-6 - g[j]) < 1e-6 * max(1, abs(g[j]))
 
 
+def test_sinusoid_full_domain_start_fixture():
+    """the committed start of config 2 (tests/golden/sinusoid_start.json, generated by
+    tests/golden/make_sinusoid_start.py): uniform over the whole domain like optSinusoid's
+    (src/optimize_sinusoid.cpp:154-165)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sinusoid_start.json")) as fh:
+        d = json.load(fh)
+    s = P.make_high_dim_sinusoid()
+    x0 = np.array(d["x0"])
+    assert len(x0) == s.nvars == 121 and d["lo"] == s.lo[0] and d["hi"] == s.hi[0]
+    assert abs(s.hi[0] - 10 * 2.000001 * 3.141592653) < 1e-4            # +-10 tp, as the generator prints it (OptimizableFunctionGenerator.cpp:660-760)
+    assert np.all(x0 >= s.lo) and np.all(x0 <= s.hi) and x0.max() - x0.min() > 100
+    o = O.OracleProblem(s)
+    o.assign(None, x0)
+    assert abs(o.eval() - 17126.136253546265) < 1e-9
+    r = O.OracleProblem(s).cgd(x=x0, maxiters=25)
+    assert r.fret < 0.2 * r.finit and np.any((r.x == s.lo) | (r.x == s.hi))   # a bound is active at the end
+
+
 # ---------------------------------------------------------------- minimiser
 def _rosen(x):
     return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
