@@ -174,6 +174,64 @@ __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12]
     }
 }
 
+// Forward-mode derivative of E along ONE direction d (the search direction of a line minimisation):
+// the slope d/da E(x + a d) at the forward state t, without forming the 12 partials -- about two
+// thirds of the adjoint sweep's instructions and no 12-entry gradient live in registers.  The
+// batched solvers use it for line-search trials (they need the slope only; the full gradient, once
+// per CG iteration, stays with the adjoint).  CAMFIX: the camera's nine entries of d are zero (and
+// are not read).  Same model, differentiated in the other order: agrees with sum_k g_k d_k to rounding.
+template <bool CAMFIX>
+__device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const double (&x)[12], const double (&d)[12]) {
+#pragma clang fp contract(on)
+    const double q0 = x[9], q1 = x[10], q2 = x[11];
+    const double e0 = d[9], e1 = d[10], e2 = d[11];          // direction of the point
+    double dP0, dP1, dP2;
+    if (t.theta > 0.0) {
+        const double omc = 1.0 - t.c;
+        // v x dq, v . dq
+        double dw0 = t.v1 * e2 - t.v2 * e1, dw1 = t.v2 * e0 - t.v0 * e2, dw2 = t.v0 * e1 - t.v1 * e0;
+        double ddot = t.v0 * e0 + t.v1 * e1 + t.v2 * e2;
+        dP0 = e0 * t.c + dw0 * t.s + t.v0 * (omc * ddot);
+        dP1 = e1 * t.c + dw1 * t.s + t.v1 * (omc * ddot);
+        dP2 = e2 * t.c + dw2 * t.s + t.v2 * (omc * ddot);
+        if constexpr (!CAMFIX) {
+            // rotation vector r = theta v: d theta = v . dr, dv = (dr - v d theta) / theta
+            const double dth = t.v0 * d[0] + t.v1 * d[1] + t.v2 * d[2];
+            const double u0 = (d[0] - t.v0 * dth) * t.itheta, u1 = (d[1] - t.v1 * dth) * t.itheta, u2 = (d[2] - t.v2 * dth) * t.itheta;
+            const double uw0 = u1 * q2 - u2 * q1, uw1 = u2 * q0 - u0 * q2, uw2 = u0 * q1 - u1 * q0;   // dv x q
+            const double ud = u0 * q0 + u1 * q1 + u2 * q2;                                             // dv . q
+            const double sd = t.s * dth, cd = t.c * dth;
+            const double k = sd * t.d + omc * ud;
+            const double od = omc * t.d;
+            dP0 += uw0 * t.s + t.w0 * cd - q0 * sd + u0 * od + t.v0 * k + d[3];
+            dP1 += uw1 * t.s + t.w1 * cd - q1 * sd + u1 * od + t.v1 * k + d[4];
+            dP2 += uw2 * t.s + t.w2 * cd - q2 * sd + u2 * od + t.v2 * k + d[5];
+        }
+    } else {   // P = q + r x q + t
+        dP0 = e0 + (t.v1 * e2 - t.v2 * e1);
+        dP1 = e1 + (t.v2 * e0 - t.v0 * e2);
+        dP2 = e2 + (t.v0 * e1 - t.v1 * e0);
+        if constexpr (!CAMFIX) {
+            dP0 += (d[1] * q2 - d[2] * q1) + d[3];
+            dP1 += (d[2] * q0 - d[0] * q2) + d[4];
+            dP2 += (d[0] * q1 - d[1] * q0) + d[5];
+        }
+    }
+    const double dpp0 = -(dP0 + t.pp0 * dP2) * t.iz;
+    const double dpp1 = -(dP1 + t.pp1 * dP2) * t.iz;
+    const double dr2 = 2.0 * (t.pp0 * dpp0 + t.pp1 * dpp1);
+    double ddst = dr2 * (x[7] + 2.0 * x[8] * t.r2);
+    double scale = x[6] * ddst;          // d(f dstn) = df dstn + f ddstn
+    if constexpr (!CAMFIX) {
+        ddst += t.r2 * (d[7] + d[8] * t.r2);
+        scale = d[6] * t.dstn + x[6] * ddst;
+    }
+    const double fd = x[6] * t.dstn;
+    const double dpix0 = scale * t.pp0 + fd * dpp0;
+    const double dpix1 = scale * t.pp1 + fd * dpp1;
+    return t.res0 * dpix0 + t.res1 * dpix1;
+}
+
 // value + the 12 partials
 __device__ __forceinline__ double ba_eval_grad(const double (&x)[12], double ox, double oy,
                                                double (&g)[12]) {

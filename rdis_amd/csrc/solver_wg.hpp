@@ -22,6 +22,9 @@ namespace rdis_hip {
 constexpr int MAX_WAVES = 16;
 constexpr int WG_LONG_LIST = 64;   // batch solver: variables fed by more partials than this are summed by a whole wave
 constexpr int WG_LONG_QUEUE = 512; // ... up to this many per component (LDS queue)
+// line-search slopes of bundle-adjustment factors in the batched / streaming solvers: forward mode along
+// the search direction (factors.hpp ba_slope_dir) instead of the 12 partials dotted with it
+constexpr bool FWD_SLOPE = true;
 
 // Wave-wide reductions; every lane of a full wave returns the same bits.  Within a row of 16
 // lanes the partner comes through DPP (quad_perm / row_half_mirror / row_mirror: an ALU-speed
@@ -153,7 +156,14 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
         for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
         f = ba_project(v, o.x, o.y, t);
         s = 0.0;
-        if constexpr (SLOPE) {
+        if constexpr (SLOPE && FWD_SLOPE) {
+            double d[12];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_RECORDS) ? dir[c + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[9 + k] = dir[q + k];
+            s = ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
+        } else if constexpr (SLOPE) {
             double g[12];
             ba_adjoint(t, v, t.res0, t.res1, g);
             double acc = 0.0;
@@ -173,7 +183,16 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
         for (int k = 0; k < 9; ++k) v[k] = P.x[c + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[9 + k] = P.x[q + k];
-        if constexpr (SLOPE) {
+        if constexpr (SLOPE && FWD_SLOPE) {
+            BaFwd t;
+            f = ba_forward(v, o.x, o.y, t);
+            double d[12];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = dir[c + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[9 + k] = dir[q + k];
+            s = ba_slope_dir<false>(t, v, d);
+        } else if constexpr (SLOPE) {
             double g[12];
             f = ba_eval_grad(v, o.x, o.y, g);
             double acc = 0.0;
