@@ -43,7 +43,7 @@ struct HipRDISLevelOptimizer::LevelPlan {
 };
 
 HipRDISLevelOptimizer::HipRDISLevelOptimizer(OptimizableFunction& f, HipCGDSubspaceOptimizer& ssopt)
-    : f_(f), ss_(ssopt), blkpct_(0.2), steptol_(1.0e-4), maxSweeps_(20), batch_(true),
+    : f_(f), ss_(ssopt), blkpct_(0.2), steptol_(1.0e-4), seppct_(0.0), maxSweeps_(20), batch_(true),
       ssmaxit_(ssopt.getMaxIters()), ssftol_(ssopt.getFtol()), sweeps_(0), decomp_ms_(0) {}
 
 HipRDISLevelOptimizer::~HipRDISLevelOptimizer() { releasePlans(); }
@@ -61,6 +61,7 @@ void HipRDISLevelOptimizer::setParameters(const Options& o) {
     if (o.count("steptol")) steptol_ = o.as<double>("steptol");      // :1089-1090
     if (o.count("maxSweeps")) maxSweeps_ = o.as<int>("maxSweeps");
     if (o.count("batch")) batch_ = o.as<int>("batch") != 0;
+    if (o.count("sepPiecePct")) seppct_ = o.as<double>("sepPiecePct");
     if (blkpct_ <= 0 || blkpct_ > 1 || maxSweeps_ < 1) throw std::invalid_argument("HipRDISLevelOptimizer: bad options");
 }
 
@@ -188,7 +189,10 @@ void HipRDISLevelOptimizer::buildTree() {
         for (int ni : frontier) {
             Node& nd = nodes_[(size_t)ni];
             if (nd.factors.empty() || nd.vars.size() <= leafMax) continue;
-            chooseSeparator(f_, nd.vars, nd.factors, leafMax, nd.separator);
+            // (sepPiecePct > 0: pieces of up to that fraction of the NODE -- a bisection-like cut whose children
+            // may be split again, the shape of the reference's two-way partitions; default: pieces that are leaves)
+            const size_t piece = seppct_ > 0 ? std::max<size_t>(leafMax, (size_t)std::llround(seppct_ * (double)nd.vars.size())) : leafMax;
+            chooseSeparator(f_, nd.vars, nd.factors, piece, nd.separator);
             if (nd.separator.empty() || nd.separator.size() >= nd.vars.size()) { nd.separator.clear(); continue; }
             nd.leaf = false;
             std::vector<char> is_sep(N, 0);   // (only this node's entries are read)

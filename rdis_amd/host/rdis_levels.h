@@ -57,7 +57,9 @@ public:
 
     // AVblkpct (0.2), steptol (1e-4), maxSweeps (20), SSmaxit / SSftol (forwarded to the subspace
     // optimizer by the caller), batch (1; 0 = one ssopt.optimize call per component, in the
-    // reference's child order: the same results bit for bit, for tests and comparison)
+    // reference's child order: the same results bit for bit, for tests and comparison), sepPiecePct (0: a
+    // separator leaves pieces that are leaves; > 0: pieces of up to that fraction of the node, which are
+    // split again -- deeper trees, like the reference's two-way partitions)
     void setParameters(const Options& options);
 
     // Every variable must be assigned (the initial state, optBA.cpp:189-205).  Returns the final
@@ -72,7 +74,8 @@ public:
     // The separator of one component: variable blocks (OptimizableFunction::getBlockRangeByVid) are
     // put back into an empty graph in order of ascending degree (number of the component's factors
     // that read the block; ties by block id) for as long as the largest connected piece of what has
-    // been put back stays within maxPiece variables; the blocks that do not fit are the separator.
+    // been put back stays within maxPiece variables; from the first block that does not fit on, blocks are
+    // separator blocks.
     // Then, like ensureFactorWillBeAssigned (RDISOptimizer.cpp:412-458), the remaining variables of the
     // first factor (in list order) that reads a separator variable and has the fewest other
     // variables are added, with their blocks.  On ladybug-49-7776 with maxPiece = 0.2 x 23769: 46 of
@@ -89,7 +92,7 @@ private:
     double runPlan(LevelPlan& lp, int sweep, double objective, bool printInfo);
     OptimizableFunction& f_;
     HipCGDSubspaceOptimizer& ss_;
-    double blkpct_, steptol_;
+    double blkpct_, steptol_, seppct_;
     int maxSweeps_;
     bool batch_;
     size_t ssmaxit_;

@@ -324,4 +324,41 @@ int harness_call_shapes(const char* path, int nsep, int npt_calls, int maxit, in
     } catch (const std::exception& e) { std::cerr << "harness_call_shapes: " << e.what() << std::endl; return -2; }
 }
 
+// ---- GPU: the level driver on the default high-dimensional sinusoid (BASELINE config 2: 121 variables in a
+// ternary tree, every variable its own block): a decomposition several levels deep.  x0: start (121 values).
+// out = {final, initial, sweeps, #nodes, #leaves, #split, max depth, monotone, |running sum - evaluated|, wall ms}
+int harness_level_driver_sinusoid(const double* x0, int maxit, int max_sweeps, double blkpct, double seppct, int batch, double* out, double* x_out) {
+    try {
+        std::unique_ptr<PolynomialFunction> f = PolynomialFunction::makeHighDimSinusoid();
+        NumericVec x(x0, x0 + f->getNumVars());
+        f->assignAll(x);
+        const Numeric before = f->eval();
+        HipCGDSubspaceOptimizer ssopt(*f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        HipRDISLevelOptimizer rdis(*f, ssopt);
+        Options ro; ro.set("AVblkpct", blkpct); ro.set("maxSweeps", max_sweeps); ro.set("batch", batch); ro.set("sepPiecePct", seppct);
+        rdis.setParameters(ro);
+        const auto t0 = std::chrono::steady_clock::now();
+        const Numeric fin = rdis.optimize(false);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        size_t nleaf = 0, nsplit = 0; int maxd = 0;
+        for (const auto& nd : rdis.nodes()) { (nd.leaf ? nleaf : nsplit)++; maxd = std::max(maxd, nd.depth); }
+        // the tree is a partition: every variable in exactly one leaf or one separator
+        std::vector<int> seen((size_t)f->getNumVars(), 0);
+        for (const auto& nd : rdis.nodes()) {
+            if (nd.leaf) for (VariableID v : nd.vars) ++seen[(size_t)v];
+            else for (VariableID v : nd.separator) ++seen[(size_t)v];
+        }
+        bool part = true;
+        for (int c : seen) part = part && c == 1;
+        bool mono = true; double prev = before;
+        for (const auto& st : rdis.trace()) { mono = mono && st.objective <= prev; prev = st.objective; }
+        out[0] = fin; out[1] = before; out[2] = rdis.sweepsDone(); out[3] = (double)rdis.nodes().size(); out[4] = (double)nleaf;
+        out[5] = (double)nsplit; out[6] = maxd; out[7] = (mono && part) ? 1 : 0; out[8] = std::fabs(prev - fin); out[9] = ms;
+        if (x_out) for (size_t i = 0; i < f->getVariables().size(); ++i) x_out[i] = f->getVariables()[i]->eval();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_level_driver_sinusoid: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

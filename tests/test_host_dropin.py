@@ -322,3 +322,33 @@ def test_unchanged_caller_one_call_at_a_time(harness, bal_path):
     print("731 optimize() calls one at a time: %.1f ms with the plan cache, %.1f ms without; CPU oracle on one core %.1f ms; "
           "function value %.6f (oracle's own trajectory: %.6f)" % (o1[0], o0[0], cpu_ms, o1[2], orc.eval()))
     assert o1[0] < o0[0] and o1[0] < 2.5 * cpu_ms
+
+
+@pytest.mark.gpu
+def test_level_driver_multi_level_tree_on_the_sinusoid(harness):
+    """config 2 through the level driver from the committed full-domain start: every variable is its own
+    block; with leaves of at most 12 variables and separators that cut a node roughly in half
+    (sepPiecePct 0.5) the 121-variable tree is split over several depths: the nodes partition the variables, the function is monotone launch by launch, the
+    batched run equals the one-call-at-a-time run bit for bit, and the result is the oracle's objective
+    at the returned point"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "sinusoid_start.json")) as fh:
+        x0 = np.array(json.load(fh)["x0"])
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    res = {}
+    for batch in (1, 0):
+        out, x = np.zeros(10), np.zeros(121)
+        assert harness.harness_level_driver_sinusoid(v(x0), 25, 10, C.c_double(0.1), C.c_double(0.5), batch, v(out), v(x)) == 0
+        res[batch] = (out.copy(), x.copy())
+    (ob, xb), (os_, xs) = res[1], res[0]
+    print("sinusoid: %.3f -> %.6f in %d sweeps; %d nodes (%d split, %d leaves), depth %d; %.1f ms batched, %.1f ms one call at a time" % (
+        ob[1], ob[0], ob[2], ob[3], ob[5], ob[4], ob[6], ob[9], os_[9]))
+    assert abs(ob[1] - 17126.136253546265) < 1e-6 and ob[7] == 1.0 and ob[8] <= 1e-9 * max(abs(ob[0]), 1.0)
+    assert ob[6] >= 2 and ob[5] >= 2                                   # really a multi-level decomposition
+    assert ob[0] < 0.2 * ob[1]
+    assert ob[0] == os_[0] and np.array_equal(xb, xs)                  # batched == sequential, bit for bit
+    pp = P.make_high_dim_sinusoid()
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    o.assign(None, xb)
+    assert abs(o.eval() - ob[0]) <= 1e-12 * max(abs(ob[0]), 1.0)
+    assert np.all(xb >= pp.lo) and np.all(xb <= pp.hi)
