@@ -27,6 +27,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -217,6 +218,7 @@ private:
     mutable int device_;
     mutable std::vector<VariableID> dirty_;
     mutable std::vector<char> is_dirty_;
+    std::unordered_map<std::string, Variable*> by_name_;
 };
 
 class BundleAdjustmentFunction : public OptimizableFunction {

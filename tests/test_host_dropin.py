@@ -352,3 +352,24 @@ def test_level_driver_multi_level_tree_on_the_sinusoid(harness):
     o.assign(None, xb)
     assert abs(o.eval() - ob[0]) <= 1e-12 * max(abs(ob[0]), 1.0)
     assert np.all(xb >= pp.lo) and np.all(xb <= pp.hi)
+
+
+@pytest.mark.gpu
+def test_level_driver_on_a_larger_bal_file(harness, tmp_path):
+    """the whole caller side at a size beyond ladybug: a BAL file of 64 cameras x 20000 points (80000
+    observations, 60576 variables) written by the saver, read by the C++ loader, decomposed (separator:
+    52 of the 64 cameras + 1 point; one launch of 12706 children) and optimised by sweeps -- the 65505-factor
+    separator solve fills the cooperative solver to its capacity (256 workgroups of 256 lanes)"""
+    pp = P.make_synthetic_ba(1, 64, 20000, obs_per_pt=4)
+    path = str(tmp_path / "synthetic_64_20000.txt")
+    P.save_bal(pp, path)
+    out, tr, x = _level_driver(harness, path.encode(), 0, 0, sweeps=6, nvars=pp.nvars)
+    print("64 x 20000: %.6g -> %.6g in %d sweeps, %d launches, %.1f ms (decomposition %.1f ms); %d components, largest separator %d" % (
+        out[1], out[0], out[2], len(tr), out[6], out[7], out[3], out[8]))
+    assert out[10] == 1.0 and out[11] <= 1e-9 * out[0] and out[0] < 0.05 * out[1]
+    assert out[5] == 1 and out[8] % 9 == 3 and out[3] > 10000
+    o = O.OracleProblem(pp, emulate_stale_cache=False)
+    assert abs(o.eval() - out[1]) <= 1e-12 * out[1]                     # the file round trip kept the start
+    o.assign(None, x)
+    assert abs(o.eval() - out[0]) <= 1e-12 * out[0]
+    assert np.all(x >= pp.lo) and np.all(x <= pp.hi)
