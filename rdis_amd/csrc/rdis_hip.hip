@@ -18,6 +18,7 @@
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
+#include "solver_pipe.hpp"
 #include "solver_quad.hpp"
 #include "solver_stream.hpp"
 
@@ -199,6 +200,9 @@ struct rdis_hip_plan {
     size_t off_cb_ptr = 0, off_cb = 0, off_cb_li = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     int coop_speculate = 1;           // option: guesses at the following trial steps ride along with every line-search trial
+    int coop_pipeline = 0;            // option: cooperative groups with a control wave of their own (solver_pipe.hpp); 0 = solver_coop.hpp
+    bool pipelined() const { return coop_pipeline != 0 && coop_threads == PIPE_THREADS; }
+    int coop_lanes() const { return pipelined() ? PIPE_LANES : coop_threads; }   // factor lanes per workgroup of a cooperative group
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
     int dump_iters = 0;
@@ -880,6 +884,8 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->coop_threads = (int)value;
     } else if (n == "coop_speculate") {
         L->coop_speculate = value != 0;
+    } else if (n == "coop_pipeline") {
+        L->coop_pipeline = value != 0;
     } else if (n == "force_stream") {
         L->force_stream = value != 0;
     } else if (n == "coop_poll_delay") {
@@ -925,7 +931,7 @@ int prepare_partition(rdis_hip_plan* L) {
     // The grid solvers are for a few large components that would leave the device idle as single
     // workgroups, one launch each.  When there are more large components than that, the batch
     // kernel fills the device by itself (one workgroup per component) and is the better fit.
-    const int wpw = L->coop_threads / 64;
+    const int wpw = L->coop_lanes() / 64;
     auto groups_of = [&](int cc) {   // workgroups of a component's cooperative group: a lane per factor / variable, a wave per long gradient run
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
@@ -933,7 +939,7 @@ int prepare_partition(rdis_hip_plan* L) {
         int64_t nlong = 0;
         for (int64_t i = 0; i < n; ++i)
             if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) ++nlong;
-        const int64_t need = (std::max(m, n) + L->coop_threads - 1) / L->coop_threads;
+        const int64_t need = (std::max(m, n) + L->coop_lanes() - 1) / L->coop_lanes();
         // (small groups only: a large one has its waves anyway, and more workgroups lengthen every sweep)
         const int64_t for_long = need < 16 ? std::min<int64_t>((nlong + wpw - 1) / wpw, 2 * need + 2) : 0;
         return std::max<int64_t>(1, std::max(need, for_long));
@@ -944,7 +950,7 @@ int prepare_partition(rdis_hip_plan* L) {
     bool any_big = L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors &&
                    nbig <= L->coop_max_components;
     const bool coop_on = L->coop_min_factors > 0 && L->coop_max_components > 0 && p->kind == KIND_BA && !L->force_stream;
-    if (coop_on) cap = coop_max_workgroups(L->coop_threads, c->num_cus);
+    if (coop_on) cap = L->pipelined() ? pipe_max_workgroups(c->num_cus) : coop_max_workgroups(L->coop_threads, c->num_cus);
     if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
     // Group mode: every component of some size gets a cooperative group when all the groups are
     // resident at once -- a device that the batch kernel would leave mostly idle (49 camera components
@@ -1015,7 +1021,7 @@ int prepare_partition(rdis_hip_plan* L) {
         }
         // owners of the CG recurrence: a lane per variable, a whole wave for variables fed by
         // many partials (longest first), see solver_coop.hpp
-        const int lanes = it.nwg * L->coop_threads, waves = lanes / 64;
+        const int lanes = it.nwg * L->coop_lanes(), waves = lanes / 64;
         std::vector<int> lane_var((size_t)lanes, -1), wave_var((size_t)waves, -1), longv;
         for (int64_t i = 0; i < n; ++i)
             if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) longv.push_back((int)i);
@@ -1100,7 +1106,7 @@ int prepare_partition(rdis_hip_plan* L) {
             g.a = CoopArgs{i == 0 ? p->coop_timing.as<long long>() : nullptr, nullptr /* set below */, L->coop_ints.as<int>() + it.slot_li,
                            L->coop_ints.as<int>() + it.lane_var, L->coop_ints.as<int>() + it.wave_var, L->xi_glob.as<double>() + it.xi_off, it.comp,
                            // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
-                           it.nwg * (L->coop_threads / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay,
+                           it.nwg * (L->coop_lanes() / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay,
                            L->coop_speculate};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
             hg.push_back(g);
@@ -1194,8 +1200,11 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     }
     for (size_t l = 0; l < L->coop_launches.size(); ++l) {
         const CoopLaunch& cl = L->coop_launches[l];
-        int rc = launch_coop(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
-                             cl.count, cl.total_wg, L->coop_threads, maxiters, ftol);
+        int rc = L->pipelined()
+                     ? launch_pipe(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+                                   cl.count, cl.total_wg, maxiters, ftol)
+                     : launch_coop(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+                                   cl.count, cl.total_wg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
