@@ -200,8 +200,9 @@ struct rdis_hip_plan {
     size_t off_cb_ptr = 0, off_cb = 0, off_cb_li = 0;
     int coop_workgroups = 0, coop_threads = 256, coop_poll_delay = 16;
     int coop_speculate = 1;           // option: guesses at the following trial steps ride along with every line-search trial
-    int coop_pipeline = 0;            // option: cooperative groups with a control wave of their own (solver_pipe.hpp); 0 = solver_coop.hpp
-    bool pipelined() const { return coop_pipeline != 0 && coop_threads == PIPE_THREADS; }
+    int coop_pipeline = 1;            // option: cooperative groups with a control wave of their own (solver_pipe.hpp); 0 = solver_coop.hpp
+    bool use_pipe = false;            // decided by prepare_partition: the plan's groups fit the pipelined layout (fewer factor lanes per workgroup)
+    bool pipelined() const { return use_pipe; }
     int coop_lanes() const { return pipelined() ? PIPE_LANES : coop_threads; }   // factor lanes per workgroup of a cooperative group
     bool force_stream = false;        // send large components to the streaming grid solver even if they fit the register-resident one
     int trace_records = 0;
@@ -931,8 +932,8 @@ int prepare_partition(rdis_hip_plan* L) {
     // The grid solvers are for a few large components that would leave the device idle as single
     // workgroups, one launch each.  When there are more large components than that, the batch
     // kernel fills the device by itself (one workgroup per component) and is the better fit.
-    const int wpw = L->coop_lanes() / 64;
     auto groups_of = [&](int cc) {   // workgroups of a component's cooperative group: a lane per factor / variable, a wave per long gradient run
+        const int wpw = L->coop_lanes() / 64;
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
         const int f0 = L->h_free_ptr[(size_t)cc];
@@ -950,8 +951,33 @@ int prepare_partition(rdis_hip_plan* L) {
     bool any_big = L->coop_min_factors > 0 && L->coop_max_components > 0 && L->nfac >= L->coop_min_factors &&
                    nbig <= L->coop_max_components;
     const bool coop_on = L->coop_min_factors > 0 && L->coop_max_components > 0 && p->kind == KIND_BA && !L->force_stream;
-    if (coop_on) cap = L->pipelined() ? pipe_max_workgroups(c->num_cus) : coop_max_workgroups(L->coop_threads, c->num_cus);
-    if (L->coop_workgroups > 0) cap = std::min(cap, L->coop_workgroups);
+    auto cap_of = [&]() {
+        int k = L->pipelined() ? pipe_max_workgroups(c->num_cus) : coop_max_workgroups(L->coop_threads, c->num_cus);
+        if (L->coop_workgroups > 0) k = std::min(k, L->coop_workgroups);
+        return k;
+    };
+    // The pipelined layout (solver_pipe.hpp) has half the factor lanes per workgroup: it is used when
+    // everything that gets a cooperative group with the plain layout also gets one with it.
+    L->use_pipe = false;
+    if (coop_on && L->coop_pipeline != 0 && L->coop_threads == PIPE_THREADS) {
+        auto census = [&](int64_t& group_total, int64_t& group_count, int64_t& big_unfit) {
+            const int k = cap_of();
+            group_total = group_count = big_unfit = 0;
+            for (int cc : L->h_order) {
+                const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
+                if (L->coop_group_min_factors > 0 && m >= L->coop_group_min_factors) { group_total += groups_of(cc); ++group_count; }
+                if (m >= L->coop_min_factors && groups_of(cc) > k) ++big_unfit;
+            }
+            return k;
+        };
+        int64_t gt0, gc0, bu0, gt1, gc1, bu1;
+        const int k0 = census(gt0, gc0, bu0);
+        L->use_pipe = true;
+        const int k1 = census(gt1, gc1, bu1);
+        const bool group0 = gc0 > 0 && gt0 <= k0 && gc0 <= COOP_MAX_GROUPS, group1 = gc1 > 0 && gt1 <= k1 && gc1 <= COOP_MAX_GROUPS;
+        if ((group0 && !group1) || bu1 > bu0) L->use_pipe = false;
+    }
+    if (coop_on) cap = cap_of();
     // Group mode: every component of some size gets a cooperative group when all the groups are
     // resident at once -- a device that the batch kernel would leave mostly idle (49 camera components
     // of ladybug: 6.6 ms as one workgroup each).  Otherwise only the few very large ones do.

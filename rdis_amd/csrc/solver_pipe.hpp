@@ -1,41 +1,46 @@
-// solver_pipe.hpp -- the cooperative solver (solver_coop.hpp) with the control logic on a wave of
-// its own, so that a line search runs as a pipeline instead of a chain.
+// solver_pipe.hpp -- the cooperative solver (solver_coop.hpp) with the control logic and the
+// exchange on waves of their own, so that a line search runs as a pipeline instead of a chain.
 //
 // In solver_coop.hpp an objective evaluation is a chain of four latencies: the factor arithmetic of
 // one wave (~2100 cycles), reduction + publication (~450), the exchange between workgroups (store
 // lands, load returns, slowest wave: ~4200), a step of the control logic (~2000) -- and the wave
-// that sweeps and steps is also a wave that evaluates, so nothing overlaps.  Here a workgroup is
+// that sweeps and steps is also a wave that evaluates, so nothing overlaps.  Here a workgroup of
+// four waves is
 //
-//   wave 0        CONTROL: owns no factor and no variable.  It keeps the state machine of
-//                 minimizer.hpp in REGISTERS (nothing of the factor arithmetic competes for them),
-//                 sweeps the exchange, steps the machine and posts requests in an LDS mailbox.
-//   waves 1..     LANES: a factor per lane, variables per lane / wave exactly as in solver_coop.hpp;
-//                 they serve the request in the mailbox and publish their partial sums.
+//   wave 0   STEPPER: keeps the state machine of minimizer.hpp in registers (nothing of the factor
+//            arithmetic competes for them), steps it on the sums it is handed and posts requests in
+//            an LDS mailbox.  It touches no global memory.
+//   wave 1   COLLECTOR: sweeps the exchange slot the stepper names (all entries of the group, summed
+//            in index order), re-arms dead slots, hands the sums back through LDS.
+//   waves 2, 3   LANES: a factor per lane, variables per lane / wave exactly as in solver_coop.hpp;
+//            they serve the request in the mailbox and publish their partial sums.
 //
-// ladybug-49-7776 then needs 166 workgroups of 256 instead of 125 -- the device has 256 compute
-// units and the solve used half of them.  The two sides are decoupled, which is what makes
-// speculation free: with a value+slope request the control wave also posts a CHAIN of guesses at the
+// ladybug-49-7776 then needs 249 workgroups of 256 instead of 125 -- the device has 256 compute
+// units and the solve used half of them.  The three sides are decoupled, which is what makes
+// speculation free: with a value+slope request the stepper also posts a CHAIN of guesses at the
 // following trial steps (Predictor, minimizer.hpp: Brent's method mostly bisects towards the best
 // point, and the step a bisection takes does not depend on the value the pending trial returns).
 // The lanes evaluate the request, then the guesses one after the other, each into its own exchange
-// slot, looking at the mailbox in between.  When the machine, stepped with the reply, asks for
-// exactly the step that was guessed (same bits) the reply is already on its way or there: the
-// control wave sweeps that slot at once and the lanes never stopped working.  A guess that does not
-// hold costs nothing but the arithmetic of lanes that would have idled; the machine never sees a
-// guess -- decisions, trace and call counts are those of the unspeculated run, and the sums are
-// formed entry by entry in the order solver_coop.hpp uses (same bits).
+// slot, looking at the mailbox in between; the collector is sent to the first guess's slot while the
+// stepper still works on the reply before it.  When the machine, stepped with that reply, asks for
+// exactly the step that was guessed (same bits) its sums are there or on their way, and the lanes
+// never stopped working: per trial step the three sides then cost max(arithmetic, sweep, step)
+// instead of their sum.  A guess that does not hold costs the arithmetic of lanes that would have
+// idled; the machine never sees a guess -- decisions, trace and call counts are those of the
+// unspeculated run, and the sums are formed entry by entry in the order solver_coop.hpp uses (same
+// bits: entry = the group's lane wave, 64 consecutive factors).
 //
-// Exchange slots.  Every exchange has a number e, agreed by construction (all control waves take
-// the same decisions on the same bits): a request's evaluation gets the next free number E, the
+// Exchange slots.  Every exchange has a number e, agreed by construction (all steppers take the
+// same decisions on the same bits): a request's evaluation gets the next free number E, the
 // guesses of its chain E+1 .. E+DEPTH; a hit continues at E+1, a miss jumps to E+DEPTH+1.  Slot e
 // lives in buffer e mod 16 of the granule ring (data is the flag, grid_sync.hpp).  A lane wave
 // publishes every slot at most once, in increasing order, and waits for its previous stores before
-// each publication, so its stores land in order.  After its sweep of slot y a control wave re-arms
-// its workgroup's entries of all slots <= y - DEPTH - 1: the sweep of y completing proves that every
-// lane wave has published y, hence that its control wave had posted a request numbered >= y - DEPTH,
-// hence finished every sweep below that.  Those re-arming stores are waited for by the next sweep
-// (before the next request is posted); a buffer comes round again after 16 >= 4 DEPTH + 3 slots,
-// which is more than the lanes can be ahead of that point.
+// each publication, so its stores land in order.  After a completed sweep of slot y a collector
+// re-arms its workgroup's entries of all slots <= y - DEPTH - 1: the sweep of y completing proves
+// that every lane wave has published y, hence that its stepper had posted a request numbered
+// >= y - DEPTH, hence consumed every sweep below that.  Those re-arming stores are waited for by
+// the collector's next sweep, i.e. before the stepper can post the next request; a buffer comes
+// round again after 16 >= 4 DEPTH + 3 slots, which is more than the lanes can be ahead of that point.
 #pragma once
 #include "solver_coop.hpp"
 
@@ -44,57 +49,79 @@ namespace rdis_hip {
 constexpr int PIPE_NBUF = 16;     // granule buffers (ring over exchange numbers)
 constexpr int PIPE_DEPTH = 3;     // guesses in flight behind a request
 constexpr int PIPE_ENT = 1024;    // entries (lane waves of a group) per buffer
-constexpr int PIPE_MAILS = 8;     // request slots in LDS: the control wave posts at most 2 (DEPTH + 1) - 1 < 8 times before a lane wave must act
+constexpr int PIPE_MAILS = 4;     // request slots in LDS (every post is a request the lanes must act on before the next one can follow)
 constexpr int PIPE_THREADS = 256;
-constexpr int PIPE_LANES = PIPE_THREADS - 64;   // factor lanes per workgroup
+constexpr int PIPE_CTRL = 2;      // stepper + collector
+constexpr int PIPE_LANES = PIPE_THREADS - 64 * PIPE_CTRL;   // factor lanes per workgroup
+constexpr int PIPE_QUIT = 0x7FFFFFFF;
 static_assert(PIPE_NBUF >= 4 * PIPE_DEPTH + 3 && (PIPE_NBUF & (PIPE_NBUF - 1)) == 0, "ring too short for the run-ahead");
 
 // same memory as a CoopState (one per concurrent group), cut differently
 struct PipeState {
-    alignas(32) unsigned long long granule[PIPE_NBUF][PIPE_ENT][COOP_KP];
+    // granules 0, 1 of an entry (the value and slope of a line-search trial: the exchange that matters)
+    // are packed 16 bytes apart, granules 2, 3 live in a second array: a sweep of pairs reads half
+    // the cache lines it would read from 32-byte entries
+    alignas(32) unsigned long long granule[2][PIPE_NBUF][PIPE_ENT][2];
     unsigned int abort_flag;
     unsigned int pad[15];
 };
 static_assert(sizeof(PipeState) <= sizeof(CoopState), "PipeState must fit the exchange state the host allocates");
 
-struct alignas(16) PipeMail {   // 64 bytes: four 16-byte LDS accesses
+struct alignas(16) PipeMail {   // 96 bytes: six 16-byte LDS accesses
     int kind, flags;
     int e;                       // exchange number of the request's first collective operation
-    int ng;                      // guesses: guess[j] belongs to slot (slot of the request's evaluation) + 1 + j
+    int g_ph;                    // with a value+slope request: the Predictor (minimizer.hpp) the lanes continue from ...
     double a, b;
-    double guess[PIPE_DEPTH];
-    double pad;
+    double g_a, g_b, g_x, g_dx, g_ax, g_bx, g_cx;
+    int g_need_first, pad;
 };
-constexpr int PIPE_PRE = PIPE_ENT / 64;   // 16-byte pairs per lane a control wave can fetch ahead
+constexpr int PIPE_RECS = 8;    // guess records the stepper may still want: slots verified + 1 .. verified + DEPTH + 1
 struct PipeShared {
-    // the next slot's (value, slope) pairs fetched ahead by the control wave: [chunk][lane]
-    alignas(16) unsigned long long pre[PIPE_PRE][64][2];
     PipeMail mail[PIPE_MAILS];
     int seq;                     // number of the latest post (mail[seq % PIPE_MAILS])
-    int dead;                    // an exchange gave up (set by the control wave before a workgroup barrier)
+    int verified;                // stepper -> lanes: the latest slot the machine has asked for; they stay within DEPTH of it
+    // lanes -> stepper: what the chain guesses for slot z: rec_slot[z % 8] = 2 z + 1 and the step in rec_val, or 2 z = no guess
+    int rec_slot[PIPE_RECS];
+    double rec_val[PIPE_RECS];
+    // stepper -> collector: (slot << 2 | number of values), slots only ever increase; sleep before the first look
+    int cmd, cmd_delay;
+    // collector -> stepper: the sums of slot res_slot
+    int res_slot;
+    double res[3];
+    int bar_done;                // the last grid-wide barrier slot that is complete (stepper -> lanes)
+    int pub[PIPE_LANES / 64];    // lanes -> collector: the last slot each lane wave of this workgroup has published
+    int dead;                    // an exchange gave up
     // the result, for the lanes' write-back
     int status, rolled_back, iter;
     long long nfeval, ngeval;
     double fret, finit;
 };
+// words of PipeShared that one wave writes and another polls.  The casts name the LDS address
+// space: a volatile access through a generic pointer is compiled as a FLAT access at system scope
+// followed by a wait for every outstanding memory operation of the wave.
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ int lds_int(const int& x) { return *(const volatile lds_i32*)&x; }
+__device__ __forceinline__ void lds_set(int& x, int v) { *(volatile lds_i32*)&x = v; }
+__device__ __forceinline__ double lds_f64_get(const double& x) { return *(const volatile lds_f64*)&x; }
+__device__ __forceinline__ void lds_f64_set(double& x, double v) { *(volatile lds_f64*)&x = v; }
 
 struct PipeSync {
     PipeState* st;
     int tid, nwg, wg, nw;        // lane in workgroup, #workgroups, my workgroup, lane waves per workgroup
     int poll_delay;
-    int e;                       // next exchange number of the request being served (all waves agree)
-    int rearmed;                 // control wave: slots <= rearmed are re-armed
+    int e;                       // next exchange number of the request being served (stepper and lanes agree)
+    int rearmed;                 // collector: slots <= rearmed are re-armed
     bool dead;
 #ifdef RDIS_COOP_TIMING
     long long tm[COOP_TM];
 #endif
-    __device__ bool ctrl() const { return tid < 64; }
     __device__ void tick(int slot, long long dt) {
 #ifdef RDIS_COOP_TIMING
         tm[slot] += dt;
 #endif
     }
-    __device__ gu64* gran(int ex, int k, int w) const { return (gu64*)&st->granule[ex & (PIPE_NBUF - 1)][w][k]; }
+    __device__ gu64* gran(int ex, int k, int w) const { return (gu64*)&st->granule[k >> 1][ex & (PIPE_NBUF - 1)][w][k & 1]; }
     __device__ u64x2 load_pair(int ex, int k, int w) const {
         u64x2 r;
         const gu64* p = gran(ex, k, w);
@@ -109,43 +136,30 @@ struct PipeSync {
 
     // A lane wave (all 64 lanes) publishes its partial results of exchange ex: sums, the last NMAX maxima.
     template <int N, int NMAX>
-    __device__ void publish(int ex, double (&v)[N]) {
+    __device__ void publish(int ex, double (&v)[N], int* pub) {
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(v[k]) : wave_max(v[k]);
         // this wave's earlier stores -- data handed over by the exchange (SYNC_DRAIN of grid_sync.hpp)
         // and its previous publication -- are complete: a wave's publications land in order
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((tid & 63) == 0) {
-            const int ent = wg * nw + (tid >> 6) - 1;
+            const int ent = wg * nw + (tid >> 6) - PIPE_CTRL;
 #pragma unroll
             for (int k = 0; k + 1 < N; k += 2) store_pair(ex, k, ent, GridSync::bits_of(v[k]), GridSync::bits_of(v[k + 1]));
             if constexpr (N & 1) GridSync::publish(gran(ex, N - 1, ent), v[N - 1]);
+            lds_set(pub[(tid >> 6) - PIPE_CTRL], ex);   // the collector next door: the others' stores are about as far
         }
     }
 
-    // The control wave collects exchange ex: on return v holds the sums (maxima) over all lane waves
-    // of the group, entry by entry in index order -- bit-identical in every workgroup.  `delay`
-    // (x64 cycles) is slept before the first look.  Then re-arms what is certainly dead.
-    // The control wave asks for the (value, slope) pairs of slot ex ahead of time: straight into LDS
-    // (global_load_lds: no register is tied up while the wave steps the machine), to be handed to
-    // sweep() as `pre`.  What has not arrived by then is polled for as usual.
-    __device__ bool fetch_ahead(int ex, unsigned long long (*pre)[64][2]) const {
-        const int nent = nwg * nw, per = (nent + 63) >> 6, lane = tid & 63;
-        if (per > 8) return false;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < per) {
-                const int ww = lane + (j << 6);
-                const gu64* src = gran(ex, 0, ww < nent ? ww : 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)&pre[j][0][0], 16, 0, 16 /* sc1 */);
-            }
-        }
-        return true;
-    }
-
+    // The collector gathers exchange ex: on success v holds the sums (maxima) over all lane waves of
+    // the group, entry by entry in index order -- bit-identical in every workgroup -- and what is
+    // certainly dead has been re-armed.  It first waits (in LDS) for the lane waves of its own
+    // workgroup to publish the slot -- the other workgroups' are about as far, whatever held them
+    // up -- and, if it had to wait, sleeps `delay` (x64 cycles: a store needs about that long to land;
+    // polling earlier only slows it down) before the first look at memory.
+    // Returns false, v untouched, when the stepper has named another slot in the meantime (`cmd`).
     template <int N, int NMAX>
-    __device__ void sweep(int ex, double (&v)[N], int delay, const unsigned long long (*pre)[64][2] = nullptr) {
+    __device__ bool sweep(int ex, double (&v)[N], int delay, const int& cmd, int cmd_mine, const int* pub) {
         const int lane = tid & 63;
         const int nent = nwg * nw;
         double acc[N];
@@ -155,22 +169,30 @@ struct PipeSync {
         bool ok = !dead;
         const int per = (nent + 63) >> 6;
         constexpr int CH = N <= 2 ? 8 : 4;
-        for (int d = 0; d < delay; d += 8) __builtin_amdgcn_s_sleep(8);
+        const long long tq0 = coop_clock();
+        {
+            bool waited = false;
+            for (;;) {
+                int lo = lds_int(pub[0]);
+#pragma unroll
+                for (int w = 1; w < PIPE_LANES / 64; ++w) { const int t = lds_int(pub[w]); lo = t < lo ? t : lo; }
+                if (lo >= ex || dead) break;
+                if (lds_int(cmd) != cmd_mine) return false;
+                waited = true;
+                if (++spins > COOP_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            spins = 0;
+            if (waited) { tick(26, coop_clock() - tq0); tick(27, 1); }
+            if (waited) for (int d = 0; d < delay; d += 8) __builtin_amdgcn_s_sleep(8);
+        }
+        const long long tq1 = coop_clock();
         for (int j0 = 0; j0 < per && ok; j0 += CH) {
             unsigned long long val[CH][N];
 #pragma unroll
             for (int j = 0; j < CH; ++j)
 #pragma unroll
                 for (int k = 0; k < N; ++k) val[j][k] = COOP_SENTINEL;
-            if constexpr (N == 2) {
-                if (pre != nullptr) {   // fetched ahead (fetch_ahead: at most 8 chunks, i.e. j0 = 0 only)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        if (j0 + j < per) { val[j][0] = pre[j0 + j][lane][0]; val[j][1] = pre[j0 + j][lane][1]; }
-                    }
-                }
-            }
             for (;;) {
                 tick(6, 1);
                 constexpr int NP = N / 2;
@@ -209,6 +231,7 @@ struct PipeSync {
 #pragma unroll
                     for (int k = 0; k < N; ++k) here = here && val[j][k] != COOP_SENTINEL;
                 if (__all(here)) break;
+                if (lds_int(cmd) != cmd_mine) return false;   // the stepper wants something else
                 ++spins;
                 if (spins > COOP_SPIN_LIMIT ||
                     ((spins & 255u) == 0u &&
@@ -231,15 +254,18 @@ struct PipeSync {
             }
         }
         if (!__all(ok)) dead = true;
+        const long long tq2 = coop_clock();
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(acc[k]) : wave_max(acc[k]);
-        tick(5, 1);
-        // (every memory operation of this wave, the previous re-arming stores included, is complete:
-        // the sweep's last wait was for vmcnt(0))
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tick(5, 1); tick(28, tq2 - tq1); tick(29, coop_clock() - tq2);
+        return true;
+    }
+    // after a completed sweep of slot ex (every memory operation of this wave, the previous re-arming
+    // stores included, is complete: the sweep's last wait was for vmcnt(0))
+    __device__ void rearm_behind(int ex) {
         const int upto = ex - PIPE_DEPTH - 1;
-        if (tid < nw) {
-            const int ent = wg * nw + tid;
+        if ((tid & 63) < nw) {
+            const int ent = wg * nw + (tid & 63);
             for (int x = rearmed + 1; x <= upto; ++x) {
 #pragma unroll
                 for (int k = 0; k < COOP_KP; k += 2) store_pair(x, k, ent, COOP_SENTINEL, COOP_SENTINEL);
@@ -248,19 +274,14 @@ struct PipeSync {
         if (upto > rearmed) rearmed = upto;
     }
 
-    // Grid-wide barrier, all lanes of the workgroup call: the lanes' coherent stores issued before it
-    // are visible to coherent loads after it.  Takes one exchange number.
+    // Grid-wide barrier as the lanes see it: their coherent stores issued before it are visible to
+    // coherent loads after it.  Takes one exchange number; the stepper's side is pipe_ctrl_barrier.
     __device__ void barrier(PipeShared& S) {
         double z[1] = {0.0};
-        if (ctrl()) {
-            sweep<1, 0>(e, z, poll_delay);
-            if (tid == 0 && dead) S.dead = 1;
-        } else {
-            publish<1, 0>(e, z);
-        }
+        publish<1, 0>(e, z, S.pub);
+        while (lds_int(S.bar_done) < e) __builtin_amdgcn_s_sleep(1);
         ++e;
-        __syncthreads();
-        if (S.dead != 0) dead = true;
+        if (lds_int(S.dead) != 0) dead = true;
     }
 };
 
@@ -272,7 +293,7 @@ struct PipeEnv {
     const CoopArgs& A;
     PipeShared& S;
     int n, m, f0, c0;
-    int gt, tid;              // factor lane index in the group (-1 on the control wave), lane in workgroup
+    int gt, tid;              // factor lane index in the group (-1 on the two control waves), lane in workgroup
     PipeSync X;
     double* tr;
     int trn, lm_count;
@@ -416,7 +437,7 @@ struct PipeEnv {
             b = b + (wv.xi + wv.g) * wv.xi;
         }
         double v[3] = {a, b, t};
-        X.publish<3, 1>(X.e, v);
+        X.publish<3, 1>(X.e, v, S.pub);
         ++X.e;
     }
     __device__ void cg_update(double gam) {
@@ -436,40 +457,59 @@ struct PipeEnv {
     }
 };
 
-// debug counters (-DRDIS_COOP_TIMING): slots filled by a lane wave, the others by the control wave
-// lanes: 0 factor arithmetic, 2 reduce + publish, 9 waiting for a request, 10 requests evaluated, 11 guesses evaluated
-// control: 1 / 3 sweep of a guessed / fresh step (16 / 17 their counts), 5 #sweeps, 6 #polls, 7 whole kernel, 8 step + post,
-//          18 guesses that held, 19 guesses posted, 12.. cycles serving a request after its post: 12 value, 13 value+slope,
-//          14 gradient (+ reduction), 15 value+slope at the start of a line (direction update first); 22.. their counts
-__device__ __forceinline__ bool pipe_lane_slot(int i) { return i == 0 || i == 2 || (i >= 9 && i <= 11); }
-__device__ __forceinline__ int lds_seq(const PipeShared& S) { return *(const volatile int*)&S.seq; }
-
-// the control wave posts a request (lane 0 writes; LDS operations of a wave execute in order, so
-// whoever reads the new sequence number reads the new slot)
-__device__ __forceinline__ void pipe_post(PipeShared& S, int seq, int kind, int flags, int e, int ng, double a, double b,
-                                          const double (&guess)[PIPE_DEPTH], bool writer) {
-    if (writer) {
-        PipeMail t;
-        t.kind = kind; t.flags = flags; t.e = e; t.ng = ng; t.a = a; t.b = b; t.pad = 0.0;
-#pragma unroll
-        for (int k = 0; k < PIPE_DEPTH; ++k) t.guess[k] = guess[k];
-        S.mail[seq & (PIPE_MAILS - 1)] = t;
-        asm volatile("" ::: "memory");
-        *(volatile int*)&S.seq = seq;
-    }
+// debug counters (-DRDIS_COOP_TIMING)
+// lanes (wave 2 of workgroup 0): 0 factor arithmetic, 2 reduce + publish, 9 waiting for a request, 10 requests evaluated, 11 guesses evaluated
+// collector: 1 cycles in completed sweeps, 5 their number, 6 polls, 4 sweeps given up for another slot
+// stepper: 7 whole kernel, 8 step + post, 16 / 17 guessed / fresh value+slope steps and 20 / 21 the cycles spent waiting for their sums,
+//          19 guesses posted, 12.. cycles serving a request after its post: 12 value, 13 value+slope, 14 gradient (+ reduction),
+//          15 value+slope at the start of a line (direction update first); 22.. their counts
+// collector also: 26 cycles waiting for the own lanes' publication (27 how often), 28 polling memory, 29 final reduction
+// lanes also: 30 cycles from seeing a value+slope request to its publication (31 how often)
+__device__ __forceinline__ int pipe_slot_owner(int i) {   // 0 stepper, 1 collector, 2 lanes
+    return (i == 0 || i == 2 || (i >= 9 && i <= 11) || i == 30 || i == 31) ? 2 : (i == 1 || (i >= 4 && i <= 6) || (i >= 26 && i <= 29)) ? 1 : 0;
 }
 
-// ---- control wave ------------------------------------------------------------------------
-__device__ __forceinline__ void pipe_control(PipeEnv& E, PipeShared& S, int maxiters, double ftol) {
+// the stepper posts a request (lane 0 writes; LDS operations of a wave execute in order, so whoever
+// reads the new sequence number reads the new slot)
+__device__ __forceinline__ void pipe_post(PipeShared& S, int seq, int kind, int flags, int e, double a, double b,
+                                          const Predictor& G, bool writer) {
+    if (writer) {
+        PipeMail t;
+        t.kind = kind; t.flags = flags; t.e = e; t.a = a; t.b = b;
+        t.g_ph = G.ph; t.g_need_first = G.need_first ? 1 : 0; t.pad = 0;
+        t.g_a = G.a; t.g_b = G.b; t.g_x = G.x; t.g_dx = G.dx; t.g_ax = G.ax; t.g_bx = G.bx; t.g_cx = G.cx;
+        S.mail[seq & (PIPE_MAILS - 1)] = t;
+        asm volatile("" ::: "memory");
+        lds_set(S.seq, seq);
+    }
+}
+// the stepper sends the collector to slot ex (n values) ...
+__device__ __forceinline__ void pipe_command(PipeShared& S, int ex, int n, int delay, bool writer) {
+    if (writer) { lds_set(S.cmd_delay, delay); lds_set(S.cmd, (ex << 2) | n); }
+}
+// ... and waits for its sums
+template <int N>
+__device__ __forceinline__ void pipe_result(PipeShared& S, int ex, double (&v)[N], bool& dead) {
+    while (lds_int(S.res_slot) != ex) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = uniform(lds_f64_get(S.res[k]));
+    if (lds_int(S.dead) != 0) dead = true;
+}
+__device__ __forceinline__ void pipe_ctrl_barrier(PipeSync& X, PipeShared& S, bool writer) {
+    double z[1];
+    pipe_command(S, X.e, 1, X.poll_delay, writer);
+    pipe_result(S, X.e, z, X.dead);
+    if (writer) lds_set(S.bar_done, X.e);
+    ++X.e;
+}
+
+// ---- wave 0: the control logic -----------------------------------------------------------
+__device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxiters, double ftol) {
     CgdMachine M;
     M.init(maxiters, ftol);
-    Predictor G;
-    G.ph = Predictor::P_STOP; G.need_first = false; G.a = G.b = G.x = G.dx = 0.0; G.ax = G.bx = G.cx = 0.0;
-    double chain[PIPE_DEPTH];   // guesses posted and not yet asked for: chain[j] is slot e_last + 1 + j
-#pragma unroll
-    for (int k = 0; k < PIPE_DEPTH; ++k) chain[k] = 0.0;
-    int nchain = 0;
     int e_last = 0;             // slot of the last value+slope evaluation
+    bool chain_live = false;    // ... and the lanes may be evaluating guesses behind it
     int next_free = 0;          // first exchange number not handed out
     bool swapped = true;        // did the last bracketing go to the other side of the origin?
     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
@@ -477,16 +517,27 @@ __device__ __forceinline__ void pipe_control(PipeEnv& E, PipeShared& S, int maxi
     const bool writer = E.tid == 0;
     for (;;) {
         const long long ts0 = coop_clock();
-        // the reply to the first guess of the chain is probably what the machine will ask for next:
-        // its loads travel while the machine is stepped
-        const bool fetched = nchain > 0 && E.X.fetch_ahead(e_last + 1, S.pre);
+        // What do the lanes guess for the slot after the last evaluation?  (They wrote it down before
+        // they evaluated that one.)  It is probably what the machine will ask for next: the collector
+        // gathers its sums while the machine is stepped.
+        bool guessed = false;
+        double gval = 0.0;
+        if (chain_live) {
+            const int z = e_last + 1;
+            int rec;
+            while (((rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)])) >> 1) != z) __builtin_amdgcn_s_sleep(1);
+            guessed = (rec & 1) != 0;
+            gval = uniform(lds_f64_get(S.rec_val[z & (PIPE_RECS - 1)]));
+            if (guessed) pipe_command(S, z, 2, E.X.poll_delay, writer);
+        }
         Request nq;
-        Predictor Gn;
+        Predictor G;
+        G.ph = Predictor::P_STOP; G.need_first = false; G.a = G.b = G.x = G.dx = 0.0; G.ax = G.bx = G.cx = 0.0;
         bool was_hot;
         {
             double un, pa, pb, pc;
             int ptag;
-            was_hot = M.hot(r0, r1, un, ptag, pa, pb, pc, Gn);
+            was_hot = M.hot(r0, r1, un, ptag, pa, pb, pc, G);
             if (was_hot) {
                 nq = CgdMachine::req(REQ_EVAL, un, RF_SLOPE | RF_LINE);
                 nq.pre_tag = ptag; nq.pre_a = pa; nq.pre_b = pb; nq.pre_c = pc;
@@ -500,21 +551,19 @@ __device__ __forceinline__ void pipe_control(PipeEnv& E, PipeShared& S, int maxi
             M.reason = EXIT_SYNC_TIMEOUT; M.rolled_back = true; M.fret = M.finit;
         }
         const bool slope = nq.kind == REQ_EVAL && (nq.flags & RF_SLOPE) != 0;
-        const bool hit = slope && nq.flags == (RF_SLOPE | RF_LINE) && nchain > 0 && same_bits(nq.a, chain[0]);
+        const bool hit = slope && nq.flags == (RF_SLOPE | RF_LINE) && guessed && same_bits(nq.a, gval);
         int e;
         if (hit) {
-            // the step asked for is the first guess of the chain: its slot is the next one, the chain moves up
+            // the step asked for is the chain's guess: its slot is the next one, and the lanes, who are at
+            // work on the chain already, only need to hear how far the machine has come
             e = e_last + 1;
-#pragma unroll
-            for (int k = 0; k + 1 < PIPE_DEPTH; ++k) chain[k] = chain[k + 1];
-            --nchain;
-            E.X.tick(18, 1);
+            if (writer) lds_set(S.verified, e);
         } else {
             e = next_free;
-            nchain = 0;
+            if (slope && E.A.speculate) { if (!was_hot) G.start(M, swapped); }
+            else G.ph = Predictor::P_STOP;
+            pipe_post(S, ++seq, nq.kind, nq.flags, e, nq.a, nq.b, G, writer);
         }
-        // (a guessed step: the lanes are at work on the chain already and hear of it once, with the chain's new end)
-        if (!hit) pipe_post(S, ++seq, nq.kind, nq.flags, e, nchain, nq.a, nq.b, chain, writer);
         if (E.tr != nullptr) {
             if ((nq.flags & RF_TR_FIRST) && nq.tr_tag != TR_NONE) E.trace(nq.tr_tag, nq.tr_a, nq.tr_b, nq.tr_c);
             if (nq.pre_tag != TR_NONE) E.trace(nq.pre_tag, nq.pre_a, nq.pre_b, nq.pre_c);
@@ -524,47 +573,39 @@ __device__ __forceinline__ void pipe_control(PipeEnv& E, PipeShared& S, int maxi
         E.X.tick(8, ts1 - ts0);
         if (nq.kind == REQ_DONE) break;
         E.X.e = e;
+        chain_live = false;
         [[maybe_unused]] const int tkind = nq.kind == REQ_GRAD ? 2 : !slope ? 0 : (nq.flags & (RF_PRE_START | RF_PRE_UPDATE)) ? 3 : 1;
         switch (nq.kind) {
         case REQ_EVAL:
-            if (nq.flags & (RF_PRE_START | RF_PRE_UPDATE)) E.X.barrier(S);   // the lanes' publish_xi
+            if (nq.flags & (RF_PRE_START | RF_PRE_UPDATE)) pipe_ctrl_barrier(E.X, S, writer);   // the lanes' publish_xi
             if (slope) {
-                // lengthen the chain while the lanes work, and tell them (a second post of the same
-                // request: its evaluation is slot E.X.e, which they have or are about to publish)
-                if (!hit) { if (was_hot) G = Gn; else G.start(M, swapped); }
-                const int had = nchain;
-                if (E.A.speculate) {
-#pragma unroll
-                    for (int k = 0; k < PIPE_DEPTH; ++k) {
-                        double c;
-                        if (nchain == k && G.next(c)) { chain[k] = c; nchain = k + 1; }
-                    }
-                }
-                if (hit || nchain != had) pipe_post(S, ++seq, REQ_EVAL, RF_SLOPE | RF_LINE, E.X.e, nchain, nq.a, nq.b, chain, writer);
-                E.X.tick(19, nchain - had);
-                double v[2] = {0.0, 0.0};
+                // a fresh step takes the lanes an evaluation: the collector goes there now
+                if (!hit) pipe_command(S, E.X.e, 2, E.X.poll_delay, writer);
+                double v[2];
                 const long long tw0 = coop_clock();
-                // a guessed step is under way or done; a fresh one takes the lanes an evaluation
-                E.X.sweep<2, 0>(E.X.e, v, hit ? 0 : E.X.poll_delay, hit && fetched ? S.pre : nullptr);
-                if (hit) { E.X.tick(1, coop_clock() - tw0); E.X.tick(16, 1); }
-                else { E.X.tick(3, coop_clock() - tw0); E.X.tick(17, 1); }
+                pipe_result(S, E.X.e, v, E.X.dead);
+                if (hit) { E.X.tick(20, coop_clock() - tw0); E.X.tick(16, 1); }
+                else { E.X.tick(21, coop_clock() - tw0); E.X.tick(17, 1); }
                 r0 = v[0]; r1 = v[1];
                 e_last = E.X.e;
+                chain_live = true;
                 next_free = e_last + PIPE_DEPTH + 1;
                 E.trace(TR_FD, nq.a, r0, r1);
             } else {
-                double v[1] = {0.0};
-                E.X.sweep<1, 0>(E.X.e, v, E.X.poll_delay);
+                double v[1];
+                pipe_command(S, E.X.e, 1, E.X.poll_delay, writer);
+                pipe_result(S, E.X.e, v, E.X.dead);
                 r0 = v[0];
                 next_free = E.X.e + 1;
                 if (nq.flags & RF_LINE) E.trace(TR_F, nq.a, r0, 0.0);
             }
             break;
         case REQ_GRAD:
-            E.X.barrier(S);   // gradient_to_xi: partials -> per-variable sums
+            pipe_ctrl_barrier(E.X, S, writer);   // gradient_to_xi: partials -> per-variable sums
             if (nq.flags & RF_POST_REDUCE) {
-                double v[3] = {0.0, 0.0, 0.0};
-                E.X.sweep<3, 1>(E.X.e, v, E.X.poll_delay);
+                double v[3];
+                pipe_command(S, E.X.e, 3, E.X.poll_delay, writer);
+                pipe_result(S, E.X.e, v, E.X.dead);
                 ++E.X.e;
                 r1 = v[0]; r2 = v[1]; r0 = v[2];   // (test, gg, dgg) <- (max, sum a, sum b)
             }
@@ -579,21 +620,58 @@ __device__ __forceinline__ void pipe_control(PipeEnv& E, PipeShared& S, int maxi
         else if (tkind == 2) { E.X.tick(14, coop_clock() - ts1); E.X.tick(24, 1); }
         else { E.X.tick(15, coop_clock() - ts1); E.X.tick(25, 1); }
     }
-    // the result, for everybody
     if (writer) {
+        lds_set(S.cmd, PIPE_QUIT);
+        // the result, for everybody
         S.status = M.status(); S.rolled_back = M.rolled_back ? 1 : 0; S.iter = M.iter;
         S.nfeval = M.nfeval; S.ngeval = M.ngeval; S.fret = M.fret; S.finit = M.finit;
     }
 }
 
-// ---- lane waves ----------------------------------------------------------------------------
+// ---- wave 1: the exchange ----------------------------------------------------------------
+__device__ __forceinline__ void pipe_collector(PipeSync& X, PipeShared& S) {
+    int mine = -1;   // the command last acted on
+    const bool writer = (X.tid & 63) == 0;
+    for (;;) {
+        int c;
+        while ((c = lds_int(S.cmd)) == mine) __builtin_amdgcn_s_sleep(1);
+        if (c == PIPE_QUIT) break;
+        mine = c;
+        const int ex = c >> 2, n = c & 3;
+        const int delay = lds_int(S.cmd_delay);
+        double v[3] = {0.0, 0.0, 0.0};
+        bool got;
+        const long long t0 = coop_clock();
+        if (n == 2) { double w[2]; got = X.sweep<2, 0>(ex, w, delay, S.cmd, c, S.pub); v[0] = w[0]; v[1] = w[1]; }
+        else if (n == 3) { got = X.sweep<3, 1>(ex, v, delay, S.cmd, c, S.pub); }
+        else { double w[1]; got = X.sweep<1, 0>(ex, w, delay, S.cmd, c, S.pub); v[0] = w[0]; }
+        if (!got) { X.tick(4, 1); continue; }
+        X.tick(1, coop_clock() - t0);
+        if (writer) {
+            if (X.dead) lds_set(S.dead, 1);
+            lds_f64_set(S.res[0], v[0]); lds_f64_set(S.res[1], v[1]); lds_f64_set(S.res[2], v[2]);
+            lds_set(S.res_slot, ex);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X.rearm_behind(ex);
+    }
+}
+
+// ---- waves 2, 3: the factors and variables -------------------------------------------------
+// what the chain guesses for slot z (both lane waves know; one writes it down for the stepper)
+__device__ __forceinline__ void pipe_record(PipeShared& S, int z, bool valid, double val, bool writer) {
+    if (writer) {
+        lds_f64_set(S.rec_val[z & (PIPE_RECS - 1)], val);
+        lds_set(S.rec_slot[z & (PIPE_RECS - 1)], 2 * z + (valid ? 1 : 0));
+    }
+}
 __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
     int seen = 0;      // last post acted on
-    int done = -1;     // highest slot this wave has published
+    const bool recorder = E.tid == 64 * PIPE_CTRL;
     for (;;) {
         int s;
         const long long tm0 = coop_clock();
-        while ((s = lds_seq(S)) == seen) __builtin_amdgcn_s_sleep(1);
+        while ((s = lds_int(S.seq)) == seen) __builtin_amdgcn_s_sleep(1);
         E.X.tick(9, coop_clock() - tm0);
         seen = s;
         asm volatile("" ::: "memory");
@@ -601,7 +679,6 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
         const PipeMail* m = &mm;
         const int kind = __builtin_amdgcn_readfirstlane(m->kind);
         const int flags = __builtin_amdgcn_readfirstlane(m->flags);
-        const int ng = __builtin_amdgcn_readfirstlane(m->ng);
         E.X.e = __builtin_amdgcn_readfirstlane(m->e);
         const double qa = uniform(m->a);
         if (kind == REQ_DONE) break;
@@ -610,41 +687,57 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
             if (flags & RF_PRE_UPDATE) E.cg_update(uniform(m->b));
             if (flags & RF_PRE_BEGIN) E.line_begin();
             if (flags & RF_SLOPE) {
+                const long long tl0 = coop_clock();
                 const int e0 = E.X.e;
-                if (e0 > done) {
+                // the chain of guesses behind this step: the one for a slot is written down before the slot
+                // before it is evaluated (for the first: while this step's sums travel), so the stepper
+                // finds it when it has those sums
+                Predictor G;
+                G.ph = __builtin_amdgcn_readfirstlane(m->g_ph);
+                G.need_first = __builtin_amdgcn_readfirstlane(m->g_need_first) != 0;
+                G.a = uniform(m->g_a); G.b = uniform(m->g_b); G.x = uniform(m->g_x); G.dx = uniform(m->g_dx);
+                G.ax = uniform(m->g_ax); G.bx = uniform(m->g_bx); G.cx = uniform(m->g_cx);
+                {
                     double v[2];
                     const long long te0 = coop_clock();
                     E.eval_line<true>(qa, v[0], v[1]);
                     const long long te1 = coop_clock();
-                    E.X.publish<2, 0>(e0, v);
+                    E.X.publish<2, 0>(e0, v, S.pub);
                     E.X.tick(0, te1 - te0); E.X.tick(2, coop_clock() - te1); E.X.tick(10, 1);
-                    done = e0;
+                    E.X.tick(30, coop_clock() - tl0); E.X.tick(31, 1);
                 }
-                // guesses at the following steps, until the control wave has something new to say
-#pragma unroll
-                for (int j = 0; j < PIPE_DEPTH; ++j) {
-                    if (j >= ng || lds_seq(S) != seen) break;
-                    const int ge = e0 + 1 + j;
-                    if (ge <= done) continue;
+                // (written down long before the stepper can have this step's sums: they are still on their way)
+                double cval = 0.0;
+                bool cvalid = G.next(cval);
+                int cz = e0 + 1;           // (cvalid, cval): the guess for slot cz, not evaluated yet
+                pipe_record(S, cz, cvalid, cval, recorder);
+                // guesses, at most DEPTH slots ahead of what the machine has asked for, until the stepper
+                // has something new to say or the chain ends
+                while (cvalid && lds_int(S.seq) == seen) {
+                    const int ver = lds_int(S.verified);
+                    if (cz > (ver > e0 ? ver : e0) + PIPE_DEPTH) { __builtin_amdgcn_s_sleep(1); continue; }
+                    const double ca = cval;
+                    const int z = cz;
+                    cvalid = G.next(cval);
+                    cz = z + 1;
+                    pipe_record(S, cz, cvalid, cval, recorder);
                     double v[2];
                     const long long te0 = coop_clock();
-                    E.eval_line<true>(uniform(m->guess[j]), v[0], v[1]);
+                    E.eval_line<true>(ca, v[0], v[1]);
                     const long long te1 = coop_clock();
-                    E.X.publish<2, 0>(ge, v);
+                    E.X.publish<2, 0>(z, v, S.pub);
                     E.X.tick(0, te1 - te0); E.X.tick(2, coop_clock() - te1); E.X.tick(11, 1);
-                    done = ge;
                 }
             } else {
                 if (flags & RF_RESTORE) E.load_base(E.L.xstart + E.f0);
                 double v[1], dummy;
                 E.eval_line<false>((flags & RF_RESTORE) ? 0.0 : qa, v[0], dummy);
-                E.X.publish<1, 0>(E.X.e, v);
-                done = E.X.e;
+                E.X.publish<1, 0>(E.X.e, v, S.pub);
             }
         } else if (kind == REQ_GRAD) {
             if (flags & RF_PRE_LINE_END) E.line_end(qa);
             E.gradient_to_xi();
-            if (flags & RF_POST_REDUCE) { E.cg_reduce_publish(uniform(m->b)); done = E.X.e - 1; }
+            if (flags & RF_POST_REDUCE) E.cg_reduce_publish(uniform(m->b));
         } else if (kind == REQ_LINE_END) {
             E.line_end(qa);
         }
@@ -654,14 +747,14 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
 template <int THREADS>
 __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView& L, const CoopArgs& A, int nwg, int wg,
                                            int maxiters, double ftol) {
-    static_assert(THREADS == PIPE_THREADS, "one control wave + three lane waves");
+    static_assert(THREADS == PIPE_THREADS, "stepper + collector + two lane waves");
     __shared__ PipeShared S;
     [[maybe_unused]] const long long tk0 = coop_clock();
     const int comp = A.comp;
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
     const int tid = (int)threadIdx.x;
-    const int gt = tid < 64 ? -1 : wg * PIPE_LANES + tid - 64;
+    const int gt = tid < 64 * PIPE_CTRL ? -1 : wg * PIPE_LANES + tid - 64 * PIPE_CTRL;
 
     PipeEnv E{P, L, A, S, n, m, f0, c0, gt, tid,
               PipeSync{(PipeState*)A.st, tid, nwg, wg, PIPE_LANES / 64, A.poll_delay, 0, -1, false
@@ -676,10 +769,13 @@ __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView&
         const double2 o = P.obs[E.fid];
         E.ox = o.x; E.oy = o.y;
     }
-    if (tid == 0) { S.seq = 0; S.dead = 0; }
+    if (tid == 0) { S.seq = 0; S.cmd = -1; S.cmd_delay = 0; S.res_slot = -1; S.bar_done = -1; S.dead = 0; S.verified = -1; }
+    if (tid < PIPE_RECS) S.rec_slot[tid] = -1;
+    if (tid < PIPE_LANES / 64) S.pub[tid] = -1;
     E.init_vectors();
     __syncthreads();
-    if (tid < 64) pipe_control(E, S, maxiters, ftol);
+    if (tid < 64) pipe_stepper(E, S, maxiters, ftol);
+    else if (tid < 128) pipe_collector(E.X, S);
     else pipe_lanes(E, S);
     __syncthreads();
     const bool restore = S.rolled_back != 0;
@@ -689,13 +785,12 @@ __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView&
         L.fret[comp] = S.fret; L.delta[comp] = S.fret - S.finit; L.iters[comp] = S.iter;
         L.status[comp] = S.status; L.nfeval[comp] = S.nfeval; L.ngeval[comp] = S.ngeval;
         if (L.trace_n) L.trace_n[comp] = E.trn;
-#ifdef RDIS_COOP_TIMING
-        E.X.tm[7] = coop_clock() - tk0;
-        if (A.timing) for (int i = 0; i < COOP_TM; ++i) if (!pipe_lane_slot(i)) A.timing[i] = E.X.tm[i];
-#endif
     }
 #ifdef RDIS_COOP_TIMING
-    if (wg == 0 && tid == 64 && A.timing) for (int i = 0; i < COOP_TM; ++i) if (pipe_lane_slot(i)) A.timing[i] = E.X.tm[i];
+    if (wg == 0 && (tid & 63) == 0 && tid < 192 && A.timing) {
+        if (tid == 0) E.X.tm[7] = coop_clock() - tk0;
+        for (int i = 0; i < COOP_TM; ++i) if (pipe_slot_owner(i) == (tid >> 6)) A.timing[i] = E.X.tm[i];
+    }
 #endif
 }
 
@@ -718,7 +813,7 @@ __global__ void __launch_bounds__(256) pipe_arm_kernel(const CoopGroup* __restri
     const int entries = G.nwg * (PIPE_LANES / 64);
     for (int t = threadIdx.x; t < PIPE_NBUF * COOP_KP * entries; t += blockDim.x) {
         const int k = t % COOP_KP, e = (t / COOP_KP) % entries, b = t / (COOP_KP * entries);
-        st->granule[b][e][k] = ~0ull;
+        st->granule[k >> 1][b][e][k & 1] = ~0ull;
     }
     if (threadIdx.x == 0) st->abort_flag = 0u;
 }

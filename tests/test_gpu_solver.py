@@ -875,3 +875,49 @@ def test_large_components_packed_into_one_cooperative_launch(gctx):
     assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb)
     assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.nfeval, rb.nfeval) and np.all((ra.status & 0xFF) != 5)
     assert np.all(ra.delta < 0)
+
+
+def test_pipelined_groups_give_the_bits_of_the_plain_cooperative_solver(gctx):
+    """solver_pipe.hpp (control logic and exchange on waves of their own, guesses at the following trial
+    steps evaluated ahead) against solver_coop.hpp: the sums are formed entry by entry in the same order
+    and the control logic never sees a guess, so values, call counts and the whole trace are the same
+    bits -- with speculation on or off, for one group (full ladybug; a sub-function with constants)
+    and for several groups side by side in one launch"""
+    lb = P.load_bal()
+    sub = P.load_bal(ncams=49, npts=500)
+    # (few cameras: both layouts then have a wave for every variable fed by many partials, whose
+    # sums are the one place where the order depends on how many waves a group has, DESIGN.md 3.2)
+    syn = P.make_synthetic_ba(5, 3, 900, obs_per_pt=3)
+    whole = lambda pp: (np.array([0, pp.nvars]), np.arange(pp.nvars, dtype=np.int64), np.array([0, pp.nfac]), np.arange(pp.nfac, dtype=np.int64))
+    # the first 441 variables (the cameras) of the sub-problem held constant: only points are free
+    cams_const = (np.array([0, sub.nvars - 441]), np.arange(441, sub.nvars, dtype=np.int64), np.array([0, sub.nfac]), np.arange(sub.nfac, dtype=np.int64))
+    cases = (("ladybug", lb, whole(lb), {}, 25),
+             ("cameras constant", sub, cams_const, {"coop_min_factors": 1000, "coop_max_components": 4}, 6),
+             ("five groups", syn, (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id), {"coop_min_factors": 1000}, 10))
+    for name, pp, comps, opts, iters in cases:
+        g = capi.Problem(gctx, pp)
+        out = {}
+        for label, extra in (("plain", {"coop_pipeline": 0}), ("pipelined", {"coop_pipeline": 1}), ("no guesses", {"coop_pipeline": 1, "coop_speculate": 0})):
+            g.set_x(pp.x0)
+            plan = capi.Plan(g, *comps)
+            for k, v in {**opts, **extra}.items():
+                plan.set_option(k, v)
+            plan.set_option("trace_records", 4096)
+            plan.set_option("dump_iters", iters)
+            plan.set_start(None)
+            plan.solve(iters, 3e-8)
+            r = plan.fetch()
+            ncomp = len(comps[0]) - 1
+            out[label] = (r, g.get_x(), [plan.get_trace(c, 4096) for c in range(ncomp)], plan.last_kernel_ms()[1])
+            assert np.all((r.status & 0xFF) != 7), (name, label)      # no exchange gave up
+            plan.close()
+        ra, xa, ta, na = out["plain"]
+        assert np.all(ra.delta <= 0) and np.all(ra.nfeval > 20), name
+        for label in ("pipelined", "no guesses"):
+            rb, xb, tb, nb = out[label]
+            assert na == nb == 1, (name, label)
+            assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (name, label)
+            assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.status, rb.status), (name, label)
+            assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (name, label)
+            for (tra, ca), (trb, cb) in zip(ta, tb):
+                assert ca == cb and np.array_equal(tra[:min(ca, 4096)], trb[:min(cb, 4096)]), (name, label)

@@ -23,10 +23,14 @@ print("%s kernel %.3f ms (best of 7), fret %.6f nfeval %d ngeval %d status %d ->
 tm = plan.debug_counters()
 if tm[7] > 0:
     nh, nm = max(int(tm[16]), 1), max(int(tm[17]), 1)
-    print("   control: sweeps %d polls %d | value+slope: %d guessed (sweep %.0f cycles), %d fresh (sweep %.0f) | step+post %.0f per sweep | guesses posted %d held %d" % (
-        tm[5], tm[6], tm[16], tm[1] / nh, tm[17], tm[3] / nm, tm[8] / max(int(tm[5]), 1), tm[19], tm[18]))
+    print("   stepper: value+slope steps %d guessed (waits %.0f cycles for the sums), %d fresh (waits %.0f) | step+post %.0f cycles | guesses posted %d" % (
+        tm[16], tm[20] / nh, tm[17], tm[21] / nm, tm[8] / max(int(tm[16] + tm[17] + tm[22] + tm[24]), 1), tm[19]))
+    names = ["value", "value+slope", "gradient", "line start"]
+    print("   stepper, cycles serving a request after its post: " + "  ".join("%s %d x %.0f" % (nm_, tm[22 + i], tm[12 + i] / max(int(tm[22 + i]), 1)) for i, nm_ in enumerate(names)))
+    print("   collector: %d sweeps completed (%.0f cycles each, %d polls in all), %d given up" % (tm[5], tm[1] / max(int(tm[5]), 1), tm[6], tm[4]))
     ne = max(int(tm[10] + tm[11]), 1)
     print("   lanes: %d requests + %d guesses evaluated: arithmetic %.0f, reduce+publish %.0f cycles each; waiting for requests %d cycles of %d" % (
         tm[10], tm[11], tm[0] / ne, tm[2] / ne, tm[9], tm[7]))
-    names = ["value", "value+slope", "gradient", "line start"]
-    print("   control, cycles serving a request: " + "  ".join("%s %d x %.0f" % (nm, tm[22 + i], tm[12 + i] / max(int(tm[22 + i]), 1)) for i, nm in enumerate(names)))
+    print("   collector: waited %d times for its own lanes (%.0f cycles each); polling memory %.0f, final reduction %.0f cycles per sweep" % (
+        tm[27], tm[26] / max(int(tm[27]), 1), tm[28] / max(int(tm[5]), 1), tm[29] / max(int(tm[5]), 1)))
+    print("   lanes: request seen -> published %.0f cycles (%d)" % (tm[30] / max(int(tm[31]), 1), tm[31]))
