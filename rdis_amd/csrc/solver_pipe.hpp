@@ -75,6 +75,8 @@ struct alignas(16) PipeMail {   // 96 bytes: six 16-byte LDS accesses
     double g_a, g_b, g_x, g_dx, g_ax, g_bx, g_cx;
     int g_need_first, pad;
 };
+constexpr int PIPE_RES = 4;
+static_assert(PIPE_RES > PIPE_DEPTH, "result ring");
 constexpr int PIPE_RECS = 8;    // guess records the stepper may still want: slots verified + 1 .. verified + DEPTH + 1
 struct PipeShared {
     PipeMail mail[PIPE_MAILS];
@@ -85,9 +87,10 @@ struct PipeShared {
     double rec_val[PIPE_RECS];
     // stepper -> collector: (slot << 2 | number of values), slots only ever increase; sleep before the first look
     int cmd, cmd_delay;
-    // collector -> stepper: the sums of slot res_slot
-    int res_slot;
-    double res[3];
+    // collector -> stepper: the sums of slot res_slot[slot % 4] (the collector follows a chain of guesses
+    // on its own and can be up to DEPTH slots ahead of what the stepper has consumed)
+    int res_slot[PIPE_RES];
+    double res[PIPE_RES][3];
     int bar_done;                // the last grid-wide barrier slot that is complete (stepper -> lanes)
     int pub[PIPE_LANES / 64];    // lanes -> collector: the last slot each lane wave of this workgroup has published
     int dead;                    // an exchange gave up
@@ -168,7 +171,7 @@ struct PipeSync {
         unsigned spins = 0;
         bool ok = !dead;
         const int per = (nent + 63) >> 6;
-        constexpr int CH = N <= 2 ? 8 : 4;
+        constexpr int CH = 8;
         const long long tq0 = coop_clock();
         {
             bool waited = false;
@@ -380,7 +383,7 @@ struct PipeEnv {
         }
         X.barrier(S);
         const int* vp = L.v2s_ptr + f0;
-        if (lv.li >= 0) lv.xi = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]);
+        if (lv.li >= 0) lv.xi = run_sum_ordered<true, 16>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         if (wv.li >= 0) wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
     }
     __device__ void publish_xi() {
@@ -490,10 +493,10 @@ __device__ __forceinline__ void pipe_command(PipeShared& S, int ex, int n, int d
 // ... and waits for its sums
 template <int N>
 __device__ __forceinline__ void pipe_result(PipeShared& S, int ex, double (&v)[N], bool& dead) {
-    while (lds_int(S.res_slot) != ex) __builtin_amdgcn_s_sleep(1);
+    while (lds_int(S.res_slot[ex & (PIPE_RES - 1)]) != ex) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = uniform(lds_f64_get(S.res[k]));
+    for (int k = 0; k < N; ++k) v[k] = uniform(lds_f64_get(S.res[ex & (PIPE_RES - 1)][k]));
     if (lds_int(S.dead) != 0) dead = true;
 }
 __device__ __forceinline__ void pipe_ctrl_barrier(PipeSync& X, PipeShared& S, bool writer) {
@@ -519,7 +522,7 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
         const long long ts0 = coop_clock();
         // What do the lanes guess for the slot after the last evaluation?  (They wrote it down before
         // they evaluated that one.)  It is probably what the machine will ask for next: the collector
-        // gathers its sums while the machine is stepped.
+        // has gone on to that slot by itself and gathers its sums while the machine is stepped.
         bool guessed = false;
         double gval = 0.0;
         if (chain_live) {
@@ -528,7 +531,6 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
             while (((rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)])) >> 1) != z) __builtin_amdgcn_s_sleep(1);
             guessed = (rec & 1) != 0;
             gval = uniform(lds_f64_get(S.rec_val[z & (PIPE_RECS - 1)]));
-            if (guessed) pipe_command(S, z, 2, E.X.poll_delay, writer);
         }
         Request nq;
         Predictor G;
@@ -629,31 +631,54 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
 }
 
 // ---- wave 1: the exchange ----------------------------------------------------------------
+// Sweeps the slot the stepper names; after a (value, slope) slot it goes on to the next one by
+// itself as long as the lanes' chain has a guess there -- the stepper finds the sums of a guessed
+// step waiting -- until the stepper names another slot.
 __device__ __forceinline__ void pipe_collector(PipeSync& X, PipeShared& S) {
     int mine = -1;   // the command last acted on
+    int next = -1;   // the slot to go on to without being told
     const bool writer = (X.tid & 63) == 0;
     for (;;) {
-        int c;
-        while ((c = lds_int(S.cmd)) == mine) __builtin_amdgcn_s_sleep(1);
-        if (c == PIPE_QUIT) break;
-        mine = c;
-        const int ex = c >> 2, n = c & 3;
+        const int c = lds_int(S.cmd);
+        int ex, n;
+        if (c != mine) {
+            if (c == PIPE_QUIT) break;
+            mine = c;
+            ex = c >> 2; n = c & 3;
+        } else if (next >= 0) {
+            ex = next; n = 2;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        next = -1;
         const int delay = lds_int(S.cmd_delay);
         double v[3] = {0.0, 0.0, 0.0};
         bool got;
         const long long t0 = coop_clock();
-        if (n == 2) { double w[2]; got = X.sweep<2, 0>(ex, w, delay, S.cmd, c, S.pub); v[0] = w[0]; v[1] = w[1]; }
-        else if (n == 3) { got = X.sweep<3, 1>(ex, v, delay, S.cmd, c, S.pub); }
-        else { double w[1]; got = X.sweep<1, 0>(ex, w, delay, S.cmd, c, S.pub); v[0] = w[0]; }
+        if (n == 2) { double w[2]; got = X.sweep<2, 0>(ex, w, delay, S.cmd, mine, S.pub); v[0] = w[0]; v[1] = w[1]; }
+        else if (n == 3) { got = X.sweep<3, 1>(ex, v, delay, S.cmd, mine, S.pub); }
+        else { double w[1]; got = X.sweep<1, 0>(ex, w, delay, S.cmd, mine, S.pub); v[0] = w[0]; }
         if (!got) { X.tick(4, 1); continue; }
         X.tick(1, coop_clock() - t0);
         if (writer) {
             if (X.dead) lds_set(S.dead, 1);
-            lds_f64_set(S.res[0], v[0]); lds_f64_set(S.res[1], v[1]); lds_f64_set(S.res[2], v[2]);
-            lds_set(S.res_slot, ex);
+            double* r = S.res[ex & (PIPE_RES - 1)];
+            lds_f64_set(r[0], v[0]); lds_f64_set(r[1], v[1]); lds_f64_set(r[2], v[2]);
+            lds_set(S.res_slot[ex & (PIPE_RES - 1)], ex);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         X.rearm_behind(ex);
+        if (n == 2 && !X.dead) {
+            // does the chain go on?  (the lanes write a slot's guess down before they evaluate the slot before it)
+            const int z = ex + 1;
+            for (;;) {
+                const int rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)]);
+                if ((rec >> 1) == z) { if (rec & 1) next = z; break; }
+                if (lds_int(S.cmd) != mine) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
     }
 }
 
@@ -769,8 +794,9 @@ __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView&
         const double2 o = P.obs[E.fid];
         E.ox = o.x; E.oy = o.y;
     }
-    if (tid == 0) { S.seq = 0; S.cmd = -1; S.cmd_delay = 0; S.res_slot = -1; S.bar_done = -1; S.dead = 0; S.verified = -1; }
+    if (tid == 0) { S.seq = 0; S.cmd = -1; S.cmd_delay = 0; S.bar_done = -1; S.dead = 0; S.verified = -1; }
     if (tid < PIPE_RECS) S.rec_slot[tid] = -1;
+    if (tid < PIPE_RES) S.res_slot[tid] = -1;
     if (tid < PIPE_LANES / 64) S.pub[tid] = -1;
     E.init_vectors();
     __syncthreads();
