@@ -399,7 +399,11 @@ def main():
                          # (factor arithmetic of one wave + wave reduction + one store->load hop between compute
                          # units + sweep + one step of the control logic, tools/microbench)
                          "latency": ({"evals": float(nfe.sum()) / max(a.steps, 1), "us_per_eval": kms / max(a.steps, 1) * 1e3 / max(float(nfe.sum()) / max(a.steps, 1), 1.0),
-                                      "us_floor": 2.6, "floor": "2170 cycles arithmetic + 360 reduce + ~900 one hop + ~500 sweep + ~2000 control step at 2.4 GHz"}
+                                      "us_floor": 1.15, "us_chain": 2.6,
+                                      "floor": ("pipelined solver (solver_pipe.hpp): a trial step that was guessed costs the slowest of three overlapping sides "
+                                                "-- a lane wave's arithmetic + reduction 2300 + 400 cycles, the collector's sweep, a step of the control logic -- "
+                                                "us_floor is the lanes' side at 2.4 GHz; a step that was not guessed pays the whole chain, us_chain "
+                                                "(arithmetic + reduce + one store->load hop between compute units + sweep + control step)")}
                                      if pp.ncomp == 1 else None)},
         }
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only

@@ -1,7 +1,7 @@
 """exploratory: cooperative solver on full ladybug -- kernel time, per-evaluation cost, speculation
 hit counts (timing build), and the replay check (bit-identical decisions against the oracle)"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rdis_amd import problems as P, capi
 from oracle import oracle as O

@@ -16,7 +16,7 @@ for w in ladybug-full synthetic-S synthetic-L; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o strong -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_strong.json 2>> $D/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kernels -- python tools/profile_kernels.py > $D/kernels.txt 2>> $D/err.txt
-python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_coop_
+python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_pipe_
 python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_wg_kernel
 python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_wg_kernel
 cp profiles/traffic.json $D/
