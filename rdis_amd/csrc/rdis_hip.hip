@@ -1212,7 +1212,13 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     // second stream and fills the CUs the few workgroups of a cooperative solve leave idle.  The
     // cooperative kernels are enqueued first, so their workgroups are resident before the batch arrives.
     // (not next to a streaming solve: that grid takes every CU and waits for all of its workgroups)
-    const bool overlap = L->overlap_batch && !L->h_rest.empty() && !L->coop.empty() && L->stream.empty();
+    // (and only when the cooperative launches leave half of the device free: their workgroups must all be
+    // resident and take a compute unit each; were the batch to arrive first on a full device, they would
+    // wait for it -- serialised, and spinning meanwhile -- instead of running beside it)
+    int coop_wg_max = 0;
+    for (const CoopLaunch& cl : L->coop_launches) coop_wg_max = std::max(coop_wg_max, cl.total_wg);
+    const bool overlap = L->overlap_batch && !L->h_rest.empty() && !L->coop.empty() && L->stream.empty() &&
+                         2 * coop_wg_max <= c->num_cus;
     hipStream_t bs = c->stream;
     if (overlap) {
         if (!c->aux) {

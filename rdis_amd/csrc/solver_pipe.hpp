@@ -368,6 +368,7 @@ struct PipeEnv {
         load_base(L.xstart + f0);
     }
     __device__ void gradient_to_xi() {
+        const long long tg0 = coop_clock();
         if (has_fac) {
             double v[12], g[12];
 #pragma unroll
@@ -381,10 +382,13 @@ struct PipeEnv {
             for (int k = 0; k < 12; ++k)
                 if (t[k] >= 0) store_f64<true>(L.gfac + t[k], g[k]);
         }
+        const long long tg1 = coop_clock();
         X.barrier(S);
+        const long long tg2 = coop_clock();
         const int* vp = L.v2s_ptr + f0;
         if (lv.li >= 0) lv.xi = run_sum_ordered<true, 16>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         if (wv.li >= 0) wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
+        X.tick(3, tg1 - tg0); X.tick(18, tg2 - tg1); X.tick(30, coop_clock() - tg2); X.tick(31, 1);
     }
     __device__ void publish_xi() {
         if (lv.li >= 0) store_f64<true>(A.xi_glob + lv.li, lv.xi);
@@ -396,15 +400,32 @@ struct PipeEnv {
         { const double t = -wv.xi; wv.g = t; wv.h = t; wv.xi = t; }
         publish_xi();
     }
-    __device__ void line_begin() {
+    // FROM_GH: the new direction is formed here, from the -gradient the owners published with their
+    // Polak-Ribiere sums and the previous direction, with the owner's own operations (cg_update:
+    // h_new = g_new + gamma h): same bits, and no exchange between the direction update and the line's
+    // first trial
+    template <bool FROM_GH>
+    __device__ void line_begin(double gam) {
         if (has_fac) {
             const int* sl = A.slot_li + 12ll * gt;
             int li[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) li[k] = sl[k];
             double d[12];
+            if constexpr (FROM_GH) {
+                // (the previous h of a variable is the previous direction: what dirv still holds)
+                const double* gb = L.ws + 5ll * f0;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) d[k] = load_f64<true>(A.xi_glob + (li[k] >= 0 ? li[k] : 0));
+                for (int k = 0; k < 12; ++k) d[k] = load_f64<true>(gb + (li[k] >= 0 ? li[k] : 0));
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) d[k] = d[k] + gam * dirv[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) d[k] = load_f64<true>(A.xi_glob + (li[k] >= 0 ? li[k] : 0));
+            }
 #pragma unroll
             for (int k = 0; k < 12; ++k) dirv[k] = li[k] >= 0 ? d[k] : 0.0;
         }
@@ -424,32 +445,38 @@ struct PipeEnv {
             for (int k = 0; k < 12; ++k) { const double t = dirv[k] * amin; base[k] = base[k] + t; }
         }
     }
-    // the lanes' share of the Polak-Ribiere sums (nrc :655-672); the control wave collects them
+    // the lanes' share of the Polak-Ribiere sums (nrc :655-672); the collector gathers them
     __device__ void cg_reduce_publish(double fp) {
-#pragma clang fp contract(off)
-        const double den = fmax(fabs(fp), 1.0);
-        double a = 0.0, b = 0.0, t = 0.0;
-        if (lv.li >= 0) {
-            t = fabs(lv.xi) * fmax(fabs(lv.p), 1.0) / den;
-            a = lv.g * lv.g;
-            b = (lv.xi + lv.g) * lv.xi;
+        // first what the factor lanes will form the next direction from (line_begin<true>): g_new =
+        // -gradient of every variable; the publication below waits for these stores
+        {
+            double* gb = L.ws + 5ll * f0;
+            if (lv.li >= 0) store_f64<true>(gb + lv.li, -lv.xi);
+            if (wv.li >= 0 && (tid & 63) == 0) store_f64<true>(gb + wv.li, -wv.xi);
         }
-        if (wv.li >= 0 && (tid & 63) == 0) {
-            t = fmax(t, fabs(wv.xi) * fmax(fabs(wv.p), 1.0) / den);
-            a = a + wv.g * wv.g;
-            b = b + (wv.xi + wv.g) * wv.xi;
+        double a = 0.0, b = 0.0, t = 0.0;
+        {
+#pragma clang fp contract(off)
+            const double den = fmax(fabs(fp), 1.0);
+            if (lv.li >= 0) {
+                t = fabs(lv.xi) * fmax(fabs(lv.p), 1.0) / den;
+                a = lv.g * lv.g;
+                b = (lv.xi + lv.g) * lv.xi;
+            }
+            if (wv.li >= 0 && (tid & 63) == 0) {
+                t = fmax(t, fabs(wv.xi) * fmax(fabs(wv.p), 1.0) / den);
+                a = a + wv.g * wv.g;
+                b = b + (wv.xi + wv.g) * wv.xi;
+            }
         }
         double v[3] = {a, b, t};
         X.publish<3, 1>(X.e, v, S.pub);
         ++X.e;
     }
-    __device__ void cg_update(double gam) {
-        {
+    __device__ void cg_update(double gam) {   // (nothing to publish: line_begin<true>)
 #pragma clang fp contract(off)
-            { const double gn = -lv.xi; const double hn = gn + gam * lv.h; lv.g = gn; lv.h = hn; lv.xi = hn; }
-            { const double gn = -wv.xi; const double hn = gn + gam * wv.h; wv.g = gn; wv.h = hn; wv.xi = hn; }
-        }
-        publish_xi();
+        { const double gn = -lv.xi; const double hn = gn + gam * lv.h; lv.g = gn; lv.h = hn; lv.xi = hn; }
+        { const double gn = -wv.xi; const double hn = gn + gam * wv.h; wv.g = gn; wv.h = hn; wv.xi = hn; }
     }
     __device__ void write_back(const VarState& V, bool restore, bool writer) {
         if (V.li >= 0 && writer) {
@@ -467,9 +494,9 @@ struct PipeEnv {
 //          19 guesses posted, 12.. cycles serving a request after its post: 12 value, 13 value+slope, 14 gradient (+ reduction),
 //          15 value+slope at the start of a line (direction update first); 22.. their counts
 // collector also: 26 cycles waiting for the own lanes' publication (27 how often), 28 polling memory, 29 final reduction
-// lanes also: 30 cycles from seeing a value+slope request to its publication (31 how often)
+// lanes also, per full gradient (31 how many): 3 partials + scatter, 18 the grid-wide barrier behind it, 30 per-variable sums
 __device__ __forceinline__ int pipe_slot_owner(int i) {   // 0 stepper, 1 collector, 2 lanes
-    return (i == 0 || i == 2 || (i >= 9 && i <= 11) || i == 30 || i == 31) ? 2 : (i == 1 || (i >= 4 && i <= 6) || (i >= 26 && i <= 29)) ? 1 : 0;
+    return (i == 0 || i == 2 || i == 3 || i == 18 || (i >= 9 && i <= 11) || i == 30 || i == 31) ? 2 : (i == 1 || (i >= 4 && i <= 6) || (i >= 26 && i <= 29)) ? 1 : 0;
 }
 
 // the stepper posts a request (lane 0 writes; LDS operations of a wave execute in order, so whoever
@@ -579,7 +606,7 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
         [[maybe_unused]] const int tkind = nq.kind == REQ_GRAD ? 2 : !slope ? 0 : (nq.flags & (RF_PRE_START | RF_PRE_UPDATE)) ? 3 : 1;
         switch (nq.kind) {
         case REQ_EVAL:
-            if (nq.flags & (RF_PRE_START | RF_PRE_UPDATE)) pipe_ctrl_barrier(E.X, S, writer);   // the lanes' publish_xi
+            if (nq.flags & RF_PRE_START) pipe_ctrl_barrier(E.X, S, writer);   // the lanes' publish_xi (a direction update needs none)
             if (slope) {
                 // a fresh step takes the lanes an evaluation: the collector goes there now
                 if (!hit) pipe_command(S, E.X.e, 2, E.X.poll_delay, writer);
@@ -710,9 +737,8 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
         if (kind == REQ_EVAL) {
             if (flags & RF_PRE_START) E.cg_start();
             if (flags & RF_PRE_UPDATE) E.cg_update(uniform(m->b));
-            if (flags & RF_PRE_BEGIN) E.line_begin();
+            if (flags & RF_PRE_BEGIN) { if (flags & RF_PRE_UPDATE) E.line_begin<true>(uniform(m->b)); else E.line_begin<false>(0.0); }
             if (flags & RF_SLOPE) {
-                const long long tl0 = coop_clock();
                 const int e0 = E.X.e;
                 // the chain of guesses behind this step: the one for a slot is written down before the slot
                 // before it is evaluated (for the first: while this step's sums travel), so the stepper
@@ -729,7 +755,7 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
                     const long long te1 = coop_clock();
                     E.X.publish<2, 0>(e0, v, S.pub);
                     E.X.tick(0, te1 - te0); E.X.tick(2, coop_clock() - te1); E.X.tick(10, 1);
-                    E.X.tick(30, coop_clock() - tl0); E.X.tick(31, 1);
+
                 }
                 // (written down long before the stepper can have this step's sums: they are still on their way)
                 double cval = 0.0;

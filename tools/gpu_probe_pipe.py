@@ -33,4 +33,4 @@ if tm[7] > 0:
         tm[10], tm[11], tm[0] / ne, tm[2] / ne, tm[9], tm[7]))
     print("   collector: waited %d times for its own lanes (%.0f cycles each); polling memory %.0f, final reduction %.0f cycles per sweep" % (
         tm[27], tm[26] / max(int(tm[27]), 1), tm[28] / max(int(tm[5]), 1), tm[29] / max(int(tm[5]), 1)))
-    print("   lanes: request seen -> published %.0f cycles (%d)" % (tm[30] / max(int(tm[31]), 1), tm[31]))
+    print("   lanes gradient: partials+scatter %.0f, barrier %.0f, sums %.0f (x%d)" % (tm[3] / max(int(tm[31]), 1), tm[18] / max(int(tm[31]), 1), tm[30] / max(int(tm[31]), 1), tm[31]))
