@@ -212,7 +212,12 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * components with at least this many factors fit the device together, each of them gets one and
  * they run side by side in one launch; 0 = off), "coop_workgroups" (cap, 0 = what fits),
  * "coop_threads" (128, 256 or 512), "coop_poll_delay" (x64 cycles between publishing and the
- * first granule sweep), "force_stream" (send large components to the streaming grid solver even
+ * first granule sweep), "coop_pipeline" (default 1: cooperative groups run with the control logic,
+ * the exchange and the factor arithmetic on waves of their own, solver_pipe.hpp, whenever every
+ * group of the plan fits that layout of 128 factor lanes per workgroup; 0 = the plain cooperative
+ * kernel; same bits either way as long as every variable fed by more than 48 partials has a wave),
+ * "coop_speculate" (default 1: the pipelined groups evaluate guesses at the following trial steps
+ * of a line search ahead of the control logic; results do not depend on it), "force_stream" (send large components to the streaming grid solver even
  * when they fit the register-resident one; large components that do not fit, and large
  * nonlinear-product components, always go there),
  * "quad_max_vars" / "quad_min_components" / "row_min_components" (bundle-adjustment components
@@ -229,7 +234,7 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * "tiny_max_blocks" (cap on the grid of the persistent tiny-component kernels, 0 = what is
  * resident; for tests),
  * "overlap_batch" (default 1: the batched launch of a plan runs on a second stream, concurrently
- * with its cooperative launches),
+ * with its cooperative launches when those take at most half of the compute units),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

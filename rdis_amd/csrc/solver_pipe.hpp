@@ -859,21 +859,23 @@ cgd_pipe_single_kernel(ProblemView P, PlanView L, CoopArgs A, int maxiters, doub
     pipe_solve<THREADS>(P, L, A, (int)gridDim.x, (int)blockIdx.x, maxiters, ftol);
 }
 
+// arms the granules the groups of a launch will use: a block per (group, buffer)
 __global__ void __launch_bounds__(256) pipe_arm_kernel(const CoopGroup* __restrict__ groups) {
-    const CoopGroup G = groups[blockIdx.x];
+    const CoopGroup G = groups[blockIdx.x / PIPE_NBUF];
+    const int b = blockIdx.x % PIPE_NBUF;
     PipeState* st = (PipeState*)G.a.st;
     const int entries = G.nwg * (PIPE_LANES / 64);
-    for (int t = threadIdx.x; t < PIPE_NBUF * COOP_KP * entries; t += blockDim.x) {
-        const int k = t % COOP_KP, e = (t / COOP_KP) % entries, b = t / (COOP_KP * entries);
+    for (int t = threadIdx.x; t < COOP_KP * entries; t += blockDim.x) {
+        const int k = t % COOP_KP, e = t / COOP_KP;
         st->granule[k >> 1][b][e][k & 1] = ~0ull;
     }
-    if (threadIdx.x == 0) st->abort_flag = 0u;
+    if (b == 0 && threadIdx.x == 0) st->abort_flag = 0u;
 }
 
 inline int launch_pipe(hipStream_t stream, int kind, const ProblemView& P, const PlanView& V, const CoopGroup& first,
                        const CoopGroup* groups, const int* wg_group, int ngroups, int total_wg, int maxiters, double ftol) {
     if (kind != KIND_BA) return (int)hipErrorNotSupported;
-    pipe_arm_kernel<<<ngroups, 256, 0, stream>>>(groups);
+    pipe_arm_kernel<<<ngroups * PIPE_NBUF, 256, 0, stream>>>(groups);
     hipError_t e0 = hipGetLastError();
     if (e0 != hipSuccess) return (int)e0;
     ProblemView p = P;
