@@ -67,13 +67,14 @@ struct PipeState {
 };
 static_assert(sizeof(PipeState) <= sizeof(CoopState), "PipeState must fit the exchange state the host allocates");
 
-struct alignas(16) PipeMail {   // 96 bytes: six 16-byte LDS accesses
+struct alignas(16) PipeMail {   // 160 bytes: ten 16-byte LDS accesses
     int kind, flags;
     int e;                       // exchange number of the request's first collective operation
     int g_ph;                    // with a value+slope request: the Predictor (minimizer.hpp) the lanes continue from ...
     double a, b;
     double g_a, g_b, g_x, g_dx, g_ax, g_bx, g_cx;
-    int g_need_first, pad;
+    int g_need_first, g_known;
+    double g_w, g_v, g_dw, g_dv, g_d, g_e, g_uu, pad;
 };
 constexpr int PIPE_RES = 4;
 static_assert(PIPE_RES > PIPE_DEPTH, "result ring");
@@ -506,8 +507,9 @@ __device__ __forceinline__ void pipe_post(PipeShared& S, int seq, int kind, int 
     if (writer) {
         PipeMail t;
         t.kind = kind; t.flags = flags; t.e = e; t.a = a; t.b = b;
-        t.g_ph = G.ph; t.g_need_first = G.need_first ? 1 : 0; t.pad = 0;
+        t.g_ph = G.ph; t.g_need_first = G.need_first ? 1 : 0; t.g_known = G.known ? 1 : 0; t.pad = 0.0;
         t.g_a = G.a; t.g_b = G.b; t.g_x = G.x; t.g_dx = G.dx; t.g_ax = G.ax; t.g_bx = G.bx; t.g_cx = G.cx;
+        t.g_w = G.w; t.g_v = G.v; t.g_dw = G.dw; t.g_dv = G.dv; t.g_d = G.d; t.g_e = G.e; t.g_uu = G.uu;
         S.mail[seq & (PIPE_MAILS - 1)] = t;
         asm volatile("" ::: "memory");
         lds_set(S.seq, seq);
@@ -559,14 +561,17 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
             guessed = (rec & 1) != 0;
             gval = uniform(lds_f64_get(S.rec_val[z & (PIPE_RECS - 1)]));
         }
+        asm volatile("; PIPE_STEP_BEGIN");
         Request nq;
         Predictor G;
-        G.ph = Predictor::P_STOP; G.need_first = false; G.a = G.b = G.x = G.dx = 0.0; G.ax = G.bx = G.cx = 0.0;
+        G.ph = Predictor::P_STOP; G.need_first = false; G.known = false; G.a = G.b = G.x = G.dx = 0.0; G.ax = G.bx = G.cx = 0.0;
+        G.w = G.v = G.dw = G.dv = G.d = G.e = G.uu = 0.0;
         bool was_hot;
         {
             double un, pa, pb, pc;
             int ptag;
-            was_hot = M.hot(r0, r1, un, ptag, pa, pb, pc, G);
+            Predictor unused;   // (what hot() would hand on is formed from the machine below, and only for a fresh request)
+            was_hot = M.hot(r0, r1, un, ptag, pa, pb, pc, unused);
             if (was_hot) {
                 nq = CgdMachine::req(REQ_EVAL, un, RF_SLOPE | RF_LINE);
                 nq.pre_tag = ptag; nq.pre_a = pa; nq.pre_b = pb; nq.pre_c = pc;
@@ -589,7 +594,7 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
             if (writer) lds_set(S.verified, e);
         } else {
             e = next_free;
-            if (slope && E.A.speculate) { if (!was_hot) G.start(M, swapped); }
+            if (slope && E.A.speculate) G.start(M, swapped);
             else G.ph = Predictor::P_STOP;
             pipe_post(S, ++seq, nq.kind, nq.flags, e, nq.a, nq.b, G, writer);
         }
@@ -598,6 +603,7 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
             if (nq.pre_tag != TR_NONE) E.trace(nq.pre_tag, nq.pre_a, nq.pre_b, nq.pre_c);
             if (!(nq.flags & RF_TR_FIRST) && nq.tr_tag != TR_NONE) E.trace(nq.tr_tag, nq.tr_a, nq.tr_b, nq.tr_c);
         }
+        asm volatile("; PIPE_STEP_END");
         const long long ts1 = coop_clock();
         E.X.tick(8, ts1 - ts0);
         if (nq.kind == REQ_DONE) break;
@@ -748,6 +754,9 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
                 G.need_first = __builtin_amdgcn_readfirstlane(m->g_need_first) != 0;
                 G.a = uniform(m->g_a); G.b = uniform(m->g_b); G.x = uniform(m->g_x); G.dx = uniform(m->g_dx);
                 G.ax = uniform(m->g_ax); G.bx = uniform(m->g_bx); G.cx = uniform(m->g_cx);
+                G.known = __builtin_amdgcn_readfirstlane(m->g_known) != 0;
+                G.w = uniform(m->g_w); G.v = uniform(m->g_v); G.dw = uniform(m->g_dw); G.dv = uniform(m->g_dv);
+                G.d = uniform(m->g_d); G.e = uniform(m->g_e); G.uu = uniform(m->g_uu);
                 {
                     double v[2];
                     const long long te0 = coop_clock();
