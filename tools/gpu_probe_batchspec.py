@@ -1,4 +1,4 @@
-"""exploratory: the batch solver with and without guessed trial steps (option batch_speculate) on decompositions of
+"""exploratory (needs tools/experiments/r02_batch_speculation.patch applied: option batch_speculate): the batch solver with and without guessed trial steps on decompositions of
 small and middling components: kernel time, and whether every result and call count is the same bits"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
