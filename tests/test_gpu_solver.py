@@ -891,7 +891,15 @@ def test_pipelined_groups_give_the_bits_of_the_plain_cooperative_solver(gctx):
     whole = lambda pp: (np.array([0, pp.nvars]), np.arange(pp.nvars, dtype=np.int64), np.array([0, pp.nfac]), np.arange(pp.nfac, dtype=np.int64))
     # the first 441 variables (the cameras) of the sub-problem held constant: only points are free
     cams_const = (np.array([0, sub.nvars - 441]), np.arange(441, sub.nvars, dtype=np.int64), np.array([0, sub.nfac]), np.arange(sub.nfac, dtype=np.int64))
+    # bounds that bite: every seventh variable may move 1e-4 of its size up, every eleventh down (the clamp
+    # of a trial point is part of the lanes' arithmetic in both solvers)
+    import copy
+    tight = copy.deepcopy(sub)
+    idx = np.arange(tight.nvars)
+    tight.hi = np.where(idx % 7 == 0, tight.x0 + 1e-4 * np.abs(tight.x0) + 1e-9, tight.hi)
+    tight.lo = np.where(idx % 11 == 0, tight.x0 - 1e-4 * np.abs(tight.x0) - 1e-9, tight.lo)
     cases = (("ladybug", lb, whole(lb), {}, 25),
+             ("active bounds", tight, whole(tight), {"coop_min_factors": 1000}, 8),
              ("cameras constant", sub, cams_const, {"coop_min_factors": 1000, "coop_max_components": 4}, 6),
              ("five groups", syn, (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id), {"coop_min_factors": 1000}, 10))
     for name, pp, comps, opts, iters in cases:
@@ -913,6 +921,8 @@ def test_pipelined_groups_give_the_bits_of_the_plain_cooperative_solver(gctx):
             plan.close()
         ra, xa, ta, na = out["plain"]
         assert np.all(ra.delta <= 0) and np.all(ra.nfeval > 20), name
+        if name == "active bounds":
+            assert np.sum(ra.x == tight.hi) + np.sum(ra.x == tight.lo) > 10      # ... and they do bite
         for label in ("pipelined", "no guesses"):
             rb, xb, tb, nb = out[label]
             assert na == nb == 1, (name, label)
