@@ -42,5 +42,18 @@ plan = capi.Plan(g, *comps)
 for _ in range(REPS):
     g.set_x(big.x0); plan.set_start(None); plan.solve(25, 3e-8); r = plan.fetch()
 out["cgd_group_kernel<4> %d synthetic points" % (len(comps[0]) - 1)] = (plan.last_kernel_ms()[0], int(r.nfeval.sum()))
+plan.close(); g.close()
+# the evaluation entry points in their streaming regime: 256 x (49 cameras, 7776 points) = 8.0e6 factors, 6.1e6 variables
+# (OptimizableFunction::evalFactors / computeGradient; algorithmic bytes 24 F + 8 N and 24 F + 16 N)
+import time
+huge = P.make_synthetic_ba(256, 49, 7776, obs_per_pt=4)
+g = capi.Problem(ctx, huge)
+g.set_x(huge.x0); g.eval(); g.eval_grad()
+for name, fn, nbytes in (("eval_sum_kernel (value) 8.0e6 factors", g.eval, 24 * huge.nfac + 8 * huge.nvars),
+                         ("eval_sum_kernel<grad> + gather_grad_kernel 8.0e6 factors", g.eval_grad, 24 * huge.nfac + 16 * huge.nvars)):
+    t0 = time.perf_counter()
+    for _ in range(REPS): fn()
+    dt = (time.perf_counter() - t0) / REPS
+    print("%s: %.3f ms per call (host clock, result fetched), algorithmic %.0f MB -> %.0f GB/s" % (name, dt * 1e3, nbytes / 1e6, nbytes / dt / 1e9))
 for k, (ms, nf) in out.items():
     print("%s: %.3f ms per launch (HIP events), %d f-evaluations" % (k, ms, nf))
