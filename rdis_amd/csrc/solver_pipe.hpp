@@ -67,21 +67,27 @@ struct PipeState {
 };
 static_assert(sizeof(PipeState) <= sizeof(CoopState), "PipeState must fit the exchange state the host allocates");
 
+// a request: its head (32 bytes) is posted first -- the lanes start on it at once -- and, with a
+// value+slope request, the Predictor (minimizer.hpp) they continue from follows while they evaluate
 struct alignas(16) PipeMail {   // 160 bytes: ten 16-byte LDS accesses
     int kind, flags;
     int e;                       // exchange number of the request's first collective operation
-    int g_ph;                    // with a value+slope request: the Predictor (minimizer.hpp) the lanes continue from ...
+    int pad0;
     double a, b;
+    // (second part, PipeShared::pred_seq)
     double g_a, g_b, g_x, g_dx, g_ax, g_bx, g_cx;
     int g_need_first, g_known;
-    double g_w, g_v, g_dw, g_dv, g_d, g_e, g_uu, pad;
+    double g_w, g_v, g_dw, g_dv, g_d, g_e, g_uu;
+    int g_ph, pad1;
 };
+static_assert(sizeof(PipeMail) == 160, "mail layout");
 constexpr int PIPE_RES = 4;
 static_assert(PIPE_RES > PIPE_DEPTH, "result ring");
 constexpr int PIPE_RECS = 8;    // guess records the stepper may still want: slots verified + 1 .. verified + DEPTH + 1
 struct PipeShared {
     PipeMail mail[PIPE_MAILS];
     int seq;                     // number of the latest post (mail[seq % PIPE_MAILS])
+    int pred_seq;                // ... and of the latest post whose predictor part is there too
     int verified;                // stepper -> lanes: the latest slot the machine has asked for; they stay within DEPTH of it
     // lanes -> stepper: what the chain guesses for slot z: rec_slot[z % 8] = 2 z + 1 and the step in rec_val, or 2 z = no guess
     int rec_slot[PIPE_RECS];
@@ -502,17 +508,22 @@ __device__ __forceinline__ int pipe_slot_owner(int i) {   // 0 stepper, 1 collec
 
 // the stepper posts a request (lane 0 writes; LDS operations of a wave execute in order, so whoever
 // reads the new sequence number reads the new slot)
-__device__ __forceinline__ void pipe_post(PipeShared& S, int seq, int kind, int flags, int e, double a, double b,
-                                          const Predictor& G, bool writer) {
+__device__ __forceinline__ void pipe_post(PipeShared& S, int seq, int kind, int flags, int e, double a, double b, bool writer) {
     if (writer) {
-        PipeMail t;
-        t.kind = kind; t.flags = flags; t.e = e; t.a = a; t.b = b;
-        t.g_ph = G.ph; t.g_need_first = G.need_first ? 1 : 0; t.g_known = G.known ? 1 : 0; t.pad = 0.0;
-        t.g_a = G.a; t.g_b = G.b; t.g_x = G.x; t.g_dx = G.dx; t.g_ax = G.ax; t.g_bx = G.bx; t.g_cx = G.cx;
-        t.g_w = G.w; t.g_v = G.v; t.g_dw = G.dw; t.g_dv = G.dv; t.g_d = G.d; t.g_e = G.e; t.g_uu = G.uu;
-        S.mail[seq & (PIPE_MAILS - 1)] = t;
+        PipeMail* m = &S.mail[seq & (PIPE_MAILS - 1)];
+        m->kind = kind; m->flags = flags; m->e = e; m->pad0 = 0; m->a = a; m->b = b;
         asm volatile("" ::: "memory");
         lds_set(S.seq, seq);
+    }
+}
+__device__ __forceinline__ void pipe_post_predictor(PipeShared& S, int seq, const Predictor& G, bool writer) {
+    if (writer) {
+        PipeMail* m = &S.mail[seq & (PIPE_MAILS - 1)];
+        m->g_ph = G.ph; m->g_need_first = G.need_first ? 1 : 0; m->g_known = G.known ? 1 : 0; m->pad1 = 0;
+        m->g_a = G.a; m->g_b = G.b; m->g_x = G.x; m->g_dx = G.dx; m->g_ax = G.ax; m->g_bx = G.bx; m->g_cx = G.cx;
+        m->g_w = G.w; m->g_v = G.v; m->g_dw = G.dw; m->g_dv = G.dv; m->g_d = G.d; m->g_e = G.e; m->g_uu = G.uu;
+        asm volatile("" ::: "memory");
+        lds_set(S.pred_seq, seq);
     }
 }
 // the stepper sends the collector to slot ex (n values) ...
@@ -554,10 +565,15 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
         // has gone on to that slot by itself and gathers its sums while the machine is stepped.
         bool guessed = false;
         double gval = 0.0;
+        int ahead_slot = -1;          // the collector's result words for that slot, read ahead: they travel
+        double ahead0 = 0.0, ahead1 = 0.0;   // from LDS while the machine is stepped (slot word first: sums valid if it matches)
         if (chain_live) {
             const int z = e_last + 1;
-            int rec;
-            while (((rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)])) >> 1) != z) __builtin_amdgcn_s_sleep(1);
+            int rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)]);
+            ahead_slot = lds_int(S.res_slot[z & (PIPE_RES - 1)]);
+            ahead0 = lds_f64_get(S.res[z & (PIPE_RES - 1)][0]);
+            ahead1 = lds_f64_get(S.res[z & (PIPE_RES - 1)][1]);
+            while ((rec >> 1) != z) { __builtin_amdgcn_s_sleep(1); rec = lds_int(S.rec_slot[z & (PIPE_RECS - 1)]); }
             guessed = (rec & 1) != 0;
             gval = uniform(lds_f64_get(S.rec_val[z & (PIPE_RECS - 1)]));
         }
@@ -594,9 +610,11 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
             if (writer) lds_set(S.verified, e);
         } else {
             e = next_free;
-            if (slope && E.A.speculate) G.start(M, swapped);
-            else G.ph = Predictor::P_STOP;
-            pipe_post(S, ++seq, nq.kind, nq.flags, e, nq.a, nq.b, G, writer);
+            pipe_post(S, ++seq, nq.kind, nq.flags, e, nq.a, nq.b, writer);
+            if (slope) {   // (the lanes are at work on the request; what they continue with follows)
+                if (E.A.speculate) G.start(M, swapped);
+                pipe_post_predictor(S, seq, G, writer);
+            }
         }
         if (E.tr != nullptr) {
             if ((nq.flags & RF_TR_FIRST) && nq.tr_tag != TR_NONE) E.trace(nq.tr_tag, nq.tr_a, nq.tr_b, nq.tr_c);
@@ -618,7 +636,12 @@ __device__ __forceinline__ void pipe_stepper(PipeEnv& E, PipeShared& S, int maxi
                 if (!hit) pipe_command(S, E.X.e, 2, E.X.poll_delay, writer);
                 double v[2];
                 const long long tw0 = coop_clock();
-                pipe_result(S, E.X.e, v, E.X.dead);
+                if (hit && __builtin_amdgcn_readfirstlane(ahead_slot) == E.X.e) {
+                    v[0] = uniform(ahead0); v[1] = uniform(ahead1);
+                    if (lds_int(S.dead) != 0) E.X.dead = true;
+                } else {
+                    pipe_result(S, E.X.e, v, E.X.dead);
+                }
                 if (hit) { E.X.tick(20, coop_clock() - tw0); E.X.tick(16, 1); }
                 else { E.X.tick(21, coop_clock() - tw0); E.X.tick(17, 1); }
                 r0 = v[0]; r1 = v[1];
@@ -733,8 +756,7 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
         E.X.tick(9, coop_clock() - tm0);
         seen = s;
         asm volatile("" ::: "memory");
-        const PipeMail mm = S.mail[s & (PIPE_MAILS - 1)];
-        const PipeMail* m = &mm;
+        const PipeMail* m = &S.mail[s & (PIPE_MAILS - 1)];
         const int kind = __builtin_amdgcn_readfirstlane(m->kind);
         const int flags = __builtin_amdgcn_readfirstlane(m->flags);
         E.X.e = __builtin_amdgcn_readfirstlane(m->e);
@@ -749,14 +771,6 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
                 // the chain of guesses behind this step: the one for a slot is written down before the slot
                 // before it is evaluated (for the first: while this step's sums travel), so the stepper
                 // finds it when it has those sums
-                Predictor G;
-                G.ph = __builtin_amdgcn_readfirstlane(m->g_ph);
-                G.need_first = __builtin_amdgcn_readfirstlane(m->g_need_first) != 0;
-                G.a = uniform(m->g_a); G.b = uniform(m->g_b); G.x = uniform(m->g_x); G.dx = uniform(m->g_dx);
-                G.ax = uniform(m->g_ax); G.bx = uniform(m->g_bx); G.cx = uniform(m->g_cx);
-                G.known = __builtin_amdgcn_readfirstlane(m->g_known) != 0;
-                G.w = uniform(m->g_w); G.v = uniform(m->g_v); G.dw = uniform(m->g_dw); G.dv = uniform(m->g_dv);
-                G.d = uniform(m->g_d); G.e = uniform(m->g_e); G.uu = uniform(m->g_uu);
                 {
                     double v[2];
                     const long long te0 = coop_clock();
@@ -766,6 +780,17 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
                     E.X.tick(0, te1 - te0); E.X.tick(2, coop_clock() - te1); E.X.tick(10, 1);
 
                 }
+                // the predictor has followed the request's head by now
+                while (lds_int(S.pred_seq) != seen) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                Predictor G;
+                G.ph = __builtin_amdgcn_readfirstlane(m->g_ph);
+                G.need_first = __builtin_amdgcn_readfirstlane(m->g_need_first) != 0;
+                G.a = uniform(m->g_a); G.b = uniform(m->g_b); G.x = uniform(m->g_x); G.dx = uniform(m->g_dx);
+                G.ax = uniform(m->g_ax); G.bx = uniform(m->g_bx); G.cx = uniform(m->g_cx);
+                G.known = __builtin_amdgcn_readfirstlane(m->g_known) != 0;
+                G.w = uniform(m->g_w); G.v = uniform(m->g_v); G.dw = uniform(m->g_dw); G.dv = uniform(m->g_dv);
+                G.d = uniform(m->g_d); G.e = uniform(m->g_e); G.uu = uniform(m->g_uu);
                 // (written down long before the stepper can have this step's sums: they are still on their way)
                 double cval = 0.0;
                 bool cvalid = G.next(cval);
@@ -829,7 +854,7 @@ __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView&
         const double2 o = P.obs[E.fid];
         E.ox = o.x; E.oy = o.y;
     }
-    if (tid == 0) { S.seq = 0; S.cmd = -1; S.cmd_delay = 0; S.bar_done = -1; S.dead = 0; S.verified = -1; }
+    if (tid == 0) { S.seq = 0; S.pred_seq = 0; S.cmd = -1; S.cmd_delay = 0; S.bar_done = -1; S.dead = 0; S.verified = -1; }
     if (tid < PIPE_RECS) S.rec_slot[tid] = -1;
     if (tid < PIPE_RES) S.res_slot[tid] = -1;
     if (tid < PIPE_LANES / 64) S.pub[tid] = -1;
