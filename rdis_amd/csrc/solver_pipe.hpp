@@ -309,6 +309,7 @@ struct PipeEnv {
     int trn, lm_count;
     bool has_fac;
     int fid;
+    int gpos[12];             // where this factor's partials go in gfac (variable-major), -1 = not a free variable: constant for the solve
     double base[12], dirv[12], lov[12], hiv[12];
     double ox, oy;
     VarState lv, wv;
@@ -381,19 +382,15 @@ struct PipeEnv {
 #pragma unroll
             for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
             ba_eval_grad(v, ox, oy, g);
-            const int* sp = L.slot_pos + L.slot_base[c0 + gt];
-            int t[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) t[k] = sp[k];
 #pragma unroll
             for (int k = 0; k < 12; ++k)
-                if (t[k] >= 0) store_f64<true>(L.gfac + t[k], g[k]);
+                if (gpos[k] >= 0) store_f64<true>(L.gfac + gpos[k], g[k]);
         }
         const long long tg1 = coop_clock();
         X.barrier(S);
         const long long tg2 = coop_clock();
         const int* vp = L.v2s_ptr + f0;
-        if (lv.li >= 0) lv.xi = run_sum_ordered<true, 16>(L.gfac, vp[lv.li], vp[lv.li + 1]);
+        if (lv.li >= 0) lv.xi = run_sum_ordered<true, 32>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         if (wv.li >= 0) wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
         X.tick(3, tg1 - tg0); X.tick(18, tg2 - tg1); X.tick(30, coop_clock() - tg2); X.tick(31, 1);
     }
@@ -848,11 +845,14 @@ __device__ __forceinline__ void pipe_solve(const ProblemView& P, const PlanView&
 #endif
               },
               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
-              gt >= 0 && gt < m, 0, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
+              gt >= 0 && gt < m, 0, {}, {}, {}, {}, {}, 0.0, 0.0, {}, {}};
     if (E.has_fac) {
         E.fid = L.fac_id[c0 + gt];
         const double2 o = P.obs[E.fid];
         E.ox = o.x; E.oy = o.y;
+        const int* sp = L.slot_pos + L.slot_base[c0 + gt];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) E.gpos[k] = sp[k];
     }
     if (tid == 0) { S.seq = 0; S.pred_seq = 0; S.cmd = -1; S.cmd_delay = 0; S.bar_done = -1; S.dead = 0; S.verified = -1; }
     if (tid < PIPE_RECS) S.rec_slot[tid] = -1;
