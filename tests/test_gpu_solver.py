@@ -901,7 +901,11 @@ def test_pipelined_groups_give_the_bits_of_the_plain_cooperative_solver(gctx):
     cases = (("ladybug", lb, whole(lb), {}, 25),
              ("active bounds", tight, whole(tight), {"coop_min_factors": 1000}, 8),
              ("cameras constant", sub, cams_const, {"coop_min_factors": 1000, "coop_max_components": 4}, 6),
-             ("five groups", syn, (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id), {"coop_min_factors": 1000}, 10))
+             ("five groups", syn, (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id), {"coop_min_factors": 1000}, 10)) + tuple(
+        # odd shapes: more variables than factors (the variables decide the number of lanes), a last workgroup
+        # that is mostly empty, one factor beyond a full workgroup
+        ("%d cameras x %d points x %d" % (c, q, o), sp, whole(sp), {"coop_min_factors": 1000}, 6)
+        for c, q, o in ((2, 1500, 2), (4, 1000, 4), (3, 1067, 3), (2, 1153, 2)) for sp in (P.make_synthetic_ba(1, c, q, obs_per_pt=o),))
     for name, pp, comps, opts, iters in cases:
         g = capi.Problem(gctx, pp)
         out = {}
