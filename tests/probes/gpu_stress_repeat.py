@@ -44,4 +44,27 @@ for rep in range(100):
     if np.any((r.status & 0xFF) == 7): bad += 1; print("SYNC TIMEOUT six pipelined groups", rep)
 print("%-30s %d repetitions, %d launches, identical" % ("six pipelined groups", 100, plan.last_kernel_ms()[1]))
 plan.close()
+# the pipelined group under timing changes: every poll delay, guesses on and off, tracing on and off, several
+# group sizes -- the bits must not depend on any of it (RDIS_STRESS_SOAK=1: a few thousand solves)
+if os.environ.get("RDIS_STRESS_SOAK"):
+    for label, prob in (("ladybug 49/7776", pp), ("ladybug 49/500", P.load_bal(ncams=49, npts=500)), ("ladybug 5/30", P.load_bal(ncams=5, npts=30))):
+        gp = capi.Problem(ctx, prob)
+        wh = (np.array([0, prob.nvars]), np.arange(prob.nvars, dtype=np.int64), np.array([0, prob.nfac]), np.arange(prob.nfac, dtype=np.int64))
+        ref = None
+        n = 0
+        for delay in (0, 4, 16, 48):
+            for spec in (1, 0):
+                for tr in (0, 2048):
+                    plan = capi.Plan(gp, *wh)
+                    plan.set_option("coop_min_factors", 64); plan.set_option("coop_poll_delay", delay); plan.set_option("coop_speculate", spec)
+                    if tr: plan.set_option("trace_records", tr)
+                    for rep in range(60 if spec and not tr else 15):
+                        gp.set_x(prob.x0); plan.set_start(None); plan.solve(25, 3e-8); r = plan.fetch(); n += 1
+                        key = (r.fret.tobytes(), r.x.tobytes(), r.iters.tobytes(), r.status.tobytes(), r.nfeval.tobytes(), r.ngeval.tobytes())
+                        if ref is None: ref = key
+                        elif key != ref: bad += 1; print("MISMATCH", label, "delay", delay, "guesses", spec, "trace", tr, "repetition", rep)
+                        if np.any((r.status & 0xFF) == 7): bad += 1; print("SYNC TIMEOUT", label, delay, spec, tr, rep)
+                    plan.close()
+        print("%-30s %d solves under 16 timing variants, identical" % (label + " (soak)", n))
+        gp.close()
 print("FAILED" if bad else "ok")
