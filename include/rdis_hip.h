@@ -215,7 +215,9 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * first granule sweep), "coop_pipeline" (default 1: cooperative groups run with the control logic,
  * the exchange and the factor arithmetic on waves of their own, solver_pipe.hpp, whenever every
  * group of the plan fits that layout of 128 factor lanes per workgroup; 0 = the plain cooperative
- * kernel; same bits either way as long as every variable fed by more than 48 partials has a wave),
+ * kernel; same bits either way as long as every variable fed by more than 48 partials has a wave;
+ * the environment variable RDIS_HIP_COOP_PIPELINE=0 / 1 sets the default for plans the caller does
+ * not see, e.g. the transient one of rdis_hip_cgd_batch),
  * "coop_speculate" (default 1: the pipelined groups evaluate guesses at the following trial steps
  * of a line search ahead of the control logic; results do not depend on it), "force_stream" (send large components to the streaming grid solver even
  * when they fit the register-resident one; large components that do not fit, and large

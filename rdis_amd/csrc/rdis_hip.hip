@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -679,6 +680,8 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     if (!L) return fail(c, RDIS_HIP_ENOMEM, "plan_create: host allocation");
     struct Guard { rdis_hip_plan* l; ~Guard() { if (l) rdis_hip_plan_destroy(l); } } guard{L};
     L->prob = p; L->transient = transient; L->ncomp = ncomp; L->nfree = nfree; L->nfac = nfac;
+    // (A/B runs of callers that cannot reach the plan's options, e.g. rdis_hip_cgd_batch: RDIS_HIP_COOP_PIPELINE=0 / 1)
+    if (const char* ev = std::getenv("RDIS_HIP_COOP_PIPELINE")) L->coop_pipeline = std::atoi(ev) != 0;
 
     // --- validate independence (free sets disjoint, factors owned once, no factor of one
     // component reading a free variable of another); owner / local are persistent per-problem
@@ -932,14 +935,18 @@ int prepare_partition(rdis_hip_plan* L) {
     // The grid solvers are for a few large components that would leave the device idle as single
     // workgroups, one launch each.  When there are more large components than that, the batch
     // kernel fills the device by itself (one workgroup per component) and is the better fit.
+    std::vector<int64_t> nlong_of((size_t)L->ncomp, -1);   // (counted once per component: the layouts are compared below)
     auto groups_of = [&](int cc) {   // workgroups of a component's cooperative group: a lane per factor / variable, a wave per long gradient run
         const int wpw = L->coop_lanes() / 64;
         const int64_t m = L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc];
         const int64_t n = L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc];
         const int f0 = L->h_free_ptr[(size_t)cc];
-        int64_t nlong = 0;
-        for (int64_t i = 0; i < n; ++i)
-            if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) ++nlong;
+        int64_t& nlong = nlong_of[(size_t)cc];
+        if (nlong < 0) {
+            nlong = 0;
+            for (int64_t i = 0; i < n; ++i)
+                if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) ++nlong;
+        }
         const int64_t need = (std::max(m, n) + L->coop_lanes() - 1) / L->coop_lanes();
         // (small groups only: a large one has its waves anyway, and more workgroups lengthen every sweep)
         const int64_t for_long = need < 16 ? std::min<int64_t>((nlong + wpw - 1) / wpw, 2 * need + 2) : 0;
@@ -952,7 +959,12 @@ int prepare_partition(rdis_hip_plan* L) {
                    nbig <= L->coop_max_components;
     const bool coop_on = L->coop_min_factors > 0 && L->coop_max_components > 0 && p->kind == KIND_BA && !L->force_stream;
     auto cap_of = [&]() {
-        int k = L->pipelined() ? pipe_max_workgroups(c->num_cus) : coop_max_workgroups(L->coop_threads, c->num_cus);
+        // (the occupancy queries behind these are not free: asked once per process and layout)
+        static int cap_pipe = -1, cap_coop[3] = {-1, -1, -1};
+        int& kc = cap_coop[L->coop_threads == 128 ? 0 : L->coop_threads == 256 ? 1 : 2];
+        if (L->pipelined() && cap_pipe < 0) cap_pipe = pipe_max_workgroups(c->num_cus);
+        if (!L->pipelined() && kc < 0) kc = coop_max_workgroups(L->coop_threads, c->num_cus);
+        int k = L->pipelined() ? cap_pipe : kc;
         if (L->coop_workgroups > 0) k = std::min(k, L->coop_workgroups);
         return k;
     };
