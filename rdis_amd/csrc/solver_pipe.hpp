@@ -86,9 +86,10 @@ static_assert(PIPE_RES > PIPE_DEPTH, "result ring");
 constexpr int PIPE_RECS = 8;    // guess records the stepper may still want: slots verified + 1 .. verified + DEPTH + 1
 struct PipeShared {
     PipeMail mail[PIPE_MAILS];
-    int seq;                     // number of the latest post (mail[seq % PIPE_MAILS])
-    int pred_seq;                // ... and of the latest post whose predictor part is there too
+    alignas(8) int seq;          // number of the latest post (mail[seq % PIPE_MAILS])
     int verified;                // stepper -> lanes: the latest slot the machine has asked for; they stay within DEPTH of it
+                                 // (next to seq: a lane wave reads both with one 8-byte access per guess)
+    int pred_seq;                // number of the latest post whose predictor part is there too
     // lanes -> stepper: what the chain guesses for slot z: rec_slot[z % 8] = 2 z + 1 and the step in rec_val, or 2 z = no guess
     int rec_slot[PIPE_RECS];
     double rec_val[PIPE_RECS];
@@ -113,6 +114,8 @@ typedef __attribute__((address_space(3))) int lds_i32;
 typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ int lds_int(const int& x) { return *(const volatile lds_i32*)&x; }
 __device__ __forceinline__ void lds_set(int& x, int v) { *(volatile lds_i32*)&x = v; }
+typedef __attribute__((address_space(3))) long long lds_i64;
+__device__ __forceinline__ long long lds_int_pair(const int& x) { return *(const volatile lds_i64*)&x; }   // x and the int after it (8-byte aligned)
 __device__ __forceinline__ double lds_f64_get(const double& x) { return *(const volatile lds_f64*)&x; }
 __device__ __forceinline__ void lds_f64_set(double& x, double v) { *(volatile lds_f64*)&x = v; }
 
@@ -795,8 +798,10 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
                 pipe_record(S, cz, cvalid, cval, recorder);
                 // guesses, at most DEPTH slots ahead of what the machine has asked for, until the stepper
                 // has something new to say or the chain ends
-                while (cvalid && lds_int(S.seq) == seen) {
-                    const int ver = lds_int(S.verified);
+                for (;;) {
+                    const long long sv = lds_int_pair(S.seq);   // (seq, verified)
+                    if (!cvalid || (int)sv != seen) break;
+                    const int ver = (int)(sv >> 32);
                     if (cz > (ver > e0 ? ver : e0) + PIPE_DEPTH) { __builtin_amdgcn_s_sleep(1); continue; }
                     const double ca = cval;
                     const int z = cz;
