@@ -45,7 +45,7 @@ for rep in range(100):
 print("%-30s %d repetitions, %d launches, identical" % ("six pipelined groups", 100, plan.last_kernel_ms()[1]))
 plan.close()
 # the pipelined group under timing changes: every poll delay, guesses on and off, tracing on and off, several
-# group sizes -- the bits must not depend on any of it (RDIS_STRESS_SOAK=1: a few thousand solves)
+# group sizes -- the bits must not depend on any of it (RDIS_STRESS_SOAK=k: k x 1260 solves)
 if os.environ.get("RDIS_STRESS_SOAK"):
     for label, prob in (("ladybug 49/7776", pp), ("ladybug 49/500", P.load_bal(ncams=49, npts=500)), ("ladybug 5/30", P.load_bal(ncams=5, npts=30))):
         gp = capi.Problem(ctx, prob)
@@ -58,7 +58,7 @@ if os.environ.get("RDIS_STRESS_SOAK"):
                     plan = capi.Plan(gp, *wh)
                     plan.set_option("coop_min_factors", 64); plan.set_option("coop_poll_delay", delay); plan.set_option("coop_speculate", spec)
                     if tr: plan.set_option("trace_records", tr)
-                    for rep in range(60 if spec and not tr else 15):
+                    for rep in range((60 if spec and not tr else 15) * max(1, int(os.environ.get("RDIS_STRESS_SOAK", "1")))):
                         gp.set_x(prob.x0); plan.set_start(None); plan.solve(25, 3e-8); r = plan.fetch(); n += 1
                         key = (r.fret.tobytes(), r.x.tobytes(), r.iters.tobytes(), r.status.tobytes(), r.nfeval.tobytes(), r.ngeval.tobytes())
                         if ref is None: ref = key
