@@ -292,14 +292,73 @@ def cpu_baseline(pp, maxiters: int):
     return out
 
 
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port), pass their
+    output through, and print rank 0's JSON line last."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        sys.exit(f"bench.py --gpus {n}: the ranks exited with {proc.returncode}" + ("" if line else " and printed no result line"))
+    print(line, flush=True)
+
+
+def dry_dist(a, rank: int, world: int) -> None:
+    """RDIS_BENCH_DRY_DIST=gloo (tests, no GPU): the distributed mechanics of the bench -- process
+    group, barrier, the MAX-over-ranks clock, the summed iteration count, rank 0's line last -- with
+    the rank's LPT shard of the strong-scaling decomposition standing in for the device work."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(os.environ["RDIS_BENCH_DRY_DIST"])
+    _, csr, mine, loads = strong_scaling_shard(rank, world, components=64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    it = torch.tensor([float(len(mine)), float(csr[2][-1])], dtype=torch.float64)
+    dist.all_reduce(it)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "subspace-solver iters/sec (all components), ladybug BA", "dry_run": True, "value": None,
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "seconds_max_over_ranks": float(tt.item()),
+                          "components_all_ranks": int(it[0].item()), "factors_all_ranks": int(it[1].item()),
+                          "factors_per_rank": [int(v) for v in loads]}), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)          # `python bench.py --gpus N`: start the N ranks ourselves
     if a.gpus > 1 and world != a.gpus:
         sys.exit(f"--gpus {a.gpus} needs one process per GPU: launch with torch.distributed.run "
                  f"--nproc-per-node {a.gpus} (WORLD_SIZE is {world})")
+    if os.environ.get("RDIS_BENCH_DRY_DIST"):
+        return dry_dist(a, rank, world)
     dist = None
     torch = None
     if world > 1 or os.environ.get("RDIS_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path on one GPU

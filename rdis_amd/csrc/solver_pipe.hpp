@@ -33,28 +33,33 @@
 // Exchange slots.  Every exchange has a number e, agreed by construction (all steppers take the
 // same decisions on the same bits): a request's evaluation gets the next free number E, the
 // guesses of its chain E+1 .. E+DEPTH; a hit continues at E+1, a miss jumps to E+DEPTH+1.  Slot e
-// lives in buffer e mod 16 of the granule ring (data is the flag, grid_sync.hpp).  A lane wave
+// lives in buffer e mod 32 of the granule ring (data is the flag, grid_sync.hpp).  A lane wave
 // publishes every slot at most once, in increasing order, and waits for its previous stores before
 // each publication, so its stores land in order.  After a completed sweep of slot y a collector
 // re-arms its workgroup's entries of all slots <= y - DEPTH - 1: the sweep of y completing proves
 // that every lane wave has published y, hence that its stepper had posted a request numbered
-// >= y - DEPTH, hence consumed every sweep below that.  Those re-arming stores are waited for by
-// the collector's next sweep, i.e. before the stepper can post the next request; a buffer comes
-// round again after 16 >= 4 DEPTH + 3 slots, which is more than the lanes can be ahead of that point.
+// >= y - DEPTH, hence consumed every sweep below that.  The collector hands the sums of y to its
+// stepper BEFORE it issues those re-arming stores (they are waited for by its next sweep), so what
+// is certain when a stepper holds the result of slot q is only that its workgroup's entries are
+// re-armed up to q - 2 DEPTH - 2 (the re-arming after the previous completed sweep, which was of a
+// slot >= q - DEPTH - 1).  From there the steppers can go on by a miss and a full chain of hits to
+// slot q + 3 DEPTH + 2 before this collector must have swept again.  A buffer comes round again
+// after 32 >= 5 DEPTH + 4 slots: nobody can poll a slot whose buffer still holds an earlier use
+// (with 16 buffers that held only by timing -- a 15k-cycle window against one store latency).
 #pragma once
 #include "solver_coop.hpp"
 
 namespace rdis_hip {
 
-constexpr int PIPE_NBUF = 16;     // granule buffers (ring over exchange numbers)
+constexpr int PIPE_NBUF = 32;     // granule buffers (ring over exchange numbers)
 constexpr int PIPE_DEPTH = 3;     // guesses in flight behind a request
-constexpr int PIPE_ENT = 1024;    // entries (lane waves of a group) per buffer
+constexpr int PIPE_ENT = 512;     // entries (lane waves of a group) per buffer: 256 workgroups, one per compute unit
 constexpr int PIPE_MAILS = 4;     // request slots in LDS (every post is a request the lanes must act on before the next one can follow)
 constexpr int PIPE_THREADS = 256;
 constexpr int PIPE_CTRL = 2;      // stepper + collector
 constexpr int PIPE_LANES = PIPE_THREADS - 64 * PIPE_CTRL;   // factor lanes per workgroup
 constexpr int PIPE_QUIT = 0x7FFFFFFF;
-static_assert(PIPE_NBUF >= 4 * PIPE_DEPTH + 3 && (PIPE_NBUF & (PIPE_NBUF - 1)) == 0, "ring too short for the run-ahead");
+static_assert(PIPE_NBUF >= 5 * PIPE_DEPTH + 4 && (PIPE_NBUF & (PIPE_NBUF - 1)) == 0, "ring too short for the run-ahead");
 
 // same memory as a CoopState (one per concurrent group), cut differently
 struct PipeState {
@@ -754,9 +759,14 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
         const long long tm0 = coop_clock();
         while ((s = lds_int(S.seq)) == seen) __builtin_amdgcn_s_sleep(1);
         E.X.tick(9, coop_clock() - tm0);
-        seen = s;
+        // Every post is acted on, in order: REQ_LINE_END is the one request the stepper does not wait
+        // for, and the post that follows it (REQ_DONE after an ftol exit, or the rollback's evaluation)
+        // can be there before a lane wave that was still evaluating a guess has looked.  Jumping to the
+        // newest post would skip the move to the line minimum: x of that wave's variables would be the
+        // point before the step.  The stepper is never more than two posts ahead (PIPE_MAILS = 4 slots).
+        seen = seen + 1;
         asm volatile("" ::: "memory");
-        const PipeMail* m = &S.mail[s & (PIPE_MAILS - 1)];
+        const PipeMail* m = &S.mail[seen & (PIPE_MAILS - 1)];
         const int kind = __builtin_amdgcn_readfirstlane(m->kind);
         const int flags = __builtin_amdgcn_readfirstlane(m->flags);
         E.X.e = __builtin_amdgcn_readfirstlane(m->e);
@@ -781,7 +791,7 @@ __device__ __forceinline__ void pipe_lanes(PipeEnv& E, PipeShared& S) {
 
                 }
                 // the predictor has followed the request's head by now
-                while (lds_int(S.pred_seq) != seen) __builtin_amdgcn_s_sleep(1);
+                while (lds_int(S.pred_seq) < seen) __builtin_amdgcn_s_sleep(1);   // (posts only ever increase)
                 asm volatile("" ::: "memory");
                 Predictor G;
                 G.ph = __builtin_amdgcn_readfirstlane(m->g_ph);

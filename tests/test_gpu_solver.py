@@ -935,3 +935,41 @@ def test_pipelined_groups_give_the_bits_of_the_plain_cooperative_solver(gctx):
             assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (name, label)
             for (tra, ca), (trb, cb) in zip(ta, tb):
                 assert ca == cb and np.array_equal(tra[:min(ca, 4096)], trb[:min(cb, 4096)]), (name, label)
+
+
+def test_pipelined_groups_move_to_the_line_minimum_before_an_ftol_exit(gctx):
+    """REQ_LINE_END is the one request the pipelined stepper does not wait for; on an
+    ftol exit the next post (REQ_DONE) follows a few hundred cycles later, and a lane wave still busy
+    with a guess used to jump to the newest post and skip the move to the line minimum -- x of its
+    variables was the point before the step while fret reported the moved one.  The lanes now act on
+    every post in order.  Run to EXIT_FTOL under several tolerances (different exits of the line
+    searches) and compare every bit with the plain cooperative solver, which has no such hand-over;
+    the returned value must also be the function at the returned point."""
+    cases = [(P.make_synthetic_ba(1, 3, 900, obs_per_pt=3, first_comp=s), ft) for s in (0, 1, 2) for ft in (1e-2, 1e-4, 1e-6, 3e-8)]
+    cases.append((P.load_bal(ncams=49, npts=500), 1e-3))
+    n_ftol = 0
+    for pp, ftol in cases:
+        comps = (np.array([0, pp.nvars]), np.arange(pp.nvars, dtype=np.int64), np.array([0, pp.nfac]), np.arange(pp.nfac, dtype=np.int64))
+        g = capi.Problem(gctx, pp)
+        out = {}
+        for label, extra in (("plain", {"coop_pipeline": 0}), ("pipelined", {"coop_pipeline": 1}), ("slow polls", {"coop_pipeline": 1, "coop_poll_delay": 64})):
+            g.set_x(pp.x0)
+            plan = capi.Plan(g, *comps)
+            for k, v in {"coop_min_factors": 1000, **extra}.items():
+                plan.set_option(k, v)
+            plan.set_start(None)
+            plan.solve(600, ftol)
+            out[label] = (plan.fetch(), g.get_x())
+            plan.close()
+        ra, xa = out["plain"]
+        n_ftol += int((ra.status[0] & 0xFF) == 0)
+        for label in ("pipelined", "slow polls"):
+            rb, xb = out[label]
+            assert np.array_equal(ra.status, rb.status) and np.array_equal(ra.iters, rb.iters), (ftol, label)
+            assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (ftol, label)
+            assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (ftol, label)
+        o = O.OracleProblem(pp, emulate_stale_cache=False)
+        o.assign(np.arange(pp.nvars, dtype=np.int64), out["pipelined"][0].x)
+        fo = o.eval()
+        assert abs(fo - out["pipelined"][0].fret[0]) <= 1e-12 * abs(fo), (ftol, fo)
+    assert n_ftol >= 8, n_ftol      # the exit this test is about

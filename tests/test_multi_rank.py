@@ -178,3 +178,19 @@ def test_strong_scaling_block_two_ranks_gloo(tmp_path):
     pp, _, _, _ = bench.strong_scaling_shard(0, 1, components=6)
     tot = O.OracleProblem(pp).eval()
     assert abs(res["total"] - tot) <= 1e-12 * tot and len(res["mine"]) == 3 and sum(res["loads"]) == pp.nfac
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that does not use
+    torch.distributed.run would type): the script re-runs itself as two ranks, they reach
+    init_process_group, and rank 0's JSON line is the last line of stdout.  RDIS_BENCH_DRY_DIST=gloo
+    swaps the device work for the ranks' LPT shards so that this runs without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RDIS_BENCH_DRY_DIST"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert line["components_all_ranks"] == 64 and sum(line["factors_per_rank"]) == line["factors_all_ranks"]
