@@ -65,6 +65,16 @@ struct PlanView {
     const int* cb;        // ... camera blocks (first variable id) with a free rotation variable, per component
     const int* cb_li;     // [3 per block] local index of the block's three rotation variables, -1 = constant
     const int* slot_pos;  // [slot_base[nfac_total]] listed factor's slot -> position in gfac (variable-major), -1 = not a free variable
+    // LDS-resident batch solver (solver_lds.hpp): a component's variables -- free ones and the constants its
+    // factors read -- as slots, camera blocks first (9 each), then point blocks (3 each)
+    const int* ls_ptr;    // [ncomp + 1] first slot of a component (equal to the next: the component has no table)
+    const int* ls_vid;    // [slots] variable id
+    const int* ls_free;   // [slots] local free index, -1 = constant
+    const int* ls_ncb;    // [ncomp] camera blocks of the component
+    const double2* ls_obs;    // [nfac_total] observation of every listed factor (copy in listed order: no indirection in the trial loop)
+    const int* ls_gperm;      // [nfac_total] per component: local indices of its listed factors sorted by camera block (stable)
+    const unsigned* ls_fidx;  // [nfac_total] listed factor -> camera block | point block << 12 (block numbers within the component)
+    long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]
     double* gfac;         // [v2s_ptr[nfree_total]] per-factor partials, variable-major

@@ -41,6 +41,12 @@ camera_rotations_kernel(const double* __restrict__ x, const int* __restrict__ ca
     store_rotation(x[c], x[c + 1], x[c + 2], xrot + c);
 }
 
+// a plan's copy of its listed factors' observations, in listed order (solver_lds.hpp)
+__global__ void __launch_bounds__(256)
+gather_obs_kernel(int n, const int* __restrict__ fac, const double2* __restrict__ obs, double2* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = obs[fac[i]];
+}
+
 __global__ void __launch_bounds__(256)
 gather_rows12_kernel(int nf, const int* __restrict__ fac, const double* __restrict__ gfac,
                      double* __restrict__ out) {

@@ -19,6 +19,7 @@
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
+#include "solver_lds.hpp"
 #include "solver_pipe.hpp"
 #include "solver_quad.hpp"
 #include "solver_stream.hpp"
@@ -97,6 +98,8 @@ struct rdis_hip_problem {
     DevBuf cam_blocks, xrot;                        // distinct camera blocks; their rotation records (shadow of x)
     int64_t ncam_blocks = 0;
     std::vector<int> h_block_of;                    // [N] first variable id of the camera block a variable belongs to, -1 = none
+    std::vector<int> h_ptblock_of;                  // [N] ... of the point block, -1 = none (valid when ncam_blocks > 0)
+    std::vector<int> h_blk_stamp, h_blk_idx;        // [N] scratch of the slot tables (solver_lds.hpp), valid by stamp
     std::vector<int> h_cam, h_pt, h_rowptr, h_vid;  // host copies for plan building
     // scratch for the eval entry points
     DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
@@ -191,6 +194,15 @@ struct rdis_hip_plan {
     int coop_max_components = 48;     // ... for at most this many components per plan (packed two or more to a launch); or ...
     int64_t coop_group_min_factors = 256;  // ... for every component of at least this many factors when all their groups fit the device at once
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
+    int rest_lds = 0;                 // the LAST rest_lds entries run on the LDS-resident solver (solver_lds.hpp)
+    int lds_resident = 1;             // option "lds_resident": 0 = never
+    int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
+    int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
+    int lds_ns_cap = 0, lds_ncb_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
+    int64_t lds_max_factors = 0;
+    DevBuf lds_ints, lds_obs;
+    std::vector<int> h_lds_ints;
+    size_t off_ls_ptr = 0, off_ls_vid = 0, off_ls_free = 0, off_ls_ncb = 0, off_ls_fidx = 0, off_ls_gperm = 0;
     int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
     int64_t row_min_components = 4096; // option: sixteen lanes each from this many tiny components (below: a workgroup each)
     int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
@@ -222,6 +234,12 @@ struct rdis_hip_plan {
         v.fac_ptr = ip(off_fac_ptr); v.fac_id = ip(off_fac_id);
         v.v2s_ptr = ip(off_v2s_ptr); v.slot_base = ip(off_slot_base); v.slot_pos = ip(off_slot_pos);
         v.cb_ptr = ip(off_cb_ptr); v.cb = ip(off_cb); v.cb_li = ip(off_cb_li);
+        const int* li = lds_ints.as<int>();
+        v.ls_ptr = li + off_ls_ptr; v.ls_vid = li + off_ls_vid; v.ls_free = li + off_ls_free; v.ls_ncb = li + off_ls_ncb;
+        v.ls_fidx = reinterpret_cast<const unsigned*>(li + off_ls_fidx);
+        v.ls_obs = lds_obs.as<double2>();
+        v.ls_gperm = li + off_ls_gperm;
+        v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
         v.xout = out_f64(0);
@@ -358,6 +376,17 @@ extern "C" int rdis_hip_upload_ba(rdis_hip_ctx* c, int64_t nvars, const double* 
             for (int k = 0; k < 9; ++k) p->h_block_of[(size_t)cb + k] = cb;
         for (int64_t i = 0; i < nfac && disjoint; ++i)   // a point block inside a camera block: likewise
             for (int k = 0; k < 3; ++k) disjoint = disjoint && p->h_block_of[(size_t)p->h_pt[(size_t)i] + k] < 0;
+        if (disjoint) {   // the point blocks likewise: coinciding or at least 3 apart
+            p->h_ptblock_of.assign((size_t)nvars, -1);
+            for (int64_t i = 0; i < nfac && disjoint; ++i) {
+                const int q = p->h_pt[(size_t)i];
+                for (int k = 0; k < 3; ++k) {
+                    int& o = p->h_ptblock_of[(size_t)q + k];
+                    disjoint = disjoint && (o < 0 || o == q);
+                    o = q;
+                }
+            }
+        }
         p->ncam_blocks = disjoint ? (int64_t)blocks.size() : 0;
         if (!rc && p->ncam_blocks > 0) {
             rc = upload(c, p->cam_blocks, blocks);
@@ -796,6 +825,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         // lane_var / wave_var of the cooperative groups: at most 3 x the lanes a component needs, rounded up to workgroups
         need += 5 * (3 * (size_t)(nfac + nfree) + 2048 * (size_t)std::min<int64_t>(ncomp, 4096)) + align_up(lanes_max * 4, 256);
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
+        need += align_up((size_t)(2 * (12 * nfac + 9 * nfree) + 2 * nfac + 2 * ncomp + 2) * 4, 256) + align_up((size_t)nfac * 16, 256) + 256;   // slot tables, observations of the LDS-resident solver
         need += (size_t)COOP_MAX_GROUPS * (4 * 256 + sizeof(CoopGroup)) + (size_t)COOP_MAX_WG * 4 + lanes_max * 4 + 64 * 256;  // groups, their alignment slack
         if (p->arena.bytes < need) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -890,6 +920,15 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->coop_speculate = value != 0;
     } else if (n == "coop_pipeline") {
         L->coop_pipeline = value != 0;
+    } else if (n == "lds_resident") {
+        L->lds_resident = value != 0;
+    } else if (n == "lds_rot") {
+        if (value < -1 || value > 1) return fail(c, RDIS_HIP_EINVAL, "lds_rot must be -1, 0 or 1");
+        L->lds_rot = (int)value;
+    } else if (n == "lds_threads") {
+        if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)
+            return fail(c, RDIS_HIP_EINVAL, "lds_threads must be 0, 64, 128, 256, 512, 768 or 1024");
+        L->lds_threads = (int)value;
     } else if (n == "force_stream") {
         L->force_stream = value != 0;
     } else if (n == "coop_poll_delay") {
@@ -1114,6 +1153,103 @@ int prepare_partition(rdis_hip_plan* L) {
         for (int cc : L->h_rest) mf = std::max<int64_t>(mf, L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc]);
         L->rest_rot_mode = camfix ? ROT_CAMFIX : (L->camera_records == 2 || mf > 2048) ? ROT_RECORDS : ROT_PER_FACTOR;
     }
+    // The LDS-resident solver (solver_lds.hpp) takes the bundle-adjustment components of the batch list
+    // whose variables -- free ones and the constants their factors read -- fit a compute unit's LDS as
+    // slots: camera blocks (9 slots each, ascending by id), then point blocks (3 each, ascending).
+    // They move to the end of the list; what does not fit stays with solver_wg.hpp.
+    L->rest_lds = 0;
+    L->h_lds_ints.clear();
+    L->lds_ns_cap = L->lds_ncb_cap = 0;
+    L->lds_max_factors = 0;
+    if (p->kind == KIND_BA && L->lds_resident != 0 && p->ncam_blocks > 0 && (int)L->h_rest.size() > L->rest_tiny) {
+        if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
+        std::vector<int> ls_ptr((size_t)L->ncomp + 1, 0), ls_len((size_t)L->ncomp, 0), ls_ncb((size_t)L->ncomp, 0), ls_vid, ls_free;
+        std::vector<int> ls_fidx((size_t)L->nfac, 0), ls_gperm((size_t)L->nfac, 0);
+        std::vector<char> fits((size_t)L->ncomp, 0);
+        std::vector<int> cams, pts;
+        for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
+            const int cc = L->h_rest[r];
+            const int f0 = L->h_free_ptr[(size_t)cc], f1 = L->h_free_ptr[(size_t)cc + 1];
+            const int c0 = L->h_fac_ptr[(size_t)cc], c1 = L->h_fac_ptr[(size_t)cc + 1];
+            if (c1 == c0) continue;   // (an empty factor list needs no table; such a component may ride with either solver)
+            const int stamp = ++p->stamp;
+            cams.clear(); pts.clear();
+            auto note = [&](int b, std::vector<int>& list) {
+                if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; list.push_back(b); }
+            };
+            bool ok = true;
+            for (int j = c0; j < c1; ++j) { const int f = L->h_fac_id[(size_t)j]; note(p->h_cam[(size_t)f], cams); note(p->h_pt[(size_t)f], pts); }
+            for (int i = f0; i < f1 && ok; ++i) {
+                const int v = L->h_free_vid[(size_t)i];
+                if (p->h_block_of[(size_t)v] >= 0) note(p->h_block_of[(size_t)v], cams);
+                else if (p->h_ptblock_of[(size_t)v] >= 0) note(p->h_ptblock_of[(size_t)v], pts);
+                else ok = false;   // a variable no factor of the problem reads: no block to put it in
+            }
+            const int64_t ns = 9ll * (int64_t)cams.size() + 3ll * (int64_t)pts.size();
+            ok = ok && cams.size() <= 4095 && pts.size() < (1u << 20) && lds_bytes_for((int)ns, (int)cams.size()) <= (size_t)LDS_MAX_BYTES;
+            if (!ok) continue;
+            std::sort(cams.begin(), cams.end());
+            std::sort(pts.begin(), pts.end());
+            for (size_t k = 0; k < cams.size(); ++k) p->h_blk_idx[(size_t)cams[k]] = (int)k;
+            for (size_t k = 0; k < pts.size(); ++k) p->h_blk_idx[(size_t)pts[k]] = (int)k;
+            // local free index of the component's variables (the per-problem arrays are valid for one stamp)
+            for (int i = f0; i < f1; ++i) { const int v = L->h_free_vid[(size_t)i]; p->h_owner_stamp[(size_t)v] = stamp; p->h_local[(size_t)v] = i - f0; }
+            ls_ptr[(size_t)cc] = (int)ls_vid.size();   // (start in append order; turned into a CSR over all components below)
+            ls_len[(size_t)cc] = (int)ns;
+            for (int b : cams) for (int k = 0; k < 9; ++k) { ls_vid.push_back(b + k); ls_free.push_back(p->h_owner_stamp[(size_t)(b + k)] == stamp ? p->h_local[(size_t)(b + k)] : -1); }
+            for (int b : pts) for (int k = 0; k < 3; ++k) { ls_vid.push_back(b + k); ls_free.push_back(p->h_owner_stamp[(size_t)(b + k)] == stamp ? p->h_local[(size_t)(b + k)] : -1); }
+            for (int j = c0; j < c1; ++j) {
+                const int f = L->h_fac_id[(size_t)j];
+                ls_fidx[(size_t)j] = (int)((unsigned)p->h_blk_idx[(size_t)p->h_cam[(size_t)f]] | ((unsigned)p->h_blk_idx[(size_t)p->h_pt[(size_t)f]] << 12));
+            }
+            {   // the order of the gradient pass: by camera block, listed order within a camera
+                int* gp = ls_gperm.data() + c0;
+                std::iota(gp, gp + (c1 - c0), 0);
+                std::stable_sort(gp, gp + (c1 - c0), [&](int a, int b) { return (ls_fidx[(size_t)(c0 + a)] & 0xFFF) < (ls_fidx[(size_t)(c0 + b)] & 0xFFF); });
+            }
+            ls_ncb[(size_t)cc] = (int)cams.size();
+            fits[(size_t)cc] = 1;
+            L->lds_ns_cap = std::max(L->lds_ns_cap, (int)ns);
+            L->lds_ncb_cap = std::max(L->lds_ncb_cap, (int)cams.size());
+            L->lds_max_factors = std::max<int64_t>(L->lds_max_factors, c1 - c0);
+        }
+        // the two maxima may come from different components: the launch's LDS must hold both
+        if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap) > (size_t)LDS_MAX_BYTES) {
+            std::fill(fits.begin(), fits.end(), 0);
+            L->lds_ns_cap = L->lds_ncb_cap = 0;
+        }
+        if (L->lds_ns_cap > 0) {
+            auto mid = std::stable_partition(L->h_rest.begin() + L->rest_tiny, L->h_rest.end(), [&](int cc) { return !fits[(size_t)cc]; });
+            L->rest_lds = (int)(L->h_rest.end() - mid);
+            // the tables were appended in list order (heaviest first): re-emit them in component order, so that
+            // ls_ptr is a plain CSR in which a component without a table has an empty range
+            std::vector<int> ptr2((size_t)L->ncomp + 1, 0), vid2, free2;
+            vid2.reserve(ls_vid.size()); free2.reserve(ls_free.size());
+            for (int64_t cc = 0; cc < L->ncomp; ++cc) {
+                ptr2[(size_t)cc] = (int)vid2.size();
+                if (!fits[(size_t)cc]) continue;
+                const int b0 = ls_ptr[(size_t)cc], len = ls_len[(size_t)cc];
+                vid2.insert(vid2.end(), ls_vid.begin() + b0, ls_vid.begin() + b0 + len);
+                free2.insert(free2.end(), ls_free.begin() + b0, ls_free.begin() + b0 + len);
+            }
+            ptr2[(size_t)L->ncomp] = (int)vid2.size();
+            ls_vid.swap(vid2); ls_free.swap(free2);
+            std::vector<int>& blk = L->h_lds_ints;
+            auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
+            L->off_ls_ptr = put(ptr2); L->off_ls_vid = put(ls_vid); L->off_ls_free = put(ls_free);
+            L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gperm = put(ls_gperm);
+            // rotations: no camera variable free among these components -> records, read only; otherwise records that
+            // follow the trial point when a lane has several factors per camera and trial (else each factor forms its own)
+            bool camfix = true;
+            for (size_t r = L->h_rest.size() - (size_t)L->rest_lds; r < L->h_rest.size() && camfix; ++r) {
+                const int cc = L->h_rest[r];
+                for (int k = L->h_free_ptr[(size_t)cc]; k < L->h_free_ptr[(size_t)cc + 1] && camfix; ++k)
+                    camfix = p->h_block_of[(size_t)L->h_free_vid[(size_t)k]] < 0;
+            }
+            const bool records = L->lds_rot >= 0 ? L->lds_rot == 1 : L->lds_max_factors > 512;
+            L->lds_rot_mode = L->camera_records == 0 ? ROT_PER_FACTOR : camfix ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
+        }
+    }
     if (L->rest_tiny > 0 && L->group_blocks4 == 0) {
         int b4 = 0, b16 = 0;
         HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cgd_group_kernel<4, QUAD_THREADS>, QUAD_THREADS, 0));
@@ -1125,6 +1261,15 @@ int prepare_partition(rdis_hip_plan* L) {
     if (!rc) rc = plan_alloc(L, L->queue, 256);
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
+    if (L->rest_lds > 0) {
+        rc = plan_alloc(L, L->lds_ints, L->h_lds_ints.size() * sizeof(int));
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(L->lds_ints.p, L->h_lds_ints.data(), L->h_lds_ints.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        rc = plan_alloc(L, L->lds_obs, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(double2));
+        if (rc) return rc;
+        gather_obs_kernel<<<grid_for(c, L->nfac, 256), 256, 0, c->stream>>>((int)L->nfac, L->ip(L->off_fac_id), p->obs.as<double2>(), L->lds_obs.as<double2>());
+        HIPCHK(c, hipGetLastError());
+    }
     if (!L->coop.empty()) {
         rc = plan_alloc(L, L->coop_ints, L->h_coop_ints.size() * sizeof(int));
         if (rc) return rc;
@@ -1201,6 +1346,39 @@ int launch_wg(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int 
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+template <int ROT>
+int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    ProblemView P = L->prob->view();
+    PlanView V = L->view();
+    V.order += first;
+    const size_t dyn = lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap);
+    const int nsc = L->lds_ns_cap, ncc = L->lds_ncb_cap;
+#define RDIS_LDS_LAUNCH(T)                                                                                              \
+    do {                                                                                                                \
+        if (dyn > 48 * 1024)                                                                                            \
+            HIPCHK(c, hipFuncSetAttribute((const void*)cgd_lds_kernel<T, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+        cgd_lds_kernel<T, ROT><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, nsc, ncc);                                \
+    } while (0)
+    switch (threads) {
+        case 64: RDIS_LDS_LAUNCH(64); break;
+        case 128: RDIS_LDS_LAUNCH(128); break;
+        case 256: RDIS_LDS_LAUNCH(256); break;
+        case 512: RDIS_LDS_LAUNCH(512); break;
+        case 768: RDIS_LDS_LAUNCH(768); break;
+        default: RDIS_LDS_LAUNCH(1024); break;
+    }
+#undef RDIS_LDS_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int launch_lds(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    switch (L->lds_rot_mode) {
+        case ROT_CAMFIX: return launch_lds_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
+        case ROT_RECORDS: return launch_lds_rot<ROT_RECORDS>(L, stream, threads, first, grid, maxiters, ftol);
+        default: return launch_lds_rot<ROT_PER_FACTOR>(L, stream, threads, first, grid, maxiters, ftol);
+    }
+}
 }  // namespace
 
 extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ftol) {
@@ -1260,7 +1438,9 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
-    if (L->rest_rot_mode != ROT_PER_FACTOR) {   // (cameras the batch reads are not free in the launches above)
+    const int rest = (int)L->h_rest.size() - L->rest_tiny - L->rest_lds;   // components of the plain batch solver
+    // (the LDS-resident solver forms the records it reads itself)
+    if (L->rest_rot_mode != ROT_PER_FACTOR && (L->rest_tiny > 0 || rest > 0)) {   // (cameras the batch reads are not free in the launches above)
         camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, bs>>>(
             p->x.as<double>(), p->cam_blocks.as<int>(), (int)p->ncam_blocks, p->xrot.as<double>());
         HIPCHK(c, hipGetLastError());
@@ -1286,10 +1466,21 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         HIPCHK(c, hipGetLastError());
         ++L->last_launches;
     }
-    const int rest = (int)L->h_rest.size() - L->rest_tiny;
+    if (L->rest_lds > 0) {
+        const int64_t mf = L->lds_max_factors;
+        int threads = L->lds_threads ? L->lds_threads : L->block_threads;
+        // A lane per factor up to 512, then 768 lanes (three waves per SIMD) -- unless the launch has more
+        // components than compute units: then 256 lanes, two workgroups per compute unit, so that one
+        // component's arithmetic fills the unit while the other's control step (one lane) or barrier runs
+        // (1000 x 2048 factors: 11.9 against 13.7 ms; 125 of them, a unit each: 3.5 against 4.7 ms)
+        if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : L->rest_lds > c->num_cus ? 256 : mf <= 512 ? 512 : 768;
+        int rc = launch_lds(L, bs, threads, L->rest_tiny + rest, L->rest_lds, maxiters, ftol);
+        if (rc) return rc;
+        ++L->last_launches;
+    }
     if (rest > 0) {
         int64_t mf = 0;
-        for (size_t i = (size_t)L->rest_tiny; i < L->h_rest.size(); ++i) {
+        for (size_t i = (size_t)L->rest_tiny; i < L->h_rest.size() - (size_t)L->rest_lds; ++i) {
             const int cc = L->h_rest[i];
             mf = std::max<int64_t>(mf, std::max<int64_t>(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
                                                          (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));

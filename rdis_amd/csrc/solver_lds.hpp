@@ -1,0 +1,427 @@
+// solver_lds.hpp -- one workgroup solves one bundle-adjustment component whose variables fit
+// the compute unit's LDS: the whole CGDSubspaceOptimizer::optimize call (reference
+// src/optimizers/CGDSubspaceOptimizer.cpp:19-98) with the CG iterate resident in LDS, a batch of
+// independent components per launch (grid = components, heaviest first).
+//
+// solver_wg.hpp forms every trial point in global memory: phase A writes x[vid] = clamp(p + a*xi)
+// for the component's free variables, a barrier, phase B gathers 12 values of x and 12 of the
+// direction per factor through L2 -- per trial point and component that is a round trip of p, xi,
+// lo, hi, x and dir (measured on the 256 x ladybug-size batch: 2.8 x the algorithmic bytes in HBM
+// traffic, and with every compute unit busy a component ran three times slower than alone).
+// Here a component's variables get SLOTS in LDS, camera blocks first (9 slots each), then point
+// blocks (3 each); a slot holds a free variable or a constant the component's factors read:
+//
+//   Pv[s]  the CG iterate p (unclamped; a constant's assigned value)      LO[s], HI[s]  the domain
+//   XI[s]  the search direction / gradient (0 for a constant)            X[s]   clamp(p + a*xi)
+//   ROT[c] rotation record of camera block c (factors.hpp) when the launch uses records
+//
+// Per line-search trial (SubfunctionFD::operator() / df, .cpp:124-184):
+//   phase A  every free slot: X = clamp(Pv + a XI)                     LDS -> LDS, no global access
+//   phase B  every factor: 12 values of X and XI from two slot bases (one packed 32-bit word per
+//            listed factor), its observation; value and forward-mode slope as in solver_wg.hpp
+//   reduce   wave (DPP) + LDS, fixed order: the same bits run to run, and -- the factor arithmetic
+//            and the order of the sums being those of solver_wg.hpp -- the same bits as that solver
+//            whenever the slots are the free variables in their listed order (every block free,
+//            cameras before points, ascending: what RDIS and the generators produce; tested).
+// The full gradient, once per CG iteration, goes through the variable-major gfac[] like
+// solver_wg.hpp's (per-variable sums in factor-list order, src/State.h:157-210); g and h of the
+// Polak-Ribiere recurrence stay in the plan's workspace (touched twice per iteration).
+#pragma once
+#include "solver_wg.hpp"
+
+namespace rdis_hip {
+
+constexpr int LDS_MAX_BYTES = 160 * 1024 - 4096;   // dynamic LDS a launch may ask for (static: machine, requests, reduction slots)
+constexpr int LDS_DOUBLES_PER_SLOT = 5;            // Pv, XI, LO, HI, X
+__host__ __device__ inline size_t lds_bytes_for(int ns, int ncb) {
+    return (size_t)ns * (LDS_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) + 64;
+}
+
+template <int ROT, bool PREFETCH>
+struct LdsEnv {
+    const ProblemView& P;
+    const PlanView& L;
+    int comp, n, m, f0, c0, tid, nt, nwaves;
+    int ns, ncb;              // slots, camera blocks of this component
+    const double2* fobs;      // its listed factors' observations (plan-local copy in listed order)
+    const unsigned* fidx;     // its listed factors' slot word: camera block | point block << 12
+    const int* gperm;         // its listed factors (local index) sorted by camera block: the order of the gradient pass
+    const int* vptr;          // v2s_ptr + free offset
+    const int* svid;          // variable id of a slot
+    double *Pv, *XI, *LO, *HI, *X, *ROTR;   // LDS
+    int* SF;                  // LDS: local free index of a slot, -1 = constant
+    double *g, *h;            // plan workspace, by free index
+    double (*red)[3][MAX_WAVES];
+    int parity;
+    int *long_q, *long_n;
+    double* tr;
+    int trn, lm_count;
+
+    template <int K>
+    __device__ void sumk(double& a, double& b, double& mx) {
+        a = wave_sum(a);
+        if constexpr (K >= 2) b = wave_sum(b);
+        if constexpr (K >= 3) mx = wave_max(mx);
+        if (nwaves > 1) {
+            const int w = tid >> 6;
+            if ((tid & 63) == 0) {
+                red[parity][0][w] = a;
+                if constexpr (K >= 2) red[parity][1][w] = b;
+                if constexpr (K >= 3) red[parity][2][w] = mx;
+            }
+            __syncthreads();
+            combine_waves<K>(red[parity], nwaves, a, b, mx);
+            parity ^= 1;
+        }
+    }
+    __device__ void trace(int tag, double a, double b, double c) {
+        if (tr != nullptr && tid == 0) {
+            if (trn < L.trace_cap) { double* r = tr + 4ll * trn; r[0] = (double)tag; r[1] = a; r[2] = b; r[3] = c; }
+            ++trn;
+        }
+    }
+
+    // rotation records of the camera blocks with a free rotation variable (ROT_RECORDS), formed
+    // from the trial point the way phase A forms it -- no need to wait for X; taken by the last
+    // lanes of the workgroup (the first wave steps the control logic)
+    template <class At>
+    __device__ void refresh_records(At at) {
+        if constexpr (ROT == ROT_RECORDS) {
+            for (int c = nt - 1 - tid; c < ncb; c += nt) {
+                const int s = 9 * c;
+                if (SF[s] < 0 && SF[s + 1] < 0 && SF[s + 2] < 0) continue;   // a constant camera: its record stays
+                double r[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r[k] = SF[s + k] >= 0 ? at(s + k) : Pv[s + k];
+                store_rotation(r[0], r[1], r[2], ROTR + 7 * c);
+            }
+        }
+    }
+    // SubfunctionFD::quickAssignVals at p + a*xi (reference .cpp:160-184; the trial point is
+    // formed unfused like minimize_nrc.h:434)
+    __device__ void assign_line(double a) {
+#pragma clang fp contract(off)
+        for (int s = tid; s < ns; s += nt) {
+            if (SF[s] < 0) continue;
+            const double t = a * XI[s];
+            X[s] = clampd(Pv[s] + t, LO[s], HI[s]);
+        }
+        refresh_records([&](int s) {
+#pragma clang fp contract(off)
+            const double t = a * XI[s];
+            return clampd(Pv[s] + t, LO[s], HI[s]);
+        });
+        __syncthreads();
+    }
+    __device__ void assign_p() {
+        for (int s = tid; s < ns; s += nt)
+            if (SF[s] >= 0) X[s] = clampd(Pv[s], LO[s], HI[s]);
+        refresh_records([&](int s) { return clampd(Pv[s], LO[s], HI[s]); });
+        __syncthreads();
+    }
+    __device__ void assign_start() {   // clamp(x_init): the rollback (CGD .cpp:71)
+        const double* xs = L.xstart + f0;
+        for (int s = tid; s < ns; s += nt)
+            if (SF[s] >= 0) X[s] = clampd(xs[SF[s]], LO[s], HI[s]);
+        refresh_records([&](int s) { return clampd(xs[SF[s]], LO[s], HI[s]); });
+        __syncthreads();
+    }
+
+    // the forward state of a listed factor (slot word w, observation o) at X: v = its 12 inputs (v[0..2] not loaded with records)
+    __device__ __forceinline__ double forward(unsigned w, double2 o, double (&v)[12], BaFwd& t, int& cb, int& pb) {
+        const int c = (int)(w & 0xFFFu);
+        cb = 9 * c;
+        pb = 9 * ncb + 3 * (int)(w >> 12);
+#pragma unroll
+        for (int k = 3; k < 9; ++k) v[k] = X[cb + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = X[pb + k];
+        if constexpr (ROT == ROT_PER_FACTOR) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = X[cb + k];
+            return ba_forward(v, o.x, o.y, t);
+        } else {
+            v[0] = v[1] = v[2] = 0.0;
+            ba_load_rotation(ROTR + 7 * c, t);
+            return ba_project(v, o.x, o.y, t);
+        }
+    }
+
+    // This lane's share of the sums.  A factor's slot word and observation (20 bytes, plan-local arrays in
+    // listed order: coalesced, no indirection) are fetched one round ahead: with two or three waves per
+    // SIMD nothing else hides the ~600 cycles of an L2 round trip in front of ~1000 cycles of arithmetic
+    // (counters before: 60 % of all wave-cycles waiting, VALU busy 39 %).  Not at three waves per SIMD: the five
+    // registers it holds are spilled there (768 lanes: 3.76 against 3.47 ms on 125 x 2048 factors).
+    template <bool SLOPE>
+    __device__ __forceinline__ void eval_partial(double& af, double& as) {
+        int j = tid;
+        unsigned wn = 0u;
+        double2 on = make_double2(0.0, 0.0);
+        if (PREFETCH && j < m) { wn = fidx[j]; on = fobs[j]; }
+        for (; j < m; j += nt) {
+            unsigned w;
+            double2 o;
+            if constexpr (PREFETCH) {
+                w = wn; o = on;
+                if (j + nt < m) { wn = fidx[j + nt]; on = fobs[j + nt]; }
+            } else {
+                w = fidx[j]; o = fobs[j];
+            }
+            double v[12];
+            BaFwd t;
+            int cb, pb;
+            af += forward(w, o, v, t, cb, pb);
+            if constexpr (SLOPE) {
+                double d[12];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_CAMFIX) ? 0.0 : XI[cb + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d[9 + k] = XI[pb + k];
+                as += ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
+            }
+        }
+    }
+    template <bool SLOPE>
+    __device__ void eval_sum(double& f, double& s) {
+        double af = 0.0, as = 0.0, dummy = 0.0;
+        eval_partial<SLOPE>(af, as);
+        sumk<SLOPE ? 2 : 1>(af, as, dummy);
+        f = af; s = as;
+    }
+
+    static constexpr bool UNIFORM = true;
+    static constexpr int SPEC = 1;
+    __device__ bool stepper() const { return threadIdx.x < 64; }
+    __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
+    __device__ void sync() const { __syncthreads(); }
+    __device__ bool tracing() const { return tr != nullptr; }
+    __device__ bool aborted() const { return false; }
+    // cycle stamps of workgroup 0's first lane (build with -DRDIS_COOP_TIMING; rdis_hip_plan_debug_counters):
+    // 0 phase A, 1 phase B, 2 reduction of a value+slope trial, 3 their number; 8 / 9 control step / hand-over,
+    // 12.. cycles per request kind (12 value, 13 value+slope, 14 gradient + reduction, 17 line end), 22.. their counts
+#ifdef RDIS_COOP_TIMING
+    long long tm[32];
+    __device__ void tick(int slot, long long dt) { tm[slot] += dt; }
+    __device__ long long clock() const { return clock64(); }
+#else
+    __device__ void tick(int, long long) {}
+    __device__ long long clock() const { return 0; }
+#endif
+    __device__ double eval_value(double a, bool restore) {
+        if (restore) assign_start(); else assign_line(a);
+        double f, s;
+        eval_sum<false>(f, s);
+        return f;
+    }
+    __device__ void eval_value_slope(double a, double& f, double& s) {
+        const long long t0 = clock();
+        assign_line(a);
+        const long long t1 = clock();
+        double af = 0.0, as = 0.0, dummy = 0.0;
+        eval_partial<true>(af, as);
+        const long long t2 = clock();
+        sumk<2>(af, as, dummy);
+        f = af; s = as;
+        tick(0, t1 - t0); tick(1, t2 - t1); tick(2, clock() - t2); tick(3, 1);
+    }
+
+    __device__ void init_vectors() {   // CGD .cpp:34-39: p = x0 (unclamped); the slots of constants hold their assigned value
+        const double* xs = L.xstart + f0;
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s], v = svid[s];
+            if (fi >= 0) {
+                const double lo = P.lo[v], hi = P.hi[v], x0 = xs[fi];
+                Pv[s] = x0; LO[s] = lo; HI[s] = hi; X[s] = clampd(x0, lo, hi);
+            } else {
+                const double xc = P.x[v];
+                Pv[s] = xc; X[s] = xc; LO[s] = -__builtin_inf(); HI[s] = __builtin_inf();
+            }
+            XI[s] = 0.0;
+        }
+        __syncthreads();
+        if constexpr (ROT != ROT_PER_FACTOR) {   // every camera block's record at the start (those of constant cameras stay)
+            for (int c = tid; c < ncb; c += nt) store_rotation(X[9 * c], X[9 * c + 1], X[9 * c + 2], ROTR + 7 * c);
+            __syncthreads();
+        }
+    }
+
+    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p)
+    __device__ void gradient_to_xi() {
+        const long long tg0 = clock();
+        assign_p();
+        // The factors are taken camera by camera here (gperm: the listed factors sorted by camera block, stable):
+        // gfac is variable-major, so the nine camera partials of neighbouring lanes then land next to each other --
+        // in listed order (by point) every one of a wave's 64 x 12 stores went to a cache line of its own, and the
+        // scatter was 42 000 of a gradient's 70 000 cycles.  Which lane forms a partial does not change its bits.
+        for (int jj = tid; jj < m; jj += nt) {
+            const int j = gperm[jj];
+            double v[12], gq[12];
+            BaFwd t;
+            int cb, pb;
+            const int* sp = L.slot_pos + L.slot_base[c0 + j];
+            int u[12];
+#pragma unroll
+            for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) u[k] = sp[k];
+            forward(fidx[j], fobs[j], v, t, cb, pb);
+            ba_adjoint(t, v, t.res0, t.res1, gq);
+#pragma unroll
+            for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) if (u[k] >= 0) L.gfac[u[k]] = gq[k];
+        }
+        if (tid == 0) *long_n = 0;
+        __syncthreads();
+        const long long tg1 = clock();
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const int b = vptr[fi], e = vptr[fi + 1];
+            if (e - b > WG_LONG_LIST) {
+                const int k = atomicAdd(long_n, 1);
+                if (k < WG_LONG_QUEUE) { long_q[k] = s; continue; }
+            }
+            XI[s] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
+        }
+        __syncthreads();
+        const long long tg2 = clock();
+        const int nq = min(*long_n, WG_LONG_QUEUE);
+        if (nq > 0) {
+            // (a wave takes its runs three at a time: their loads are in flight together; each sum is that of solver_wg.hpp)
+            for (int k = tid >> 6; k < nq; k += 3 * nwaves) {
+                int sl[3];
+                double part[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int kk = k + q * nwaves;
+                    sl[q] = kk < nq ? long_q[kk] : -1;
+                    const int fi = sl[q] >= 0 ? SF[sl[q]] : 0;
+                    part[q] = sl[q] >= 0 ? run_sum_strided(L.gfac, vptr[fi], vptr[fi + 1], tid & 63) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (sl[q] < 0) continue;   // (wave-uniform)
+                    const double sm = wave_sum(part[q]);
+                    if ((tid & 63) == 0) XI[sl[q]] = sm;
+                }
+            }
+            __syncthreads();
+        }
+        tick(4, tg1 - tg0); tick(5, tg2 - tg1); tick(6, clock() - tg2); tick(10, 1);
+    }
+
+    __device__ void cg_start() {
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi >= 0) { const double t = -XI[s]; g[fi] = t; h[fi] = t; XI[s] = t; }
+        }
+        __syncthreads();
+    }
+    __device__ void line_begin() {
+        if (L.vdump != nullptr && lm_count < L.dump_iters) {
+            double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;
+            for (int s = tid; s < ns; s += nt) {
+                const int fi = SF[s];
+                if (fi >= 0) { d[fi] = Pv[s]; d[n + fi] = XI[s]; }
+            }
+        }
+        ++lm_count;
+    }
+    __device__ void line_end(double amin) {
+#pragma clang fp contract(off)
+        for (int s = tid; s < ns; s += nt) {
+            if (SF[s] < 0) continue;
+            const double t = XI[s] * amin;
+            XI[s] = t;
+            Pv[s] = Pv[s] + t;
+        }
+        __syncthreads();
+    }
+    __device__ void cg_reduce(double fp, double& test, double& gg, double& dgg) {
+#pragma clang fp contract(off)
+        const double den = fmax(fabs(fp), 1.0);
+        double a = 0.0, b = 0.0, t = 0.0;
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const double x = XI[s], gi = g[fi];
+            t = fmax(t, fabs(x) * fmax(fabs(Pv[s]), 1.0) / den);
+            a = a + gi * gi;
+            b = b + (x + gi) * x;
+        }
+        sumk<3>(a, b, t);
+        gg = a; dgg = b; test = t;
+    }
+    __device__ void cg_update(double gam) {
+#pragma clang fp contract(off)
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const double gn = -XI[s];
+            const double hn = gn + gam * h[fi];
+            g[fi] = gn; h[fi] = hn; XI[s] = hn;
+        }
+        __syncthreads();
+    }
+};
+
+template <int THREADS, int ROT>
+__global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
+cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap, int ncb_cap) {
+    extern __shared__ double lds_dyn[];
+    __shared__ double red[2][3][MAX_WAVES];
+    __shared__ int long_q[WG_LONG_QUEUE];
+    __shared__ int long_n;
+    const int comp = L.order[blockIdx.x];
+    const int f0 = L.free_ptr[comp], f1 = L.free_ptr[comp + 1];
+    const int c0 = L.fac_ptr[comp], c1 = L.fac_ptr[comp + 1];
+    const int n = f1 - f0, m = c1 - c0;
+
+    if (m == 0) {  // nothing to optimise: return 0, leave x as it was (.cpp:26-29)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) L.xout[f0 + i] = L.xstart[f0 + i];
+        if (threadIdx.x == 0) {
+            L.fret[comp] = 0.0; L.delta[comp] = 0.0; L.iters[comp] = 0;
+            L.status[comp] = EXIT_EMPTY; L.nfeval[comp] = 0; L.ngeval[comp] = 0;
+            if (L.trace_n) L.trace_n[comp] = 0;
+        }
+        return;
+    }
+    const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp];
+    double* base = lds_dyn;
+    int* SF = (int*)(base + LDS_DOUBLES_PER_SLOT * ns_cap + 7 * ncb_cap);
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
+    __syncthreads();
+    double* ws = L.ws + 5ll * f0;
+    LdsEnv<ROT, (THREADS <= 512)> E{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
+                  ns, ncb, L.ls_obs + c0, L.ls_fidx + c0, L.ls_gperm + c0, L.v2s_ptr + f0, L.ls_vid + s0,
+                  base, base + ns_cap, base + 2 * ns_cap, base + 3 * ns_cap, base + 4 * ns_cap, base + LDS_DOUBLES_PER_SLOT * ns_cap,
+                  SF, ws + 2ll * n, ws + 3ll * n,
+                  red, 0, long_q, &long_n,
+                  L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0
+#ifdef RDIS_COOP_TIMING
+                  , {}
+#endif
+    };
+    [[maybe_unused]] const long long tk0 = E.clock();
+
+    __shared__ CgdMachine M;
+    __shared__ Request Q[2];
+    E.init_vectors();
+    run_machine(E, M, Q, maxiters, ftol);
+    // assign gdmin.p with sanitisation (.cpp:61); after a rollback X already holds clamp(x_init)
+    if (!M.rolled_back) E.assign_p();
+    for (int s = E.tid; s < ns; s += E.nt) {
+        const int fi = SF[s];
+        if (fi >= 0) { const double xv = E.X[s]; P.x[E.svid[s]] = xv; L.xout[f0 + fi] = xv; }
+    }
+    if (E.tid == 0) {
+        L.fret[comp] = M.fret; L.delta[comp] = M.fret - M.finit; L.iters[comp] = M.iter;
+        L.status[comp] = M.status(); L.nfeval[comp] = M.nfeval; L.ngeval[comp] = M.ngeval;
+        if (L.trace_n) L.trace_n[comp] = E.trn;
+#ifdef RDIS_COOP_TIMING
+        if (blockIdx.x == 0 && L.timing) {
+            E.tm[7] = E.clock() - tk0;
+            for (int i = 0; i < 32; ++i) L.timing[i] = E.tm[i];
+        }
+#endif
+    }
+}
+
+}  // namespace rdis_hip

@@ -48,7 +48,7 @@ def solve(gctx, pp, maxiters=25, ftol=3e-8, free_vid=None, fac_id=None, x=None, 
     return g, r, tr
 
 
-def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None):
+def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None, iter_tol=1e-11):
     """The oracle re-runs the solve, (a) fed the scalars the device's control logic saw and
     (b) restarted at every line search from the device's own point and direction, so both
     sides evaluate at bit-identical points.  Then over the WHOLE run:
@@ -75,7 +75,7 @@ def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=
     # rounding bound of the sum at that point (below 1 at ordinary points, up to ~1e3 far out).
     assert rep.max_f_rel_near <= 1e-12 and rep.max_slope_rel_near <= 1e-11, rep
     assert rep.max_f_rel <= 1e-6 and rep.max_slope_rel <= 1e-6, rep
-    assert rep.max_iter_rel <= 1e-11, rep       # gg, dgg, gradient test
+    assert rep.max_iter_rel <= iter_tol, rep    # gg, dgg, gradient test
     assert rep.max_vec_rel <= 1e-8, rep         # one iteration of drift in p / xi (inf-norm relative)
     if not (r.status[0] & capi.STATUS_ROLLED_BACK):
         assert rep.fret == r.fret[0]
@@ -154,8 +154,18 @@ def test_first_line_minimisation_prefix(name, gctx):
     pp = make()
     _, r, _ = solve(gctx, pp, maxiters=1)
     ro = O.OracleProblem(pp).cgd(maxiters=1)
-    assert abs(r.fret[0] - ro.fret) <= 1e-6 * abs(ro.fret)          # Brent's tol is 3e-8 in the step
-    assert abs(r.delta[0] - ro.delta) <= 1e-6 * abs(ro.delta)
+    # SURVEY 8c proposed 1e-10 (the value is second order in the step at a line minimum).  Measured: two correct
+    # roundings of the SAME algorithm -- the oracle against the oracle started one unit in the last place away,
+    # or with its second derivative formula -- end one line minimisation 1e-14 .. 1e-7 apart with (nearly)
+    # identical evaluation counts: Dbrent places its steps by slopes and compares nearly equal values, and
+    # their rounding noise near the minimum moves the last trial points.  The bar is therefore a few times
+    # Brent's 3e-8, and the device must be no further from the oracle than the oracle is from itself (x 10).
+    rng = np.random.default_rng(7)
+    own = max(abs(O.OracleProblem(pp).cgd(x=ulp_perturbed(pp.x0, rng), maxiters=1).fret - ro.fret) / abs(ro.fret) for _ in range(8))
+    dev = abs(r.fret[0] - ro.fret) / abs(ro.fret)
+    print("%s: one line minimisation, device against oracle %.2e, oracle against itself (8 one-ulp starts, max) %.2e" % (name, dev, own))
+    assert dev <= 3e-7 and dev <= 10.0 * max(own, 3e-8), (dev, own)
+    assert abs(r.delta[0] - ro.delta) <= 3e-7 * abs(ro.delta)
     assert abs(int(r.nfeval[0]) - ro.nfeval) <= 3 and r.iters[0] == ro.iters == 0
 
 
@@ -202,7 +212,19 @@ def device_end_values(gctx, pp, starts, maxiters):
     return np.array(out)
 
 
-BAND_MARGIN = 0.5   # the oracle's band [min, max] is widened by this fraction of its width on either side
+def _end_value_fixture():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "end_values.json")) as fh:
+        return json.load(fh)
+
+
+def _ks2(a, b):
+    """two-sample Kolmogorov-Smirnov statistic and its critical value at alpha = 0.001"""
+    a, b = np.sort(a), np.sort(b)
+    allv = np.concatenate([a, b])
+    d = np.max(np.abs(np.searchsorted(a, allv, side="right") / len(a) - np.searchsorted(b, allv, side="right") / len(b)))
+    return d, 1.9495 * np.sqrt((len(a) + len(b)) / (len(a) * len(b)))
 
 
 @pytest.mark.parametrize("key", ["ladybug_5_30", "ladybug_full"])
@@ -210,35 +232,66 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     """BASELINE configs 3 and 4.  25 unconverged CG iterations are a chaotic map of the start (a one-ulp
     change of x0 moves the end value by percents, for the reference itself too), so the end value of ONE
     run cannot be compared to 1e-6 between implementations that round differently.  What can: the
-    DISTRIBUTION of end values over one-ulp-perturbed starts.  16 such starts on the device, 8 (full
-    ladybug) or 32 on the oracle (which reproduces the reference's recorded end value bit for bit from
-    the unperturbed start): the device's median and quartiles must lie inside the oracle's band
-    widened by BAND_MARGIN of its width, at most two of its sixteen values outside it (long tails), the
-    medians within half a band width of each other, and the reference's recorded value inside the
-    device's band widened likewise."""
+    DISTRIBUTION of end values over one-ulp-perturbed starts.  The oracle's sample is a committed fixture
+    (tests/golden/end_values.json, 128 / 64 values from the reference-faithful oracle, generated by
+    tests/golden/make_end_values.py; its unperturbed entry IS the reference's recorded end value); the
+    device draws 64 values from OTHER one-ulp starts (independent samples).  Asserted: two-sample
+    Kolmogorov-Smirnov at alpha = 0.001, the device's median inside the oracle's interquartile range,
+    and the reference's recorded value inside the device's range."""
     c = golden["cgd"][key]
+    fx = _end_value_fixture()
+    oe = np.array(fx[key]["end_values"])
+    assert oe[0] == c["fret"] and len(oe) >= 64                   # the unperturbed oracle run IS the reference's
     pp = P.load_bal(ncams=c["ncams"], npts=c["npts"])
-    rng = np.random.default_rng(20260929)
-    n_or = 8 if key == "ladybug_full" else 32
-    ostarts = [pp.x0] + [ulp_perturbed(pp.x0, rng) for _ in range(n_or - 1)]
-    dstarts = [pp.x0] + [ulp_perturbed(pp.x0, rng) for _ in range(15)]
-    oe = oracle_end_values(pp, ostarts, c["maxiters"])
-    assert oe[0] == c["fret"]                                      # the unperturbed oracle run IS the reference's
+    dstarts = [ulp_perturbed(pp.x0, np.random.default_rng([fx["seed"], 100000 + k])) for k in range(64)]
     de = device_end_values(gctx, pp, dstarts, c["maxiters"])
-    olo, ohi, dlo, dhi = oe.min(), oe.max(), de.min(), de.max()
-    print("%s end values after %d iterations: oracle (%d) [%.6g, %.6g, %.6g] device (16) [%.6g, %.6g, %.6g] (min, median, max), reference %.6g" % (
-        key, c["maxiters"], n_or, olo, np.median(oe), ohi, dlo, np.median(de), dhi, c["fret"]))
-    assert ohi - olo > 1e-4 * olo and dhi - dlo > 1e-4 * dlo       # the bands are real: chaos, on both sides
-    w = BAND_MARGIN * (ohi - olo)
-    # the bulk of the device's values lies inside the oracle's widened band (the tails of these
-    # distributions are long: at most two of sixteen may fall outside), its median and quartiles do
-    outside = int(np.sum((de < olo - w) | (de > ohi + w)))
-    assert outside <= 2, (oe, de)
-    for qd in np.quantile(de, [0.25, 0.5, 0.75]):
-        assert olo - w <= qd <= ohi + w, (oe, de)
-    assert abs(np.median(de) - np.median(oe)) <= 0.5 * (ohi - olo)
-    wd = BAND_MARGIN * (dhi - dlo)
-    assert dlo - wd <= c["fret"] <= dhi + wd, (c["fret"], de)
+    d, crit = _ks2(de, oe)
+    oq, dq = np.quantile(oe, [0.25, 0.5, 0.75]), np.quantile(de, [0.25, 0.5, 0.75])
+    print("%s end values after %d iterations: oracle (%d) quartiles %s range [%.6g, %.6g]; device (64) quartiles %s range [%.6g, %.6g]; "
+          "KS %.3f (critical %.3f); reference %.6g" % (key, c["maxiters"], len(oe), oq, oe.min(), oe.max(), dq, de.min(), de.max(), d, crit, c["fret"]))
+    assert de.max() - de.min() > 1e-4 * de.min()                  # chaos on the device's side too
+    assert d <= crit, (d, crit)
+    assert oq[0] <= dq[1] <= oq[2], (oq, dq)
+    assert de.min() <= c["fret"] <= de.max(), (c["fret"], de.min(), de.max())
+
+
+def test_prefix_values_part_from_the_oracle_at_the_rate_of_chaos(gctx):
+    """The curve that makes "chaos, not a bug" falsifiable on the device itself: |f_k(device) - f_k(oracle)| / f_k
+    for k = 1 .. 25 CG iterations from the SAME start, next to the oracle's curves against ITSELF (committed
+    fixture, tests/golden/make_end_values.py): from eight starts one unit in the last place away -- there the
+    VALUES f differ in the last place, as they do between oracle and device -- and with only its derivative
+    formula exchanged (values bit-identical, slopes 2e-14 apart: a calm curve, printed for contrast).
+    Measured: one line minimisation is reproducible to 1e-9 .. 1e-7 between two correct roundings, not to the
+    1e-14 a second-order argument suggests (Dbrent places its steps by slopes and compares nearly equal
+    values); on the full problem the oracle is 4e-5 .. 5e-3 from itself after TWO iterations and saturated at
+    1e-2 after three (device: 4e-4, 4e-2).  Asserted: at every k the device's envelope (running maximum) is
+    within a factor 10 of the oracle family's -- the device is as far from the oracle as the oracle is from
+    itself; an error in an evaluation would show at k = 1 --, and the curves do saturate (so the distribution
+    test is the right comparison at k = 25)."""
+    fx = _end_value_fixture()
+    for key, kw in (("ladybug_5_30", dict(ncams=5, npts=30)), ("ladybug_full", {})):
+        pp = P.load_bal(**kw)
+        of = np.array(fx[key]["prefix_values_from_x0"])
+        calm = np.abs(of - np.array(fx[key]["prefix_values_from_x0_adjoint_derivative"])) / np.abs(of)
+        own = np.max(np.abs(of - np.array(fx[key]["prefix_values_from_ulp_starts_1_to_8"])) / np.abs(of), axis=0)
+        g = capi.Problem(gctx, pp)
+        fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
+        plan = capi.Plan(g, np.array([0, len(fv)]), fv, np.array([0, len(fc)]), fc)
+        rel = []
+        for k in range(1, 26):
+            plan.set_start(pp.x0)
+            plan.solve(k, 3e-8)
+            rel.append(abs(plan.fetch().fret[0] - of[k - 1]) / abs(of[k - 1]))
+        plan.close()
+        rel = np.array(rel)
+        env, env_own = np.maximum.accumulate(rel), np.maximum.accumulate(own)
+        print(key, "device against oracle, k = 1..25:           ", " ".join("%.1e" % v for v in rel))
+        print(key, "oracle against itself (8 one-ulp starts, max):", " ".join("%.1e" % v for v in own))
+        print(key, "oracle against itself (derivative exchanged): ", " ".join("%.1e" % v for v in calm))
+        assert rel[0] <= 3e-7, rel[0]
+        for k in range(25):
+            assert env[k] <= 10.0 * max(env_own[k], 3e-8), (key, k + 1, env[k], env_own[k])
+        assert env[-1] >= 1e-6 and env_own[-1] >= 1e-6      # the trajectories do separate: chaos, on both sides
 
 
 def test_ladybug_full_objective(golden, gctx):
@@ -973,3 +1026,67 @@ def test_pipelined_groups_move_to_the_line_minimum_before_an_ftol_exit(gctx):
         fo = o.eval()
         assert abs(fo - out["pipelined"][0].fret[0]) <= 1e-12 * abs(fo), (ftol, fo)
     assert n_ftol >= 8, n_ftol      # the exit this test is about
+
+
+def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
+    """solver_lds.hpp keeps a component's variables in LDS slots instead of forming every trial point in
+    global memory (solver_wg.hpp).  The factor arithmetic and the orders of all sums are the same, so when
+    the slots are the free variables in their listed order (every block free, cameras before points,
+    ascending ids) every bit of the result is the same: synthetic components under three workgroup sizes,
+    with per-factor rotations and with records.  With constants among the slots (ladybug's camera
+    components: points fixed; its point components: cameras fixed; a sub-function with partly free
+    blocks) the per-factor values are still the same bits and only the Polak-Ribiere sums run over the
+    slots in another grouping: there the replay check against the oracle is the judge."""
+    syn = P.make_synthetic_ba(40, 5, 64, obs_per_pt=3)
+    csr = (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id)
+    g = capi.Problem(gctx, syn)
+
+    def run(opts, comps=csr, prob=g, pp=syn, iters=25, trace=0):
+        prob.set_x(pp.x0)
+        plan = capi.Plan(prob, *comps)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        if trace:
+            plan.set_option("trace_records", trace)
+            plan.set_option("dump_iters", iters)
+        plan.set_start(None)
+        plan.solve(iters, 3e-8)
+        r = plan.fetch()
+        tr = [(plan.get_trace(c, trace)[0], plan.get_vectors(c, iters)) for c in range(len(comps[0]) - 1)] if trace else None
+        out = (r, prob.get_x(), plan.last_kernel_ms()[1], tr)
+        plan.close()
+        return out
+    for threads in (128, 256, 768):
+        for rot in (0, 2):
+            ra, xa, _, _ = run({"lds_resident": 0, "block_threads": threads, "camera_records": rot})
+            rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0})
+            assert nb == 1
+            assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (threads, rot)
+            assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.status, rb.status), (threads, rot)
+            assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (threads, rot)
+    assert np.all(ra.delta < 0)
+    # constants among the slots
+    lb = P.load_bal(ncams=49, npts=500)
+    cams, pts = P.ba_alternation_plans(lb)
+    gl = capi.Problem(gctx, lb)
+    for comps, base in ((cams, {"coop_group_min_factors": 0, "coop_min_factors": 0}), (pts, {"row_min_components": 1 << 30, "quad_min_components": 1 << 30})):
+        ra, xa, _, _ = run({**base, "lds_resident": 0}, comps, gl, lb, 12)
+        rb, xb, _, trb = run({**base, "lds_resident": 1}, comps, gl, lb, 12, trace=2048)
+        # same decisions as long as the sums agree to the last bit; they may part in the last place -- population check
+        assert np.all(rb.delta <= 0) and abs(rb.fret.sum() - ra.fret.sum()) <= 0.05 * abs(ra.fret.sum())
+        for c in (0, len(comps[0]) // 2, len(comps[0]) - 2):
+            fv = comps[1][comps[0][c]:comps[0][c + 1]]
+            fc = comps[3][comps[2][c]:comps[2][c + 1]]
+            sub = type("R", (), {"status": rb.status[c:c + 1], "iters": rb.iters[c:c + 1], "fret": rb.fret[c:c + 1]})
+            # (a camera's nine gradient entries are sums of 361..906 partials that cancel to a few digits -- in the last iterations before a tolerance exit to very few: 1e-8; observed 1.6e-9)
+            check_replay(lb, trb[c], sub, 12, free_vid=fv, fac_id=fc, x=lb.x0[fv], iter_tol=1e-8)
+    # partly free blocks: two of a camera's nine, one of a point's three held constant
+    free = np.array([v for v in range(lb.nvars) if not (v < 441 and v % 9 in (6, 8)) and not (v >= 441 and v % 3 == 1 and v % 5 == 0)], dtype=np.int64)
+    one = (np.array([0, len(free)]), free, np.array([0, lb.nfac]), np.arange(lb.nfac, dtype=np.int64))
+    base = {"coop_min_factors": 0, "coop_group_min_factors": 0}
+    ra, xa, _, _ = run({**base, "lds_resident": 0}, one, gl, lb, 8)
+    rb, xb, _, trb = run({**base, "lds_resident": 1}, one, gl, lb, 8, trace=4096)
+    if lb.nvars * 44 < 150 * 1024:     # (fits the LDS: the new solver ran)
+        check_replay(lb, trb[0], rb, 8, free_vid=free, fac_id=one[3], x=lb.x0[free])
+        const = np.setdiff1d(np.arange(lb.nvars), free)
+        assert np.array_equal(xb[const], lb.x0[const])
