@@ -72,8 +72,18 @@ struct PlanView {
     const int* ls_free;   // [slots] local free index, -1 = constant
     const int* ls_ncb;    // [ncomp] camera blocks of the component
     const double2* ls_obs;    // [nfac_total] observation of every listed factor (copy in listed order: no indirection in the trial loop)
-    const int* ls_gperm;      // [nfac_total] per component: local indices of its listed factors sorted by camera block (stable)
+    int ls_cam_gfac;          // option lds_camera_sums = 0: camera partials through gfac[] like solver_wg.hpp (bit-for-bit comparisons)
+    const int* ls_gptr;       // [ncomp + 1] wave-chunks (64 entries) of ls_gperm, per component
+    const int* ls_gperm;      // per component: local indices of its listed factors grouped by camera block (listed order inside a
+                          // group), every group padded to whole chunks with -1
     const unsigned* ls_fidx;  // [nfac_total] listed factor -> camera block | point block << 12 (block numbers within the component)
+    // point-major streaming solver (solver_ptm.hpp): the same slot tables, point blocks ordered by their number of factors
+    const int* pm_pt0;    // [ncomp] a component's first point block in pm_rec
+    const int* pm_rank;   // [ncomp] its rank among the streaming components (pm_pptr has one more entry than blocks per component)
+    const int* pm_pptr;   // a point block's factors: entries [pm_pptr[b + rank], pm_pptr[b + rank + 1]) of pm_cam / pm_obs
+    double* pm_rec;       // [blocks][12] p, xi, lo, hi of a point block's three variables
+    const int* pm_cam;    // [entries] camera block (number within the component) ...
+    const double2* pm_obs;  // ... and observation of a point's factor
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

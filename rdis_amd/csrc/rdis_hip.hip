@@ -20,6 +20,7 @@
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
 #include "solver_lds.hpp"
+#include "solver_ptm.hpp"
 #include "solver_pipe.hpp"
 #include "solver_quad.hpp"
 #include "solver_stream.hpp"
@@ -195,14 +196,23 @@ struct rdis_hip_plan {
     int64_t coop_group_min_factors = 256;  // ... for every component of at least this many factors when all their groups fit the device at once
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
     int rest_lds = 0;                 // the LAST rest_lds entries run on the LDS-resident solver (solver_lds.hpp)
+    int rest_ptm = 0;                 // the rest_ptm entries before them on the point-major streaming solver (solver_ptm.hpp)
+    int ptm_stream = 1;               // option "ptm_stream": 0 = never
+    int ptm_threads = 0;              // option "ptm_threads": its workgroup size, 0 = auto
+    int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
+    int64_t pm_blocks = 0, pm_entries = 0;
+    std::vector<int> h_pm_jg;
+    DevBuf pm_rec, pm_cam, pm_obs;
+    size_t off_pm_pt0 = 0, off_pm_rank = 0, off_pm_pptr = 0, off_pm_jg = 0;
     int lds_resident = 1;             // option "lds_resident": 0 = never
     int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
-    int lds_ns_cap = 0, lds_ncb_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
+    int lds_camera_sums = 1;          // option "lds_camera_sums": 0 = camera partials through gfac[] like the plain batch solver
+    int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
     DevBuf lds_ints, lds_obs;
     std::vector<int> h_lds_ints;
-    size_t off_ls_ptr = 0, off_ls_vid = 0, off_ls_free = 0, off_ls_ncb = 0, off_ls_fidx = 0, off_ls_gperm = 0;
+    size_t off_ls_ptr = 0, off_ls_vid = 0, off_ls_free = 0, off_ls_ncb = 0, off_ls_fidx = 0, off_ls_gperm = 0, off_ls_gptr = 0;
     int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
     int64_t row_min_components = 4096; // option: sixteen lanes each from this many tiny components (below: a workgroup each)
     int quad_max_vars = QUAD_MAX_VARS; // option "quad_max_vars": 0 = never use the quad solver
@@ -238,7 +248,10 @@ struct rdis_hip_plan {
         v.ls_ptr = li + off_ls_ptr; v.ls_vid = li + off_ls_vid; v.ls_free = li + off_ls_free; v.ls_ncb = li + off_ls_ncb;
         v.ls_fidx = reinterpret_cast<const unsigned*>(li + off_ls_fidx);
         v.ls_obs = lds_obs.as<double2>();
-        v.ls_gperm = li + off_ls_gperm;
+        v.ls_gperm = li + off_ls_gperm; v.ls_gptr = li + off_ls_gptr;
+        v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
+        v.pm_pt0 = li + off_pm_pt0; v.pm_rank = li + off_pm_rank; v.pm_pptr = li + off_pm_pptr;
+        v.pm_rec = pm_rec.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -663,7 +676,8 @@ int plan_alloc(rdis_hip_plan* L, DevBuf& b, size_t bytes) {
     if (!L->transient) return dalloc(p->ctx, b, bytes);
     b.release();
     bytes = align_up(std::max<size_t>(bytes, 8), 256);
-    if (p->arena_used + bytes > p->arena.bytes) return fail(p->ctx, RDIS_HIP_ENOMEM, "plan arena exhausted (internal sizing error)");
+    // (the arena is sized from bounds, plan_create_impl; what exceeds them -- rare shapes -- gets memory of its own)
+    if (p->arena_used + bytes > p->arena.bytes) return dalloc(p->ctx, b, bytes);
     b.p = static_cast<char*>(p->arena.p) + p->arena_used;
     b.bytes = bytes;
     b.owned = false;
@@ -825,7 +839,8 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         // lane_var / wave_var of the cooperative groups: at most 3 x the lanes a component needs, rounded up to workgroups
         need += 5 * (3 * (size_t)(nfac + nfree) + 2048 * (size_t)std::min<int64_t>(ncomp, 4096)) + align_up(lanes_max * 4, 256);
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
-        need += align_up((size_t)(2 * (12 * nfac + 9 * nfree) + 2 * nfac + 2 * ncomp + 2) * 4, 256) + align_up((size_t)nfac * 16, 256) + 256;   // slot tables, observations of the LDS-resident solver
+        need += align_up((size_t)(2 * (12 * nfac + 9 * nfree) + 2 * nfac + 64 * (nfac / 64 + std::min<int64_t>(nfac, nfree / 9 + 1) + ncomp) + 3 * ncomp + 3) * 4, 256) + align_up((size_t)nfac * 16, 256) + 256;   // slot tables, observations of the LDS-resident solver
+        need += align_up((size_t)(2 * nfac + nfree / 3 + 3 * ncomp + 16) * 4, 256) + align_up((size_t)(nfac + 1) * 20, 256) + align_up((size_t)(12 * nfac + 4 * nfree + 16) * 8, 256);   // ... of the streaming solver
         need += (size_t)COOP_MAX_GROUPS * (4 * 256 + sizeof(CoopGroup)) + (size_t)COOP_MAX_WG * 4 + lanes_max * 4 + 64 * 256;  // groups, their alignment slack
         if (p->arena.bytes < need) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -922,6 +937,13 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->coop_pipeline = value != 0;
     } else if (n == "lds_resident") {
         L->lds_resident = value != 0;
+    } else if (n == "ptm_stream") {
+        L->ptm_stream = value != 0;
+    } else if (n == "ptm_threads") {
+        if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
+        L->ptm_threads = (int)value;
+    } else if (n == "lds_camera_sums") {
+        L->lds_camera_sums = value != 0;
     } else if (n == "lds_rot") {
         if (value < -1 || value > 1) return fail(c, RDIS_HIP_EINVAL, "lds_rot must be -1, 0 or 1");
         L->lds_rot = (int)value;
@@ -1153,101 +1175,164 @@ int prepare_partition(rdis_hip_plan* L) {
         for (int cc : L->h_rest) mf = std::max<int64_t>(mf, L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc]);
         L->rest_rot_mode = camfix ? ROT_CAMFIX : (L->camera_records == 2 || mf > 2048) ? ROT_RECORDS : ROT_PER_FACTOR;
     }
-    // The LDS-resident solver (solver_lds.hpp) takes the bundle-adjustment components of the batch list
-    // whose variables -- free ones and the constants their factors read -- fit a compute unit's LDS as
-    // slots: camera blocks (9 slots each, ascending by id), then point blocks (3 each, ascending).
-    // They move to the end of the list; what does not fit stays with solver_wg.hpp.
-    L->rest_lds = 0;
+    // Slot tables.  The LDS-resident solver (solver_lds.hpp) takes the bundle-adjustment components of the
+    // batch list whose variables -- free ones and the constants their factors read -- fit a compute unit's
+    // LDS as slots: camera blocks (9 slots each, ascending by id), then point blocks (3 each, ascending).
+    // Of the others, those whose CAMERA blocks fit go to the point-major streaming solver (solver_ptm.hpp:
+    // point blocks as records in HBM, ordered by their number of factors, descending).  Both move to the
+    // end of the list (streaming ones first); what fits neither stays with solver_wg.hpp.
+    L->rest_lds = L->rest_ptm = 0;
     L->h_lds_ints.clear();
-    L->lds_ns_cap = L->lds_ncb_cap = 0;
+    L->h_pm_jg.clear();
+    L->lds_ns_cap = L->lds_ncb_cap = L->lds_chunk_cap = L->ptm_ncb_cap = L->ptm_chunk_cap = 0;
     L->lds_max_factors = 0;
-    if (p->kind == KIND_BA && L->lds_resident != 0 && p->ncam_blocks > 0 && (int)L->h_rest.size() > L->rest_tiny) {
+    L->pm_blocks = L->pm_entries = 0;
+    if (p->kind == KIND_BA && (L->lds_resident != 0 || L->ptm_stream != 0) && p->ncam_blocks > 0 && (int)L->h_rest.size() > L->rest_tiny) {
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
-        std::vector<int> ls_ptr((size_t)L->ncomp + 1, 0), ls_len((size_t)L->ncomp, 0), ls_ncb((size_t)L->ncomp, 0), ls_vid, ls_free;
-        std::vector<int> ls_fidx((size_t)L->nfac, 0), ls_gperm((size_t)L->nfac, 0);
-        std::vector<char> fits((size_t)L->ncomp, 0);
-        std::vector<int> cams, pts;
+        const size_t nc = (size_t)L->ncomp;
+        std::vector<char> kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
+        std::vector<int> ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), pm_rank(nc, 0), ls_fidx((size_t)L->nfac, 0);
+        std::vector<std::vector<int>> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
+        std::vector<int> cams, pts, deg;
         for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
             const int cc = L->h_rest[r];
             const int f0 = L->h_free_ptr[(size_t)cc], f1 = L->h_free_ptr[(size_t)cc + 1];
             const int c0 = L->h_fac_ptr[(size_t)cc], c1 = L->h_fac_ptr[(size_t)cc + 1];
-            if (c1 == c0) continue;   // (an empty factor list needs no table; such a component may ride with either solver)
+            if (c1 == c0) continue;   // (an empty factor list needs no table: solver_wg.hpp returns 0 for it)
             const int stamp = ++p->stamp;
             cams.clear(); pts.clear();
             auto note = [&](int b, std::vector<int>& list) {
                 if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; list.push_back(b); }
             };
-            bool ok = true;
+            bool ok = true, free_cam = false;
             for (int j = c0; j < c1; ++j) { const int f = L->h_fac_id[(size_t)j]; note(p->h_cam[(size_t)f], cams); note(p->h_pt[(size_t)f], pts); }
             for (int i = f0; i < f1 && ok; ++i) {
                 const int v = L->h_free_vid[(size_t)i];
-                if (p->h_block_of[(size_t)v] >= 0) note(p->h_block_of[(size_t)v], cams);
+                if (p->h_block_of[(size_t)v] >= 0) { note(p->h_block_of[(size_t)v], cams); free_cam = true; }
                 else if (p->h_ptblock_of[(size_t)v] >= 0) note(p->h_ptblock_of[(size_t)v], pts);
                 else ok = false;   // a variable no factor of the problem reads: no block to put it in
             }
-            const int64_t ns = 9ll * (int64_t)cams.size() + 3ll * (int64_t)pts.size();
-            ok = ok && cams.size() <= 4095 && pts.size() < (1u << 20) && lds_bytes_for((int)ns, (int)cams.size()) <= (size_t)LDS_MAX_BYTES;
-            if (!ok) continue;
+            if (!ok || cams.size() > 4095 || pts.size() >= (1u << 20)) continue;
+            const int ncb = (int)cams.size(), npb = (int)pts.size(), ns = 9 * ncb + 3 * npb, m = c1 - c0;
             std::sort(cams.begin(), cams.end());
-            std::sort(pts.begin(), pts.end());
-            for (size_t k = 0; k < cams.size(); ++k) p->h_blk_idx[(size_t)cams[k]] = (int)k;
-            for (size_t k = 0; k < pts.size(); ++k) p->h_blk_idx[(size_t)pts[k]] = (int)k;
+            for (int k = 0; k < ncb; ++k) p->h_blk_idx[(size_t)cams[(size_t)k]] = k;
+            // the order of the gradient pass: camera by camera (listed order within a camera), whole waves per camera --
+            // where a camera variable is free; otherwise nothing is summed per camera and the listed order serves
+            std::vector<int>& gp = gp_of[(size_t)cc];
+            if (free_cam) {
+                std::vector<int> start((size_t)ncb + 1, 0);
+                for (int j = c0; j < c1; ++j) ++start[(size_t)p->h_blk_idx[(size_t)p->h_cam[(size_t)L->h_fac_id[(size_t)j]]] + 1];
+                for (int k = 0; k < ncb; ++k) start[(size_t)k + 1] = start[(size_t)k] + (start[(size_t)k + 1] + 63) / 64 * 64;
+                gp.assign((size_t)start[(size_t)ncb], -1);
+                for (int j = c0; j < c1; ++j) gp[(size_t)start[(size_t)p->h_blk_idx[(size_t)p->h_cam[(size_t)L->h_fac_id[(size_t)j]]]]++] = j - c0;
+            } else {
+                gp.assign((size_t)((m + 63) / 64 * 64), -1);
+                std::iota(gp.begin(), gp.begin() + m, 0);
+            }
+            const int nchunk = (int)gp.size() / 64;
+            const bool fits_lds = L->lds_resident != 0 && lds_bytes_for(ns, ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+            const bool fits_ptm = !fits_lds && L->ptm_stream != 0 && ptm_bytes_for(ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+            if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
+            if (fits_lds) std::sort(pts.begin(), pts.end());
+            else {   // by number of factors, descending (ties: ascending id): the lanes of a wave run loops of equal length
+                std::sort(pts.begin(), pts.end());
+                for (int k = 0; k < npb; ++k) p->h_blk_idx[(size_t)pts[(size_t)k]] = k;
+                deg.assign((size_t)npb, 0);
+                for (int j = c0; j < c1; ++j) ++deg[(size_t)p->h_blk_idx[(size_t)p->h_pt[(size_t)L->h_fac_id[(size_t)j]]]];
+                std::vector<int> ord((size_t)npb);
+                std::iota(ord.begin(), ord.end(), 0);
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return deg[(size_t)a] > deg[(size_t)b]; });
+                std::vector<int> pts2((size_t)npb);
+                for (int k = 0; k < npb; ++k) pts2[(size_t)k] = pts[(size_t)ord[(size_t)k]];
+                pts.swap(pts2);
+            }
+            for (int k = 0; k < npb; ++k) p->h_blk_idx[(size_t)pts[(size_t)k]] = k;
             // local free index of the component's variables (the per-problem arrays are valid for one stamp)
             for (int i = f0; i < f1; ++i) { const int v = L->h_free_vid[(size_t)i]; p->h_owner_stamp[(size_t)v] = stamp; p->h_local[(size_t)v] = i - f0; }
-            ls_ptr[(size_t)cc] = (int)ls_vid.size();   // (start in append order; turned into a CSR over all components below)
-            ls_len[(size_t)cc] = (int)ns;
-            for (int b : cams) for (int k = 0; k < 9; ++k) { ls_vid.push_back(b + k); ls_free.push_back(p->h_owner_stamp[(size_t)(b + k)] == stamp ? p->h_local[(size_t)(b + k)] : -1); }
-            for (int b : pts) for (int k = 0; k < 3; ++k) { ls_vid.push_back(b + k); ls_free.push_back(p->h_owner_stamp[(size_t)(b + k)] == stamp ? p->h_local[(size_t)(b + k)] : -1); }
+            std::vector<int>& sv = vid_of[(size_t)cc];
+            std::vector<int>& sf = free_of[(size_t)cc];
+            sv.reserve((size_t)ns); sf.reserve((size_t)ns);
+            auto slot = [&](int v) { sv.push_back(v); sf.push_back(p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1); };
+            for (int b : cams) for (int k = 0; k < 9; ++k) slot(b + k);
+            for (int b : pts) for (int k = 0; k < 3; ++k) slot(b + k);
             for (int j = c0; j < c1; ++j) {
                 const int f = L->h_fac_id[(size_t)j];
                 ls_fidx[(size_t)j] = (int)((unsigned)p->h_blk_idx[(size_t)p->h_cam[(size_t)f]] | ((unsigned)p->h_blk_idx[(size_t)p->h_pt[(size_t)f]] << 12));
             }
-            {   // the order of the gradient pass: by camera block, listed order within a camera
-                int* gp = ls_gperm.data() + c0;
-                std::iota(gp, gp + (c1 - c0), 0);
-                std::stable_sort(gp, gp + (c1 - c0), [&](int a, int b) { return (ls_fidx[(size_t)(c0 + a)] & 0xFFF) < (ls_fidx[(size_t)(c0 + b)] & 0xFFF); });
+            ls_ncb[(size_t)cc] = ncb;
+            ls_gcount[(size_t)cc] = nchunk;
+            if (fits_lds) {
+                kind_of[(size_t)cc] = 1;
+                L->lds_ns_cap = std::max(L->lds_ns_cap, ns);
+                L->lds_ncb_cap = std::max(L->lds_ncb_cap, ncb);
+                L->lds_chunk_cap = std::max(L->lds_chunk_cap, nchunk);
+                L->lds_max_factors = std::max<int64_t>(L->lds_max_factors, m);
+            } else {
+                kind_of[(size_t)cc] = 2;
+                L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, ncb);
+                L->ptm_chunk_cap = std::max(L->ptm_chunk_cap, nchunk);
+                // the point's factors, in listed order (a CSR over the point blocks in their slot order)
+                std::vector<int>& pp = pptr_of[(size_t)cc];
+                pp.assign((size_t)npb + 1, 0);
+                for (int j = c0; j < c1; ++j) ++pp[(size_t)(((unsigned)ls_fidx[(size_t)j]) >> 12) + 1];
+                for (int k = 0; k < npb; ++k) pp[(size_t)k + 1] += pp[(size_t)k];
             }
-            ls_ncb[(size_t)cc] = (int)cams.size();
-            fits[(size_t)cc] = 1;
-            L->lds_ns_cap = std::max(L->lds_ns_cap, (int)ns);
-            L->lds_ncb_cap = std::max(L->lds_ncb_cap, (int)cams.size());
-            L->lds_max_factors = std::max<int64_t>(L->lds_max_factors, c1 - c0);
         }
-        // the two maxima may come from different components: the launch's LDS must hold both
-        if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap) > (size_t)LDS_MAX_BYTES) {
-            std::fill(fits.begin(), fits.end(), 0);
-            L->lds_ns_cap = L->lds_ncb_cap = 0;
-        }
-        if (L->lds_ns_cap > 0) {
-            auto mid = std::stable_partition(L->h_rest.begin() + L->rest_tiny, L->h_rest.end(), [&](int cc) { return !fits[(size_t)cc]; });
-            L->rest_lds = (int)(L->h_rest.end() - mid);
-            // the tables were appended in list order (heaviest first): re-emit them in component order, so that
-            // ls_ptr is a plain CSR in which a component without a table has an empty range
-            std::vector<int> ptr2((size_t)L->ncomp + 1, 0), vid2, free2;
-            vid2.reserve(ls_vid.size()); free2.reserve(ls_free.size());
-            for (int64_t cc = 0; cc < L->ncomp; ++cc) {
-                ptr2[(size_t)cc] = (int)vid2.size();
-                if (!fits[(size_t)cc]) continue;
-                const int b0 = ls_ptr[(size_t)cc], len = ls_len[(size_t)cc];
-                vid2.insert(vid2.end(), ls_vid.begin() + b0, ls_vid.begin() + b0 + len);
-                free2.insert(free2.end(), ls_free.begin() + b0, ls_free.begin() + b0 + len);
+        // (the maxima of a launch may come from different components: its LDS must hold them together)
+        if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap) > (size_t)LDS_MAX_BYTES)
+            for (size_t cc = 0; cc < nc; ++cc) if (kind_of[cc] == 1) kind_of[cc] = 0;
+        if (L->ptm_ncb_cap > 0 && ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap) > (size_t)LDS_MAX_BYTES)
+            for (size_t cc = 0; cc < nc; ++cc) if (kind_of[cc] == 2) kind_of[cc] = 0;
+        auto first_other = std::stable_partition(L->h_rest.begin() + L->rest_tiny, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 0; });
+        auto first_lds = std::stable_partition(first_other, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 2; });
+        L->rest_ptm = (int)(first_lds - first_other);
+        L->rest_lds = (int)(L->h_rest.end() - first_lds);
+        if (L->rest_ptm + L->rest_lds > 0) {
+            // one int32 block, tables in component order (a component without one has empty ranges)
+            std::vector<int> sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm, pptr;
+            for (size_t cc = 0; cc < nc; ++cc) {
+                const bool has = kind_of[cc] != 0;
+                sptr[cc + 1] = sptr[cc] + (has ? (int)vid_of[cc].size() : 0);
+                gptr[cc + 1] = gptr[cc] + (has ? ls_gcount[cc] : 0);
+                if (!has) continue;
+                svid.insert(svid.end(), vid_of[cc].begin(), vid_of[cc].end());
+                sfree.insert(sfree.end(), free_of[cc].begin(), free_of[cc].end());
+                gperm.insert(gperm.end(), gp_of[cc].begin(), gp_of[cc].end());
             }
-            ptr2[(size_t)L->ncomp] = (int)vid2.size();
-            ls_vid.swap(vid2); ls_free.swap(free2);
+            // point-major factor order of the streaming components: entry -> listed factor (plan-wide index)
+            int rank = 0;
+            for (size_t cc = 0; cc < nc; ++cc) {
+                if (kind_of[cc] != 2) continue;
+                const int c0 = L->h_fac_ptr[cc], c1 = L->h_fac_ptr[cc + 1], npb = (int)pptr_of[cc].size() - 1;
+                pm_pt0[cc] = (int)L->pm_blocks;
+                pm_rank[cc] = rank++;
+                const int e0 = (int)L->h_pm_jg.size();
+                std::vector<int> fill(pptr_of[cc].begin(), pptr_of[cc].end() - 1);
+                L->h_pm_jg.resize((size_t)e0 + (size_t)(c1 - c0));
+                for (int j = c0; j < c1; ++j) L->h_pm_jg[(size_t)e0 + (size_t)fill[(size_t)(((unsigned)ls_fidx[(size_t)j]) >> 12)]++] = j;
+                for (int k = 0; k <= npb; ++k) pptr.push_back(e0 + pptr_of[cc][(size_t)k]);
+                L->pm_blocks += npb;
+            }
+            L->pm_entries = (int64_t)L->h_pm_jg.size();
             std::vector<int>& blk = L->h_lds_ints;
             auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
-            L->off_ls_ptr = put(ptr2); L->off_ls_vid = put(ls_vid); L->off_ls_free = put(ls_free);
-            L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gperm = put(ls_gperm);
-            // rotations: no camera variable free among these components -> records, read only; otherwise records that
-            // follow the trial point when a lane has several factors per camera and trial (else each factor forms its own)
-            bool camfix = true;
-            for (size_t r = L->h_rest.size() - (size_t)L->rest_lds; r < L->h_rest.size() && camfix; ++r) {
-                const int cc = L->h_rest[r];
-                for (int k = L->h_free_ptr[(size_t)cc]; k < L->h_free_ptr[(size_t)cc + 1] && camfix; ++k)
-                    camfix = p->h_block_of[(size_t)L->h_free_vid[(size_t)k]] < 0;
-            }
+            L->off_ls_ptr = put(sptr); L->off_ls_vid = put(svid); L->off_ls_free = put(sfree);
+            L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gptr = put(gptr); L->off_ls_gperm = put(gperm);
+            L->off_pm_pt0 = put(pm_pt0); L->off_pm_rank = put(pm_rank); L->off_pm_pptr = put(pptr); L->off_pm_jg = put(L->h_pm_jg);
+            // rotations: no camera variable free among a launch's components -> records, read only; otherwise records
+            // that follow the trial point when a lane has several factors per camera and trial (else each factor forms its own)
+            auto camfix_of = [&](size_t r0, size_t r1) {
+                for (size_t r = r0; r < r1; ++r) {
+                    const int cc = L->h_rest[r];
+                    for (int k = L->h_free_ptr[(size_t)cc]; k < L->h_free_ptr[(size_t)cc + 1]; ++k)
+                        if (p->h_block_of[(size_t)L->h_free_vid[(size_t)k]] >= 0) return false;
+                }
+                return true;
+            };
+            const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
             const bool records = L->lds_rot >= 0 ? L->lds_rot == 1 : L->lds_max_factors > 512;
-            L->lds_rot_mode = L->camera_records == 0 ? ROT_PER_FACTOR : camfix ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
+            L->lds_rot_mode = L->camera_records == 0 ? ROT_PER_FACTOR : camfix_of(r_lds, L->h_rest.size()) ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
+            L->ptm_rot_mode = L->camera_records == 0 || L->lds_rot == 0 ? ROT_PER_FACTOR : camfix_of(r_ptm, r_lds) ? ROT_CAMFIX : ROT_RECORDS;
         }
     }
     if (L->rest_tiny > 0 && L->group_blocks4 == 0) {
@@ -1261,13 +1346,23 @@ int prepare_partition(rdis_hip_plan* L) {
     if (!rc) rc = plan_alloc(L, L->queue, 256);
     if (!rc && max_n > 0) rc = plan_alloc(L, L->xi_glob, (size_t)max_n * sizeof(double));
     if (rc) return rc;
-    if (L->rest_lds > 0) {
+    if (L->rest_lds + L->rest_ptm > 0) {
         rc = plan_alloc(L, L->lds_ints, L->h_lds_ints.size() * sizeof(int));
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(L->lds_ints.p, L->h_lds_ints.data(), L->h_lds_ints.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         rc = plan_alloc(L, L->lds_obs, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(double2));
         if (rc) return rc;
         gather_obs_kernel<<<grid_for(c, L->nfac, 256), 256, 0, c->stream>>>((int)L->nfac, L->ip(L->off_fac_id), p->obs.as<double2>(), L->lds_obs.as<double2>());
+        HIPCHK(c, hipGetLastError());
+    }
+    if (L->rest_ptm > 0) {   // the streaming components' point records and point-major factor arrays
+        rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
+        if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(int));
+        if (!rc) rc = plan_alloc(L, L->pm_obs, (size_t)L->pm_entries * sizeof(double2));
+        if (rc) return rc;
+        const PlanView V = L->view();
+        ptm_gather_kernel<<<grid_for(c, L->pm_entries, 256), 256, 0, c->stream>>>((int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
+                                                                                 L->pm_cam.as<int>(), L->pm_obs.as<double2>());
         HIPCHK(c, hipGetLastError());
     }
     if (!L->coop.empty()) {
@@ -1352,13 +1447,13 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    const size_t dyn = lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap);
-    const int nsc = L->lds_ns_cap, ncc = L->lds_ncb_cap;
+    const size_t dyn = lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap);
+    const int nsc = L->lds_ns_cap, ncc = L->lds_ncb_cap, chc = L->lds_chunk_cap;
 #define RDIS_LDS_LAUNCH(T)                                                                                              \
     do {                                                                                                                \
         if (dyn > 48 * 1024)                                                                                            \
             HIPCHK(c, hipFuncSetAttribute((const void*)cgd_lds_kernel<T, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
-        cgd_lds_kernel<T, ROT><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, nsc, ncc);                                \
+        cgd_lds_kernel<T, ROT><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, nsc, ncc, chc);                                \
     } while (0)
     switch (threads) {
         case 64: RDIS_LDS_LAUNCH(64); break;
@@ -1371,6 +1466,36 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
 #undef RDIS_LDS_LAUNCH
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+template <int ROT>
+int launch_ptm_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    ProblemView P = L->prob->view();
+    PlanView V = L->view();
+    V.order += first;
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
+    const int ncc = L->ptm_ncb_cap, chc = L->ptm_chunk_cap;
+#define RDIS_PTM_LAUNCH(T)                                                                                              \
+    do {                                                                                                                \
+        if (dyn > 48 * 1024)                                                                                            \
+            HIPCHK(c, hipFuncSetAttribute((const void*)cgd_ptm_kernel<T, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+        cgd_ptm_kernel<T, ROT><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, ncc, chc);                                \
+    } while (0)
+    switch (threads) {
+        case 256: RDIS_PTM_LAUNCH(256); break;
+        case 512: RDIS_PTM_LAUNCH(512); break;
+        default: RDIS_PTM_LAUNCH(768); break;
+    }
+#undef RDIS_PTM_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    switch (L->ptm_rot_mode) {
+        case ROT_CAMFIX: return launch_ptm_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
+        case ROT_RECORDS: return launch_ptm_rot<ROT_RECORDS>(L, stream, threads, first, grid, maxiters, ftol);
+        default: return launch_ptm_rot<ROT_PER_FACTOR>(L, stream, threads, first, grid, maxiters, ftol);
+    }
 }
 int launch_lds(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
     switch (L->lds_rot_mode) {
@@ -1438,7 +1563,7 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("streaming grid solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;
     }
-    const int rest = (int)L->h_rest.size() - L->rest_tiny - L->rest_lds;   // components of the plain batch solver
+    const int rest = (int)L->h_rest.size() - L->rest_tiny - L->rest_lds - L->rest_ptm;   // components of the plain batch solver
     // (the LDS-resident solver forms the records it reads itself)
     if (L->rest_rot_mode != ROT_PER_FACTOR && (L->rest_tiny > 0 || rest > 0)) {   // (cameras the batch reads are not free in the launches above)
         camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, bs>>>(
@@ -1474,13 +1599,19 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         // component's arithmetic fills the unit while the other's control step (one lane) or barrier runs
         // (1000 x 2048 factors: 11.9 against 13.7 ms; 125 of them, a unit each: 3.5 against 4.7 ms)
         if (threads == 0) threads = mf <= 64 ? 64 : mf <= 128 ? 128 : mf <= 256 ? 256 : L->rest_lds > c->num_cus ? 256 : mf <= 512 ? 512 : 768;
-        int rc = launch_lds(L, bs, threads, L->rest_tiny + rest, L->rest_lds, maxiters, ftol);
+        int rc = launch_lds(L, bs, threads, L->rest_tiny + rest + L->rest_ptm, L->rest_lds, maxiters, ftol);
+        if (rc) return rc;
+        ++L->last_launches;
+    }
+    if (L->rest_ptm > 0) {
+        int threads = L->ptm_threads ? L->ptm_threads : (L->rest_ptm > c->num_cus ? 256 : 768);
+        int rc = launch_ptm(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
     }
     if (rest > 0) {
         int64_t mf = 0;
-        for (size_t i = (size_t)L->rest_tiny; i < L->h_rest.size() - (size_t)L->rest_lds; ++i) {
+        for (size_t i = (size_t)L->rest_tiny; i < L->h_rest.size() - (size_t)L->rest_lds - (size_t)L->rest_ptm; ++i) {
             const int cc = L->h_rest[i];
             mf = std::max<int64_t>(mf, std::max<int64_t>(L->h_fac_ptr[(size_t)cc + 1] - L->h_fac_ptr[(size_t)cc],
                                                          (L->h_free_ptr[(size_t)cc + 1] - L->h_free_ptr[(size_t)cc]) / 4));

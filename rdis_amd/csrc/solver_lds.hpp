@@ -22,10 +22,12 @@
 //   reduce   wave (DPP) + LDS, fixed order: the same bits run to run, and -- the factor arithmetic
 //            and the order of the sums being those of solver_wg.hpp -- the same bits as that solver
 //            whenever the slots are the free variables in their listed order (every block free,
-//            cameras before points, ascending: what RDIS and the generators produce; tested).
-// The full gradient, once per CG iteration, goes through the variable-major gfac[] like
-// solver_wg.hpp's (per-variable sums in factor-list order, src/State.h:157-210); g and h of the
-// Polak-Ribiere recurrence stay in the plan's workspace (touched twice per iteration).
+//            cameras before points, ascending: what RDIS and the generators produce) and no camera
+//            variable is free (a camera's gradient entries are grouped differently, below); tested.
+// The full gradient, once per CG iteration: camera partials are summed across waves whose factors
+// share a camera, point partials go through the variable-major gfac[] like solver_wg.hpp's (per-variable
+// sums in factor-list order, src/State.h:157-210) -- see gradient_to_xi; g and h of the Polak-Ribiere
+// recurrence stay in the plan's workspace (touched twice per iteration).
 #pragma once
 #include "solver_wg.hpp"
 
@@ -33,8 +35,9 @@ namespace rdis_hip {
 
 constexpr int LDS_MAX_BYTES = 160 * 1024 - 4096;   // dynamic LDS a launch may ask for (static: machine, requests, reduction slots)
 constexpr int LDS_DOUBLES_PER_SLOT = 5;            // Pv, XI, LO, HI, X
-__host__ __device__ inline size_t lds_bytes_for(int ns, int ncb) {
-    return (size_t)ns * (LDS_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) + 64;
+__host__ __device__ inline size_t lds_bytes_for(int ns, int ncb, int nchunk) {
+    return (size_t)ns * (LDS_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) +
+           (size_t)nchunk * (9 * sizeof(double) + sizeof(int)) + 64;
 }
 
 template <int ROT, bool PREFETCH>
@@ -45,7 +48,10 @@ struct LdsEnv {
     int ns, ncb;              // slots, camera blocks of this component
     const double2* fobs;      // its listed factors' observations (plan-local copy in listed order)
     const unsigned* fidx;     // its listed factors' slot word: camera block | point block << 12
-    const int* gperm;         // its listed factors (local index) sorted by camera block: the order of the gradient pass
+    const int* gperm;         // its listed factors (local index) grouped by camera block, groups padded to whole waves with -1
+    int nchunk;               // ... in wave-chunks of 64
+    double* CG;               // LDS [nchunk][9]: a chunk's camera partial sums
+    int* CGC;                 // LDS [nchunk]: its camera block
     const int* vptr;          // v2s_ptr + free offset
     const int* svid;          // variable id of a slot
     double *Pv, *XI, *LO, *HI, *X, *ROTR;   // LDS
@@ -53,7 +59,6 @@ struct LdsEnv {
     double *g, *h;            // plan workspace, by free index
     double (*red)[3][MAX_WAVES];
     int parity;
-    int *long_q, *long_n;
     double* tr;
     int trn, lm_count;
 
@@ -245,66 +250,106 @@ struct LdsEnv {
         }
     }
 
-    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p)
+    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p).
+    // The factors are taken camera by camera (gperm: the listed factors grouped by camera block, every group
+    // padded to whole waves, -1 = no factor), so a wave's 64 factors share their camera:
+    //   camera partials  summed across the wave (DPP), one 9-vector per wave-chunk in LDS, then per camera
+    //                    variable the chunks in order -- no memory traffic at all (through the variable-major
+    //                    gfac[] like solver_wg.hpp the scatter alone was 42 000 of a gradient's 70 000 cycles:
+    //                    in listed order every one of a wave's 64 x 12 stores went to a cache line of its own,
+    //                    and the per-camera sums over 256 partials another 16 000);
+    //   point partials   to gfac[] (three per factor), then every point variable sums its run in factor-list
+    //                    order (src/State.h:157-210) -- the same bits as solver_wg.hpp.
+    // A camera variable's sum is therefore grouped differently from solver_wg.hpp's (which strides a wave over the
+    // run): with free cameras the two solvers agree to rounding, not to the bit.
     __device__ void gradient_to_xi() {
+        if (L.ls_cam_gfac) { gradient_via_gfac(); return; }
         const long long tg0 = clock();
         assign_p();
-        // The factors are taken camera by camera here (gperm: the listed factors sorted by camera block, stable):
-        // gfac is variable-major, so the nine camera partials of neighbouring lanes then land next to each other --
-        // in listed order (by point) every one of a wave's 64 x 12 stores went to a cache line of its own, and the
-        // scatter was 42 000 of a gradient's 70 000 cycles.  Which lane forms a partial does not change its bits.
-        for (int jj = tid; jj < m; jj += nt) {
-            const int j = gperm[jj];
+        const int lane = tid & 63;
+        for (int ch = tid >> 6; ch < nchunk; ch += nwaves) {
+            const int j = gperm[64 * ch + lane];
+            double gq[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gq[k] = 0.0;
+            int u9 = -1, u10 = -1, u11 = -1;
+            unsigned w = 0u;
+            if (j >= 0) {
+                double v[12];
+                BaFwd t;
+                int cb, pb;
+                const int* sp = L.slot_pos + L.slot_base[c0 + j];
+                u9 = sp[9]; u10 = sp[10]; u11 = sp[11];
+                w = fidx[j];
+                forward(w, fobs[j], v, t, cb, pb);
+                ba_adjoint(t, v, t.res0, t.res1, gq);
+                if (u9 >= 0) L.gfac[u9] = gq[9];
+                if (u10 >= 0) L.gfac[u10] = gq[10];
+                if (u11 >= 0) L.gfac[u11] = gq[11];
+            }
+            if constexpr (ROT != ROT_CAMFIX) {
+                // (a chunk's first lane always holds a factor: the padding is at the end of a camera's group)
+                const int c = __builtin_amdgcn_readfirstlane((int)(w & 0xFFFu));
+                double cs[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) cs[k] = wave_sum(gq[k]);
+                if (lane < 9) CG[9 * ch + lane] = pick(cs, lane);
+                if (lane == 0) CGC[ch] = c;
+            }
+        }
+        __syncthreads();
+        const long long tg1 = clock();
+        if constexpr (ROT != ROT_CAMFIX) {
+            for (int s = tid; s < 9 * ncb; s += nt) {
+                if (SF[s] < 0) continue;
+                const int c = s / 9, k = s - 9 * c;
+                double sm = 0.0;
+                bool first = true;
+                for (int ch = 0; ch < nchunk; ++ch)
+                    if (CGC[ch] == c) { sm = first ? CG[9 * ch + k] : sm + CG[9 * ch + k]; first = false; }
+                XI[s] = sm;
+            }
+        }
+        for (int s = 9 * ncb + tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const int b = vptr[fi], e = vptr[fi + 1];
+            XI[s] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
+        }
+        __syncthreads();
+        tick(4, tg1 - tg0); tick(5, clock() - tg1); tick(10, 1);
+    }
+
+    // option lds_camera_sums = 0 (tests): every partial through gfac[] and every variable's sum formed as
+    // solver_wg.hpp forms it -- short runs in factor-list order by a lane, long ones strided over a wave -- so
+    // that the two solvers can be compared bit for bit with free cameras too
+    __device__ void gradient_via_gfac() {
+        assign_p();
+        for (int j = tid; j < m; j += nt) {
             double v[12], gq[12];
             BaFwd t;
             int cb, pb;
-            const int* sp = L.slot_pos + L.slot_base[c0 + j];
-            int u[12];
-#pragma unroll
-            for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) u[k] = sp[k];
             forward(fidx[j], fobs[j], v, t, cb, pb);
             ba_adjoint(t, v, t.res0, t.res1, gq);
+            const int* sp = L.slot_pos + L.slot_base[c0 + j];
 #pragma unroll
-            for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) if (u[k] >= 0) L.gfac[u[k]] = gq[k];
+            for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) { const int u = sp[k]; if (u >= 0) L.gfac[u] = gq[k]; }
         }
-        if (tid == 0) *long_n = 0;
         __syncthreads();
-        const long long tg1 = clock();
         for (int s = tid; s < ns; s += nt) {
             const int fi = SF[s];
             if (fi < 0) continue;
             const int b = vptr[fi], e = vptr[fi + 1];
-            if (e - b > WG_LONG_LIST) {
-                const int k = atomicAdd(long_n, 1);
-                if (k < WG_LONG_QUEUE) { long_q[k] = s; continue; }
-            }
+            if (e - b > WG_LONG_LIST) continue;
             XI[s] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
         }
-        __syncthreads();
-        const long long tg2 = clock();
-        const int nq = min(*long_n, WG_LONG_QUEUE);
-        if (nq > 0) {
-            // (a wave takes its runs three at a time: their loads are in flight together; each sum is that of solver_wg.hpp)
-            for (int k = tid >> 6; k < nq; k += 3 * nwaves) {
-                int sl[3];
-                double part[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int kk = k + q * nwaves;
-                    sl[q] = kk < nq ? long_q[kk] : -1;
-                    const int fi = sl[q] >= 0 ? SF[sl[q]] : 0;
-                    part[q] = sl[q] >= 0 ? run_sum_strided(L.gfac, vptr[fi], vptr[fi + 1], tid & 63) : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (sl[q] < 0) continue;   // (wave-uniform)
-                    const double sm = wave_sum(part[q]);
-                    if ((tid & 63) == 0) XI[sl[q]] = sm;
-                }
-            }
-            __syncthreads();
+        for (int s = tid >> 6; s < ns; s += nwaves) {   // (wave-uniform: the long runs, a wave each)
+            const int fi = SF[s];
+            if (fi < 0 || vptr[fi + 1] - vptr[fi] <= WG_LONG_LIST) continue;
+            const double sm = wave_sum(run_sum_strided(L.gfac, vptr[fi], vptr[fi + 1], tid & 63));
+            if ((tid & 63) == 0) XI[s] = sm;
         }
-        tick(4, tg1 - tg0); tick(5, tg2 - tg1); tick(6, clock() - tg2); tick(10, 1);
+        __syncthreads();
     }
 
     __device__ void cg_start() {
@@ -364,11 +409,9 @@ struct LdsEnv {
 
 template <int THREADS, int ROT>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
-cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap, int ncb_cap) {
+cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap, int ncb_cap, int chunk_cap) {
     extern __shared__ double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
-    __shared__ int long_q[WG_LONG_QUEUE];
-    __shared__ int long_n;
     const int comp = L.order[blockIdx.x];
     const int f0 = L.free_ptr[comp], f1 = L.free_ptr[comp + 1];
     const int c0 = L.fac_ptr[comp], c1 = L.fac_ptr[comp + 1];
@@ -385,15 +428,17 @@ cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap,
     }
     const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp];
     double* base = lds_dyn;
-    int* SF = (int*)(base + LDS_DOUBLES_PER_SLOT * ns_cap + 7 * ncb_cap);
+    double* CG = base + LDS_DOUBLES_PER_SLOT * ns_cap + 7 * ncb_cap;
+    int* CGC = (int*)(CG + 9 * chunk_cap);
+    int* SF = CGC + chunk_cap;
     for (int s = threadIdx.x; s < ns; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     double* ws = L.ws + 5ll * f0;
     LdsEnv<ROT, (THREADS <= 512)> E{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
-                  ns, ncb, L.ls_obs + c0, L.ls_fidx + c0, L.ls_gperm + c0, L.v2s_ptr + f0, L.ls_vid + s0,
+                  ns, ncb, L.ls_obs + c0, L.ls_fidx + c0, L.ls_gperm + 64ll * L.ls_gptr[comp], L.ls_gptr[comp + 1] - L.ls_gptr[comp], CG, CGC, L.v2s_ptr + f0, L.ls_vid + s0,
                   base, base + ns_cap, base + 2 * ns_cap, base + 3 * ns_cap, base + 4 * ns_cap, base + LDS_DOUBLES_PER_SLOT * ns_cap,
                   SF, ws + 2ll * n, ws + 3ll * n,
-                  red, 0, long_q, &long_n,
+                  red, 0,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0
 #ifdef RDIS_COOP_TIMING
                   , {}

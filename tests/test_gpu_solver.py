@@ -1033,7 +1033,9 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
     global memory (solver_wg.hpp).  The factor arithmetic and the orders of all sums are the same, so when
     the slots are the free variables in their listed order (every block free, cameras before points,
     ascending ids) every bit of the result is the same: synthetic components under three workgroup sizes,
-    with per-factor rotations and with records.  With constants among the slots (ladybug's camera
+    with per-factor rotations and with records (option lds_camera_sums = 0: by default a camera's gradient
+    entries are summed across waves that share the camera -- no memory traffic -- which groups the partials
+    differently from the plain solver's strided wave sum; that default is replayed against the oracle).  With constants among the slots (ladybug's camera
     components: points fixed; its point components: cameras fixed; a sub-function with partly free
     blocks) the per-factor values are still the same bits and only the Polak-Ribiere sums run over the
     slots in another grouping: there the replay check against the oracle is the judge."""
@@ -1059,12 +1061,21 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
     for threads in (128, 256, 768):
         for rot in (0, 2):
             ra, xa, _, _ = run({"lds_resident": 0, "block_threads": threads, "camera_records": rot})
-            rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0})
+            # (lds_camera_sums 0: a camera variable's gradient entry summed as the plain solver sums it -- by default
+            # the LDS solver sums camera partials across waves that share a camera, another grouping)
+            rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0, "lds_camera_sums": 0})
             assert nb == 1
             assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (threads, rot)
             assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.status, rb.status), (threads, rot)
             assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (threads, rot)
     assert np.all(ra.delta < 0)
+    # the default (camera partials summed across waves): same problem, replayed against the oracle
+    rc, xc, _, trc = run({"lds_resident": 1}, trace=4096)
+    assert np.all(rc.delta < 0) and abs(rc.fret.sum() - ra.fret.sum()) <= 0.05 * ra.fret.sum()
+    for c in (0, 17, 39):
+        fv, fc = syn.component(c)
+        sub = type("R", (), {"status": rc.status[c:c + 1], "iters": rc.iters[c:c + 1], "fret": rc.fret[c:c + 1]})
+        check_replay(syn, trc[c], sub, 25, free_vid=fv, fac_id=fc, x=syn.x0[fv])
     # constants among the slots
     lb = P.load_bal(ncams=49, npts=500)
     cams, pts = P.ba_alternation_plans(lb)
