@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--maxiters", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling block (the fixed 1000-component decomposition)")
+    ap.add_argument("--strong-size", default="L", choices=sorted(STRONG_SIZES), help="component size of the strong_scaling block")
     ap.add_argument("--no-objective-band", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
     return ap.parse_args()
@@ -103,24 +104,28 @@ def build_problem(workload: str, rank: int, components: int = 256, world: int = 
 
 # The strong-scaling workload of north_star ("1000-component synthetic decomposition"): a FIXED
 # decomposition of 1000 independent bundle-adjustment components, sharded over the ranks.  Size of
-# a component: 8 cameras x 512 points x 4 observations per point = 2048 factors, 1608 variables
-# (2.05e6 factors in all).  Why this size: at 120 factors (synthetic-S) a launch is as long as its
-# slowest component's latency chain whatever the number of GPUs (2 ms on 1 or 8); at 2048 factors a
-# component occupies a whole compute unit (one 768-lane workgroup, three waves per SIMD), so one
-# GPU needs ceil(1000 / 256) = 4 rounds of workgroups where eight need one -- the time is bound by
-# arithmetic throughput, which is what sharding can divide.  (With one workgroup per component the
-# speed-up from 1 to 8 GPUs is therefore bounded by 4 rounds : 1 round)
-STRONG = {"components": 1000, "ncams": 8, "npts": 512, "obs_per_pt": 4}
+# a component ("L", the default): SURVEY 8d's config-5-L -- 49 cameras x 7776 points x 4 observations
+# per point = 31104 factors, 23769 variables, ladybug's own size; 3.1e7 factors / 2.4e7 variables in
+# all, the size at which the path streams from HBM.  One GPU works through its 1000 components a
+# workgroup each (four rounds of 256 compute units); at eight GPUs a rank has 125, fewer than compute
+# units, and four workgroups share a component (solver_ptm.hpp: cgd_ptmg_kernel) -- that is what lets the
+# time keep falling with the number of ranks.  "small": 8 cameras x 512 points x 4 = 2048 factors (round 2's
+# block): a component fits one compute unit's LDS and an evaluation is 2 us of arithmetic, too little
+# to share between workgroups -- 125 components use 125 compute units, and a launch lasts as long as
+# its slowest component's chain of ~460 evaluations.
+STRONG_SIZES = {"L": {"components": 1000, "ncams": 49, "npts": 7776, "obs_per_pt": 4},
+                "small": {"components": 1000, "ncams": 8, "npts": 512, "obs_per_pt": 4}}
+STRONG = dict(STRONG_SIZES["L"])
 
 
-def strong_scaling_shard(rank: int, world: int, components: int = STRONG["components"]):
+def strong_scaling_shard(rank: int, world: int, components: int = None):
     """(problem, CSR of this rank's components, their ids, per-rank factor loads): the whole fixed
     decomposition is generated on every rank (components come from their ids: identical
     everywhere) and shared out by dist.rank_decomposition -- longest-processing-time by factor
     count, the same partition on every rank, no communication."""
     from rdis_amd import problems as P
     from rdis_amd.dist import rank_decomposition
-    pp = P.make_synthetic_ba(components, STRONG["ncams"], STRONG["npts"], obs_per_pt=STRONG["obs_per_pt"])
+    pp = P.make_synthetic_ba(components or STRONG["components"], STRONG["ncams"], STRONG["npts"], obs_per_pt=STRONG["obs_per_pt"])
     free_ptr, free_vid, fac_ptr, fac_id, mine = rank_decomposition(pp, rank, world)
     w = np.diff(pp.comp_fac_ptr)
     loads = np.array([int(w[part].sum()) for part in P.shard_components(pp.ncomp, w, world)])
@@ -183,8 +188,8 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
            "value": iters / dt, "unit": "iters/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
            "kernel_ms_max_over_ranks": kmax, "objective": objective,
            "load_imbalance": float(loads.max() / loads.mean()), "factors_per_rank": [int(v) for v in loads],
-           # one 768-lane workgroup per component, one resident per compute unit: rounds a rank's launch needs
-           "workgroup_rounds": int(-(-int(max_comps) // ncu)),
+           # rounds of one workgroup per compute unit a rank's launch needs; below one round workgroups share a component
+           "workgroup_rounds": int(-(-int(max_comps) // ncu)), "workgroups_per_component": int(plan.info("point_major_group")),
            "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))}}
     plan.close()
     prob.close()
@@ -347,6 +352,7 @@ def dry_dist(a, rank: int, world: int) -> None:
     import torch
     import torch.distributed as dist
     dist.init_process_group(os.environ["RDIS_BENCH_DRY_DIST"])
+    STRONG.update(STRONG_SIZES["small"])   # (the mechanics, not the size)
     _, csr, mine, loads = strong_scaling_shard(rank, world, components=64)
     dist.barrier()
     t0 = time.perf_counter()
@@ -501,6 +507,7 @@ def main():
     prob.close()
     # north_star's scaling workload, in the command the driver runs: for every N, N = 1 included
     if a.workload == "ladybug-full" and not a.no_strong_scaling:
+        STRONG.clear(); STRONG.update(STRONG_SIZES[a.strong_size])
         ss = run_strong_scaling(ctx, rank, world, local_rank, dist, torch, a.maxiters)
         if rank == 0:
             line["strong_scaling"] = ss

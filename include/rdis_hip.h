@@ -240,6 +240,15 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);
+/* which solver the plan's components go to (a test and tuning aid; the partition is computed on demand):
+ * "components_cooperative", "components_grid_stream", "components_tiny", "components_lds",
+ * "components_point_major", "components_plain" (counts), "pipelined" (0/1: cooperative groups use the
+ * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch) */
+int rdis_hip_plan_get_info(rdis_hip_plan *plan, const char *name, int64_t *value);
+/* device memory the plan holds beyond the problem's (index tables, workspace, per-factor
+ * partials, results): what a host-side cache of plans budgets with
+ * (rdis::HipCGDSubspaceOptimizer::setPlanCacheBytes) */
+int rdis_hip_plan_device_bytes(rdis_hip_plan *plan, int64_t *bytes);
 /* device time of the solver kernel(s) of the last plan_solve, measured with HIP
  * events on the launch stream; launches = number of kernel launches it covers */
 int rdis_hip_plan_last_kernel_ms(rdis_hip_plan *plan, double *ms, int32_t *launches);

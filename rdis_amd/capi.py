@@ -78,6 +78,8 @@ SYMBOLS = {
     "rdis_hip_plan_objective_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "rdis_hip_plan_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "rdis_hip_plan_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "rdis_hip_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rdis_hip_plan_get_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "rdis_hip_plan_get_trace": (C.c_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "rdis_hip_plan_get_vectors": (C.c_int, [_vp, _i64, _vp, _i64]),
     "rdis_hip_plan_debug_counters": (C.c_int, [_vp, _vp]),
@@ -421,6 +423,16 @@ class Plan:
         ms, n = C.c_double(), C.c_int32()
         self.ctx.check(self.ctx.lib.rdis_hip_plan_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def info(self, name: str) -> int:
+        v = C.c_int64()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_get_info(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def device_bytes(self) -> int:
+        b = C.c_int64()
+        self.ctx.check(self.ctx.lib.rdis_hip_plan_device_bytes(self.h, C.byref(b)))
+        return b.value
 
     def debug_counters(self) -> np.ndarray:
         out = np.zeros(32, dtype=np.int64)

@@ -78,12 +78,19 @@ struct PlanView {
                           // group), every group padded to whole chunks with -1
     const unsigned* ls_fidx;  // [nfac_total] listed factor -> camera block | point block << 12 (block numbers within the component)
     // point-major streaming solver (solver_ptm.hpp): the same slot tables, point blocks ordered by their number of factors
+    // and taken 64 at a time (a wave-chunk)
     const int* pm_pt0;    // [ncomp] a component's first point block in pm_rec
-    const int* pm_rank;   // [ncomp] its rank among the streaming components (pm_pptr has one more entry than blocks per component)
-    const int* pm_pptr;   // a point block's factors: entries [pm_pptr[b + rank], pm_pptr[b + rank + 1]) of pm_cam / pm_obs
+    const int* pm_ch0;    // [ncomp] its first entry in pm_cptr (which has one more entry than wave-chunks per component)
+    const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_pg, slot-major --
+                          // entry pm_cptr[c] + 64 t + lane is the t-th factor of the lane's point block
     double* pm_rec;       // [blocks][12] p, xi, lo, hi of a point block's three variables
-    const int* pm_cam;    // [entries] camera block (number within the component) ...
+    const int* pm_cam;    // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
+    double* pm_pg;        // [entries][3] the factor's three point partials, as the last gradient pass left them
+    // ... and in the order of the gradient pass (position q = 64 * chunk + lane of ls_gperm):
+    const unsigned* pm_gqw;   // the factor's slot word (camera block | point block << 12), 0xFFFFFFFF = no factor
+    const int* pm_gqe;        // its entry in pm_pg
+    const double2* pm_gqobs;  // its observation
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

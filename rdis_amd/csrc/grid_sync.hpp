@@ -74,8 +74,18 @@ struct CoopState {
 };
 inline size_t coop_state_bytes() { return sizeof(CoopState); }
 
-struct GridSync {
-    CoopState* st;
+// the same for a small group: a component shared by a few workgroups of the point-major streaming solver
+// (solver_ptm.hpp), one state per group that runs concurrently -- up to a hundred or so per launch
+constexpr int SMALL_COOP_ENTRIES = 256;   // workgroups x waves of a group
+struct SmallCoopState {
+    alignas(32) unsigned long long granule[COOP_NBUF][SMALL_COOP_ENTRIES][COOP_KP];
+    unsigned int abort_flag;
+    unsigned int pad[15];
+};
+
+template <class ST>
+struct GridSyncT {
+    ST* st;
     int tid, nwg, wg;                   // lane in workgroup, #workgroups, my workgroup
     double* bcast;                      // LDS [2][4]
     int poll_delay;                     // x64 cycles between publishing and the first sweep
@@ -292,5 +302,6 @@ struct GridSync {
     __device__ void barrier_ordered() { barrier(SYNC_FENCE); }
 
 };
+using GridSync = GridSyncT<CoopState>;
 
 }  // namespace rdis_hip

@@ -36,6 +36,8 @@ struct rdis_hip_ctx {
     // second stream for the batched launch of a plan that also has cooperative launches (they overlap)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // resident-workgroup caps of the cooperative layouts on THIS device (occupancy queries, asked once per context)
+    int cap_pipe = -1, cap_coop[3] = {-1, -1, -1};
 };
 
 namespace {
@@ -163,6 +165,7 @@ struct StreamItem {
 struct rdis_hip_plan {
     rdis_hip_problem* prob = nullptr;
     bool transient = false;  // lives in the problem's arena (rdis_hip_cgd_batch): one at a time
+    size_t dev_bytes = 0;    // device memory of its own (plan_alloc; rdis_hip_plan_device_bytes)
     int64_t ncomp = 0, nfree = 0, nfac = 0, nslots = 0, ngfac = 0;
     // one device block of int32 (order | free_ptr | free_vid | fac_ptr | fac_id | v2s_ptr |
     // slot_base | slot_pos) and one of results (see out_layout)
@@ -197,13 +200,19 @@ struct rdis_hip_plan {
     int rest_tiny = 0;                // the first rest_tiny entries of the batch list run on the quad / wave solver
     int rest_lds = 0;                 // the LAST rest_lds entries run on the LDS-resident solver (solver_lds.hpp)
     int rest_ptm = 0;                 // the rest_ptm entries before them on the point-major streaming solver (solver_ptm.hpp)
-    int ptm_stream = 1;               // option "ptm_stream": 0 = never
+    int ptm_stream = 1;               // option "ptm_stream": 0 = never, 1 = components too large for the LDS, 2 = every component
     int ptm_threads = 0;              // option "ptm_threads": its workgroup size, 0 = auto
     int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     std::vector<int> h_pm_jg;
-    DevBuf pm_rec, pm_cam, pm_obs;
-    size_t off_pm_pt0 = 0, off_pm_rank = 0, off_pm_pptr = 0, off_pm_jg = 0;
+    DevBuf pm_rec, pm_cam, pm_obs, pm_pg, pm_gqw, pm_gqe, pm_gqobs;
+    // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
+    int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
+    int ptm_last_group = 1;           // what the last solve used (rdis_hip_plan_debug_counters has no slot for it: get_option)
+    int64_t ls_total_chunks = 0;      // gradient chunks of all slot tables
+    int64_t ptm_min_points = 0;       // the smallest streaming component's point blocks
+    DevBuf ptm_cgg, ptm_state;
+    size_t off_pm_pt0 = 0, off_pm_ch0 = 0, off_pm_cptr = 0, off_pm_jg = 0, off_pm_eof = 0;
     int lds_resident = 1;             // option "lds_resident": 0 = never
     int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
@@ -250,8 +259,9 @@ struct rdis_hip_plan {
         v.ls_obs = lds_obs.as<double2>();
         v.ls_gperm = li + off_ls_gperm; v.ls_gptr = li + off_ls_gptr;
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
-        v.pm_pt0 = li + off_pm_pt0; v.pm_rank = li + off_pm_rank; v.pm_pptr = li + off_pm_pptr;
+        v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
         v.pm_rec = pm_rec.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
+        v.pm_pg = pm_pg.as<double>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -673,7 +683,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // hipMalloc / hipFree (each of which synchronises the device)
 int plan_alloc(rdis_hip_plan* L, DevBuf& b, size_t bytes) {
     rdis_hip_problem* p = L->prob;
-    if (!L->transient) return dalloc(p->ctx, b, bytes);
+    if (!L->transient) {
+        L->dev_bytes -= std::min(L->dev_bytes, b.owned ? b.bytes : 0);
+        const int rc = dalloc(p->ctx, b, bytes);
+        if (!rc) L->dev_bytes += b.bytes;
+        return rc;
+    }
     b.release();
     bytes = align_up(std::max<size_t>(bytes, 8), 256);
     // (the arena is sized from bounds, plan_create_impl; what exceeds them -- rare shapes -- gets memory of its own)
@@ -938,7 +953,11 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "lds_resident") {
         L->lds_resident = value != 0;
     } else if (n == "ptm_stream") {
-        L->ptm_stream = value != 0;
+        if (value < 0 || value > 2) return fail(c, RDIS_HIP_EINVAL, "ptm_stream must be 0 (never), 1 (components too large for the LDS) or 2 (every component its tables fit)");
+        L->ptm_stream = (int)value;
+    } else if (n == "ptm_group") {
+        if (value < 0 || value > PTM_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16)");
+        L->ptm_group = (int)value;
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
         L->ptm_threads = (int)value;
@@ -1020,12 +1039,12 @@ int prepare_partition(rdis_hip_plan* L) {
                    nbig <= L->coop_max_components;
     const bool coop_on = L->coop_min_factors > 0 && L->coop_max_components > 0 && p->kind == KIND_BA && !L->force_stream;
     auto cap_of = [&]() {
-        // (the occupancy queries behind these are not free: asked once per process and layout)
-        static int cap_pipe = -1, cap_coop[3] = {-1, -1, -1};
-        int& kc = cap_coop[L->coop_threads == 128 ? 0 : L->coop_threads == 256 ? 1 : 2];
-        if (L->pipelined() && cap_pipe < 0) cap_pipe = pipe_max_workgroups(c->num_cus);
+        // (the occupancy queries behind these are not free: asked once per context -- a device -- and layout;
+        // calls on a context are serialised, include/rdis_hip.h)
+        int& kc = c->cap_coop[L->coop_threads == 128 ? 0 : L->coop_threads == 256 ? 1 : 2];
+        if (L->pipelined() && c->cap_pipe < 0) c->cap_pipe = pipe_max_workgroups(c->num_cus);
         if (!L->pipelined() && kc < 0) kc = coop_max_workgroups(L->coop_threads, c->num_cus);
-        int k = L->pipelined() ? cap_pipe : kc;
+        int k = L->pipelined() ? c->cap_pipe : kc;
         if (L->coop_workgroups > 0) k = std::min(k, L->coop_workgroups);
         return k;
     };
@@ -1191,7 +1210,7 @@ int prepare_partition(rdis_hip_plan* L) {
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
         const size_t nc = (size_t)L->ncomp;
         std::vector<char> kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
-        std::vector<int> ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), pm_rank(nc, 0), ls_fidx((size_t)L->nfac, 0);
+        std::vector<int> ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
         std::vector<std::vector<int>> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
         std::vector<int> cams, pts, deg;
         for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
@@ -1230,8 +1249,12 @@ int prepare_partition(rdis_hip_plan* L) {
                 std::iota(gp.begin(), gp.begin() + m, 0);
             }
             const int nchunk = (int)gp.size() / 64;
-            const bool fits_lds = L->lds_resident != 0 && lds_bytes_for(ns, ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
-            const bool fits_ptm = !fits_lds && L->ptm_stream != 0 && ptm_bytes_for(ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+            // (the streaming solver is for what is too LARGE for the LDS: with lds_resident = 0 such components stay with
+            // solver_wg.hpp -- the comparison the bit-identity tests make; ptm_stream = 2 sends everything its tables fit)
+            const bool lds_size_ok = lds_bytes_for(ns, ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+            const bool fits_lds = L->lds_resident != 0 && lds_size_ok && L->ptm_stream != 2;
+            const bool fits_ptm = !fits_lds && (L->ptm_stream == 2 || (L->ptm_stream == 1 && !lds_size_ok)) &&
+                                  ptm_bytes_for(ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
             if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
             if (fits_lds) std::sort(pts.begin(), pts.end());
             else {   // by number of factors, descending (ties: ascending id): the lanes of a wave run loops of equal length
@@ -1289,7 +1312,7 @@ int prepare_partition(rdis_hip_plan* L) {
         L->rest_lds = (int)(L->h_rest.end() - first_lds);
         if (L->rest_ptm + L->rest_lds > 0) {
             // one int32 block, tables in component order (a component without one has empty ranges)
-            std::vector<int> sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm, pptr;
+            std::vector<int> sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm;
             for (size_t cc = 0; cc < nc; ++cc) {
                 const bool has = kind_of[cc] != 0;
                 sptr[cc + 1] = sptr[cc] + (has ? (int)vid_of[cc].size() : 0);
@@ -1299,26 +1322,46 @@ int prepare_partition(rdis_hip_plan* L) {
                 sfree.insert(sfree.end(), free_of[cc].begin(), free_of[cc].end());
                 gperm.insert(gperm.end(), gp_of[cc].begin(), gp_of[cc].end());
             }
-            // point-major factor order of the streaming components: entry -> listed factor (plan-wide index)
-            int rank = 0;
+            // Point-major factor order of the streaming components.  A component's point blocks stand in slot order
+            // (by number of factors, descending) and are taken 64 at a time -- a wave-chunk, a lane per block.  The
+            // factors of a chunk's blocks are laid out slot-major: entry cptr[chunk] + 64 t + lane is the t-th listed
+            // factor of the lane's block (or no factor: -1), so a wave's loads of a slot are 64 neighbours and their
+            // addresses depend on nothing the wave has loaded before.  entry -> listed factor (plan-wide index),
+            // listed factor -> entry (where the gradient pass leaves the factor's three point partials).
+            std::vector<int> pm_ch0v(nc, 0), cptr, eof((size_t)L->nfac, -1);
+            L->h_pm_jg.clear();
             for (size_t cc = 0; cc < nc; ++cc) {
                 if (kind_of[cc] != 2) continue;
-                const int c0 = L->h_fac_ptr[cc], c1 = L->h_fac_ptr[cc + 1], npb = (int)pptr_of[cc].size() - 1;
+                const int c0 = L->h_fac_ptr[cc], c1 = L->h_fac_ptr[cc + 1], npb = (int)pptr_of[cc].size() - 1, npc = (npb + 63) / 64;
                 pm_pt0[cc] = (int)L->pm_blocks;
-                pm_rank[cc] = rank++;
+                pm_ch0v[cc] = (int)cptr.size();
+
                 const int e0 = (int)L->h_pm_jg.size();
-                std::vector<int> fill(pptr_of[cc].begin(), pptr_of[cc].end() - 1);
-                L->h_pm_jg.resize((size_t)e0 + (size_t)(c1 - c0));
-                for (int j = c0; j < c1; ++j) L->h_pm_jg[(size_t)e0 + (size_t)fill[(size_t)(((unsigned)ls_fidx[(size_t)j]) >> 12)]++] = j;
-                for (int k = 0; k <= npb; ++k) pptr.push_back(e0 + pptr_of[cc][(size_t)k]);
+                std::vector<int> cbase((size_t)npc + 1, 0);
+                for (int ch = 0; ch < npc; ++ch)   // (descending: a chunk's first block has the most factors)
+                    cbase[(size_t)ch + 1] = cbase[(size_t)ch] + 64 * (pptr_of[cc][(size_t)(64 * ch) + 1] - pptr_of[cc][(size_t)(64 * ch)]);
+                L->h_pm_jg.resize((size_t)e0 + (size_t)cbase[(size_t)npc], -1);
+                std::vector<int> fill((size_t)npb, 0);
+                for (int j = c0; j < c1; ++j) {
+                    const int pi = (int)(((unsigned)ls_fidx[(size_t)j]) >> 12);
+                    const int e = e0 + cbase[(size_t)(pi / 64)] + 64 * fill[(size_t)pi]++ + (pi % 64);
+                    L->h_pm_jg[(size_t)e] = j;
+                    eof[(size_t)j] = e;
+                }
+                for (int k = 0; k <= npc; ++k) cptr.push_back(e0 + cbase[(size_t)k]);
                 L->pm_blocks += npb;
             }
             L->pm_entries = (int64_t)L->h_pm_jg.size();
+            L->ls_total_chunks = gptr[nc];
+            L->ptm_min_points = INT64_MAX;
+            for (size_t cc = 0; cc < nc; ++cc)
+                if (kind_of[cc] == 2) L->ptm_min_points = std::min<int64_t>(L->ptm_min_points, (int64_t)pptr_of[cc].size() - 1);
             std::vector<int>& blk = L->h_lds_ints;
             auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
             L->off_ls_ptr = put(sptr); L->off_ls_vid = put(svid); L->off_ls_free = put(sfree);
             L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gptr = put(gptr); L->off_ls_gperm = put(gperm);
-            L->off_pm_pt0 = put(pm_pt0); L->off_pm_rank = put(pm_rank); L->off_pm_pptr = put(pptr); L->off_pm_jg = put(L->h_pm_jg);
+            L->off_pm_pt0 = put(pm_pt0); L->off_pm_ch0 = put(pm_ch0v); L->off_pm_cptr = put(cptr); L->off_pm_jg = put(L->h_pm_jg);
+            L->off_pm_eof = put(eof);
             // rotations: no camera variable free among a launch's components -> records, read only; otherwise records
             // that follow the trial point when a lane has several factors per camera and trial (else each factor forms its own)
             auto camfix_of = [&](size_t r0, size_t r1) {
@@ -1355,14 +1398,23 @@ int prepare_partition(rdis_hip_plan* L) {
         gather_obs_kernel<<<grid_for(c, L->nfac, 256), 256, 0, c->stream>>>((int)L->nfac, L->ip(L->off_fac_id), p->obs.as<double2>(), L->lds_obs.as<double2>());
         HIPCHK(c, hipGetLastError());
     }
-    if (L->rest_ptm > 0) {   // the streaming components' point records and point-major factor arrays
+    if (L->rest_ptm > 0) {   // the streaming components' point records, point-major factor arrays, gradient-order arrays
+        const size_t gq = (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 64;
         rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
+        if (!rc) rc = plan_alloc(L, L->ptm_cgg, (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 9 * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(int));
         if (!rc) rc = plan_alloc(L, L->pm_obs, (size_t)L->pm_entries * sizeof(double2));
+        if (!rc) rc = plan_alloc(L, L->pm_pg, (size_t)L->pm_entries * 3 * sizeof(double));
+        if (!rc) rc = plan_alloc(L, L->pm_gqw, gq * sizeof(unsigned));
+        if (!rc) rc = plan_alloc(L, L->pm_gqe, gq * sizeof(int));
+        if (!rc) rc = plan_alloc(L, L->pm_gqobs, gq * sizeof(double2));
         if (rc) return rc;
         const PlanView V = L->view();
         ptm_gather_kernel<<<grid_for(c, L->pm_entries, 256), 256, 0, c->stream>>>((int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
                                                                                  L->pm_cam.as<int>(), L->pm_obs.as<double2>());
+        HIPCHK(c, hipGetLastError());
+        ptm_gather_gradient_kernel<<<(int)std::min<int64_t>(std::max<int64_t>(L->ncomp, 1), 2048), 256, 0, c->stream>>>(V, L->lds_ints.as<int>() + L->off_pm_eof, L->pm_gqw.as<unsigned>(),
+                                                                                                    L->pm_gqe.as<int>(), L->pm_gqobs.as<double2>());
         HIPCHK(c, hipGetLastError());
     }
     if (!L->coop.empty()) {
@@ -1490,6 +1542,54 @@ int launch_ptm_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+// K workgroups per component (cgd_ptmg_kernel): how many groups of K fit the device, and the launch
+template <int ROT>
+const void* ptmg_kernel_ptr(int threads) {
+    switch (threads) {
+        case 256: return (const void*)cgd_ptmg_kernel<256, ROT>;
+        case 512: return (const void*)cgd_ptmg_kernel<512, ROT>;
+        default: return (const void*)cgd_ptmg_kernel<768, ROT>;
+    }
+}
+const void* ptmg_kernel(rdis_hip_plan* L, int threads) {
+    switch (L->ptm_rot_mode) {
+        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads);
+        case ROT_RECORDS: return ptmg_kernel_ptr<ROT_RECORDS>(threads);
+        default: return ptmg_kernel_ptr<ROT_PER_FACTOR>(threads);
+    }
+}
+int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
+    const void* fn = ptmg_kernel(L, threads);
+    if (dyn > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int per_cu = 0;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn));
+    *out = per_cu * c->num_cus;
+    return 0;
+}
+int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int ngroups, int K, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    ProblemView P = L->prob->view();
+    PlanView V = L->view();
+    V.order += first;
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
+    int ncc = L->ptm_ncb_cap, chc = L->ptm_chunk_cap;
+    if (L->ptm_state.bytes < (size_t)ngroups * sizeof(SmallCoopState)) {
+        int rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * sizeof(SmallCoopState));
+        if (rc) return rc;
+    }
+    // arm every granule, clear the abort words
+    HIPCHK(c, hipMemsetAsync(L->ptm_state.p, 0xFF, (size_t)ngroups * sizeof(SmallCoopState), stream));
+    HIPCHK(c, hipMemset2DAsync((char*)L->ptm_state.p + offsetof(SmallCoopState, abort_flag), sizeof(SmallCoopState), 0, 64, (size_t)ngroups, stream));
+    PtmGroupArgs A{L->ptm_state.as<SmallCoopState>(), L->ptm_cgg.as<double>(), K, ngroups, std::min(4, L->coop_poll_delay)};
+    int mi = maxiters;
+    double ft = ftol;
+    void* args[] = {&P, &V, &A, &mi, &ft, &ncc, &chc};
+    const int grid = 8 * K * ((ngroups + 7) / 8);
+    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel(L, threads), dim3(grid), dim3(threads), args, dyn, stream));
+    return 0;
+}
 int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
     switch (L->ptm_rot_mode) {
         case ROT_CAMFIX: return launch_ptm_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
@@ -1604,8 +1704,28 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         ++L->last_launches;
     }
     if (L->rest_ptm > 0) {
-        int threads = L->ptm_threads ? L->ptm_threads : (L->rest_ptm > c->num_cus ? 256 : 768);
-        int rc = launch_ptm(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, maxiters, ftol);
+        // 768 lanes, three waves per SIMD (1000 / 500 components of ladybug's size: 187 / 99 ms, 196 / 109 with 256 lanes and two
+        // workgroups per compute unit).  Fewer components than resident workgroups: K workgroups share a component
+        // (cooperative launch, every workgroup of it resident), of 256 lanes -- two per compute unit, the finer grain
+        // loses less to whole wave-chunks -- as long as a workgroup keeps some twenty wave-chunks of points per trial point
+        // (below that the exchange costs what the split saves: 125 components of 2048 points 9.6 ms alone, 9.7 as pairs;
+        // of 7776 points 35.8 ms alone, 27.7 as groups of four)
+        int threads = L->ptm_threads ? L->ptm_threads : 768;
+        int K = 1;
+        if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty()) {
+            const int gthreads = L->ptm_threads ? L->ptm_threads : 256;
+            int cap = 0;
+            int rc = ptmg_resident_workgroups(L, gthreads, &cap);
+            if (rc) return rc;
+            const int slots8 = 8 * ((L->rest_ptm + 7) / 8);   // (groups are placed eight at a time, one per XCD)
+            const int fit = std::min(std::min(PTM_MAX_GROUP, cap / slots8), SMALL_COOP_ENTRIES / (gthreads / 64));
+            const int useful = (int)std::max<int64_t>(1, (L->ptm_min_points + 63) / 64 / 24);
+            K = L->ptm_group > 1 ? std::min(L->ptm_group, fit) : std::min(fit, useful);
+            if (K >= 2) threads = gthreads;
+        }
+        L->ptm_last_group = std::max(K, 1);
+        int rc = K >= 2 ? launch_ptm_groups(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, K, maxiters, ftol)
+                        : launch_ptm(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
     }
@@ -1665,6 +1785,30 @@ extern "C" int rdis_hip_plan_fetch(rdis_hip_plan* L, double* x_out, double* fret
 extern "C" int rdis_hip_plan_objective_device(rdis_hip_plan* L, void** dev_ptr) {
     if (!L || !dev_ptr) return RDIS_HIP_EINVAL;
     *dev_ptr = L->objective.p;
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_t* value) {
+    if (!L || !name || !value) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
+    const std::string n(name);
+    const int64_t rest = (int64_t)L->h_rest.size() - L->rest_tiny - L->rest_lds - L->rest_ptm;
+    if (n == "components_cooperative") *value = (int64_t)L->coop.size();
+    else if (n == "components_grid_stream") *value = (int64_t)L->stream.size();
+    else if (n == "components_tiny") *value = L->rest_tiny;
+    else if (n == "components_lds") *value = L->rest_lds;
+    else if (n == "components_point_major") *value = L->rest_ptm;
+    else if (n == "components_plain") *value = rest;
+    else if (n == "pipelined") *value = L->pipelined() ? 1 : 0;
+    else if (n == "point_major_group") *value = L->ptm_last_group;
+    else return fail(c, RDIS_HIP_EINVAL, "plan_get_info: unknown name '" + n + "'");
+    return 0;
+}
+
+extern "C" int rdis_hip_plan_device_bytes(rdis_hip_plan* L, int64_t* bytes) {
+    if (!L || !bytes) return RDIS_HIP_EINVAL;
+    *bytes = (int64_t)(L->dev_bytes + L->trace.bytes + L->vdump.bytes);
     return 0;
 }
 

@@ -108,6 +108,9 @@ void NonlinearProductFactor::addVariable(Variable* v, Numeric exponent, Numeric 
 OptimizableFunction::OptimizableFunction() : defaultDomain(0, 0), ctx_(nullptr), prob_(nullptr), device_(0) {}
 
 OptimizableFunction::~OptimizableFunction() {
+    // optimisers that outlive the function must not be left with plans of a freed device problem
+    for (HipCGDSubspaceOptimizer* o : plan_holders_) o->functionGone();
+    plan_holders_.clear();
     if (prob_) rdis_hip_free_problem(prob_);
     if (ctx_) rdis_hip_destroy(ctx_);
     for (Variable* v : variables) delete v;
@@ -442,26 +445,57 @@ void SubspaceOptimizer::setParameters(const Options& options) {
 // ------------------------------------------------------------------ HipCGDSubspaceOptimizer
 struct HipCGDSubspaceOptimizer::CachedPlan {
     unsigned long long hash = 0, used = 0;
+    int64_t bytes = 0;
     std::vector<int64_t> free_ptr, free_vid, fac_ptr, fac_id;
     rdis_hip_plan* plan = nullptr;
 };
 
 HipCGDSubspaceOptimizer::HipCGDSubspaceOptimizer(OptimizableFunction& f_)
     : SubspaceOptimizer(f_), last_iters_(0), last_status_(0), last_nfeval_(0), last_ngeval_(0),
-      cache_cap_(256), cache_hits_(0), cache_misses_(0), cache_tick_(0) {
+      cache_cap_(256), cache_hits_(0), cache_misses_(0), cache_tick_(0),
+      cache_byte_cap_((size_t)4 << 30), cache_bytes_(0), cache_fallbacks_(0), function_alive_(true) {
     if (doAscent) throw std::invalid_argument("HipCGDSubspaceOptimizer: only the MinSum (descent) semiring is supported");
+    f.plan_holders_.push_back(this);
 }
 
-HipCGDSubspaceOptimizer::~HipCGDSubspaceOptimizer() { dropPlans(); }
+HipCGDSubspaceOptimizer::~HipCGDSubspaceOptimizer() {
+    dropPlans();
+    if (function_alive_) {
+        std::vector<HipCGDSubspaceOptimizer*>& h = f.plan_holders_;
+        h.erase(std::remove(h.begin(), h.end(), this), h.end());
+    }
+}
+
+void HipCGDSubspaceOptimizer::functionGone() {   // called by ~OptimizableFunction while its device problem still exists
+    dropPlans();
+    function_alive_ = false;
+}
 
 void HipCGDSubspaceOptimizer::dropPlans() {
     for (CachedPlan* e : cache_) { if (e->plan) rdis_hip_plan_destroy(e->plan); delete e; }
     cache_.clear();
+    cache_bytes_ = 0;
+}
+
+bool HipCGDSubspaceOptimizer::evictOne() {   // least recently used goes
+    if (cache_.empty()) return false;
+    size_t lru = 0;
+    for (size_t i = 1; i < cache_.size(); ++i) if (cache_[i]->used < cache_[lru]->used) lru = i;
+    if (cache_[lru]->plan) rdis_hip_plan_destroy(cache_[lru]->plan);
+    cache_bytes_ -= std::min<size_t>(cache_bytes_, (size_t)cache_[lru]->bytes);
+    delete cache_[lru];
+    cache_.erase(cache_.begin() + (long)lru);
+    return true;
 }
 
 void HipCGDSubspaceOptimizer::setPlanCache(size_t entries) {
     cache_cap_ = entries;
     if (cache_.size() > cache_cap_) dropPlans();
+}
+
+void HipCGDSubspaceOptimizer::setPlanCacheBytes(size_t bytes) {
+    cache_byte_cap_ = bytes;
+    while (cache_bytes_ > cache_byte_cap_ && evictOne()) {}
 }
 
 HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
@@ -480,19 +514,30 @@ HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const s
             return e;
         }
     ++cache_misses_;
-    if (cache_.size() >= cache_cap_) {   // least recently used goes
-        size_t lru = 0;
-        for (size_t i = 1; i < cache_.size(); ++i) if (cache_[i]->used < cache_[lru]->used) lru = i;
-        if (cache_[lru]->plan) rdis_hip_plan_destroy(cache_[lru]->plan);
-        delete cache_[lru];
-        cache_.erase(cache_.begin() + (long)lru);
-    }
+    while (cache_.size() >= cache_cap_ && evictOne()) {}
     CachedPlan* e = new CachedPlan;
     e->hash = h; e->used = ++cache_tick_;
     e->free_ptr = free_ptr; e->free_vid = free_vid; e->fac_ptr = fac_ptr; e->fac_id = fac_id;
-    const int rc = rdis_hip_plan_create(f.deviceProblem(), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
-                                        fac_ptr.data(), fac_id.data(), &e->plan);
+    // Device memory is the cache's real bound: when the device is out of it the least recently used plans
+    // go, one at a time, and the creation is tried again; with nothing left to drop the call is served by
+    // the transient path (rdis_hip_cgd_batch, in the problem's arena) like an uncached one.
+    int rc;
+    for (;;) {
+        rc = rdis_hip_plan_create(f.deviceProblem(), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
+                                  fac_ptr.data(), fac_id.data(), &e->plan);
+        if (rc != RDIS_HIP_ENOMEM || !evictOne()) break;
+    }
+    if (rc == RDIS_HIP_ENOMEM) { delete e; ++cache_fallbacks_; return nullptr; }
     if (rc != 0) { delete e; check(f.deviceContext(), rc, "rdis_hip_plan_create"); }
+    (void)rdis_hip_plan_device_bytes(e->plan, &e->bytes);
+    if ((size_t)e->bytes > cache_byte_cap_) {   // larger than the whole budget: not kept
+        rdis_hip_plan_destroy(e->plan);
+        delete e;
+        ++cache_fallbacks_;
+        return nullptr;
+    }
+    while (cache_bytes_ + (size_t)e->bytes > cache_byte_cap_ && evictOne()) {}
+    cache_bytes_ += (size_t)e->bytes;
     cache_.push_back(e);
     return e;
 }

@@ -47,6 +47,7 @@ typedef std::vector<std::pair<VariableID, Numeric> > PartialGradient;
 
 class Factor;
 class OptimizableFunction;
+class HipCGDSubspaceOptimizer;
 
 // SSmaxit / SSftol carrier (stands in for boost::program_options::variables_map)
 class Options {
@@ -219,6 +220,7 @@ private:
     mutable std::vector<VariableID> dirty_;
     mutable std::vector<char> is_dirty_;
     std::unordered_map<std::string, Variable*> by_name_;
+    mutable std::vector<HipCGDSubspaceOptimizer*> plan_holders_;   // optimisers with cached plans of prob_
 };
 
 class BundleAdjustmentFunction : public OptimizableFunction {
@@ -315,8 +317,16 @@ public:
     // `entries` plans are kept (least recently used goes first); 0 switches the cache off.  Results
     // are bit-identical either way.
     void setPlanCache(size_t entries);
+    // ... and at most `bytes` of device memory in all (default 4 GiB; rdis_hip_plan_device_bytes).  When
+    // the device runs out of memory while a plan is created, least recently used plans are dropped and the
+    // creation retried; a call whose plan cannot be kept at all is served by the transient path
+    // (rdis_hip_cgd_batch), counted in planCacheFallbacks().
+    void setPlanCacheBytes(size_t bytes);
     size_t planCacheHits() const { return cache_hits_; }
     size_t planCacheMisses() const { return cache_misses_; }
+    size_t planCacheFallbacks() const { return cache_fallbacks_; }
+    size_t planCacheBytes() const { return cache_bytes_; }
+    size_t planCacheEntries() const { return cache_.size(); }
 
     // results of the last optimize() beyond what the reference returns
     int lastIters() const { return last_iters_; }
@@ -328,11 +338,16 @@ private:
     CachedPlan* cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
                            const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id);
     void dropPlans();
+    bool evictOne();
+    friend class OptimizableFunction;
+    void functionGone();   // the function is being destroyed: its device problem goes, and the plans with it
     int last_iters_, last_status_;
     long long last_nfeval_, last_ngeval_;
     std::vector<CachedPlan*> cache_;
     size_t cache_cap_, cache_hits_, cache_misses_;
     unsigned long long cache_tick_;
+    size_t cache_byte_cap_, cache_bytes_, cache_fallbacks_;
+    bool function_alive_;
 };
 
 // The drop-in for LMSubspaceOptimizer (src/optimizers/LMSubspaceOptimizer.h): same contract and

@@ -1060,7 +1060,7 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
         return out
     for threads in (128, 256, 768):
         for rot in (0, 2):
-            ra, xa, _, _ = run({"lds_resident": 0, "block_threads": threads, "camera_records": rot})
+            ra, xa, _, _ = run({"lds_resident": 0, "ptm_stream": 0, "block_threads": threads, "camera_records": rot})
             # (lds_camera_sums 0: a camera variable's gradient entry summed as the plain solver sums it -- by default
             # the LDS solver sums camera partials across waves that share a camera, another grouping)
             rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0, "lds_camera_sums": 0})
@@ -1081,7 +1081,7 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
     cams, pts = P.ba_alternation_plans(lb)
     gl = capi.Problem(gctx, lb)
     for comps, base in ((cams, {"coop_group_min_factors": 0, "coop_min_factors": 0}), (pts, {"row_min_components": 1 << 30, "quad_min_components": 1 << 30})):
-        ra, xa, _, _ = run({**base, "lds_resident": 0}, comps, gl, lb, 12)
+        ra, xa, _, _ = run({**base, "lds_resident": 0, "ptm_stream": 0}, comps, gl, lb, 12)
         rb, xb, _, trb = run({**base, "lds_resident": 1}, comps, gl, lb, 12, trace=2048)
         # same decisions as long as the sums agree to the last bit; they may part in the last place -- population check
         assert np.all(rb.delta <= 0) and abs(rb.fret.sum() - ra.fret.sum()) <= 0.05 * abs(ra.fret.sum())
@@ -1095,9 +1095,88 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
     free = np.array([v for v in range(lb.nvars) if not (v < 441 and v % 9 in (6, 8)) and not (v >= 441 and v % 3 == 1 and v % 5 == 0)], dtype=np.int64)
     one = (np.array([0, len(free)]), free, np.array([0, lb.nfac]), np.arange(lb.nfac, dtype=np.int64))
     base = {"coop_min_factors": 0, "coop_group_min_factors": 0}
-    ra, xa, _, _ = run({**base, "lds_resident": 0}, one, gl, lb, 8)
+    ra, xa, _, _ = run({**base, "lds_resident": 0, "ptm_stream": 0}, one, gl, lb, 8)
     rb, xb, _, trb = run({**base, "lds_resident": 1}, one, gl, lb, 8, trace=4096)
     if lb.nvars * 44 < 150 * 1024:     # (fits the LDS: the new solver ran)
         check_replay(lb, trb[0], rb, 8, free_vid=free, fac_id=one[3], x=lb.x0[free])
         const = np.setdiff1d(np.arange(lb.nvars), free)
         assert np.array_equal(xb[const], lb.x0[const])
+
+
+def test_point_major_streaming_solver_alone_and_in_groups(gctx):
+    """solver_ptm.hpp: components too large for the LDS keep their cameras in LDS and stream their point blocks
+    (one record per block, a lane per point); with fewer components than compute units K workgroups share a
+    component (cgd_ptmg_kernel: partial sums exchanged per trial point, two ordered grid barriers per gradient).
+    Every variant is replayed against the oracle (bit-identical decisions, values to rounding); the variants
+    differ from each other only in the grouping of their sums, so their first line minimisation agrees to 1e-9
+    and their end values are draws of the same family.  Option ptm_stream = 2 sends components here that would
+    fit the LDS solver (small enough for the oracle to replay in seconds)."""
+    syn = P.make_synthetic_ba(5, 6, 700, obs_per_pt=3)     # 2100 factors, 2154 variables per component
+    csr = (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id)
+    g = capi.Problem(gctx, syn)
+
+    def run(opts, comps=csr, prob=g, pp=syn, iters=12, trace=4096):
+        prob.set_x(pp.x0)
+        plan = capi.Plan(prob, *comps)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        plan.set_option("trace_records", trace)
+        plan.set_option("dump_iters", iters)
+        plan.set_start(None)
+        plan.solve(iters, 3e-8)
+        r = plan.fetch()
+        nc = len(comps[0]) - 1
+        tr = [(plan.get_trace(c, trace)[0], plan.get_vectors(c, iters)) for c in range(nc)]
+        info = {k: plan.info(k) for k in ("components_point_major", "point_major_group", "components_lds", "components_plain")}
+        out = (r, prob.get_x(), plan.last_kernel_ms(), tr, info)
+        plan.close()
+        return out
+
+    def first_line(tr):   # value the first line minimisation ended on
+        t = tr[0]
+        k = np.nonzero(t[:, 0] == 5)[0][0]
+        return t[k, 2]
+
+    base = {"ptm_stream": 2, "coop_group_min_factors": 0, "coop_min_factors": 0}   # (no cooperative groups: the batch list)
+    ref = None
+    for threads, K in ((768, 1), (256, 1), (768, 2), (512, 3), (256, 4), (256, 8)):
+        r, x, (ms, nl), tr, info = run({**base, "ptm_threads": threads, "ptm_group": K})
+        assert info["components_point_major"] == 5 and info["components_lds"] == 0 and info["components_plain"] == 0, info
+        assert info["point_major_group"] == K and nl == 1, (info, nl)
+        assert np.all(r.delta < 0) and np.all((r.status & 0xFF) != 7)
+        for c in (0, 4):
+            fv, fc = syn.component(c)
+            sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
+            check_replay(syn, tr[c], sub, 12, free_vid=fv, fac_id=fc, x=syn.x0[fv], iter_tol=1e-10)
+        # the variables are left assigned to what was returned
+        assert np.array_equal(x[csr[1]], r.x)
+        fl = np.array([first_line(tr[c]) for c in range(5)])
+        if ref is None: ref = (r, fl)
+        else:
+            assert np.all(np.abs(fl - ref[1]) <= 1e-9 * np.abs(ref[1])), (threads, K, fl, ref[1])
+            assert abs(r.fret.sum() - ref[0].fret.sum()) <= 0.25 * ref[0].fret.sum()
+    # run to run: the same bits (fixed orders of summation in and across the workgroups)
+    r1 = run({**base, "ptm_threads": 256, "ptm_group": 4})[0]
+    r2 = run({**base, "ptm_threads": 256, "ptm_group": 4})[0]
+    assert np.array_equal(r1.fret, r2.fret) and np.array_equal(r1.x, r2.x) and np.array_equal(r1.nfeval, r2.nfeval)
+
+    # constants among the slots: ladybug's camera components (points fixed) and point components (cameras
+    # fixed: rotation records only read, a single point block -- most workgroups of a group own nothing)
+    lb = P.load_bal(ncams=49, npts=500)
+    cams, pts = P.ba_alternation_plans(lb)
+    gl = capi.Problem(gctx, lb)
+    def first(comps, k):   # the first k components of a decomposition
+        fp, fv, cp, ci = comps
+        return (fp[:k + 1], fv[:fp[k]], cp[:k + 1], ci[:cp[k]])
+    # (a group needs all its workgroups resident: sixty of the point components)
+    for comps, opts in ((cams, {"coop_group_min_factors": 0, "coop_min_factors": 0}), (first(pts, 60), {"row_min_components": 1 << 30, "quad_min_components": 1 << 30})):
+        nc = len(comps[0]) - 1
+        for K in (1, 2):
+            r, x, _, tr, info = run({**base, **opts, "ptm_group": K, "ptm_threads": 256}, comps, gl, lb, 10, trace=2048)
+            assert info["components_point_major"] == nc and info["point_major_group"] == K, info
+            assert np.all(r.delta <= 0)
+            for c in (0, nc // 2, nc - 1):
+                fv = comps[1][comps[0][c]:comps[0][c + 1]]
+                fc = comps[3][comps[2][c]:comps[2][c + 1]]
+                sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
+                check_replay(lb, tr[c], sub, 10, free_vid=fv, fac_id=fc, x=lb.x0[fv], iter_tol=1e-8)

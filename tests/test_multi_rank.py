@@ -100,6 +100,7 @@ def test_strong_scaling_shards_of_the_bench_cover_the_decomposition():
     """bench.py --scaling strong: every rank builds only its share of a fixed synthetic decomposition;
     the shares are the components of the whole, each exactly once (they are generated from their ids)"""
     import bench
+    bench.STRONG.update(bench.STRONG_SIZES["small"])   # (the partition logic, not the size)
     whole = P.make_synthetic_ba(1000, 3, 40)
     nv, nf = whole.nvars // 1000, whole.nfac // 1000
     seen = 0
@@ -122,6 +123,7 @@ def test_strong_scaling_block_shards_with_lpt():
     through dist.rank_decomposition (LPT by factor count) on every rank -- a partition, balanced,
     the same on every rank, lists bit-exact"""
     import bench
+    bench.STRONG.update(bench.STRONG_SIZES["small"])   # (the partition logic, not the size)
     for world in (1, 2, 8):
         seen, loads_seen = [], None
         for rank in range(world):
@@ -144,6 +146,7 @@ _WORKER_STRONG = textwrap.dedent("""
     import numpy as np
     import torch, torch.distributed as dist
     import bench
+    bench.STRONG.update(bench.STRONG_SIZES["small"])   # (the partition logic, not the size)
     from rdis_amd.dist import allreduce_objective
     from oracle import oracle as O
     dist.init_process_group("gloo")
@@ -173,6 +176,7 @@ def test_strong_scaling_block_two_ranks_gloo(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     import bench
+    bench.STRONG.update(bench.STRONG_SIZES["small"])   # (the partition logic, not the size)
     from oracle import oracle as O
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     pp, _, _, _ = bench.strong_scaling_shard(0, 1, components=6)

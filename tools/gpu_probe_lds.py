@@ -5,6 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
+bench.STRONG.update(bench.STRONG_SIZES["small"])   # (round 2's block: 2048-factor components, the LDS-resident solver's case)
 from rdis_amd import capi, problems as P
 ctx = capi.Context(0)
 
