@@ -91,6 +91,8 @@ struct PlanView {
     const unsigned* pm_gqw;   // the factor's slot word (camera block | point block << 12), 0xFFFFFFFF = no factor
     const int* pm_gqe;        // its entry in pm_pg
     const double2* pm_gqobs;  // its observation
+    int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...
+    double* st_val;       // ... and that value; null unless the plan's option emulate_stale_cache is set
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

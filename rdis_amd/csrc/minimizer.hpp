@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <type_traits>
 
 namespace rdis_hip {
 
@@ -173,7 +174,7 @@ struct Predictor {
 
 struct CgdMachine {
     enum : int {
-        S_BEGIN, S_FIRST, S_GRAD0, S_BR_FB, S_BR_FC, S_BR_HEAD,
+        S_BEGIN, S_FIRST, S_GRAD0, S_BR_FA, S_BR_FB, S_BR_FC, S_BR_HEAD,
         S_BR_CASE1, S_BR_CASE2, S_BR_SHIFT, S_DB_START, S_DB_FIRST, S_DB_HEAD, S_DB_EVAL,
         S_AFTER_LINMIN, S_REDUCED, S_FINISH, S_ROLLED, S_DONE
     };
@@ -194,9 +195,14 @@ struct CgdMachine {
     double a, b, x, w, v, fx, fw, fv, dx, dw, dv, d, e, uu;
     int it;
     bool tiny;
+    // noskip: evaluate even where the value is known bit for bit -- f at step 0 of a new line, f and slope at the
+    // bracket's middle point.  Set by environments that emulate the reference's stale factor cache
+    // (Variable.cpp:66-76, Factor.h:228-234): there the reference's repeated evaluation of the same point can
+    // return another value (factors keep what they computed before their variables moved by less than 1e-12).
+    bool noskip;
 
-    __device__ void init(int maxiters_, double ftol_) {
-        maxiters = maxiters_; ftol = ftol_;
+    __device__ void init(int maxiters_, double ftol_, bool noskip_ = false) {
+        maxiters = maxiters_; ftol = ftol_; noskip = noskip_;
         st = S_BEGIN; its = 0; iter = 0; reason = EXIT_ITMAX;
         finit = 0.0; fp = 0.0; fret = DBL_MAX;
         saw_nan = false; rolled_back = false; nfeval = 0; ngeval = 0;
@@ -234,6 +240,13 @@ struct CgdMachine {
         iter = its;
         ax = 0.0; bx = 1.0;
         fa = fp; sa = 0.0; va = false;
+        if (noskip) {   // the reference's fa = func(ax) (nrc :87), evaluated
+            st = S_BR_FA;
+            Request r = want_f(ax);
+            r.flags |= pre_ops | RF_PRE_BEGIN;
+            r.b = gamma;
+            return r;
+        }
         ++nfeval;
         pp_tag = TR_F; pp_a = 0.0; pp_b = fp; pp_c = 0.0;
         st = S_BR_FB;
@@ -363,6 +376,10 @@ struct CgdMachine {
                 return start_line(RF_PRE_START, 0.0);
 
             // ---- bracket from (0, 1) (start_line) -----------------------------------------
+            case S_BR_FA:   // (noskip only)
+                fa = r0; if (r0 != r0) saw_nan = true;
+                st = S_BR_FB;
+                return want_fd(bx);
             case S_BR_FB:
                 fb = r0; sb = r1; vb = true; if (r0 != r0) saw_nan = true;
                 if (fb > fa) {
@@ -429,7 +446,7 @@ struct CgdMachine {
                 b = (ax > cx ? ax : cx);
                 x = w = v = bx;
                 d = 0.0; e = 0.0; it = 0;
-                if (vb) {  // value and slope at bx are known from the bracketing: same point, same bits
+                if (vb && !noskip) {  // value and slope at bx are known from the bracketing: same point, same bits
                     ++nfeval; ++ngeval;  // the reference's funcd(x), funcd.df(x) (nrc :314-315)
                     fx = fb; dx = sb;
                     fw = fv = fx; dw = dv = dx;
@@ -637,6 +654,10 @@ __device__ __forceinline__ double pick(const double (&v)[N], int j) {
 }
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
 
+// Env::NOSKIP (optional, default false): CgdMachine::noskip
+template <class E, class = void> struct EnvNoSkip { static constexpr bool value = false; };
+template <class E> struct EnvNoSkip<E, std::void_t<decltype(E::NOSKIP)>> { static constexpr bool value = E::NOSKIP; };
+
 // Env::SPEC: trial steps evaluated per value+slope request (1 = no speculation).  With SPEC > 1 Env
 // provides eval_value_slope_spec(steps, f, s) for SPEC steps at once and spec_hint() / spec_note().
 template <class Env>
@@ -655,7 +676,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
     // words to the same LDS addresses is a 64-way bank conflict on every store (measured: 1700 of the
     // 2300 cycles of a step); the request reaches everybody, this lane's own wave included, through LDS
     const bool stepper = E.stepper() && E.writer();
-    if (stepper) M.init(maxiters, ftol);
+    if (stepper) M.init(maxiters, ftol, EnvNoSkip<Env>::value);
     for (int round = 0;; ++round) {
         const long long ts0 = E.clock();
         if (stepper) {
@@ -747,7 +768,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
             if constexpr (Env::UNIFORM) break;
             else {
                 if (!E.next_problem(M)) break;
-                if (stepper) M.init(maxiters, ftol);
+                if (stepper) M.init(maxiters, ftol, EnvNoSkip<Env>::value);
                 r0 = r1 = r2 = 0.0;
                 continue;
             }

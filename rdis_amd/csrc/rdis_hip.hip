@@ -217,6 +217,8 @@ struct rdis_hip_plan {
     int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
     int lds_camera_sums = 1;          // option "lds_camera_sums": 0 = camera partials through gfac[] like the plain batch solver
+    int emulate_stale = 0;            // option "emulate_stale_cache": the reference's factor cache, emulated (solver_lds.hpp; that solver only)
+    DevBuf st_ev, st_val;
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
     DevBuf lds_ints, lds_obs;
@@ -259,6 +261,7 @@ struct rdis_hip_plan {
         v.ls_obs = lds_obs.as<double2>();
         v.ls_gperm = li + off_ls_gperm; v.ls_gptr = li + off_ls_gptr;
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
+        v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
         v.pm_rec = pm_rec.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_pg = pm_pg.as<double>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
@@ -961,6 +964,8 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
         L->ptm_threads = (int)value;
+    } else if (n == "emulate_stale_cache") {
+        L->emulate_stale = value != 0;
     } else if (n == "lds_camera_sums") {
         L->lds_camera_sums = value != 0;
     } else if (n == "lds_rot") {
@@ -1374,7 +1379,8 @@ int prepare_partition(rdis_hip_plan* L) {
             };
             const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
             const bool records = L->lds_rot >= 0 ? L->lds_rot == 1 : L->lds_max_factors > 512;
-            L->lds_rot_mode = L->camera_records == 0 ? ROT_PER_FACTOR : camfix_of(r_lds, L->h_rest.size()) ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
+            // (the stale-cache emulation is instantiated for per-factor rotations only: the same bits per factor, fewer kernels)
+            L->lds_rot_mode = (L->camera_records == 0 || L->emulate_stale) ? ROT_PER_FACTOR : camfix_of(r_lds, L->h_rest.size()) ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
             L->ptm_rot_mode = L->camera_records == 0 || L->lds_rot == 0 ? ROT_PER_FACTOR : camfix_of(r_ptm, r_lds) ? ROT_CAMFIX : ROT_RECORDS;
         }
     }
@@ -1597,7 +1603,33 @@ int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int
         default: return launch_ptm_rot<ROT_PER_FACTOR>(L, stream, threads, first, grid, maxiters, ftol);
     }
 }
+int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    ProblemView P = L->prob->view();
+    PlanView V = L->view();
+    V.order += first;
+    const size_t dyn = lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap);
+    const int nsc = L->lds_ns_cap, ncc = L->lds_ncb_cap, chc = L->lds_chunk_cap;
+#define RDIS_LDS_LAUNCH(T)                                                                                              \
+    do {                                                                                                                \
+        if (dyn > 48 * 1024)                                                                                            \
+            HIPCHK(c, hipFuncSetAttribute((const void*)cgd_lds_kernel<T, ROT_PER_FACTOR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
+        cgd_lds_kernel<T, ROT_PER_FACTOR, true><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, nsc, ncc, chc);                \
+    } while (0)
+    switch (threads) {
+        case 64: RDIS_LDS_LAUNCH(64); break;
+        case 128: RDIS_LDS_LAUNCH(128); break;
+        case 256: RDIS_LDS_LAUNCH(256); break;
+        case 512: RDIS_LDS_LAUNCH(512); break;
+        case 768: RDIS_LDS_LAUNCH(768); break;
+        default: RDIS_LDS_LAUNCH(1024); break;
+    }
+#undef RDIS_LDS_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 int launch_lds(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    if (L->emulate_stale) return launch_lds_stale(L, stream, threads, first, grid, maxiters, ftol);
     switch (L->lds_rot_mode) {
         case ROT_CAMFIX: return launch_lds_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
         case ROT_RECORDS: return launch_lds_rot<ROT_RECORDS>(L, stream, threads, first, grid, maxiters, ftol);
@@ -1621,6 +1653,17 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     // (also when another plan of the problem has moved the exchange-state buffer this plan's
     // cooperative group tables point into)
     if (L->partition_dirty || (!L->coop.empty() && L->coop_state_gen != p->coop_state_gen)) { int rc = prepare_partition(L); if (rc) return rc; }
+    if (L->emulate_stale) {
+        // implemented where config 5's components run: the LDS-resident batch solver (and per-factor rotations)
+        if ((size_t)L->rest_lds != L->h_rest.size() || !L->coop.empty() || !L->stream.empty() || L->lds_rot_mode != ROT_PER_FACTOR)
+            return fail(c, RDIS_HIP_EINVAL, "emulate_stale_cache: every component of the plan must run on the LDS-resident batch solver "
+                                            "(bundle adjustment, variables fitting a compute unit's LDS, no cooperative groups)");
+        if (!L->st_ev.p) {
+            int rc = plan_alloc(L, L->st_ev, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(int));
+            if (!rc) rc = plan_alloc(L, L->st_val, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(double));
+            if (rc) return rc;
+        }
+    }
     PlanView V = L->view();
     HIPCHK(c, hipEventRecord(p->ev0, c->stream));
     // The batched launch is independent of the cooperative ones (disjoint components): it goes to a
@@ -1721,6 +1764,9 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             const int fit = std::min(std::min(PTM_MAX_GROUP, cap / slots8), SMALL_COOP_ENTRIES / (gthreads / 64));
             const int useful = (int)std::max<int64_t>(1, (L->ptm_min_points + 63) / 64 / 24);
             K = L->ptm_group > 1 ? std::min(L->ptm_group, fit) : std::min(fit, useful);
+            // (a group must bring more lanes to a component than the one workgroup it replaces: 250 components of
+            // ladybug's size 50.4 ms a workgroup of 768 lanes each, 56.0 as pairs of 256)
+            if (L->ptm_group == 0 && K * gthreads <= threads) K = 1;
             if (K >= 2) threads = gthreads;
         }
         L->ptm_last_group = std::max(K, 1);

@@ -36,12 +36,25 @@ namespace rdis_hip {
 constexpr int LDS_MAX_BYTES = 160 * 1024 - 4096;   // dynamic LDS a launch may ask for (static: machine, requests, reduction slots)
 constexpr int LDS_DOUBLES_PER_SLOT = 5;            // Pv, XI, LO, HI, X
 __host__ __device__ inline size_t lds_bytes_for(int ns, int ncb, int nchunk) {
-    return (size_t)ns * (LDS_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) +
+    // (per slot two ints: the local free index, and the assignment at which the slot last changed by 1e-12 or more --
+    // the latter used by the stale-cache emulation only)
+    return (size_t)ns * (LDS_DOUBLES_PER_SLOT * sizeof(double) + 2 * sizeof(int)) + (size_t)ncb * 7 * sizeof(double) +
            (size_t)nchunk * (9 * sizeof(double) + sizeof(int)) + 64;
 }
 
-template <int ROT, bool PREFETCH>
+// STALE: emulate the reference's factor cache (plan option emulate_stale_cache).  Variable::assign tells a variable's
+// factors to recompute only when the new value differs from the variable's previous one by 1e-12 or more
+// (src/Variable.cpp:66-76); Factor::eval returns the cached value otherwise (src/Factor.h:228-234).  On the plateaus
+// of these descents the last trial points of a line search lie closer together than that, and the reference's sums
+// then mix values of neighbouring points -- 1e-12-level differences that decide how often the 3e-8 stopping test fires
+// (of 1000 synthetic components 859 leave by a tolerance with the cache, 939 without).  Emulated with two counters:
+// every assignment of a trial point has a number (epoch); a slot remembers the last assignment that moved it by
+// >= 1e-12 (CHE), a factor the assignment of its last VALUE evaluation (fev) and that value (fvv); the factor is
+// recomputed iff one of its twelve slots moved since.  Slopes and gradients are always fresh, like the reference's
+// computeGradient.  The control logic then evaluates every point the reference evaluates (CgdMachine::noskip).
+template <int ROT, bool PREFETCH, bool STALE = false>
 struct LdsEnv {
+    static constexpr bool NOSKIP = STALE;
     const ProblemView& P;
     const PlanView& L;
     int comp, n, m, f0, c0, tid, nt, nwaves;
@@ -56,6 +69,10 @@ struct LdsEnv {
     const int* svid;          // variable id of a slot
     double *Pv, *XI, *LO, *HI, *X, *ROTR;   // LDS
     int* SF;                  // LDS: local free index of a slot, -1 = constant
+    int* CHE;                 // LDS (STALE): the assignment that last moved the slot by 1e-12 or more
+    int* fev;                 // (STALE) per listed factor: the assignment of its last value evaluation, -1 = never
+    double* fvv;              //         ... and the value
+    int epoch;                //         assignments so far
     double *g, *h;            // plan workspace, by free index
     double (*red)[3][MAX_WAVES];
     int parity;
@@ -104,12 +121,20 @@ struct LdsEnv {
     }
     // SubfunctionFD::quickAssignVals at p + a*xi (reference .cpp:160-184; the trial point is
     // formed unfused like minimize_nrc.h:434)
+    // Variable::assign of an assigned variable (src/Variable.cpp:66-88)
+    __device__ __forceinline__ void set_x(int s, double xn) {
+        if constexpr (STALE) {
+            if (!(fabs(xn - X[s]) < 1e-12)) CHE[s] = epoch;
+        }
+        X[s] = xn;
+    }
     __device__ void assign_line(double a) {
 #pragma clang fp contract(off)
+        if constexpr (STALE) ++epoch;
         for (int s = tid; s < ns; s += nt) {
             if (SF[s] < 0) continue;
             const double t = a * XI[s];
-            X[s] = clampd(Pv[s] + t, LO[s], HI[s]);
+            set_x(s, clampd(Pv[s] + t, LO[s], HI[s]));
         }
         refresh_records([&](int s) {
 #pragma clang fp contract(off)
@@ -119,15 +144,17 @@ struct LdsEnv {
         __syncthreads();
     }
     __device__ void assign_p() {
+        if constexpr (STALE) ++epoch;
         for (int s = tid; s < ns; s += nt)
-            if (SF[s] >= 0) X[s] = clampd(Pv[s], LO[s], HI[s]);
+            if (SF[s] >= 0) set_x(s, clampd(Pv[s], LO[s], HI[s]));
         refresh_records([&](int s) { return clampd(Pv[s], LO[s], HI[s]); });
         __syncthreads();
     }
     __device__ void assign_start() {   // clamp(x_init): the rollback (CGD .cpp:71)
         const double* xs = L.xstart + f0;
+        if constexpr (STALE) ++epoch;
         for (int s = tid; s < ns; s += nt)
-            if (SF[s] >= 0) X[s] = clampd(xs[SF[s]], LO[s], HI[s]);
+            if (SF[s] >= 0) set_x(s, clampd(xs[SF[s]], LO[s], HI[s]));
         refresh_records([&](int s) { return clampd(xs[SF[s]], LO[s], HI[s]); });
         __syncthreads();
     }
@@ -175,7 +202,18 @@ struct LdsEnv {
             double v[12];
             BaFwd t;
             int cb, pb;
-            af += forward(w, o, v, t, cb, pb);
+            double fj = forward(w, o, v, t, cb, pb);
+            if constexpr (STALE) {   // Factor::eval -> evalFactorCached
+                int moved = CHE[pb];
+#pragma unroll
+                for (int k = 1; k < 3; ++k) moved = max(moved, CHE[pb + k]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) moved = max(moved, CHE[cb + k]);
+                const int ev = fev[j];
+                if (ev < 0 || moved > ev) fvv[j] = fj; else fj = fvv[j];
+                fev[j] = epoch;
+            }
+            af += fj;
             if constexpr (SLOPE) {
                 double d[12];
 #pragma unroll
@@ -242,6 +280,11 @@ struct LdsEnv {
                 Pv[s] = xc; X[s] = xc; LO[s] = -__builtin_inf(); HI[s] = __builtin_inf();
             }
             XI[s] = 0.0;
+            if constexpr (STALE) CHE[s] = 0;
+        }
+        if constexpr (STALE) {
+            for (int j = tid; j < m; j += nt) fev[j] = -1;
+            epoch = 0;
         }
         __syncthreads();
         if constexpr (ROT != ROT_PER_FACTOR) {   // every camera block's record at the start (those of constant cameras stay)
@@ -407,7 +450,7 @@ struct LdsEnv {
     }
 };
 
-template <int THREADS, int ROT>
+template <int THREADS, int ROT, bool STALE = false>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap, int ncb_cap, int chunk_cap) {
     extern __shared__ double lds_dyn[];
@@ -431,13 +474,14 @@ cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap,
     double* CG = base + LDS_DOUBLES_PER_SLOT * ns_cap + 7 * ncb_cap;
     int* CGC = (int*)(CG + 9 * chunk_cap);
     int* SF = CGC + chunk_cap;
+    int* CHE = SF + ns_cap;
     for (int s = threadIdx.x; s < ns; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     double* ws = L.ws + 5ll * f0;
-    LdsEnv<ROT, (THREADS <= 512)> E{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
+    LdsEnv<ROT, (THREADS <= 512), STALE> E{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
                   ns, ncb, L.ls_obs + c0, L.ls_fidx + c0, L.ls_gperm + 64ll * L.ls_gptr[comp], L.ls_gptr[comp + 1] - L.ls_gptr[comp], CG, CGC, L.v2s_ptr + f0, L.ls_vid + s0,
                   base, base + ns_cap, base + 2 * ns_cap, base + 3 * ns_cap, base + 4 * ns_cap, base + LDS_DOUBLES_PER_SLOT * ns_cap,
-                  SF, ws + 2ll * n, ws + 3ll * n,
+                  SF, CHE, STALE ? L.st_ev + c0 : nullptr, STALE ? L.st_val + c0 : nullptr, 0, ws + 2ll * n, ws + 3ll * n,
                   red, 0,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0
 #ifdef RDIS_COOP_TIMING

@@ -308,6 +308,18 @@ double HipRDISLevelOptimizer::runPlan(LevelPlan& lp, int sweep, double objective
     return objective;
 }
 
+void HipRDISLevelOptimizer::decompose() {
+    buildTree();
+    buildPlans();
+}
+
+void HipRDISLevelOptimizer::planLists(size_t i, int& depth, int& kind, std::vector<int64_t>& free_ptr, std::vector<int64_t>& free_vid,
+                                      std::vector<int64_t>& fac_ptr, std::vector<int64_t>& fac_id) const {
+    const LevelPlan& lp = *plans_.at(i);
+    depth = lp.depth; kind = lp.kind;
+    free_ptr = lp.free_ptr; free_vid = lp.free_vid; fac_ptr = lp.fac_ptr; fac_id = lp.fac_id;
+}
+
 Numeric HipRDISLevelOptimizer::optimize(bool printInfo) {
     for (const Variable* v : f_.getVariables())
         if (!v->isAssigned()) throw std::logic_error("HipRDISLevelOptimizer::optimize: assign an initial state first");

@@ -66,6 +66,15 @@ public:
     // value of the function; the variables are left assigned to the optimum found.
     Numeric optimize(bool printInfo = false);
 
+    // The decomposition alone -- tree and per-depth plans, nothing solved (what optimize() does first): for callers
+    // that want to look at it, and for the parity tests against oracle/levels.py.
+    void decompose();
+    // the launches of a sweep, in order: plan i solves the separators (kind 0) or the leaves (kind 1) of one depth;
+    // its lists are the arguments of rdis_hip_plan_create
+    size_t numPlans() const { return plans_.size(); }
+    void planLists(size_t i, int& depth, int& kind, std::vector<int64_t>& free_ptr, std::vector<int64_t>& free_vid,
+                   std::vector<int64_t>& fac_ptr, std::vector<int64_t>& fac_id) const;
+
     const std::vector<Node>& nodes() const { return nodes_; }
     const std::vector<Step>& trace() const { return trace_; }
     int sweepsDone() const { return sweeps_; }

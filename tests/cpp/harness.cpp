@@ -361,4 +361,55 @@ int harness_level_driver_sinusoid(const double* x0, int maxit, int max_sweeps, d
     } catch (const std::exception& e) { std::cerr << "harness_level_driver_sinusoid: " << e.what() << std::endl; return -2; }
 }
 
+// ---- GPU (component labelling): the level driver's decomposition, nothing solved.  which: 0 = BAL file (path, ncams, npts),
+// 1 = the default high-dimensional sinusoid.  out (capacity cap int64): #nodes, then per node {depth, parent, leaf, #vars,
+// #factors, #separator, #sepFactors, vars.., factors.., separator.., sepFactors..}; then #plans, per plan {depth, kind, #components,
+// free_ptr.. (ncomp + 1), #free, free_vid.., fac_ptr.. (ncomp + 1), #fac, fac_id..}.  Returns the number of entries written (< 0: error).
+long long harness_level_tree(int which, const char* path, long long ncams, long long npts, double blkpct, double seppct, long long* out, long long cap) {
+    try {
+        std::unique_ptr<OptimizableFunction> owner;
+        if (which == 0) {
+            std::unique_ptr<BundleAdjustmentFunction> f(new BundleAdjustmentFunction);
+            if (!f->load(path, ncams, npts)) return -1;
+            f->assignAll(f->getInitialState());
+            owner = std::move(f);
+        } else {
+            std::unique_ptr<PolynomialFunction> f = PolynomialFunction::makeHighDimSinusoid();
+            NumericVec x((size_t)f->getNumVars(), 0.5);
+            f->assignAll(x);
+            owner = std::move(f);
+        }
+        HipCGDSubspaceOptimizer ssopt(*owner);
+        HipRDISLevelOptimizer rdis(*owner, ssopt);
+        Options ro; ro.set("AVblkpct", blkpct); ro.set("sepPiecePct", seppct);
+        rdis.setParameters(ro);
+        rdis.decompose();
+        long long n = 0;
+        auto put = [&](long long v) { if (n < cap) out[n] = v; ++n; };
+        put((long long)rdis.nodes().size());
+        for (const auto& nd : rdis.nodes()) {
+            put(nd.depth); put(nd.parent); put(nd.leaf ? 1 : 0);
+            put((long long)nd.vars.size()); put((long long)nd.factors.size()); put((long long)nd.separator.size()); put((long long)nd.sepFactors.size());
+            for (auto v : nd.vars) put(v);
+            for (auto v : nd.factors) put(v);
+            for (auto v : nd.separator) put(v);
+            for (auto v : nd.sepFactors) put(v);
+        }
+        put((long long)rdis.numPlans());
+        for (size_t i = 0; i < rdis.numPlans(); ++i) {
+            int depth, kind;
+            std::vector<int64_t> fp, fv, cp, ci;
+            rdis.planLists(i, depth, kind, fp, fv, cp, ci);
+            put(depth); put(kind); put((long long)fp.size() - 1);
+            for (auto v : fp) put(v);
+            put((long long)fv.size());
+            for (auto v : fv) put(v);
+            for (auto v : cp) put(v);
+            put((long long)ci.size());
+            for (auto v : ci) put(v);
+        }
+        return n <= cap ? n : -3;
+    } catch (const std::exception& e) { std::cerr << "harness_level_tree: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

@@ -397,6 +397,56 @@ def test_config5_synthetic_1000_components(gctx):
     o = O.OracleProblem(pp, emulate_stale_cache=False)
     o.assign(None, r.x)
     assert abs(o.eval() - r.fret.sum()) <= 1e-12 * r.fret.sum()          # returned values ARE the objective at the returned point
+    # The device with the quirk EMULATED (plan option emulate_stale_cache: a factor keeps its cached value until one of
+    # its variables is assigned a value 1e-12 or more away from its previous one, src/Variable.cpp:66-76, src/Factor.h:228-234;
+    # every point the reference evaluates is evaluated): now the reference-faithful population is the comparator --
+    # exit rates included, which the recomputing device misses by 76 of 1000.
+    g.set_x(pp.x0)
+    plan_e = capi.Plan(g)
+    plan_e.set_option("emulate_stale_cache", 1)
+    plan_e.set_start(pp.x0)
+    plan_e.solve(25, 3e-8)
+    re_ = plan_e.fetch()
+    ms_e, _ = plan_e.last_kernel_ms()
+    est = re_.status & 0xFF
+    d_eq = np.abs(re_.fret - qf) / np.abs(qf)
+    print("   device with the cache emulated (%.2f ms): tolerance exits %d (reference-faithful oracle %d, recomputing device %d), objective %.6g (%.6g), "
+          "KS device:reference %.3f, paired |df|/f median %.3f, evaluations %d (oracle %d)" % (
+              ms_e, (est <= 2).sum(), (qfst <= 2).sum(), (dst <= 2).sum(), re_.fret.sum(), qf.sum(), _ks(re_.fret / finit, qf / finit),
+              np.median(d_eq), re_.nfeval.sum(), sum(q.nfeval for q in rq)))
+    assert abs(int((est <= 2).sum()) - int((qfst <= 2).sum())) <= 35 and np.all((est != 5) & (est != 7))    # 3 sigma of a binomial count
+    assert _ks(re_.fret / finit, qf / finit) <= 0.0872
+    assert np.median(d_eq) <= 1.5 * np.median(d_oo) and np.quantile(d_eq, 0.75) <= 1.5 * np.quantile(d_oo, 0.75)
+    assert abs(re_.fret.sum() - qf.sum()) <= max(3 * spread, 0.03 * qf.sum())
+    assert abs(int(re_.nfeval.sum()) - sum(q.nfeval for q in rq)) <= 0.03 * re_.nfeval.sum()
+    assert np.max(np.abs((re_.fret - re_.delta) - finit) / finit) <= 1e-12 and np.all(re_.delta <= 0)
+    # short prefixes are not yet chaotic: after two iterations device and emulating oracle agree component by component
+    g.set_x(pp.x0)
+    plan_e.set_start(pp.x0)
+    plan_e.solve(2, 3e-8)
+    r2 = plan_e.fetch()
+    def run2(c):
+        fv, fc = pp.component(c)
+        return O.OracleProblem(pp, emulate_stale_cache=True).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=2, ftol=3e-8)
+    with ThreadPoolExecutor(8) as ex:
+        o2 = list(ex.map(run2, range(1000)))
+    f2 = np.array([q.fret for q in o2])
+    same_counts = np.mean([(q.nfeval == a and q.ngeval == b) for q, a, b in zip(o2, r2.nfeval, r2.ngeval)])
+    rel2 = np.abs(r2.fret - f2) / np.abs(f2)
+    print("   two iterations, cache emulated: identical f / df call counts in %.1f %% of the components, |df|/f median %.2e, 99 %% %.2e" % (
+        100 * same_counts, np.median(rel2), np.quantile(rel2, 0.99)))
+    assert same_counts >= 0.95 and np.median(rel2) <= 1e-9
+    plan_e.close()
+    # the option is refused where it is not implemented (a cooperative group)
+    lb = P.load_bal(ncams=5, npts=30).single_component()
+    gl = capi.Problem(gctx, lb)
+    pl = capi.Plan(gl)
+    pl.set_option("emulate_stale_cache", 1)
+    pl.set_option("lds_resident", 0)
+    pl.set_start(lb.x0)
+    with pytest.raises(capi.RdisHipError):
+        pl.solve(3, 3e-8)
+    pl.close(); gl.close()
 
 
 def test_plans_survive_a_move_of_the_exchange_state(gctx):

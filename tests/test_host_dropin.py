@@ -373,3 +373,101 @@ def test_level_driver_on_a_larger_bal_file(harness, tmp_path):
     o.assign(None, x)
     assert abs(o.eval() - out[0]) <= 1e-12 * out[0]
     assert np.all(x >= pp.lo) and np.all(x <= pp.hi)
+
+
+# ---- the decomposition against its independent restatement (oracle/levels.py) -----------------------------------
+def _cpp_tree(h, which, path, nc, npnt, pct, seppct):
+    h.harness_level_tree.restype = C.c_longlong
+    cap = 1 << 22
+    buf = np.zeros(cap, dtype=np.int64)
+    n = h.harness_level_tree(which, path, C.c_longlong(nc), C.c_longlong(npnt), C.c_double(pct), C.c_double(seppct),
+                             buf.ctypes.data_as(C.c_void_p), C.c_longlong(cap))
+    assert n > 0, n
+    pos = [0]
+
+    def take(k=None):
+        if k is None:
+            v = int(buf[pos[0]]); pos[0] += 1
+            return v
+        v = buf[pos[0]:pos[0] + k].copy(); pos[0] += k
+        return v
+    nodes = []
+    for _ in range(take()):
+        depth, parent, leaf, nv, nf, ns, nsf = (take() for _ in range(7))
+        nodes.append(dict(depth=depth, parent=parent, leaf=bool(leaf), vars=take(nv), factors=take(nf), separator=take(ns), sep_factors=take(nsf)))
+    plans = []
+    for _ in range(take()):
+        depth, kind, nc_ = take(), take(), take()
+        fp = take(nc_ + 1); fv = take(take()); cp = take(nc_ + 1); ci = take(take())
+        plans.append((depth, kind, fp, fv, cp, ci))
+    assert pos[0] == n
+    return nodes, plans
+
+
+def _compare_tree(pp, cpp_nodes, cpp_plans, pct, seppct):
+    from oracle import levels as LV
+    orc = O.OracleProblem(pp)
+    nodes = LV.build_tree(pp, orc, blkpct=pct, seppct=seppct)
+    assert len(nodes) == len(cpp_nodes)
+    for a, b in zip(nodes, cpp_nodes):
+        assert (a.depth, a.parent, a.leaf) == (b["depth"], b["parent"], b["leaf"])
+        assert np.array_equal(a.vars, b["vars"]) and np.array_equal(a.factors, b["factors"])
+        assert np.array_equal(a.separator, b["separator"]) and np.array_equal(a.sep_factors, b["sep_factors"])
+    plans = LV.level_plans(nodes)
+    assert len(plans) == len(cpp_plans)
+    for (d, k, _idx, fp, fv, cp, ci), (d2, k2, fp2, fv2, cp2, ci2) in zip(plans, cpp_plans):
+        assert (d, k) == (d2, k2)
+        assert np.array_equal(fp, fp2) and np.array_equal(fv, fv2) and np.array_equal(cp, cp2) and np.array_equal(ci, ci2)
+    # a partition: every variable in exactly one leaf or one separator
+    seen = np.zeros(pp.nvars, np.int64)
+    for nd in nodes:
+        np.add.at(seen, nd.vars if nd.leaf else nd.separator, 1)
+    assert np.all(seen == 1)
+    return nodes, plans, orc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,npnt,pct,seppct", [(5, 30, 0.2, 0.0), (0, 0, 0.2, 0.0), (7, 50, 0.2, 0.0), (20, 300, 0.1, 0.0),
+                                                (49, 1000, 0.05, 0.5), (12, 200, 0.1, 0.4)])
+def test_level_tree_is_the_stated_rule_bit_for_bit(harness, bal_path, nc, npnt, pct, seppct):
+    """The level driver's decomposition -- nodes, separators, children, the CSR lists of every launch -- equals
+    the independent Python restatement of the stated rule (oracle/levels.py: sets and a fresh search per step
+    instead of the C++'s incremental union-find; components from the CPU oracle's union-find instead of the
+    device labelling) entry for entry: ladybug 5/30, full, and four subsets with other block fractions, two of
+    them with sepPiecePct > 0 (several levels)."""
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 0, bal_path, nc, npnt, pct, seppct)
+    pp = P.load_bal(ncams=nc, npts=npnt)
+    nodes, plans, _ = _compare_tree(pp, cpp_nodes, cpp_plans, pct, seppct)
+    if (nc, npnt) == (0, 0):
+        assert len(nodes[0].separator) == 417 and sum(1 for nd in nodes if nd.depth == 1) == 6561   # 46 cameras + a point; 3 cameras' piece + 6560 points
+    if seppct > 0:
+        assert max(nd.depth for nd in nodes) >= 2
+
+
+@pytest.mark.gpu
+def test_level_tree_of_the_sinusoid_and_first_sweep_against_the_oracle(harness, bal_path):
+    """config 2's tree (every variable its own block, sepPiecePct 0.5: depth 4) bit for bit, and the first sweep
+    of ladybug 5/30 launch by launch: the oracle, solving the same components from the same values one after
+    the other, follows the device's objective within the spread two roundings of this chaotic descent show
+    after 25 iterations (the first launch: one 48-variable solve, a percent or two)."""
+    from oracle import levels as LV
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 1, None, 0, 0, 0.1, 0.5)
+    pp = P.make_high_dim_sinusoid()
+    nodes, plans, _ = _compare_tree(pp, cpp_nodes, cpp_plans, 0.1, 0.5)
+    assert max(nd.depth for nd in nodes) >= 3 and len(nodes) > 40
+    # first sweep, ladybug 5/30
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 0, bal_path, 5, 30, 0.2, 0.0)
+    lb = P.load_bal(ncams=5, npts=30)
+    nodes, plans, orc = _compare_tree(lb, cpp_nodes, cpp_plans, 0.2, 0.0)
+    obj, x = LV.sweep(lb, O.OracleProblem(lb), plans, lb.x0, maxiters=25)
+    out, tr, _ = _level_driver(harness, bal_path, 5, 30, sweeps=1, nvars=135)
+    dev = tr[:, 6]
+    assert len(dev) == len(obj) == len(plans)
+    print("first sweep, ladybug 5/30: device %s, oracle %s" % (np.array2string(dev, precision=6), np.array2string(obj, precision=6)))
+    f0 = out[1]
+    assert np.all(np.diff(np.concatenate([[f0], obj])) <= 0)                 # monotone on the oracle too
+    assert np.all(np.abs(dev - obj) <= 0.1 * np.abs(obj))                    # same descent, two roundings
+    # the oracle's running sum of deltas is its function value
+    o2 = O.OracleProblem(lb)
+    o2.assign(np.arange(lb.nvars, dtype=np.int64), x)
+    assert abs(o2.eval() - obj[-1]) <= 1e-9 * abs(obj[-1])

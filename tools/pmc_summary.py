@@ -20,5 +20,9 @@ for k in sorted(acc):
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         # SQ_ACTIVE_INST_* count quad-cycles summed over waves; 1024 SIMDs can each issue VALU every cycle
         print("    VALU issue utilisation   %.3f  (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE))" % (4 * c["SQ_ACTIVE_INST_VALU"] / (1024 * c["GRBM_GUI_ACTIVE"])))
+    if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0:
+        w = c["SQ_WAVE_CYCLES"]
+        print("    of all wave-cycles: issuing %.3f, parked (s_waitcnt / barrier) %.3f, issue-stalled %.3f" % (
+            c.get("SQ_ACTIVE_INST_ANY", 0) / w, c.get("SQ_WAIT_ANY", 0) / w, c.get("SQ_WAIT_INST_ANY", 0) / w))
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         print("    VALU instructions / SIMD-cycle  %.4f" % (c["SQ_INSTS_VALU"] / (1024 * c["GRBM_GUI_ACTIVE"])))

@@ -17,8 +17,8 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o strong -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_strong.json 2>> $D/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kernels -- python tools/profile_kernels.py > $D/kernels.txt 2>> $D/err.txt
 python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_pipe_
-python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_wg_kernel
-python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_wg_kernel
+python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_lds_kernel
+python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_ptm
 cp profiles/traffic.json $D/
 tail -1 $D/bench_ladybug_full.json
 head -3 $D/ladybug_kernel_stats.csv
