@@ -52,3 +52,19 @@ def test_null_arguments_are_rejected():
     assert lib.rdis_hip_create(0, None) == -1
     assert lib.rdis_hip_plan_solve(None, 10, 1e-8) == -1
     assert lib.rdis_hip_eval(None, 0, None, None) == -1
+
+
+def test_inline_asm_granule_loads_are_waited_for_before_use():
+    """grid_sync.hpp / solver_pipe.hpp load granule pairs with an inline-assembly `global_load_dwordx4 ... sc1` the
+    compiler's wait counting does not see.  tools/check_async_loads.py disassembles the gfx950 code object
+    of the library as built and verifies that no instruction touches such a load's destination registers before the
+    explicit `s_waitcnt vmcnt(0)` that follows the batch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "rdis_amd", "lib", "obj", "rdis_hip.o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("object file or llvm-objdump not available")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), obj], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 touched before" in out.stdout and " 0 reach a branch first" in out.stdout, out.stdout
