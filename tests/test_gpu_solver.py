@@ -1233,3 +1233,80 @@ def test_point_major_streaming_solver_alone_and_in_groups(gctx):
                 fc = comps[3][comps[2][c]:comps[2][c + 1]]
                 sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
                 check_replay(lb, tr[c], sub, 10, free_vid=fv, fac_id=fc, x=lb.x0[fv], iter_tol=1e-8)
+
+
+@pytest.mark.parametrize("solver", ["lds", "point-major", "point-major x2", "plain"])
+def test_batch_solvers_with_active_bounds_partial_blocks_and_rollback(gctx, solver):
+    """The edges of CGDSubspaceOptimizer::optimize on every batch solver a bundle-adjustment component can reach --
+    the LDS-resident one (default), the point-major streaming one alone and with two workgroups per component, the
+    plain one: domains tight enough that the clamp is active during the line searches (the objective is evaluated at
+    clamp(p + a xi) while CG keeps the unclamped iterate, .cpp:165-168), camera and point blocks only partly free,
+    constants untouched, results inside their domains and some on a bound; and the roll-back (.cpp:66-80): a component
+    whose start is already better than anything 2 iterations from a hopeless start reach is returned restored."""
+    opts = {"lds": {}, "point-major": {"ptm_stream": 2, "ptm_group": 1}, "point-major x2": {"ptm_stream": 2, "ptm_group": 2, "ptm_threads": 256},
+            "plain": {"lds_resident": 0, "ptm_stream": 0}}[solver]
+    opts = {"coop_group_min_factors": 0, "coop_min_factors": 0, **opts}
+    rng = np.random.default_rng(31)
+    pp = P.make_synthetic_ba(6, 4, 300, obs_per_pt=3)
+    nv = pp.nvars // 6
+    w = np.where(np.arange(pp.nvars) % nv < 36, 0.02, 0.01)      # cameras a little more room than points
+    pp.lo = np.maximum(pp.lo, pp.x0 - w * rng.uniform(0.2, 1.0, pp.nvars) * np.maximum(np.abs(pp.x0), 1e-3))
+    pp.hi = np.minimum(pp.hi, pp.x0 + w * rng.uniform(0.2, 1.0, pp.nvars) * np.maximum(np.abs(pp.x0), 1e-3))
+    # partly free blocks: a fifth of the variables held constant, spread over cameras and points
+    const = rng.random(pp.nvars) < 0.2
+    fp, fv, cp, ci = [0], [], [0], []
+    for c in range(6):
+        v, f = pp.component(c)
+        v = v[~const[v]]
+        fv.extend(v.tolist()); fp.append(len(fv)); ci.extend(f.tolist()); cp.append(len(ci))
+    comps = tuple(np.array(a, dtype=np.int64) for a in (fp, fv, cp, ci))
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g, *comps)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    plan.set_option("trace_records", 4096)
+    plan.set_option("dump_iters", 12)
+    plan.set_start(None)
+    plan.solve(12, 3e-8)
+    r = plan.fetch()
+    info = {k: plan.info(k) for k in ("components_lds", "components_point_major", "components_plain", "point_major_group")}
+    want = {"lds": "components_lds", "plain": "components_plain"}.get(solver, "components_point_major")
+    assert info[want] == 6, info
+    if solver == "point-major x2":
+        assert info["point_major_group"] == 2, info
+    fva = comps[1]
+    assert np.all(r.x >= pp.lo[fva]) and np.all(r.x <= pp.hi[fva]) and np.all(r.delta <= 0)
+    assert np.any((r.x == pp.lo[fva]) | (r.x == pp.hi[fva]))                        # the clamp was active
+    after = g.get_x()
+    assert np.array_equal(after[const], pp.x0[const]) and np.array_equal(after[fva], r.x)
+    for c in (0, 3, 5):
+        v, f = fva[comps[0][c]:comps[0][c + 1]], comps[3][comps[2][c]:comps[2][c + 1]]
+        sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
+        check_replay(pp, (plan.get_trace(c, 4096)[0], plan.get_vectors(c, 12)), sub, 12, free_vid=v, fac_id=f, x=pp.x0[v], iter_tol=1e-9)
+    plan.close()
+    # a NaN objective (an assert in the reference, CGDSubspaceOptimizer.cpp:175): reported as such with the start
+    # restored (.cpp:66-80's path), and the launch's other components are none the wiser.  Component 1's first point
+    # sits at the origin and so does the camera that sees it: the projection divides 0 by 0.
+    q = P.make_synthetic_ba(3, 4, 300, obs_per_pt=3)
+    v1, f1 = q.component(1)
+    cam, pt = int(q.cam_vid0[f1[0]]), int(q.pt_vid0[f1[0]])
+    q.x0[pt:pt + 3] = 0.0
+    q.x0[cam + 3:cam + 6] = 0.0
+    q.lo[pt:pt + 3] = np.minimum(q.lo[pt:pt + 3], -1.0); q.hi[pt:pt + 3] = np.maximum(q.hi[pt:pt + 3], 1.0)
+    q.lo[cam + 3:cam + 6] = np.minimum(q.lo[cam + 3:cam + 6], -1.0); q.hi[cam + 3:cam + 6] = np.maximum(q.hi[cam + 3:cam + 6], 1.0)
+    gq = capi.Problem(gctx, q)
+    pq = capi.Plan(gq)
+    for k, v in opts.items():
+        pq.set_option(k, v)
+    pq.set_start(q.x0)
+    pq.solve(3, 3e-8)
+    rq = pq.fetch()
+    assert (rq.status[1] & 0xFF) == 5 and (rq.status[1] & capi.STATUS_ROLLED_BACK)
+    nv1 = len(v1)
+    assert np.array_equal(rq.x[nv1:2 * nv1], q.x0[v1]) and np.array_equal(gq.get_x()[v1], q.x0[v1])
+    for c in (0, 2):
+        v, f = q.component(c)
+        ro = O.OracleProblem(q, emulate_stale_cache=False).cgd(free_vid=v, fac=f, x=q.x0[v], maxiters=3)
+        assert (rq.status[c] & 0xFF) == 3 and rq.delta[c] < 0
+        assert abs((rq.fret[c] - rq.delta[c]) - ro.finit) <= 1e-12 * ro.finit and abs(rq.fret[c] - ro.fret) <= 0.2 * ro.fret
+    pq.close()
