@@ -285,7 +285,43 @@ int harness_level_driver(const char* path, long long ncams, long long npts, int 
 // (SURVEY.md 3.2b).  The same call shapes, in rounds (one separator call, then the next few points in
 // turn), every call starting from the values the previous ones left.  cache: plan cache entries (0 = off).
 // out = {wall ms of all calls, #calls, final value of the function, sum of returned values, cache hits, cache misses}
+static int call_shapes(const char* path, int nsep, int npt_calls, int maxit, int cache, double cache_bytes, double* out, double* x_out);
 int harness_call_shapes(const char* path, int nsep, int npt_calls, int maxit, int cache, double* out, double* x_out) {
+    return call_shapes(path, nsep, npt_calls, maxit, cache, -1.0, out, x_out);
+}
+// ... with the cache's byte budget set too (cache_bytes < 0: left at its default); out has three more entries:
+// {.., calls served by the transient path because their plan could not be kept, plans resident at the end, their bytes}
+int harness_call_shapes_budget(const char* path, int nsep, int npt_calls, int maxit, int cache, double cache_bytes, double* out, double* x_out) {
+    return call_shapes(path, nsep, npt_calls, maxit, cache, cache_bytes, out, x_out);
+}
+// the optimizer outlives its function: the function's destructor drops the optimizer's cached plans (they belong to its
+// device problem), the optimizer's own destructor then has nothing left to touch.  Returns the plans cached before.
+int harness_optimizer_outlives_function(const char* path) {
+    try {
+        BundleAdjustmentFunction* f = new BundleAdjustmentFunction;
+        if (!f->load(path, 5, 30)) { delete f; return -1; }
+        f->assignAll(f->getInitialState());
+        HipCGDSubspaceOptimizer* ssopt = new HipCGDSubspaceOptimizer(*f);
+        Options o; o.set("SSmaxit", 3);
+        ssopt->setParameters(o);
+        const VariablePtrVec& V = f->getVariables();
+        int made = 0;
+        for (int p = 0; p < 4; ++p) {
+            VariablePtrVec pv; FactorPtrVec pf;
+            for (int k = 0; k < 3; ++k) pv.push_back(V[(size_t)(45 + 3 * p + k)]);
+            for (Factor* fa : f->getFactors()) if (static_cast<BundleAdjustmentFactor*>(fa)->getPointID() == p) pf.push_back(fa);
+            NumericVec y(3); Numeric d = 0;
+            for (size_t i = 0; i < 3; ++i) y[i] = pv[i]->eval();
+            ssopt->optimize(pv, pf, y, d, false);
+            ++made;
+        }
+        const int cached = (int)ssopt->planCacheEntries();
+        delete f;        // first the function (and its device problem) ...
+        delete ssopt;    // ... then the optimizer
+        return cached == made ? cached : -3;
+    } catch (const std::exception& e) { std::cerr << "harness_optimizer_outlives_function: " << e.what() << std::endl; return -2; }
+}
+static int call_shapes(const char* path, int nsep, int npt_calls, int maxit, int cache, double cache_bytes, double* out, double* x_out) {
     try {
         BundleAdjustmentFunction f;
         if (!f.load(path, 5, 30)) return -1;
@@ -294,6 +330,7 @@ int harness_call_shapes(const char* path, int nsep, int npt_calls, int maxit, in
         Options o; o.set("SSmaxit", maxit);
         ssopt.setParameters(o);
         ssopt.setPlanCache((size_t)cache);
+        if (cache_bytes >= 0) ssopt.setPlanCacheBytes((size_t)cache_bytes);
         (void)f.eval();   // upload outside the timed region
         const VariablePtrVec& V = f.getVariables();
         VariablePtrVec sepv(V.begin(), V.begin() + 48);
@@ -319,6 +356,7 @@ int harness_call_shapes(const char* path, int nsep, int npt_calls, int maxit, in
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         out[0] = ms; out[1] = (double)calls; out[2] = f.eval(); out[3] = sum;
         out[4] = (double)ssopt.planCacheHits(); out[5] = (double)ssopt.planCacheMisses();
+        if (cache_bytes >= 0) { out[6] = (double)ssopt.planCacheFallbacks(); out[7] = (double)ssopt.planCacheEntries(); out[8] = (double)ssopt.planCacheBytes(); }
         if (x_out) for (size_t i = 0; i < V.size(); ++i) x_out[i] = V[i]->eval();
         return 0;
     } catch (const std::exception& e) { std::cerr << "harness_call_shapes: " << e.what() << std::endl; return -2; }

@@ -471,3 +471,31 @@ def test_level_tree_of_the_sinusoid_and_first_sweep_against_the_oracle(harness, 
     o2 = O.OracleProblem(lb)
     o2.assign(np.arange(lb.nvars, dtype=np.int64), x)
     assert abs(o2.eval() - obj[-1]) <= 1e-9 * abs(obj[-1])
+
+
+@pytest.mark.gpu
+def test_plan_cache_is_bounded_and_never_changes_a_bit(harness, bal_path):
+    """The host-side cache of resident plans: bounded by entries AND by device bytes, least recently used
+    first; a call whose plan does not fit the budget at all is served by the transient path.  Whatever the bounds,
+    the 243 calls (30 shapes) give the bits of the uncached run.  And an optimizer may outlive its function: the
+    function takes the cached plans of its device problem with it."""
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(cache, nbytes):
+        out, x = np.zeros(9), np.zeros(135)
+        assert harness.harness_call_shapes_budget(bal_path, 27, 216, 10, cache, C.c_double(nbytes), v(out), v(x)) == 0
+        return out, x
+    base, xb = run(0, 0)                                   # no cache at all
+    assert base[4] == 0 and base[1] == 243
+    full, xf = run(256, 4 << 30)
+    assert full[4] == 243 - 30 and full[5] == 30 and full[6] == 0 and full[7] == 30 and full[8] > 0
+    small, xs = run(4, 4 << 30)                            # four entries for thirty shapes: constant eviction
+    assert small[7] == 4 and small[5] > 30 and small[6] == 0
+    per_plan = full[8] / 30
+    tight, xt = run(256, 3.5 * per_plan)                   # room for a few plans (the separator's is larger than a point's)
+    assert 1 <= tight[7] < 30 and 0 < tight[8] <= 3.5 * per_plan and tight[5] > 30
+    none, xn = run(256, 16)                                # nothing fits: every call goes the transient way
+    assert none[7] == 0 and none[8] == 0 and none[6] == none[5] == 243 and none[4] == 0
+    for o, x in ((full, xf), (small, xs), (tight, xt), (none, xn)):
+        assert o[2] == base[2] and o[3] == base[3] and np.array_equal(x, xb)
+    assert harness.harness_optimizer_outlives_function(bal_path) == 4
