@@ -11,7 +11,6 @@ if len(sys.argv) > 1: sizes = [tuple(int(v) for v in a.split("x")) for a in sys.
 for (ncam, npt, obs) in sizes:
     res = {}
     for ncomp in (125, 1000):
-        if ncam * npt * obs * ncomp > 4e7: ncomp_eff = ncomp  # (fits: 3.2e7 factors is the largest)
         t0 = time.time()
         pp = P.make_synthetic_ba(ncomp, ncam, npt, obs_per_pt=obs)
         csr = (pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id)
