@@ -81,15 +81,17 @@ struct PlanView {
     // and taken 64 at a time (a wave-chunk)
     const int* pm_pt0;    // [ncomp] a component's first point block in pm_rec
     const int* pm_ch0;    // [ncomp] its first entry in pm_cptr (which has one more entry than wave-chunks per component)
-    const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_pg, slot-major --
+    const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_cgp, slot-major --
                           // entry pm_cptr[c] + 64 t + lane is the t-th factor of the lane's point block
     double* pm_rec;       // [blocks][12] p, xi, lo, hi of a point block's three variables
     const int* pm_cam;    // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
-    double* pm_pg;        // [entries][3] the factor's three point partials, as the last gradient pass left them
+    double* pm_pg;        // [entries][3] the factor's three point partials (the one-pass gradient of workgroups that share a component; zeros where no factor)
+    const int* pm_gqpos;  // [entries] the factor's position in its component's camera-grouped order (ls_gperm)
+    double* pm_cgq;       // [positions of all components' orders][10] the factor's nine camera partials, as pass 1 of the last gradient left them (zeros where no factor)
     // ... and in the order of the gradient pass (position q = 64 * chunk + lane of ls_gperm):
     const unsigned* pm_gqw;   // the factor's slot word (camera block | point block << 12), 0xFFFFFFFF = no factor
-    const int* pm_gqe;        // its entry in pm_pg
+    const int* pm_gqe;        // its point-major entry (pm_cgp)
     const double2* pm_gqobs;  // its observation
     int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...
     double* st_val;       // ... and that value; null unless the plan's option emulate_stale_cache is set

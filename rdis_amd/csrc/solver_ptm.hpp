@@ -26,12 +26,10 @@
 // HBM bytes per value+slope trial: 32 per point variable + 20 per factor (SURVEY 8d counts 16 + 24:
 // x and g once per variable, observation + two indices per factor), no write traffic at all.
 //
-// The full gradient, once per CG iteration, runs camera by camera like solver_lds.hpp's: the factors
-// grouped by camera block, groups padded to whole waves (ls_gperm), so a wave's 64 factors share
-// their camera and its partials are summed across the wave.  What a factor needs there -- slot word,
-// observation, where its point partials go -- stands in that order too (pm_gq*: no indirection).
-// The point partials go to pm_pg at the factor's point-major entry; every point variable then adds up
-// its block's entries slot by slot, which is factor-list order (src/State.h:157-210).
+// The full gradient, once per CG iteration, is a point-major pass like a trial (forward + adjoint; a block's
+// point entries summed in registers in slot order = factor-list order, src/State.h:157-210; a factor's nine camera
+// partials written to pm_cgq at its position in that order) followed by a pass in camera order (ls_gperm: the factors grouped by
+// camera block, whole wave-chunks per camera) that only gathers those partials and adds: see gradient_to_xi.
 //
 // GROUP = true: K workgroups share a component (cgd_ptmg_kernel, a cooperative launch of several such
 // groups side by side).  A launch with fewer components than compute units -- one rank's share of a
@@ -56,6 +54,7 @@ constexpr int PT_REC = 12;   // doubles per point record: p, xi, lo, hi of the b
 constexpr int PTM_DOUBLES_PER_SLOT = LDS_DOUBLES_PER_SLOT + 2;   // Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
 constexpr int PTM_MAX_GROUP = 16;  // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
 constexpr unsigned PTM_NO_FACTOR = 0xFFFFFFFFu;
+constexpr int CGQ_REC = 10;  // doubles per camera-partials record (nine + one of padding: five 16-byte accesses)
 __host__ __device__ inline size_t ptm_bytes_for(int ncb, int nchunk) {
     return (size_t)ncb * 9 * (PTM_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * (7 * sizeof(double) + 2 * sizeof(int)) +
            (size_t)nchunk * (9 * sizeof(double) + sizeof(int)) + 64;
@@ -86,7 +85,9 @@ struct PtmEnv {
     const int* cptr;          // [npc + 1] a point chunk's entries ...
     const int* pcam;          // ... their camera block (-1: none)
     const double2* pobs;      // ... their observation
-    double* pg;               // ... the three point partials of the last gradient pass
+    double* pg;               // ... the three point partials of the last gradient pass (gradient_camera_order)
+    const int* gqpos;         // ... the factor's position in the camera-grouped order
+    double* cgq;              // [positions of that order][CGQ_REC] a factor's nine camera partials, handed from pass 1 to pass 2
     double *g, *h;            // plan workspace, by free index (point variables)
     double (*red)[3][MAX_WAVES];
     int parity;
@@ -331,48 +332,168 @@ struct PtmEnv {
         __syncthreads();
     }
 
-    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p); see the header.
-    // GROUP: the factor chunks are dealt out over the group's waves like the point chunks; a factor's point may
-    // belong to another workgroup (its record is read after an ordered barrier), its point partials go to pm_pg
-    // for the owner, a chunk's camera sums to cgg[] -- after a second ordered barrier every workgroup adds up ALL
-    // chunks of a camera in chunk order, so the cameras' gradient entries have the same bits in every workgroup.
+    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p), in two passes.
+    //   1. point-major, like a trial: every lane evaluates its block's factors (forward + adjoint) against the cameras in
+    //      LDS -- coalesced, no indirection.  The block's three point entries are the sums of its factors' point partials
+    //      in slot order, which is factor-list order (src/State.h:157-210): formed in registers, written to the record.
+    //      A factor's nine CAMERA partials go to pm_cgq at the factor's position in the camera-grouped order (an 80-byte
+    //      record; the position comes with the factor's camera and observation: a scattered store nobody waits for).
+    //   2. camera by camera: the gradient pass's order (ls_gperm: factors grouped by camera block, whole wave-chunks per
+    //      camera) with every wave taking a contiguous run of chunks; a lane reads the record at its position -- 64
+    //      neighbours per load, no index: positions that are no factor hold zeros --, keeps adding over the chunks of one
+    //      camera, and the wave reduces once per camera and run.  The run's sums stand at its last chunk of the camera, zeros at the others, so "a camera's
+    //      chunks in order" is the whole sum.
+    // (One workgroup per component; workgroups that share a component use gradient_camera_order below.  1000 components of
+    // ladybug's size: 175.5 ms a launch with this form, 183.6 with the other.)
     __device__ void gradient_to_xi() {
+        if constexpr (GROUP) gradient_camera_order(); else gradient_two_pass();
+    }
+    __device__ void gradient_two_pass() {
+        const long long tg0 = clock();
+        assign_cameras<AT_LINE>(0.0);
+        const int lane = tid & 63;
+        for (int c = first_chunk(); c < npc; c += chunk_step()) {
+            const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
+            int cn = -1, qn = 0;
+            double2 on = make_double2(0.0, 0.0);
+            if (e0 < e1) { cn = pcam[e0 + lane]; on = pobs[e0 + lane]; qn = gqpos[e0 + lane]; }
+            const int ps = 64 * c + lane;
+            double x[3] = {0.0, 0.0, 0.0};
+            if (ps < npb) point_position(ps, x);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int e = e0; e < e1; e += 64) {
+                const int cc = cn, q = qn;
+                const double2 o = on;
+                if (e + 64 < e1) { cn = pcam[e + 64 + lane]; on = pobs[e + 64 + lane]; qn = gqpos[e + 64 + lane]; }
+                if (cc >= 0) {
+                    double v[12], gq[12];
+                    BaFwd t;
+                    forward(cc, o, x, v, t);
+                    ba_adjoint(t, v, t.res0, t.res1, gq);
+                    s0 = (e == e0) ? gq[9] : s0 + gq[9]; s1 = (e == e0) ? gq[10] : s1 + gq[10]; s2 = (e == e0) ? gq[11] : s2 + gq[11];
+                    if constexpr (ROT != ROT_CAMFIX) {
+                        double2* dst = reinterpret_cast<double2*>(cgq + (long long)CGQ_REC * q);
+                        dst[0] = make_double2(gq[0], gq[1]); dst[1] = make_double2(gq[2], gq[3]);
+                        dst[2] = make_double2(gq[4], gq[5]); dst[3] = make_double2(gq[6], gq[7]);
+                        dst[4] = make_double2(gq[8], 0.0);
+                    }
+                }
+            }
+            if (ps < npb) {
+                const int* sf = sfree + 9 * ncb + 3 * ps;
+                double* rec = PT + (long long)PT_REC * ps + 3;
+                if (sf[0] >= 0) rec[0] = s0;
+                if (sf[1] >= 0) rec[1] = s1;
+                if (sf[2] >= 0) rec[2] = s2;
+            }
+        }
+        const long long tg1 = clock();
+        if constexpr (ROT != ROT_CAMFIX) {
+            if constexpr (GROUP) GX.barrier_ordered(); else __syncthreads();   // pm_cgq
+            const int gw = (GROUP ? r * nwaves : 0) + (tid >> 6), gwn = (GROUP ? K : 1) * nwaves;
+            const int ch0 = (int)((long long)gw * nchunk / gwn), ch1 = (int)((long long)(gw + 1) * nchunk / gwn);
+            // (positions that are no factor hold zeros: nothing but the chunk number decides an address; the next chunk's
+            // records are in flight while a chunk is added)
+            double2 nx[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) nx[i] = make_double2(0.0, 0.0);
+            if (ch0 < ch1) {
+                const double2* src = reinterpret_cast<const double2*>(cgq + (long long)CGQ_REC * (64 * ch0 + lane));
+#pragma unroll
+                for (int i = 0; i < 5; ++i) nx[i] = src[i];
+            }
+            double acc[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+            for (int ch = ch0; ch < ch1; ++ch) {
+                double2 cur[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) cur[i] = nx[i];
+                if (ch + 1 < ch1) {
+                    const double2* src = reinterpret_cast<const double2*>(cgq + (long long)CGQ_REC * (64 * (ch + 1) + lane));
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) nx[i] = src[i];
+                }
+                acc[0] += cur[0].x; acc[1] += cur[0].y; acc[2] += cur[1].x; acc[3] += cur[1].y; acc[4] += cur[2].x;
+                acc[5] += cur[2].y; acc[6] += cur[3].x; acc[7] += cur[3].y; acc[8] += cur[4].x;
+                double* dstc = GROUP ? cgg + 9 * ch : CG + 9 * ch;
+                if (ch + 1 == ch1 || CGC[ch + 1] != CGC[ch]) {   // the run's last chunk of this camera (wave-uniform)
+                    double cs[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { cs[k] = wave_sum(acc[k]); acc[k] = 0.0; }
+                    if (lane < 9) dstc[lane] = pick(cs, lane);
+                } else {
+                    if (lane < 9) dstc[lane] = 0.0;
+                }
+            }
+            if constexpr (GROUP) {
+                GX.barrier_ordered();   // cgg[] of every workgroup
+                for (int q = tid; q < 9 * nchunk; q += nt) CG[q] = cgg[q];
+            }
+            __syncthreads();
+            for (int s = tid; s < 9 * ncb; s += nt) {
+                if (SF[s] < 0) continue;
+                const int c = s / 9, k = s - 9 * c;
+                const int b = CST[c], e = CEN[c];
+                double sm = 0.0;
+                for (int q = b; q < e; ++q) sm = (q == b) ? CG[9 * q + k] : sm + CG[9 * q + k];
+                XI[s] = sm;
+            }
+        }
+        __syncthreads();
+        tick(4, tg1 - tg0); tick(5, clock() - tg1); tick(10, 1);
+    }
+
+    // The same gradient in ONE pass in camera order, for workgroups that share a component: there the two-pass form's
+    // hand-over of 80 bytes per factor through an ordered grid barrier (a write-back of megabytes of freshly dirtied L2
+    // lines) costs more than it saves -- 125 components of ladybug's size as groups of four: 27.5 ms against 25.7.  Every
+    // wave takes a contiguous run of the camera-grouped chunks; a factor gathers its point's position from the block's
+    // record (read after an ordered barrier: it may belong to another workgroup), its three point partials go to pm_pg at
+    // its point-major entry for the owner, its nine camera partials are added lane-wise over the chunks of one camera and
+    // reduced once per camera and run (sums at the run's last chunk of the camera, zeros at the others); after a second
+    // barrier every workgroup adds up ALL chunks of a camera in chunk order, and every point variable its block's
+    // entries slot by slot (entries that are no factor hold zeros, set once at plan creation).
+    __device__ void gradient_camera_order() {
         const long long tg0 = clock();
         assign_cameras<AT_LINE>(0.0);
         if constexpr (GROUP) GX.barrier_ordered();   // the point records as line_end / init_vectors left them
         const int lane = tid & 63;
-        // (the next chunk's slot word, entry and observation are in flight while a chunk is worked on)
-        int ch = first_chunk();
+        const int gw = (GROUP ? r * nwaves : 0) + (tid >> 6), gwn = (GROUP ? K : 1) * nwaves;
+        const int ch0 = (int)((long long)gw * nchunk / gwn), ch1 = (int)((long long)(gw + 1) * nchunk / gwn);
         unsigned wn = PTM_NO_FACTOR;
         int en = 0;
         double2 on = make_double2(0.0, 0.0);
-        if (ch < nchunk) { wn = gqw[64 * ch + lane]; en = gqe[64 * ch + lane]; on = gqobs[64 * ch + lane]; }
-        for (; ch < nchunk; ch += chunk_step()) {
+        if (ch0 < ch1) { wn = gqw[64 * ch0 + lane]; en = gqe[64 * ch0 + lane]; on = gqobs[64 * ch0 + lane]; }
+        double acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+        for (int ch = ch0; ch < ch1; ++ch) {
             const unsigned w = wn;
             const int e = en;
             const double2 o = on;
-            const int chn = ch + chunk_step();
-            if (chn < nchunk) { wn = gqw[64 * chn + lane]; en = gqe[64 * chn + lane]; on = gqobs[64 * chn + lane]; }
-            double gq[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) gq[k] = 0.0;
+            if (ch + 1 < ch1) { wn = gqw[64 * (ch + 1) + lane]; en = gqe[64 * (ch + 1) + lane]; on = gqobs[64 * (ch + 1) + lane]; }
             if (w != PTM_NO_FACTOR) {
-                double x[3], v[12];
+                double x[3], v[12], gq[12];
                 BaFwd t;
                 point_position((int)(w >> 12), x);
                 forward((int)(w & 0xFFFu), o, x, v, t);
                 ba_adjoint(t, v, t.res0, t.res1, gq);
                 double* dst = pg + 3ll * e;
                 dst[0] = gq[9]; dst[1] = gq[10]; dst[2] = gq[11];
+                if constexpr (ROT != ROT_CAMFIX) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc[k] += gq[k];
+                }
             }
             if constexpr (ROT != ROT_CAMFIX) {
-                double cs[9];
+                double* dstc = GROUP ? cgg + 9 * ch : CG + 9 * ch;
+                if (ch + 1 == ch1 || CGC[ch + 1] != CGC[ch]) {   // the run's last chunk of this camera (wave-uniform)
+                    double cs[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) cs[k] = wave_sum(gq[k]);
-                if constexpr (GROUP) {
-                    if (lane < 9) cgg[9 * ch + lane] = pick(cs, lane);
+                    for (int k = 0; k < 9; ++k) { cs[k] = wave_sum(acc[k]); acc[k] = 0.0; }
+                    if (lane < 9) dstc[lane] = pick(cs, lane);
                 } else {
-                    if (lane < 9) CG[9 * ch + lane] = pick(cs, lane);
+                    if (lane < 9) dstc[lane] = 0.0;
                 }
             }
         }
@@ -393,18 +514,14 @@ struct PtmEnv {
                 XI[s] = sm;
             }
         }
-        // the point variables: a block's entries slot by slot (factor-list order), three sums per lane
         for (int c = first_chunk(); c < npc; c += chunk_step()) {
             const int ps = 64 * c + lane;
             const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            bool first = true;
             for (int e = e0; e < e1; e += 64) {
-                if (pcam[e + lane] < 0) continue;
                 const double* src = pg + 3ll * (e + lane);
                 const double a0 = src[0], a1 = src[1], a2 = src[2];
-                s0 = first ? a0 : s0 + a0; s1 = first ? a1 : s1 + a1; s2 = first ? a2 : s2 + a2;
-                first = false;
+                s0 = (e == e0) ? a0 : s0 + a0; s1 = (e == e0) ? a1 : s1 + a1; s2 = (e == e0) ? a2 : s2 + a2;
             }
             if (ps < npb) {
                 const int* sf = sfree + 9 * ncb + 3 * ps;
@@ -514,7 +631,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc,
                               lds + PTM_DOUBLES_PER_SLOT * sc, CG, CGC, CST, CEN, SF,
-                              L.pm_rec + (long long)PT_REC * pb0, L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_pg,
+                              L.pm_rec + (long long)PT_REC * pb0, L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_pg, L.pm_gqpos, L.pm_cgq + (long long)CGQ_REC * q0,
                               ws + 2ll * n, ws + 3ll * n, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
@@ -599,7 +716,8 @@ ptm_gather_kernel(int n, const int* __restrict__ jg, const unsigned* __restrict_
 }
 // ... and the gradient pass's arrays: position q of a component's ls_gperm -> slot word, point-major entry, observation
 __global__ void __launch_bounds__(256)
-ptm_gather_gradient_kernel(PlanView L, const int* __restrict__ eof, unsigned* __restrict__ gqw, int* __restrict__ gqe, double2* __restrict__ gqobs) {
+ptm_gather_gradient_kernel(PlanView L, const int* __restrict__ eof, unsigned* __restrict__ gqw, int* __restrict__ gqe, double2* __restrict__ gqobs,
+                           int* __restrict__ gqpos) {
     for (int comp = blockIdx.x; comp < L.ncomp; comp += gridDim.x) {
         const int c0 = L.fac_ptr[comp];
         const long long q0 = 64ll * L.ls_gptr[comp], q1 = 64ll * L.ls_gptr[comp + 1];
@@ -609,6 +727,7 @@ ptm_gather_gradient_kernel(PlanView L, const int* __restrict__ eof, unsigned* __
             gqw[q] = j >= 0 ? L.ls_fidx[j] : PTM_NO_FACTOR;
             gqe[q] = j >= 0 ? eof[j] : 0;
             gqobs[q] = j >= 0 ? L.ls_obs[j] : make_double2(0.0, 0.0);
+            if (j >= 0 && eof[j] >= 0) gqpos[eof[j]] = (int)(q - q0);   // (position within the component's order)
         }
     }
 }
