@@ -128,6 +128,9 @@ int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, d
  * residual_model 1 is that formulation; 2 replaces it by the two pixel residuals of every
  * observation (the usual bundle-adjustment Gauss-Newton model: J^T J of rank 2 per factor instead
  * of 1, same machinery) -- not something the reference offers, far faster convergence.
+ * Bits 4-5 of residual_model choose how the Schur product Z Z^T is formed: 0 = by fill (block-sparse over the
+ * camera pairs that share a point where cameras see few of the points -- every BAL problem --, dense on the
+ * matrix cores otherwise), 1 = dense, 2 = block-sparse.
  * Same calling convention as one component of rdis_hip_cgd_batch; x_inout may be NULL (start at
  * the currently assigned x; the result is left assigned either way).
  * info[8] = {iterations, stop code (levmar's: 1 small gradient, 2 small step, 3 itmax,

@@ -275,10 +275,10 @@ class Problem:
         val, vid = _f(val), _i(vid)
         self.ctx.check(self.ctx.lib.rdis_hip_set_x(self.h, val.shape[0], _ptr(vid), _ptr(val)))
 
-    def lm_optimize(self, free_vid=None, fac_id=None, x=None, maxiters=25, ftol=3e-8, history=256, model=1):
+    def lm_optimize(self, free_vid=None, fac_id=None, x=None, maxiters=25, ftol=3e-8, history=256, model=1, schur=0):
         """Levenberg-Marquardt over the listed free variables / factors (bundle adjustment; the
         least-squares problem of LMSubspaceOptimizer).  Returns an LmResult; the variables are left
-        assigned to the result."""
+        assigned to the result.  schur: 0 = Schur product by fill, 1 = dense on the matrix cores, 2 = block-sparse."""
         fv = np.arange(self.nvars, dtype=np.int64) if free_vid is None else _i(free_vid)
         fc = np.arange(self.nfac, dtype=np.int64) if fac_id is None else _i(fac_id)
         xin = None if x is None else _f(x).copy()
@@ -286,7 +286,7 @@ class Problem:
         info = np.zeros(8)
         hist = np.zeros((max(history, 1), 4))
         nh = np.zeros(1, dtype=np.int64)
-        self.ctx.check(self.ctx.lib.rdis_hip_lm_optimize(self.h, fv.shape[0], _ptr(fv), fc.shape[0], _ptr(fc), _ptr(xin), maxiters, ftol, model,
+        self.ctx.check(self.ctx.lib.rdis_hip_lm_optimize(self.h, fv.shape[0], _ptr(fv), fc.shape[0], _ptr(fc), _ptr(xin), maxiters, ftol, model | (schur << 4),
                                                          C.c_void_p(out.ctypes.data), C.c_void_p(out.ctypes.data + 8), _ptr(info),
                                                          _ptr(hist), hist.shape[0], _ptr(nh)))
         return LmResult(x=self.get_x(fv), fret=float(out[0]), delta=float(out[1]), iters=int(info[0]), stop=int(info[1]),

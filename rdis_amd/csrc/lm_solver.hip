@@ -42,10 +42,14 @@ struct Dev {            // everything the kernels need, by value
     const unsigned char* freem;              // [N]
     const int *cam_ptr, *cam_list, *pt_ptr, *pt_list;
     const int *cam_id, *pt_id;               // first variable id of each active block
+    // sparse Schur product: the camera pairs (a >= b) that share a point, and per pair its (factor of a, factor of b) entries
+    const int *pair_ab, *pair_ptr, *pair_ja, *pair_jb;
+    int npair, sparse;
     double *Jc, *Jp, *e;                     // [nf*R*9], [nf*R*3], [nf*R]  (row jr = j*R + r)
     double *U, *bc;                          // [nca*81], [Mp]
     double *V, *bp, *Lp, *yp, *T;            // [npa*6], [npa*3], [npa*6], [npa*3], [nf*R*3]
-    double *Zt;                              // [Kp][Mp]   k-major
+    double *Zt;                              // [Kp][Mp]   k-major (dense Schur product)
+    double *Zc;                              // [nf][3][9] a factor's Z block, column by column (block-sparse Schur product)
     double *Spart, *S, *rhs, *dc, *dp;       // [SK][Mp*Mp], [Mp*Mp], [Mp], [Mp], [npa*3]
     double *psave;                           // accepted point: [9*nca + 3*npa] by block slot
     double *part, *sc;                       // block partials [4096*4], scalars [16]
@@ -278,6 +282,15 @@ __global__ void __launch_bounds__(256) k_z(Dev D) {
         D.T[3 * jr] = t0[r]; D.T[3 * jr + 1] = t1[r]; D.T[3 * jr + 2] = t2[r];
     }
     if (ci < 0) return;
+    if (D.sparse) {   // the block itself, 27 numbers: what k_schur's operands are
+        double* z = D.Zc + 27ll * j;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            const double jc0 = D.Jc[9ll * j * D.R + a], jc1 = D.R == 2 ? D.Jc[9ll * (2 * j + 1) + a] : 0.0;
+            z[a] = jc0 * t0[0] + jc1 * t0[1]; z[9 + a] = jc0 * t1[0] + jc1 * t1[1]; z[18 + a] = jc0 * t2[0] + jc1 * t2[1];
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
         const double jc0 = D.Jc[9ll * j * D.R + a], jc1 = D.R == 2 ? D.Jc[9ll * (2 * j + 1) + a] : 0.0;
@@ -341,6 +354,81 @@ __global__ void __launch_bounds__(256) k_sfinish(Dev D) {
     }
     D.S[t] = v;
 }
+// ---- 6b. the same product where Z is what it is: block-sparse ------------------------------------------------------
+// Z's block (c, p) is non-zero only where camera c sees point p, so block (a, b) of Z Z^T is a sum over the points
+// both cameras see: sum_p Z_(a,p) Z_(b,p)^T with Z_(c,p) = Jc_j^T T_j (9 x R times R x 3) for the factor j that joins c
+// and p.  On a BAL problem a point is seen by a handful of the cameras (ladybug: 4.1 of 49): the dense rank-3P update
+// above multiplies zeros 98 % of the time (4.5 GFLOP against 0.06), and writing, zeroing and re-reading the dense Z (82 MB)
+// is most of what a damped solve costs besides the Cholesky chain.  Here: the host lists, once per call, the camera pairs
+// (a >= b) that share a point with their (factor of a, factor of b) entries in point order; one workgroup per pair owns the
+// 9 x 9 block and subtracts the sum from S, which k_sinit has set to U + damping (block diagonal) and zero elsewhere.
+// No atomics, a fixed order of summation.  (First form: a wave per pair, a lane per entry of the block, looping over the
+// pair's factors -- a chain of dependent gathers, 906 links long for a camera with itself: slower than the dense product.)  The dense path stays for
+// problems where most cameras see most points (chosen by fill; `model` bits 4-5 of rdis_hip_lm_optimize force one).
+__global__ void __launch_bounds__(256) k_sinit(Dev D) {
+    const double mu = D.sc[SC_MU], floor_ = D.sc[SC_FLOOR];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)D.Mp * D.Mp) return;
+    const int row = (int)(t / D.Mp), col = (int)(t % D.Mp);
+    if (col > row) return;
+    double v = 0.0;
+    if (row < D.M) {
+        if (row / 9 == col / 9) v = D.U[81ll * (row / 9) + 9 * (row % 9) + (col % 9)];
+        if (row == col) v += damp(D, mu, floor_, D.U[81ll * (row / 9) + 10 * (row % 9)]);
+    } else {
+        v = row == col ? 1.0 : 0.0;
+    }
+    D.S[t] = v;
+}
+// One workgroup of sixteen waves per camera pair; the block is a small product on the matrix cores (v_mfma_f64_16x16x4_f64
+// as in k_cam, with two different operands): D[row][col] = sum_k A[row][k] B[k][col], k running over (entry, t) -- the three
+// columns of every shared point's Z blocks --, lane l supplying A[i = l & 15][k = l >> 4] = Z_(a,p)[i][t] and
+// B[k][n = l & 15] = Z_(b,p)[n][t], read from the factors' 27-number Z blocks (k_z; 7 MB for ladybug where the dense Z is 82).
+// Wave w takes the steps w, w + 16, ... (four k each), four at a time so that their gathers are in flight together;
+// the sixteen partial blocks are added in wave order.
+constexpr int SCH_WAVES = 16;
+__global__ void __launch_bounds__(64 * SCH_WAVES) k_schur(Dev D) {
+    __shared__ double part[SCH_WAVES][4][64];
+    const int q = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int a = D.pair_ab[2 * q], b = D.pair_ab[2 * q + 1];
+    const int e0 = D.pair_ptr[q], nk = 3 * (D.pair_ptr[q + 1] - e0);
+    const int i = l & 15, kk = l >> 4;
+    auto operands = [&](int step, double& av, double& bv) {
+        av = 0.0; bv = 0.0;
+        const int k = 4 * step + kk;
+        if (k < nk && i < 9) {
+            const int e = e0 + k / 3, t = k % 3;
+            av = D.Zc[27ll * D.pair_ja[e] + 9 * t + i];
+            bv = D.Zc[27ll * D.pair_jb[e] + 9 * t + i];
+        }
+    };
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int nsteps = (nk + 3) / 4;
+    for (int s = w; s < nsteps; s += 4 * SCH_WAVES) {   // four steps' loads in flight (beyond the end: zeros)
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) operands(s + u * SCH_WAVES, av[u], bv[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w][r][l] = acc[r];
+    __syncthreads();
+    if (w != 0) return;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int v = 0; v < SCH_WAVES; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += part[v][r][l];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r, col = i;
+        if (row < 9 && col < 9) {
+            const int gr = 9 * a + row, gc = 9 * b + col;
+            if (gc <= gr) D.S[(long long)gr * D.Mp + gc] -= t[r];   // lower triangle (a >= b; within a diagonal block col <= row)
+        }
+    }
+}
+
 // rhs = bc - Z y, one wave per active camera over its factor list: Z's block of factor j times y_p
 // is Jc_j (T_j . y_p)
 constexpr int RHS_WAVES = 8;   // (a camera of ladybug has 361-906 factors: eight waves share them)
@@ -688,6 +776,47 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                 seen[(size_t)ci] = p;
             }
     }
+    // the camera pairs (a >= b) that share a point, with their (factor of a, factor of b) entries in point order
+    std::vector<int> pair_ab, pair_ptr(1, 0), pair_ja, pair_jb;
+    int64_t pair_entries = 0;
+    {
+        std::vector<int64_t> cnt((size_t)nca * (size_t)(nca + 1) / 2, 0);
+        auto key = [&](int a, int b) { return (size_t)a * (size_t)(a + 1) / 2 + (size_t)b; };   // a >= b
+        std::vector<int> cams_of_p;
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int64_t> fill;
+            if (pass == 1) {
+                // pairs that occur, in (a, b) order; their ranges
+                std::vector<int64_t> start(cnt.size(), -1);
+                int64_t at = 0;
+                for (int a = 0; a < nca; ++a)
+                    for (int b = 0; b <= a; ++b)
+                        if (cnt[key(a, b)] > 0) {
+                            start[key(a, b)] = at;
+                            pair_ab.push_back(a); pair_ab.push_back(b);
+                            at += cnt[key(a, b)];
+                            pair_ptr.push_back((int)at);
+                        }
+                pair_ja.assign((size_t)at, 0); pair_jb.assign((size_t)at, 0);
+                pair_entries = at;
+                fill.swap(start);
+                cnt.swap(fill);   // cnt now holds the next free entry of every pair
+            }
+            for (int p = 0; p < npa; ++p) {
+                const int t0 = pt_ptr[(size_t)p], t1 = pt_ptr[(size_t)p + 1];
+                for (int t = t0; t < t1; ++t) {
+                    const int ja = pt_list[(size_t)t], a = fci[(size_t)ja];
+                    if (a < 0) continue;
+                    for (int u = t0; u < t1; ++u) {
+                        const int jb = pt_list[(size_t)u], b = fci[(size_t)jb];
+                        if (b < 0 || b > a) continue;
+                        if (pass == 0) ++cnt[key(a, b)];
+                        else { const int64_t e = cnt[key(a, b)]++; pair_ja[(size_t)e] = ja; pair_jb[(size_t)e] = jb; }
+                    }
+                }
+            }
+        }
+    }
     Dev D{};
     if (opt.model != 1 && opt.model != 2) return fail("lm: residual model must be 1 or 2");
     D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa; D.R = opt.model;
@@ -695,12 +824,21 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     const int ntile = D.Mp / 64;
     D.SK = std::max(1, std::min(64, 2048 / std::max(1, ntile * (ntile + 1) / 2)));
     D.SK = std::min(D.SK, std::max(1, D.Kp / 64));
-    if ((double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
+    // sparse or dense Schur product: the flops of the pairs' 9 x 9 blocks against the dense rank-3P update on the matrix
+    // cores (which runs some three times faster per flop than the vector units and streams instead of gathering)
+    D.npair = (int)(pair_ptr.size() - 1);
+    {
+        const double sparse_flops = (double)pair_entries * 81.0 * (2.0 * opt.model * opt.model + 1.0) * 2.0;
+        const double dense_flops = (double)D.Mp * D.Mp * D.Kp;   // lower triangle, 2 flops per multiply-add
+        D.sparse = opt.schur == 2 || (opt.schur == 0 && sparse_flops * 8.0 < dense_flops) ? 1 : 0;
+    }
+    if (!D.sparse && (double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
+    if ((double)D.Mp * D.Mp * 8.0 > 16e9) return fail("lm: reduced system too large");
 
     // Every device buffer of the solve is a slice of one workspace the caller keeps between solves
     // (some thirty allocations and releases per call otherwise: 2 ms on ladybug).
-    Buf b_lf, b_fci, b_fpi, b_free, b_cptr, b_clist, b_pptr, b_plist, b_cid, b_pid;
-    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Spart, S, rhs, dc, dp, psave, part, sc;
+    Buf b_lf, b_fci, b_fpi, b_free, b_cptr, b_clist, b_pptr, b_plist, b_cid, b_pid, b_pab, b_pptr2, b_pja, b_pjb;
+    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Zc, Spart, S, rhs, dc, dp, psave, part, sc;
     const size_t MM = (size_t)D.Mp * D.Mp;
     {
         const size_t n1c = (size_t)std::max(nca, 1), n1p = (size_t)std::max(npa, 1);
@@ -708,9 +846,10 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             {&b_lf, lf.size() * 4}, {&b_fci, fci.size() * 4}, {&b_fpi, fpi.size() * 4}, {&b_free, freem.size()},
             {&b_cptr, cam_ptr.size() * 4}, {&b_clist, cam_list.size() * 4}, {&b_pptr, pt_ptr.size() * 4},
             {&b_plist, pt_list.size() * 4}, {&b_cid, cam_id.size() * 4}, {&b_pid, pt_id.size() * 4},
+            {&b_pab, pair_ab.size() * 4}, {&b_pptr2, pair_ptr.size() * 4}, {&b_pja, pair_ja.size() * 4}, {&b_pjb, pair_jb.size() * 4},
             {&Jc, (size_t)nf * 72 * D.R}, {&Jp, (size_t)nf * 24 * D.R}, {&e, (size_t)nf * 8 * D.R}, {&U, n1c * 81 * 8},
             {&bc, (size_t)D.Mp * 8}, {&V, n1p * 48}, {&bp, n1p * 24}, {&Lp, n1p * 48}, {&yp, (size_t)D.Kp * 8},
-            {&T, (size_t)nf * 24 * D.R}, {&Zt, (size_t)D.Kp * D.Mp * 8}, {&Spart, MM * 8 * (size_t)D.SK}, {&S, MM * 8},
+            {&T, (size_t)nf * 24 * D.R}, {&Zt, D.sparse ? 8 : (size_t)D.Kp * D.Mp * 8}, {&Zc, D.sparse ? (size_t)nf * 27 * 8 : 8}, {&Spart, D.sparse ? 8 : MM * 8 * (size_t)D.SK}, {&S, MM * 8},
             {&rhs, (size_t)D.Mp * 8}, {&dc, (size_t)D.Mp * 8}, {&dp, (size_t)D.Kp * 8},
             {&psave, (size_t)(9 * nca + 3 * npa + 1) * 8}, {&part, 4096 * 8}, {&sc, 16 * 8}};
         size_t total = 0;
@@ -728,16 +867,18 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     int rc;
     if ((rc = up(b_lf, lf, stream)) || (rc = up(b_fci, fci, stream)) || (rc = up(b_fpi, fpi, stream)) || (rc = up(b_free, freem, stream)) ||
         (rc = up(b_cptr, cam_ptr, stream)) || (rc = up(b_clist, cam_list, stream)) || (rc = up(b_pptr, pt_ptr, stream)) ||
-        (rc = up(b_plist, pt_list, stream)) || (rc = up(b_cid, cam_id, stream)) || (rc = up(b_pid, pt_id, stream))) return rc;
+        (rc = up(b_plist, pt_list, stream)) || (rc = up(b_cid, cam_id, stream)) || (rc = up(b_pid, pt_id, stream)) ||
+        (rc = up(b_pab, pair_ab, stream)) || (rc = up(b_pptr2, pair_ptr, stream)) || (rc = up(b_pja, pair_ja, stream)) || (rc = up(b_pjb, pair_jb, stream))) return rc;
     D.lf = b_lf.as<int>(); D.fci = b_fci.as<int>(); D.fpi = b_fpi.as<int>(); D.freem = b_free.as<unsigned char>();
     D.cam_ptr = b_cptr.as<int>(); D.cam_list = b_clist.as<int>(); D.pt_ptr = b_pptr.as<int>(); D.pt_list = b_plist.as<int>();
     D.cam_id = b_cid.as<int>(); D.pt_id = b_pid.as<int>();
+    D.pair_ab = b_pab.as<int>(); D.pair_ptr = b_pptr2.as<int>(); D.pair_ja = b_pja.as<int>(); D.pair_jb = b_pjb.as<int>();
     D.Jc = Jc.as<double>(); D.Jp = Jp.as<double>(); D.e = e.as<double>(); D.U = U.as<double>(); D.bc = bc.as<double>();
     D.V = V.as<double>(); D.bp = bp.as<double>(); D.Lp = Lp.as<double>(); D.yp = yp.as<double>(); D.T = T.as<double>();
-    D.Zt = Zt.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
+    D.Zt = Zt.as<double>(); D.Zc = Zc.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
     D.dc = dc.as<double>(); D.dp = dp.as<double>(); D.psave = psave.as<double>(); D.part = part.as<double>(); D.sc = sc.as<double>();
     LM_CHK(hipMemsetAsync(D.sc, 0, 16 * 8, stream));                      // (the workspace is reused: k_apply's ticket starts at zero)
-    LM_CHK(hipMemsetAsync(D.Zt, 0, (size_t)D.Kp * D.Mp * 8, stream));   // the block pattern of Z is fixed: zero once
+    if (!D.sparse) LM_CHK(hipMemsetAsync(D.Zt, 0, (size_t)D.Kp * D.Mp * 8, stream));   // the block pattern of Z is fixed: zero once
     LM_CHK(hipMemsetAsync(D.bc, 0, (size_t)D.Mp * 8, stream));
     LM_CHK(hipMemsetAsync(D.yp, 0, (size_t)D.Kp * 8, stream));
     LM_CHK(hipMemsetAsync(D.dc, 0, (size_t)D.Mp * 8, stream));
@@ -774,9 +915,14 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             k_z<<<gf, 256, 0, stream>>>(D);
         }
         if (nca) {
-            const int nt = D.Mp / 64;
-            k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
-            k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D);
+            if (D.sparse) {
+                k_sinit<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D);
+                if (D.npair) k_schur<<<D.npair, 64 * SCH_WAVES, 0, stream>>>(D);
+            } else {
+                const int nt = D.Mp / 64;
+                k_syrk<<<dim3(nt * nt, D.SK), 64, 0, stream>>>(D);
+                k_sfinish<<<(unsigned)((MM + 255) / 256), 256, 0, stream>>>(D);
+            }
             k_rhs<<<nca, 64 * RHS_WAVES, 0, stream>>>(D);
             LM_CHK(hipMemsetAsync(D.sc + 8, 0, 8, stream));
             for (int kb = 0; kb < D.Mp; kb += 32) {
@@ -808,7 +954,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     LM_CHK(hipStreamSynchronize(stream));
     double p_eL2 = 2.0 * h[5];
     out->finit = h[5];
-    out->ncam_blocks = nca; out->npt_blocks = npa;
+    out->ncam_blocks = nca; out->npt_blocks = npa; out->sparse_schur = D.sparse;
     out->nfev = 1;
     double mu = 0.0;
     long long nu = 2;

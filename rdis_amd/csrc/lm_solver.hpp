@@ -21,6 +21,7 @@ struct LmOptions {
     int maxiters;           // SSmaxit
     double tau, eps1, eps2, eps3;   // levmar opts[0..3] (reference: 1e-3, 1e-15, 1e-15, SSftol)
     int model;              // residual rows per factor: 1 = sqrt(2 E_j) (the reference's), 2 = the two pixel residuals
+    int schur;              // the Schur product Z Z^T: 0 = by fill, 1 = dense on the matrix cores, 2 = block-sparse (camera pairs that share a point)
 };
 
 struct LmStep { double mu, dp_l2, f_trial; int accepted; };
@@ -29,6 +30,7 @@ struct LmResult {
     double fret = 0, finit = 0, mu = 0;
     int iters = 0, stop = 0, nfev = 0, njev = 0, nsolve = 0;
     int ncam_blocks = 0, npt_blocks = 0;
+    int sparse_schur = 0;           // which Schur product ran
     std::vector<LmStep> history;    // one entry per linear solve
 };
 

@@ -1915,7 +1915,7 @@ extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const in
     }
     LmProblem P{(int)p->N, (int)p->F, ncams, p->x.as<double>(), p->lo.as<double>(), p->hi.as<double>(),
                 p->cam.as<int>(), p->pt.as<int>(), p->h_cam.data(), p->h_pt.data(), p->obs.as<double2>()};
-    LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol, model};
+    LmOptions o{maxiters, 1e-3, 1e-15, 1e-15, ftol, model & 15, (model >> 4) & 3};
     LmResult r;
     std::string err;
     const int e = device_lm_ba(c->stream, P, nfree, free_vid, nf, fac_id, o, &p->lm_ws, &r, &err);

@@ -127,3 +127,43 @@ def test_lm_argument_errors(gctx):
     pp = P.load_bal(ncams=5, npts=30)
     with pytest.raises(capi.RdisHipError):
         capi.Problem(gctx, pp).lm_optimize(np.array([0, 99999]), None)
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_sparse_and_dense_schur_products_agree(model, gctx):
+    """The Schur product Z Z^T formed two ways -- dense on the matrix cores (a rank-3P update that multiplies mostly
+    zeros on a BAL problem) and block-sparse over the camera pairs that share a point -- against the dense oracle step
+    by step, and against each other: same decisions, values to rounding.  On full ladybug the default (by fill) is
+    the sparse one, and a damped solve is cheaper for it."""
+    import time
+    pp = P.load_bal(ncams=49, npts=300)
+    ro = LM.lm_optimize(O.OracleProblem(pp, emulate_stale_cache=False), maxiters=10, model=model)
+    res = {}
+    for schur in (1, 2):
+        res[schur] = capi.Problem(gctx, pp).lm_optimize(maxiters=10, model=model, schur=schur)
+        _compare(res[schur], ro)
+    a, b = res[1], res[2]
+    assert len(a.history) == len(b.history) and np.array_equal(a.history[:, 3], b.history[:, 3])
+    assert np.max(np.abs(a.history[:, 2] - b.history[:, 2]) / np.abs(a.history[:, 2])) <= 1e-9
+    assert abs(a.fret - b.fret) <= 1e-9 * abs(a.fret) and np.max(np.abs(a.x - b.x)) <= 1e-8 * (1.0 + np.max(np.abs(a.x)))
+    # a sub-block with constants, cameras only, both ways
+    free = np.concatenate([np.arange(0, 6), np.arange(27, 36), np.arange(441, 471)]).astype(np.int64)
+    fac = np.where(pp.pt_vid0 < 471)[0].astype(np.int64)
+    rs = [capi.Problem(gctx, pp).lm_optimize(free, fac, maxiters=8, model=model, schur=s) for s in (1, 2)]
+    assert abs(rs[0].fret - rs[1].fret) <= 1e-9 * abs(rs[0].fret) and np.array_equal(rs[0].history[:, 3], rs[1].history[:, 3])
+    # full ladybug: time per call
+    full = P.load_bal()
+    g = capi.Problem(gctx, full)
+    ms = {}
+    for schur in (1, 2, 0):
+        g.set_x(full.x0)
+        g.lm_optimize(maxiters=3, model=model, schur=schur)
+        g.set_x(full.x0)
+        t = time.perf_counter()
+        r = g.lm_optimize(maxiters=25, model=model, schur=schur)
+        gctx.synchronize()
+        ms[schur] = ((time.perf_counter() - t) * 1e3, r.fret, r.nsolve)
+    print("LM model %d, full ladybug, 25 iterations: dense Schur %.1f ms, sparse %.1f ms, by fill %.1f ms (%d damped solves); end values %.8g / %.8g" % (
+        model, ms[1][0], ms[2][0], ms[0][0], ms[0][2], ms[1][1], ms[2][1]))
+    assert abs(ms[1][1] - ms[2][1]) <= 1e-6 * abs(ms[1][1]) and ms[0][1] == ms[2][1]      # by fill = sparse here, bit for bit
+    assert ms[2][0] < ms[1][0]
