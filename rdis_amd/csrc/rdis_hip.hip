@@ -9,6 +9,7 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -1998,11 +1999,22 @@ extern "C" int rdis_hip_cgd_batch(rdis_hip_problem* p, int64_t ncomp, const int6
                                   double* x_inout, int32_t maxiters, double ftol, double* fret, double* delta,
                                   int32_t* iters, int32_t* status, int64_t* nfeval, int64_t* ngeval) {
     rdis_hip_plan* L = nullptr;
+    // RDIS_HIP_TIMING=1: where a one-shot call's host time goes (stderr), for the tuning of this path
+    static const bool timing = std::getenv("RDIS_HIP_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = timing ? now() : 0.0;
     int rc = plan_create_impl(p, true, ncomp, free_ptr, free_vid, fac_ptr, fac_id, &L);
     if (rc) return rc;
+    const double t1 = timing ? now() : 0.0;
     rc = rdis_hip_plan_set_start(L, x_inout);
+    double t2 = 0.0, t3 = 0.0;
+    if (!rc && timing) { t2 = now(); rc = prepare_partition(L); t3 = now(); }
     if (!rc) rc = rdis_hip_plan_solve(L, maxiters, ftol);
+    const double t4 = timing ? now() : 0.0;
     if (!rc) rc = rdis_hip_plan_fetch(L, x_inout, fret, delta, iters, status, nfeval, ngeval);
+    if (timing)
+        std::fprintf(stderr, "rdis_hip_cgd_batch: lists + index tables %.3f ms, start %.3f, partition %.3f, launch %.3f, wait + results %.3f\n",
+                     t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
     if (rc) {   // kernels or copies that use the plan's host staging vectors / arena slices may still be queued
         (void)hipStreamSynchronize(p->ctx->stream);
         if (p->ctx->aux) (void)hipStreamSynchronize(p->ctx->aux);
