@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "host_blocks.hpp"
 #include "components.hpp"
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
@@ -85,6 +86,7 @@ int upload(rdis_hip_ctx* c, DevBuf& b, const T* src, size_t n) {
 }
 template <class T>
 int upload(rdis_hip_ctx* c, DevBuf& b, const std::vector<T>& v) { return upload(c, b, v.data(), v.size()); }
+inline int upload(rdis_hip_ctx* c, DevBuf& b, const ivec& v) { return upload(c, b, v.data(), v.size()); }
 
 int grid_for(const rdis_hip_ctx* c, long long work, int threads) {
     long long blocks = (work + threads - 1) / threads;
@@ -94,6 +96,8 @@ int grid_for(const rdis_hip_ctx* c, long long work, int threads) {
 
 }  // namespace
 
+struct VarMark { int stamp, owner, gidx, pad; };
+
 struct rdis_hip_problem {
     rdis_hip_ctx* ctx = nullptr;
     int kind = KIND_BA;
@@ -101,10 +105,10 @@ struct rdis_hip_problem {
     DevBuf x, lo, hi, cam, pt, obs, coeff, rowptr, vid, expo, cons, sine;
     DevBuf cam_blocks, xrot;                        // distinct camera blocks; their rotation records (shadow of x)
     int64_t ncam_blocks = 0;
-    std::vector<int> h_block_of;                    // [N] first variable id of the camera block a variable belongs to, -1 = none
-    std::vector<int> h_ptblock_of;                  // [N] ... of the point block, -1 = none (valid when ncam_blocks > 0)
-    std::vector<int> h_blk_stamp, h_blk_idx;        // [N] scratch of the slot tables (solver_lds.hpp), valid by stamp
-    std::vector<int> h_cam, h_pt, h_rowptr, h_vid;  // host copies for plan building
+    ivec h_block_of;                    // [N] first variable id of the camera block a variable belongs to, -1 = none
+    ivec h_ptblock_of;                  // [N] ... of the point block, -1 = none (valid when ncam_blocks > 0)
+    ivec h_blk_stamp, h_blk_idx;        // [N] scratch of the slot tables (solver_lds.hpp), valid by stamp
+    ivec h_cam, h_pt, h_rowptr, h_vid;  // host copies for plan building
     // scratch for the eval entry points
     DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
     DevBuf all_v2s_ptr, all_v2s_idx;  // gather lists for "all factors"
@@ -116,7 +120,8 @@ struct rdis_hip_problem {
     size_t arena_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct rdis_hip_plan* last_timed_plan = nullptr;
-    std::vector<int> h_owner, h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
+    ivec h_local, h_owner_stamp, h_fac_stamp;  // validity by stamp: no O(N) clears per call
+    std::vector<VarMark> h_mark;           // [N] plan_create's view of a variable: free in which component, where in the free list
     LmWorkspace lm_ws;                     // scratch of rdis_hip_lm_optimize, kept between calls
     CcWorkspace cc_ws;                     // ... and of rdis_hip_components
     ComponentLists comps;                  // result of the last rdis_hip_components call
@@ -175,21 +180,22 @@ struct rdis_hip_plan {
            off_slot_base = 0, off_slot_pos = 0;
     // results block: xout[nfree] fret[nc] delta[nc] (f64) | nfeval[nc] ngeval[nc] (i64) | iters[nc] status[nc] trace_n[nc] (i32)
     size_t out_bytes = 0;
-    std::vector<char> h_out;
-    std::vector<int> h_blk;   // host image of `ints` (kept alive: its upload is asynchronous)
-    std::vector<int> h_order, h_fac_ptr, h_free_ptr, h_free_vid, h_fac_id, h_v2s_ptr;
+    cvec h_out;
+    ivec h_blk;   // host image of `ints` (kept alive: its upload is asynchronous)
+    ivec h_order, h_fac_ptr, h_free_ptr, h_free_vid, h_fac_id, h_v2s_ptr;
+    ivec h_slot_li;           // [nslots] per listed factor slot: index of its variable within its component, -1 = constant (may be dropped: plan_create)
     bool have_start = false;
     // which components go where (rebuilt when an option changes)
     bool partition_dirty = true;
     int coop_state_gen = -1;          // generation of the problem's exchange-state buffer this partition points into
     std::vector<CoopItem> coop;
     std::vector<CoopLaunch> coop_launches;
-    std::vector<int> h_coop_ints;   // host image of coop_ints (kept: the upload is asynchronous)
+    ivec h_coop_ints;   // host image of coop_ints (kept: the upload is asynchronous)
     DevBuf coop_ints;
     std::vector<std::vector<CoopGroup>> h_coop_groups;
-    std::vector<std::vector<int>> h_coop_wg;
+    std::vector<ivec> h_coop_wg;
     std::vector<StreamItem> stream;
-    std::vector<int> h_rest;
+    ivec h_rest;
     DevBuf rest_order, xi_glob, queue;
     int group_blocks4 = 0, group_blocks16 = 0;   // resident blocks of the tiny-component kernels
     int tiny_max_blocks = 0;                     // option (tests): cap on their grid, 0 = what is resident
@@ -205,7 +211,7 @@ struct rdis_hip_plan {
     int ptm_threads = 0;              // option "ptm_threads": its workgroup size, 0 = auto
     int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
-    std::vector<int> h_pm_jg;
+    ivec h_pm_jg;
     DevBuf pm_rec, pm_cam, pm_obs, pm_pg, pm_cgq, pm_gqpos, pm_gqw, pm_gqe, pm_gqobs;
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
@@ -223,7 +229,7 @@ struct rdis_hip_plan {
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
     DevBuf lds_ints, lds_obs;
-    std::vector<int> h_lds_ints;
+    ivec h_lds_ints;
     size_t off_ls_ptr = 0, off_ls_vid = 0, off_ls_free = 0, off_ls_ncb = 0, off_ls_fidx = 0, off_ls_gperm = 0, off_ls_gptr = 0;
     int tiny_group = 4;               // ... with this many lanes per component (4 or 16)
     int64_t row_min_components = 4096; // option: sixteen lanes each from this many tiny components (below: a workgroup each)
@@ -390,7 +396,7 @@ extern "C" int rdis_hip_upload_ba(rdis_hip_ctx* c, int64_t nvars, const double* 
     if (!rc) rc = upload(c, p->cam, p->h_cam);
     if (!rc) rc = upload(c, p->pt, p->h_pt);
     if (!rc) rc = upload(c, p->obs, obs, (size_t)(2 * nfac));
-    std::vector<int> blocks;   // (alive until the copies below have completed)
+    ivec blocks;   // (alive until the copies below have completed)
     {   // the distinct camera blocks, for the rotation records of launches that leave the cameras constant
         p->h_block_of.assign((size_t)nvars, -1);
         blocks = p->h_cam;
@@ -474,7 +480,7 @@ int stage_ids(rdis_hip_problem* p, int64_t n, const int64_t* ids, int64_t limit,
     rdis_hip_ctx* c = p->ctx;
     *dev = nullptr;
     if (!ids) return 0;
-    std::vector<int> tmp((size_t)n);
+    ivec tmp((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         if (ids[i] < 0 || ids[i] >= limit) return fail(c, RDIS_HIP_EINVAL, "id out of range");
         tmp[(size_t)i] = (int)ids[i];
@@ -536,8 +542,8 @@ extern "C" int rdis_hip_get_x(rdis_hip_problem* p, int64_t n, const int64_t* vid
 namespace {
 
 // for every variable the gradient slots that feed it, in factor-list order
-void build_v2s(const rdis_hip_problem* p, int64_t nf, const int64_t* fac, std::vector<int>& ptr,
-               std::vector<int>& idx) {
+void build_v2s(const rdis_hip_problem* p, int64_t nf, const int64_t* fac, ivec& ptr,
+               ivec& idx) {
     ptr.assign((size_t)p->N + 1, 0);
     for (int64_t i = 0; i < nf; ++i) {
         const int f = (int)(fac ? fac[i] : i);
@@ -545,7 +551,7 @@ void build_v2s(const rdis_hip_problem* p, int64_t nf, const int64_t* fac, std::v
     }
     for (int64_t v = 0; v < p->N; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
     idx.resize((size_t)ptr[(size_t)p->N]);
-    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    ivec fill(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < nf; ++i) {
         const int f = (int)(fac ? fac[i] : i);
         for (int k = 0, a = p->arity(f); k < a; ++k) idx[(size_t)fill[(size_t)p->var_of(f, k)]++] = p->slot_of(f, k);
@@ -602,7 +608,7 @@ extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t
     DevBuf lptr, lidx;
     if (!fac) {
         if (!p->have_all_v2s) {
-            std::vector<int> ptr, idx;
+            ivec ptr, idx;
             build_v2s(p, nf, nullptr, ptr, idx);
             if ((rc = upload(c, p->all_v2s_ptr, ptr))) return rc;
             if ((rc = upload(c, p->all_v2s_idx, idx))) return rc;
@@ -611,7 +617,7 @@ extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t
         }
         dptr = p->all_v2s_ptr.as<int>(); didx = p->all_v2s_idx.as<int>();
     } else {
-        std::vector<int> ptr, idx;
+        ivec ptr, idx;
         build_v2s(p, nf, fac, ptr, idx);
         if ((rc = upload(c, lptr, ptr))) return rc;
         if ((rc = upload(c, lidx, idx))) return rc;
@@ -714,7 +720,7 @@ int ensure_problem_scratch(rdis_hip_problem* p) {
         HIPCHK(c, hipMemsetAsync(p->dir.p, 0, p->dir.bytes, c->stream));
         HIPCHK(c, hipEventCreate(&p->ev0));
         HIPCHK(c, hipEventCreate(&p->ev1));
-        p->h_owner.assign((size_t)p->N, -1);
+        p->h_mark.assign((size_t)p->N, VarMark{0, -1, -1, 0});
         p->h_local.assign((size_t)p->N, -1);
         p->h_owner_stamp.assign((size_t)p->N, 0);
         p->h_fac_stamp.assign((size_t)p->F, 0);
@@ -746,10 +752,10 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     if (const char* ev = std::getenv("RDIS_HIP_COOP_PIPELINE")) L->coop_pipeline = std::atoi(ev) != 0;
 
     // --- validate independence (free sets disjoint, factors owned once, no factor of one
-    // component reading a free variable of another); owner / local are persistent per-problem
-    // arrays validated by a stamp, so a call costs O(its own size), not O(N)
+    // component reading a free variable of another); the marks are a persistent per-problem
+    // array validated by a stamp, so a call costs O(its own size), not O(N)
     const int stamp = ++p->stamp;
-    auto owner_of = [&](int v) { return p->h_owner_stamp[(size_t)v] == stamp ? p->h_owner[(size_t)v] : -1; };
+    VarMark* const mark = p->h_mark.data();
     L->h_free_ptr.resize((size_t)ncomp + 1); L->h_fac_ptr.resize((size_t)ncomp + 1);
     L->h_free_vid.resize((size_t)nfree); L->h_fac_id.resize((size_t)nfac);
     for (int64_t cc = 0; cc <= ncomp; ++cc) {
@@ -762,49 +768,81 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         for (int64_t i = free_ptr[cc]; i < free_ptr[cc + 1]; ++i) {
             const int64_t v = free_vid[i];
             if (v < 0 || v >= p->N) return fail(c, RDIS_HIP_EINVAL, "plan_create: free variable id out of range");
-            if (owner_of((int)v) != -1) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: variable " + std::to_string(v) + " is free in two components (or listed twice)");
-            p->h_owner_stamp[(size_t)v] = stamp;
-            p->h_owner[(size_t)v] = (int)cc;
-            p->h_local[(size_t)v] = (int)(i - free_ptr[cc]);
+            VarMark& mk = mark[(size_t)v];
+            if (mk.stamp == stamp) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: variable " + std::to_string(v) + " is free in two components (or listed twice)");
+            mk.stamp = stamp; mk.owner = (int)cc; mk.gidx = (int)i;
             L->h_free_vid[(size_t)i] = (int)v;
         }
-    std::vector<int>& v2s_ptr = L->h_v2s_ptr;
+    // One pass over the listed factors' slots leaves, per slot, the position of its variable in the
+    // plan's free list (-1: a constant for this solve) and counts the slots per variable; a second,
+    // sequential one turns that into the variable-major position of the slot's partial (slot_pos) and
+    // the variable's index within its component (h_slot_li: what the cooperative layouts address by).
+    ivec& v2s_ptr = L->h_v2s_ptr;
     v2s_ptr.assign((size_t)nfree + 1, 0);
-    std::vector<int> slot_base((size_t)nfac + 1, 0);
-    for (int64_t cc = 0; cc < ncomp; ++cc)
+    ivec slot_base((size_t)nfac + 1);
+    slot_base[0] = 0;
+    int* const fid32 = L->h_fac_id.data();
+    int* const cnt = v2s_ptr.data() + 1;
+    const bool ba = p->kind == KIND_BA;
+    if (ba) L->nslots = 12 * nfac;
+    else {
+        int64_t ns = 0;
+        for (int64_t j = 0; j < nfac; ++j) {
+            const int64_t f = fac_id[j];
+            if (f < 0 || f >= p->F) return fail(c, RDIS_HIP_EINVAL, "plan_create: factor id out of range");
+            ns += p->arity((int)f);
+        }
+        if (ns >= (1ll << 31) - 16) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
+        L->nslots = ns;
+    }
+    ivec& sli = L->h_slot_li;
+    sli.resize((size_t)L->nslots);
+    int* const gi = sli.data();
+    auto other_owner = [&](int64_t f, int64_t cc, int o) {
+        return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " of component " + std::to_string(cc) + " reads a free variable of component " + std::to_string(o));
+    };
+    for (int64_t cc = 0; cc < ncomp; ++cc) {
+        const int icc = (int)cc;
         for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
             const int64_t f = fac_id[j];
             if (f < 0 || f >= p->F) return fail(c, RDIS_HIP_EINVAL, "plan_create: factor id out of range");
             if (p->h_fac_stamp[(size_t)f] == stamp) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " listed twice");
             p->h_fac_stamp[(size_t)f] = stamp;
-            L->h_fac_id[(size_t)j] = (int)f;
-            const int a = p->arity((int)f);
-            slot_base[(size_t)j + 1] = slot_base[(size_t)j] + a;
-            for (int k = 0; k < a; ++k) {
-                const int v = p->var_of((int)f, k);
-                const int o = owner_of(v);
-                if (o == -1) continue;  // a constant for this solve
-                if (o != (int)cc) return fail(c, RDIS_HIP_EOVERLAP, "plan_create: factor " + std::to_string(f) + " of component " + std::to_string(cc) + " reads a free variable of component " + std::to_string(o));
-                ++v2s_ptr[(size_t)(free_ptr[cc] + p->h_local[(size_t)v]) + 1];
-            }
-        }
-    for (int64_t i = 0; i < nfree; ++i) v2s_ptr[(size_t)i + 1] += v2s_ptr[(size_t)i];
-    L->nslots = slot_base[(size_t)nfac];
-    L->ngfac = v2s_ptr[(size_t)nfree];
-    // gfac is variable-major: slot_pos[s] = where listed factor slot s lands in it (-1: not free here)
-    std::vector<int> slot_pos((size_t)L->nslots, -1);
-    {
-        std::vector<int> fill(v2s_ptr.begin(), v2s_ptr.end() - 1);
-        for (int64_t cc = 0; cc < ncomp; ++cc)
-            for (int64_t j = fac_ptr[cc]; j < fac_ptr[cc + 1]; ++j) {
-                const int f = L->h_fac_id[(size_t)j];
-                for (int k = 0, a = p->arity(f); k < a; ++k) {
-                    const int v = p->var_of(f, k);
-                    if (owner_of(v) != (int)cc) continue;
-                    slot_pos[(size_t)slot_base[(size_t)j] + k] = fill[(size_t)(free_ptr[cc] + p->h_local[(size_t)v])]++;
+            fid32[j] = (int)f;
+            if (ba) {
+                slot_base[(size_t)j + 1] = 12 * (int)(j + 1);
+                int* g = gi + 12 * j;
+                const VarMark* mc = mark + p->h_cam[(size_t)f];
+                const VarMark* mp = mark + p->h_pt[(size_t)f];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const VarMark& mk = k < 9 ? mc[k] : mp[k - 9];
+                    int pos = -1;
+                    if (mk.stamp == stamp) {
+                        if (mk.owner != icc) return other_owner(f, cc, mk.owner);
+                        pos = mk.gidx;
+                        ++cnt[pos];
+                    }
+                    g[k] = pos;
+                }
+            } else {
+                const int a = p->arity((int)f), sb = slot_base[(size_t)j];
+                slot_base[(size_t)j + 1] = sb + a;
+                for (int k = 0; k < a; ++k) {
+                    const VarMark& mk = mark[(size_t)p->var_of((int)f, k)];
+                    int pos = -1;
+                    if (mk.stamp == stamp) {
+                        if (mk.owner != icc) return other_owner(f, cc, mk.owner);
+                        pos = mk.gidx;
+                        ++cnt[pos];
+                    }
+                    gi[sb + k] = pos;
                 }
             }
+        }
     }
+    for (int64_t i = 0; i < nfree; ++i) v2s_ptr[(size_t)i + 1] += v2s_ptr[(size_t)i];
+    L->ngfac = v2s_ptr[(size_t)nfree];
     // heaviest components first (longest-processing-time order for the launch)
     L->h_order.resize((size_t)ncomp);
     std::iota(L->h_order.begin(), L->h_order.end(), 0);
@@ -813,15 +851,36 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     });
 
     // --- one int32 block, one H2D copy
-    std::vector<int>& blk = L->h_blk;
-    auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
+    ivec& blk = L->h_blk;
+    blk.reserve((size_t)(4 * ncomp + 3 * nfree + 2 * nfac + L->nslots) + 64);
+    auto put = [&](const ivec& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
     L->off_order = put(L->h_order);
     L->off_free_ptr = put(L->h_free_ptr); L->off_free_vid = put(L->h_free_vid);
     L->off_fac_ptr = put(L->h_fac_ptr); L->off_fac_id = put(L->h_fac_id);
-    L->off_v2s_ptr = put(v2s_ptr); L->off_slot_base = put(slot_base); L->off_slot_pos = put(slot_pos);
+    L->off_v2s_ptr = put(v2s_ptr); L->off_slot_base = put(slot_base);
+    {   // gfac is variable-major: slot_pos[s] = where listed factor slot s lands in it (-1: not free here),
+        // the slots of a variable in listed order; the positions above become component-local indices
+        L->off_slot_pos = blk.size();
+        blk.resize(blk.size() + (size_t)L->nslots);
+        int* const slot_pos = blk.data() + L->off_slot_pos;
+        ivec fill(v2s_ptr.begin(), v2s_ptr.end() - 1);
+        int* const fl = fill.data();
+        for (int64_t cc = 0; cc < ncomp; ++cc) {
+            const int f0 = (int)free_ptr[cc];
+            const int64_t s0 = slot_base[(size_t)fac_ptr[cc]], s1 = slot_base[(size_t)fac_ptr[cc + 1]];
+            for (int64_t s = s0; s < s1; ++s) {
+                const int g = gi[s];
+                slot_pos[s] = g >= 0 ? fl[g]++ : -1;
+                gi[s] = g >= 0 ? g - f0 : -1;
+            }
+        }
+    }
+    // (the per-slot local indices serve prepare_partition's cooperative groups, bundle adjustment only; a plan
+    // too large for them to matter does not keep them: prepare_partition then forms a group's indices itself)
+    if (!ba || L->nslots > (64ll << 20)) { ivec().swap(L->h_slot_li); }
     {   // per component: the camera blocks with a free rotation variable (their records follow the trial
         // point) and where in the component's vectors their three rotation variables are (-1: constant)
-        std::vector<int> cb_ptr((size_t)ncomp + 1, 0), cb, cb_li;
+        ivec cb_ptr((size_t)ncomp + 1, 0), cb, cb_li;
         if (p->kind == KIND_BA && p->ncam_blocks > 0) {
             std::vector<std::array<int, 3>> ent;   // (block, which of the three, local index)
             for (int64_t cc = 0; cc < ncomp; ++cc) {
@@ -1092,7 +1151,7 @@ int prepare_partition(rdis_hip_plan* L) {
     if (any_big) scap = stream_max_workgroups(p->kind, c->num_cus);
     if (L->coop_workgroups > 0) scap = std::min(scap, L->coop_workgroups);
     int64_t max_n = 0;
-    std::vector<int> blk_all;
+    ivec blk_all;
     // (one allocation: growing this by appending costs a transient call on ladybug 1.5 ms in page faults)
     L->h_coop_ints.reserve((size_t)(any_big ? 12 * L->nfac + 4 * (L->nfac + L->nfree) + 4096 * (int64_t)std::min<int64_t>(L->ncomp, 64) : 0));
     for (int cc : L->h_order) {  // heaviest first
@@ -1110,7 +1169,7 @@ int prepare_partition(rdis_hip_plan* L) {
             st.comp = cc;
             st.nwg = (int)std::max<int64_t>(1, std::min<int64_t>(scap, (std::max(m, n) + 2 * STREAM_THREADS - 1) / (2 * STREAM_THREADS)));
             const int f0s = L->h_free_ptr[(size_t)cc];
-            std::vector<int> longv;
+            ivec longv;
             for (int64_t i = 0; i < n; ++i)
                 if (L->h_v2s_ptr[(size_t)(f0s + i) + 1] - L->h_v2s_ptr[(size_t)(f0s + i)] > STREAM_LONG_LIST) longv.push_back((int)i);
             st.nlong = (int)longv.size();
@@ -1129,40 +1188,47 @@ int prepare_partition(rdis_hip_plan* L) {
         it.nwg = (int)need;
         it.xi_off = (size_t)max_n;   // (max_n: running total of the cooperative components' variables)
         const int f0 = L->h_free_ptr[(size_t)cc], c0 = L->h_fac_ptr[(size_t)cc];
-        // local free index of each factor slot (h_local is still valid for this plan's stamp only
-        // while no other plan was created in between: rebuild it for the component)
-        for (int64_t i = 0; i < n; ++i) p->h_local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = (int)i;
-        std::vector<char> is_free_here;  // via a per-call marker: stamp the component's variables
-        const int stamp = ++p->stamp;
-        for (int64_t i = 0; i < n; ++i) p->h_owner_stamp[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = stamp;
-        std::vector<int> sl((size_t)(12 * m));
-        for (int64_t j = 0; j < m; ++j) {
-            const int f = L->h_fac_id[(size_t)(c0 + j)];
-            for (int k = 0; k < 12; ++k) {
-                const int v = p->var_of(f, k);
-                sl[(size_t)(12 * j + k)] = p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1;
+        // local free index of each factor slot: plan_create's table, or (a plan that did not keep it) formed
+        // here from the per-problem marks, valid for one stamp
+        ivec sl_own;
+        const int* sl = nullptr;
+        if (!L->h_slot_li.empty()) sl = L->h_slot_li.data() + 12 * (size_t)c0;
+        else {
+            for (int64_t i = 0; i < n; ++i) p->h_local[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = (int)i;
+            const int stamp = ++p->stamp;
+            for (int64_t i = 0; i < n; ++i) p->h_owner_stamp[(size_t)L->h_free_vid[(size_t)(f0 + i)]] = stamp;
+            sl_own.resize((size_t)(12 * m));
+            for (int64_t j = 0; j < m; ++j) {
+                const int f = L->h_fac_id[(size_t)(c0 + j)];
+                for (int k = 0; k < 12; ++k) {
+                    const int v = p->var_of(f, k);
+                    sl_own[(size_t)(12 * j + k)] = p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1;
+                }
             }
+            sl = sl_own.data();
         }
         // owners of the CG recurrence: a lane per variable, a whole wave for variables fed by
         // many partials (longest first), see solver_coop.hpp
         const int lanes = it.nwg * L->coop_lanes(), waves = lanes / 64;
-        std::vector<int> lane_var((size_t)lanes, -1), wave_var((size_t)waves, -1), longv;
+        ivec lane_var((size_t)lanes, -1), wave_var((size_t)waves, -1), longv;
         for (int64_t i = 0; i < n; ++i)
             if (L->h_v2s_ptr[(size_t)(f0 + i) + 1] - L->h_v2s_ptr[(size_t)(f0 + i)] > COOP_LONG_LIST) longv.push_back((int)i);
         std::stable_sort(longv.begin(), longv.end(), [&](int a, int b) {
             return (L->h_v2s_ptr[(size_t)(f0 + a) + 1] - L->h_v2s_ptr[(size_t)(f0 + a)]) >
                    (L->h_v2s_ptr[(size_t)(f0 + b) + 1] - L->h_v2s_ptr[(size_t)(f0 + b)]);
         });
-        std::vector<char> wave_owned((size_t)n, 0);
+        cvec wave_owned((size_t)n, 0);
         for (size_t k = 0; k < longv.size() && (int)k < waves; ++k) { wave_var[k] = longv[k]; wave_owned[(size_t)longv[k]] = 1; }
         for (int64_t i = 0; i < n; ++i) if (!wave_owned[(size_t)i]) lane_var[(size_t)i] = (int)i;
-        auto append = [&](const std::vector<int>& v) {
+        auto append = [&](const int* v, size_t count) {
             const size_t off = L->h_coop_ints.size();
-            L->h_coop_ints.insert(L->h_coop_ints.end(), v.begin(), v.end());
+            L->h_coop_ints.insert(L->h_coop_ints.end(), v, v + count);
             L->h_coop_ints.resize((L->h_coop_ints.size() + 63) / 64 * 64, -1);
             return off;
         };
-        it.slot_li = append(sl); it.lane_var = append(lane_var); it.wave_var = append(wave_var);
+        it.slot_li = append(sl, (size_t)(12 * m));
+        it.lane_var = append(lane_var.data(), lane_var.size());
+        it.wave_var = append(wave_var.data(), wave_var.size());
         max_n += n;
     }
     // tiny bundle-adjustment components (at most QUAD_MAX_VARS free variables: a point against fixed
@@ -1215,10 +1281,10 @@ int prepare_partition(rdis_hip_plan* L) {
     if (p->kind == KIND_BA && (L->lds_resident != 0 || L->ptm_stream != 0) && p->ncam_blocks > 0 && (int)L->h_rest.size() > L->rest_tiny) {
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
         const size_t nc = (size_t)L->ncomp;
-        std::vector<char> kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
-        std::vector<int> ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
-        std::vector<std::vector<int>> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
-        std::vector<int> cams, pts, deg;
+        cvec kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
+        ivec ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
+        std::vector<ivec> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
+        ivec cams, pts, deg;
         for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
             const int cc = L->h_rest[r];
             const int f0 = L->h_free_ptr[(size_t)cc], f1 = L->h_free_ptr[(size_t)cc + 1];
@@ -1226,7 +1292,7 @@ int prepare_partition(rdis_hip_plan* L) {
             if (c1 == c0) continue;   // (an empty factor list needs no table: solver_wg.hpp returns 0 for it)
             const int stamp = ++p->stamp;
             cams.clear(); pts.clear();
-            auto note = [&](int b, std::vector<int>& list) {
+            auto note = [&](int b, ivec& list) {
                 if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; list.push_back(b); }
             };
             bool ok = true, free_cam = false;
@@ -1243,9 +1309,9 @@ int prepare_partition(rdis_hip_plan* L) {
             for (int k = 0; k < ncb; ++k) p->h_blk_idx[(size_t)cams[(size_t)k]] = k;
             // the order of the gradient pass: camera by camera (listed order within a camera), whole waves per camera --
             // where a camera variable is free; otherwise nothing is summed per camera and the listed order serves
-            std::vector<int>& gp = gp_of[(size_t)cc];
+            ivec& gp = gp_of[(size_t)cc];
             if (free_cam) {
-                std::vector<int> start((size_t)ncb + 1, 0);
+                ivec start((size_t)ncb + 1, 0);
                 for (int j = c0; j < c1; ++j) ++start[(size_t)p->h_blk_idx[(size_t)p->h_cam[(size_t)L->h_fac_id[(size_t)j]]] + 1];
                 for (int k = 0; k < ncb; ++k) start[(size_t)k + 1] = start[(size_t)k] + (start[(size_t)k + 1] + 63) / 64 * 64;
                 gp.assign((size_t)start[(size_t)ncb], -1);
@@ -1268,18 +1334,18 @@ int prepare_partition(rdis_hip_plan* L) {
                 for (int k = 0; k < npb; ++k) p->h_blk_idx[(size_t)pts[(size_t)k]] = k;
                 deg.assign((size_t)npb, 0);
                 for (int j = c0; j < c1; ++j) ++deg[(size_t)p->h_blk_idx[(size_t)p->h_pt[(size_t)L->h_fac_id[(size_t)j]]]];
-                std::vector<int> ord((size_t)npb);
+                ivec ord((size_t)npb);
                 std::iota(ord.begin(), ord.end(), 0);
                 std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return deg[(size_t)a] > deg[(size_t)b]; });
-                std::vector<int> pts2((size_t)npb);
+                ivec pts2((size_t)npb);
                 for (int k = 0; k < npb; ++k) pts2[(size_t)k] = pts[(size_t)ord[(size_t)k]];
                 pts.swap(pts2);
             }
             for (int k = 0; k < npb; ++k) p->h_blk_idx[(size_t)pts[(size_t)k]] = k;
             // local free index of the component's variables (the per-problem arrays are valid for one stamp)
             for (int i = f0; i < f1; ++i) { const int v = L->h_free_vid[(size_t)i]; p->h_owner_stamp[(size_t)v] = stamp; p->h_local[(size_t)v] = i - f0; }
-            std::vector<int>& sv = vid_of[(size_t)cc];
-            std::vector<int>& sf = free_of[(size_t)cc];
+            ivec& sv = vid_of[(size_t)cc];
+            ivec& sf = free_of[(size_t)cc];
             sv.reserve((size_t)ns); sf.reserve((size_t)ns);
             auto slot = [&](int v) { sv.push_back(v); sf.push_back(p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1); };
             for (int b : cams) for (int k = 0; k < 9; ++k) slot(b + k);
@@ -1301,7 +1367,7 @@ int prepare_partition(rdis_hip_plan* L) {
                 L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, ncb);
                 L->ptm_chunk_cap = std::max(L->ptm_chunk_cap, nchunk);
                 // the point's factors, in listed order (a CSR over the point blocks in their slot order)
-                std::vector<int>& pp = pptr_of[(size_t)cc];
+                ivec& pp = pptr_of[(size_t)cc];
                 pp.assign((size_t)npb + 1, 0);
                 for (int j = c0; j < c1; ++j) ++pp[(size_t)(((unsigned)ls_fidx[(size_t)j]) >> 12) + 1];
                 for (int k = 0; k < npb; ++k) pp[(size_t)k + 1] += pp[(size_t)k];
@@ -1318,7 +1384,7 @@ int prepare_partition(rdis_hip_plan* L) {
         L->rest_lds = (int)(L->h_rest.end() - first_lds);
         if (L->rest_ptm + L->rest_lds > 0) {
             // one int32 block, tables in component order (a component without one has empty ranges)
-            std::vector<int> sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm;
+            ivec sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm;
             for (size_t cc = 0; cc < nc; ++cc) {
                 const bool has = kind_of[cc] != 0;
                 sptr[cc + 1] = sptr[cc] + (has ? (int)vid_of[cc].size() : 0);
@@ -1334,7 +1400,7 @@ int prepare_partition(rdis_hip_plan* L) {
             // factor of the lane's block (or no factor: -1), so a wave's loads of a slot are 64 neighbours and their
             // addresses depend on nothing the wave has loaded before.  entry -> listed factor (plan-wide index),
             // listed factor -> entry (where the gradient pass leaves the factor's three point partials).
-            std::vector<int> pm_ch0v(nc, 0), cptr, eof((size_t)L->nfac, -1);
+            ivec pm_ch0v(nc, 0), cptr, eof((size_t)L->nfac, -1);
             L->h_pm_jg.clear();
             for (size_t cc = 0; cc < nc; ++cc) {
                 if (kind_of[cc] != 2) continue;
@@ -1343,11 +1409,11 @@ int prepare_partition(rdis_hip_plan* L) {
                 pm_ch0v[cc] = (int)cptr.size();
 
                 const int e0 = (int)L->h_pm_jg.size();
-                std::vector<int> cbase((size_t)npc + 1, 0);
+                ivec cbase((size_t)npc + 1, 0);
                 for (int ch = 0; ch < npc; ++ch)   // (descending: a chunk's first block has the most factors)
                     cbase[(size_t)ch + 1] = cbase[(size_t)ch] + 64 * (pptr_of[cc][(size_t)(64 * ch) + 1] - pptr_of[cc][(size_t)(64 * ch)]);
                 L->h_pm_jg.resize((size_t)e0 + (size_t)cbase[(size_t)npc], -1);
-                std::vector<int> fill((size_t)npb, 0);
+                ivec fill((size_t)npb, 0);
                 for (int j = c0; j < c1; ++j) {
                     const int pi = (int)(((unsigned)ls_fidx[(size_t)j]) >> 12);
                     const int e = e0 + cbase[(size_t)(pi / 64)] + 64 * fill[(size_t)pi]++ + (pi % 64);
@@ -1362,8 +1428,8 @@ int prepare_partition(rdis_hip_plan* L) {
             L->ptm_min_points = INT64_MAX;
             for (size_t cc = 0; cc < nc; ++cc)
                 if (kind_of[cc] == 2) L->ptm_min_points = std::min<int64_t>(L->ptm_min_points, (int64_t)pptr_of[cc].size() - 1);
-            std::vector<int>& blk = L->h_lds_ints;
-            auto put = [&](const std::vector<int>& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
+            ivec& blk = L->h_lds_ints;
+            auto put = [&](const ivec& v) { const size_t off = blk.size(); blk.insert(blk.end(), v.begin(), v.end()); return off; };
             L->off_ls_ptr = put(sptr); L->off_ls_vid = put(svid); L->off_ls_free = put(sfree);
             L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gptr = put(gptr); L->off_ls_gperm = put(gperm);
             L->off_pm_pt0 = put(pm_pt0); L->off_pm_ch0 = put(pm_ch0v); L->off_pm_cptr = put(cptr); L->off_pm_jg = put(L->h_pm_jg);
@@ -1441,7 +1507,7 @@ int prepare_partition(rdis_hip_plan* L) {
         CoopLaunch cl;
         cl.first = (int)i;
         std::vector<CoopGroup> hg;
-        std::vector<int> hw;
+        ivec hw;
         while (i < L->coop.size() && (cl.count == 0 || cl.total_wg + L->coop[i].nwg <= cap) && cl.count < COOP_MAX_GROUPS) {
             const CoopItem& it = L->coop[i];
             CoopGroup g{};
@@ -1480,7 +1546,8 @@ int prepare_partition(rdis_hip_plan* L) {
         for (size_t g = 0; g < hg.size(); ++g) hg[g].a.st = p->coop_state.as<CoopState>() + g;
         HIPCHK(c, hipMemcpyAsync(L->coop_launches[l].groups.p, hg.data(), hg.size() * sizeof(CoopGroup), hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (a transient plan lives until its results are fetched, which waits for the stream)
+    if (!L->transient) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!L->h_rest.empty()) HIPCHK(c, hipMemcpyAsync(L->rest_order.p, L->h_rest.data(), L->h_rest.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     L->partition_dirty = false;
     L->coop_state_gen = p->coop_state_gen;
