@@ -44,7 +44,8 @@ public:
                     return p;
                 }
         }
-        return std::malloc(cls);
+        void* p = nullptr;   // page-aligned, like the mappings the C library would hand out at this size
+        return posix_memalign(&p, 4096, cls) == 0 ? p : nullptr;
     }
     void give(void* p, size_t bytes) {
         if (!p) return;
