@@ -48,12 +48,13 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     bool owned = true;  // false: a slice of the problem's arena
+    bool host = false;  // pinned host memory (hipHostMalloc), mapped into the device's address space
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned), host(o.host) { o.p = nullptr; o.bytes = 0; }
     ~DevBuf() { release(); }
-    void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
+    void release() { if (p && owned) (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; bytes = 0; owned = true; host = false; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -75,6 +76,16 @@ int dalloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
     b.owned = true;
+    return 0;
+}
+// pinned host memory, mapped into the device's address space (the same pointer on both sides)
+int halloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
+    b.release();
+    if (bytes == 0) bytes = 8;
+    HIPCHK(c, hipHostMalloc(&b.p, bytes, hipHostMallocDefault));
+    b.bytes = bytes;
+    b.owned = true;
+    b.host = true;
     return 0;
 }
 template <class T>
@@ -117,6 +128,9 @@ struct rdis_hip_problem {
     DevBuf dir, coop_state, coop_timing;   // search direction by variable id (kept zero between solves), ...
     int coop_state_gen = 0;                // bumped whenever coop_state moves: plans re-derive the pointers they baked in
     DevBuf arena;                          // memory of the transient plan of rdis_hip_cgd_batch
+    DevBuf stage_x;                        // pinned staging of a resident plan's start point (rdis_hip_plan_set_start)
+    hipEvent_t stage_ev = nullptr;         // ... recorded behind its copy: the next use waits for it
+    bool stage_busy = false;
     size_t arena_used = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     struct rdis_hip_plan* last_timed_plan = nullptr;
@@ -127,7 +141,7 @@ struct rdis_hip_problem {
     ComponentLists comps;                  // result of the last rdis_hip_components call
     DevBuf assigned;
     int stamp = 0;
-    ~rdis_hip_problem() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+    ~rdis_hip_problem() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); if (stage_ev) (void)hipEventDestroy(stage_ev); }
 
     ProblemView view() const {
         ProblemView v{};
@@ -687,6 +701,7 @@ extern "C" int rdis_hip_grad_each_ba(rdis_hip_problem* p, int64_t nf, const int6
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t STAGE_MAX_BYTES = 1u << 20;   // start points staged through pinned memory up to this size (resident plans)
 
 // plan memory: a persistent plan owns hipMalloc'ed buffers; a transient one (cgd_batch, i.e.
 // one optimize() call) carves them out of the problem's arena so that a call costs no
@@ -958,9 +973,23 @@ extern "C" int rdis_hip_plan_set_start(rdis_hip_plan* L, const double* xs) {
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->nfree == 0) { L->have_start = true; return 0; }
     if (xs) {
-        // pageable source: the copy is staged by the runtime before the call returns
-        HIPCHK(c, hipMemcpyAsync(L->xstart.p, xs, (size_t)L->nfree * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (!L->transient) HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t bytes = (size_t)L->nfree * sizeof(double);
+        rdis_hip_problem* p = L->prob;
+        if (!L->transient && bytes <= STAGE_MAX_BYTES) {
+            // a resident plan's caller may reuse xs the moment this returns: the values go through a pinned staging
+            // buffer of the problem (one host copy, an asynchronous upload) instead of a wait for the stream
+            if (p->stage_busy) { HIPCHK(c, hipEventSynchronize(p->stage_ev)); p->stage_busy = false; }
+            if (p->stage_x.bytes < bytes) { int rc = halloc(c, p->stage_x, std::max<size_t>(2 * bytes, 4096)); if (rc) return rc; }
+            if (!p->stage_ev) HIPCHK(c, hipEventCreateWithFlags(&p->stage_ev, hipEventDisableTiming));
+            std::memcpy(p->stage_x.p, xs, bytes);
+            HIPCHK(c, hipMemcpyAsync(L->xstart.p, p->stage_x.p, bytes, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(p->stage_ev, c->stream));
+            p->stage_busy = true;
+        } else {
+            // pageable source: a transient plan's caller keeps xs alive until the results are fetched
+            HIPCHK(c, hipMemcpyAsync(L->xstart.p, xs, bytes, hipMemcpyHostToDevice, c->stream));
+            if (!L->transient) HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     } else {
         gather_x_kernel<<<grid_for(c, L->nfree, 256), 256, 0, c->stream>>>((int)L->nfree, L->ip(L->off_free_vid), L->prob->x.as<double>(), L->xstart.as<double>());
         HIPCHK(c, hipGetLastError());
