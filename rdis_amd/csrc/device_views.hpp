@@ -83,7 +83,9 @@ struct PlanView {
     const int* pm_ch0;    // [ncomp] its first entry in pm_cptr (which has one more entry than wave-chunks per component)
     const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_cgp, slot-major --
                           // entry pm_cptr[c] + 64 t + lane is the t-th factor of the lane's point block
-    double* pm_rec;       // [blocks][12] p, xi, lo, hi of a point block's three variables
+    double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
+    float* pm_bnd;        // [blocks][6] their bounds lo, hi as floats rounded inward ...
+    double* pm_bex;       // [blocks][6] ... and exact
     const int* pm_cam;    // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
     double* pm_pg;        // [entries][3] the factor's three point partials (the one-pass gradient of workgroups that share a component; zeros where no factor)

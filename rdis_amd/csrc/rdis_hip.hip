@@ -226,7 +226,7 @@ struct rdis_hip_plan {
     int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     ivec h_pm_jg;
-    DevBuf pm_rec, pm_cam, pm_obs, pm_pg, pm_cgq, pm_gqpos, pm_gqw, pm_gqe, pm_gqobs;
+    DevBuf pm_rec, pm_bnd, pm_bex, pm_cam, pm_obs, pm_pg, pm_cgq, pm_gqpos, pm_gqw, pm_gqe, pm_gqobs;
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
     int ptm_last_group = 1;           // what the last solve used (rdis_hip_plan_debug_counters has no slot for it: get_option)
@@ -284,7 +284,7 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
-        v.pm_rec = pm_rec.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
+        v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_pg = pm_pg.as<double>(); v.pm_cgq = pm_cgq.as<double>(); v.pm_gqpos = pm_gqpos.as<int>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
@@ -933,7 +933,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         need += 5 * (3 * (size_t)(nfac + nfree) + 2048 * (size_t)std::min<int64_t>(ncomp, 4096)) + align_up(lanes_max * 4, 256);
         need += align_up((size_t)(12 * nfac) * 4, 256) + 8 * 256;                               // slot_li of all cooperative components
         need += align_up((size_t)(2 * (12 * nfac + 9 * nfree) + 2 * nfac + 64 * (nfac / 64 + std::min<int64_t>(nfac, nfree / 9 + 1) + ncomp) + 3 * ncomp + 3) * 4, 256) + align_up((size_t)nfac * 16, 256) + 256;   // slot tables, observations of the LDS-resident solver
-        need += align_up((size_t)(2 * nfac + nfree / 3 + 3 * ncomp + 16) * 4, 256) + align_up((size_t)(nfac + 1) * 20, 256) + align_up((size_t)(24 * nfac + 4 * nfree + 16 * ncomp + 1024) * 8, 256);   // ... of the streaming solver (records, point-major arrays, camera partials)
+        need += align_up((size_t)(2 * nfac + nfree / 3 + 3 * ncomp + 16) * 4, 256) + align_up((size_t)(nfac + 1) * 20, 256) + align_up((size_t)(24 * nfac + 6 * nfree + 16 * ncomp + 2048) * 8, 256);   // ... of the streaming solver (records, point-major arrays, camera partials)
         need += (size_t)COOP_MAX_GROUPS * (4 * 256 + sizeof(CoopGroup)) + (size_t)COOP_MAX_WG * 4 + lanes_max * 4 + 64 * 256;  // groups, their alignment slack
         if (p->arena.bytes < need) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1503,6 +1503,8 @@ int prepare_partition(rdis_hip_plan* L) {
     if (L->rest_ptm > 0) {   // the streaming components' point records, point-major factor arrays, gradient-order arrays
         const size_t gq = (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 64;
         rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
+        if (!rc) rc = plan_alloc(L, L->pm_bnd, (size_t)L->pm_blocks * PT_BND * sizeof(float));
+        if (!rc) rc = plan_alloc(L, L->pm_bex, (size_t)L->pm_blocks * PT_BND * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->ptm_cgg, (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 9 * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(int));
         if (!rc) rc = plan_alloc(L, L->pm_obs, (size_t)L->pm_entries * sizeof(double2));

@@ -9,7 +9,11 @@
 //
 //   cameras   slots in LDS as in solver_lds.hpp (Pv, XI, LO, HI, X, rotation records; also g and h
 //             of the Polak-Ribiere recurrence);
-//   points    one 96-byte record per point block in HBM: p[3], xi[3], lo[3], hi[3].  The blocks stand
+//   points    one 72-byte record per point block in HBM: p[3], xi[3] (doubles) and its bounds as six floats rounded
+//             INWARD (lo32 >= lo, hi32 <= hi): a trial value strictly inside them is inside the bounds and is its
+//             own clamp; only a lane whose value is not (an active bound: rare) fetches the block's exact bounds
+//             from a third array and clamps as ever -- the same bits either way, 24 bytes less per block and trial.
+//             The blocks stand
 //             in order of their number of factors (descending) and are taken 64 at a time, a
 //             wave-chunk: a lane takes a block, loads its record ONCE, forms clamp(p + a xi) in
 //             registers and evaluates the block's factors one after the other against the cameras in
@@ -23,7 +27,7 @@
 //             time was a fixed ~65 000 cycles that did not shrink with the work; three waves per SIMD do
 //             not hide thirty exposed round trips.)
 //
-// HBM bytes per value+slope trial: 32 per point variable + 20 per factor (SURVEY 8d counts 16 + 24:
+// HBM bytes per value+slope trial: 24 per point variable + 20 per factor (SURVEY 8d counts 16 + 24:
 // x and g once per variable, observation + two indices per factor), no write traffic at all.
 //
 // The full gradient, once per CG iteration, is a point-major pass like a trial (forward + adjoint; a block's
@@ -50,7 +54,21 @@
 
 namespace rdis_hip {
 
-constexpr int PT_REC = 12;   // doubles per point record: p, xi, lo, hi of the block's three variables
+constexpr int PT_REC = 6;    // doubles per point record: p, xi of the block's three variables
+constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded inward (PB), exact doubles (PE)
+// the float nearest to a bound on its inner side (never subnormal: conversions may flush those)
+__device__ __forceinline__ float inner_lo32(double lo) {
+    float f = (float)lo;
+    if ((double)f < lo) f = nextafterf(f, __builtin_inff());
+    if (fabsf(f) < 1.17549435e-38f) f = lo <= 0.0 ? 0.0f : 1.17549435e-38f;
+    return f;
+}
+__device__ __forceinline__ float inner_hi32(double hi) {
+    float f = (float)hi;
+    if ((double)f > hi) f = nextafterf(f, -__builtin_inff());
+    if (fabsf(f) < 1.17549435e-38f) f = hi >= 0.0 ? 0.0f : -1.17549435e-38f;
+    return f;
+}
 constexpr int PTM_DOUBLES_PER_SLOT = LDS_DOUBLES_PER_SLOT + 2;   // Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
 constexpr int PTM_MAX_GROUP = 16;  // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
 constexpr unsigned PTM_NO_FACTOR = 0xFFFFFFFFu;
@@ -81,7 +99,9 @@ struct PtmEnv {
     const int* sfree;         // local free index of a slot, -1 = constant (global copy; the cameras' also in SF)
     double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR, *CG;   // LDS, cameras (GC, HC: g and h of the recurrence)
     int *CGC, *CST, *CEN, *SF;   // LDS: a gradient chunk's camera; a camera's chunks [CST, CEN); local free index of a camera slot
-    double* PT;               // [npb][12] point records
+    double* PT;               // [npb][6] point records: p, xi
+    float* PB;                // [npb][6] their bounds rounded inward (lo, hi)
+    double* PE;               // [npb][6] ... and exact
     const int* cptr;          // [npc + 1] a point chunk's entries ...
     const int* pcam;          // ... their camera block (-1: none)
     const double2* pobs;      // ... their observation
@@ -183,31 +203,50 @@ struct PtmEnv {
     }
 
     // ---- a point's trial values: clamp(p + a xi) from its record (registers only) -------------------
+    // exact clamp of a block's three values that are not all strictly inside the inward-rounded bounds
+    __device__ __forceinline__ void clamp_exact(int ps, double (&x)[3]) {
+        const double2* be = reinterpret_cast<const double2*>(PE + (long long)PT_BND * ps);
+        const double2 e0 = be[0], e1 = be[1], e2 = be[2];
+        x[0] = clampd(x[0], e0.x, e1.y);
+        x[1] = clampd(x[1], e0.y, e2.x);
+        x[2] = clampd(x[2], e1.x, e2.y);
+    }
+    __device__ __forceinline__ bool inside32(int ps, const double (&x)[3]) {
+        const float2* bq = reinterpret_cast<const float2*>(PB + (long long)PT_BND * ps);
+        const float2 b0 = bq[0], b1 = bq[1], b2 = bq[2];
+        return x[0] > (double)b0.x && x[0] < (double)b1.y && x[1] > (double)b0.y && x[1] < (double)b2.x &&
+               x[2] > (double)b1.x && x[2] < (double)b2.y;
+    }
     template <int MODE>
     __device__ __forceinline__ void point_at(int ps, double a, double (&x)[3], double (&d)[3]) {
 #pragma clang fp contract(off)
         const double2* rec = reinterpret_cast<const double2*>(PT + (long long)PT_REC * ps);
-        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
-        const double p[3] = {r0.x, r0.y, r1.x}, xi[3] = {r1.y, r2.x, r2.y}, lo[3] = {r3.x, r3.y, r4.x}, hi[3] = {r4.y, r5.x, r5.y};
+        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const double p[3] = {r0.x, r0.y, r1.x}, xi[3] = {r1.y, r2.x, r2.y};
+        if constexpr (MODE == AT_START) {
+            const double* be = PE + (long long)PT_BND * ps;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            d[k] = xi[k];
-            if constexpr (MODE == AT_START) {
+            for (int k = 0; k < 3; ++k) {
+                d[k] = xi[k];
                 const int fi = sfree[9 * ncb + 3 * ps + k];
-                x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], lo[k], hi[k]) : p[k];
-            } else {
-                const double t = a * xi[k];
-                x[k] = clampd(p[k] + t, lo[k], hi[k]);
+                x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : p[k];
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = xi[k];
+                const double t = a * xi[k];
+                x[k] = p[k] + t;
+            }
+            if (!inside32(ps, x)) clamp_exact(ps, x);
         }
     }
     // ... at clamp(p), position only (the gradient pass: any workgroup's lanes, a factor each)
     __device__ __forceinline__ void point_position(int ps, double (&x)[3]) {
         const double2* rec = reinterpret_cast<const double2*>(PT + (long long)PT_REC * ps);
-        const double2 r0 = rec[0], r1 = rec[1], r3 = rec[3], r4 = rec[4], r5 = rec[5];
-        x[0] = clampd(r0.x, r3.x, r4.y);
-        x[1] = clampd(r0.y, r3.y, r5.x);
-        x[2] = clampd(r1.x, r4.x, r5.y);
+        const double2 r0 = rec[0], r1 = rec[1];
+        x[0] = r0.x; x[1] = r0.y; x[2] = r1.x;
+        if (!inside32(ps, x)) clamp_exact(ps, x);
     }
     __device__ __forceinline__ double forward(int c, double2 o, const double (&x)[3], double (&v)[12], BaFwd& t) {
         const int cb = 9 * c;
@@ -312,9 +351,12 @@ struct PtmEnv {
         my_point_vars([&](int ps, int k) {
             const int s = 9 * ncb + 3 * ps + k, fi = sfree[s], v = svid[s];
             double* rec = PT + (long long)PT_REC * ps + k;
-            if (fi >= 0) { rec[0] = xs[fi]; rec[6] = P.lo[v]; rec[9] = P.hi[v]; }
-            else { rec[0] = P.x[v]; rec[6] = -__builtin_inf(); rec[9] = __builtin_inf(); }
+            double lo = -__builtin_inf(), hi = __builtin_inf();
+            if (fi >= 0) { rec[0] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
+            else rec[0] = P.x[v];
             rec[3] = 0.0;
+            PE[(long long)PT_BND * ps + k] = lo; PE[(long long)PT_BND * ps + 3 + k] = hi;
+            PB[(long long)PT_BND * ps + k] = inner_lo32(lo); PB[(long long)PT_BND * ps + 3 + k] = inner_hi32(hi);
         });
         // the gradient pass's chunks by camera: chunk -> camera, and every camera's (contiguous) range of chunks
         for (int c = tid; c < ncb; c += nt) { CST[c] = 0; CEN[c] = 0; }
@@ -631,7 +673,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc,
                               lds + PTM_DOUBLES_PER_SLOT * sc, CG, CGC, CST, CEN, SF,
-                              L.pm_rec + (long long)PT_REC * pb0, L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_pg, L.pm_gqpos, L.pm_cgq + (long long)CGQ_REC * q0,
+                              L.pm_rec + (long long)PT_REC * pb0, L.pm_bnd + (long long)PT_BND * pb0, L.pm_bex + (long long)PT_BND * pb0, L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_pg, L.pm_gqpos, L.pm_cgq + (long long)CGQ_REC * q0,
                               ws + 2ll * n, ws + 3ll * n, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
