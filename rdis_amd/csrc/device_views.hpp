@@ -86,7 +86,7 @@ struct PlanView {
     double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
     float* pm_bnd;        // [blocks][6] their bounds lo, hi as floats rounded inward ...
     double* pm_bex;       // [blocks][6] ... and exact
-    const int* pm_cam;    // [entries] camera block (number within the component), -1 = no factor ...
+    const short* pm_cam;  // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
     double* pm_pg;        // [entries][3] the factor's three point partials (the one-pass gradient of workgroups that share a component; zeros where no factor)
     const int* pm_gqpos;  // [entries] the factor's position in its component's camera-grouped order (ls_gperm)

@@ -284,7 +284,7 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
-        v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<int>(); v.pm_obs = pm_obs.as<double2>();
+        v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_pg = pm_pg.as<double>(); v.pm_cgq = pm_cgq.as<double>(); v.pm_gqpos = pm_gqpos.as<int>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
@@ -1506,7 +1506,7 @@ int prepare_partition(rdis_hip_plan* L) {
         if (!rc) rc = plan_alloc(L, L->pm_bnd, (size_t)L->pm_blocks * PT_BND * sizeof(float));
         if (!rc) rc = plan_alloc(L, L->pm_bex, (size_t)L->pm_blocks * PT_BND * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->ptm_cgg, (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 9 * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(int));
+        if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(short));
         if (!rc) rc = plan_alloc(L, L->pm_obs, (size_t)L->pm_entries * sizeof(double2));
         if (!rc) rc = plan_alloc(L, L->pm_pg, (size_t)std::max<int64_t>(L->pm_entries, 1) * 3 * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->pm_cgq, gq * CGQ_REC * sizeof(double));
@@ -1520,7 +1520,7 @@ int prepare_partition(rdis_hip_plan* L) {
         HIPCHK(c, hipMemsetAsync(L->pm_gqpos.p, 0, (size_t)std::max<int64_t>(L->pm_entries, 1) * sizeof(int), c->stream));
         const PlanView V = L->view();
         ptm_gather_kernel<<<grid_for(c, L->pm_entries, 256), 256, 0, c->stream>>>((int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
-                                                                                 L->pm_cam.as<int>(), L->pm_obs.as<double2>());
+                                                                                 L->pm_cam.as<short>(), L->pm_obs.as<double2>());
         HIPCHK(c, hipGetLastError());
         ptm_gather_gradient_kernel<<<(int)std::min<int64_t>(std::max<int64_t>(L->ncomp, 1), 2048), 256, 0, c->stream>>>(V, L->lds_ints.as<int>() + L->off_pm_eof, L->pm_gqw.as<unsigned>(),
                                                                                                     L->pm_gqe.as<int>(), L->pm_gqobs.as<double2>(), L->pm_gqpos.as<int>());

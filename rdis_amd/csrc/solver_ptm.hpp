@@ -19,7 +19,7 @@
 //             registers and evaluates the block's factors one after the other against the cameras in
 //             LDS.  The trial point of a point variable is never stored.
 //   factors   slot-major per wave-chunk: entry cptr[chunk] + 64 t + lane is the t-th listed factor of the
-//             lane's block (camera block 4 B + observation 16 B; camera -1 = the block has fewer
+//             lane's block (camera block 2 B + observation 16 B; camera -1 = the block has fewer
 //             factors).  A wave's loads of a slot are 64 neighbours, and their addresses depend on
 //             nothing the wave has loaded before: slot t + 1 is fetched while slot t is evaluated.
 //             (Round 3, first form: a CSR per point -- point -> range -> camera, observation, every factor
@@ -27,7 +27,7 @@
 //             time was a fixed ~65 000 cycles that did not shrink with the work; three waves per SIMD do
 //             not hide thirty exposed round trips.)
 //
-// HBM bytes per value+slope trial: 24 per point variable + 20 per factor (SURVEY 8d counts 16 + 24:
+// HBM bytes per value+slope trial: 24 per point variable + 18 per factor (SURVEY 8d counts 16 + 24:
 // x and g once per variable, observation + two indices per factor), no write traffic at all.
 //
 // The full gradient, once per CG iteration, is a point-major pass like a trial (forward + adjoint; a block's
@@ -103,7 +103,7 @@ struct PtmEnv {
     float* PB;                // [npb][6] their bounds rounded inward (lo, hi)
     double* PE;               // [npb][6] ... and exact
     const int* cptr;          // [npc + 1] a point chunk's entries ...
-    const int* pcam;          // ... their camera block (-1: none)
+    const short* pcam;        // ... their camera block (-1: none; at most 4095 camera blocks: two bytes a factor and trial)
     const double2* pobs;      // ... their observation
     double* pg;               // ... the three point partials of the last gradient pass (gradient_camera_order)
     const int* gqpos;         // ... the factor's position in the camera-grouped order
@@ -749,10 +749,10 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
 // (-1: the slot is empty, the lane's block has fewer factors than its chunk's first)
 __global__ void __launch_bounds__(256)
 ptm_gather_kernel(int n, const int* __restrict__ jg, const unsigned* __restrict__ fidx, const double2* __restrict__ fobs,
-                  int* __restrict__ pcam, double2* __restrict__ pobs) {
+                  short* __restrict__ pcam, double2* __restrict__ pobs) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int j = jg[i];
-        pcam[i] = j >= 0 ? (int)(fidx[j] & 0xFFFu) : -1;
+        pcam[i] = j >= 0 ? (short)(fidx[j] & 0xFFFu) : (short)-1;
         pobs[i] = j >= 0 ? fobs[j] : make_double2(0.0, 0.0);
     }
 }
