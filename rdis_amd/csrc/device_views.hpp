@@ -86,6 +86,7 @@ struct PlanView {
     double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
     float* pm_bnd;        // [blocks][6] their bounds lo, hi as floats rounded inward ...
     double* pm_bex;       // [blocks][6] ... and exact
+    int pm_grad_form;     // a lone workgroup's full gradient: 0 = two passes (point-major, then camera order), 1 = one pass in camera order
     const short* pm_cam;  // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
     double* pm_pg;        // [entries][3] the factor's three point partials (the one-pass gradient of workgroups that share a component; zeros where no factor)

@@ -223,6 +223,7 @@ struct rdis_hip_plan {
     int rest_ptm = 0;                 // the rest_ptm entries before them on the point-major streaming solver (solver_ptm.hpp)
     int ptm_stream = 1;               // option "ptm_stream": 0 = never, 1 = components too large for the LDS, 2 = every component
     int ptm_threads = 0;              // option "ptm_threads": its workgroup size, 0 = auto
+    int ptm_gradient = 0;             // option "ptm_gradient": a lone workgroup's full gradient, 0 = two passes, 1 = one pass in camera order
     int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     ivec h_pm_jg;
@@ -284,6 +285,7 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
+        v.pm_grad_form = ptm_gradient;
         v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_pg = pm_pg.as<double>(); v.pm_cgq = pm_cgq.as<double>(); v.pm_gqpos = pm_gqpos.as<int>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
         v.timing = prob->coop_timing.as<long long>();
@@ -1050,6 +1052,10 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "ptm_group") {
         if (value < 0 || value > PTM_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16)");
         L->ptm_group = (int)value;
+    } else if (n == "ptm_gradient") {
+        if (value < 0 || value > 1) return fail(c, RDIS_HIP_EINVAL, "ptm_gradient must be 0 (two passes) or 1 (one pass in camera order)");
+        L->ptm_gradient = (int)value;
+        return 0;   // (no table depends on it)
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
         L->ptm_threads = (int)value;

@@ -388,7 +388,9 @@ struct PtmEnv {
     // (One workgroup per component; workgroups that share a component use gradient_camera_order below.  1000 components of
     // ladybug's size: 175.5 ms a launch with this form, 183.6 with the other.)
     __device__ void gradient_to_xi() {
-        if constexpr (GROUP) gradient_camera_order(); else gradient_two_pass();
+        if constexpr (GROUP) gradient_camera_order();
+        else if (L.pm_grad_form != 0) gradient_camera_order();
+        else gradient_two_pass();
     }
     __device__ void gradient_two_pass() {
         const long long tg0 = clock();
@@ -502,10 +504,17 @@ struct PtmEnv {
         const int lane = tid & 63;
         const int gw = (GROUP ? r * nwaves : 0) + (tid >> 6), gwn = (GROUP ? K : 1) * nwaves;
         const int ch0 = (int)((long long)gw * nchunk / gwn), ch1 = (int)((long long)(gw + 1) * nchunk / gwn);
-        unsigned wn = PTM_NO_FACTOR;
+        // two chunks ahead: the slot word; one chunk ahead: entry, observation and the point's position (its address
+        // comes from the slot word) -- a factor's gathers are in flight while the chunk before it is evaluated
+        unsigned wn = PTM_NO_FACTOR, wnn = PTM_NO_FACTOR;
         int en = 0;
         double2 on = make_double2(0.0, 0.0);
-        if (ch0 < ch1) { wn = gqw[64 * ch0 + lane]; en = gqe[64 * ch0 + lane]; on = gqobs[64 * ch0 + lane]; }
+        double xn[3] = {0.0, 0.0, 0.0};
+        if (ch0 < ch1) {
+            wn = gqw[64 * ch0 + lane]; en = gqe[64 * ch0 + lane]; on = gqobs[64 * ch0 + lane];
+            if (ch0 + 1 < ch1) wnn = gqw[64 * (ch0 + 1) + lane];
+            if (wn != PTM_NO_FACTOR) point_position((int)(wn >> 12), xn);
+        }
         double acc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = 0.0;
@@ -513,11 +522,15 @@ struct PtmEnv {
             const unsigned w = wn;
             const int e = en;
             const double2 o = on;
-            if (ch + 1 < ch1) { wn = gqw[64 * (ch + 1) + lane]; en = gqe[64 * (ch + 1) + lane]; on = gqobs[64 * (ch + 1) + lane]; }
+            const double x[3] = {xn[0], xn[1], xn[2]};
+            if (ch + 1 < ch1) {
+                wn = wnn; en = gqe[64 * (ch + 1) + lane]; on = gqobs[64 * (ch + 1) + lane];
+                if (ch + 2 < ch1) wnn = gqw[64 * (ch + 2) + lane];
+                if (wn != PTM_NO_FACTOR) point_position((int)(wn >> 12), xn);
+            }
             if (w != PTM_NO_FACTOR) {
-                double x[3], v[12], gq[12];
+                double v[12], gq[12];
                 BaFwd t;
-                point_position((int)(w >> 12), x);
                 forward((int)(w & 0xFFFu), o, x, v, t);
                 ba_adjoint(t, v, t.res0, t.res1, gq);
                 double* dst = pg + 3ll * e;
