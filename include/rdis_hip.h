@@ -240,6 +240,21 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * resident; for tests),
  * "overlap_batch" (default 1: the batched launch of a plan runs on a second stream, concurrently
  * with its cooperative launches when those take at most half of the compute units),
+ * "lds_resident" (bundle adjustment, default 1: a component of the batched launch whose variables --
+ * free ones and the constants its factors read -- fit a compute unit's LDS keeps them there as slots,
+ * solver_lds.hpp; 0 = never: such components run on the plain batch solver, bit-identical where the
+ * slots are the free variables), "lds_threads" / "lds_rot" / "lds_camera_sums" (its workgroup size,
+ * 0 = auto; rotation records in it, -1 = auto; 0 = camera partials through memory like the plain
+ * solver, for bit-for-bit comparisons),
+ * "ptm_stream" (default 1: components too large for the LDS whose CAMERA blocks fit it stream their
+ * point blocks from HBM once per trial point, solver_ptm.hpp; 0 = never, 2 = every component whose
+ * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups
+ * that share one such component when the launch has fewer components than compute units: 0 = auto,
+ * 1 = never, k <= 16 = k), "ptm_gradient" (a lone workgroup's full gradient: 0 = default, two passes --
+ * point-major, then camera order; 1 = one pass in camera order, the form shared components use),
+ * "emulate_stale_cache" (default 0; 1 = the reference's factor cache, Variable.cpp:66-76 and
+ * Factor.h:228-234 -- a factor keeps its value while its variables have moved by less than 1e-12 since
+ * it was computed -- emulated in the LDS-resident batch solver; refused where other solvers would run),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);
