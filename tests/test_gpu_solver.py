@@ -473,6 +473,37 @@ def test_plans_survive_a_move_of_the_exchange_state(gctx):
     assert r2.fret[0] == r1.fret[0] and np.array_equal(r2.x, r1.x) and r2.nfeval[0] == r1.nfeval[0]
 
 
+def test_start_points_of_resident_plans_are_taken_when_the_call_returns(gctx):
+    """rdis_hip_plan_set_start on a resident plan copies the caller's values through a pinned staging buffer of
+    the problem and does not wait for the stream: the caller may overwrite its array the moment the call returns,
+    and the start points of two plans set back to back (one staging buffer, reused) do not mix"""
+    pp = P.load_bal(ncams=5, npts=30)
+    g = capi.Problem(gctx, pp)
+    cams, pts = P.ba_alternation_plans(pp)
+    pa, pb = capi.Plan(g, *cams), capi.Plan(g, *pts)
+    xa, xb = np.ascontiguousarray(pp.x0[cams[1]]), np.ascontiguousarray(pp.x0[pts[1]])
+
+    def solve(plan, x):
+        g.set_x(pp.x0)
+        plan.set_start(x)
+        plan.solve(5, 3e-8)
+        return plan.fetch()
+    ra, rb = solve(pa, xa), solve(pb, xb)
+    # the same starts from scratch arrays that are overwritten as soon as set_start returns, both plans' starts
+    # set before either is solved (the second copy follows the first through the same staging buffer)
+    g.set_x(pp.x0)
+    ta, tb = xa.copy(), xb.copy()
+    pa.set_start(ta); ta[:] = np.nan
+    pb.set_start(tb); tb[:] = np.nan
+    pa.solve(5, 3e-8)
+    r1 = pa.fetch()
+    g.set_x(pp.x0)
+    pb.solve(5, 3e-8)
+    r2 = pb.fetch()
+    assert np.array_equal(r1.fret, ra.fret) and np.array_equal(r1.x, ra.x)
+    assert np.array_equal(r2.fret, rb.fret) and np.array_equal(r2.x, rb.x)
+
+
 def test_rdis_separator_block_on_full_ladybug(gctx):
     """the call RDIS spends its time in on ladybug: the separator block -- 46 cameras and
     one point, 417 free variables -- against every factor of those cameras (30285), all other points
@@ -1212,6 +1243,13 @@ def test_point_major_streaming_solver_alone_and_in_groups(gctx):
     r1 = run({**base, "ptm_threads": 256, "ptm_group": 4})[0]
     r2 = run({**base, "ptm_threads": 256, "ptm_group": 4})[0]
     assert np.array_equal(r1.fret, r2.fret) and np.array_equal(r1.x, r2.x) and np.array_equal(r1.nfeval, r2.nfeval)
+
+    # a lone workgroup's full gradient in its two forms (two passes / one pass in camera order, option ptm_gradient):
+    # the same sums in the same orders, hence the same bits
+    ra = run({**base, "ptm_threads": 768, "ptm_group": 1, "ptm_gradient": 0})[0]
+    rb = run({**base, "ptm_threads": 768, "ptm_group": 1, "ptm_gradient": 1})[0]
+    assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(ra.nfeval, rb.nfeval)
+    assert np.array_equal(ra.fret, ref[0].fret)
 
     # constants among the slots: ladybug's camera components (points fixed) and point components (cameras
     # fixed: rotation records only read, a single point block -- most workgroups of a group own nothing)
