@@ -20,7 +20,9 @@ public:
     static constexpr size_t MIN_CACHED = 64u << 10;
     static constexpr size_t CACHE_LIMIT = 256u << 20;
 
-    static HostBlocks& get() { static HostBlocks b; return b; }
+    // (never destroyed: a plan dropped by a static destructor of the caller's may still hand its blocks back;
+    // the process's exit returns the memory)
+    static HostBlocks& get() { static HostBlocks* b = new HostBlocks; return *b; }
 
     // the size class a request is rounded up to: 2^k * {1, 1.25, 1.5, 1.75}
     static size_t size_class(size_t bytes) {
@@ -60,7 +62,6 @@ public:
         }
         std::free(p);
     }
-    ~HostBlocks() { for (auto& b : free_) std::free(b.p); }
 
 private:
     struct Block { void* p; size_t bytes; };
