@@ -290,7 +290,7 @@ def test_unchanged_caller_one_call_at_a_time(harness, bal_path):
     """What an unmodified RDISOptimizer would do with the drop-in: 80 calls over (5 cameras + 1 point) and 651
     calls over single points of ladybug 5/30 (the reference's own run), one optimize() at a
     time.  The plan cache makes the sequence faster and changes no bit.  Measured on the GPU box (host: EPYC
-    9575F): 120 ms with the cache, 160 ms without, 87 ms for the CPU oracle on one core making the same calls --
+    9575F): 99-107 ms with the cache, 120-127 ms without, 87-108 ms for the CPU oracle on one core making the same calls --
     a 3-variable call is 0.07 ms on that CPU, less than one kernel launch plus the latency chain of its ~70
     dependent evaluations, so call-at-a-time cannot win on the tiny calls; the 80 large calls do (0.5 ms against
     1 ms each).  The same work as sibling batches (test_level_driver_ladybug_5_30) takes 20 ms."""
