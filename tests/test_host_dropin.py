@@ -321,7 +321,7 @@ def test_unchanged_caller_one_call_at_a_time(harness, bal_path):
     cpu_ms = (time.perf_counter() - t0) * 1e3
     print("731 optimize() calls one at a time: %.1f ms with the plan cache, %.1f ms without; CPU oracle on one core %.1f ms; "
           "function value %.6f (oracle's own trajectory: %.6f)" % (o1[0], o0[0], cpu_ms, o1[2], orc.eval()))
-    assert o1[0] < o0[0] and o1[0] < 2.5 * cpu_ms
+    assert o1[0] < o0[0] and o1[0] < 1.5 * cpu_ms          # (on a par with the CPU box by box: 0.9 ... 1.25 x)
 
 
 @pytest.mark.gpu
