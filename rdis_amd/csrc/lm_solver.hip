@@ -51,6 +51,8 @@ struct Dev {            // everything the kernels need, by value
     double *Zt;                              // [Kp][Mp]   k-major (dense Schur product)
     double *Zc;                              // [nf][3][9] a factor's Z block, column by column (block-sparse Schur product)
     double *Spart, *S, *rhs, *dc, *dp;       // [SK][Mp*Mp], [Mp*Mp], [Mp], [Mp], [npa*3]
+    double *Ld;                              // [Mp/32][32][32] the factored diagonal blocks (S keeps the unfactored ones: every
+                                             // workgroup of a k_panel launch reads its panel's, one writes the factor -- not over it)
     double *psave;                           // accepted point: [9*nca + 3*npa] by block slot
     double *part, *sc;                       // block partials [4096*4], scalars [16]
 };
@@ -466,7 +468,10 @@ __global__ void __launch_bounds__(64 * RHS_WAVES) k_rhs(Dev D) {
 // place, right-looking, two launches per panel:
 //   k_panel  every workgroup factors the 32 x 32 diagonal block inside one wave (a row per lane,
 //            in registers, columns broadcast with v_readlane: no LDS round trip and no barrier in
-//            the 32 dependent steps), then its rows below take X = A L^-T, one lane per row;
+//            the 32 dependent steps), then its rows below take X = A L^-T, one lane per row (measured and dropped:
+//            the rows moved row-wise through LDS, 32 lanes a row, and loaded while the block is factored --
+//            17.9 against 15.1 us a launch: the in-wave factorisation, not the rows' traffic, is what a launch costs);
+//            the factored block goes to Ld, not over S's: the other workgroups of the launch still read that;
 //   k_trail  trailing matrix -= X X^T on the matrix cores.
 // The right-hand side rides along as one more row (kept in dc): when the last panel is done it
 // holds z = L^-1 rhs, so only the backward substitution L^T dc = z is left for k_trsv.
@@ -511,7 +516,7 @@ __global__ void __launch_bounds__(256) k_panel(Dev D, int kb) {
             }
             rd[i] = 1.0 / dii;
             if (blockIdx.x == 0) {
-                double* dst = D.S + (long long)(kb + i) * ld + kb;
+                double* dst = D.Ld + 32ll * kb + 32 * i;   // (block kb / 32, row i)
 #pragma unroll
                 for (int c = 0; c < 32; ++c) if (c <= i) dst[c] = r[c];
                 if (!ok) D.sc[8] = 1.0;
@@ -573,11 +578,77 @@ __global__ void __launch_bounds__(64) k_trail(Dev D, int kb) {
         o[16ll * ld + 16] -= c11[r];
     }
 }
-// L^T dc = z (z = L^-1 rhs is already in dc, see above), one workgroup, left-looking by blocks of 32
+// L^T dc = z (z = L^-1 rhs is already in dc, see above), one workgroup, blocks of 32 from the bottom.  Right-looking:
+// z lives in LDS; per block one wave solves the 32 x 32 triangle (values broadcast with v_readlane) and everybody
+// then takes the block's contribution off the entries above it -- thread j holds rows kb .. kb + 31 of column j,
+// loaded BEFORE the triangle is solved (they do not depend on it), so a block costs the triangle, two barriers and
+// 32 multiply-adds instead of a chain of dependent round trips to the L2; the diagonal element is selected first and
+// inverted once (the select-after-divide form cost a division per column).  ladybug's 448 unknowns: 82 -> 51 us.
+// (Measured and dropped: a pass over the whole factor first, to bring it into this unit's caches: +5 us, no gain.)
+constexpr int TRSV_MAX = 4096;    // unknowns this form keeps in LDS
+constexpr int TRSV_THREADS = 512;
+__global__ void __launch_bounds__(TRSV_THREADS) k_trsv(Dev D) {
+    __shared__ double zs[TRSV_MAX];
+    __shared__ double xb[32];
+    const int n = D.Mp, ld = D.Mp, tid = threadIdx.x, i = tid & 31;
+    const double* S = D.S;
+    if (D.sc[8] != 0.0) return;
+    for (int r = tid; r < n; r += TRSV_THREADS) zs[r] = D.dc[r];
+    __syncthreads();
+    double col[32];   // wave 0: this lane's column of the diagonal block -- the NEXT block's is loaded while this one is solved
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) col[c] = c >= i ? D.Ld[32ll * (n - 32) + 32 * c + i] : 0.0;
+    }
+    for (int kb = n - 32; kb >= 0; kb -= 32) {
+        double a[32], coln[32];
+        if (tid < kb) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) a[c] = S[(long long)(kb + c) * ld + tid];
+        }
+        if (tid < 64) {
+            if (kb >= 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) coln[c] = c >= i ? D.Ld[32ll * (kb - 32) + 32 * c + i] : 0.0;
+            }
+            double zi = zs[kb + i], dii = 1.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c == i) dii = col[c];   // (select, then ONE division: not one per column)
+            const double dinv = 1.0 / dii;
+#pragma unroll
+            for (int c = 31; c >= 0; --c) {
+                const double xc = bcast_lane(zi * dinv, c);
+                if (i == c) zi = xc;
+                else if (i < c) zi -= col[c] * xc;
+            }
+            if (tid < 32) { zs[kb + i] = zi; xb[i] = zi; }
+            if (kb >= 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) col[c] = coln[c];
+            }
+        }
+        __syncthreads();
+        if (tid < kb) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc += a[c] * xb[c];
+            zs[tid] -= acc;
+        }
+        for (int j = tid + TRSV_THREADS; j < kb; j += TRSV_THREADS) {   // (more unknowns than threads)
+            double acc = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) acc += S[(long long)(kb + c) * ld + j] * xb[c];
+            zs[j] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int r = tid; r < n; r += TRSV_THREADS) D.dc[r] = zs[r];
+}
+// The same solve for systems beyond TRSV_MAX unknowns, in place in global memory: one workgroup, left-looking by blocks of 32
 // from the bottom: the 32 x 32 lane grid first sums what the rows already solved contribute to the
 // block (lane column i, row group g; S is read once, coalesced), then one wave finishes the sums
 // and solves the 32 x 32 triangle (values broadcast with v_readlane).
-__global__ void __launch_bounds__(1024) k_trsv(Dev D) {
+__global__ void __launch_bounds__(1024) k_trsv_left(Dev D) {
     __shared__ double red[32][33];
     const int n = D.Mp, ld = D.Mp, tid = threadIdx.x, i = tid & 31, g = tid >> 5;
     const double* S = D.S;
@@ -587,7 +658,7 @@ __global__ void __launch_bounds__(1024) k_trsv(Dev D) {
         double col[32];   // wave 0: this lane's column of the diagonal block, in flight during the sums
         if (tid < 64) {
 #pragma unroll
-            for (int c = 0; c < 32; ++c) col[c] = c >= i ? S[(long long)(kb + c) * ld + kb + i] : 0.0;
+            for (int c = 0; c < 32; ++c) col[c] = c >= i ? D.Ld[32ll * kb + 32 * c + i] : 0.0;
         }
         double acc = 0.0;
         for (int r = kb + 32 + g; r < n; r += 32) acc += S[(long long)r * ld + kb + i] * z[r];
@@ -597,9 +668,10 @@ __global__ void __launch_bounds__(1024) k_trsv(Dev D) {
             double sum = 0.0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) sum += red[q][i];
-            double zi = z[kb + i] - sum, dinv = 1.0;
+            double zi = z[kb + i] - sum, dii = 1.0;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) if (c == i) dinv = 1.0 / col[c];
+            for (int c = 0; c < 32; ++c) if (c == i) dii = col[c];
+            const double dinv = 1.0 / dii;
 #pragma unroll
             for (int c = 31; c >= 0; --c) {
                 const double xc = bcast_lane(zi * dinv, c);
@@ -838,7 +910,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     // Every device buffer of the solve is a slice of one workspace the caller keeps between solves
     // (some thirty allocations and releases per call otherwise: 2 ms on ladybug).
     Buf b_lf, b_fci, b_fpi, b_free, b_cptr, b_clist, b_pptr, b_plist, b_cid, b_pid, b_pab, b_pptr2, b_pja, b_pjb;
-    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Zc, Spart, S, rhs, dc, dp, psave, part, sc;
+    Buf Jc, Jp, e, U, bc, V, bp, Lp, yp, T, Zt, Zc, Spart, S, Ld, rhs, dc, dp, psave, part, sc;
     const size_t MM = (size_t)D.Mp * D.Mp;
     {
         const size_t n1c = (size_t)std::max(nca, 1), n1p = (size_t)std::max(npa, 1);
@@ -849,7 +921,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
             {&b_pab, pair_ab.size() * 4}, {&b_pptr2, pair_ptr.size() * 4}, {&b_pja, pair_ja.size() * 4}, {&b_pjb, pair_jb.size() * 4},
             {&Jc, (size_t)nf * 72 * D.R}, {&Jp, (size_t)nf * 24 * D.R}, {&e, (size_t)nf * 8 * D.R}, {&U, n1c * 81 * 8},
             {&bc, (size_t)D.Mp * 8}, {&V, n1p * 48}, {&bp, n1p * 24}, {&Lp, n1p * 48}, {&yp, (size_t)D.Kp * 8},
-            {&T, (size_t)nf * 24 * D.R}, {&Zt, D.sparse ? 8 : (size_t)D.Kp * D.Mp * 8}, {&Zc, D.sparse ? (size_t)nf * 27 * 8 : 8}, {&Spart, D.sparse ? 8 : MM * 8 * (size_t)D.SK}, {&S, MM * 8},
+            {&T, (size_t)nf * 24 * D.R}, {&Zt, D.sparse ? 8 : (size_t)D.Kp * D.Mp * 8}, {&Zc, D.sparse ? (size_t)nf * 27 * 8 : 8}, {&Spart, D.sparse ? 8 : MM * 8 * (size_t)D.SK}, {&S, MM * 8}, {&Ld, (size_t)D.Mp * 32 * 8},
             {&rhs, (size_t)D.Mp * 8}, {&dc, (size_t)D.Mp * 8}, {&dp, (size_t)D.Kp * 8},
             {&psave, (size_t)(9 * nca + 3 * npa + 1) * 8}, {&part, 4096 * 8}, {&sc, 16 * 8}};
         size_t total = 0;
@@ -875,7 +947,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     D.pair_ab = b_pab.as<int>(); D.pair_ptr = b_pptr2.as<int>(); D.pair_ja = b_pja.as<int>(); D.pair_jb = b_pjb.as<int>();
     D.Jc = Jc.as<double>(); D.Jp = Jp.as<double>(); D.e = e.as<double>(); D.U = U.as<double>(); D.bc = bc.as<double>();
     D.V = V.as<double>(); D.bp = bp.as<double>(); D.Lp = Lp.as<double>(); D.yp = yp.as<double>(); D.T = T.as<double>();
-    D.Zt = Zt.as<double>(); D.Zc = Zc.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.rhs = rhs.as<double>();
+    D.Zt = Zt.as<double>(); D.Zc = Zc.as<double>(); D.Spart = Spart.as<double>(); D.S = S.as<double>(); D.Ld = Ld.as<double>(); D.rhs = rhs.as<double>();
     D.dc = dc.as<double>(); D.dp = dp.as<double>(); D.psave = psave.as<double>(); D.part = part.as<double>(); D.sc = sc.as<double>();
     LM_CHK(hipMemsetAsync(D.sc, 0, 16 * 8, stream));                      // (the workspace is reused: k_apply's ticket starts at zero)
     if (!D.sparse) LM_CHK(hipMemsetAsync(D.Zt, 0, (size_t)D.Kp * D.Mp * 8, stream));   // the block pattern of Z is fixed: zero once
@@ -933,7 +1005,8 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                     k_trail<<<ntr * ntr + ntr, 64, 0, stream>>>(D, kb);
                 }
             }
-            k_trsv<<<1, 1024, 0, stream>>>(D);
+            if (D.Mp <= TRSV_MAX) k_trsv<<<1, TRSV_THREADS, 0, stream>>>(D);
+            else k_trsv_left<<<1, 1024, 0, stream>>>(D);
         }
         if (npa) k_back<<<(npa + 15) / 16, 256, 0, stream>>>(D);
         k_apply<<<gapply, 1024, 0, stream>>>(D, 0);
