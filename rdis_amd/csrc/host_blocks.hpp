@@ -49,6 +49,7 @@ public:
         void* p = nullptr;   // page-aligned, like the mappings the C library would hand out at this size
         return posix_memalign(&p, 4096, cls) == 0 ? p : nullptr;
     }
+    size_t held_bytes() { std::lock_guard<std::mutex> g(m_); return held_; }   // what the cache holds right now
     void give(void* p, size_t bytes) {
         if (!p) return;
         if (bytes >= MIN_CACHED) {

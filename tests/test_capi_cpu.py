@@ -68,3 +68,14 @@ def test_inline_asm_granule_loads_are_waited_for_before_use():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), obj], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 touched before" in out.stdout and " 0 reach a branch first" in out.stdout, out.stdout
+
+
+def test_host_block_cache(tmp_path):
+    """rdis_amd/csrc/host_blocks.hpp -- where a plan's host index arrays live (no HIP in it): size classes, a block given
+    back is the block taken next, page alignment, the cache's byte limit, vectors over it (tests/cpp/host_blocks_test.cpp)"""
+    import subprocess
+    exe = str(tmp_path / "host_blocks_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "host_blocks_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
