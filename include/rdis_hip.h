@@ -250,8 +250,7 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * point blocks from HBM once per trial point, solver_ptm.hpp; 0 = never, 2 = every component whose
  * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups
  * that share one such component when the launch has fewer components than compute units: 0 = auto,
- * 1 = never, k <= 16 = k), "ptm_gradient" (a lone workgroup's full gradient: 0 = default, two passes --
- * point-major, then camera order; 1 = one pass in camera order, the form shared components use),
+ * 1 = never, k <= 16 = k),
  * "emulate_stale_cache" (default 0; 1 = the reference's factor cache, Variable.cpp:66-76 and
  * Factor.h:228-234 -- a factor keeps its value while its variables have moved by less than 1e-12 since
  * it was computed -- emulated in the LDS-resident batch solver; refused where other solvers would run),

@@ -86,16 +86,13 @@ struct PlanView {
     double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
     float* pm_bnd;        // [blocks][6] their bounds lo, hi as floats rounded inward ...
     double* pm_bex;       // [blocks][6] ... and exact
-    int pm_grad_form;     // a lone workgroup's full gradient: 0 = two passes (point-major, then camera order), 1 = one pass in camera order
     const short* pm_cam;  // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
-    double* pm_pg;        // [entries][3] the factor's three point partials (the one-pass gradient of workgroups that share a component; zeros where no factor)
-    const int* pm_gqpos;  // [entries] the factor's position in its component's camera-grouped order (ls_gperm)
-    double* pm_cgq;       // [positions of all components' orders][10] the factor's nine camera partials, as pass 1 of the last gradient left them (zeros where no factor)
-    // ... and in the order of the gradient pass (position q = 64 * chunk + lane of ls_gperm):
-    const unsigned* pm_gqw;   // the factor's slot word (camera block | point block << 12), 0xFFFFFFFF = no factor
-    const int* pm_gqe;        // its point-major entry (pm_cgp)
-    const double2* pm_gqobs;  // its observation
+    // the gradient's round lists (solver_ptm.hpp: gradient_to_xi), for workgroup w = component * K + rank of the launch:
+    const unsigned short* pm_rounds;   // per round ptm_round_stride(ncb, threads) 16-bit words: camera segment starts [ncb + 1],
+                                       // then the staging indices (wave * 64 + lane) that hold a factor, grouped by camera
+    const long long* pm_rd_off;        // [ncomp * K] a workgroup's first word in pm_rounds ...
+    const int* pm_rd_n;                // ... and its number of rounds
     int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...
     double* st_val;       // ... and that value; null unless the plan's option emulate_stale_cache is set
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null

@@ -1,0 +1,49 @@
+// ptm_api.hpp -- what the host side (rdis_hip.hip) needs of the point-major streaming solver (solver_ptm.hpp):
+// layout constants, the LDS a launch asks for, and the launches.  The kernels themselves are compiled in a
+// translation unit of their own (ptm_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "device_views.hpp"
+
+namespace rdis_hip {
+
+struct SmallCoopState;
+
+constexpr int PT_REC = 6;    // doubles per point record: p, xi of the block's three variables
+constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded inward (PB), exact doubles (PE)
+#ifndef RDIS_PTM_BLK
+#define RDIS_PTM_BLK 2
+#endif
+constexpr int PTM_BLK = RDIS_PTM_BLK;  // slots of a point block asked for (and evaluated) together; pm_cam / pm_obs are padded by 64 (PTM_BLK - 1) entries
+constexpr int PTM_CAM_VECTORS = 7;     // LDS vectors over the camera slots: Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
+constexpr int PTM_MAX_GROUP = 16;      // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
+constexpr int PTM_MAX_CAMERAS = 4095;  // camera blocks per component (twelve bits of a factor's slot word; two bytes in the trial stream)
+
+// A round list's length in 16-bit words: the segment starts of the component's ncb cameras (ncb + 1 of them) and
+// at most `threads` staging indices, rounded up to whole 32-bit words.
+__host__ __device__ inline int ptm_round_stride(int ncb, int threads) { return (ncb + 1 + threads + 1) & ~1; }
+
+// LDS of a workgroup: [7 vectors of 9 ncb_cap camera slots][7 ncb_cap rotation records][threads x 9 staged camera
+// partials][two round lists][9 ncb_cap free indices (int)]
+__host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads) {
+    return (size_t)ncb * 9 * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) +
+           (size_t)threads * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb, threads) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
+}
+
+struct PtmGroupArgs {
+    SmallCoopState* st;   // one exchange state per group of the launch
+    double* xch;          // [groups][2][K][9 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth)
+    int K, ngroups;       // workgroups per component, components of the launch
+    int poll_delay;
+};
+
+// launches (ptm_kernels.hip); rot = ROT_PER_FACTOR / ROT_RECORDS / ROT_CAMFIX, threads = 256 / 512 / 768
+hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t stream, const ProblemView& P, const PlanView& V,
+                      int maxiters, double ftol, int ncb_cap);
+const void* ptmg_kernel_fn(int rot, int threads);   // cgd_ptmg_kernel<threads, rot> (a cooperative launch by the caller)
+hipError_t ptm_gather_launch(int grid, hipStream_t stream, int n, const int* jg, const unsigned* fidx, const double2* fobs,
+                             short* pcam, double2* pobs);
+
+}  // namespace rdis_hip

@@ -22,7 +22,7 @@
 #include "eval_kernels.hpp"
 #include "solver_coop.hpp"
 #include "solver_lds.hpp"
-#include "solver_ptm.hpp"
+#include "ptm_api.hpp"
 #include "solver_pipe.hpp"
 #include "solver_quad.hpp"
 #include "solver_stream.hpp"
@@ -223,18 +223,20 @@ struct rdis_hip_plan {
     int rest_ptm = 0;                 // the rest_ptm entries before them on the point-major streaming solver (solver_ptm.hpp)
     int ptm_stream = 1;               // option "ptm_stream": 0 = never, 1 = components too large for the LDS, 2 = every component
     int ptm_threads = 0;              // option "ptm_threads": its workgroup size, 0 = auto
-    int ptm_gradient = 0;             // option "ptm_gradient": a lone workgroup's full gradient, 0 = two passes, 1 = one pass in camera order
-    int ptm_ncb_cap = 0, ptm_chunk_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
+    int ptm_ncb_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     ivec h_pm_jg;
-    DevBuf pm_rec, pm_bnd, pm_bex, pm_cam, pm_obs, pm_pg, pm_cgq, pm_gqpos, pm_gqw, pm_gqe, pm_gqobs;
+    DevBuf pm_rec, pm_bnd, pm_bex, pm_cam, pm_obs;
+    // the gradient's round lists (solver_ptm.hpp), built for one workgroup size and group size at a time (ptm_build_rounds)
+    DevBuf pm_rounds, pm_rd_off, pm_rd_n;
+    int rounds_threads = 0, rounds_K = 0;
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
     int ptm_last_group = 1;           // what the last solve used (rdis_hip_plan_debug_counters has no slot for it: get_option)
     int64_t ls_total_chunks = 0;      // gradient chunks of all slot tables
     int64_t ptm_min_points = 0;       // the smallest streaming component's point blocks
-    DevBuf ptm_cgg, ptm_state;
-    size_t off_pm_pt0 = 0, off_pm_ch0 = 0, off_pm_cptr = 0, off_pm_jg = 0, off_pm_eof = 0;
+    DevBuf ptm_xch, ptm_state;
+    size_t off_pm_pt0 = 0, off_pm_ch0 = 0, off_pm_cptr = 0, off_pm_jg = 0;
     int lds_resident = 1;             // option "lds_resident": 0 = never
     int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
@@ -285,9 +287,8 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
-        v.pm_grad_form = ptm_gradient;
         v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
-        v.pm_pg = pm_pg.as<double>(); v.pm_cgq = pm_cgq.as<double>(); v.pm_gqpos = pm_gqpos.as<int>(); v.pm_gqw = pm_gqw.as<unsigned>(); v.pm_gqe = pm_gqe.as<int>(); v.pm_gqobs = pm_gqobs.as<double2>();
+        v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -1053,9 +1054,6 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "ptm_group") {
         if (value < 0 || value > PTM_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16)");
         L->ptm_group = (int)value;
-    } else if (n == "ptm_gradient") {
-        if (value < 0 || value > 1) return fail(c, RDIS_HIP_EINVAL, "ptm_gradient must be 0 (two passes) or 1 (one pass in camera order)");
-        L->ptm_gradient = (int)value;
         return 0;   // (no table depends on it)
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
@@ -1311,13 +1309,15 @@ int prepare_partition(rdis_hip_plan* L) {
     L->rest_lds = L->rest_ptm = 0;
     L->h_lds_ints.clear();
     L->h_pm_jg.clear();
-    L->lds_ns_cap = L->lds_ncb_cap = L->lds_chunk_cap = L->ptm_ncb_cap = L->ptm_chunk_cap = 0;
+    L->lds_ns_cap = L->lds_ncb_cap = L->lds_chunk_cap = L->ptm_ncb_cap = 0;
+    L->rounds_threads = L->rounds_K = 0;
     L->lds_max_factors = 0;
     L->pm_blocks = L->pm_entries = 0;
     if (p->kind == KIND_BA && (L->lds_resident != 0 || L->ptm_stream != 0) && p->ncam_blocks > 0 && (int)L->h_rest.size() > L->rest_tiny) {
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
         const size_t nc = (size_t)L->ncomp;
         cvec kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
+        const int ptm_max_threads = L->ptm_threads ? L->ptm_threads : 768;   // (the staging area of its gradient grows with the workgroup)
         ivec ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
         std::vector<ivec> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
         ivec cams, pts, deg;
@@ -1339,7 +1339,7 @@ int prepare_partition(rdis_hip_plan* L) {
                 else if (p->h_ptblock_of[(size_t)v] >= 0) note(p->h_ptblock_of[(size_t)v], pts);
                 else ok = false;   // a variable no factor of the problem reads: no block to put it in
             }
-            if (!ok || cams.size() > 4095 || pts.size() >= (1u << 20)) continue;
+            if (!ok || cams.size() > (size_t)PTM_MAX_CAMERAS || pts.size() >= (1u << 20)) continue;
             const int ncb = (int)cams.size(), npb = (int)pts.size(), ns = 9 * ncb + 3 * npb, m = c1 - c0;
             std::sort(cams.begin(), cams.end());
             for (int k = 0; k < ncb; ++k) p->h_blk_idx[(size_t)cams[(size_t)k]] = k;
@@ -1362,7 +1362,7 @@ int prepare_partition(rdis_hip_plan* L) {
             const bool lds_size_ok = lds_bytes_for(ns, ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
             const bool fits_lds = L->lds_resident != 0 && lds_size_ok && L->ptm_stream != 2;
             const bool fits_ptm = !fits_lds && (L->ptm_stream == 2 || (L->ptm_stream == 1 && !lds_size_ok)) &&
-                                  ptm_bytes_for(ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+                                  ptm_bytes_for(ncb, ptm_max_threads) <= (size_t)LDS_MAX_BYTES;
             if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
             if (fits_lds) std::sort(pts.begin(), pts.end());
             else {   // by number of factors, descending (ties: ascending id): the lanes of a wave run loops of equal length
@@ -1401,7 +1401,6 @@ int prepare_partition(rdis_hip_plan* L) {
             } else {
                 kind_of[(size_t)cc] = 2;
                 L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, ncb);
-                L->ptm_chunk_cap = std::max(L->ptm_chunk_cap, nchunk);
                 // the point's factors, in listed order (a CSR over the point blocks in their slot order)
                 ivec& pp = pptr_of[(size_t)cc];
                 pp.assign((size_t)npb + 1, 0);
@@ -1412,8 +1411,6 @@ int prepare_partition(rdis_hip_plan* L) {
         // (the maxima of a launch may come from different components: its LDS must hold them together)
         if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap) > (size_t)LDS_MAX_BYTES)
             for (size_t cc = 0; cc < nc; ++cc) if (kind_of[cc] == 1) kind_of[cc] = 0;
-        if (L->ptm_ncb_cap > 0 && ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap) > (size_t)LDS_MAX_BYTES)
-            for (size_t cc = 0; cc < nc; ++cc) if (kind_of[cc] == 2) kind_of[cc] = 0;
         auto first_other = std::stable_partition(L->h_rest.begin() + L->rest_tiny, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 0; });
         auto first_lds = std::stable_partition(first_other, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 2; });
         L->rest_ptm = (int)(first_lds - first_other);
@@ -1434,9 +1431,8 @@ int prepare_partition(rdis_hip_plan* L) {
             // (by number of factors, descending) and are taken 64 at a time -- a wave-chunk, a lane per block.  The
             // factors of a chunk's blocks are laid out slot-major: entry cptr[chunk] + 64 t + lane is the t-th listed
             // factor of the lane's block (or no factor: -1), so a wave's loads of a slot are 64 neighbours and their
-            // addresses depend on nothing the wave has loaded before.  entry -> listed factor (plan-wide index),
-            // listed factor -> entry (where the gradient pass leaves the factor's three point partials).
-            ivec pm_ch0v(nc, 0), cptr, eof((size_t)L->nfac, -1);
+            // addresses depend on nothing the wave has loaded before.  entry -> listed factor (plan-wide index).
+            ivec pm_ch0v(nc, 0), cptr;
             L->h_pm_jg.clear();
             for (size_t cc = 0; cc < nc; ++cc) {
                 if (kind_of[cc] != 2) continue;
@@ -1454,7 +1450,6 @@ int prepare_partition(rdis_hip_plan* L) {
                     const int pi = (int)(((unsigned)ls_fidx[(size_t)j]) >> 12);
                     const int e = e0 + cbase[(size_t)(pi / 64)] + 64 * fill[(size_t)pi]++ + (pi % 64);
                     L->h_pm_jg[(size_t)e] = j;
-                    eof[(size_t)j] = e;
                 }
                 for (int k = 0; k <= npc; ++k) cptr.push_back(e0 + cbase[(size_t)k]);
                 L->pm_blocks += npb;
@@ -1469,7 +1464,6 @@ int prepare_partition(rdis_hip_plan* L) {
             L->off_ls_ptr = put(sptr); L->off_ls_vid = put(svid); L->off_ls_free = put(sfree);
             L->off_ls_ncb = put(ls_ncb); L->off_ls_fidx = put(ls_fidx); L->off_ls_gptr = put(gptr); L->off_ls_gperm = put(gperm);
             L->off_pm_pt0 = put(pm_pt0); L->off_pm_ch0 = put(pm_ch0v); L->off_pm_cptr = put(cptr); L->off_pm_jg = put(L->h_pm_jg);
-            L->off_pm_eof = put(eof);
             // rotations: no camera variable free among a launch's components -> records, read only; otherwise records
             // that follow the trial point when a lane has several factors per camera and trial (else each factor forms its own)
             auto camfix_of = [&](size_t r0, size_t r1) {
@@ -1507,31 +1501,17 @@ int prepare_partition(rdis_hip_plan* L) {
         gather_obs_kernel<<<grid_for(c, L->nfac, 256), 256, 0, c->stream>>>((int)L->nfac, L->ip(L->off_fac_id), p->obs.as<double2>(), L->lds_obs.as<double2>());
         HIPCHK(c, hipGetLastError());
     }
-    if (L->rest_ptm > 0) {   // the streaming components' point records, point-major factor arrays, gradient-order arrays
-        const size_t gq = (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 64;
+    if (L->rest_ptm > 0) {   // the streaming components' point records and point-major factor arrays
         rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->pm_bnd, (size_t)L->pm_blocks * PT_BND * sizeof(float));
         if (!rc) rc = plan_alloc(L, L->pm_bex, (size_t)L->pm_blocks * PT_BND * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->ptm_cgg, (size_t)std::max<int64_t>(L->ls_total_chunks, 1) * 9 * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->pm_cam, (size_t)L->pm_entries * sizeof(short));
-        if (!rc) rc = plan_alloc(L, L->pm_obs, (size_t)L->pm_entries * sizeof(double2));
-        if (!rc) rc = plan_alloc(L, L->pm_pg, (size_t)std::max<int64_t>(L->pm_entries, 1) * 3 * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->pm_cgq, gq * CGQ_REC * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->pm_gqpos, (size_t)std::max<int64_t>(L->pm_entries, 1) * sizeof(int));
-        if (!rc) rc = plan_alloc(L, L->pm_gqw, gq * sizeof(unsigned));
-        if (!rc) rc = plan_alloc(L, L->pm_gqe, gq * sizeof(int));
-        if (!rc) rc = plan_alloc(L, L->pm_gqobs, gq * sizeof(double2));
+        // (a block of PTM_BLK slots is loaded whole: the last chunk's may reach past the last entry)
+        if (!rc) rc = plan_alloc(L, L->pm_cam, ((size_t)L->pm_entries + 64 * PTM_BLK) * sizeof(short));
+        if (!rc) rc = plan_alloc(L, L->pm_obs, ((size_t)L->pm_entries + 64 * PTM_BLK) * sizeof(double2));
         if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(L->pm_cgq.p, 0, gq * CGQ_REC * sizeof(double), c->stream));   // (positions / entries that are no factor stay zero)
-        HIPCHK(c, hipMemsetAsync(L->pm_pg.p, 0, (size_t)std::max<int64_t>(L->pm_entries, 1) * 3 * sizeof(double), c->stream));
-        HIPCHK(c, hipMemsetAsync(L->pm_gqpos.p, 0, (size_t)std::max<int64_t>(L->pm_entries, 1) * sizeof(int), c->stream));
         const PlanView V = L->view();
-        ptm_gather_kernel<<<grid_for(c, L->pm_entries, 256), 256, 0, c->stream>>>((int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
-                                                                                 L->pm_cam.as<short>(), L->pm_obs.as<double2>());
-        HIPCHK(c, hipGetLastError());
-        ptm_gather_gradient_kernel<<<(int)std::min<int64_t>(std::max<int64_t>(L->ncomp, 1), 2048), 256, 0, c->stream>>>(V, L->lds_ints.as<int>() + L->off_pm_eof, L->pm_gqw.as<unsigned>(),
-                                                                                                    L->pm_gqe.as<int>(), L->pm_gqobs.as<double2>(), L->pm_gqpos.as<int>());
-        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, ptm_gather_launch(grid_for(c, L->pm_entries, 256), c->stream, (int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
+                                    L->pm_cam.as<short>(), L->pm_obs.as<double2>()));
     }
     if (!L->coop.empty()) {
         rc = plan_alloc(L, L->coop_ints, L->h_coop_ints.size() * sizeof(int));
@@ -1636,49 +1616,98 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
     HIPCHK(c, hipGetLastError());
     return 0;
 }
-template <int ROT>
-int launch_ptm_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+// The gradient's round lists of the point-major streaming solver (solver_ptm.hpp: gradient_to_xi) for workgroups of
+// `threads` lanes, K to a component.  Workgroup (component, rank r) takes the point chunks c = r (mod K), its wave w
+// those with (c / K) mod waves = w, slot by slot: that is the wave's sequence of steps, and round rr of the workgroup
+// is every wave's rr-th step.  A round's list: for every camera block of the component the first position of its
+// segment [ncb + 1], then the staging indices (wave * 64 + lane) of the round's factors, grouped by camera, within a
+// camera in ascending order -- the order of the sums.  Built on the host from the plan's point-major tables (two bytes
+// per factor), once per (threads, K); nothing to build when no camera variable is free.
+int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     rdis_hip_ctx* c = L->prob->ctx;
+    if (L->rounds_threads == threads && L->rounds_K == K) return 0;
+    L->rounds_threads = threads; L->rounds_K = K;
+    if (L->ptm_rot_mode == ROT_CAMFIX) return 0;
+    const int nw = threads / 64;
+    const int* li = L->h_lds_ints.data();
+    const int* ls_ptr = li + L->off_ls_ptr;
+    const int* ls_ncb = li + L->off_ls_ncb;
+    const unsigned* fidx = reinterpret_cast<const unsigned*>(li + L->off_ls_fidx);
+    const int* pm_ch0 = li + L->off_pm_ch0;
+    const int* cptr = li + L->off_pm_cptr;
+    const int* jg = li + L->off_pm_jg;
+    const size_t nwg = (size_t)L->ncomp * (size_t)K;
+    std::vector<long long> off(nwg, 0);
+    ivec nr(nwg, 0);
+    std::vector<unsigned short> tab;
+    std::vector<ivec> steps((size_t)nw);
+    ivec seg, pos;
+    const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
+    for (size_t ri = r_ptm; ri < r_lds; ++ri) {
+        const int cc = L->h_rest[ri];
+        const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - 9 * ncb) / 3, npc = (npb + 63) / 64;
+        const int* cp = cptr + pm_ch0[cc];
+        const size_t stride = (size_t)ptm_round_stride(ncb, threads);
+        for (int rk = 0; rk < K; ++rk) {
+            size_t nrounds = 0;
+            for (int w = 0; w < nw; ++w) {
+                ivec& st = steps[(size_t)w];
+                st.clear();
+                for (int ch = rk + K * w; ch < npc; ch += K * nw)
+                    for (int e = cp[ch]; e < cp[ch + 1]; e += 64) st.push_back(e);
+                nrounds = std::max(nrounds, st.size());
+            }
+            const size_t base = tab.size();
+            off[(size_t)cc * K + rk] = (long long)base;
+            nr[(size_t)cc * K + rk] = (int)nrounds;
+            tab.resize(base + nrounds * stride, 0);
+            for (size_t rr = 0; rr < nrounds; ++rr) {
+                unsigned short* rec = tab.data() + base + rr * stride;
+                seg.assign((size_t)ncb + 1, 0);
+                for (int w = 0; w < nw; ++w) {
+                    if (rr >= steps[(size_t)w].size()) continue;
+                    const int e = steps[(size_t)w][rr];
+                    for (int l = 0; l < 64; ++l) { const int j = jg[e + l]; if (j >= 0) ++seg[(size_t)(fidx[j] & 0xFFFu) + 1]; }
+                }
+                for (int k = 0; k < ncb; ++k) seg[(size_t)k + 1] += seg[(size_t)k];
+                for (int k = 0; k <= ncb; ++k) rec[k] = (unsigned short)seg[(size_t)k];
+                pos.assign(seg.begin(), seg.end() - 1);
+                for (int w = 0; w < nw; ++w) {
+                    if (rr >= steps[(size_t)w].size()) continue;
+                    const int e = steps[(size_t)w][rr];
+                    for (int l = 0; l < 64; ++l) {
+                        const int j = jg[e + l];
+                        if (j >= 0) rec[ncb + 1 + pos[(size_t)(fidx[j] & 0xFFFu)]++] = (unsigned short)(64 * w + l);
+                    }
+                }
+            }
+        }
+    }
+    int rc = plan_alloc(L, L->pm_rounds, std::max<size_t>(tab.size(), 2) * sizeof(unsigned short));
+    if (!rc) rc = plan_alloc(L, L->pm_rd_off, nwg * sizeof(long long));
+    if (!rc) rc = plan_alloc(L, L->pm_rd_n, nwg * sizeof(int));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(L->pm_rounds.p, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(L->pm_rd_off.p, off.data(), nwg * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(L->pm_rd_n.p, nr.data(), nwg * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host tables go out of scope; a launch on another stream follows)
+    return 0;
+}
+int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    int rc = ptm_build_rounds(L, threads, 1);
+    if (rc) return rc;
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
-    const int ncc = L->ptm_ncb_cap, chc = L->ptm_chunk_cap;
-#define RDIS_PTM_LAUNCH(T)                                                                                              \
-    do {                                                                                                                \
-        if (dyn > 48 * 1024)                                                                                            \
-            HIPCHK(c, hipFuncSetAttribute((const void*)cgd_ptm_kernel<T, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); \
-        cgd_ptm_kernel<T, ROT><<<grid, T, dyn, stream>>>(P, V, maxiters, ftol, ncc, chc);                                \
-    } while (0)
-    switch (threads) {
-        case 256: RDIS_PTM_LAUNCH(256); break;
-        case 512: RDIS_PTM_LAUNCH(512); break;
-        default: RDIS_PTM_LAUNCH(768); break;
-    }
-#undef RDIS_PTM_LAUNCH
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, ptm_launch(L->ptm_rot_mode, threads, grid, ptm_bytes_for(L->ptm_ncb_cap, threads), stream, P, V, maxiters, ftol, L->ptm_ncb_cap));
     return 0;
 }
 // K workgroups per component (cgd_ptmg_kernel): how many groups of K fit the device, and the launch
-template <int ROT>
-const void* ptmg_kernel_ptr(int threads) {
-    switch (threads) {
-        case 256: return (const void*)cgd_ptmg_kernel<256, ROT>;
-        case 512: return (const void*)cgd_ptmg_kernel<512, ROT>;
-        default: return (const void*)cgd_ptmg_kernel<768, ROT>;
-    }
-}
-const void* ptmg_kernel(rdis_hip_plan* L, int threads) {
-    switch (L->ptm_rot_mode) {
-        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads);
-        case ROT_RECORDS: return ptmg_kernel_ptr<ROT_RECORDS>(threads);
-        default: return ptmg_kernel_ptr<ROT_PER_FACTOR>(threads);
-    }
-}
 int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out) {
     rdis_hip_ctx* c = L->prob->ctx;
-    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
-    const void* fn = ptmg_kernel(L, threads);
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
+    const void* fn = ptmg_kernel_fn(L->ptm_rot_mode, threads);
     if (dyn > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn));
@@ -1687,32 +1716,32 @@ int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out) {
 }
 int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int ngroups, int K, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;
+    int rc = ptm_build_rounds(L, threads, K);
+    if (rc) return rc;
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, L->ptm_chunk_cap);
-    int ncc = L->ptm_ncb_cap, chc = L->ptm_chunk_cap;
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
+    int ncc = L->ptm_ncb_cap;
     if (L->ptm_state.bytes < (size_t)ngroups * sizeof(SmallCoopState)) {
-        int rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * sizeof(SmallCoopState));
+        rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * sizeof(SmallCoopState));
+        if (rc) return rc;
+    }
+    const size_t xch_bytes = (size_t)ngroups * 2 * (size_t)K * 9 * (size_t)ncc * sizeof(double);
+    if (L->ptm_xch.bytes < xch_bytes) {
+        rc = plan_alloc(L, L->ptm_xch, xch_bytes);
         if (rc) return rc;
     }
     // arm every granule, clear the abort words
     HIPCHK(c, hipMemsetAsync(L->ptm_state.p, 0xFF, (size_t)ngroups * sizeof(SmallCoopState), stream));
     HIPCHK(c, hipMemset2DAsync((char*)L->ptm_state.p + offsetof(SmallCoopState, abort_flag), sizeof(SmallCoopState), 0, 64, (size_t)ngroups, stream));
-    PtmGroupArgs A{L->ptm_state.as<SmallCoopState>(), L->ptm_cgg.as<double>(), K, ngroups, std::min(4, L->coop_poll_delay)};
+    PtmGroupArgs A{L->ptm_state.as<SmallCoopState>(), L->ptm_xch.as<double>(), K, ngroups, std::min(4, L->coop_poll_delay)};
     int mi = maxiters;
     double ft = ftol;
-    void* args[] = {&P, &V, &A, &mi, &ft, &ncc, &chc};
+    void* args[] = {&P, &V, &A, &mi, &ft, &ncc};
     const int grid = 8 * K * ((ngroups + 7) / 8);
-    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel(L, threads), dim3(grid), dim3(threads), args, dyn, stream));
+    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel_fn(L->ptm_rot_mode, threads), dim3(grid), dim3(threads), args, dyn, stream));
     return 0;
-}
-int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
-    switch (L->ptm_rot_mode) {
-        case ROT_CAMFIX: return launch_ptm_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
-        case ROT_RECORDS: return launch_ptm_rot<ROT_RECORDS>(L, stream, threads, first, grid, maxiters, ftol);
-        default: return launch_ptm_rot<ROT_PER_FACTOR>(L, stream, threads, first, grid, maxiters, ftol);
-    }
 }
 int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
     rdis_hip_ctx* c = L->prob->ctx;

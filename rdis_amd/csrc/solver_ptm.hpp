@@ -13,49 +13,53 @@
 //             INWARD (lo32 >= lo, hi32 <= hi): a trial value strictly inside them is inside the bounds and is its
 //             own clamp; only a lane whose value is not (an active bound: rare) fetches the block's exact bounds
 //             from a third array and clamps as ever -- the same bits either way, 24 bytes less per block and trial.
-//             The blocks stand
-//             in order of their number of factors (descending) and are taken 64 at a time, a
+//             The blocks stand in order of their number of factors (descending) and are taken 64 at a time, a
 //             wave-chunk: a lane takes a block, loads its record ONCE, forms clamp(p + a xi) in
 //             registers and evaluates the block's factors one after the other against the cameras in
 //             LDS.  The trial point of a point variable is never stored.
 //   factors   slot-major per wave-chunk: entry cptr[chunk] + 64 t + lane is the t-th listed factor of the
 //             lane's block (camera block 2 B + observation 16 B; camera -1 = the block has fewer
 //             factors).  A wave's loads of a slot are 64 neighbours, and their addresses depend on
-//             nothing the wave has loaded before: slot t + 1 is fetched while slot t is evaluated.
-//             (Round 3, first form: a CSR per point -- point -> range -> camera, observation, every factor
-//             a dependent chain of loads in front of ~1000 cycles of arithmetic.  Stamps: half a trial's
-//             time was a fixed ~65 000 cycles that did not shrink with the work; three waves per SIMD do
-//             not hide thirty exposed round trips.)
+//             nothing the wave has loaded before.
+//
+// Nothing a wave needs is asked for when it is needed (round 4).  A chunk's entry range comes through the scalar
+// cache; its point records (and their float bounds, all six at once: the short-circuit form was three dependent
+// round trips) are loaded while the chunk BEFORE it is evaluated, slot t + 1 while slot t is evaluated, and the
+// first slot of the next chunk during the last slot of this one.  Before, every chunk began with five dependent
+// memory round trips (range -> records -> bounds x 3) in front of four slots' arithmetic, and three waves per SIMD
+// do not hide that: 62 % of all wave-cycles were parked (profiles/r03_c_pmc_sq_synthL.txt).
 //
 // HBM bytes per value+slope trial: 24 per point variable + 18 per factor (SURVEY 8d counts 16 + 24:
 // x and g once per variable, observation + two indices per factor), no write traffic at all.
 //
-// The full gradient, once per CG iteration, is a point-major pass like a trial (forward + adjoint; a block's
-// point entries summed in registers in slot order = factor-list order, src/State.h:157-210; a factor's nine camera
-// partials written to pm_cgq at its position in that order) followed by a pass in camera order (ls_gperm: the factors grouped by
-// camera block, whole wave-chunks per camera) that only gathers those partials and adds: see gradient_to_xi.
+// The full gradient, once per CG iteration, is ONE point-major pass like a trial (forward + adjoint; a block's
+// point entries summed in registers in slot order = factor-list order, src/State.h:157-210, and written to the
+// record).  The nine CAMERA partials of a factor never leave the compute unit: the pass runs in ROUNDS -- in round r
+// every wave evaluates its r-th slot of factors and leaves the 64 x 9 camera partials in an LDS staging area; after a
+// barrier lane (camera c, entry k) adds up the staged partials of camera c, whose staging indices the plan lists per
+// round grouped by camera (two bytes a factor and gradient from HBM; the list of round r + 1 is fetched during round
+// r), into the camera's gradient entry in LDS.  Sums in a fixed order (rounds in order, within a round by wave and
+// lane): the same bits run to run.  (Round 3 handed the camera partials from a point-major pass to a pass in camera
+// order through HBM, 160 bytes per factor and gradient -- most of the 1.6 x the algorithmic bytes the launch moved.)
 //
 // GROUP = true: K workgroups share a component (cgd_ptmg_kernel, a cooperative launch of several such
 // groups side by side).  A launch with fewer components than compute units -- one rank's share of a
 // decomposition spread over eight GPUs -- would otherwise leave the rest of the device idle while every
 // busy unit works through its component's factors alone.  The camera slots are replicated in every
 // workgroup's LDS (each steps the same control logic on the same sums and applies the same vector updates to
-// them: nothing about the cameras is ever exchanged but chunk sums of the gradient); the point chunks are
-// dealt out round robin (chunk c belongs to workgroup c mod K), and so are the gradient pass's factor
-// chunks.  Per trial point the workgroups exchange their partial (value, slope) through the granules of
-// grid_sync.hpp (every wave an entry, summed in entry order: the same bits in every workgroup); per CG
-// iteration two ordered grid barriers hand over the points' positions (read by the gradient pass of
-// whichever workgroup takes a factor) and the per-factor point partials / per-chunk camera sums.
+// them); the point chunks are dealt out round robin (chunk c belongs to workgroup c mod K).  Per trial point the
+// workgroups exchange their partial (value, slope) through the granules of grid_sync.hpp (every wave an entry,
+// summed in entry order: the same bits in every workgroup); per CG iteration ONE ordered grid barrier hands over
+// the workgroups' partial camera gradients (9 ncb doubles each, summed in rank order by everybody).
 // A group's workgroups sit on one XCD (blockIdx mod 8 is the same for all of them), so what they hand to
 // each other through plain stores stays in that XCD's L2.
 #pragma once
 #include "solver_lds.hpp"
 #include "grid_sync.hpp"
+#include "ptm_api.hpp"
 
 namespace rdis_hip {
 
-constexpr int PT_REC = 6;    // doubles per point record: p, xi of the block's three variables
-constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded inward (PB), exact doubles (PE)
 // the float nearest to a bound on its inner side (never subnormal: conversions may flush those)
 __device__ __forceinline__ float inner_lo32(double lo) {
     float f = (float)lo;
@@ -69,20 +73,18 @@ __device__ __forceinline__ float inner_hi32(double hi) {
     if (fabsf(f) < 1.17549435e-38f) f = hi >= 0.0 ? 0.0f : -1.17549435e-38f;
     return f;
 }
-constexpr int PTM_DOUBLES_PER_SLOT = LDS_DOUBLES_PER_SLOT + 2;   // Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
-constexpr int PTM_MAX_GROUP = 16;  // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
-constexpr unsigned PTM_NO_FACTOR = 0xFFFFFFFFu;
-constexpr int CGQ_REC = 10;  // doubles per camera-partials record (nine + one of padding: five 16-byte accesses)
-__host__ __device__ inline size_t ptm_bytes_for(int ncb, int nchunk) {
-    return (size_t)ncb * 9 * (PTM_DOUBLES_PER_SLOT * sizeof(double) + sizeof(int)) + (size_t)ncb * (7 * sizeof(double) + 2 * sizeof(int)) +
-           (size_t)nchunk * (9 * sizeof(double) + sizeof(int)) + 64;
-}
 
-struct PtmGroupArgs {
-    SmallCoopState* st;   // one exchange state per group of the launch
-    double* cgg;          // [plan's gradient chunks][9] camera partial sums of a chunk (handed over between workgroups)
-    int K, ngroups;       // workgroups per component, components of the launch
-    int poll_delay;
+// camera block (-1: no factor) and observation of PTM_BLK consecutive slots of a lane's point block
+struct SlotBlock {
+    int c[PTM_BLK];
+    double2 o[PTM_BLK];
+};
+// a point block's record and float bounds as loaded (a chunk ahead of their use).  Twelve separate loads on purpose:
+// the values are carried around the chunk loop, and the halves of a 16-byte load's register tuple are not coalesced
+// with loop-carried registers -- the compiler copies them out right behind the load, i.e. waits for it at once.
+struct PtRecs {
+    double p[3], xi[3];
+    float lo[3], hi[3];
 };
 
 template <int ROT, bool GROUP = false>
@@ -91,38 +93,36 @@ struct PtmEnv {
     const PlanView& L;
     int comp, n, m, f0, c0, tid, nt, nwaves;
     int ncb, npb, npc;        // camera blocks (9 LDS slots each), point blocks (a record each), wave-chunks of point blocks
-    int nchunk;               // wave-chunks of the gradient pass (factors grouped by camera)
-    const unsigned* gqw;      // ... per position: slot word,
-    const int* gqe;           //     point-major entry,
-    const double2* gqobs;     //     observation
     const int* svid;          // variable id of a slot (cameras, then points)
     const int* sfree;         // local free index of a slot, -1 = constant (global copy; the cameras' also in SF)
-    double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR, *CG;   // LDS, cameras (GC, HC: g and h of the recurrence)
-    int *CGC, *CST, *CEN, *SF;   // LDS: a gradient chunk's camera; a camera's chunks [CST, CEN); local free index of a camera slot
+    double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR;   // LDS, cameras (GC, HC: g and h of the recurrence)
+    double* STG;              // LDS [nt][9]: the camera partials of a round's factors, by lane of the workgroup
+    unsigned short* RL;       // LDS [2][rl_cap]: round lists (camera segment starts, then staging indices grouped by camera)
+    int rl_cap;
+    int* SF;                  // LDS: local free index of a camera slot
     double* PT;               // [npb][6] point records: p, xi
     float* PB;                // [npb][6] their bounds rounded inward (lo, hi)
     double* PE;               // [npb][6] ... and exact
     const int* cptr;          // [npc + 1] a point chunk's entries ...
     const short* pcam;        // ... their camera block (-1: none; at most 4095 camera blocks: two bytes a factor and trial)
     const double2* pobs;      // ... their observation
-    double* pg;               // ... the three point partials of the last gradient pass (gradient_camera_order)
-    const int* gqpos;         // ... the factor's position in the camera-grouped order
-    double* cgq;              // [positions of that order][CGQ_REC] a factor's nine camera partials, handed from pass 1 to pass 2
+    const unsigned short* rounds;   // this workgroup's round lists, rl_stride 16-bit words each ...
+    int nrounds, rl_stride;         // ... and their number
     double *g, *h;            // plan workspace, by free index (point variables)
     double (*red)[3][MAX_WAVES];
     int parity;
     double* tr;
     int trn, lm_count;
-    // GROUP: rank r of the K workgroups that share the component, their exchange, the chunk sums in HBM
+    // GROUP: rank r of the K workgroups that share the component, their exchange, their partial camera gradients in HBM
     int r, K;
     GridSyncT<SmallCoopState> GX;
-    double* cgg;
+    double* xch;              // [2][K][xch_stride]
+    int xch_stride, gpar;
 #ifdef RDIS_COOP_TIMING
     long long tmv[32];
 #endif
 
-    // the wave-chunks (of point blocks, or of the gradient pass) this wave takes: chunk c belongs to workgroup
-    // c mod K, wave (c / K) mod nwaves
+    // the wave-chunks of point blocks this wave takes: chunk c belongs to workgroup c mod K, wave (c / K) mod nwaves
     __device__ __forceinline__ int first_chunk() const { return GROUP ? r + K * (tid >> 6) : (tid >> 6); }
     __device__ __forceinline__ int chunk_step() const { return GROUP ? K * nwaves : nwaves; }
     // the point blocks this workgroup owns, a lane each
@@ -203,52 +203,55 @@ struct PtmEnv {
     }
 
     // ---- a point's trial values: clamp(p + a xi) from its record (registers only) -------------------
+    __device__ __forceinline__ void load_recs(int ps, PtRecs& R) const {
+        const double* rec = PT + (long long)PT_REC * ps;
+        const float* bq = PB + (long long)PT_BND * ps;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { R.p[k] = rec[k]; R.xi[k] = rec[3 + k]; R.lo[k] = bq[k]; R.hi[k] = bq[3 + k]; }
+    }
     // exact clamp of a block's three values that are not all strictly inside the inward-rounded bounds
-    __device__ __forceinline__ void clamp_exact(int ps, double (&x)[3]) {
+    __device__ __forceinline__ void clamp_exact(int ps, double (&x)[3]) const {
         const double2* be = reinterpret_cast<const double2*>(PE + (long long)PT_BND * ps);
         const double2 e0 = be[0], e1 = be[1], e2 = be[2];
         x[0] = clampd(x[0], e0.x, e1.y);
         x[1] = clampd(x[1], e0.y, e2.x);
         x[2] = clampd(x[2], e1.x, e2.y);
     }
-    __device__ __forceinline__ bool inside32(int ps, const double (&x)[3]) {
-        const float2* bq = reinterpret_cast<const float2*>(PB + (long long)PT_BND * ps);
-        const float2 b0 = bq[0], b1 = bq[1], b2 = bq[2];
-        return x[0] > (double)b0.x && x[0] < (double)b1.y && x[1] > (double)b0.y && x[1] < (double)b2.x &&
-               x[2] > (double)b1.x && x[2] < (double)b2.y;
+    // (all six comparisons, no short circuit: nothing here may wait for memory)
+    __device__ __forceinline__ bool inside32(const PtRecs& R, const double (&x)[3]) const {
+        int in = 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in &= (int)(x[k] > (double)R.lo[k]) & (int)(x[k] < (double)R.hi[k]);
+        return in != 0;
     }
-    template <int MODE>
-    __device__ __forceinline__ void point_at(int ps, double a, double (&x)[3], double (&d)[3]) {
+    // clamp(p + a xi) and the direction, from a loaded record
+    __device__ __forceinline__ void point_line(const PtRecs& R, int ps, double a, double (&x)[3], double (&d)[3]) const {
 #pragma clang fp contract(off)
-        const double2* rec = reinterpret_cast<const double2*>(PT + (long long)PT_REC * ps);
-        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        const double p[3] = {r0.x, r0.y, r1.x}, xi[3] = {r1.y, r2.x, r2.y};
-        if constexpr (MODE == AT_START) {
-            const double* be = PE + (long long)PT_BND * ps;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d[k] = xi[k];
-                const int fi = sfree[9 * ncb + 3 * ps + k];
-                x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : p[k];
-            }
-        } else {
+        for (int k = 0; k < 3; ++k) {
+            d[k] = R.xi[k];
+            const double t = a * d[k];
+            x[k] = R.p[k] + t;
+        }
+        if (!inside32(R, x)) clamp_exact(ps, x);
+    }
+    // clamp(p): the gradient's point
+    __device__ __forceinline__ void point_position(const PtRecs& R, int ps, double (&x)[3]) const {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d[k] = xi[k];
-                const double t = a * xi[k];
-                x[k] = p[k] + t;
-            }
-            if (!inside32(ps, x)) clamp_exact(ps, x);
+        for (int k = 0; k < 3; ++k) x[k] = R.p[k];
+        if (!inside32(R, x)) clamp_exact(ps, x);
+    }
+    // clamp(x_start): the rollback's point (rare: loads where it stands)
+    __device__ __forceinline__ void point_start(int ps, double (&x)[3]) const {
+        const double* rec = PT + (long long)PT_REC * ps;
+        const double* be = PE + (long long)PT_BND * ps;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int fi = sfree[9 * ncb + 3 * ps + k];
+            x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : rec[k];
         }
     }
-    // ... at clamp(p), position only (the gradient pass: any workgroup's lanes, a factor each)
-    __device__ __forceinline__ void point_position(int ps, double (&x)[3]) {
-        const double2* rec = reinterpret_cast<const double2*>(PT + (long long)PT_REC * ps);
-        const double2 r0 = rec[0], r1 = rec[1];
-        x[0] = r0.x; x[1] = r0.y; x[2] = r1.x;
-        if (!inside32(ps, x)) clamp_exact(ps, x);
-    }
-    __device__ __forceinline__ double forward(int c, double2 o, const double (&x)[3], double (&v)[12], BaFwd& t) {
+    __device__ __forceinline__ double forward(int c, double2 o, const double (&x)[3], double (&v)[12], BaFwd& t) const {
         const int cb = 9 * c;
 #pragma unroll
         for (int k = 3; k < 9; ++k) v[k] = X[cb + k];
@@ -264,36 +267,82 @@ struct PtmEnv {
             return ba_project(v, o.x, o.y, t);
         }
     }
-    // This workgroup's share of the sums: its point chunks, a block per lane, the block's factors slot by slot.
-    // The next slot's camera and observation are in flight while a slot is evaluated.
-    template <bool SLOPE, int MODE>
-    __device__ __forceinline__ void eval_partial(double a, double& af, double& as) {
+    __device__ __forceinline__ void factor_trial(int cc, double2 o, const double (&x)[3], const double (&dp)[3], bool slope, double& af, double& as) const {
+        double v[12];
+        BaFwd t;
+        af += forward(cc, o, x, v, t);
+        if (slope) {
+            double d[12];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_CAMFIX) ? 0.0 : XI[9 * cc + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[9 + k] = dp[k];
+            as += ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
+        }
+    }
+    // the (camera, observation) entries of PTM_BLK consecutive slots of a chunk, from entry e on (this lane's: e + lane, + 64 per
+    // slot).  Unconditional: slots beyond the chunk's last are loaded too (the arrays are padded) and not looked at.
+    __device__ __forceinline__ void load_block(int e, SlotBlock& B) const {
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < PTM_BLK; ++k) { B.c[k] = pcam[e + 64 * k + lane]; B.o[k] = pobs[e + 64 * k + lane]; }
+    }
+    // This workgroup's share of the sums at clamp(p + a xi): its point chunks, a block per lane, the block's factors
+    // PTM_BLK slots at a time.  Everything is asked for a block of slots before it is used: while one block of slots is
+    // evaluated the next one's cameras and observations are in flight (the next chunk's first block during a chunk's last),
+    // from a chunk's first block on the next chunk's point records, and the entry range of the chunk after that.
+    // (Chunks stand in descending order of their blocks' factor counts: behind a chunk without factors there is none with.)
+    template <bool SLOPE>
+    __device__ __forceinline__ void eval_line(double a, double& af, double& as) {
+        const int lane = tid & 63, cs = chunk_step();
+        int cu = __builtin_amdgcn_readfirstlane(first_chunk());
+        if (cu >= npc) return;
+        int e = __builtin_amdgcn_readfirstlane(cptr[cu]), e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]);
+        if (e >= e1) return;
+        int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
+        if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
+        if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+        PtRecs R;
+        load_recs(min(64 * cu + lane, npb - 1), R);
+        SlotBlock N;
+        load_block(e, N);
+        bool fresh = true;
+        double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0};
+        for (;;) {
+            const SlotBlock B = N;
+            const int bn = min(PTM_BLK, (e1 - e) >> 6);
+            if (fresh) {   // a chunk's first block: its trial point from the records; the next chunk's records
+                point_line(R, min(64 * cu + lane, npb - 1), a, x, dp);
+                if (ne < ne1) load_recs(min(64 * cx + lane, npb - 1), R);
+                fresh = false;
+            }
+            const int en = e + 64 * PTM_BLK;
+            if (en < e1) load_block(en, N);
+            else if (ne < ne1) load_block(ne, N);
+#pragma unroll
+            for (int k = 0; k < PTM_BLK; ++k)
+                if (k < bn && B.c[k] >= 0) factor_trial(B.c[k], B.o[k], x, dp, SLOPE, af, as);
+            if (en < e1) { e = en; continue; }
+            if (ne >= ne1) break;
+            cu = cx; e = ne; e1 = ne1; fresh = true;
+            cx += cs;
+            ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);   // (asked for a chunk ago)
+            v0 = v1 = 0;
+            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+        }
+    }
+    // ... at clamp(x_start) (the rollback; value only)
+    __device__ void eval_start(double& af) {
         const int lane = tid & 63;
         for (int c = first_chunk(); c < npc; c += chunk_step()) {
             const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
-            int cn = -1;
-            double2 on = make_double2(0.0, 0.0);
-            if (e0 < e1) { cn = pcam[e0 + lane]; on = pobs[e0 + lane]; }
             const int ps = 64 * c + lane;
-            double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0};
-            if (ps < npb) point_at<MODE>(ps, a, x, dp);
+            double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0}, as = 0.0;
+            if (ps < npb) point_start(ps, x);
             for (int e = e0; e < e1; e += 64) {
-                const int cc = cn;
-                const double2 o = on;
-                if (e + 64 < e1) { cn = pcam[e + 64 + lane]; on = pobs[e + 64 + lane]; }
-                if (cc >= 0) {
-                    double v[12];
-                    BaFwd t;
-                    af += forward(cc, o, x, v, t);
-                    if constexpr (SLOPE) {
-                        double d[12];
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_CAMFIX) ? 0.0 : XI[9 * cc + k];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) d[9 + k] = dp[k];
-                        as += ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
-                    }
-                }
+                const int cc = pcam[e + lane];
+                const double2 o = pobs[e + lane];
+                if (cc >= 0) factor_trial(cc, o, x, dp, false, af, as);
             }
         }
     }
@@ -307,7 +356,7 @@ struct PtmEnv {
     __device__ bool aborted() const { if constexpr (GROUP) return GX.dead; else return false; }
     // cycle stamps of the launch's first workgroup (build with -DRDIS_COOP_TIMING; rdis_hip_plan_debug_counters):
     // 0 cameras' trial point, 1 this workgroup's factors, 2 sums (GROUP: the exchange), 3 their number (value+slope
-    // trials); 4 / 5 gradient before / after the hand-over, 10 their number; 8 / 9 control step / hand-over, 12.. cycles
+    // trials); 4 / 5 gradient: the rounds / what follows them, 10 their number; 8 / 9 control step / hand-over, 12.. cycles
     // per request kind, 22.. their counts; GROUP: 28 exchanges, 29 publish, 30 sweep, 31 tail of the exchanges
 #ifdef RDIS_COOP_TIMING
     __device__ void tick(int slot, long long dt) { tmv[slot] += dt; }
@@ -318,8 +367,8 @@ struct PtmEnv {
 #endif
     __device__ double eval_value(double a, bool restore) {
         double af = 0.0, as = 0.0, dummy = 0.0;
-        if (restore) { assign_cameras<AT_START>(0.0); eval_partial<false, AT_START>(0.0, af, as); }
-        else { assign_cameras<AT_LINE>(a); eval_partial<false, AT_LINE>(a, af, as); }
+        if (restore) { assign_cameras<AT_START>(0.0); eval_start(af); }
+        else { assign_cameras<AT_LINE>(a); eval_line<false>(a, af, as); }
         sumk<1>(af, as, dummy);
         return af;
     }
@@ -328,7 +377,7 @@ struct PtmEnv {
         const long long t0 = clock();
         assign_cameras<AT_LINE>(a);
         const long long t1 = clock();
-        eval_partial<true, AT_LINE>(a, af, as);
+        eval_line<true>(a, af, as);
         const long long t2 = clock();
         sumk<2>(af, as, dummy);
         f = af; s = as;
@@ -358,235 +407,154 @@ struct PtmEnv {
             PE[(long long)PT_BND * ps + k] = lo; PE[(long long)PT_BND * ps + 3 + k] = hi;
             PB[(long long)PT_BND * ps + k] = inner_lo32(lo); PB[(long long)PT_BND * ps + 3 + k] = inner_hi32(hi);
         });
-        // the gradient pass's chunks by camera: chunk -> camera, and every camera's (contiguous) range of chunks
-        for (int c = tid; c < ncb; c += nt) { CST[c] = 0; CEN[c] = 0; }
-        for (int ch = tid; ch < nchunk; ch += nt) CGC[ch] = (int)(gqw[64 * ch] & 0xFFFu);   // (a chunk's first entry always is a factor)
-        __syncthreads();
-        if constexpr (ROT != ROT_CAMFIX) {
-            for (int ch = tid; ch < nchunk; ch += nt) {
-                const int c = CGC[ch];
-                if (ch == 0 || CGC[ch - 1] != c) CST[c] = ch;
-                if (ch == nchunk - 1 || CGC[ch + 1] != c) CEN[c] = ch + 1;
-            }
-        }
         if constexpr (ROT != ROT_PER_FACTOR)
             for (int c = tid; c < ncb; c += nt) store_rotation(X[9 * c], X[9 * c + 1], X[9 * c + 2], ROTR + 7 * c);
         __syncthreads();
     }
 
-    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): full gradient at clamp(p), in two passes.
-    //   1. point-major, like a trial: every lane evaluates its block's factors (forward + adjoint) against the cameras in
-    //      LDS -- coalesced, no indirection.  The block's three point entries are the sums of its factors' point partials
-    //      in slot order, which is factor-list order (src/State.h:157-210): formed in registers, written to the record.
-    //      A factor's nine CAMERA partials go to pm_cgq at the factor's position in the camera-grouped order (an 80-byte
-    //      record; the position comes with the factor's camera and observation: a scattered store nobody waits for).
-    //   2. camera by camera: the gradient pass's order (ls_gperm: factors grouped by camera block, whole wave-chunks per
-    //      camera) with every wave taking a contiguous run of chunks; a lane reads the record at its position -- 64
-    //      neighbours per load, no index: positions that are no factor hold zeros --, keeps adding over the chunks of one
-    //      camera, and the wave reduces once per camera and run.  The run's sums stand at its last chunk of the camera, zeros at the others, so "a camera's
-    //      chunks in order" is the whole sum.
-    // (One workgroup per component; workgroups that share a component use gradient_camera_order below.  1000 components of
-    // ladybug's size: 175.5 ms a launch with this form, 183.6 with the other.)
+    // SubfunctionFD::df(p, xi) (reference .cpp:135-157): the full gradient at clamp(p) in one point-major pass.
+    // Every lane evaluates its block's factors (forward + adjoint) against the cameras in LDS.  The block's three point
+    // entries are the sums of its factors' point partials in slot order, which is factor-list order
+    // (src/State.h:157-210): formed in registers, written to the record.  The camera partials are summed in LDS, round by
+    // round (file header): in round rr a wave evaluates the rr-th of its (chunk, slot) steps and stages its lanes' nine
+    // camera partials at STG[9 lane-of-workgroup ..]; the round's list -- fetched from HBM a round ahead -- names per camera
+    // the staging indices that hold a factor of it, and lane (camera, entry) adds them to the camera's gradient entry.
+    // With no camera variable free (ROT_CAMFIX) there are no rounds: the pass runs like a trial.
     __device__ void gradient_to_xi() {
-        if constexpr (GROUP) gradient_camera_order();
-        else if (L.pm_grad_form != 0) gradient_camera_order();
-        else gradient_two_pass();
-    }
-    __device__ void gradient_two_pass() {
+        constexpr bool CAMS = ROT != ROT_CAMFIX;
         const long long tg0 = clock();
         assign_cameras<AT_LINE>(0.0);
-        const int lane = tid & 63;
-        for (int c = first_chunk(); c < npc; c += chunk_step()) {
-            const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
-            int cn = -1, qn = 0;
-            double2 on = make_double2(0.0, 0.0);
-            if (e0 < e1) { cn = pcam[e0 + lane]; on = pobs[e0 + lane]; qn = gqpos[e0 + lane]; }
-            const int ps = 64 * c + lane;
-            double x[3] = {0.0, 0.0, 0.0};
-            if (ps < npb) point_position(ps, x);
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            for (int e = e0; e < e1; e += 64) {
-                const int cc = cn, q = qn;
-                const double2 o = on;
-                if (e + 64 < e1) { cn = pcam[e + 64 + lane]; on = pobs[e + 64 + lane]; qn = gqpos[e + 64 + lane]; }
+        const int lane = tid & 63, cs = chunk_step();
+        const int nd = rl_stride >> 1;   // a round's list in 32-bit words
+        const unsigned* rsrc = reinterpret_cast<const unsigned*>(rounds);
+        unsigned lv0 = 0u, lv1 = 0u;
+        if constexpr (CAMS) {
+            for (int s = tid; s < 9 * ncb; s += nt) XI[s] = 0.0;   // (a slot's lane here is its lane in every round's sum)
+            if (nrounds > 0) {
+                if (tid < nd) lv0 = rsrc[tid];
+                if (tid + nt < nd) lv1 = rsrc[tid + nt];
+            }
+        }
+        // this wave's chunks, as in eval_line: a block of slots, the next chunk's records and the range of the chunk after
+        // that are asked for a block / a chunk ahead; a round evaluates ONE slot (slot ks of the block at hand)
+        int cu = __builtin_amdgcn_readfirstlane(first_chunk());
+        int e = 0, e1 = 0;
+        if (cu < npc) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
+        bool have = e < e1;
+        int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
+        PtRecs R = {};
+        SlotBlock B = {}, N = {};
+        if (have) {
+            if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
+            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+            load_recs(min(64 * cu + lane, npb - 1), R);
+            load_block(e, N);
+        }
+        bool fresh = true;
+        int ks = 0;
+        double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int rr = 0; CAMS ? rr < nrounds : have; ++rr) {
+            double gq[12];
+            int cc = -1;
+            if (have) {
+                const bool first = fresh;
+                if (ks == 0) {   // a block's first slot
+                    B = N;
+                    if (fresh) {   // ... a chunk's: its blocks' position from the records; the next chunk's records
+                        point_position(R, min(64 * cu + lane, npb - 1), x);
+                        s0 = s1 = s2 = 0.0;
+                        if (ne < ne1) load_recs(min(64 * cx + lane, npb - 1), R);
+                        fresh = false;
+                    }
+                    if (e + 64 * PTM_BLK < e1) load_block(e + 64 * PTM_BLK, N);
+                    else if (ne < ne1) load_block(ne, N);
+                }
+                cc = B.c[0];
+                double2 o = B.o[0];
+#pragma unroll
+                for (int k = 1; k < PTM_BLK; ++k) { cc = ks == k ? B.c[k] : cc; o.x = ks == k ? B.o[k].x : o.x; o.y = ks == k ? B.o[k].y : o.y; }
                 if (cc >= 0) {
-                    double v[12], gq[12];
+                    double v[12];
                     BaFwd t;
                     forward(cc, o, x, v, t);
                     ba_adjoint(t, v, t.res0, t.res1, gq);
-                    s0 = (e == e0) ? gq[9] : s0 + gq[9]; s1 = (e == e0) ? gq[10] : s1 + gq[10]; s2 = (e == e0) ? gq[11] : s2 + gq[11];
-                    if constexpr (ROT != ROT_CAMFIX) {
-                        double2* dst = reinterpret_cast<double2*>(cgq + (long long)CGQ_REC * q);
-                        dst[0] = make_double2(gq[0], gq[1]); dst[1] = make_double2(gq[2], gq[3]);
-                        dst[2] = make_double2(gq[4], gq[5]); dst[3] = make_double2(gq[6], gq[7]);
-                        dst[4] = make_double2(gq[8], 0.0);
+                    s0 = first ? gq[9] : s0 + gq[9]; s1 = first ? gq[10] : s1 + gq[10]; s2 = first ? gq[11] : s2 + gq[11];
+                }
+                ++ks;
+                if (e + 64 * ks >= e1) {   // the chunk's last slot: its blocks' point entries
+                    const int ps = 64 * cu + lane;
+                    if (ps < npb) {
+                        const int* sf = sfree + 9 * ncb + 3 * ps;
+                        double* rec = PT + (long long)PT_REC * ps + 3;
+                        if (sf[0] >= 0) rec[0] = s0;
+                        if (sf[1] >= 0) rec[1] = s1;
+                        if (sf[2] >= 0) rec[2] = s2;
+                    }
+                    have = ne < ne1;
+                    cu = cx; e = ne; e1 = ne1; fresh = true; ks = 0;
+                    cx += cs;
+                    ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);
+                    v0 = v1 = 0;
+                    if (have && cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+                } else if (ks == PTM_BLK) { e += 64 * PTM_BLK; ks = 0; }
+            }
+            if constexpr (CAMS) {
+                __syncthreads();   // the sums of the round before have read the staging area
+                if (cc >= 0) {
+                    double* dst = STG + 9 * tid;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dst[k] = gq[k];
+                }
+                {   // this round's list into LDS, the next one's on its way
+                    unsigned* d = reinterpret_cast<unsigned*>(RL + (rr & 1) * rl_cap);
+                    if (tid < nd) d[tid] = lv0;
+                    if (tid + nt < nd) d[tid + nt] = lv1;
+                    for (int i = tid + 2 * nt; i < nd; i += nt) d[i] = rsrc[(long long)rr * nd + i];
+                    if (rr + 1 < nrounds) {
+                        const unsigned* nx = rsrc + (long long)(rr + 1) * nd;
+                        if (tid < nd) lv0 = nx[tid];
+                        if (tid + nt < nd) lv1 = nx[tid + nt];
                     }
                 }
+                __syncthreads();
+                const unsigned short* seg = RL + (rr & 1) * rl_cap;
+                const unsigned short* lst = seg + ncb + 1;
+                for (int s = tid; s < 9 * ncb; s += nt) {
+                    if (SF[s] < 0) continue;
+                    const int c = s / 9, k = s - 9 * c;
+                    const int b = seg[c], en = seg[c + 1];
+                    double sm = XI[s];
+                    for (int q = b; q < en; ++q) sm += STG[9 * (int)lst[q] + k];
+                    XI[s] = sm;
+                }
             }
+        }
+        // blocks no listed factor reads (free variables only; their chunks stand last): zero entries
+        for (int c = first_chunk(); c < npc; c += cs) {
+            if (cptr[c] < cptr[c + 1]) continue;
+            const int ps = 64 * c + lane;
             if (ps < npb) {
                 const int* sf = sfree + 9 * ncb + 3 * ps;
                 double* rec = PT + (long long)PT_REC * ps + 3;
-                if (sf[0] >= 0) rec[0] = s0;
-                if (sf[1] >= 0) rec[1] = s1;
-                if (sf[2] >= 0) rec[2] = s2;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (sf[k] >= 0) rec[k] = 0.0;
             }
         }
         const long long tg1 = clock();
-        if constexpr (ROT != ROT_CAMFIX) {
-            if constexpr (GROUP) GX.barrier_ordered(); else __syncthreads();   // pm_cgq
-            const int gw = (GROUP ? r * nwaves : 0) + (tid >> 6), gwn = (GROUP ? K : 1) * nwaves;
-            const int ch0 = (int)((long long)gw * nchunk / gwn), ch1 = (int)((long long)(gw + 1) * nchunk / gwn);
-            // (positions that are no factor hold zeros: nothing but the chunk number decides an address; the next chunk's
-            // records are in flight while a chunk is added)
-            double2 nx[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) nx[i] = make_double2(0.0, 0.0);
-            if (ch0 < ch1) {
-                const double2* src = reinterpret_cast<const double2*>(cgq + (long long)CGQ_REC * (64 * ch0 + lane));
-#pragma unroll
-                for (int i = 0; i < 5; ++i) nx[i] = src[i];
-            }
-            double acc[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-            for (int ch = ch0; ch < ch1; ++ch) {
-                double2 cur[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) cur[i] = nx[i];
-                if (ch + 1 < ch1) {
-                    const double2* src = reinterpret_cast<const double2*>(cgq + (long long)CGQ_REC * (64 * (ch + 1) + lane));
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) nx[i] = src[i];
-                }
-                acc[0] += cur[0].x; acc[1] += cur[0].y; acc[2] += cur[1].x; acc[3] += cur[1].y; acc[4] += cur[2].x;
-                acc[5] += cur[2].y; acc[6] += cur[3].x; acc[7] += cur[3].y; acc[8] += cur[4].x;
-                double* dstc = GROUP ? cgg + 9 * ch : CG + 9 * ch;
-                if (ch + 1 == ch1 || CGC[ch + 1] != CGC[ch]) {   // the run's last chunk of this camera (wave-uniform)
-                    double cs[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) { cs[k] = wave_sum(acc[k]); acc[k] = 0.0; }
-                    if (lane < 9) dstc[lane] = pick(cs, lane);
-                } else {
-                    if (lane < 9) dstc[lane] = 0.0;
-                }
-            }
-            if constexpr (GROUP) {
-                GX.barrier_ordered();   // cgg[] of every workgroup
-                for (int q = tid; q < 9 * nchunk; q += nt) CG[q] = cgg[q];
+        __syncthreads();
+        if constexpr (GROUP && CAMS) {   // the workgroups' partial camera gradients, summed in rank order by everybody
+            double* buf = xch + (long long)gpar * K * xch_stride;
+            gpar ^= 1;
+            for (int s = tid; s < 9 * ncb; s += nt) buf[(long long)r * xch_stride + s] = XI[s];
+            GX.barrier_ordered();
+            for (int s = tid; s < 9 * ncb; s += nt) {
+                if (SF[s] < 0) continue;
+                double sm = buf[s];
+                for (int q = 1; q < K; ++q) sm += buf[(long long)q * xch_stride + s];
+                XI[s] = sm;
             }
             __syncthreads();
-            for (int s = tid; s < 9 * ncb; s += nt) {
-                if (SF[s] < 0) continue;
-                const int c = s / 9, k = s - 9 * c;
-                const int b = CST[c], e = CEN[c];
-                double sm = 0.0;
-                for (int q = b; q < e; ++q) sm = (q == b) ? CG[9 * q + k] : sm + CG[9 * q + k];
-                XI[s] = sm;
-            }
         }
-        __syncthreads();
-        tick(4, tg1 - tg0); tick(5, clock() - tg1); tick(10, 1);
-    }
-
-    // The same gradient in ONE pass in camera order, for workgroups that share a component: there the two-pass form's
-    // hand-over of 80 bytes per factor through an ordered grid barrier (a write-back of megabytes of freshly dirtied L2
-    // lines) costs more than it saves -- 125 components of ladybug's size as groups of four: 27.5 ms against 25.7.  Every
-    // wave takes a contiguous run of the camera-grouped chunks; a factor gathers its point's position from the block's
-    // record (read after an ordered barrier: it may belong to another workgroup), its three point partials go to pm_pg at
-    // its point-major entry for the owner, its nine camera partials are added lane-wise over the chunks of one camera and
-    // reduced once per camera and run (sums at the run's last chunk of the camera, zeros at the others); after a second
-    // barrier every workgroup adds up ALL chunks of a camera in chunk order, and every point variable its block's
-    // entries slot by slot (entries that are no factor hold zeros, set once at plan creation).
-    __device__ void gradient_camera_order() {
-        const long long tg0 = clock();
-        assign_cameras<AT_LINE>(0.0);
-        if constexpr (GROUP) GX.barrier_ordered();   // the point records as line_end / init_vectors left them
-        const int lane = tid & 63;
-        const int gw = (GROUP ? r * nwaves : 0) + (tid >> 6), gwn = (GROUP ? K : 1) * nwaves;
-        const int ch0 = (int)((long long)gw * nchunk / gwn), ch1 = (int)((long long)(gw + 1) * nchunk / gwn);
-        // two chunks ahead: the slot word; one chunk ahead: entry, observation and the point's position (its address
-        // comes from the slot word) -- a factor's gathers are in flight while the chunk before it is evaluated
-        unsigned wn = PTM_NO_FACTOR, wnn = PTM_NO_FACTOR;
-        int en = 0;
-        double2 on = make_double2(0.0, 0.0);
-        double xn[3] = {0.0, 0.0, 0.0};
-        if (ch0 < ch1) {
-            wn = gqw[64 * ch0 + lane]; en = gqe[64 * ch0 + lane]; on = gqobs[64 * ch0 + lane];
-            if (ch0 + 1 < ch1) wnn = gqw[64 * (ch0 + 1) + lane];
-            if (wn != PTM_NO_FACTOR) point_position((int)(wn >> 12), xn);
-        }
-        double acc[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-        for (int ch = ch0; ch < ch1; ++ch) {
-            const unsigned w = wn;
-            const int e = en;
-            const double2 o = on;
-            const double x[3] = {xn[0], xn[1], xn[2]};
-            if (ch + 1 < ch1) {
-                wn = wnn; en = gqe[64 * (ch + 1) + lane]; on = gqobs[64 * (ch + 1) + lane];
-                if (ch + 2 < ch1) wnn = gqw[64 * (ch + 2) + lane];
-                if (wn != PTM_NO_FACTOR) point_position((int)(wn >> 12), xn);
-            }
-            if (w != PTM_NO_FACTOR) {
-                double v[12], gq[12];
-                BaFwd t;
-                forward((int)(w & 0xFFFu), o, x, v, t);
-                ba_adjoint(t, v, t.res0, t.res1, gq);
-                double* dst = pg + 3ll * e;
-                dst[0] = gq[9]; dst[1] = gq[10]; dst[2] = gq[11];
-                if constexpr (ROT != ROT_CAMFIX) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) acc[k] += gq[k];
-                }
-            }
-            if constexpr (ROT != ROT_CAMFIX) {
-                double* dstc = GROUP ? cgg + 9 * ch : CG + 9 * ch;
-                if (ch + 1 == ch1 || CGC[ch + 1] != CGC[ch]) {   // the run's last chunk of this camera (wave-uniform)
-                    double cs[9];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) { cs[k] = wave_sum(acc[k]); acc[k] = 0.0; }
-                    if (lane < 9) dstc[lane] = pick(cs, lane);
-                } else {
-                    if (lane < 9) dstc[lane] = 0.0;
-                }
-            }
-        }
-        const long long tg1 = clock();
-        if constexpr (GROUP) {
-            GX.barrier_ordered();   // pm_pg and cgg[] of every workgroup
-            if constexpr (ROT != ROT_CAMFIX)
-                for (int q = tid; q < 9 * nchunk; q += nt) CG[q] = cgg[q];
-        }
-        __syncthreads();
-        if constexpr (ROT != ROT_CAMFIX) {
-            for (int s = tid; s < 9 * ncb; s += nt) {
-                if (SF[s] < 0) continue;
-                const int c = s / 9, k = s - 9 * c;
-                const int b = CST[c], e = CEN[c];
-                double sm = 0.0;
-                for (int q = b; q < e; ++q) sm = (q == b) ? CG[9 * q + k] : sm + CG[9 * q + k];
-                XI[s] = sm;
-            }
-        }
-        for (int c = first_chunk(); c < npc; c += chunk_step()) {
-            const int ps = 64 * c + lane;
-            const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            for (int e = e0; e < e1; e += 64) {
-                const double* src = pg + 3ll * (e + lane);
-                const double a0 = src[0], a1 = src[1], a2 = src[2];
-                s0 = (e == e0) ? a0 : s0 + a0; s1 = (e == e0) ? a1 : s1 + a1; s2 = (e == e0) ? a2 : s2 + a2;
-            }
-            if (ps < npb) {
-                const int* sf = sfree + 9 * ncb + 3 * ps;
-                double* rec = PT + (long long)PT_REC * ps + 3;
-                if (sf[0] >= 0) rec[0] = s0;
-                if (sf[1] >= 0) rec[1] = s1;
-                if (sf[2] >= 0) rec[2] = s2;
-            }
-        }
-        __syncthreads();
         tick(4, tg1 - tg0); tick(5, clock() - tg1); tick(10, 1);
     }
 
@@ -660,37 +628,44 @@ struct PtmEnv {
     }
 };
 
-// LDS of a workgroup: [7 vectors of 9 ncb_cap camera slots][7 ncb_cap rotation records][9 chunk_cap chunk sums]
-// [chunk_cap chunk cameras][2 ncb_cap chunk ranges][9 ncb_cap free indices] (the last three int)
+// LDS of a workgroup (ptm_bytes_for): [7 vectors of 9 ncb_cap camera slots][7 ncb_cap rotation records][9 blockDim staged
+// camera partials][two round lists (16-bit)][9 ncb_cap free indices (int)]
 template <int ROT, bool GROUP>
 __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
-                                                       int ncb_cap, int chunk_cap, int r, int K, SmallCoopState* st, double* bcast,
-                                                       int poll_delay, double* cgg_base) {
+                                                       int ncb_cap, int r, int K, SmallCoopState* st, double* bcast,
+                                                       int poll_delay, double* xch) {
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
     const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp], npb = (ns - 9 * ncb) / 3;
-    const int sc = 9 * ncb_cap;
-    double* CG = lds + PTM_DOUBLES_PER_SLOT * sc + 7 * ncb_cap;
-    int* CGC = (int*)(CG + 9 * chunk_cap);
-    int* CST = CGC + chunk_cap;
-    int* CEN = CST + ncb_cap;
-    int* SF = CEN + ncb_cap;
+    const int sc = 9 * ncb_cap, nt = (int)blockDim.x;
+    double* ROTR = lds + PTM_CAM_VECTORS * sc;
+    double* STG = ROTR + 7 * ncb_cap;
+    unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * nt);
+    const int rl_cap = ptm_round_stride(ncb_cap, nt);
+    int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
     for (int s = threadIdx.x; s < 9 * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     double* ws = L.ws + 5ll * f0;
     const int pb0 = L.pm_pt0[comp];
-    const long long q0 = 64ll * L.ls_gptr[comp];
-    return PtmEnv<ROT, GROUP>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
-                              ncb, npb, (npb + 63) / 64, L.ls_gptr[comp + 1] - L.ls_gptr[comp],
-                              L.pm_gqw + q0, L.pm_gqe + q0, L.pm_gqobs + q0,
+    const unsigned short* rounds = nullptr;
+    int nrounds = 0;
+    if constexpr (ROT != ROT_CAMFIX) {
+        const long long w = (long long)comp * K + r;
+        rounds = L.pm_rounds + L.pm_rd_off[w];
+        nrounds = L.pm_rd_n[w];
+    }
+    return PtmEnv<ROT, GROUP>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
+                              ncb, npb, (npb + 63) / 64,
                               L.ls_vid + s0, L.ls_free + s0,
-                              lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc,
-                              lds + PTM_DOUBLES_PER_SLOT * sc, CG, CGC, CST, CEN, SF,
-                              L.pm_rec + (long long)PT_REC * pb0, L.pm_bnd + (long long)PT_BND * pb0, L.pm_bex + (long long)PT_BND * pb0, L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_pg, L.pm_gqpos, L.pm_cgq + (long long)CGQ_REC * q0,
+                              lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR,
+                              STG, RL, rl_cap, SF,
+                              L.pm_rec + (long long)PT_REC * pb0, L.pm_bnd + (long long)PT_BND * pb0, L.pm_bex + (long long)PT_BND * pb0,
+                              L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs,
+                              rounds, nrounds, ptm_round_stride(ncb, nt),
                               ws + 2ll * n, ws + 3ll * n, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
-                              cgg_base ? cgg_base + 9ll * L.ls_gptr[comp] : nullptr
+                              xch, 9 * ncb_cap, 0
 #ifdef RDIS_COOP_TIMING
                               , {}
 #endif
@@ -699,12 +674,12 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
 
 template <int THREADS, int ROT>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
-cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap, int chunk_cap) {
+cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap) {
     extern __shared__ double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     const int comp = L.order[blockIdx.x];
     // (a component without factors never gets here: it has no slot table and stays with solver_wg.hpp)
-    PtmEnv<ROT, false> E = ptm_env<ROT, false>(P, L, comp, lds_dyn, red, ncb_cap, chunk_cap, 0, 1, nullptr, nullptr, 0, nullptr);
+    PtmEnv<ROT, false> E = ptm_env<ROT, false>(P, L, comp, lds_dyn, red, ncb_cap, 0, 1, nullptr, nullptr, 0, nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
@@ -729,7 +704,7 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
 // the dispatcher is observed to give them (a matter of speed only); blocks beyond the last group leave at once.
 template <int THREADS, int ROT>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
-cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double ftol, int ncb_cap, int chunk_cap) {
+cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double ftol, int ncb_cap) {
     extern __shared__ double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     __shared__ double bcast[8];
@@ -737,7 +712,8 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
     const int grp = (b / (8 * K)) * 8 + (b & 7), r = (b >> 3) % K;
     if (grp >= A.ngroups) return;
     const int comp = L.order[grp];
-    PtmEnv<ROT, true> E = ptm_env<ROT, true>(P, L, comp, lds_dyn, red, ncb_cap, chunk_cap, r, K, A.st + grp, bcast, A.poll_delay, A.cgg);
+    PtmEnv<ROT, true> E = ptm_env<ROT, true>(P, L, comp, lds_dyn, red, ncb_cap, r, K, A.st + grp, bcast, A.poll_delay,
+                                              A.xch ? A.xch + (long long)grp * 2 * K * 9 * ncb_cap : nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
@@ -767,23 +743,6 @@ ptm_gather_kernel(int n, const int* __restrict__ jg, const unsigned* __restrict_
         const int j = jg[i];
         pcam[i] = j >= 0 ? (short)(fidx[j] & 0xFFFu) : (short)-1;
         pobs[i] = j >= 0 ? fobs[j] : make_double2(0.0, 0.0);
-    }
-}
-// ... and the gradient pass's arrays: position q of a component's ls_gperm -> slot word, point-major entry, observation
-__global__ void __launch_bounds__(256)
-ptm_gather_gradient_kernel(PlanView L, const int* __restrict__ eof, unsigned* __restrict__ gqw, int* __restrict__ gqe, double2* __restrict__ gqobs,
-                           int* __restrict__ gqpos) {
-    for (int comp = blockIdx.x; comp < L.ncomp; comp += gridDim.x) {
-        const int c0 = L.fac_ptr[comp];
-        const long long q0 = 64ll * L.ls_gptr[comp], q1 = 64ll * L.ls_gptr[comp + 1];
-        for (long long q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
-            const int jl = L.ls_gperm[q];
-            const int j = jl >= 0 ? c0 + jl : -1;
-            gqw[q] = j >= 0 ? L.ls_fidx[j] : PTM_NO_FACTOR;
-            gqe[q] = j >= 0 ? eof[j] : 0;
-            gqobs[q] = j >= 0 ? L.ls_obs[j] : make_double2(0.0, 0.0);
-            if (j >= 0 && eof[j] >= 0) gqpos[eof[j]] = (int)(q - q0);   // (position within the component's order)
-        }
     }
 }
 

@@ -1244,12 +1244,10 @@ def test_point_major_streaming_solver_alone_and_in_groups(gctx):
     r2 = run({**base, "ptm_threads": 256, "ptm_group": 4})[0]
     assert np.array_equal(r1.fret, r2.fret) and np.array_equal(r1.x, r2.x) and np.array_equal(r1.nfeval, r2.nfeval)
 
-    # a lone workgroup's full gradient in its two forms (two passes / one pass in camera order, option ptm_gradient):
-    # the same sums in the same orders, hence the same bits
-    ra = run({**base, "ptm_threads": 768, "ptm_group": 1, "ptm_gradient": 0})[0]
-    rb = run({**base, "ptm_threads": 768, "ptm_group": 1, "ptm_gradient": 1})[0]
-    assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(ra.nfeval, rb.nfeval)
-    assert np.array_equal(ra.fret, ref[0].fret)
+    # a lone workgroup, run to run: the same bits too (the camera partials of a gradient are summed round by round in LDS,
+    # rounds in order, within a round by wave and lane)
+    ra = run({**base, "ptm_threads": 768, "ptm_group": 1})[0]
+    assert np.array_equal(ra.fret, ref[0].fret) and np.array_equal(ra.x, ref[0].x) and np.array_equal(ra.nfeval, ref[0].nfeval)
 
     # constants among the slots: ladybug's camera components (points fixed) and point components (cameras
     # fixed: rotation records only read, a single point block -- most workgroups of a group own nothing)
