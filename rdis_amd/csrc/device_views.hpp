@@ -84,13 +84,13 @@ struct PlanView {
     const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_cgp, slot-major --
                           // entry pm_cptr[c] + 64 t + lane is the t-th factor of the lane's point block
     double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
-    float* pm_bnd;        // [blocks][6] their bounds lo, hi as floats rounded inward ...
-    double* pm_bex;       // [blocks][6] ... and exact
+    float* pm_cbox;       // [entries of pm_cptr][8] per wave-chunk a box inside the domains of its blocks: lo[3], -, hi[3], - (floats, rounded inward)
+    double* pm_bex;       // [blocks][6] the blocks' exact bounds lo[3], hi[3]
     const short* pm_cam;  // [entries] camera block (number within the component), -1 = no factor ...
     const double2* pm_obs;  // ... and observation of a point's factor
-    // the gradient's round lists (solver_ptm.hpp: gradient_to_xi), for workgroup w = component * K + rank of the launch:
-    const unsigned short* pm_rounds;   // per round ptm_round_stride(ncb, threads) 16-bit words: camera segment starts [ncb + 1],
-                                       // then the staging indices (wave * 64 + lane) that hold a factor, grouped by camera
+    // the gradient's rounds (solver_ptm.hpp: gradient_to_xi), for workgroup w = component * K + rank of the launch:
+    const unsigned short* pm_grow;     // [entries] the factor's staging row in its round: its rank among the round's factors ordered by camera
+    const unsigned short* pm_rounds;   // per round ptm_round_stride(ncb) 16-bit words: per camera the first row of its segment [ncb + 1]
     const long long* pm_rd_off;        // [ncomp * K] a workgroup's first word in pm_rounds ...
     const int* pm_rd_n;                // ... and its number of rounds
     int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...

@@ -20,7 +20,7 @@ namespace rdis_hip {
 // and the fdlibm minimax kernels on [-pi/4, pi/4] with the reduction's tail carried through --
 // below 1 ulp, like the library routine it replaces, at about a third of its instructions and
 // without its large-argument branch.  Beyond the exact range the library is used.
-__device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
+__host__ __device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
 #pragma clang fp contract(on)
     if (!(x < 1.0e6)) { sincos(x, sn, cs); return; }
     const double fn = rint(x * 6.36619772367581382433e-01);
@@ -60,7 +60,7 @@ struct BaFwd {
 // angle-axis vector.  It depends on the camera alone, so a launch whose components leave every
 // camera constant computes it once per camera (camera_rotations_kernel) instead of once per
 // factor and trial point; the arithmetic is the same either way.
-__device__ __forceinline__ void ba_rotation(double r0, double r1, double r2, BaFwd& t) {
+__host__ __device__ __forceinline__ void ba_rotation(double r0, double r1, double r2, BaFwd& t) {
 #pragma clang fp contract(on)
     const double th2 = r0 * r0 + r1 * r1 + r2 * r2;
     t.theta = sqrt(th2);
@@ -79,7 +79,7 @@ __device__ __forceinline__ void ba_rotation(double r0, double r1, double r2, BaF
 
 // ... and the rest, given the rotation fields of t: rotate, translate, project, distort, residual.
 // x[0..2] are not read.
-__device__ __forceinline__ double ba_project(const double (&x)[12], double ox, double oy, BaFwd& t) {
+__host__ __device__ __forceinline__ double ba_project(const double (&x)[12], double ox, double oy, BaFwd& t) {
 #pragma clang fp contract(on)
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     t.w0 = t.v1 * q2 - t.v2 * q1;
@@ -106,7 +106,7 @@ __device__ __forceinline__ double ba_project(const double (&x)[12], double ox, d
     return (t.res0 * t.res0 + t.res1 * t.res1) * 0.5;
 }
 
-__device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, double oy, BaFwd& t) {
+__host__ __device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, double oy, BaFwd& t) {
     ba_rotation(x[0], x[1], x[2], t);
     return ba_project(x, ox, oy, t);
 }
@@ -114,13 +114,13 @@ __device__ __forceinline__ double ba_forward(const double (&x)[12], double ox, d
 // Rotation record of a camera block as camera_rotations_kernel leaves it: seven doubles at the
 // block's first variable id in a shadow array of x.
 constexpr int ROT_V0 = 0, ROT_THETA = 3, ROT_ITHETA = 4, ROT_SIN = 5, ROT_COS = 6;
-__device__ __forceinline__ void store_rotation(double r0, double r1, double r2, double* __restrict__ r) {
+__host__ __device__ __forceinline__ void store_rotation(double r0, double r1, double r2, double* __restrict__ r) {
     BaFwd t;
     ba_rotation(r0, r1, r2, t);
     r[ROT_V0] = t.v0; r[ROT_V0 + 1] = t.v1; r[ROT_V0 + 2] = t.v2;
     r[ROT_THETA] = t.theta; r[ROT_ITHETA] = t.itheta; r[ROT_SIN] = t.s; r[ROT_COS] = t.c;
 }
-__device__ __forceinline__ void ba_load_rotation(const double* __restrict__ r, BaFwd& t) {
+__host__ __device__ __forceinline__ void ba_load_rotation(const double* __restrict__ r, BaFwd& t) {
     t.v0 = r[ROT_V0]; t.v1 = r[ROT_V0 + 1]; t.v2 = r[ROT_V0 + 2];
     t.theta = r[ROT_THETA]; t.itheta = r[ROT_ITHETA]; t.s = r[ROT_SIN]; t.c = r[ROT_COS];
 }
@@ -181,7 +181,7 @@ __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12]
 // per CG iteration, stays with the adjoint).  CAMFIX: the camera's nine entries of d are zero (and
 // are not read).  Same model, differentiated in the other order: agrees with sum_k g_k d_k to rounding.
 template <bool CAMFIX>
-__device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const double (&x)[12], const double (&d)[12]) {
+__host__ __device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const double (&x)[12], const double (&d)[12]) {
 #pragma clang fp contract(on)
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double e0 = d[9], e1 = d[10], e2 = d[11];          // direction of the point
@@ -229,6 +229,108 @@ __device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const double (&x)
     const double fd = x[6] * t.dstn;
     const double dpix0 = scale * t.pp0 + fd * dpp0;
     const double dpix1 = scale * t.pp1 + fd * dpp1;
+    return t.res0 * dpix0 + t.res1 * dpix1;
+}
+
+// ---- a line-search trial in matrix form (solver_ptm.hpp) ----------------------------------------
+// Everything about a camera that is the same for all its factors at one trial point is formed ONCE per camera and trial
+// instead of once per factor: the rotation matrix R of its angle-axis vector (Rodrigues: R = c I + s [v]x + (1 - c) v v^T;
+// I + [r]x at theta = 0, the reference's first-order branch, BundleAdjustmentFactor.cpp:304-329) and, for the slope of a
+// line search, the derivative dR of that matrix along the camera's part of the search direction.  A factor then costs
+//   P = R q + t (9 fused multiply-adds) ... E                                  about 30 fp64 operations + one division,
+//   dP = dR q + R e + dt (18) ... dE/da                                        about 40,
+// where the vector form above (ba_project + ba_slope_dir: cross products, dot products and the chain through the unit
+// axis, per factor) takes about 150: the streaming solver's trials are bound by dependent fp64 issue, not by bytes.
+// Same model, other association of the same sums: values and slopes agree with the vector form to a few ulp of their
+// terms (tests/cpp/factors_forms_test.hip), far inside the 1e-12 the parity tests allow per evaluation.
+// Records (16 doubles each, read by the factors as 16-byte pairs):
+//   TR = [R00 R01 R02 t0 | R10 R11 R12 t1 | R20 R21 R22 t2 | f k1 k2 -]
+//   DR = [dR00 dR01 dR02 dt0 | dR10 ... dt1 | dR20 ... dt2 | df dk1 dk2 -]
+constexpr int CAM_TRIAL = 16;
+// x: the camera's nine values at the trial point [r t f k1 k2]; rot: ba_rotation(x[0..2])
+__host__ __device__ __forceinline__ void ba_camera_trial(const BaFwd& rot, const double (&x)[9], double* __restrict__ TR) {
+#pragma clang fp contract(on)
+    const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2, s = rot.s, c = rot.c;
+    if (rot.theta > 0.0) {
+        const double omc = 1.0 - c;
+        const double a0 = omc * v0, a1 = omc * v1, a2 = omc * v2;
+        TR[0] = c + a0 * v0;      TR[1] = a0 * v1 - s * v2;  TR[2] = a0 * v2 + s * v1;
+        TR[4] = a1 * v0 + s * v2; TR[5] = c + a1 * v1;       TR[6] = a1 * v2 - s * v0;
+        TR[8] = a2 * v0 - s * v1; TR[9] = a2 * v1 + s * v0;  TR[10] = c + a2 * v2;
+    } else {   // P = q + r x q
+        TR[0] = 1.0; TR[1] = -v2; TR[2] = v1;
+        TR[4] = v2;  TR[5] = 1.0; TR[6] = -v0;
+        TR[8] = -v1; TR[9] = v0;  TR[10] = 1.0;
+    }
+    TR[3] = x[3]; TR[7] = x[4]; TR[11] = x[5];
+    TR[12] = x[6]; TR[13] = x[7]; TR[14] = x[8]; TR[15] = 0.0;
+}
+// d: the camera's nine entries of the search direction
+__host__ __device__ __forceinline__ void ba_camera_trial_dir(const BaFwd& rot, const double (&d)[9], double* __restrict__ DR) {
+#pragma clang fp contract(on)
+    const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2, s = rot.s, c = rot.c;
+    if (rot.theta > 0.0) {
+        const double omc = 1.0 - c;
+        const double dth = v0 * d[0] + v1 * d[1] + v2 * d[2];          // d theta = v . dr
+        const double u0 = (d[0] - v0 * dth) * rot.itheta, u1 = (d[1] - v1 * dth) * rot.itheta, u2 = (d[2] - v2 * dth) * rot.itheta;   // dv
+        const double ds = c * dth, dc = -(s * dth), domc = s * dth;
+        const double a0 = omc * v0, a1 = omc * v1, a2 = omc * v2;
+        const double b0 = domc * v0 + omc * u0, b1 = domc * v1 + omc * u1, b2 = domc * v2 + omc * u2;   // d(a)
+        const double w0 = ds * v0 + s * u0, w1 = ds * v1 + s * u1, w2 = ds * v2 + s * u2;               // d(s v)
+        DR[0] = dc + b0 * v0 + a0 * u0;    DR[1] = b0 * v1 + a0 * u1 - w2;  DR[2] = b0 * v2 + a0 * u2 + w1;
+        DR[4] = b1 * v0 + a1 * u0 + w2;    DR[5] = dc + b1 * v1 + a1 * u1;  DR[6] = b1 * v2 + a1 * u2 - w0;
+        DR[8] = b2 * v0 + a2 * u0 - w1;    DR[9] = b2 * v1 + a2 * u1 + w0;  DR[10] = dc + b2 * v2 + a2 * u2;
+    } else {   // d(r x q) = dr x q
+        DR[0] = 0.0;   DR[1] = -d[2]; DR[2] = d[1];
+        DR[4] = d[2];  DR[5] = 0.0;   DR[6] = -d[0];
+        DR[8] = -d[1]; DR[9] = d[0];  DR[10] = 0.0;
+    }
+    DR[3] = d[3]; DR[7] = d[4]; DR[11] = d[5];
+    DR[12] = d[6]; DR[13] = d[7]; DR[14] = d[8]; DR[15] = 0.0;
+}
+struct BaTrial {   // what the slope needs of the value's evaluation
+    double iz, pp0, pp1, r2, dstn, fd, res0, res1;
+};
+// the factor's value at point q against the camera record TR; observation (ox, oy)
+__host__ __device__ __forceinline__ double ba_trial_value(const double (&TR)[CAM_TRIAL], const double (&q)[3], double ox, double oy, BaTrial& t) {
+#pragma clang fp contract(on)
+    const double P0 = TR[0] * q[0] + (TR[1] * q[1] + (TR[2] * q[2] + TR[3]));
+    const double P1 = TR[4] * q[0] + (TR[5] * q[1] + (TR[6] * q[2] + TR[7]));
+    const double P2 = TR[8] * q[0] + (TR[9] * q[1] + (TR[10] * q[2] + TR[11]));
+    t.iz = 1.0 / P2;
+    t.pp0 = -P0 * t.iz;
+    t.pp1 = -P1 * t.iz;
+    t.r2 = t.pp0 * t.pp0 + t.pp1 * t.pp1;
+    t.dstn = 1.0 + t.r2 * (TR[13] + TR[14] * t.r2);
+    t.fd = TR[12] * t.dstn;
+    t.res0 = t.fd * t.pp0 - ox;
+    t.res1 = t.fd * t.pp1 - oy;
+    return (t.res0 * t.res0 + t.res1 * t.res1) * 0.5;
+}
+// ... and its slope along (camera direction as DR, point direction e); CAMFIX: the camera does not move (DR is not read)
+template <bool CAMFIX>
+__host__ __device__ __forceinline__ double ba_trial_slope(const BaTrial& t, const double (&TR)[CAM_TRIAL], const double (&DR)[CAM_TRIAL],
+                                                          const double (&q)[3], const double (&e)[3]) {
+#pragma clang fp contract(on)
+    double dP0 = TR[0] * e[0] + (TR[1] * e[1] + TR[2] * e[2]);
+    double dP1 = TR[4] * e[0] + (TR[5] * e[1] + TR[6] * e[2]);
+    double dP2 = TR[8] * e[0] + (TR[9] * e[1] + TR[10] * e[2]);
+    if constexpr (!CAMFIX) {
+        dP0 += DR[0] * q[0] + (DR[1] * q[1] + (DR[2] * q[2] + DR[3]));
+        dP1 += DR[4] * q[0] + (DR[5] * q[1] + (DR[6] * q[2] + DR[7]));
+        dP2 += DR[8] * q[0] + (DR[9] * q[1] + (DR[10] * q[2] + DR[11]));
+    }
+    const double dpp0 = -(dP0 + t.pp0 * dP2) * t.iz;
+    const double dpp1 = -(dP1 + t.pp1 * dP2) * t.iz;
+    const double dr2 = 2.0 * (t.pp0 * dpp0 + t.pp1 * dpp1);
+    double ddst = dr2 * (TR[13] + 2.0 * TR[14] * t.r2);
+    double scale = TR[12] * ddst;          // d(f dstn) = df dstn + f ddstn
+    if constexpr (!CAMFIX) {
+        ddst += t.r2 * (DR[13] + DR[14] * t.r2);
+        scale = DR[12] * t.dstn + TR[12] * ddst;
+    }
+    const double dpix0 = scale * t.pp0 + t.fd * dpp0;
+    const double dpix1 = scale * t.pp1 + t.fd * dpp1;
     return t.res0 * dpix0 + t.res1 * dpix1;
 }
 

@@ -18,23 +18,32 @@ constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded i
 #endif
 constexpr int PTM_BLK = RDIS_PTM_BLK;  // slots of a point block asked for (and evaluated) together; pm_cam / pm_obs are padded by 64 (PTM_BLK - 1) entries
 constexpr int PTM_CAM_VECTORS = 7;     // LDS vectors over the camera slots: Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
+constexpr int PTM_SPREAD = 16;         // a component's wave-chunks of equal slot count are dealt out over this many runs of the camera-sorted order
 constexpr int PTM_MAX_GROUP = 16;      // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
 constexpr int PTM_MAX_CAMERAS = 4095;  // camera blocks per component (twelve bits of a factor's slot word; two bytes in the trial stream)
 
-// A round list's length in 16-bit words: the segment starts of the component's ncb cameras (ncb + 1 of them) and
-// at most `threads` staging indices, rounded up to whole 32-bit words.
-__host__ __device__ inline int ptm_round_stride(int ncb, int threads) { return (ncb + 1 + threads + 1) & ~1; }
+// A camera block's ten LDS slots: [tx ty tz f k1 k2 | rx ry rz | pad] -- the six values every factor reads first, from a
+// 16-byte boundary (three 16-byte reads; ds_read2_b64 pairs move half as many bytes per LDS cycle, MI355X_MICROARCH.md LDS);
+// variable k of the block (reference order r, t, f, k1, k2: BundleAdjustmentCommon.h:36-59) stands at slot ptm_slot_of(k).
+// Rotation records: seven doubles from a 16-byte boundary, stride eight.
+constexpr int PTM_CS = 10, PTM_ROT0 = 6, PTM_RS = 8;
+__host__ __device__ inline int ptm_slot_of(int k) { return k < 3 ? PTM_ROT0 + k : k - 3; }
+__host__ __device__ inline int ptm_var_of(int slot) { return slot < 6 ? slot + 3 : slot < 9 ? slot - PTM_ROT0 : -1; }   // -1: the pad
 
-// LDS of a workgroup: [7 vectors of 9 ncb_cap camera slots][7 ncb_cap rotation records][threads x 9 staged camera
-// partials][two round lists][9 ncb_cap free indices (int)]
+// A round table's length in 16-bit words: the first staging row of each of the component's ncb cameras and the end of
+// the last (ncb + 1 values), rounded up to whole 32-bit words.
+__host__ __device__ inline int ptm_round_stride(int ncb) { return (ncb + 2) & ~1; }
+
+// LDS of a workgroup: [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records (factors.hpp)][(threads + 1) x 9 staged camera
+// partials][two round tables][10 ncb_cap free indices (int)]
 __host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads) {
-    return (size_t)ncb * 9 * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * 7 * sizeof(double) +
-           (size_t)threads * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb, threads) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
+    return (size_t)ncb * PTM_CS * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * (PTM_RS + 2 * 16) * sizeof(double) +
+           (size_t)(threads + 1) * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
 }
 
 struct PtmGroupArgs {
     SmallCoopState* st;   // one exchange state per group of the launch
-    double* xch;          // [groups][2][K][9 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth)
+    double* xch;          // [groups][2][K][10 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth)
     int K, ngroups;       // workgroups per component, components of the launch
     int poll_delay;
 };

@@ -28,8 +28,7 @@ hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t st
                       int maxiters, double ftol, int ncb_cap) {
     switch (rot) {
         case ROT_CAMFIX: return ptm_launch_rot<ROT_CAMFIX>(threads, grid, dyn, stream, P, V, maxiters, ftol, ncb_cap);
-        case ROT_RECORDS: return ptm_launch_rot<ROT_RECORDS>(threads, grid, dyn, stream, P, V, maxiters, ftol, ncb_cap);
-        default: return ptm_launch_rot<ROT_PER_FACTOR>(threads, grid, dyn, stream, P, V, maxiters, ftol, ncb_cap);
+        default: return ptm_launch_rot<ROT_RECORDS>(threads, grid, dyn, stream, P, V, maxiters, ftol, ncb_cap);
     }
 }
 
@@ -44,8 +43,7 @@ static const void* ptmg_kernel_ptr(int threads) {
 const void* ptmg_kernel_fn(int rot, int threads) {
     switch (rot) {
         case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads);
-        case ROT_RECORDS: return ptmg_kernel_ptr<ROT_RECORDS>(threads);
-        default: return ptmg_kernel_ptr<ROT_PER_FACTOR>(threads);
+        default: return ptmg_kernel_ptr<ROT_RECORDS>(threads);
     }
 }
 

@@ -226,9 +226,10 @@ struct rdis_hip_plan {
     int ptm_ncb_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     ivec h_pm_jg;
-    DevBuf pm_rec, pm_bnd, pm_bex, pm_cam, pm_obs;
+    DevBuf pm_rec, pm_cbox, pm_bex, pm_cam, pm_obs;
+    int64_t pm_cptr_len = 0;          // entries of pm_cptr (a component's wave-chunks + 1)
     // the gradient's round lists (solver_ptm.hpp), built for one workgroup size and group size at a time (ptm_build_rounds)
-    DevBuf pm_rounds, pm_rd_off, pm_rd_n;
+    DevBuf pm_rounds, pm_rd_off, pm_rd_n, pm_grow;
     int rounds_threads = 0, rounds_K = 0;
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
@@ -287,8 +288,8 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
-        v.pm_rec = pm_rec.as<double>(); v.pm_bnd = pm_bnd.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
-        v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
+        v.pm_rec = pm_rec.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
+        v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -1365,14 +1366,54 @@ int prepare_partition(rdis_hip_plan* L) {
                                   ptm_bytes_for(ncb, ptm_max_threads) <= (size_t)LDS_MAX_BYTES;
             if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
             if (fits_lds) std::sort(pts.begin(), pts.end());
-            else {   // by number of factors, descending (ties: ascending id): the lanes of a wave run loops of equal length
+            else {
+                // By number of factors, descending: the lanes of a wave run loops of equal length.  Among blocks of equal
+                // count by their cameras, in listed order, lexicographically: neighbours in a wave-chunk then read the SAME
+                // camera slots at the same time -- one LDS access serves them all, and the few distinct cameras of a chunk
+                // are neighbours too, which keeps them on different banks (random cameras: 54 % of the LDS cycles were bank
+                // conflicts, profiles/r03_a_pmc_lds_synthL.txt).  Ties: ascending id.
                 std::sort(pts.begin(), pts.end());
                 for (int k = 0; k < npb; ++k) p->h_blk_idx[(size_t)pts[(size_t)k]] = k;
-                deg.assign((size_t)npb, 0);
-                for (int j = c0; j < c1; ++j) ++deg[(size_t)p->h_blk_idx[(size_t)p->h_pt[(size_t)L->h_fac_id[(size_t)j]]]];
+                deg.assign((size_t)npb + 1, 0);
+                for (int j = c0; j < c1; ++j) ++deg[(size_t)p->h_blk_idx[(size_t)p->h_pt[(size_t)L->h_fac_id[(size_t)j]]] + 1];
+                for (int k = 0; k < npb; ++k) deg[(size_t)k + 1] += deg[(size_t)k];   // (now a CSR over the blocks in id order)
+                ivec pcam((size_t)m), fill(deg.begin(), deg.end() - 1);
+                for (int j = c0; j < c1; ++j) {
+                    const int f = L->h_fac_id[(size_t)j];
+                    // (camera numbers within the component: h_blk_idx of the camera blocks was set above and is still valid for them)
+                    pcam[(size_t)fill[(size_t)p->h_blk_idx[(size_t)p->h_pt[(size_t)f]]]++] = p->h_blk_idx[(size_t)p->h_cam[(size_t)f]];
+                }
                 ivec ord((size_t)npb);
                 std::iota(ord.begin(), ord.end(), 0);
-                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return deg[(size_t)a] > deg[(size_t)b]; });
+                std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+                    const int da = deg[(size_t)a + 1] - deg[(size_t)a], db = deg[(size_t)b + 1] - deg[(size_t)b];
+                    if (da != db) return da > db;
+                    const int* pa = pcam.data() + deg[(size_t)a];
+                    const int* pb = pcam.data() + deg[(size_t)b];
+                    for (int t = 0; t < da; ++t) if (pa[t] != pb[t]) return pa[t] < pb[t];
+                    return a < b;
+                });
+                // Whole wave-chunks of equal slot count are then dealt out over PTM_SPREAD runs of the sorted order: the chunks
+                // that the waves of a workgroup evaluate at the same time come from different runs and meet different cameras
+                // (the gradient's round sums, solver_ptm.hpp, are as long as a round's longest camera segment).
+                {
+                    const int nfull = npb / 64;
+                    ivec chunk_of((size_t)nfull);
+                    int pos = 0;
+                    for (int a0 = 0; a0 < nfull;) {
+                        const int T = deg[(size_t)ord[(size_t)(64 * a0)] + 1] - deg[(size_t)ord[(size_t)(64 * a0)]];
+                        int a1 = a0;
+                        while (a1 < nfull && deg[(size_t)ord[(size_t)(64 * a1)] + 1] - deg[(size_t)ord[(size_t)(64 * a1)]] == T) ++a1;
+                        const int mm = a1 - a0, q = (mm + PTM_SPREAD - 1) / PTM_SPREAD;
+                        for (int rr = 0; rr < q; ++rr)
+                            for (int gg = 0; gg < PTM_SPREAD; ++gg) { const int idx = gg * q + rr; if (idx < mm) chunk_of[(size_t)pos++] = a0 + idx; }
+                        a0 = a1;
+                    }
+                    ivec ord2(ord);
+                    for (int a = 0; a < nfull; ++a)
+                        for (int l = 0; l < 64; ++l) ord2[(size_t)(64 * a + l)] = ord[(size_t)(64 * chunk_of[(size_t)a] + l)];
+                    ord.swap(ord2);
+                }
                 ivec pts2((size_t)npb);
                 for (int k = 0; k < npb; ++k) pts2[(size_t)k] = pts[(size_t)ord[(size_t)k]];
                 pts.swap(pts2);
@@ -1384,7 +1425,14 @@ int prepare_partition(rdis_hip_plan* L) {
             ivec& sf = free_of[(size_t)cc];
             sv.reserve((size_t)ns); sf.reserve((size_t)ns);
             auto slot = [&](int v) { sv.push_back(v); sf.push_back(p->h_owner_stamp[(size_t)v] == stamp ? p->h_local[(size_t)v] : -1); };
-            for (int b : cams) for (int k = 0; k < 9; ++k) slot(b + k);
+            if (fits_lds) { for (int b : cams) for (int k = 0; k < 9; ++k) slot(b + k); }
+            else {   // the streaming solver's camera slots: ten per block, [t f k1 k2 | r | pad] (ptm_api.hpp)
+                for (int b : cams)
+                    for (int q = 0; q < PTM_CS; ++q) {
+                        const int k = ptm_var_of(q);
+                        if (k >= 0) slot(b + k); else { sv.push_back(b); sf.push_back(-1); }
+                    }
+            }
             for (int b : pts) for (int k = 0; k < 3; ++k) slot(b + k);
             for (int j = c0; j < c1; ++j) {
                 const int f = L->h_fac_id[(size_t)j];
@@ -1455,6 +1503,7 @@ int prepare_partition(rdis_hip_plan* L) {
                 L->pm_blocks += npb;
             }
             L->pm_entries = (int64_t)L->h_pm_jg.size();
+            L->pm_cptr_len = (int64_t)cptr.size();
             L->ls_total_chunks = gptr[nc];
             L->ptm_min_points = INT64_MAX;
             for (size_t cc = 0; cc < nc; ++cc)
@@ -1478,7 +1527,8 @@ int prepare_partition(rdis_hip_plan* L) {
             const bool records = L->lds_rot >= 0 ? L->lds_rot == 1 : L->lds_max_factors > 512;
             // (the stale-cache emulation is instantiated for per-factor rotations only: the same bits per factor, fewer kernels)
             L->lds_rot_mode = (L->camera_records == 0 || L->emulate_stale) ? ROT_PER_FACTOR : camfix_of(r_lds, L->h_rest.size()) ? ROT_CAMFIX : records ? ROT_RECORDS : ROT_PER_FACTOR;
-            L->ptm_rot_mode = L->camera_records == 0 || L->lds_rot == 0 ? ROT_PER_FACTOR : camfix_of(r_ptm, r_lds) ? ROT_CAMFIX : ROT_RECORDS;
+            // (the streaming solver always works from per-camera records: rewritten at every trial point, or never)
+            L->ptm_rot_mode = camfix_of(r_ptm, r_lds) ? ROT_CAMFIX : ROT_RECORDS;
         }
     }
     if (L->rest_tiny > 0 && L->group_blocks4 == 0) {
@@ -1503,7 +1553,7 @@ int prepare_partition(rdis_hip_plan* L) {
     }
     if (L->rest_ptm > 0) {   // the streaming components' point records and point-major factor arrays
         rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
-        if (!rc) rc = plan_alloc(L, L->pm_bnd, (size_t)L->pm_blocks * PT_BND * sizeof(float));
+        if (!rc) rc = plan_alloc(L, L->pm_cbox, (size_t)std::max<int64_t>(L->pm_cptr_len, 1) * 8 * sizeof(float));
         if (!rc) rc = plan_alloc(L, L->pm_bex, (size_t)L->pm_blocks * PT_BND * sizeof(double));
         // (a block of PTM_BLK slots is loaded whole: the last chunk's may reach past the last entry)
         if (!rc) rc = plan_alloc(L, L->pm_cam, ((size_t)L->pm_entries + 64 * PTM_BLK) * sizeof(short));
@@ -1616,13 +1666,13 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
     HIPCHK(c, hipGetLastError());
     return 0;
 }
-// The gradient's round lists of the point-major streaming solver (solver_ptm.hpp: gradient_to_xi) for workgroups of
+// The gradient's rounds of the point-major streaming solver (solver_ptm.hpp: gradient_to_xi) for workgroups of
 // `threads` lanes, K to a component.  Workgroup (component, rank r) takes the point chunks c = r (mod K), its wave w
 // those with (c / K) mod waves = w, slot by slot: that is the wave's sequence of steps, and round rr of the workgroup
-// is every wave's rr-th step.  A round's list: for every camera block of the component the first position of its
-// segment [ncb + 1], then the staging indices (wave * 64 + lane) of the round's factors, grouped by camera, within a
-// camera in ascending order -- the order of the sums.  Built on the host from the plan's point-major tables (two bytes
-// per factor), once per (threads, K); nothing to build when no camera variable is free.
+// is every wave's rr-th step.  Within a round the factors are ranked by camera block (within a camera by wave and
+// lane): a factor's rank is the staging row of its camera partials (pm_grow, two bytes per factor), and a round's
+// table names per camera the first row of its segment [ncb + 1] -- the order of the sums.  Built on the host from the
+// plan's point-major tables, once per (threads, K); nothing to build when no camera variable is free.
 int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->rounds_threads == threads && L->rounds_K == K) return 0;
@@ -1639,15 +1689,15 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     const size_t nwg = (size_t)L->ncomp * (size_t)K;
     std::vector<long long> off(nwg, 0);
     ivec nr(nwg, 0);
-    std::vector<unsigned short> tab;
+    std::vector<unsigned short> tab, grow((size_t)L->pm_entries + 64 * PTM_BLK, 0);
     std::vector<ivec> steps((size_t)nw);
     ivec seg, pos;
     const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
     for (size_t ri = r_ptm; ri < r_lds; ++ri) {
         const int cc = L->h_rest[ri];
-        const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - 9 * ncb) / 3, npc = (npb + 63) / 64;
+        const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - PTM_CS * ncb) / 3, npc = (npb + 63) / 64;
         const int* cp = cptr + pm_ch0[cc];
-        const size_t stride = (size_t)ptm_round_stride(ncb, threads);
+        const size_t stride = (size_t)ptm_round_stride(ncb);
         for (int rk = 0; rk < K; ++rk) {
             size_t nrounds = 0;
             for (int w = 0; w < nw; ++w) {
@@ -1677,17 +1727,19 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
                     const int e = steps[(size_t)w][rr];
                     for (int l = 0; l < 64; ++l) {
                         const int j = jg[e + l];
-                        if (j >= 0) rec[ncb + 1 + pos[(size_t)(fidx[j] & 0xFFFu)]++] = (unsigned short)(64 * w + l);
+                        if (j >= 0) grow[(size_t)(e + l)] = (unsigned short)pos[(size_t)(fidx[j] & 0xFFFu)]++;
                     }
                 }
             }
         }
     }
     int rc = plan_alloc(L, L->pm_rounds, std::max<size_t>(tab.size(), 2) * sizeof(unsigned short));
+    if (!rc) rc = plan_alloc(L, L->pm_grow, grow.size() * sizeof(unsigned short));
     if (!rc) rc = plan_alloc(L, L->pm_rd_off, nwg * sizeof(long long));
     if (!rc) rc = plan_alloc(L, L->pm_rd_n, nwg * sizeof(int));
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(L->pm_rounds.p, tab.data(), tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(L->pm_grow.p, grow.data(), grow.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_off.p, off.data(), nwg * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_n.p, nr.data(), nwg * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host tables go out of scope; a launch on another stream follows)
@@ -1727,7 +1779,7 @@ int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int fir
         rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * sizeof(SmallCoopState));
         if (rc) return rc;
     }
-    const size_t xch_bytes = (size_t)ngroups * 2 * (size_t)K * 9 * (size_t)ncc * sizeof(double);
+    const size_t xch_bytes = (size_t)ngroups * 2 * (size_t)K * PTM_CS * (size_t)ncc * sizeof(double);
     if (L->ptm_xch.bytes < xch_bytes) {
         rc = plan_alloc(L, L->ptm_xch, xch_bytes);
         if (rc) return rc;

@@ -78,13 +78,14 @@ __device__ __forceinline__ float inner_hi32(double hi) {
 struct SlotBlock {
     int c[PTM_BLK];
     double2 o[PTM_BLK];
+    int r[PTM_BLK];   // (the gradient only) the staging row of the factor's camera partials in its round
 };
 // a point block's record and float bounds as loaded (a chunk ahead of their use).  Twelve separate loads on purpose:
 // the values are carried around the chunk loop, and the halves of a 16-byte load's register tuple are not coalesced
 // with loop-carried registers -- the compiler copies them out right behind the load, i.e. waits for it at once.
 struct PtRecs {
     double p[3], xi[3];
-    float lo[3], hi[3];
+    float lo[3], hi[3];   // the chunk's box: inside every block's domain (the same in every lane)
 };
 
 template <int ROT, bool GROUP = false>
@@ -96,17 +97,19 @@ struct PtmEnv {
     const int* svid;          // variable id of a slot (cameras, then points)
     const int* sfree;         // local free index of a slot, -1 = constant (global copy; the cameras' also in SF)
     double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR;   // LDS, cameras (GC, HC: g and h of the recurrence)
-    double* STG;              // LDS [nt][9]: the camera partials of a round's factors, by lane of the workgroup
-    unsigned short* RL;       // LDS [2][rl_cap]: round lists (camera segment starts, then staging indices grouped by camera)
+    double *CTR, *CDR;        // LDS [ncb][16] each: the cameras' trial records at the trial point at hand (factors.hpp: CAM_TRIAL)
+    double* STG;              // LDS [nt + 1][9]: the camera partials of a round's factors, grouped by camera (a factor's row: grow); a row of zeros
+    unsigned short* RL;       // LDS [2][rl_cap]: round tables (per camera the first row of its segment)
     int rl_cap;
     int* SF;                  // LDS: local free index of a camera slot
     double* PT;               // [npb][6] point records: p, xi
-    float* PB;                // [npb][6] their bounds rounded inward (lo, hi)
-    double* PE;               // [npb][6] ... and exact
+    float* CBX;               // [npc][8] per wave-chunk a box inside the domains of all its blocks (lo[3], hi[3] as floats rounded inward)
+    double* PE;               // [npb][6] the blocks' exact bounds (lo[3], hi[3])
     const int* cptr;          // [npc + 1] a point chunk's entries ...
     const short* pcam;        // ... their camera block (-1: none; at most 4095 camera blocks: two bytes a factor and trial)
     const double2* pobs;      // ... their observation
-    const unsigned short* rounds;   // this workgroup's round lists, rl_stride 16-bit words each ...
+    const unsigned short* grow;     // ... the staging row of their camera partials in the gradient's rounds
+    const unsigned short* rounds;   // this workgroup's round tables (per camera the first row of its segment), rl_stride 16-bit words each ...
     int nrounds, rl_stride;         // ... and their number
     double *g, *h;            // plan workspace, by free index (point variables)
     double (*red)[3][MAX_WAVES];
@@ -172,22 +175,44 @@ struct PtmEnv {
         }
     }
 
-    // ---- the cameras' trial point (LDS), as in solver_lds.hpp --------------------------------------
-    template <class At>
+    // ---- the cameras' trial point (LDS) -----------------------------------------------------------------
+    // X = clamp(p + a xi) slot by slot as in solver_lds.hpp; then, a lane per camera with a free variable (the workgroup's
+    // last lanes: its first wave steps the control logic), what the camera's factors read at this trial point:
+    //   TRIAL   the trial records of factors.hpp -- rotation matrix, translation, f, k1, k2 (CTR) and, SLOPE, their derivative
+    //           along the search direction (CDR); a camera without a free variable keeps the records init_vectors gave it;
+    //   !TRIAL  the rotation record (axis, angle, sine, cosine: ROTR) the gradient's forward + adjoint sweep reads.
+    template <bool TRIAL, bool SLOPE, class At>
     __device__ void refresh_records(At at) {
-        if constexpr (ROT == ROT_RECORDS) {
-            for (int c = nt - 1 - tid; c < ncb; c += nt) {
-                const int s = 9 * c;
-                if (SF[s] < 0 && SF[s + 1] < 0 && SF[s + 2] < 0) continue;
-                double rv[3];
+        if constexpr (ROT == ROT_CAMFIX) return;
+        for (int c = nt - 1 - tid; c < ncb; c += nt) {
+            const int s0 = PTM_CS * c;
+            bool any = false;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) rv[k] = SF[s + k] >= 0 ? at(s + k) : Pv[s + k];
-                store_rotation(rv[0], rv[1], rv[2], ROTR + 7 * c);
+            for (int q = 0; q < 9; ++q) any = any || SF[s0 + q] >= 0;
+            if (!any) continue;
+            double xc[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const int s = s0 + ptm_slot_of(k); xc[k] = SF[s] >= 0 ? at(s) : Pv[s]; }
+            BaFwd rot;
+            ba_rotation(xc[0], xc[1], xc[2], rot);
+            if constexpr (TRIAL) {
+                ba_camera_trial(rot, xc, CTR + CAM_TRIAL * c);
+                if constexpr (SLOPE) {
+                    double dc[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dc[k] = XI[s0 + ptm_slot_of(k)];   // (a constant's entry is zero)
+                    ba_camera_trial_dir(rot, dc, CDR + CAM_TRIAL * c);
+                }
+            } else {
+                double* rr = ROTR + PTM_RS * c;
+                rr[ROT_V0] = rot.v0; rr[ROT_V0 + 1] = rot.v1; rr[ROT_V0 + 2] = rot.v2;
+                rr[ROT_THETA] = rot.theta; rr[ROT_ITHETA] = rot.itheta; rr[ROT_SIN] = rot.s; rr[ROT_COS] = rot.c;
             }
         }
     }
     enum : int { AT_LINE = 0, AT_START = 1 };
-    template <int MODE>
+    // RECS: 0 = the gradient's point (rotation records), 1 = a value trial (trial records), 2 = a value + slope trial
+    template <int MODE, int RECS>
     __device__ void assign_cameras(double a) {
 #pragma clang fp contract(off)
         const double* xs = L.xstart + f0;
@@ -196,18 +221,21 @@ struct PtmEnv {
             if constexpr (MODE == AT_START) return clampd(xs[SF[s]], LO[s], HI[s]);
             else { const double t = a * XI[s]; return clampd(Pv[s] + t, LO[s], HI[s]); }
         };
-        for (int s = tid; s < 9 * ncb; s += nt)
-            if (SF[s] >= 0) X[s] = at(s);
-        refresh_records(at);
+        if constexpr (RECS == 0) {   // (the trial records are formed from p, xi and the bounds directly: X is the gradient's)
+            for (int s = tid; s < PTM_CS * ncb; s += nt)
+                if (SF[s] >= 0) X[s] = at(s);
+        }
+        refresh_records<RECS != 0, RECS == 2>(at);
         __syncthreads();
     }
 
     // ---- a point's trial values: clamp(p + a xi) from its record (registers only) -------------------
-    __device__ __forceinline__ void load_recs(int ps, PtRecs& R) const {
-        const double* rec = PT + (long long)PT_REC * ps;
-        const float* bq = PB + (long long)PT_BND * ps;
+    // the records of chunk c (this lane's block: the chunk's last where the chunk has fewer) and the chunk's box
+    __device__ __forceinline__ void load_recs(int c, PtRecs& R) const {
+        const double* rec = PT + (long long)PT_REC * min(64 * c + (tid & 63), npb - 1);
+        const float* bq = CBX + 8 * c;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { R.p[k] = rec[k]; R.xi[k] = rec[3 + k]; R.lo[k] = bq[k]; R.hi[k] = bq[3 + k]; }
+        for (int k = 0; k < 3; ++k) { R.p[k] = rec[k]; R.xi[k] = rec[3 + k]; R.lo[k] = bq[k]; R.hi[k] = bq[4 + k]; }
     }
     // exact clamp of a block's three values that are not all strictly inside the inward-rounded bounds
     __device__ __forceinline__ void clamp_exact(int ps, double (&x)[3]) const {
@@ -247,45 +275,65 @@ struct PtmEnv {
         const double* be = PE + (long long)PT_BND * ps;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int fi = sfree[9 * ncb + 3 * ps + k];
+            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
             x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : rec[k];
         }
     }
     __device__ __forceinline__ double forward(int c, double2 o, const double (&x)[3], double (&v)[12], BaFwd& t) const {
-        const int cb = 9 * c;
-#pragma unroll
-        for (int k = 3; k < 9; ++k) v[k] = X[cb + k];
+        // (16-byte reads: a camera's slots stand [t f k1 k2 | r | pad], ten doubles from a 16-byte boundary)
+        const double2* xc = reinterpret_cast<const double2*>(X + PTM_CS * c);
+        const double2 a0 = xc[0], a1 = xc[1], a2 = xc[2];
+        v[3] = a0.x; v[4] = a0.y; v[5] = a1.x; v[6] = a1.y; v[7] = a2.x; v[8] = a2.y;
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[9 + k] = x[k];
-        if constexpr (ROT == ROT_PER_FACTOR) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = X[cb + k];
-            return ba_forward(v, o.x, o.y, t);
-        } else {
-            v[0] = v[1] = v[2] = 0.0;
-            ba_load_rotation(ROTR + 7 * c, t);
-            return ba_project(v, o.x, o.y, t);
-        }
+        // (the rotation always comes from the camera's record: ROT_RECORDS rewrites it at the gradient's point, ROT_CAMFIX never)
+        v[0] = v[1] = v[2] = 0.0;
+        const double2* rr = reinterpret_cast<const double2*>(ROTR + PTM_RS * c);
+        const double2 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
+        t.v0 = r0.x; t.v1 = r0.y; t.v2 = r1.x; t.theta = r1.y; t.itheta = r2.x; t.s = r2.y; t.c = r3.x;
+        return ba_project(v, o.x, o.y, t);
     }
+    // a factor's value (and slope) at the trial point, from its camera's trial records (factors.hpp: matrix form)
+    // (RDIS_PTM_ABLATE, measurement builds only -- wrong results: 1 = no slope arithmetic, 2 = every factor reads camera 0
+    // (no LDS traffic in the loop), 3 = every block of slots is the component's first (no HBM traffic for the factors))
     __device__ __forceinline__ void factor_trial(int cc, double2 o, const double (&x)[3], const double (&dp)[3], bool slope, double& af, double& as) const {
-        double v[12];
-        BaFwd t;
-        af += forward(cc, o, x, v, t);
+#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 2
+        cc = 0;
+#endif
+#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 1
+        slope = false;
+#endif
+        double TR[CAM_TRIAL], DR[CAM_TRIAL];
+        const double2* tc = reinterpret_cast<const double2*>(CTR + CAM_TRIAL * cc);
+#pragma unroll
+        for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = tc[k]; TR[2 * k] = v.x; TR[2 * k + 1] = v.y; }
+        BaTrial t;
+        af += ba_trial_value(TR, x, o.x, o.y, t);
         if (slope) {
-            double d[12];
+            if constexpr (ROT != ROT_CAMFIX) {
+                const double2* dc = reinterpret_cast<const double2*>(CDR + CAM_TRIAL * cc);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_CAMFIX) ? 0.0 : XI[9 * cc + k];
+                for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) d[9 + k] = dp[k];
-            as += ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
+                for (int k = 0; k < CAM_TRIAL; ++k) DR[k] = 0.0;
+            }
+            as += ba_trial_slope<ROT == ROT_CAMFIX>(t, TR, DR, x, dp);
         }
     }
     // the (camera, observation) entries of PTM_BLK consecutive slots of a chunk, from entry e on (this lane's: e + lane, + 64 per
     // slot).  Unconditional: slots beyond the chunk's last are loaded too (the arrays are padded) and not looked at.
+    template <bool ROWS = false>
     __device__ __forceinline__ void load_block(int e, SlotBlock& B) const {
         const int lane = tid & 63;
+#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 3
+        e = cptr[0] + (e & 64);
+#endif
 #pragma unroll
-        for (int k = 0; k < PTM_BLK; ++k) { B.c[k] = pcam[e + 64 * k + lane]; B.o[k] = pobs[e + 64 * k + lane]; }
+        for (int k = 0; k < PTM_BLK; ++k) {
+            B.c[k] = pcam[e + 64 * k + lane]; B.o[k] = pobs[e + 64 * k + lane];
+            if constexpr (ROWS) B.r[k] = grow[e + 64 * k + lane];
+        }
     }
     // This workgroup's share of the sums at clamp(p + a xi): its point chunks, a block per lane, the block's factors
     // PTM_BLK slots at a time.  Everything is asked for a block of slots before it is used: while one block of slots is
@@ -303,7 +351,7 @@ struct PtmEnv {
         if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
         if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
         PtRecs R;
-        load_recs(min(64 * cu + lane, npb - 1), R);
+        load_recs(cu, R);
         SlotBlock N;
         load_block(e, N);
         bool fresh = true;
@@ -313,7 +361,7 @@ struct PtmEnv {
             const int bn = min(PTM_BLK, (e1 - e) >> 6);
             if (fresh) {   // a chunk's first block: its trial point from the records; the next chunk's records
                 point_line(R, min(64 * cu + lane, npb - 1), a, x, dp);
-                if (ne < ne1) load_recs(min(64 * cx + lane, npb - 1), R);
+                if (ne < ne1) load_recs(cx, R);
                 fresh = false;
             }
             const int en = e + 64 * PTM_BLK;
@@ -359,6 +407,7 @@ struct PtmEnv {
     // trials); 4 / 5 gradient: the rounds / what follows them, 10 their number; 8 / 9 control step / hand-over, 12.. cycles
     // per request kind, 22.. their counts; GROUP: 28 exchanges, 29 publish, 30 sweep, 31 tail of the exchanges
 #ifdef RDIS_COOP_TIMING
+    __device__ long long* wave_cycles() const { return reinterpret_cast<long long*>(STG); }   // (the staging area is idle during trials)
     __device__ void tick(int slot, long long dt) { tmv[slot] += dt; }
     __device__ long long clock() const { return clock64(); }
 #else
@@ -367,26 +416,36 @@ struct PtmEnv {
 #endif
     __device__ double eval_value(double a, bool restore) {
         double af = 0.0, as = 0.0, dummy = 0.0;
-        if (restore) { assign_cameras<AT_START>(0.0); eval_start(af); }
-        else { assign_cameras<AT_LINE>(a); eval_line<false>(a, af, as); }
+        if (restore) { assign_cameras<AT_START, 1>(0.0); eval_start(af); }
+        else { assign_cameras<AT_LINE, 1>(a); eval_line<false>(a, af, as); }
         sumk<1>(af, as, dummy);
         return af;
     }
     __device__ void eval_value_slope(double a, double& f, double& s) {
         double af = 0.0, as = 0.0, dummy = 0.0;
         const long long t0 = clock();
-        assign_cameras<AT_LINE>(a);
+        assign_cameras<AT_LINE, 2>(a);
         const long long t1 = clock();
         eval_line<true>(a, af, as);
         const long long t2 = clock();
+#ifdef RDIS_COOP_TIMING
+        if ((tid & 63) == 0) wave_cycles()[tid >> 6] = t2 - t1;   // (read after the barrier of the sums)
+#endif
         sumk<2>(af, as, dummy);
         f = af; s = as;
         tick(0, t1 - t0); tick(1, t2 - t1); tick(2, clock() - t2); tick(3, 1);
+#ifdef RDIS_COOP_TIMING
+        if (tid == 0) {   // the factor phase by wave: slowest, fastest, mean (slots 20, 6, 21)
+            long long mx = 0, mn = 1ll << 62, sm = 0;
+            for (int w = 0; w < nwaves; ++w) { const long long v = wave_cycles()[w]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
+            tick(20, mx); tick(6, mn); tick(21, sm / nwaves);
+        }
+#endif
     }
 
     __device__ void init_vectors() {   // CGD .cpp:34-39: p = x0 (unclamped); constants hold their assigned value
         const double* xs = L.xstart + f0;
-        for (int s = tid; s < 9 * ncb; s += nt) {
+        for (int s = tid; s < PTM_CS * ncb; s += nt) {
             const int fi = SF[s], v = svid[s];
             if (fi >= 0) {
                 const double lo = P.lo[v], hi = P.hi[v], x0 = xs[fi];
@@ -398,17 +457,50 @@ struct PtmEnv {
             XI[s] = 0.0; GC[s] = 0.0; HC[s] = 0.0;
         }
         my_point_vars([&](int ps, int k) {
-            const int s = 9 * ncb + 3 * ps + k, fi = sfree[s], v = svid[s];
+            const int s = PTM_CS * ncb + 3 * ps + k, fi = sfree[s], v = svid[s];
             double* rec = PT + (long long)PT_REC * ps + k;
             double lo = -__builtin_inf(), hi = __builtin_inf();
             if (fi >= 0) { rec[0] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
             else rec[0] = P.x[v];
             rec[3] = 0.0;
             PE[(long long)PT_BND * ps + k] = lo; PE[(long long)PT_BND * ps + 3 + k] = hi;
-            PB[(long long)PT_BND * ps + k] = inner_lo32(lo); PB[(long long)PT_BND * ps + 3 + k] = inner_hi32(hi);
         });
-        if constexpr (ROT != ROT_PER_FACTOR)
-            for (int c = tid; c < ncb; c += nt) store_rotation(X[9 * c], X[9 * c + 1], X[9 * c + 2], ROTR + 7 * c);
+        // a chunk's box: the largest inner lower bound and the smallest inner upper bound of its blocks (a value strictly
+        // inside it is strictly inside every block's bounds); blocks' own bounds only where a trial value leaves it
+        {
+            const int lane = tid & 63;
+            for (int c = first_chunk(); c < npc; c += chunk_step()) {
+                const int ps = 64 * c + lane;
+                double bl[3], bh[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double lo = -__builtin_inf(), hi = __builtin_inf();
+                    if (ps < npb) {
+                        const int sl = PTM_CS * ncb + 3 * ps + k;
+                        if (sfree[sl] >= 0) { const int v = svid[sl]; lo = P.lo[v]; hi = P.hi[v]; }
+                    }
+                    bl[k] = wave_max((double)inner_lo32(lo));
+                    bh[k] = -wave_max(-(double)inner_hi32(hi));
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { CBX[8 * c + k] = (float)bl[k]; CBX[8 * c + 4 + k] = (float)bh[k]; }
+                }
+            }
+        }
+        __syncthreads();
+        // every camera's records at the start (a camera without a free variable keeps them; its direction record is zero)
+        for (int c = tid; c < ncb; c += nt) {
+            double xc[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) xc[k] = X[PTM_CS * c + ptm_slot_of(k)];
+            store_rotation(xc[0], xc[1], xc[2], ROTR + PTM_RS * c);
+            BaFwd rot;
+            ba_load_rotation(ROTR + PTM_RS * c, rot);
+            ba_camera_trial(rot, xc, CTR + CAM_TRIAL * c);
+#pragma unroll
+            for (int k = 0; k < CAM_TRIAL; ++k) CDR[CAM_TRIAL * c + k] = 0.0;
+        }
         __syncthreads();
     }
 
@@ -423,13 +515,14 @@ struct PtmEnv {
     __device__ void gradient_to_xi() {
         constexpr bool CAMS = ROT != ROT_CAMFIX;
         const long long tg0 = clock();
-        assign_cameras<AT_LINE>(0.0);
+        assign_cameras<AT_LINE, 0>(0.0);
         const int lane = tid & 63, cs = chunk_step();
-        const int nd = rl_stride >> 1;   // a round's list in 32-bit words
+        const int nd = rl_stride >> 1;   // a round's table in 32-bit words
         const unsigned* rsrc = reinterpret_cast<const unsigned*>(rounds);
         unsigned lv0 = 0u, lv1 = 0u;
         if constexpr (CAMS) {
-            for (int s = tid; s < 9 * ncb; s += nt) XI[s] = 0.0;   // (a slot's lane here is its lane in every round's sum)
+            for (int s = tid; s < PTM_CS * ncb; s += nt) XI[s] = 0.0;
+            for (int k = tid; k < 9; k += nt) STG[9 * nt + k] = 0.0;   // (the row that stands for "no factor" in the sums)
             if (nrounds > 0) {
                 if (tid < nd) lv0 = rsrc[tid];
                 if (tid + nt < nd) lv1 = rsrc[tid + nt];
@@ -447,15 +540,15 @@ struct PtmEnv {
         if (have) {
             if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
             if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
-            load_recs(min(64 * cu + lane, npb - 1), R);
-            load_block(e, N);
+            load_recs(cu, R);
+            load_block<CAMS>(e, N);
         }
         bool fresh = true;
         int ks = 0;
         double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0;
         for (int rr = 0; CAMS ? rr < nrounds : have; ++rr) {
             double gq[12];
-            int cc = -1;
+            int cc = -1, row = 0;
             if (have) {
                 const bool first = fresh;
                 if (ks == 0) {   // a block's first slot
@@ -463,16 +556,19 @@ struct PtmEnv {
                     if (fresh) {   // ... a chunk's: its blocks' position from the records; the next chunk's records
                         point_position(R, min(64 * cu + lane, npb - 1), x);
                         s0 = s1 = s2 = 0.0;
-                        if (ne < ne1) load_recs(min(64 * cx + lane, npb - 1), R);
+                        if (ne < ne1) load_recs(cx, R);
                         fresh = false;
                     }
-                    if (e + 64 * PTM_BLK < e1) load_block(e + 64 * PTM_BLK, N);
-                    else if (ne < ne1) load_block(ne, N);
+                    if (e + 64 * PTM_BLK < e1) load_block<CAMS>(e + 64 * PTM_BLK, N);
+                    else if (ne < ne1) load_block<CAMS>(ne, N);
                 }
-                cc = B.c[0];
+                cc = B.c[0]; row = B.r[0];
                 double2 o = B.o[0];
 #pragma unroll
-                for (int k = 1; k < PTM_BLK; ++k) { cc = ks == k ? B.c[k] : cc; o.x = ks == k ? B.o[k].x : o.x; o.y = ks == k ? B.o[k].y : o.y; }
+                for (int k = 1; k < PTM_BLK; ++k) {
+                    cc = ks == k ? B.c[k] : cc; row = ks == k ? B.r[k] : row;
+                    o.x = ks == k ? B.o[k].x : o.x; o.y = ks == k ? B.o[k].y : o.y;
+                }
                 if (cc >= 0) {
                     double v[12];
                     BaFwd t;
@@ -484,7 +580,7 @@ struct PtmEnv {
                 if (e + 64 * ks >= e1) {   // the chunk's last slot: its blocks' point entries
                     const int ps = 64 * cu + lane;
                     if (ps < npb) {
-                        const int* sf = sfree + 9 * ncb + 3 * ps;
+                        const int* sf = sfree + PTM_CS * ncb + 3 * ps;
                         double* rec = PT + (long long)PT_REC * ps + 3;
                         if (sf[0] >= 0) rec[0] = s0;
                         if (sf[1] >= 0) rec[1] = s1;
@@ -500,12 +596,12 @@ struct PtmEnv {
             }
             if constexpr (CAMS) {
                 __syncthreads();   // the sums of the round before have read the staging area
-                if (cc >= 0) {
-                    double* dst = STG + 9 * tid;
+                if (cc >= 0) {     // (its row: the factor's rank among the round's factors in camera order)
+                    double* dst = STG + 9 * row;
 #pragma unroll
                     for (int k = 0; k < 9; ++k) dst[k] = gq[k];
                 }
-                {   // this round's list into LDS, the next one's on its way
+                {   // this round's table into LDS, the next one's on its way
                     unsigned* d = reinterpret_cast<unsigned*>(RL + (rr & 1) * rl_cap);
                     if (tid < nd) d[tid] = lv0;
                     if (tid + nt < nd) d[tid + nt] = lv1;
@@ -517,14 +613,22 @@ struct PtmEnv {
                     }
                 }
                 __syncthreads();
+                // lane (camera c, entry k of its nine): the rows [seg[c], seg[c + 1]) in order, eight loads in flight at a time
                 const unsigned short* seg = RL + (rr & 1) * rl_cap;
-                const unsigned short* lst = seg + ncb + 1;
-                for (int s = tid; s < 9 * ncb; s += nt) {
+                for (int j = tid; j < 9 * ncb; j += nt) {
+                    const int c = j / 9, k = j - 9 * c;
+                    const int s = PTM_CS * c + ptm_slot_of(k);
                     if (SF[s] < 0) continue;
-                    const int c = s / 9, k = s - 9 * c;
                     const int b = seg[c], en = seg[c + 1];
+                    if (b >= en) continue;
                     double sm = XI[s];
-                    for (int q = b; q < en; ++q) sm += STG[9 * (int)lst[q] + k];
+                    for (int q0 = b; q0 < en; q0 += 8) {
+                        double tv[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) tv[t] = STG[9 * (q0 + t < en ? q0 + t : nt) + k];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) sm += tv[t];
+                    }
                     XI[s] = sm;
                 }
             }
@@ -534,7 +638,7 @@ struct PtmEnv {
             if (cptr[c] < cptr[c + 1]) continue;
             const int ps = 64 * c + lane;
             if (ps < npb) {
-                const int* sf = sfree + 9 * ncb + 3 * ps;
+                const int* sf = sfree + PTM_CS * ncb + 3 * ps;
                 double* rec = PT + (long long)PT_REC * ps + 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) if (sf[k] >= 0) rec[k] = 0.0;
@@ -545,9 +649,9 @@ struct PtmEnv {
         if constexpr (GROUP && CAMS) {   // the workgroups' partial camera gradients, summed in rank order by everybody
             double* buf = xch + (long long)gpar * K * xch_stride;
             gpar ^= 1;
-            for (int s = tid; s < 9 * ncb; s += nt) buf[(long long)r * xch_stride + s] = XI[s];
+            for (int s = tid; s < PTM_CS * ncb; s += nt) buf[(long long)r * xch_stride + s] = XI[s];
             GX.barrier_ordered();
-            for (int s = tid; s < 9 * ncb; s += nt) {
+            for (int s = tid; s < PTM_CS * ncb; s += nt) {
                 if (SF[s] < 0) continue;
                 double sm = buf[s];
                 for (int q = 1; q < K; ++q) sm += buf[(long long)q * xch_stride + s];
@@ -564,10 +668,10 @@ struct PtmEnv {
     template <class Fn>
     __device__ __forceinline__ void for_free(Fn fn, bool cameras = true) {
         if (cameras)
-            for (int s = tid; s < 9 * ncb; s += nt)
+            for (int s = tid; s < PTM_CS * ncb; s += nt)
                 if (SF[s] >= 0) fn(SF[s], Pv[s], XI[s], GC[s], HC[s]);
         my_point_vars([&](int ps, int k) {
-            const int fi = sfree[9 * ncb + 3 * ps + k];
+            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
             if (fi < 0) return;
             double* rec = PT + (long long)PT_REC * ps + k;
             fn(fi, rec[0], rec[3], g[fi], h[fi]);
@@ -628,22 +732,24 @@ struct PtmEnv {
     }
 };
 
-// LDS of a workgroup (ptm_bytes_for): [7 vectors of 9 ncb_cap camera slots][7 ncb_cap rotation records][9 blockDim staged
-// camera partials][two round lists (16-bit)][9 ncb_cap free indices (int)]
+// LDS of a workgroup (ptm_bytes_for): [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records][9 (blockDim + 1) staged
+// camera partials][two round lists (16-bit)][10 ncb_cap free indices (int)]
 template <int ROT, bool GROUP>
 __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
                                                        int ncb_cap, int r, int K, SmallCoopState* st, double* bcast,
                                                        int poll_delay, double* xch) {
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
-    const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp], npb = (ns - 9 * ncb) / 3;
-    const int sc = 9 * ncb_cap, nt = (int)blockDim.x;
+    const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp], npb = (ns - PTM_CS * ncb) / 3;
+    const int sc = PTM_CS * ncb_cap, nt = (int)blockDim.x;
     double* ROTR = lds + PTM_CAM_VECTORS * sc;
-    double* STG = ROTR + 7 * ncb_cap;
-    unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * nt);
-    const int rl_cap = ptm_round_stride(ncb_cap, nt);
+    double* CTR = ROTR + PTM_RS * ncb_cap;
+    double* CDR = CTR + CAM_TRIAL * ncb_cap;
+    double* STG = CDR + CAM_TRIAL * ncb_cap;
+    unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * (nt + 1));
+    const int rl_cap = ptm_round_stride(ncb_cap);
     int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
-    for (int s = threadIdx.x; s < 9 * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
+    for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     double* ws = L.ws + 5ll * f0;
     const int pb0 = L.pm_pt0[comp];
@@ -657,15 +763,15 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
     return PtmEnv<ROT, GROUP>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
                               ncb, npb, (npb + 63) / 64,
                               L.ls_vid + s0, L.ls_free + s0,
-                              lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR,
+                              lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR, CTR, CDR,
                               STG, RL, rl_cap, SF,
-                              L.pm_rec + (long long)PT_REC * pb0, L.pm_bnd + (long long)PT_BND * pb0, L.pm_bex + (long long)PT_BND * pb0,
-                              L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs,
-                              rounds, nrounds, ptm_round_stride(ncb, nt),
+                              L.pm_rec + (long long)PT_REC * pb0, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
+                              L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_grow,
+                              rounds, nrounds, ptm_round_stride(ncb),
                               ws + 2ll * n, ws + 3ll * n, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
-                              xch, 9 * ncb_cap, 0
+                              xch, PTM_CS * ncb_cap, 0
 #ifdef RDIS_COOP_TIMING
                               , {}
 #endif
@@ -675,7 +781,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
 template <int THREADS, int ROT>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap) {
-    extern __shared__ double lds_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     const int comp = L.order[blockIdx.x];
     // (a component without factors never gets here: it has no slot table and stays with solver_wg.hpp)
@@ -705,7 +811,7 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
 template <int THREADS, int ROT>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double ftol, int ncb_cap) {
-    extern __shared__ double lds_dyn[];
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     __shared__ double bcast[8];
     const int b = blockIdx.x, K = A.K;
@@ -713,7 +819,7 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
     if (grp >= A.ngroups) return;
     const int comp = L.order[grp];
     PtmEnv<ROT, true> E = ptm_env<ROT, true>(P, L, comp, lds_dyn, red, ncb_cap, r, K, A.st + grp, bcast, A.poll_delay,
-                                              A.xch ? A.xch + (long long)grp * 2 * K * 9 * ncb_cap : nullptr);
+                                              A.xch ? A.xch + (long long)grp * 2 * K * PTM_CS * ncb_cap : nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];

@@ -39,6 +39,15 @@ for opts in sets:
         print("%-40s kernel %8.3f ms  %6.1f GB/s algorithmic (%.3f of 8 TB/s)  group %d  evals/comp %.1f  objective %.10g  exits %s" % (
             opts, best, ab / best / 1e6, ab / best / 1e6 / 8000.0, plan.info("point_major_group"), r.nfeval.mean(), r.fret.sum(),
             dict(zip(*np.unique(r.status & 0xFF, return_counts=True)))), flush=True)
+        if "--stamps" in sys.argv:   # a -DRDIS_COOP_TIMING build: cycle stamps of the launch's first workgroup (solver_ptm.hpp)
+            tm = plan.debug_counters()
+            n = max(int(tm[3]), 1)
+            print("   first workgroup %.3f ms at 2.4 GHz; value+slope trials %d: cameras %.0f, factors %.0f, sums %.0f cycles each" % (tm[7] / 2.4e6, tm[3], tm[0] / n, tm[1] / n, tm[2] / n))
+            print("   the factor phase by wave: fastest %.0f, mean %.0f, slowest %.0f cycles" % (tm[6] / n, tm[21] / n, tm[20] / n))
+            steps = max(int(tm[22] + tm[23] + tm[24] + tm[27]), 1)
+            ng = max(int(tm[10]), 1)
+            print("   control step %.0f cycles, hand-over %.0f (x%d requests); gradient (x%d): rounds %.0f, after %.0f cycles" % (tm[8] / steps, tm[9] / steps, steps, tm[10], tm[4] / ng, tm[5] / ng))
+            print("   per request kind: " + "  ".join("%s %d x %.0f" % (nm, tm[22 + i], tm[12 + i] / max(int(tm[22 + i]), 1)) for i, nm in ((0, "value"), (1, "value+slope"), (2, "gradient"), (5, "line end"))), flush=True)
     except Exception as e:   # an option this build does not know
         print("%-40s failed: %s" % (opts, e), flush=True)
     plan.close()
