@@ -84,6 +84,7 @@ struct PlanView {
     const int* pm_cptr;   // a wave-chunk's factors: entries [pm_cptr[c], pm_cptr[c + 1]) of pm_cam / pm_obs / pm_cgp, slot-major --
                           // entry pm_cptr[c] + 64 t + lane is the t-th factor of the lane's point block
     double* pm_rec;       // [blocks][6] p, xi of a point block's three variables
+    double* pm_gh;        // [blocks][6] g, h of the Polak-Ribiere recurrence for them
     float* pm_cbox;       // [entries of pm_cptr][8] per wave-chunk a box inside the domains of its blocks: lo[3], -, hi[3], - (floats, rounded inward)
     double* pm_bex;       // [blocks][6] the blocks' exact bounds lo[3], hi[3]
     const short* pm_cam;  // [entries] camera block (number within the component), -1 = no factor ...

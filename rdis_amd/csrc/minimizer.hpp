@@ -658,6 +658,10 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 template <class E, class = void> struct EnvNoSkip { static constexpr bool value = false; };
 template <class E> struct EnvNoSkip<E, std::void_t<decltype(E::NOSKIP)>> { static constexpr bool value = E::NOSKIP; };
 
+// Env::FUSED_GRADIENT (optional, default false): the environment offers gradient_fused(line_end, amin, reduce, fp, test, gg, dgg)
+template <class E, class = void> struct EnvFusedGradient { static constexpr bool value = false; };
+template <class E> struct EnvFusedGradient<E, std::void_t<decltype(E::FUSED_GRADIENT)>> { static constexpr bool value = E::FUSED_GRADIENT; };
+
 // Env::SPEC: trial steps evaluated per value+slope request (1 = no speculation).  With SPEC > 1 Env
 // provides eval_value_slope_spec(steps, f, s) for SPEC steps at once and spec_hint() / spec_note().
 template <class Env>
@@ -810,11 +814,18 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
             }
             break;
         case REQ_GRAD:
-            if (flags & RF_PRE_LINE_END) E.line_end(qa);
-            E.gradient_to_xi();
-            if (flags & RF_POST_REDUCE) {
-                E.cg_reduce(uni<Env>(q.b), r0, r1, r2);
-                r0 = uni<Env>(r0); r1 = uni<Env>(r1); r2 = uni<Env>(r2);
+            if constexpr (EnvFusedGradient<Env>::value) {
+                // one pass of the environment over its variables for the three (solver_ptm.hpp: they stream from HBM)
+                const bool red = (flags & RF_POST_REDUCE) != 0;
+                E.gradient_fused((flags & RF_PRE_LINE_END) != 0, qa, red, uni<Env>(q.b), r0, r1, r2);
+                if (red) { r0 = uni<Env>(r0); r1 = uni<Env>(r1); r2 = uni<Env>(r2); }
+            } else {
+                if (flags & RF_PRE_LINE_END) E.line_end(qa);
+                E.gradient_to_xi();
+                if (flags & RF_POST_REDUCE) {
+                    E.cg_reduce(uni<Env>(q.b), r0, r1, r2);
+                    r0 = uni<Env>(r0); r1 = uni<Env>(r1); r2 = uni<Env>(r2);
+                }
             }
             RDIS_TICK_KIND(2);
             break;

@@ -226,7 +226,7 @@ struct rdis_hip_plan {
     int ptm_ncb_cap = 0, ptm_rot_mode = ROT_PER_FACTOR;
     int64_t pm_blocks = 0, pm_entries = 0;
     ivec h_pm_jg;
-    DevBuf pm_rec, pm_cbox, pm_bex, pm_cam, pm_obs;
+    DevBuf pm_rec, pm_gh, pm_cbox, pm_bex, pm_cam, pm_obs;
     int64_t pm_cptr_len = 0;          // entries of pm_cptr (a component's wave-chunks + 1)
     // the gradient's round lists (solver_ptm.hpp), built for one workgroup size and group size at a time (ptm_build_rounds)
     DevBuf pm_rounds, pm_rd_off, pm_rd_n, pm_grow;
@@ -288,7 +288,7 @@ struct rdis_hip_plan {
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
-        v.pm_rec = pm_rec.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
+        v.pm_rec = pm_rec.as<double>(); v.pm_gh = pm_gh.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
@@ -1553,6 +1553,7 @@ int prepare_partition(rdis_hip_plan* L) {
     }
     if (L->rest_ptm > 0) {   // the streaming components' point records and point-major factor arrays
         rc = plan_alloc(L, L->pm_rec, (size_t)L->pm_blocks * PT_REC * sizeof(double));
+        if (!rc) rc = plan_alloc(L, L->pm_gh, (size_t)L->pm_blocks * PT_REC * sizeof(double));
         if (!rc) rc = plan_alloc(L, L->pm_cbox, (size_t)std::max<int64_t>(L->pm_cptr_len, 1) * 8 * sizeof(float));
         if (!rc) rc = plan_alloc(L, L->pm_bex, (size_t)L->pm_blocks * PT_BND * sizeof(double));
         // (a block of PTM_BLK slots is loaded whole: the last chunk's may reach past the last entry)

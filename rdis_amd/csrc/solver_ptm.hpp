@@ -86,6 +86,7 @@ struct SlotBlock {
 struct PtRecs {
     double p[3], xi[3];
     float lo[3], hi[3];   // the chunk's box: inside every block's domain (the same in every lane)
+    double g[3];          // (the gradient pass only) g of the recurrence
 };
 
 template <int ROT, bool GROUP = false>
@@ -111,7 +112,7 @@ struct PtmEnv {
     const unsigned short* grow;     // ... the staging row of their camera partials in the gradient's rounds
     const unsigned short* rounds;   // this workgroup's round tables (per camera the first row of its segment), rl_stride 16-bit words each ...
     int nrounds, rl_stride;         // ... and their number
-    double *g, *h;            // plan workspace, by free index (point variables)
+    double* PG;               // [npb][6] g and h of the recurrence for the blocks' variables
     double (*red)[3][MAX_WAVES];
     int parity;
     double* tr;
@@ -231,11 +232,17 @@ struct PtmEnv {
 
     // ---- a point's trial values: clamp(p + a xi) from its record (registers only) -------------------
     // the records of chunk c (this lane's block: the chunk's last where the chunk has fewer) and the chunk's box
+    template <bool GRAD = false>
     __device__ __forceinline__ void load_recs(int c, PtRecs& R) const {
-        const double* rec = PT + (long long)PT_REC * min(64 * c + (tid & 63), npb - 1);
+        const long long ps = min(64 * c + (tid & 63), npb - 1);
+        const double* rec = PT + PT_REC * ps;
         const float* bq = CBX + 8 * c;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { R.p[k] = rec[k]; R.xi[k] = rec[3 + k]; R.lo[k] = bq[k]; R.hi[k] = bq[4 + k]; }
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) R.g[k] = PG[PT_REC * ps + k];
+        }
     }
     // exact clamp of a block's three values that are not all strictly inside the inward-rounded bounds
     __device__ __forceinline__ void clamp_exact(int ps, double (&x)[3]) const {
@@ -397,6 +404,7 @@ struct PtmEnv {
 
     static constexpr bool UNIFORM = true;
     static constexpr int SPEC = 1;
+    static constexpr bool FUSED_GRADIENT = true;
     __device__ bool stepper() const { return threadIdx.x < 64; }
     __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
     __device__ void sync() const { __syncthreads(); }
@@ -463,6 +471,7 @@ struct PtmEnv {
             if (fi >= 0) { rec[0] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
             else rec[0] = P.x[v];
             rec[3] = 0.0;
+            PG[(long long)PT_REC * ps + k] = 0.0; PG[(long long)PT_REC * ps + 3 + k] = 0.0;
             PE[(long long)PT_BND * ps + k] = lo; PE[(long long)PT_BND * ps + 3 + k] = hi;
         });
         // a chunk's box: the largest inner lower bound and the smallest inner upper bound of its blocks (a value strictly
@@ -512,9 +521,17 @@ struct PtmEnv {
     // camera partials at STG[9 lane-of-workgroup ..]; the round's list -- fetched from HBM a round ahead -- names per camera
     // the staging indices that hold a factor of it, and lane (camera, entry) adds them to the camera's gradient entry.
     // With no camera variable free (ROT_CAMFIX) there are no rounds: the pass runs like a trial.
-    __device__ void gradient_to_xi() {
+    // Fused with the pass (the records are streamed anyway):
+    //   LE   the end of the line search before it (Dlinemethod::linmin, minimize_nrc.h:508-511: xi *= amin, p += xi) -- a block's
+    //        new p is formed from its record, is the gradient's point, and goes back with the block's gradient entries;
+    //   RED  the sums of Frprmn's tests and of gamma behind it (minimize_nrc.h:658-674), a block's terms when its entries are known.
+    __device__ void gradient_to_xi() { double a, b, c; gradient_fused(false, 0.0, false, 0.0, a, b, c); }
+    __device__ void gradient_fused(bool LE, double amin, bool RED, double fp, double& test, double& gg, double& dgg) {
         constexpr bool CAMS = ROT != ROT_CAMFIX;
         const long long tg0 = clock();
+        const double den = fmax(fabs(fp), 1.0);
+        double ra = 0.0, rb = 0.0, rt = 0.0;
+        if (LE) { line_end_cameras(amin); __syncthreads(); }
         assign_cameras<AT_LINE, 0>(0.0);
         const int lane = tid & 63, cs = chunk_step();
         const int nd = rl_stride >> 1;   // a round's table in 32-bit words
@@ -540,12 +557,34 @@ struct PtmEnv {
         if (have) {
             if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
             if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
-            load_recs(cu, R);
+            load_recs<true>(cu, R);
             load_block<CAMS>(e, N);
         }
         bool fresh = true;
         int ks = 0;
-        double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0, pn[3] = {0.0, 0.0, 0.0}, go[3] = {0.0, 0.0, 0.0};
+        // a block's entries are known: its record (new p, gradient), its terms of the sums
+        auto finish_block = [&](int ps, const double (&pnew)[3], const double (&gold)[3], double e0, double e1_, double e2) {
+            const int* sf = sfree + PTM_CS * ncb + 3 * ps;
+            double* rec = PT + (long long)PT_REC * ps;
+            const double en[3] = {sf[0] >= 0 ? e0 : 0.0, sf[1] >= 0 ? e1_ : 0.0, sf[2] >= 0 ? e2 : 0.0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (LE) rec[k] = pnew[k];
+                rec[3 + k] = en[k];
+                if (RED) reduce_term(pnew[k], en[k], gold[k], den, ra, rb, rt);
+            }
+        };
+        auto line_point = [&](const PtRecs& Rc, int psc, double (&pnew)[3], double (&xx)[3]) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double t = Rc.xi[k] * amin;
+                pnew[k] = LE ? Rc.p[k] + t : Rc.p[k];
+                xx[k] = pnew[k];
+            }
+            if (!inside32(Rc, xx)) clamp_exact(psc, xx);
+        };
         for (int rr = 0; CAMS ? rr < nrounds : have; ++rr) {
             double gq[12];
             int cc = -1, row = 0;
@@ -554,9 +593,11 @@ struct PtmEnv {
                 if (ks == 0) {   // a block's first slot
                     B = N;
                     if (fresh) {   // ... a chunk's: its blocks' position from the records; the next chunk's records
-                        point_position(R, min(64 * cu + lane, npb - 1), x);
+                        line_point(R, min(64 * cu + lane, npb - 1), pn, x);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) go[k] = R.g[k];
                         s0 = s1 = s2 = 0.0;
-                        if (ne < ne1) load_recs(cx, R);
+                        if (ne < ne1) load_recs<true>(cx, R);
                         fresh = false;
                     }
                     if (e + 64 * PTM_BLK < e1) load_block<CAMS>(e + 64 * PTM_BLK, N);
@@ -579,13 +620,7 @@ struct PtmEnv {
                 ++ks;
                 if (e + 64 * ks >= e1) {   // the chunk's last slot: its blocks' point entries
                     const int ps = 64 * cu + lane;
-                    if (ps < npb) {
-                        const int* sf = sfree + PTM_CS * ncb + 3 * ps;
-                        double* rec = PT + (long long)PT_REC * ps + 3;
-                        if (sf[0] >= 0) rec[0] = s0;
-                        if (sf[1] >= 0) rec[1] = s1;
-                        if (sf[2] >= 0) rec[2] = s2;
-                    }
+                    if (ps < npb) finish_block(ps, pn, go, s0, s1, s2);
                     have = ne < ne1;
                     cu = cx; e = ne; e1 = ne1; fresh = true; ks = 0;
                     cx += cs;
@@ -638,10 +673,11 @@ struct PtmEnv {
             if (cptr[c] < cptr[c + 1]) continue;
             const int ps = 64 * c + lane;
             if (ps < npb) {
-                const int* sf = sfree + PTM_CS * ncb + 3 * ps;
-                double* rec = PT + (long long)PT_REC * ps + 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) if (sf[k] >= 0) rec[k] = 0.0;
+                PtRecs Rz;
+                load_recs<true>(c, Rz);
+                double pz[3], xz[3];
+                line_point(Rz, ps, pz, xz);
+                finish_block(ps, pz, Rz.g, 0.0, 0.0, 0.0);
             }
         }
         const long long tg1 = clock();
@@ -659,37 +695,67 @@ struct PtmEnv {
             }
             __syncthreads();
         }
+        if (RED) {
+            if (!GROUP || r == 0) camera_pass([&](double& p, double& xi, double& gv, double&) { reduce_term(p, xi, gv, den, ra, rb, rt); });
+            sumk<3>(ra, rb, rt);
+            gg = ra; dgg = rb; test = rt;
+        }
         tick(4, tg1 - tg0); tick(5, clock() - tg1); tick(10, 1);
     }
 
     // ---- the CG recurrence: cameras in LDS (every workgroup of a group keeps them), points in their records --
-    // fn(free index, p, xi, g, h) for the free variables this workgroup updates; cameras = false: the point
-    // variables only (reductions of a group's workgroups other than the first: a camera counts once)
+    // A point block's p, xi stand in its record (PT), g and h of the Polak-Ribiere recurrence in a second record (PG), both
+    // by block: a pass over the point variables is coalesced loads and stores with no index in between (round 3 kept g and h
+    // by free index behind a per-variable table: three dependent round trips per variable, 100 000 cycles a pass).  The
+    // entries of a variable that is not free are zero throughout (xi, g, h) and take part as zeros.
+    // fn(p, xi, g, h) on every camera slot with a free variable
     template <class Fn>
-    __device__ __forceinline__ void for_free(Fn fn, bool cameras = true) {
-        if (cameras)
-            for (int s = tid; s < PTM_CS * ncb; s += nt)
-                if (SF[s] >= 0) fn(SF[s], Pv[s], XI[s], GC[s], HC[s]);
-        my_point_vars([&](int ps, int k) {
-            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
-            if (fi < 0) return;
-            double* rec = PT + (long long)PT_REC * ps + k;
-            fn(fi, rec[0], rec[3], g[fi], h[fi]);
+    __device__ __forceinline__ void camera_pass(Fn fn) {
+        for (int s = tid; s < PTM_CS * ncb; s += nt)
+            if (SF[s] >= 0) fn(Pv[s], XI[s], GC[s], HC[s]);
+    }
+    // ... and on the three variables of every point block of this workgroup; WREC / WGH: the pass changes (p, xi) / (g, h)
+    template <bool WREC, bool WGH, class Fn>
+    __device__ __forceinline__ void point_pass(Fn fn) {
+        my_points([&](int ps) {
+            double2* rec = reinterpret_cast<double2*>(PT + (long long)PT_REC * ps);
+            double2* gh = reinterpret_cast<double2*>(PG + (long long)PT_REC * ps);
+            double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], g0 = gh[0], g1 = gh[1], g2 = gh[2];
+            fn(r0.x, r1.y, g0.x, g1.y); fn(r0.y, r2.x, g0.y, g2.x); fn(r1.x, r2.y, g1.x, g2.y);
+            if constexpr (WREC) { rec[0] = r0; rec[1] = r1; rec[2] = r2; }
+            if constexpr (WGH) { gh[0] = g0; gh[1] = g1; gh[2] = g2; }
         });
     }
     __device__ void cg_start() {
-        for_free([&](int, double&, double& xi, double& gv, double& hv) { const double t = -xi; gv = t; hv = t; xi = t; });
+        auto fn = [&](double&, double& xi, double& gv, double& hv) { const double t = -xi; gv = t; hv = t; xi = t; };
+        camera_pass(fn);
+        point_pass<true, true>(fn);
         __syncthreads();
     }
     __device__ void line_begin() {
-        if (L.vdump != nullptr && lm_count < L.dump_iters) {
+        if (L.vdump != nullptr && lm_count < L.dump_iters) {   // (tests: p and the direction by free index)
             double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;
-            for_free([&](int fi, double& p, double& xi, double&, double&) { d[fi] = p; d[n + fi] = xi; }, !GROUP || r == 0);
+            if (!GROUP || r == 0)
+                for (int s = tid; s < PTM_CS * ncb; s += nt)
+                    if (SF[s] >= 0) { d[SF[s]] = Pv[s]; d[n + SF[s]] = XI[s]; }
+            my_point_vars([&](int ps, int k) {
+                const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
+                if (fi >= 0) { d[fi] = PT[(long long)PT_REC * ps + k]; d[n + fi] = PT[(long long)PT_REC * ps + 3 + k]; }
+            });
         }
         ++lm_count;
     }
+    __device__ void line_end_cameras(double amin) {
+        camera_pass([&](double& p, double& xi, double&, double&) {
+#pragma clang fp contract(off)
+            const double t = xi * amin;
+            xi = t;
+            p = p + t;
+        });
+    }
     __device__ void line_end(double amin) {
-        for_free([&](int, double& p, double& xi, double&, double&) {
+        line_end_cameras(amin);
+        point_pass<true, false>([&](double& p, double& xi, double&, double&) {
 #pragma clang fp contract(off)
             const double t = xi * amin;
             xi = t;
@@ -697,38 +763,50 @@ struct PtmEnv {
         });
         __syncthreads();
     }
+    // the terms of Frprmn's tests and of gamma for one variable (minimize_nrc.h:658-674)
+    static __device__ __forceinline__ void reduce_term(double p, double x, double gi, double den, double& a, double& b, double& t) {
+#pragma clang fp contract(off)
+        t = fmax(t, fabs(x) * fmax(fabs(p), 1.0) / den);
+        a = a + gi * gi;
+        b = b + (x + gi) * x;
+    }
     __device__ void cg_reduce(double fp, double& test, double& gg, double& dgg) {
         const double den = fmax(fabs(fp), 1.0);
         double a = 0.0, b = 0.0, t = 0.0;
-        for_free([&](int, double& p, double& xi, double& gv, double&) {
-#pragma clang fp contract(off)
-            const double x = xi, gi = gv;
-            t = fmax(t, fabs(x) * fmax(fabs(p), 1.0) / den);
-            a = a + gi * gi;
-            b = b + (x + gi) * x;
-        }, !GROUP || r == 0);
+        auto fn = [&](double& p, double& xi, double& gv, double&) { reduce_term(p, xi, gv, den, a, b, t); };
+        if (!GROUP || r == 0) camera_pass(fn);   // (a camera counts once in a group)
+        point_pass<false, false>(fn);
         sumk<3>(a, b, t);
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {
-        for_free([&](int, double&, double& xi, double& gv, double& hv) {
+        auto fn = [&](double&, double& xi, double& gv, double& hv) {
 #pragma clang fp contract(off)
             const double gn = -xi;
             const double hn = gn + gam * hv;
             gv = gn; hv = hn; xi = hn;
-        });
+        };
+        camera_pass(fn);
+        point_pass<true, true>(fn);
         __syncthreads();
     }
     // leave the variables assigned (.cpp:61, :84-86): clamp(p), or clamp(x_init) after the rollback
     __device__ void write_back(bool restore) {
         const double* xs = L.xstart + f0;
-        for_free([&](int fi, double& p, double&, double&, double&) {
+        auto out = [&](int fi, double p) {
             // (lo, hi: from the problem -- the two storage classes need not be told apart here)
             const int v = L.free_vid[f0 + fi];
             const double xv = clampd(restore ? xs[fi] : p, P.lo[v], P.hi[v]);
             P.x[v] = xv;
             L.xout[f0 + fi] = xv;
-        }, !GROUP || r == 0);
+        };
+        if (!GROUP || r == 0)
+            for (int s = tid; s < PTM_CS * ncb; s += nt)
+                if (SF[s] >= 0) out(SF[s], Pv[s]);
+        my_point_vars([&](int ps, int k) {
+            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
+            if (fi >= 0) out(fi, PT[(long long)PT_REC * ps + k]);
+        });
     }
 };
 
@@ -751,7 +829,6 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
     int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
     for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
-    double* ws = L.ws + 5ll * f0;
     const int pb0 = L.pm_pt0[comp];
     const unsigned short* rounds = nullptr;
     int nrounds = 0;
@@ -768,7 +845,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               L.pm_rec + (long long)PT_REC * pb0, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
                               L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_grow,
                               rounds, nrounds, ptm_round_stride(ncb),
-                              ws + 2ll * n, ws + 3ll * n, red, 0,
+                              L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
                               xch, PTM_CS * ncb_cap, 0
