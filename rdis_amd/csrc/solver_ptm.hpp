@@ -213,7 +213,8 @@ struct PtmEnv {
     }
     enum : int { AT_LINE = 0, AT_START = 1 };
     // RECS: 0 = the gradient's point (rotation records), 1 = a value trial (trial records), 2 = a value + slope trial
-    template <int MODE, int RECS>
+    // SYNC = false: the caller's barrier follows (eval_line puts its first loads in front of it)
+    template <int MODE, int RECS, bool SYNC = true>
     __device__ void assign_cameras(double a) {
 #pragma clang fp contract(off)
         const double* xs = L.xstart + f0;
@@ -227,7 +228,7 @@ struct PtmEnv {
                 if (SF[s] >= 0) X[s] = at(s);
         }
         refresh_records<RECS != 0, RECS == 2>(at);
-        __syncthreads();
+        if constexpr (SYNC) __syncthreads();
     }
 
     // ---- a point's trial values: clamp(p + a xi) from its record (registers only) -------------------
@@ -347,20 +348,26 @@ struct PtmEnv {
     // evaluated the next one's cameras and observations are in flight (the next chunk's first block during a chunk's last),
     // from a chunk's first block on the next chunk's point records, and the entry range of the chunk after that.
     // (Chunks stand in descending order of their blocks' factor counts: behind a chunk without factors there is none with.)
+    // The workgroup's barrier behind assign_cameras<.., false> stands in here, behind the first loads: the wave that forms
+    // the cameras' records is the last to arrive, and what the others asked for is on its way meanwhile.
     template <bool SLOPE>
     __device__ __forceinline__ void eval_line(double a, double& af, double& as) {
         const int lane = tid & 63, cs = chunk_step();
         int cu = __builtin_amdgcn_readfirstlane(first_chunk());
-        if (cu >= npc) return;
-        int e = __builtin_amdgcn_readfirstlane(cptr[cu]), e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]);
-        if (e >= e1) return;
+        int e = 0, e1 = 0;
+        if (cu < npc) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
+        const bool work = e < e1;
         int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
-        if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
-        if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
-        PtRecs R;
-        load_recs(cu, R);
-        SlotBlock N;
-        load_block(e, N);
+        PtRecs R = {};
+        SlotBlock N = {};
+        if (work) {
+            if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
+            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+            load_recs(cu, R);
+            load_block(e, N);
+        }
+        __syncthreads();   // the cameras' records of this trial point
+        if (!work) return;
         bool fresh = true;
         double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0};
         for (;;) {
@@ -425,14 +432,14 @@ struct PtmEnv {
     __device__ double eval_value(double a, bool restore) {
         double af = 0.0, as = 0.0, dummy = 0.0;
         if (restore) { assign_cameras<AT_START, 1>(0.0); eval_start(af); }
-        else { assign_cameras<AT_LINE, 1>(a); eval_line<false>(a, af, as); }
+        else { assign_cameras<AT_LINE, 1, false>(a); eval_line<false>(a, af, as); }
         sumk<1>(af, as, dummy);
         return af;
     }
     __device__ void eval_value_slope(double a, double& f, double& s) {
         double af = 0.0, as = 0.0, dummy = 0.0;
         const long long t0 = clock();
-        assign_cameras<AT_LINE, 2>(a);
+        assign_cameras<AT_LINE, 2, false>(a);
         const long long t1 = clock();
         eval_line<true>(a, af, as);
         const long long t2 = clock();
