@@ -203,8 +203,37 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
                         "kernel": "cgd_ptm_kernel / cgd_ptmg_kernel (solver_ptm.hpp)", "kernel_ms_avg": kms / max(steps, 1),
                         "algorithmic_bytes_per_launch": abytes / max(steps, 1), "rank": 0}}
     plan.close()
+    if world == 1:
+        out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"])
     prob.close()
     return out
+
+
+def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
+    """rank 0's share of the fixed decomposition for world = 2, 4, 8, run on THIS one GPU: what one GPU of such a job
+    does per step -- solve + fetch of its own results (the start is resident, as in the block above; the 8-byte
+    all-reduce is not emulated) -- wall clock around exactly `steps` steps after one warm-up, and the ratio to
+    the one-rank step above.  The shard is dist.rank_decomposition's (longest processing time first, identical on
+    every rank); with 125 components a GPU has fewer components than compute units and K workgroups share each."""
+    from rdis_amd.dist import rank_decomposition
+    rows = [{"world": 1, "components_rank0": int(pp.ncomp), "ms_per_step": ms_world1, "ratio_to_world1": 1.0}]
+    for world in (2, 4, 8):
+        fp, fv, cp, ci, mine = rank_decomposition(pp, 0, world)
+        plan = capi.Plan(prob, fp, fv, cp, ci)
+        plan.set_start(pp.x0[fv])
+        plan.solve(maxiters, 3e-8); plan.fetch()
+        t0 = time.perf_counter()
+        kms = 0.0
+        for _ in range(steps):
+            plan.solve(maxiters, 3e-8)
+            r = plan.fetch()
+            kms += plan.last_kernel_ms()[0]
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        rows.append({"world": world, "components_rank0": int(len(mine)), "ms_per_step": ms, "kernel_ms": kms / steps,
+                     "workgroups_per_component": int(plan.info("point_major_group")), "ratio_to_world1": ms_world1 / ms,
+                     "objective_rank0": float(r.fret.sum())})
+        plan.close()
+    return rows
 
 
 def host_cpu():

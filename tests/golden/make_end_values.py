@@ -32,7 +32,7 @@ from oracle import oracle as O          # noqa: E402
 from rdis_amd import problems as P      # noqa: E402
 
 SEED = 20260929
-CONFIGS = {"ladybug_5_30": dict(ncams=5, npts=30, n=128), "ladybug_full": dict(ncams=None, npts=None, n=64)}
+CONFIGS = {"ladybug_5_30": dict(ncams=5, npts=30, n=512), "ladybug_full": dict(ncams=None, npts=None, n=320)}
 
 
 def start(x0, k):

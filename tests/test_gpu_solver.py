@@ -48,7 +48,7 @@ def solve(gctx, pp, maxiters=25, ftol=3e-8, free_vid=None, fac_id=None, x=None, 
     return g, r, tr
 
 
-def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None, iter_tol=1e-11):
+def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None, iter_tol=1e-11, far_tol=1e-6):
     """The oracle re-runs the solve, (a) fed the scalars the device's control logic saw and
     (b) restarted at every line search from the device's own point and direction, so both
     sides evaluate at bit-identical points.  Then over the WHOLE run:
@@ -74,7 +74,7 @@ def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=
     # rep.max_f_bound / max_slope_bound report every difference in units of eps x a first-order
     # rounding bound of the sum at that point (below 1 at ordinary points, up to ~1e3 far out).
     assert rep.max_f_rel_near <= 1e-12 and rep.max_slope_rel_near <= 1e-11, rep
-    assert rep.max_f_rel <= 1e-6 and rep.max_slope_rel <= 1e-6, rep
+    assert rep.max_f_rel <= far_tol and rep.max_slope_rel <= far_tol, rep
     assert rep.max_iter_rel <= iter_tol, rep    # gg, dgg, gradient test
     assert rep.max_vec_rel <= 1e-8, rep         # one iteration of drift in p / xi (inf-norm relative)
     if not (r.status[0] & capi.STATUS_ROLLED_BACK):
@@ -1269,6 +1269,61 @@ def test_point_major_streaming_solver_alone_and_in_groups(gctx):
                 fc = comps[3][comps[2][c]:comps[2][c + 1]]
                 sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
                 check_replay(lb, tr[c], sub, 10, free_vid=fv, fac_id=fc, x=lb.x0[fv], iter_tol=1e-8)
+
+
+def test_point_major_solver_at_the_bench_shape(gctx):
+    """BASELINE config 5, size L -- the shape bench.py's strong-scaling block and its synthetic-L workload time
+    (SURVEY 8d): components of 49 cameras x 7776 points x 4 observations = 31104 factors, 23769 variables, through the
+    kernels those launches use: cgd_ptm_kernel<768, .> with a workgroup per component (what one GPU runs on 1000 of
+    them) and cgd_ptmg_kernel with four workgroups of 256 lanes per component (what a rank of eight runs on its 125).
+    Per configuration: one component replayed by the oracle (bit-identical decisions over all 25 iterations, values and
+    slopes to rounding), every component's returned value against the oracle's objective at the returned point, the
+    variables left assigned, and the same bits from a second run.
+    Reference: src/bundleadjust/BundleAdjustmentFactor.cpp:160-185, 351-554; src/optimizers/CGDSubspaceOptimizer.cpp:19-98."""
+    ncomp = 4
+    syn = P.make_synthetic_ba(ncomp, 49, 7776, obs_per_pt=4)
+    csr = (syn.comp_free_ptr, syn.comp_free_vid, syn.comp_fac_ptr, syn.comp_fac_id)
+    assert syn.nfac == ncomp * 31104 and syn.nvars == ncomp * 23769
+    g = capi.Problem(gctx, syn)
+    orc = O.OracleProblem(syn, emulate_stale_cache=False)
+
+    def run(opts, trace=0):
+        g.set_x(syn.x0)
+        plan = capi.Plan(g, *csr)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        if trace:
+            plan.set_option("trace_records", trace)
+            plan.set_option("dump_iters", 25)
+        plan.set_start(None)
+        plan.solve(25, 3e-8)
+        r = plan.fetch()
+        tr = (plan.get_trace(0, trace)[0], plan.get_vectors(0, 25)) if trace else None
+        info = {k: plan.info(k) for k in ("components_point_major", "point_major_group", "components_cooperative", "components_lds", "components_plain")}
+        x = g.get_x()
+        plan.close()
+        return r, tr, info, x
+
+    base = {"coop_group_min_factors": 0, "coop_min_factors": 0}   # (four components alone would be packed into a cooperative launch)
+    for opts, K in (({"ptm_group": 1}, 1), ({"ptm_group": 4}, 4)):
+        r, tr, info, x = run({**base, **opts}, trace=4096)
+        assert info["components_point_major"] == ncomp and info["point_major_group"] == K, info
+        assert info["components_cooperative"] == 0 and info["components_lds"] == 0 and info["components_plain"] == 0, info
+        assert np.all(r.delta < 0) and np.all((r.status & 0xFF) != 7), (r.status, r.delta)
+        assert np.array_equal(x[csr[1]], r.x)
+        fv, fc = syn.component(0)
+        sub = type("R", (), {"status": r.status[:1], "iters": r.iters[:1], "fret": r.fret[:1]})
+        # (far-out bracketing steps: 31104 factors offer more projections next to their pole than the small cases do --
+        # observed 2e-6 at one such step, 1.3e-14 / 6e-15 at every ordinary point, no decision differs)
+        check_replay(syn, tr, sub, 25, free_vid=fv, fac_id=fc, x=syn.x0[fv], iter_tol=1e-10, far_tol=1e-5)
+        for c in range(ncomp):   # value parity at the end of the device's own trajectory, every component
+            fv, fc = syn.component(c)
+            orc.assign(fv, r.x[csr[0][c]:csr[0][c + 1]])
+            fo = orc.eval(fc)
+            assert abs(fo - r.fret[c]) <= 1e-12 * abs(fo), (K, c, fo, r.fret[c])
+        r2 = run({**base, **opts})[0]
+        assert np.array_equal(r.fret, r2.fret) and np.array_equal(r.x, r2.x) and np.array_equal(r.nfeval, r2.nfeval)
+    g.close()
 
 
 @pytest.mark.parametrize("solver", ["lds", "point-major", "point-major x2", "plain"])
