@@ -264,7 +264,9 @@ int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t valu
 int rdis_hip_plan_get_info(rdis_hip_plan *plan, const char *name, int64_t *value);
 /* device memory the plan holds beyond the problem's (index tables, workspace, per-factor
  * partials, results): what a host-side cache of plans budgets with
- * (rdis::HipCGDSubspaceOptimizer::setPlanCacheBytes) */
+ * (rdis::HipCGDSubspaceOptimizer::setPlanCacheBytes).  The solvers' tables are built on demand: the call builds
+ * them if they do not exist yet (it may return RDIS_HIP_ENOMEM); what the first solve adds for the launch shape
+ * it picks shows in a query after that solve. */
 int rdis_hip_plan_device_bytes(rdis_hip_plan *plan, int64_t *bytes);
 /* device time of the solver kernel(s) of the last plan_solve, measured with HIP
  * events on the launch stream; launches = number of kernel launches it covers */

@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
                                     _i64p, _f64p, _f64p, _u8p]
         L.ro_destroy.argtypes = [C.c_void_p]
         L.ro_set_emulate_stale_cache.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_sum_order.argtypes = [C.c_void_p, C.c_int]
         L.ro_assign.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
         L.ro_get_x.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, _f64p]
         L.ro_eval_factors.restype = C.c_double
@@ -123,7 +124,7 @@ def _opt_i64(a):
 class OracleProblem:
     """CPU oracle instance for one rdis_amd.problems.PackedProblem."""
 
-    def __init__(self, pp, emulate_stale_cache: bool = True, derivative: str = "refchain"):
+    def __init__(self, pp, emulate_stale_cache: bool = True, derivative: str = "refchain", sum_order: str = "list"):
         """derivative: "refchain" = the reference's forward chain operation by operation
         (BundleAdjustmentFactor.cpp:351-554; reproduces the reference's recorded runs bit for bit),
         "adjoint" = the independent reverse sweep (the derivation the device kernels use)"""
@@ -140,6 +141,7 @@ class OracleProblem:
             self.h = L.ro_create_nlp(pp.nvars, x0, lo, hi, pp.nfac, pp.coeff, pp.rowptr, pp.vid,
                                      pp.expo, pp.cons, pp.sine)
         L.ro_set_emulate_stale_cache(self.h, int(emulate_stale_cache))
+        L.ro_set_sum_order(self.h, {"list": 0, "pairwise": 1}[sum_order])   # (an experiment's switch; "list" is the reference's)
         self.set_derivative(derivative)
 
     def set_derivative(self, derivative: str) -> None:

@@ -273,6 +273,7 @@ struct ro_problem {
      * Variable.cpp:66-88) */
     int emulate;
     int ba_deriv;     /* RO_BA_DERIV_REFCHAIN (default) or RO_BA_DERIV_ADJOINT */
+    int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
     double *fcache;
     uint8_t *fdirty;
     int64_t *v2f_ptr, *v2f_idx;
@@ -374,6 +375,11 @@ static double ba_grad(const ro_problem *p, const double x[12], double ox, double
 {
     return p->ba_deriv == RO_BA_DERIV_ADJOINT ? ro_ba_factor_grad(x, ox, oy, g)
                                               : ro_ba_factor_grad_ref(x, ox, oy, g);
+}
+
+void ro_set_sum_order(ro_problem *p, int which)
+{
+    p->sum_order = which;
 }
 
 void ro_set_emulate_stale_cache(ro_problem *p, int on)
@@ -550,8 +556,24 @@ static double factor_value(ro_problem *p, int64_t f)
 
 /* OptimizableFunction::evalFactors (src/OptimizableFunction.cpp:95-135):
  * MinSum product is '+', identity 0, accumulated in list order. */
+static double eval_pairwise(ro_problem *p, int64_t lo, int64_t hi, const int64_t *fac)
+{
+    if (hi - lo <= 64) {
+        double s = 0.0;
+        for (int64_t i = lo; i < hi; ++i) s = s + factor_value(p, fac ? fac[i] : i);
+        return s;
+    }
+    const int64_t mid = lo + (hi - lo) / 2;
+    const double a = eval_pairwise(p, lo, mid, fac);
+    return a + eval_pairwise(p, mid, hi, fac);
+}
+
 double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
 {
+    /* RO_SUM_PAIRWISE: the same terms added as a tree over runs of 64 (an experiment's switch: how the rounding of the
+     * objective sum -- 1e-12 relative in list order over 3e4 terms, 1e-15 as a tree, which is what a device computes --
+     * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
+    if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
     double feval = 0.0;
     for (int64_t i = 0; i < nf; ++i) feval = feval + factor_value(p, fac ? fac[i] : i);
     return feval;

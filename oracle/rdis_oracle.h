@@ -80,6 +80,12 @@ void ro_set_emulate_stale_cache(ro_problem *p, int on);
 /* which of the two derivatives the gradient / solver entry points use.  Default
  * RO_BA_DERIV_REFCHAIN (reference-faithful rounding). */
 void ro_set_ba_derivative(ro_problem *p, int which);
+/* order of the objective's sum over the listed factors: RO_SUM_LIST = list order, one after the other (the
+ * reference, src/OptimizableFunction.cpp:95-135; default), RO_SUM_PAIRWISE = a tree over runs of 64 -- an
+ * experiment's switch (the rounding a device's reduction has), never used to pin anything */
+#define RO_SUM_LIST 0
+#define RO_SUM_PAIRWISE 1
+void ro_set_sum_order(ro_problem *p, int which);
 
 void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val);
 void ro_get_x(const ro_problem *p, int64_t nvid, const int64_t *vid, double *out);

@@ -13,6 +13,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Contraction of a * b + c into one fused multiply-add inside the factor arithmetic: on (the product: a third fewer fp64
+// instructions).  -DRDIS_FACTORS_NO_CONTRACT builds the library with every product rounded before it is added, like the
+// reference's x86-64 build (g++ -O2 emits no FMA) -- a measurement build: over one-ulp-perturbed starts the end values
+// after 25 CG iterations then have the oracle's distribution, while with contraction they have the distribution the
+// ORACLE has when it is compiled with contraction (tests/golden/make_end_values.py).
+#ifdef RDIS_FACTORS_NO_CONTRACT
+#define RDIS_FACTORS_FP_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define RDIS_FACTORS_FP_CONTRACT _Pragma("clang fp contract(on)")
+#endif
+
 namespace rdis_hip {
 
 // sin and cos of a non-negative angle in one pass: Cody-Waite reduction by pi/2 in three pieces
@@ -21,7 +32,7 @@ namespace rdis_hip {
 // below 1 ulp, like the library routine it replaces, at about a third of its instructions and
 // without its large-argument branch.  Beyond the exact range the library is used.
 __host__ __device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     if (!(x < 1.0e6)) { sincos(x, sn, cs); return; }
     const double fn = rint(x * 6.36619772367581382433e-01);
     const int n = (int)fn;
@@ -61,7 +72,7 @@ struct BaFwd {
 // camera constant computes it once per camera (camera_rotations_kernel) instead of once per
 // factor and trial point; the arithmetic is the same either way.
 __host__ __device__ __forceinline__ void ba_rotation(double r0, double r1, double r2, BaFwd& t) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double th2 = r0 * r0 + r1 * r1 + r2 * r2;
     t.theta = sqrt(th2);
     const bool rot = t.theta > 0.0;
@@ -80,7 +91,7 @@ __host__ __device__ __forceinline__ void ba_rotation(double r0, double r1, doubl
 // ... and the rest, given the rotation fields of t: rotate, translate, project, distort, residual.
 // x[0..2] are not read.
 __host__ __device__ __forceinline__ double ba_project(const double (&x)[12], double ox, double oy, BaFwd& t) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     t.w0 = t.v1 * q2 - t.v2 * q1;
     t.w1 = t.v2 * q0 - t.v0 * q2;
@@ -134,7 +145,7 @@ __device__ __forceinline__ double ba_eval(const double (&x)[12], double ox, doub
 // state t.  With (s0, s1) = the residual this is the gradient of E = |res|^2 / 2; with unit
 // seeds it yields the two rows of the residual's Jacobian.
 __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12], double s0, double s1, double (&g)[12]) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double f = x[6];
     const double rp = s0 * t.pp0 + s1 * t.pp1;
@@ -182,7 +193,7 @@ __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12]
 // are not read).  Same model, differentiated in the other order: agrees with sum_k g_k d_k to rounding.
 template <bool CAMFIX>
 __host__ __device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const double (&x)[12], const double (&d)[12]) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double e0 = d[9], e1 = d[10], e2 = d[11];          // direction of the point
     double dP0, dP1, dP2;
@@ -249,7 +260,7 @@ __host__ __device__ __forceinline__ double ba_slope_dir(const BaFwd& t, const do
 constexpr int CAM_TRIAL = 16;
 // x: the camera's nine values at the trial point [r t f k1 k2]; rot: ba_rotation(x[0..2])
 __host__ __device__ __forceinline__ void ba_camera_trial(const BaFwd& rot, const double (&x)[9], double* __restrict__ TR) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2, s = rot.s, c = rot.c;
     if (rot.theta > 0.0) {
         const double omc = 1.0 - c;
@@ -267,7 +278,7 @@ __host__ __device__ __forceinline__ void ba_camera_trial(const BaFwd& rot, const
 }
 // d: the camera's nine entries of the search direction
 __host__ __device__ __forceinline__ void ba_camera_trial_dir(const BaFwd& rot, const double (&d)[9], double* __restrict__ DR) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2, s = rot.s, c = rot.c;
     if (rot.theta > 0.0) {
         const double omc = 1.0 - c;
@@ -293,7 +304,7 @@ struct BaTrial {   // what the slope needs of the value's evaluation
 };
 // the factor's value at point q against the camera record TR; observation (ox, oy)
 __host__ __device__ __forceinline__ double ba_trial_value(const double (&TR)[CAM_TRIAL], const double (&q)[3], double ox, double oy, BaTrial& t) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     const double P0 = TR[0] * q[0] + (TR[1] * q[1] + (TR[2] * q[2] + TR[3]));
     const double P1 = TR[4] * q[0] + (TR[5] * q[1] + (TR[6] * q[2] + TR[7]));
     const double P2 = TR[8] * q[0] + (TR[9] * q[1] + (TR[10] * q[2] + TR[11]));
@@ -311,7 +322,7 @@ __host__ __device__ __forceinline__ double ba_trial_value(const double (&TR)[CAM
 template <bool CAMFIX>
 __host__ __device__ __forceinline__ double ba_trial_slope(const BaTrial& t, const double (&TR)[CAM_TRIAL], const double (&DR)[CAM_TRIAL],
                                                           const double (&q)[3], const double (&e)[3]) {
-#pragma clang fp contract(on)
+RDIS_FACTORS_FP_CONTRACT
     double dP0 = TR[0] * e[0] + (TR[1] * e[1] + TR[2] * e[2]);
     double dP1 = TR[4] * e[0] + (TR[5] * e[1] + TR[6] * e[2]);
     double dP2 = TR[8] * e[0] + (TR[9] * e[1] + TR[10] * e[2]);

@@ -21,6 +21,7 @@
 // k-major so that operand loads are contiguous).  Everything is summed in a fixed order.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <new>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -848,32 +849,21 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                 seen[(size_t)ci] = p;
             }
     }
-    // the camera pairs (a >= b) that share a point, with their (factor of a, factor of b) entries in point order
+    if (opt.model != 1 && opt.model != 2) return fail("lm: residual model must be 1 or 2");
+    if (opt.schur < 0 || opt.schur > 2) return fail("lm: schur must be 0 (auto), 1 (dense) or 2 (sparse)");
+    {   // (before anything sized by the reduced system is built)
+        const double Mp0 = (double)std::max(64, (9 * nca + 63) / 64 * 64);
+        if (Mp0 * Mp0 * 8.0 > 16e9) return fail("lm: reduced system too large");
+    }
+    // the camera pairs (a >= b) that share a point, with their (factor of a, factor of b) entries in point order --
+    // not needed when the dense Schur path is forced; found by sorting (pair, entry) records: memory by the pairs that
+    // occur (the sum of squared point degrees), not by the square of the number of cameras
     std::vector<int> pair_ab, pair_ptr(1, 0), pair_ja, pair_jb;
     int64_t pair_entries = 0;
-    {
-        std::vector<int64_t> cnt((size_t)nca * (size_t)(nca + 1) / 2, 0);
-        auto key = [&](int a, int b) { return (size_t)a * (size_t)(a + 1) / 2 + (size_t)b; };   // a >= b
-        std::vector<int> cams_of_p;
-        for (int pass = 0; pass < 2; ++pass) {
-            std::vector<int64_t> fill;
-            if (pass == 1) {
-                // pairs that occur, in (a, b) order; their ranges
-                std::vector<int64_t> start(cnt.size(), -1);
-                int64_t at = 0;
-                for (int a = 0; a < nca; ++a)
-                    for (int b = 0; b <= a; ++b)
-                        if (cnt[key(a, b)] > 0) {
-                            start[key(a, b)] = at;
-                            pair_ab.push_back(a); pair_ab.push_back(b);
-                            at += cnt[key(a, b)];
-                            pair_ptr.push_back((int)at);
-                        }
-                pair_ja.assign((size_t)at, 0); pair_jb.assign((size_t)at, 0);
-                pair_entries = at;
-                fill.swap(start);
-                cnt.swap(fill);   // cnt now holds the next free entry of every pair
-            }
+    if (opt.schur != 1) {
+        struct PairEntry { int64_t key; int ja, jb; };
+        std::vector<PairEntry> ents;
+        try {
             for (int p = 0; p < npa; ++p) {
                 const int t0 = pt_ptr[(size_t)p], t1 = pt_ptr[(size_t)p + 1];
                 for (int t = t0; t < t1; ++t) {
@@ -882,15 +872,27 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
                     for (int u = t0; u < t1; ++u) {
                         const int jb = pt_list[(size_t)u], b = fci[(size_t)jb];
                         if (b < 0 || b > a) continue;
-                        if (pass == 0) ++cnt[key(a, b)];
-                        else { const int64_t e = cnt[key(a, b)]++; pair_ja[(size_t)e] = ja; pair_jb[(size_t)e] = jb; }
+                        ents.push_back({(int64_t)a * (int64_t)(nca + 1) + b, ja, jb});
                     }
                 }
             }
+            // (stable: within a pair the entries keep their point order -- the order of the sums)
+            std::stable_sort(ents.begin(), ents.end(), [](const PairEntry& x, const PairEntry& y) { return x.key < y.key; });
+            pair_ja.reserve(ents.size()); pair_jb.reserve(ents.size());
+            for (size_t i = 0; i < ents.size(); ++i) {
+                if (i == 0 || ents[i].key != ents[i - 1].key) {
+                    if (i > 0) pair_ptr.push_back((int)i);
+                    pair_ab.push_back((int)(ents[i].key / (nca + 1))); pair_ab.push_back((int)(ents[i].key % (nca + 1)));
+                }
+                pair_ja.push_back(ents[i].ja); pair_jb.push_back(ents[i].jb);
+            }
+            if (!ents.empty()) pair_ptr.push_back((int)ents.size());
+        } catch (const std::bad_alloc&) {
+            return fail("lm: out of host memory for the camera-pair list (schur = 1 selects the dense path)");
         }
+        pair_entries = (int64_t)ents.size();
     }
     Dev D{};
-    if (opt.model != 1 && opt.model != 2) return fail("lm: residual model must be 1 or 2");
     D.P = P; D.nf = (int)nf; D.nca = nca; D.npa = npa; D.R = opt.model;
     D.M = 9 * nca; D.Mp = std::max(64, (D.M + 63) / 64 * 64); D.Kp = std::max(4, (3 * npa + 3) / 4 * 4);
     const int ntile = D.Mp / 64;
@@ -902,7 +904,7 @@ int device_lm_ba(hipStream_t stream, const LmProblem& P, int64_t nfree, const in
     {
         const double sparse_flops = (double)pair_entries * 81.0 * (2.0 * opt.model * opt.model + 1.0) * 2.0;
         const double dense_flops = (double)D.Mp * D.Mp * D.Kp;   // lower triangle, 2 flops per multiply-add
-        D.sparse = opt.schur == 2 || (opt.schur == 0 && sparse_flops * 8.0 < dense_flops) ? 1 : 0;
+        D.sparse = opt.schur == 2 || (opt.schur == 0 && sparse_flops * 8.0 < dense_flops) ? 1 : 0;   // (schur = 1: no pair list, dense)
     }
     if (!D.sparse && (double)D.Mp * D.Kp * 8.0 > 16e9) return fail("lm: reduced system too large for the dense Schur path");
     if ((double)D.Mp * D.Mp * 8.0 > 16e9) return fail("lm: reduced system too large");

@@ -1104,6 +1104,10 @@ namespace {
 int prepare_partition(rdis_hip_plan* L) {
     rdis_hip_ctx* c = L->prob->ctx;
     rdis_hip_problem* p = L->prob;
+    // (the device memory of the items about to be dropped leaves the plan's account with them)
+    auto drop = [&](DevBuf& b) { if (!L->transient && b.owned) L->dev_bytes -= std::min(L->dev_bytes, b.bytes); b.release(); };
+    for (CoopLaunch& cl : L->coop_launches) { drop(cl.groups); drop(cl.wg_group); }
+    for (StreamItem& st : L->stream) drop(st.long_vars);
     L->coop.clear();
     L->h_coop_ints.clear();
     L->coop_launches.clear();
@@ -1570,7 +1574,6 @@ int prepare_partition(rdis_hip_plan* L) {
         HIPCHK(c, hipMemcpyAsync(L->coop_ints.p, L->h_coop_ints.data(), L->h_coop_ints.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
     // cooperative groups, packed into launches of at most `cap` workgroups
-    L->coop_launches.clear();
     size_t max_groups = 1;
     for (size_t i = 0; i < L->coop.size();) {
         CoopLaunch cl;
@@ -2051,6 +2054,9 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
 
 extern "C" int rdis_hip_plan_device_bytes(rdis_hip_plan* L, int64_t* bytes) {
     if (!L || !bytes) return RDIS_HIP_EINVAL;
+    // (the solvers' tables are built on demand: counted once they exist -- built here if they do not yet; what a first
+    // solve adds for its launch shape, e.g. the streaming solver's round tables, shows in a query after that solve)
+    if (L->partition_dirty && !L->transient) { int rc = prepare_partition(L); if (rc) return rc; }
     *bytes = (int64_t)(L->dev_bytes + L->trace.bytes + L->vdump.bytes);
     return 0;
 }

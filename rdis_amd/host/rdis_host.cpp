@@ -113,6 +113,10 @@ OptimizableFunction::~OptimizableFunction() {
     plan_holders_.clear();
     if (prob_) rdis_hip_free_problem(prob_);
     if (ctx_) rdis_hip_destroy(ctx_);
+    for (Replica& r : replicas_) {
+        if (r.prob) rdis_hip_free_problem(r.prob);
+        if (r.ctx) rdis_hip_destroy(r.ctx);
+    }
     for (Variable* v : variables) delete v;
     for (Factor* f : factors) delete f;
 }
@@ -173,11 +177,10 @@ const OptimizableFunction::Packed& OptimizableFunction::packed() const {
 
 void OptimizableFunction::initDevice(int device) { device_ = device; ensureUploaded(); }
 
-void OptimizableFunction::ensureUploaded() const {
-    if (prob_) return;
+void OptimizableFunction::uploadTo(int device, rdis_hip_ctx*& ctx, rdis_hip_problem*& prob) const {
     const Packed& P = packed();
-    if (!ctx_) {
-        int rc = rdis_hip_create(device_, &ctx_);
+    if (!ctx) {
+        int rc = rdis_hip_create(device, &ctx);
         if (rc != 0) throw HipError(rc, "rdis_hip_create failed: no usable MI355X / HIP runtime (there is no CPU fallback)");
     }
     const size_t N = variables.size();
@@ -185,20 +188,65 @@ void OptimizableFunction::ensureUploaded() const {
     for (size_t i = 0; i < N; ++i) if (variables[i]->assigned_) x0[i] = variables[i]->value_;
     int rc;
     if (P.kind == 0)
-        rc = rdis_hip_upload_ba(ctx_, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
-                                P.cam_vid0.data(), P.pt_vid0.data(), P.obs.data(), &prob_);
+        rc = rdis_hip_upload_ba(ctx, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
+                                P.cam_vid0.data(), P.pt_vid0.data(), P.obs.data(), &prob);
     else
-        rc = rdis_hip_upload_nlp(ctx_, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
+        rc = rdis_hip_upload_nlp(ctx, (int64_t)N, x0.data(), P.lo.data(), P.hi.data(), (int64_t)factors.size(),
                                  P.coeff.data(), P.rowptr.data(), P.vid.data(), P.expo.data(), P.cons.data(),
-                                 P.sine.data(), &prob_);
-    check(ctx_, rc, "upload");
+                                 P.sine.data(), &prob);
+    check(ctx, rc, "upload");
+}
+
+void OptimizableFunction::ensureUploaded() const {
+    if (prob_) return;
+    uploadTo(device_, ctx_, prob_);
     dirty_.clear();
-    is_dirty_.assign(N, 0);
+    is_dirty_.assign(variables.size(), 0);
+}
+
+void OptimizableFunction::setDevices(const std::vector<int>& devices) {
+    if (devices.empty()) throw std::invalid_argument("setDevices: empty device list");
+    if (prob_ || !replicas_.empty()) throw std::logic_error("setDevices: the function is on a device already");
+    device_ = devices[0];
+    replicas_.resize(devices.size() - 1);
+    for (size_t d = 1; d < devices.size(); ++d) replicas_[d - 1].device = devices[d];
 }
 
 void OptimizableFunction::markDirty(VariableID id) const {
-    if (!prob_) return;  // everything is uploaded at first use
-    if (!is_dirty_[(size_t)id]) { is_dirty_[(size_t)id] = 1; dirty_.push_back(id); }
+    if (prob_ && !is_dirty_[(size_t)id]) { is_dirty_[(size_t)id] = 1; dirty_.push_back(id); }   // (everything is uploaded at first use)
+    for (Replica& r : replicas_)
+        if (r.prob && !r.is_dirty[(size_t)id]) { r.is_dirty[(size_t)id] = 1; r.dirty.push_back(id); }
+}
+
+void OptimizableFunction::markDirtyElsewhere(VariableID id, size_t holder) const {
+    if (holder != 0 && prob_ && !is_dirty_[(size_t)id]) { is_dirty_[(size_t)id] = 1; dirty_.push_back(id); }
+    for (size_t d = 1; d <= replicas_.size(); ++d) {
+        Replica& r = replicas_[d - 1];
+        if (d != holder && r.prob && !r.is_dirty[(size_t)id]) { r.is_dirty[(size_t)id] = 1; r.dirty.push_back(id); }
+    }
+}
+
+rdis_hip_problem* OptimizableFunction::deviceProblem(size_t d) const {
+    if (d == 0) return deviceProblem();
+    Replica& r = replicas_.at(d - 1);
+    if (!r.prob) {
+        uploadTo(r.device, r.ctx, r.prob);
+        r.dirty.clear();
+        r.is_dirty.assign(variables.size(), 0);
+    }
+    if (!r.dirty.empty()) {
+        std::vector<int64_t> ids(r.dirty.begin(), r.dirty.end());
+        std::vector<double> vals(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) { vals[i] = variables[(size_t)ids[i]]->value_; r.is_dirty[(size_t)ids[i]] = 0; }
+        r.dirty.clear();
+        check(r.ctx, rdis_hip_set_x(r.prob, (int64_t)ids.size(), ids.data(), vals.data()), "set_x");
+    }
+    return r.prob;
+}
+rdis_hip_ctx* OptimizableFunction::deviceContext(size_t d) const {
+    if (d == 0) return deviceContext();
+    (void)deviceProblem(d);
+    return replicas_.at(d - 1).ctx;
 }
 
 void OptimizableFunction::pushAssignments() const {
@@ -265,6 +313,7 @@ void OptimizableFunction::adoptDeviceValues(const std::vector<int64_t>& vids, co
         Variable* v = variables[(size_t)vids[i]];
         v->assigned_ = true; v->value_ = vals[i];
         onVarAssigned(v->getID(), vals[i]);
+        if (!replicas_.empty()) markDirtyElsewhere(v->getID(), 0);   // (the primary assigned them)
     }
 }
 
@@ -444,6 +493,8 @@ void SubspaceOptimizer::setParameters(const Options& options) {
 
 // ------------------------------------------------------------------ HipCGDSubspaceOptimizer
 struct HipCGDSubspaceOptimizer::CachedPlan {
+    size_t dev = 0;   // the device (OptimizableFunction::setDevices) the plan lives on
+    bool busy = false;   // a shard of the call in progress uses it
     unsigned long long hash = 0, used = 0;
     int64_t bytes = 0;
     std::vector<int64_t> free_ptr, free_vid, fac_ptr, fac_id;
@@ -477,10 +528,22 @@ void HipCGDSubspaceOptimizer::dropPlans() {
     cache_bytes_ = 0;
 }
 
-bool HipCGDSubspaceOptimizer::evictOne() {   // least recently used goes
-    if (cache_.empty()) return false;
-    size_t lru = 0;
-    for (size_t i = 1; i < cache_.size(); ++i) if (cache_[i]->used < cache_[lru]->used) lru = i;
+void HipCGDSubspaceOptimizer::forget(CachedPlan* e) {
+    for (size_t i = 0; i < cache_.size(); ++i)
+        if (cache_[i] == e) {
+            if (e->plan) rdis_hip_plan_destroy(e->plan);
+            cache_bytes_ -= std::min<size_t>(cache_bytes_, (size_t)e->bytes);
+            delete e;
+            cache_.erase(cache_.begin() + (long)i);
+            return;
+        }
+}
+
+bool HipCGDSubspaceOptimizer::evictOne(const CachedPlan* keep) {   // least recently used goes (never `keep`)
+    size_t lru = cache_.size();
+    for (size_t i = 0; i < cache_.size(); ++i)
+        if (cache_[i] != keep && !cache_[i]->busy && (lru == cache_.size() || cache_[i]->used < cache_[lru]->used)) lru = i;
+    if (lru == cache_.size()) return false;
     if (cache_[lru]->plan) rdis_hip_plan_destroy(cache_[lru]->plan);
     cache_bytes_ -= std::min<size_t>(cache_bytes_, (size_t)cache_[lru]->bytes);
     delete cache_[lru];
@@ -499,16 +562,16 @@ void HipCGDSubspaceOptimizer::setPlanCacheBytes(size_t bytes) {
 }
 
 HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
-                                                                         const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id) {
+                                                                         const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id, size_t dev) {
     if (cache_cap_ == 0) return nullptr;
-    unsigned long long h = 1469598103934665603ull;   // FNV-1a over the four lists
+    unsigned long long h = 1469598103934665603ull + dev;   // FNV-1a over the four lists
     auto mix = [&](const std::vector<int64_t>& v) {
         for (int64_t x : v) { h ^= (unsigned long long)x; h *= 1099511628211ull; }
         h ^= 0x9e3779b97f4a7c15ull + v.size(); h *= 1099511628211ull;
     };
     mix(free_ptr); mix(free_vid); mix(fac_ptr); mix(fac_id);
     for (CachedPlan* e : cache_)
-        if (e->hash == h && e->free_vid == free_vid && e->fac_id == fac_id && e->free_ptr == free_ptr && e->fac_ptr == fac_ptr) {
+        if (e->hash == h && e->dev == dev && e->free_vid == free_vid && e->fac_id == fac_id && e->free_ptr == free_ptr && e->fac_ptr == fac_ptr) {
             e->used = ++cache_tick_;
             ++cache_hits_;
             return e;
@@ -516,19 +579,19 @@ HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const s
     ++cache_misses_;
     while (cache_.size() >= cache_cap_ && evictOne()) {}
     CachedPlan* e = new CachedPlan;
-    e->hash = h; e->used = ++cache_tick_;
+    e->hash = h; e->used = ++cache_tick_; e->dev = dev;
     e->free_ptr = free_ptr; e->free_vid = free_vid; e->fac_ptr = fac_ptr; e->fac_id = fac_id;
     // Device memory is the cache's real bound: when the device is out of it the least recently used plans
     // go, one at a time, and the creation is tried again; with nothing left to drop the call is served by
     // the transient path (rdis_hip_cgd_batch, in the problem's arena) like an uncached one.
     int rc;
     for (;;) {
-        rc = rdis_hip_plan_create(f.deviceProblem(), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
+        rc = rdis_hip_plan_create(f.deviceProblem(dev), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
                                   fac_ptr.data(), fac_id.data(), &e->plan);
         if (rc != RDIS_HIP_ENOMEM || !evictOne()) break;
     }
     if (rc == RDIS_HIP_ENOMEM) { delete e; ++cache_fallbacks_; return nullptr; }
-    if (rc != 0) { delete e; check(f.deviceContext(), rc, "rdis_hip_plan_create"); }
+    if (rc != 0) { delete e; check(f.deviceContext(dev), rc, "rdis_hip_plan_create"); }
     (void)rdis_hip_plan_device_bytes(e->plan, &e->bytes);
     if ((size_t)e->bytes > cache_byte_cap_) {   // larger than the whole budget: not kept
         rdis_hip_plan_destroy(e->plan);
@@ -555,16 +618,72 @@ Numeric HipCGDSubspaceOptimizer::optimize(const VariablePtrVec& vars, const Fact
     return one[0].fret;
 }
 
+// the components of a batch that one device solves
+struct HipCGDSubspaceOptimizer::Shard {
+    size_t dev = 0;
+    std::vector<size_t> comps;   // indices into the batch, ascending
+    std::vector<int64_t> free_ptr, free_vid, fac_ptr, fac_id;
+    std::vector<double> x, fret, delta;
+    std::vector<int32_t> iters, status;
+    std::vector<int64_t> nfe, nge;
+    CachedPlan* cp = nullptr;
+};
+
+// Every shard's plan is found (or made), then every device gets its start values and its launch -- nothing here waits
+// for a device, so the launches of all devices are in flight together -- and only then are the results fetched, device
+// by device.  A shard whose plan cannot be kept is served by the transient path after the others have been launched.
+void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
+    for (Shard& S : shards) {
+        S.cp = S.fac_id.empty() ? nullptr : cachedPlan(S.free_ptr, S.free_vid, S.fac_ptr, S.fac_id, S.dev);
+        if (S.cp) S.cp->busy = true;   // (a later shard's plan must not push this one out)
+    }
+    for (Shard& S : shards) {
+        if (!S.cp) continue;
+        rdis_hip_ctx* ctx = f.deviceContext(S.dev);
+        (void)f.deviceProblem(S.dev);   // (pending assignments of constants reach this device)
+        check(ctx, rdis_hip_plan_set_start(S.cp->plan, S.x.data()), "rdis_hip_plan_set_start");
+        // A solve may still allocate (tables built for the launch shape it picks).  Out of device memory: the other
+        // plans go, least recently used first, and it is tried again; with nothing left to drop this plan goes too and
+        // the shard is served by the transient path like an uncached one.
+        int rc;
+        for (;;) {
+            rc = rdis_hip_plan_solve(S.cp->plan, (int32_t)maxiters, ftol);
+            if (rc != RDIS_HIP_ENOMEM || !evictOne(S.cp)) break;
+        }
+        if (rc == RDIS_HIP_ENOMEM) { forget(S.cp); S.cp = nullptr; ++cache_fallbacks_; continue; }
+        check(ctx, rc, "rdis_hip_plan_solve");
+    }
+    for (Shard& S : shards) {
+        const size_t nc = S.comps.size();
+        S.fret.resize(nc); S.delta.resize(nc); S.iters.resize(nc); S.status.resize(nc); S.nfe.resize(nc); S.nge.resize(nc);
+        rdis_hip_ctx* ctx = f.deviceContext(S.dev);
+        if (S.cp) {
+            check(ctx, rdis_hip_plan_fetch(S.cp->plan, S.x.data(), S.fret.data(), S.delta.data(), S.iters.data(), S.status.data(), S.nfe.data(), S.nge.data()),
+                  "rdis_hip_plan_fetch");
+            S.cp->busy = false;
+            int64_t now = S.cp->bytes;   // (what the first solve added belongs to the plan's account)
+            (void)rdis_hip_plan_device_bytes(S.cp->plan, &now);
+            if (now != S.cp->bytes) {
+                cache_bytes_ = cache_bytes_ - std::min<size_t>(cache_bytes_, (size_t)S.cp->bytes) + (size_t)now;
+                S.cp->bytes = now;
+                while (cache_bytes_ > cache_byte_cap_ && evictOne(S.cp)) {}
+            }
+        } else {
+            const int rc = rdis_hip_cgd_batch(f.deviceProblem(S.dev), (int64_t)nc, S.free_ptr.data(), S.free_vid.data(), S.fac_ptr.data(), S.fac_id.data(),
+                                              S.x.data(), (int32_t)maxiters, ftol, S.fret.data(), S.delta.data(), S.iters.data(),
+                                              S.status.data(), S.nfe.data(), S.nge.data());
+            check(ctx, rc, "rdis_hip_cgd_batch");
+        }
+    }
+}
+
 Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, const bool printdbg) {
     const size_t nc = comps.size();
-    std::vector<int64_t> free_ptr(nc + 1, 0), fac_ptr(nc + 1, 0), free_vid, fac_id;
-    std::vector<double> x;
     for (size_t c = 0; c < nc; ++c) {
         Component& C = comps[c];
         if (C.xval.size() != C.vars.size()) throw std::invalid_argument("optimizeBatch: xval.size() != vars.size()");
         // every variable of every listed factor must be assigned or free in this call
         // (the caller guarantees it, src/RDISOptimizer.cpp:1042, :1049-1059)
-        std::vector<char> is_free;
         for (const Factor* fa : C.factors)
             for (const Variable* v : fa->getVariables())
                 if (!v->isAssigned()) {
@@ -572,50 +691,75 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
                     for (const Variable* u : C.vars) if (u == v) { fr = true; break; }
                     if (!fr) throw std::logic_error("optimize: factor " + std::to_string(fa->getID()) + " reads the unassigned variable " + v->getName());
                 }
-        for (size_t i = 0; i < C.vars.size(); ++i) { free_vid.push_back(C.vars[i]->getID()); x.push_back(C.xval[i]); }
-        for (const Factor* fa : C.factors) fac_id.push_back(fa->getID());
-        free_ptr[c + 1] = (int64_t)free_vid.size();
-        fac_ptr[c + 1] = (int64_t)fac_id.size();
     }
-    std::vector<double> fret(nc), delta(nc);
-    std::vector<int32_t> iters(nc), status(nc);
-    std::vector<int64_t> nfe(nc), nge(nc);
-    rdis_hip_problem* p = f.deviceProblem();
-    CachedPlan* cp = fac_id.empty() ? nullptr : cachedPlan(free_ptr, free_vid, fac_ptr, fac_id);
-    if (cp) {   // the decomposition is resident: start values in, launch, results out
-        rdis_hip_ctx* ctx = f.deviceContext();
-        check(ctx, rdis_hip_plan_set_start(cp->plan, x.data()), "rdis_hip_plan_set_start");
-        check(ctx, rdis_hip_plan_solve(cp->plan, (int32_t)maxiters, ftol), "rdis_hip_plan_solve");
-        check(ctx, rdis_hip_plan_fetch(cp->plan, x.data(), fret.data(), delta.data(), iters.data(), status.data(), nfe.data(), nge.data()),
-              "rdis_hip_plan_fetch");
+    // Which device solves which component: sibling components share no free variable and no factor (src/Component.cpp:
+    // 508-549), so a batch is shared out whole components at a time -- heaviest first, always onto the device with the
+    // least load so far, by factor count; ties: lower component, lower device (rdis_amd/dist.py, SURVEY 8e: the same rule
+    // the ranks of a multi-process job use).  One device, or one component: everything on the primary.
+    const size_t ndev = (nc > 1) ? f.numDevices() : 1;
+    std::vector<Shard> shards(ndev);
+    for (size_t d = 0; d < ndev; ++d) shards[d].dev = d;
+    if (ndev == 1) {
+        for (size_t c = 0; c < nc; ++c) shards[0].comps.push_back(c);
     } else {
-        const int rc = rdis_hip_cgd_batch(p, (int64_t)nc, free_ptr.data(), free_vid.data(), fac_ptr.data(), fac_id.data(),
-                                          x.data(), (int32_t)maxiters, ftol, fret.data(), delta.data(), iters.data(),
-                                          status.data(), nfe.data(), nge.data());
-        check(f.deviceContext(), rc, "rdis_hip_cgd_batch");
-    }
-    Numeric total = 0;
-    for (size_t c = 0; c < nc; ++c) {
-        Component& C = comps[c];
-        C.fret = fret[c]; C.deltaFval = delta[c]; C.iters = iters[c]; C.status = status[c];
-        C.nfeval = nfe[c]; C.ngeval = nge[c];
-        total += fret[c];
-        if ((status[c] & 0xff) == RDIS_HIP_EXIT_SYNC_TIMEOUT)   // never expected; not a result the caller may build on
-            throw HipError(RDIS_HIP_EDEVICE, "HipCGD: the device-side exchange of component " + std::to_string(c) + " timed out (start restored)");
-        if ((status[c] & 0xff) == RDIS_HIP_EXIT_NAN) std::cerr << "HipCGD: NaN objective in component " << c << ", start restored" << std::endl;
-        if ((status[c] & 0xff) == RDIS_HIP_EXIT_EMPTY) continue;  // nothing touched
-        // the variables are left assigned to the final, clamped values (.cpp:84-86); the
-        // device already holds them, so they are not marked for re-upload
-        for (size_t i = 0; i < C.vars.size(); ++i) {
-            Variable* v = C.vars[i];
-            const double val = x[(size_t)free_ptr[c] + i];
-            C.xval[i] = val;
-            v->assigned_ = true; v->value_ = val;
-            f.onVarAssigned(v->getID(), val);
+        std::vector<size_t> order(nc);
+        for (size_t c = 0; c < nc; ++c) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return comps[a].factors.size() > comps[b].factors.size(); });
+        std::vector<long long> load(ndev, 0);
+        for (size_t c : order) {
+            size_t d = 0;
+            for (size_t k = 1; k < ndev; ++k) if (load[k] < load[d]) d = k;
+            shards[d].comps.push_back(c);
+            load[d] += (long long)comps[c].factors.size();
         }
-        if (printdbg)
-            std::cout << "CGD subspace result (steps " << iters[c] << "): " << fret[c] << ", diff: " << delta[c]
-                      << ", init: " << fret[c] - delta[c] << ((status[c] & RDIS_HIP_STATUS_ROLLED_BACK) ? " [restored]" : "") << std::endl;
+        for (Shard& S : shards) std::sort(S.comps.begin(), S.comps.end());
+    }
+    size_t used = 0;
+    for (Shard& S : shards) {
+        if (S.comps.empty()) continue;
+        S.free_ptr.assign(1, 0); S.fac_ptr.assign(1, 0);
+        for (size_t c : S.comps) {
+            const Component& C = comps[c];
+            for (size_t i = 0; i < C.vars.size(); ++i) { S.free_vid.push_back(C.vars[i]->getID()); S.x.push_back(C.xval[i]); }
+            for (const Factor* fa : C.factors) S.fac_id.push_back(fa->getID());
+            S.free_ptr.push_back((int64_t)S.free_vid.size());
+            S.fac_ptr.push_back((int64_t)S.fac_id.size());
+        }
+        if (&S != &shards[used]) shards[used] = std::move(S);
+        ++used;
+    }
+    shards.resize(used);
+    solveShards(shards);
+    // the value of the batch: the devices' sums, added in device order (RDISOptimizer.cpp:1491-1494 couples siblings only here)
+    Numeric total = 0;
+    for (Shard& S : shards) {
+        Numeric part = 0;
+        for (size_t k = 0; k < S.comps.size(); ++k) {
+            const size_t c = S.comps[k];
+            Component& C = comps[c];
+            C.fret = S.fret[k]; C.deltaFval = S.delta[k]; C.iters = S.iters[k]; C.status = S.status[k];
+            C.nfeval = S.nfe[k]; C.ngeval = S.nge[k];
+            part += S.fret[k];
+            if ((C.status & 0xff) == RDIS_HIP_EXIT_SYNC_TIMEOUT)   // never expected; not a result the caller may build on
+                throw HipError(RDIS_HIP_EDEVICE, "HipCGD: the device-side exchange of component " + std::to_string(c) + " timed out (start restored)");
+            if ((C.status & 0xff) == RDIS_HIP_EXIT_NAN) std::cerr << "HipCGD: NaN objective in component " << c << ", start restored" << std::endl;
+            if ((C.status & 0xff) == RDIS_HIP_EXIT_EMPTY) continue;  // nothing touched
+            // the variables are left assigned to the final, clamped values (.cpp:84-86); the device that solved the
+            // component already holds them, so they are not marked for re-upload there -- the other devices get them
+            // with the next call that goes to them
+            for (size_t i = 0; i < C.vars.size(); ++i) {
+                Variable* v = C.vars[i];
+                const double val = S.x[(size_t)S.free_ptr[k] + i];
+                C.xval[i] = val;
+                v->assigned_ = true; v->value_ = val;
+                f.onVarAssigned(v->getID(), val);
+                if (f.numDevices() > 1) f.markDirtyElsewhere(v->getID(), S.dev);
+            }
+            if (printdbg)
+                std::cout << "CGD subspace result (steps " << C.iters << "): " << C.fret << ", diff: " << C.deltaFval
+                          << ", init: " << C.fret - C.deltaFval << ((C.status & RDIS_HIP_STATUS_ROLLED_BACK) ? " [restored]" : "") << std::endl;
+        }
+        total += part;
     }
     return total;
 }

@@ -184,6 +184,15 @@ public:
     void initDevice(int device = 0);          // upload the packed function (done lazily otherwise)
     rdis_hip_problem* deviceProblem() const;  // uploads + pushes pending assignments
     rdis_hip_ctx* deviceContext() const;
+    // Several GPUs of one node from ONE process: the function is replicated, one context + device problem per listed
+    // device (devices[0] is the primary, which serves every call that is not a batch); a batch of independent
+    // components -- sibling components of a recursion level, src/Component.cpp:508-549 -- is shared out over them
+    // by HipCGDSubspaceOptimizer::optimizeBatch.  The same device may be listed more than once (two contexts on one
+    // GPU: what the tests do).  To be called before the first use of the device; replicas are uploaded when first used.
+    void setDevices(const std::vector<int>& devices);
+    size_t numDevices() const { return 1 + replicas_.size(); }
+    rdis_hip_problem* deviceProblem(size_t d) const;   // d = 0: the primary
+    rdis_hip_ctx* deviceContext(size_t d) const;
 
     // packed (structure-of-arrays) view of the function; what rdis_hip_upload_* takes
     struct Packed {
@@ -210,8 +219,18 @@ private:
     friend class HipCGDSubspaceOptimizer;
     friend class HipLMSubspaceOptimizer;
     void markDirty(VariableID id) const;
+    void markDirtyElsewhere(VariableID id, size_t holder) const;   // device `holder` has assigned the value itself
     void pushAssignments() const;
     void ensureUploaded() const;
+    struct Replica {
+        int device = 0;
+        rdis_hip_ctx* ctx = nullptr;
+        rdis_hip_problem* prob = nullptr;
+        std::vector<VariableID> dirty;
+        std::vector<char> is_dirty;
+    };
+    void uploadTo(int device, rdis_hip_ctx*& ctx, rdis_hip_problem*& prob) const;
+    mutable std::vector<Replica> replicas_;   // devices 1 .. (setDevices)
     void fillIds(const FactorPtrVec& f, std::vector<int64_t>& ids) const;
     mutable std::unique_ptr<Packed> packed_;
     mutable rdis_hip_ctx* ctx_;
@@ -336,9 +355,12 @@ public:
 private:
     struct CachedPlan;
     CachedPlan* cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
-                           const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id);
+                           const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id, size_t dev = 0);
+    struct Shard;
+    void solveShards(std::vector<Shard>& shards);
     void dropPlans();
-    bool evictOne();
+    bool evictOne(const CachedPlan* keep = nullptr);   // the least recently used plan other than `keep` goes
+    void forget(CachedPlan* e);
     friend class OptimizableFunction;
     void functionGone();   // the function is being destroyed: its device problem goes, and the plans with it
     int last_iters_, last_status_;

@@ -247,7 +247,7 @@ void HipRDISLevelOptimizer::buildPlans() {
             const size_t ncomp = lp->node.size();
             lp->x.resize(lp->free_vid.size()); lp->fret.resize(ncomp); lp->delta.resize(ncomp);
             lp->iters.resize(ncomp); lp->status.resize(ncomp);
-            if (batch_)
+            if (batch_ && f_.numDevices() == 1)
                 check(f_.deviceContext(), rdis_hip_plan_create(p, (int64_t)ncomp, lp->free_ptr.data(), lp->free_vid.data(),
                                                                lp->fac_ptr.data(), lp->fac_id.data(), &lp->plan), "rdis_hip_plan_create");
             plans_.push_back(lp);
@@ -261,7 +261,29 @@ double HipRDISLevelOptimizer::runPlan(LevelPlan& lp, int sweep, double objective
     const size_t ncomp = lp.node.size();
     long long iters = 0;
     double dsum = 0.0;
-    if (batch_) {
+    if (batch_ && f_.numDevices() > 1) {
+        // several devices (OptimizableFunction::setDevices): the level's components are shared out over them by
+        // HipCGDSubspaceOptimizer::optimizeBatch (heaviest first by factor count; launches on all devices before any
+        // result is fetched; its plan cache keeps every device's share resident from the first sweep on)
+        std::vector<HipCGDSubspaceOptimizer::Component> comps(ncomp);
+        for (size_t c = 0; c < ncomp; ++c) {
+            HipCGDSubspaceOptimizer::Component& C = comps[c];
+            for (int64_t i = lp.free_ptr[c]; i < lp.free_ptr[c + 1]; ++i) {
+                Variable* v = vars[(size_t)lp.free_vid[(size_t)i]];
+                C.vars.push_back(v); C.xval.push_back(v->eval());
+            }
+            for (int64_t j = lp.fac_ptr[c]; j < lp.fac_ptr[c + 1]; ++j) C.factors.push_back(facs[(size_t)lp.fac_id[(size_t)j]]);
+        }
+        ss_.optimizeBatch(comps, false);
+        for (size_t c = 0; c < ncomp; ++c) {
+            const HipCGDSubspaceOptimizer::Component& C = comps[c];
+            lp.fret[c] = C.fret; lp.delta[c] = C.deltaFval; lp.iters[c] = C.iters; lp.status[c] = C.status;
+            for (size_t i = 0; i < C.xval.size(); ++i) lp.x[(size_t)lp.free_ptr[c] + i] = C.xval[i];
+            if ((C.status & 0xff) == RDIS_HIP_EXIT_EMPTY) continue;
+            dsum += C.deltaFval;
+            iters += C.iters + 1;
+        }
+    } else if (batch_) {
         rdis_hip_problem* p = f_.deviceProblem();   // (pushes pending host-side assignments)
         (void)p;
         rdis_hip_ctx* ctx = f_.deviceContext();

@@ -202,6 +202,63 @@ int harness_ba_children_batch(const char* path, long long ncams, long long npts,
     } catch (const std::exception& e) { std::cerr << "harness_ba_children_batch: " << e.what() << std::endl; return -2; }
 }
 
+// The same over SEVERAL devices from one process (OptimizableFunction::setDevices; here ndev contexts on device 0 --
+// what one GPU can test): which = 0 the point components (cameras assigned), 1 the camera components (points assigned).
+// out = {sum fret, ncomp, f_before, f_after, plan cache entries}; per component (in createChildren's order): fret, iters,
+// f-evaluations; x_out: every variable's value afterwards
+int harness_ba_children_batch_devices(const char* path, long long ncams, long long npts, int maxit, int which, int ndev, int rounds,
+                                      double* out, double* fret_out, long long* iters_out, long long* nfe_out, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        if (ndev > 1) f.setDevices(std::vector<int>((size_t)ndev, 0));
+        const NumericVec x0 = f.getInitialState();
+        f.assignAll(x0);
+        const Numeric before = f.eval();
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        Numeric total = 0;
+        size_t ncomp = 0;
+        for (int rd = 0; rd < rounds; ++rd) {   // (a second round starts from what the first left: values cross between the devices)
+            const int w = (which + rd) & 1;
+            const VariableID lo = w == 0 ? 9 * f.getNumCameras() : 0, hi = w == 0 ? (VariableID)f.getNumVars() : 9 * f.getNumCameras();
+            for (VariableID v = lo; v < hi; ++v) f.getVariables()[(size_t)v]->unassign();
+            std::vector<HipCGDSubspaceOptimizer::Component> comps = ssopt.createChildren();
+            for (auto& c : comps) for (const Variable* v : c.vars) c.xval.push_back(rd == 0 ? x0[(size_t)v->getID()] : x_out[(size_t)v->getID()]);
+            total = ssopt.optimizeBatch(comps, false);
+            ncomp = comps.size();
+            for (size_t c = 0; c < comps.size(); ++c) { fret_out[c] = comps[c].fret; iters_out[c] = comps[c].iters; nfe_out[c] = comps[c].nfeval; }
+            for (size_t i = 0; i < f.getVariables().size(); ++i) x_out[i] = f.getVariables()[i]->eval();
+        }
+        const Numeric after = f.eval();
+        out[0] = total; out[1] = (double)ncomp; out[2] = before; out[3] = after; out[4] = (double)ssopt.planCacheEntries();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_ba_children_batch_devices: " << e.what() << std::endl; return -2; }
+}
+
+// ... and the level driver over ndev devices.  out = {final value, value before, sweeps, nodes}
+int harness_level_driver_devices(const char* path, long long ncams, long long npts, int maxit, int max_sweeps, double blkpct, int ndev,
+                                 double* out, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        if (ndev > 1) f.setDevices(std::vector<int>((size_t)ndev, 0));
+        f.assignAll(f.getInitialState());
+        const Numeric before = f.eval();
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        HipRDISLevelOptimizer rdis(f, ssopt);
+        Options ro; ro.set("AVblkpct", blkpct); ro.set("maxSweeps", max_sweeps); ro.set("batch", 1);
+        rdis.setParameters(ro);
+        const Numeric fin = rdis.optimize(false);
+        out[0] = fin; out[1] = before; out[2] = rdis.sweepsDone(); out[3] = (double)rdis.nodes().size();
+        for (size_t i = 0; i < f.getVariables().size(); ++i) x_out[i] = f.getVariables()[i]->eval();
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_level_driver_devices: " << e.what() << std::endl; return -2; }
+}
+
 // LMSubspaceOptimizer's place taken by HipLMSubspaceOptimizer: all variables of a BAL subset.
 // out = {fret, delta, f_before, f_after, iterations, stop, linear solves}
 int harness_ba_lm(const char* path, long long ncams, long long npts, int maxit, double* out, double* x_out) {
