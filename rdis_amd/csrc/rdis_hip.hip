@@ -1952,18 +1952,25 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         int threads = L->ptm_threads ? L->ptm_threads : 768;
         int K = 1;
         if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty()) {
-            const int gthreads = L->ptm_threads ? L->ptm_threads : 256;
-            int cap = 0;
-            int rc = ptmg_resident_workgroups(L, gthreads, &cap);
-            if (rc) return rc;
+            // groups of K workgroups: of 512 lanes (a workgroup per compute unit) or of 256 (two) -- whichever brings more
+            // lanes to a component, at equal lanes the larger workgroup (125 components of ladybug's size: pairs of 512
+            // lanes 16.0 ms, fours of 256 17.0, one workgroup of 768 each 24.2; round 4)
             const int slots8 = 8 * ((L->rest_ptm + 7) / 8);   // (groups are placed eight at a time, one per XCD)
-            const int fit = std::min(std::min(PTM_MAX_GROUP, cap / slots8), SMALL_COOP_ENTRIES / (gthreads / 64));
             const int useful = (int)std::max<int64_t>(1, (L->ptm_min_points + 63) / 64 / 24);
-            K = L->ptm_group > 1 ? std::min(L->ptm_group, fit) : std::min(fit, useful);
+            int best_lanes = 0, best_threads = 0, best_K = 1;
+            const int cands[2] = {L->ptm_threads ? L->ptm_threads : 512, 256};
+            for (int ci = 0; ci < (L->ptm_threads ? 1 : 2); ++ci) {
+                const int gt = cands[ci];
+                int cap = 0;
+                int rc = ptmg_resident_workgroups(L, gt, &cap);
+                if (rc) return rc;
+                const int fit = std::min(std::min(PTM_MAX_GROUP, cap / slots8), SMALL_COOP_ENTRIES / (gt / 64));
+                const int Kc = L->ptm_group > 1 ? std::min(L->ptm_group, fit) : std::min(fit, useful);
+                if (Kc >= 2 && Kc * gt > best_lanes) { best_lanes = Kc * gt; best_threads = gt; best_K = Kc; }
+            }
             // (a group must bring more lanes to a component than the one workgroup it replaces: 250 components of
             // ladybug's size 50.4 ms a workgroup of 768 lanes each, 56.0 as pairs of 256)
-            if (L->ptm_group == 0 && K * gthreads <= threads) K = 1;
-            if (K >= 2) threads = gthreads;
+            if (best_K >= 2 && (L->ptm_group > 1 || best_lanes > threads)) { K = best_K; threads = best_threads; }
         }
         L->ptm_last_group = std::max(K, 1);
         int rc = K >= 2 ? launch_ptm_groups(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, K, maxiters, ftol)

@@ -1275,7 +1275,7 @@ def test_point_major_solver_at_the_bench_shape(gctx):
     """BASELINE config 5, size L -- the shape bench.py's strong-scaling block and its synthetic-L workload time
     (SURVEY 8d): components of 49 cameras x 7776 points x 4 observations = 31104 factors, 23769 variables, through the
     kernels those launches use: cgd_ptm_kernel<768, .> with a workgroup per component (what one GPU runs on 1000 of
-    them) and cgd_ptmg_kernel with four workgroups of 256 lanes per component (what a rank of eight runs on its 125).
+    them) and cgd_ptmg_kernel with two workgroups of 512 lanes per component (what a rank of eight runs on its 125).
     Per configuration: one component replayed by the oracle (bit-identical decisions over all 25 iterations, values and
     slopes to rounding), every component's returned value against the oracle's objective at the returned point, the
     variables left assigned, and the same bits from a second run.
@@ -1305,7 +1305,7 @@ def test_point_major_solver_at_the_bench_shape(gctx):
         return r, tr, info, x
 
     base = {"coop_group_min_factors": 0, "coop_min_factors": 0}   # (four components alone would be packed into a cooperative launch)
-    for opts, K in (({"ptm_group": 1}, 1), ({"ptm_group": 4}, 4)):
+    for opts, K in (({"ptm_group": 1}, 1), ({"ptm_group": 2, "ptm_threads": 512}, 2)):
         r, tr, info, x = run({**base, **opts}, trace=4096)
         assert info["components_point_major"] == ncomp and info["point_major_group"] == K, info
         assert info["components_cooperative"] == 0 and info["components_lds"] == 0 and info["components_plain"] == 0, info
