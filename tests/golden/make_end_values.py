@@ -59,6 +59,7 @@ def contracted_oracle():
     subprocess.check_call(["make", "-C", odir, "liboracle_contracted.so"], stdout=subprocess.DEVNULL)
     spec = importlib.util.spec_from_file_location("oracle_contracted", os.path.join(odir, "oracle.py"))
     mod = importlib.util.module_from_spec(spec)
+    sys.modules["oracle_contracted"] = mod
     spec.loader.exec_module(mod)
     mod._LIB = os.path.join(odir, "liboracle_contracted.so")
     mod.build = lambda force=False: None
