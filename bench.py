@@ -254,16 +254,19 @@ def host_cpu():
     return {"model": model, "logical_cores": os.cpu_count() or 1, "usable_cores": usable}
 
 
-def objective_band(plan, pp, maxiters: int, k_dev: int = 32):
-    """End values over one-ulp-perturbed starts: the device's draws next to the ORACLE'S COMMITTED sample
-    (tests/golden/end_values.json: 64 end values of the reference-faithful CPU oracle, generated by
-    tests/golden/make_end_values.py; its first entry is the reference's recorded run bit for bit).  25
-    unconverged CG iterations are a chaotic map of the start, so one run's end value is a draw from a
-    distribution (tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle).  Outside the
+def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
+    """End values over one-ulp-perturbed starts: the device's draws next to the ORACLE'S COMMITTED samples
+    (tests/golden/end_values.json, generated by tests/golden/make_end_values.py: 320 end values of the
+    reference-faithful CPU oracle compiled like the reference -- its first entry is the reference's recorded run bit
+    for bit -- and 320 of the same oracle compiled with contraction, an equally valid rounding of the same algorithm).
+    25 unconverged CG iterations are a chaotic map of the start, so one run's end value is a draw from a distribution,
+    and that distribution depends on the evaluator's rounding: the oracle's two samples part with KS 0.21
+    (tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle, DESIGN.md section 6).  Outside the
     timed region; nothing under oracle/ runs here."""
     with open(os.path.join(ROOT, "tests", "golden", "end_values.json")) as fh:
         fx = json.load(fh)
     oe = np.array(fx["ladybug_full"]["end_values"])
+    oc = np.array(fx["ladybug_full"].get("end_values_contracted", []))
 
     def ulp(x, k):
         rng = np.random.default_rng([fx["seed"], 200000 + k])
@@ -275,15 +278,23 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 32):
         de.append(float(plan.fetch().fret.sum()))
     plan.set_start(pp.x0[pp.comp_free_vid])
     de = np.array(de)
-    a, b = np.sort(de), np.sort(oe)
-    allv = np.concatenate([a, b])
-    ks = float(np.max(np.abs(np.searchsorted(a, allv, side="right") / len(a) - np.searchsorted(b, allv, side="right") / len(b))))
+
+    def ks(a, b):
+        a, b = np.sort(a), np.sort(b)
+        allv = np.concatenate([a, b])
+        return float(np.max(np.abs(np.searchsorted(a, allv, side="right") / len(a) - np.searchsorted(b, allv, side="right") / len(b))))
     q = lambda v: {"n": int(len(v)), "min": float(v.min()), "q25": float(np.quantile(v, 0.25)), "median": float(np.median(v)),
                    "q75": float(np.quantile(v, 0.75)), "max": float(v.max())}
-    return {"what": "final objective over starts moved by one unit in the last place (first entry: the unperturbed start)",
-            "device": q(de), "oracle_fixture": dict(q(oe), unperturbed=float(oe[0]), file="tests/golden/end_values.json"),
-            "ks_two_sample": ks, "ks_critical_alpha_0.001": float(1.9495 * np.sqrt((len(a) + len(b)) / (len(a) * len(b)))),
-            "reference_recorded": 83227.604227756252}
+    out = {"what": "final objective over starts moved by one unit in the last place (first entry: the unperturbed start)",
+           "device": q(de), "oracle_fixture": dict(q(oe), unperturbed=float(oe[0]), file="tests/golden/end_values.json"),
+           "ks_device_vs_oracle": ks(de, oe),
+           "ks_critical_alpha_0.05": float(1.358 * np.sqrt((len(de) + len(oe)) / (len(de) * len(oe)))),
+           "reference_recorded": 83227.604227756252}
+    if len(oc):
+        out["oracle_fixture_contracted"] = dict(q(oc), what="the same oracle compiled with -ffp-contract=fast -mfma: an equally valid rounding")
+        out["ks_device_vs_oracle_contracted"] = ks(de, oc)
+        out["ks_oracle_vs_oracle_contracted"] = ks(oc, oe)
+    return out
 
 
 def plugin_call(prob, pp, maxiters: int, reps: int = 5):
@@ -528,13 +539,8 @@ def main():
                          # (factor arithmetic of one wave + wave reduction + one store->load hop between compute
                          # units + sweep + one step of the control logic, tools/microbench)
                          "latency": ({"evals": float(nfe.sum()) / max(a.steps, 1), "us_per_eval": kms / max(a.steps, 1) * 1e3 / max(float(nfe.sum()) / max(a.steps, 1), 1.0),
-                                      "us_floor": 1.15, "us_chain": 2.6,
-                                      "us_floor_us_chain_are": "constants derived from the cycle stamps of a -DRDIS_COOP_TIMING build "
-                                                               "(profiles/r02_g_pipe_ladybug_stamps.txt), not measured in this run",
-                                      "floor": ("pipelined solver (solver_pipe.hpp): a trial step that was guessed costs the slowest of three overlapping sides "
-                                                "-- a lane wave's arithmetic + reduction 2300 + 400 cycles, the collector's sweep, a step of the control logic -- "
-                                                "us_floor is the lanes' side at 2.4 GHz; a step that was not guessed pays the whole chain, us_chain "
-                                                "(arithmetic + reduce + one store->load hop between compute units + sweep + control step)")}
+                                      "what": "measured in this run: solver-kernel time per dependent evaluation of the one component (the chain, not bandwidth, "
+                                              "governs a single-component solve: DESIGN.md 3.2b; cycle stamps of the pipeline's three sides: profiles/r02_g_pipe_ladybug_stamps.txt)"}
                                      if pp.ncomp == 1 else None)},
         }
         if world == 1:

@@ -35,13 +35,22 @@ typedef struct {
  * src/bundleadjust/BundleAdjustmentFactor.cpp:266-335 (rotate+translate),
  * BundleAdjustmentFactor.h:80-107 (divide, distort, error),
  * BundleAdjustmentCommon.h:81-93 (normalize). */
+/* An experiment's switch (process-wide; tests/golden/make_end_values.py and nothing else): bit 0 = the unit axis and the
+ * perspective divide through ONE reciprocal each (x * (1 / y) in place of x / y), the device's form (rdis_amd/csrc/
+ * factors.hpp) -- an equally valid rounding, not the reference's. */
+static int g_experiment = 0;
+void ro_set_experiment(int flags) { g_experiment = flags; }
+
 static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
 {
     const double *r = x, *tr = x + 3, *q = x + 9;
     const double f = x[6], k1 = x[7], k2 = x[8];
 
     t->theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (t->theta != 0.0) {
+    if (t->theta != 0.0 && (g_experiment & 1)) {
+        const double it = 1.0 / t->theta;
+        t->v[0] = r[0] * it; t->v[1] = r[1] * it; t->v[2] = r[2] * it;
+    } else if (t->theta != 0.0) {
         t->v[0] = r[0] / t->theta; t->v[1] = r[1] / t->theta; t->v[2] = r[2] / t->theta;
     } else {
         t->v[0] = r[0]; t->v[1] = r[1]; t->v[2] = r[2];
@@ -64,8 +73,14 @@ static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
     }
     for (int i = 0; i < 3; ++i) t->P[i] += tr[i];
 
-    t->pp[0] = -t->P[0] / t->P[2];
-    t->pp[1] = -t->P[1] / t->P[2];
+    if (g_experiment & 1) {
+        const double iz = 1.0 / t->P[2];
+        t->pp[0] = -t->P[0] * iz;
+        t->pp[1] = -t->P[1] * iz;
+    } else {
+        t->pp[0] = -t->P[0] / t->P[2];
+        t->pp[1] = -t->P[1] / t->P[2];
+    }
     t->r2 = t->pp[0] * t->pp[0] + t->pp[1] * t->pp[1];
     t->dstn = 1 + t->r2 * (k1 + k2 * t->r2);
     const double pix0 = f * t->dstn * t->pp[0];

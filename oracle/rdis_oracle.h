@@ -86,6 +86,9 @@ void ro_set_ba_derivative(ro_problem *p, int which);
 #define RO_SUM_LIST 0
 #define RO_SUM_PAIRWISE 1
 void ro_set_sum_order(ro_problem *p, int which);
+/* process-wide experiment flags (bit 0: reciprocals in place of the projection's divisions, the device's form); never
+ * used to pin anything */
+void ro_set_experiment(int flags);
 
 void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val);
 void ro_get_x(const ro_problem *p, int64_t nvid, const int64_t *vid, double *out);
