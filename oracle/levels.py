@@ -206,3 +206,148 @@ def sweep(pp, oracle_problem, plans, x, maxiters=25, ftol=3e-8):
             f += r.delta
         objectives.append(f)
     return np.array(objectives), x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's schedule at a node -- doOptimization / getValueFromDomain / getSSInitialVal / updateDomain -- restated
+# from src/RDISOptimizer.cpp (not from rdis_levels.cpp), as a CHECKER: it walks the tree depth first, node by node and
+# child by child, the way the reference does (:253-334), takes every decision itself, and where the reference would
+# call the subspace optimizer (:1067) or read a component's value (:1514-1515) it consumes the next record of the
+# device run's trace for that node.  It asserts that each record is the step it expects (kind of start, restart
+# count, assignments since the last restart, and -- for a random restart -- the start vector bit for bit, through its
+# hash) and that updateDomain's verdict is the recorded one; at the end every record must have been consumed.
+# Parity status: the schedule is pinned by the reference's lines cited below; END-TO-END parity with the reference's
+# optBA is NOT pinned and cannot be here -- its cut comes from PaToH (binary-only), its restart values from Boost's
+# mt19937 in visiting order (:37, :1139, :1223-1225); this build draws them per (node, restart, variable).
+M64 = (1 << 64) - 1
+
+
+def splitmix_restart_value(seed, node, restart, vid, slo, shi, lo, hi):
+    """sampleRandomState (:1196-1216): uniform over the sampling interval, then VariableDomain::closestVal; the
+    uniform number from splitmix64 of (seed, node, restart, variable) -- rdis_levels.cpp: restartValue"""
+    z = (seed + 0x9E3779B97F4A7C15 * (node + 1) + 0xBF58476D1CE4E5B9 * (restart + 1) + 0x94D049BB133111EB * (vid + 1)) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    z ^= z >> 31
+    u = float(z >> 11) * (1.0 / 9007199254740992.0)
+    v = slo + u * (shi - slo)
+    return min(max(v, lo), hi)
+
+
+def fnv_of_doubles(xs):
+    h = 1469598103934665603
+    for b in np.asarray(xs, dtype=np.float64).view(np.uint64):
+        h = ((h ^ int(b)) * 1099511628211) & M64
+    return h
+
+
+def ba_sampling_intervals(pp, ncams):
+    """per variable (sampling lo, sampling hi): BundleAdjustmentFunction::setDomain
+    (src/bundleadjust/BundleAdjustmentFunction.cpp:402-477) from the file's initial values"""
+    x0 = pp.x0
+    typ = np.concatenate([np.arange(9 * ncams) % 9, 9 + np.arange(pp.nvars - 9 * ncams) % 3])
+    slo, shi = np.empty(pp.nvars), np.empty(pp.nvars)
+    rot = typ < 3
+    slo[rot], shi[rot] = -1.0 * np.pi, 1.0 * np.pi                                    # :419-424
+    pos = ((typ >= 3) & (typ <= 6)) | (typ >= 9)                                       # translation, focal, point: init +- 100 (:426-451)
+    slo[pos], shi[pos] = x0[pos] + -100.0, x0[pos] + 100.0
+    k1 = typ == 7
+    slo[k1], shi[k1] = x0[k1] + -1e-4, x0[k1] + 1e-4                                   # :453-457
+    k2 = typ == 8
+    slo[k2], shi[k2] = x0[k2] + -1e-6, x0[k2] + 1e-6                                   # :458-462
+    return slo, shi
+
+
+def replay_reference_schedule(nodes: List[Node], trace, pp, slo, shi, steptol=1e-4, nrr_per_lvl=2, nrr_at_top=None, min_rr=1,
+                              max_na_to_rr=10, no_assign_limit_at_top=True, seed=0x5D15, max_calls=100000):
+    """trace: rows (node, kind, nrr, va, fret, delta, value, newMin, startHash) in the order the device run made them.
+    Returns the number of subspace-optimizer calls checked."""
+    if nrr_at_top is None:
+        nrr_at_top = nrr_per_lvl                                                      # :1784-1785
+    queues = {}
+    for row in trace:
+        queues.setdefault(int(row[0]), []).append(row)
+    pos = {n: 0 for n in queues}
+    children = [[] for _ in nodes]
+    roots = []
+    for i, nd in enumerate(nodes):
+        if len(nd.factors) == 0:
+            continue                                                                   # checkEmpty (:262)
+        (children[nd.parent] if nd.parent >= 0 else roots).append(i)
+    calls = [0]
+
+    class TimedOut(Exception):
+        pass
+
+    def take(n):
+        # the reference's time limit (checkTimedOut, :317-321; here a budget of subspace-optimizer calls): the device run stopped
+        # asking once the budget was spent, and so do we -- what was recorded up to there must have been asked for in order
+        if pos.get(n, 0) >= len(queues.get(n, [])) and sum(len(q) for q in queues.values()) >= max_calls:
+            raise TimedOut()
+        assert pos.get(n, 0) < len(queues.get(n, [])), "the device made fewer steps at node %d than the reference's rules ask for" % n
+        row = queues[n][pos[n]]
+        pos[n] += 1
+        calls[0] += 1
+        return row
+
+    def do_optimization(n, random_init):                                               # :253-334, one visit of one component
+        nd = nodes[n]
+        top = nd.depth == 0                                                            # isTopCComp (:977-978): its parent has nothing assigned
+        num_restarts = max(min_rr, nrr_at_top if top else (nrr_per_lvl >> min(31, nd.depth)))   # :979-983, level = depth + 1
+        valued = nd.vars if nd.leaf else nd.separator
+        nrr, va = 0, 0                                                                 # a fresh component (src/Component.cpp:183-184)
+        assigned, last_opt, have_prev, have_opt, opt = False, False, False, False, 0.0
+        while True:                                                                    # while ( getValueFromDomain(...) ) (:279)
+            force_rr = (not (top and no_assign_limit_at_top)) and va >= max_na_to_rr   # :992-994
+            if (force_rr or not last_opt) and nrr > num_restarts:                      # :997-999: done with this component
+                return
+            if not assigned and not random_init:
+                kind = 0                                                               # xvalinit, "initial values" (:1127-1130)
+            elif assigned and not force_rr:
+                kind = 1                                                               # "iterative improvement" (:1131-1133)
+            else:
+                kind = 2                                                               # sampleRandomState (:1134-1136)
+            success = False
+            while True:                                                                # do ... while ( redoGD && !success ) (:1032-1106)
+                restart_no = nrr
+                if kind != 1:
+                    nrr += 1                                                           # incrementNumRandomRestarts (:1047) ...
+                    va = 0                                                             # ... which also clears the counter (Component.h:190-194)
+                row = take(n)                                                          # ssopt.optimize (:1067)
+                assert (int(row[1]), int(row[2])) == (kind, nrr), ("node %d: step kind / restart count" % n, row[:4], kind, nrr)
+                if kind == 2:
+                    x0 = [splitmix_restart_value(seed, n, restart_no, int(v), slo[v], shi[v], pp.lo[v], pp.hi[v]) for v in valued]
+                    assert fnv_of_doubles(x0) == int(row[8]), "node %d: the restart's start vector differs" % n
+                fret, delta = float(row[4]), float(row[5])
+                if have_prev and delta >= 0.0 - steptol:                               # approxgeq( deltafval, 0.0, ftol ) (:1086; common.h:74-76)
+                    assert np.isnan(row[6]) and int(row[3]) == va, row
+                    if nrr < num_restarts:                                             # :1087-1094: try again from a random position
+                        kind = 2
+                        continue
+                    return                                                             # :1095-1099: failure -> getValueFromDomain returns false
+                success = True
+                break
+            assert success
+            assigned = True                                                            # assign (:282)
+            va += 1                                                                    # Component::onVarsAssigned (src/Component.cpp:221)
+            assert int(row[3]) == va, ("node %d: assignments since the last restart" % n, row[:4], va)
+            for c in children[n]:                                                      # decompose, children in their order (:289-314)
+                do_optimization(c, kind == 2)   # (their initial values were used up at their first visit of this start, :1127, 1134)
+            value = float(row[6])                                                      # newsd->fx (:1515)
+            if nd.leaf:
+                assert value == fret
+            is_new_min = False
+            if not have_opt or value < opt:                                            # :1521-1525
+                is_new_min = (not have_opt) or not (abs(value - opt) < steptol)         # approxeq (common.h:66-68)
+                opt, have_opt = value, True
+            assert int(row[7]) == int(is_new_min), ("node %d: updateDomain's verdict" % n, row, opt)
+            last_opt, have_prev = is_new_min, True                                     # :1554, :1576
+
+    try:
+        for r in roots:
+            do_optimization(r, False)
+    except TimedOut:
+        return -1   # (the budget cut the run short: a depth-first walk cannot tell which nodes the lock-step run still reached)
+    for n, q in queues.items():
+        assert pos[n] == len(q), "node %d: %d records of the device run were not asked for" % (n, len(q) - pos[n])
+    return calls[0]

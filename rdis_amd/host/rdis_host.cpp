@@ -53,7 +53,7 @@ bool parseNumber(const std::string& s, double& v) {
 }  // namespace
 
 // ------------------------------------------------------------------ VariableDomain
-VariableDomain::VariableDomain(const std::string& domain) : lo_(0), hi_(0) {
+VariableDomain::VariableDomain(const std::string& domain) : lo_(0), hi_(0), slo_(0), shi_(0) {
     std::vector<double> v;
     std::string cur;
     for (char ch : domain + " ") {
@@ -65,6 +65,7 @@ VariableDomain::VariableDomain(const std::string& domain) : lo_(0), hi_(0) {
     }
     if (v.size() < 2) throw std::invalid_argument("VariableDomain: cannot parse '" + domain + "'");
     lo_ = v.front(); hi_ = v.back();
+    slo_ = lo_; shi_ = hi_;
 }
 
 // ------------------------------------------------------------------ Variable
@@ -336,7 +337,7 @@ void BundleAdjustmentFunction::setDomain(VariableID vid, Numeric init) {
         dhi = shi * dsf;
     } else if (type == 7) { slo = init + -1e-4; shi = init + 1e-4; dlo = -1e-1; dhi = 1e-1; }
     else { slo = init + -1e-6; shi = init + 1e-6; dlo = -1e-3; dhi = 1e-3; }
-    variables[(size_t)vid]->setDomain(VariableDomain(std::min(dlo, slo), std::max(dhi, shi)));  // hull
+    variables[(size_t)vid]->setDomain(VariableDomain(std::min(dlo, slo), std::max(dhi, shi), slo, shi));  // hull; sampling interval
 }
 
 bool BundleAdjustmentFunction::load(const std::string& file, VariableCount numcams, VariableCount numpoints) {
@@ -452,7 +453,8 @@ std::unique_ptr<PolynomialFunction> PolynomialFunction::makeHighDimSinusoid(Vari
     char buf[64];
     std::snprintf(buf, sizeof buf, "%g", 10 * twopi);  // boost::format("%1%") prints 6 significant digits
     const double bound = std::strtod(buf, nullptr);
-    std::unique_ptr<PolynomialFunction> poly(new PolynomialFunction(VariableDomain(-bound, bound)));
+    // (domain +-10 tp, random states sampled from +-tp: src/OptimizableFunctionGenerator.cpp:660-760)
+    std::unique_ptr<PolynomialFunction> poly(new PolynomialFunction(VariableDomain(-bound, bound, -twopi, twopi)));
     maxArity = std::min(maxArity, h + 1);
     const VariableCount nvars = k == 1 ? h + 1 : (VariableCount)((std::llround(std::pow((double)k, (double)h + 1)) - 1) / (k - 1));
     VariableID id = 0;

@@ -62,8 +62,14 @@ private:
 // single-interval domain (CGD asserts exactly one sub-interval, CGDSubspaceOptimizer.cpp:119)
 class VariableDomain {
 public:
-    VariableDomain() : lo_(0), hi_(0) {}
-    VariableDomain(Numeric lower, Numeric upper) : lo_(lower), hi_(upper) {}
+    VariableDomain() : lo_(0), hi_(0), slo_(0), shi_(0) {}
+    VariableDomain(Numeric lower, Numeric upper) : lo_(lower), hi_(upper), slo_(lower), shi_(upper) {}
+    // ... with the interval random states are sampled from (src/VariableDomain.h: getSamplingInterval; the bundle-adjustment
+    // loader sets it per variable type, src/bundleadjust/BundleAdjustmentFunction.cpp:419-471)
+    VariableDomain(Numeric lower, Numeric upper, Numeric sampleLower, Numeric sampleUpper)
+        : lo_(lower), hi_(upper), slo_(sampleLower), shi_(sampleUpper) {}
+    Numeric samplingMin() const { return slo_; }
+    Numeric samplingMax() const { return shi_; }
     explicit VariableDomain(const std::string& domain);  // "lo:hi" (src/VariableDomain.cpp:63-72)
     Numeric min() const { return lo_; }
     Numeric max() const { return hi_; }
@@ -72,7 +78,7 @@ public:
         return val < lo_ ? lo_ : hi_;
     }
 private:
-    Numeric lo_, hi_;
+    Numeric lo_, hi_, slo_, shi_;
 };
 
 class Variable {

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <numeric>
 
@@ -44,7 +45,9 @@ struct HipRDISLevelOptimizer::LevelPlan {
 
 HipRDISLevelOptimizer::HipRDISLevelOptimizer(OptimizableFunction& f, HipCGDSubspaceOptimizer& ssopt)
     : f_(f), ss_(ssopt), blkpct_(0.2), steptol_(1.0e-4), seppct_(0.0), maxSweeps_(20), batch_(true),
-      ssmaxit_(ssopt.getMaxIters()), ssftol_(ssopt.getFtol()), sweeps_(0), decomp_ms_(0) {}
+      ssmaxit_(ssopt.getMaxIters()), ssftol_(ssopt.getFtol()), sweeps_(0), decomp_ms_(0),
+      nrr_per_lvl_(2), nrr_at_top_(2), min_rr_(1), max_na_to_rr_(10), no_assign_limit_at_top_(true), nrr_at_top_set_(false),
+      restart_seed_(0x5D15ull), max_calls_(100000), ref_calls_(0) {}
 
 HipRDISLevelOptimizer::~HipRDISLevelOptimizer() { releasePlans(); }
 
@@ -62,6 +65,14 @@ void HipRDISLevelOptimizer::setParameters(const Options& o) {
     if (o.count("maxSweeps")) maxSweeps_ = o.as<int>("maxSweeps");
     if (o.count("batch")) batch_ = o.as<int>("batch") != 0;
     if (o.count("sepPiecePct")) seppct_ = o.as<double>("sepPiecePct");
+    if (o.count("nRRperLvl")) nrr_per_lvl_ = (unsigned)o.as<int>("nRRperLvl");          // RDISOptimizer.cpp:97, 1781-1782
+    if (o.count("nRRatTop")) { nrr_at_top_ = (unsigned)o.as<int>("nRRatTop"); nrr_at_top_set_ = true; }   // :99, 1784-1785
+    if (!nrr_at_top_set_) nrr_at_top_ = nrr_per_lvl_;
+    if (o.count("minRR")) min_rr_ = (unsigned)o.as<int>("minRR");                       // :102, 1778-1779
+    if (o.count("maxNAtoRR")) max_na_to_rr_ = (unsigned)o.as<int>("maxNAtoRR");         // :104, 1787-1788
+    if (o.count("noAssignLimitAtTop")) no_assign_limit_at_top_ = o.as<int>("noAssignLimitAtTop") != 0;   // :115, 1793-1794
+    if (o.count("restartSeed")) restart_seed_ = (unsigned long long)o.as<double>("restartSeed");
+    if (o.count("maxCalls")) max_calls_ = (long long)o.as<double>("maxCalls");
     if (blkpct_ <= 0 || blkpct_ > 1 || maxSweeps_ < 1) throw std::invalid_argument("HipRDISLevelOptimizer: bad options");
 }
 
@@ -366,6 +377,171 @@ Numeric HipRDISLevelOptimizer::optimize(bool printInfo) {
     const double check_f = f_.eval();   // the running sum of the launches' deltas IS the function value
     if (printInfo) std::cout << "level driver: final value " << check_f << " (sum of deltas: " << objective << ") after " << sweeps_ << " sweep(s)" << std::endl;
     return check_f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's schedule on the static tree (header comment; every rule cites src/RDISOptimizer.cpp)
+struct HipRDISLevelOptimizer::NodeState {
+    unsigned nrr = 0, va = 0;        // Component::numRandomRestarts, numVAsinceLastRR (src/Component.h:186-196)
+    bool assigned = false;           // the node's variables have been valued in this visit (vardata.isAssigned(repvid), :1023)
+    bool lastOpt = false;            // Component::wasLastEvalOpt (:1554)
+    bool havePrev = false, haveOpt = false;   // getPrevSD / getOptSD (:1025-1026, 1514)
+    double opt = 0.0;
+    std::vector<double> optx;        // the node's variables at its best evaluation (the optimum subdomain)
+    bool randomInit = false;         // its initial values have been used up by an ancestor's restart (:1127, 1134-1136)
+    int kind = 0;
+    double fret = 0.0, delta = 0.0;
+    unsigned long long hash = 0;
+};
+
+double HipRDISLevelOptimizer::restartValue(unsigned long long seed, int node, int restart, VariableID vid, const VariableDomain& dom) {
+    // sampleRandomState (:1196-1216): uniform over the sampling interval, clamped into the domain.  The number comes
+    // from splitmix64 of (seed, node, restart, variable) instead of the reference's shared generator.
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(node + 1) + 0xBF58476D1CE4E5B9ull * (unsigned long long)(restart + 1) +
+                           0x94D049BB133111EBull * (unsigned long long)(vid + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    const double lo = dom.samplingMin(), hi = dom.samplingMax();
+    return dom.closestVal(lo + u * (hi - lo));
+}
+
+void HipRDISLevelOptimizer::runSet(const std::vector<int>& set, const std::vector<char>& randomInit, std::vector<NodeState>& st, bool printInfo) {
+    const VariablePtrVec& vars = f_.getVariables();
+    const FactorPtrVec& facs = f_.getFactors();
+    for (size_t i = 0; i < set.size(); ++i) { st[(size_t)set[i]] = NodeState(); st[(size_t)set[i]].randomInit = randomInit[i] != 0; }
+    auto numRestarts = [&](int n) {   // :978-983 (level = depth + 1; a top component: depth 0)
+        const unsigned lvl = nrr_per_lvl_ >> std::min(31, nodes_[(size_t)n].depth);
+        return std::max(min_rr_, nodes_[(size_t)n].depth == 0 ? nrr_at_top_ : lvl);
+    };
+    auto valued = [&](int n) -> const std::vector<VariableID>& { return nodes_[(size_t)n].leaf ? nodes_[(size_t)n].vars : nodes_[(size_t)n].separator; };
+    auto valuedFactors = [&](int n) -> const std::vector<FactorID>& { return nodes_[(size_t)n].leaf ? nodes_[(size_t)n].factors : nodes_[(size_t)n].sepFactors; };
+    auto finish = [&](int n) {   // the node is left at its best evaluation (the optimum subdomain its parent multiplies in, :1484-1494)
+        NodeState& s = st[(size_t)n];
+        if (!s.haveOpt) return;
+        const std::vector<VariableID>& nv = nodes_[(size_t)n].vars;
+        for (size_t i = 0; i < nv.size(); ++i)
+            if (vars[(size_t)nv[i]]->eval() != s.optx[i]) { vars[(size_t)nv[i]]->assign(s.optx[i]); f_.onVarAssigned(nv[i], s.optx[i]); }
+    };
+    std::vector<int> active(set);
+    while (!active.empty()) {
+        if (ref_calls_ >= max_calls_) {   // the reference's time limit (checkTimedOut, :317-321): every loop ends where it stands
+            for (int n : active) finish(n);
+            return;
+        }
+        // getValueFromDomain's entry (:986-1000) and getSSInitialVal (:1120-1147): who goes on, and from where
+        std::vector<int> pending;
+        std::vector<std::vector<double> > start(nodes_.size());
+        for (int n : active) {
+            NodeState& s = st[(size_t)n];
+            const bool top = nodes_[(size_t)n].depth == 0;
+            const bool forceRR = !(top && no_assign_limit_at_top_) && s.va >= max_na_to_rr_;          // :992-994
+            if ((forceRR || !s.lastOpt) && s.nrr > numRestarts(n)) { finish(n); continue; }           // :997-999
+            const std::vector<VariableID>& V = valued(n);
+            std::vector<double>& x0 = start[(size_t)n];
+            if (!s.assigned && !s.randomInit) { s.kind = 0; for (VariableID v : V) x0.push_back(vars[(size_t)v]->eval()); }        // xvalinit (:1127-1130)
+            else if (s.assigned && !forceRR) { s.kind = 1; for (VariableID v : V) x0.push_back(vars[(size_t)v]->eval()); }        // :1131-1133
+            else { s.kind = 2; for (VariableID v : V) x0.push_back(restartValue(restart_seed_, n, (int)s.nrr, v, vars[(size_t)v]->getDomain())); }   // :1134-1136
+            if (s.kind != 1) { ++s.nrr; s.va = 0; }                                                     // :1047, Component.h:190-194
+            pending.push_back(n);
+        }
+        // the subspace optimizer, and again from a random state where it made no progress (:1032-1106)
+        std::vector<int> succeeded;
+        while (!pending.empty()) {
+            std::vector<HipCGDSubspaceOptimizer::Component> comps(pending.size());
+            for (size_t i = 0; i < pending.size(); ++i) {
+                const int n = pending[i];
+                for (VariableID v : valued(n)) comps[i].vars.push_back(vars[(size_t)v]);
+                for (FactorID fa : valuedFactors(n)) comps[i].factors.push_back(facs[(size_t)fa]);
+                comps[i].xval = start[(size_t)n];
+            }
+            ss_.optimizeBatch(comps, false);
+            ref_calls_ += (long long)pending.size();
+            std::vector<int> again;
+            const double ftol = steptol_;   // :1083-1084
+            for (size_t i = 0; i < pending.size(); ++i) {
+                const int n = pending[i];
+                NodeState& s = st[(size_t)n];
+                s.fret = comps[i].fret; s.delta = comps[i].deltaFval;
+                unsigned long long h = 1469598103934665603ull;
+                for (double v : start[(size_t)n]) { unsigned long long b; std::memcpy(&b, &v, 8); h = (h ^ b) * 1099511628211ull; }
+                s.hash = h;
+                if (s.havePrev && s.delta >= 0.0 - ftol) {       // approxgeq(deltafval, 0, ftol) (:1086, common.h:74-76)
+                    RefStep rs{n, s.kind, (int)s.nrr, (int)s.va, s.fret, s.delta, std::nan(""), 0, s.hash};
+                    ref_trace_.push_back(rs);
+                    if (s.nrr < numRestarts(n)) {                 // :1087-1094: try again from a random position
+                        s.kind = 2;
+                        std::vector<double>& x0 = start[(size_t)n];
+                        x0.clear();
+                        for (VariableID v : valued(n)) x0.push_back(restartValue(restart_seed_, n, (int)s.nrr, v, vars[(size_t)v]->getDomain()));
+                        ++s.nrr; s.va = 0;
+                        again.push_back(n);
+                    } else {
+                        finish(n);                                // :1095-1099: a failure ends the node's loop (:279)
+                    }
+                } else {
+                    succeeded.push_back(n);
+                }
+            }
+            pending.swap(again);
+        }
+        std::sort(succeeded.begin(), succeeded.end());
+        // assign (:282), decompose and recurse into the children (:289-314) -- all children of all these nodes together
+        std::vector<int> kids;
+        std::vector<char> kidsRandom;
+        for (int n : succeeded) {
+            NodeState& s = st[(size_t)n];
+            s.assigned = true;
+            ++s.va;                                               // Component.cpp:221
+            for (int c : children_[(size_t)n]) { kids.push_back(c); kidsRandom.push_back(s.kind == 2 ? 1 : 0); }
+        }
+        if (!kids.empty()) runSet(kids, kidsRandom, st, printInfo);
+        // updateDomain (:1507-1577)
+        for (int n : succeeded) {
+            NodeState& s = st[(size_t)n];
+            const Node& nd = nodes_[(size_t)n];
+            double value = s.fret;                                // a leaf's value IS what its solve returned
+            if (!nd.leaf) {
+                FactorPtrVec fl;
+                for (FactorID fa : nd.factors) fl.push_back(facs[(size_t)fa]);
+                Numeric ferr = 0;
+                value = f_.evalFactors(fl, ferr, true);
+            }
+            bool isNewMin = false;
+            if (!s.haveOpt || value < s.opt) {                                        // :1521-1525
+                isNewMin = !s.haveOpt || !(std::fabs(value - s.opt) < steptol_);     // approxeq (common.h:66-68)
+                s.opt = value; s.haveOpt = true;
+                s.optx.resize(nd.vars.size());
+                for (size_t i = 0; i < nd.vars.size(); ++i) s.optx[i] = vars[(size_t)nd.vars[i]]->eval();
+            }
+            s.lastOpt = isNewMin;                                                      // :1554
+            s.havePrev = true;                                                         // :1576
+            RefStep rs{n, s.kind, (int)s.nrr, (int)s.va, s.fret, s.delta, value, isNewMin ? 1 : 0, s.hash};
+            ref_trace_.push_back(rs);
+            if (printInfo && nd.depth == 0)
+                std::cout << "node " << n << ": " << (s.kind == 0 ? "initial values" : s.kind == 1 ? "iterative improvement" : "random restart")
+                          << ", nRR " << s.nrr << " / " << numRestarts(n) << " -> " << value << (isNewMin ? " (new minimum)" : "") << std::endl;
+        }
+        active.swap(succeeded);
+    }
+}
+
+Numeric HipRDISLevelOptimizer::optimizeReferenceSchedule(bool printInfo) {
+    for (const Variable* v : f_.getVariables())
+        if (!v->isAssigned()) throw std::logic_error("HipRDISLevelOptimizer::optimizeReferenceSchedule: assign an initial state first");
+    buildTree();
+    children_.assign(nodes_.size(), std::vector<int>());
+    std::vector<int> roots;
+    for (size_t i = 0; i < nodes_.size(); ++i) {
+        if (nodes_[i].factors.empty()) continue;   // checkEmpty (:262)
+        if (nodes_[i].parent >= 0) children_[(size_t)nodes_[i].parent].push_back((int)i); else roots.push_back((int)i);
+    }
+    ref_trace_.clear();
+    ref_calls_ = 0;
+    std::vector<NodeState> st(nodes_.size());
+    runSet(roots, std::vector<char>(roots.size(), 0), st, printInfo);
+    return f_.eval();
 }
 
 }  // namespace rdis

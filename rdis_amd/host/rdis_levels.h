@@ -21,8 +21,10 @@
 //     steps, :1091-1108), at most maxSweeps times.
 //
 // Not carried over (they are what makes sibling order observable in the reference, SURVEY.md 7
-// hard part 6): branch and bound, the component cache, random restarts.  With them off the
-// reference's own recursion is this alternation.
+// hard part 6): branch and bound, the component cache.  With them and the random restarts off the
+// reference's own recursion is this alternation (optimize()).  optimizeReferenceSchedule() (round 4) runs the
+// tree under the reference's own per-node schedule instead -- iterative improvement node by node and random
+// restarts, with restart values drawn per (node, restart, variable) so that siblings stay independent.
 #ifndef RDIS_LEVELS_H_
 #define RDIS_LEVELS_H_
 
@@ -65,6 +67,42 @@ public:
     // Every variable must be assigned (the initial state, optBA.cpp:189-205).  Returns the final
     // value of the function; the variables are left assigned to the optimum found.
     Numeric optimize(bool printInfo = false);
+
+    // The same tree under the REFERENCE'S schedule (round 4): what doOptimization / getValueFromDomain do at every node
+    // (src/RDISOptimizer.cpp:253-334, 971-1147, 1507-1577) with branch and bound and the component cache off --
+    //   * a node is valued again and again: first from its initial values (step type "initial values"), then, with its
+    //     children re-optimised in between, from where it stands ("iterative improvement", :1131-1133) for as long as
+    //     the subspace optimizer makes progress beyond steptol (:1086-1101); its children run their own such loops to
+    //     their end before the node is valued again (the recursion of :292-314);
+    //   * when a step makes no progress the node is restarted from a random state (:1088-1094, sampleRandomState
+    //     :1196-1216: uniform over each variable's sampling interval), at most numRestarts = max(minRR, nRRperLvl >>
+    //     depth) times (nRRatTop at depth 0; :978-983), and after maxNAtoRR assignments without one a restart is forced
+    //     below the top (:992-994); a restarted node's children start from random states too (their initial values have
+    //     been used up, :1127);
+    //   * every evaluation of a node is compared with its best so far (updateDomain :1507-1577: a new minimum only beyond
+    //     steptol), a node is done when its last evaluation was no new minimum and its restarts are spent (:997-999),
+    //     and it is left at its best.
+    // What is NOT the reference's: the tree (chooseSeparator in place of PaToH), the random numbers -- a restart's
+    // values are drawn per (node, restart, variable) from splitmix64(restartSeed ...), so siblings can be solved in any
+    // order or together (the reference draws from one shared mt19937 in visiting order, :1139, 1223-1225) -- and that
+    // every variable keeps a value throughout (the reference's alwaysUseAllFactors, :1029-1030, 1165-1182).  Independent
+    // nodes run in lock-step: all first evaluations of a set of siblings in one optimizeBatch, all their children
+    // together, and so on.  Options: nRRperLvl (2), nRRatTop (nRRperLvl), minRR (1), maxNAtoRR (10),
+    // noAssignLimitAtTop (1), restartSeed, maxCalls (100000 subspace-optimizer calls: the reference's time limit, :317-321 --
+    // when it is reached every node's loop ends where it stands, at its best).  End-to-end parity with the reference stays unpinned (PaToH, Boost's
+    // generator); what is pinned is the schedule: oracle/levels.py restates it from the reference's lines and must take
+    // the same decisions, and draw the same restart values, bit for bit, from the values this run's solves returned.
+    struct RefStep {
+        int node, kind;                    // kind 0: initial values, 1: iterative improvement, 2: random restart
+        int nrr, va;                       // the node's restart count and assignments since the last one, after the step
+        double fret, delta;                // what the subspace optimizer returned
+        double value;                      // the node's value after its children ran (NaN: the step made no progress)
+        int newMin;                        // updateDomain's verdict
+        unsigned long long startHash;      // FNV-1a over the bits of the start vector
+    };
+    Numeric optimizeReferenceSchedule(bool printInfo = false);
+    const std::vector<RefStep>& refTrace() const { return ref_trace_; }
+    static double restartValue(unsigned long long seed, int node, int restart, VariableID vid, const VariableDomain& dom);
 
     // The decomposition alone -- tree and per-depth plans, nothing solved (what optimize() does first): for callers
     // that want to look at it, and for the parity tests against oracle/levels.py.
@@ -111,6 +149,15 @@ private:
     std::vector<Step> trace_;
     int sweeps_;
     double decomp_ms_;
+    // reference schedule
+    struct NodeState;
+    void runSet(const std::vector<int>& set, const std::vector<char>& randomInit, std::vector<NodeState>& st, bool printInfo);
+    unsigned nrr_per_lvl_, nrr_at_top_, min_rr_, max_na_to_rr_;
+    bool no_assign_limit_at_top_, nrr_at_top_set_;
+    unsigned long long restart_seed_;
+    long long max_calls_, ref_calls_;   // budget of subspace-optimizer calls (the reference: a time limit, :317-321), calls so far
+    std::vector<std::vector<int> > children_;
+    std::vector<RefStep> ref_trace_;
 };
 
 }  // namespace rdis

@@ -259,6 +259,38 @@ int harness_level_driver_devices(const char* path, long long ncams, long long np
     } catch (const std::exception& e) { std::cerr << "harness_level_driver_devices: " << e.what() << std::endl; return -2; }
 }
 
+// The level driver under the reference's schedule (HipRDISLevelOptimizer::optimizeReferenceSchedule): per-node iterative
+// improvement and random restarts.  out = {final value, value before, nodes, steps}; trace rows of 10 doubles:
+// node, kind, nrr, va, fret, delta, value, newMin, start hash (high 32 bits, low 32 bits).  Returns the number of steps.
+long long harness_level_reference(const char* path, long long ncams, long long npts, int maxit, double blkpct, double seppct,
+                                  int nrr_per_lvl, int max_na_to_rr, double seed, int ndev, double max_calls, double steptol, double* out, double* trace_out,
+                                  long long trace_cap, double* x_out) {
+    try {
+        BundleAdjustmentFunction f;
+        if (!f.load(path, ncams, npts)) return -1;
+        if (ndev > 1) f.setDevices(std::vector<int>((size_t)ndev, 0));
+        f.assignAll(f.getInitialState());
+        const Numeric before = f.eval();
+        HipCGDSubspaceOptimizer ssopt(f);
+        Options o; o.set("SSmaxit", maxit);
+        ssopt.setParameters(o);
+        HipRDISLevelOptimizer rdis(f, ssopt);
+        Options ro; ro.set("AVblkpct", blkpct); ro.set("sepPiecePct", seppct); ro.set("nRRperLvl", nrr_per_lvl);
+        ro.set("maxNAtoRR", max_na_to_rr); ro.set("restartSeed", seed); ro.set("maxCalls", max_calls); ro.set("steptol", steptol);
+        rdis.setParameters(ro);
+        const Numeric fin = rdis.optimizeReferenceSchedule(false);
+        const auto& tr = rdis.refTrace();
+        out[0] = fin; out[1] = before; out[2] = (double)rdis.nodes().size(); out[3] = (double)tr.size();
+        for (size_t i = 0; i < tr.size() && (long long)i < trace_cap; ++i) {
+            double* r = trace_out + 10 * i;
+            r[0] = tr[i].node; r[1] = tr[i].kind; r[2] = tr[i].nrr; r[3] = tr[i].va; r[4] = tr[i].fret; r[5] = tr[i].delta;
+            r[6] = tr[i].value; r[7] = tr[i].newMin; r[8] = (double)(tr[i].startHash >> 32); r[9] = (double)(tr[i].startHash & 0xFFFFFFFFull);
+        }
+        if (x_out) for (size_t i = 0; i < f.getVariables().size(); ++i) x_out[i] = f.getVariables()[i]->eval();
+        return (long long)tr.size();
+    } catch (const std::exception& e) { std::cerr << "harness_level_reference: " << e.what() << std::endl; return -2; }
+}
+
 // LMSubspaceOptimizer's place taken by HipLMSubspaceOptimizer: all variables of a BAL subset.
 // out = {fret, delta, f_before, f_after, iterations, stop, linear solves}
 int harness_ba_lm(const char* path, long long ncams, long long npts, int maxit, double* out, double* x_out) {

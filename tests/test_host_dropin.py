@@ -528,6 +528,47 @@ def test_level_tree_of_the_sinusoid_and_first_sweep_against_the_oracle(harness, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nc,npnt,pct,seppct,nrr,maxna,steptol", [(5, 30, 0.2, 0.0, 2, 10, 1e-2), (12, 200, 0.1, 0.4, 2, 3, 0.5), (7, 50, 0.2, 0.0, 4, 5, 0.1)])
+def test_reference_schedule_of_the_level_driver(harness, bal_path, nc, npnt, pct, seppct, nrr, maxna, steptol):
+    """HipRDISLevelOptimizer::optimizeReferenceSchedule -- per-node iterative improvement and random restarts the way
+    RDISOptimizer::doOptimization / getValueFromDomain / updateDomain run them (src/RDISOptimizer.cpp:253-334, 971-1147,
+    1507-1577) -- against oracle/levels.py::replay_reference_schedule, a restatement written from those lines that walks
+    the tree depth first like the reference and takes every decision itself from the values the device's solves
+    returned: kind of every step (initial values / iterative improvement / random restart), restart counts, forced
+    restarts after maxNAtoRR assignments, the restart's start vector bit for bit, updateDomain's verdicts, where each
+    node's loop ends -- and nothing of the device's trace may be left over.  (steptol is the reference's absolute
+    progress threshold, default 1e-4; larger here so that the loops end in seconds.)  Lock-step batching over independent nodes
+    and several devices change none of it; the function value never rises above the start's and the variables are left
+    at the best evaluation found.  (End-to-end parity with optBA is not pinned: PaToH, Boost's generator.)"""
+    from oracle import levels as LV
+    pp = P.load_bal(ncams=nc, npts=npnt)
+    nodes = LV.build_tree(pp, O.OracleProblem(pp), blkpct=pct, seppct=seppct)
+    slo, shi = LV.ba_sampling_intervals(pp, nc)
+    res = {}
+    for ndev in (1, 2):
+        out, tr, x = np.zeros(4), np.zeros((300000, 10)), np.zeros(pp.nvars)
+        harness.harness_level_reference.restype = C.c_longlong
+        n = harness.harness_level_reference(bal_path, C.c_longlong(nc), C.c_longlong(npnt), 25, C.c_double(pct), C.c_double(seppct), nrr, maxna,
+                                            C.c_double(12345.0), ndev, C.c_double(300000.0), C.c_double(steptol), out.ctypes.data_as(C.c_void_p), tr.ctypes.data_as(C.c_void_p),
+                                            C.c_longlong(len(tr)), x.ctypes.data_as(C.c_void_p))
+        assert 0 < n <= len(tr) and out[2] == len(nodes)
+        res[ndev] = (out.copy(), tr[:n].copy(), x.copy())
+    out, tr, x = res[1]
+    assert np.array_equal(tr, res[2][1], equal_nan=True) and np.array_equal(x, res[2][2]) and np.array_equal(out, res[2][0])   # two contexts: the same run
+    rows = [tuple(r[:8]) + (int(r[8]) << 32 | int(r[9]),) for r in tr]
+    assert len(tr) < 300000                                     # (the budget of calls -- the reference's time limit -- was not what ended it)
+    calls = LV.replay_reference_schedule(nodes, rows, pp, slo, shi, steptol=steptol, nrr_per_lvl=nrr, max_na_to_rr=maxna, seed=12345, max_calls=300000)
+    kinds = np.bincount(tr[:, 1].astype(int), minlength=3)
+    print("reference schedule, %d cameras / %d points: %d nodes, %d subspace-optimizer calls (%d initial, %d iterative improvement, %d random restarts), "
+          "%.6f -> %.6f" % (nc, npnt, len(nodes), calls, kinds[0], kinds[1], kinds[2], out[1], out[0]))
+    assert calls == len(tr) and kinds[1] > 0 and kinds[2] > 0
+    assert out[0] <= out[1]
+    o = O.OracleProblem(pp)
+    o.assign(np.arange(pp.nvars, dtype=np.int64), x)
+    assert abs(o.eval() - out[0]) <= 1e-10 * abs(out[0])       # the variables are left at what was returned
+
+
+@pytest.mark.gpu
 def test_plan_cache_is_bounded_and_never_changes_a_bit(harness, bal_path):
     """The host-side cache of resident plans: bounded by entries AND by device bytes, least recently used
     first; a call whose plan does not fit the budget at all is served by the transient path.  Whatever the bounds,
