@@ -40,6 +40,9 @@ struct rdis_hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // resident-workgroup caps of the cooperative layouts on THIS device (occupancy queries, asked once per context)
     int cap_pipe = -1, cap_coop[3] = {-1, -1, -1};
+    // dynamic LDS a launch may ask for on THIS device: what a compute unit has, less the solvers' static share (at most
+    // solver_lds.hpp's LDS_MAX_BYTES, which is gfx950's); components that do not fit go to the solvers that need none
+    size_t lds_limit = LDS_MAX_BYTES;
 };
 
 namespace {
@@ -335,6 +338,8 @@ extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
     }
     c->own_stream = true;
     c->num_cus = prop.multiProcessorCount;
+    if (prop.maxSharedMemoryPerMultiProcessor > 4096)
+        c->lds_limit = std::min<size_t>((size_t)LDS_MAX_BYTES, (size_t)prop.maxSharedMemoryPerMultiProcessor - 4096);
     *out = c;
     return 0;
 }
@@ -1364,10 +1369,10 @@ int prepare_partition(rdis_hip_plan* L) {
             const int nchunk = (int)gp.size() / 64;
             // (the streaming solver is for what is too LARGE for the LDS: with lds_resident = 0 such components stay with
             // solver_wg.hpp -- the comparison the bit-identity tests make; ptm_stream = 2 sends everything its tables fit)
-            const bool lds_size_ok = lds_bytes_for(ns, ncb, nchunk) <= (size_t)LDS_MAX_BYTES;
+            const bool lds_size_ok = lds_bytes_for(ns, ncb, nchunk) <= c->lds_limit;
             const bool fits_lds = L->lds_resident != 0 && lds_size_ok && L->ptm_stream != 2;
             const bool fits_ptm = !fits_lds && (L->ptm_stream == 2 || (L->ptm_stream == 1 && !lds_size_ok)) &&
-                                  ptm_bytes_for(ncb, ptm_max_threads) <= (size_t)LDS_MAX_BYTES;
+                                  ptm_bytes_for(ncb, ptm_max_threads) <= c->lds_limit;
             if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
             if (fits_lds) std::sort(pts.begin(), pts.end());
             else {
@@ -1461,7 +1466,7 @@ int prepare_partition(rdis_hip_plan* L) {
             }
         }
         // (the maxima of a launch may come from different components: its LDS must hold them together)
-        if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap) > (size_t)LDS_MAX_BYTES)
+        if (L->lds_ns_cap > 0 && lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap) > c->lds_limit)
             for (size_t cc = 0; cc < nc; ++cc) if (kind_of[cc] == 1) kind_of[cc] = 0;
         auto first_other = std::stable_partition(L->h_rest.begin() + L->rest_tiny, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 0; });
         auto first_lds = std::stable_partition(first_other, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 2; });
