@@ -94,6 +94,11 @@ struct PlanView {
     const unsigned short* pm_rounds;   // per round ptm_round_stride(ncb) 16-bit words: per camera the first row of its segment [ncb + 1]
     const long long* pm_rd_off;        // [ncomp * K] a workgroup's first word in pm_rounds ...
     const int* pm_rd_n;                // ... and its number of rounds
+    // a trial's work by wave (solver_ptm.hpp: eval_line): rows (wave-chunk, first entry, end entry); wave w of workgroup
+    // (component, rank) takes the rows w, w + waves, w + 2 waves, ... up to the first empty one.  A workgroup's table:
+    // its number of rows R and three ints of nothing, then the rows' chunks [R], first entries [R], end entries [R]
+    const int* pm_segs;
+    const long long* pm_sg_off;        // [ncomp * K] a workgroup's table in pm_segs
     int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...
     double* st_val;       // ... and that value; null unless the plan's option emulate_stale_cache is set
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null

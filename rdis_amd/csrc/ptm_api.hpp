@@ -25,8 +25,10 @@ constexpr int PTM_MAX_CAMERAS = 4095;  // camera blocks per component (twelve bi
 // A camera block's ten LDS slots: [tx ty tz f k1 k2 | rx ry rz | pad] -- the six values every factor reads first, from a
 // 16-byte boundary (three 16-byte reads; ds_read2_b64 pairs move half as many bytes per LDS cycle, MI355X_MICROARCH.md LDS);
 // variable k of the block (reference order r, t, f, k1, k2: BundleAdjustmentCommon.h:36-59) stands at slot ptm_slot_of(k).
-// Rotation records: seven doubles from a 16-byte boundary, stride eight.
-constexpr int PTM_CS = 10, PTM_ROT0 = 6, PTM_RS = 8;
+// Rotation records: seven doubles from a 16-byte boundary, stride ten; a camera's trial records (factors.hpp: CAM_TRIAL = 16
+// doubles) at stride eighteen.  Every stride an ODD number of 16-byte units: a 16-byte LDS read serves sixteen lanes a cycle
+// when their units differ mod 16, and lanes that read DIFFERENT cameras at a stride of 8 units (16 doubles) all stand on one.
+constexpr int PTM_CS = 10, PTM_ROT0 = 6, PTM_RS = 10, PTM_TS = 18;
 __host__ __device__ inline int ptm_slot_of(int k) { return k < 3 ? PTM_ROT0 + k : k - 3; }
 __host__ __device__ inline int ptm_var_of(int slot) { return slot < 6 ? slot + 3 : slot < 9 ? slot - PTM_ROT0 : -1; }   // -1: the pad
 
@@ -34,10 +36,10 @@ __host__ __device__ inline int ptm_var_of(int slot) { return slot < 6 ? slot + 3
 // the last (ncb + 1 values), rounded up to whole 32-bit words.
 __host__ __device__ inline int ptm_round_stride(int ncb) { return (ncb + 2) & ~1; }
 
-// LDS of a workgroup: [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records (factors.hpp)][(threads + 1) x 9 staged camera
+// LDS of a workgroup: [7 vectors of 10 ncb_cap camera slots][10 ncb_cap rotation records][2 x 18 ncb_cap trial records (factors.hpp)][(threads + 1) x 9 staged camera
 // partials][two round tables][10 ncb_cap free indices (int)]
 __host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads) {
-    return (size_t)ncb * PTM_CS * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * (PTM_RS + 2 * 16) * sizeof(double) +
+    return (size_t)ncb * PTM_CS * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * (PTM_RS + 2 * PTM_TS) * sizeof(double) +
            (size_t)(threads + 1) * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
 }
 

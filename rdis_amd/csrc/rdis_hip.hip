@@ -232,7 +232,7 @@ struct rdis_hip_plan {
     DevBuf pm_rec, pm_gh, pm_cbox, pm_bex, pm_cam, pm_obs;
     int64_t pm_cptr_len = 0;          // entries of pm_cptr (a component's wave-chunks + 1)
     // the gradient's round lists (solver_ptm.hpp), built for one workgroup size and group size at a time (ptm_build_rounds)
-    DevBuf pm_rounds, pm_rd_off, pm_rd_n, pm_grow;
+    DevBuf pm_rounds, pm_rd_off, pm_rd_n, pm_grow, pm_segs, pm_sg_off;
     int rounds_threads = 0, rounds_K = 0;
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
@@ -293,6 +293,7 @@ struct rdis_hip_plan {
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
         v.pm_rec = pm_rec.as<double>(); v.pm_gh = pm_gh.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
+        v.pm_segs = pm_segs.as<int>(); v.pm_sg_off = pm_sg_off.as<long long>();
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -1682,10 +1683,70 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
 // lane): a factor's rank is the staging row of its camera partials (pm_grow, two bytes per factor), and a round's
 // table names per camera the first row of its segment [ncb + 1] -- the order of the sums.  Built on the host from the
 // plan's point-major tables, once per (threads, K); nothing to build when no camera variable is free.
+// A trial's work by wave (solver_ptm.hpp: eval_line), for the same workgroups: the workgroup's wave-chunks cut into blocks of
+// PTM_BLK slots, the blocks in chunk order dealt out in equal CONTIGUOUS shares -- a wave's share is a run of whole chunks
+// with at most a partial one at either end (a chunk's 64 point blocks times some of their slots).  By whole chunks 41 of them
+// over 12 waves are four for some and three for the rest, and a trial waits for the slowest.
+static int ptm_build_segments(rdis_hip_plan* L, int threads, int K) {
+    rdis_hip_ctx* c = L->prob->ctx;
+    const int nw = threads / 64;
+    const int* li = L->h_lds_ints.data();
+    const int* ls_ptr = li + L->off_ls_ptr;
+    const int* ls_ncb = li + L->off_ls_ncb;
+    const int* pm_ch0 = li + L->off_pm_ch0;
+    const int* cptr = li + L->off_pm_cptr;
+    const size_t nwg = (size_t)L->ncomp * (size_t)K;
+    std::vector<long long> off(nwg, 0);
+    ivec rows;   // per workgroup: its number of rows R, 0, 0, 0, then three planes of R ints
+    std::vector<ivec> share((size_t)nw);
+    const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
+    for (size_t ri = r_ptm; ri < r_lds; ++ri) {
+        const int cc = L->h_rest[ri];
+        const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - PTM_CS * ncb) / 3, npc = (npb + 63) / 64;
+        const int* cp = cptr + pm_ch0[cc];
+        for (int rk = 0; rk < K; ++rk) {
+            long long units = 0;
+            for (int ch = rk; ch < npc; ch += K) units += ((cp[ch + 1] - cp[ch]) / 64 + PTM_BLK - 1) / PTM_BLK;
+            size_t depth = 0;
+            long long u = 0;   // blocks dealt out so far
+            int ch = rk, done = 0;   // the chunk at hand and its blocks already dealt out
+            for (int w = 0; w < nw; ++w) {
+                ivec& sh = share[(size_t)w];
+                sh.clear();
+                const long long end = units * (w + 1) / nw;
+                while (u < end) {
+                    const int nb = ((cp[ch + 1] - cp[ch]) / 64 + PTM_BLK - 1) / PTM_BLK;
+                    if (done >= nb) { ch += K; done = 0; continue; }
+                    const int take = (int)std::min<long long>(nb - done, end - u);
+                    const int e0 = cp[ch] + 64 * PTM_BLK * done, e1 = std::min(cp[ch + 1], e0 + 64 * PTM_BLK * take);
+                    sh.push_back(ch); sh.push_back(e0); sh.push_back(e1); sh.push_back(0);
+                    done += take; u += take;
+                }
+                depth = std::max(depth, sh.size() / 4);
+            }
+            // (two rows of nothing behind every wave's last: the loop asks for its rows two ahead)
+            const size_t base = rows.size(), R = (depth + 2) * (size_t)nw;
+            off[(size_t)cc * K + rk] = (long long)base;
+            rows.resize(base + 4 + 3 * R, 0);
+            rows[base] = (int)R;
+            for (int w = 0; w < nw; ++w)
+                for (size_t k = 0; k < share[(size_t)w].size() / 4; ++k)
+                    for (size_t q = 0; q < 3; ++q) rows[base + 4 + q * R + k * (size_t)nw + (size_t)w] = share[(size_t)w][4 * k + q];
+        }
+    }
+    int rc = plan_alloc(L, L->pm_segs, std::max<size_t>(rows.size(), 4) * sizeof(int));
+    if (!rc) rc = plan_alloc(L, L->pm_sg_off, nwg * sizeof(long long));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(L->pm_segs.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(L->pm_sg_off.p, off.data(), nwg * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->rounds_threads == threads && L->rounds_K == K) return 0;
     L->rounds_threads = threads; L->rounds_K = K;
+    { const int rc = ptm_build_segments(L, threads, K); if (rc) { L->rounds_threads = L->rounds_K = 0; return rc; } }
     if (L->ptm_rot_mode == ROT_CAMFIX) return 0;
     const int nw = threads / 64;
     const int* li = L->h_lds_ints.data();

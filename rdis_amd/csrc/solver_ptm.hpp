@@ -9,27 +9,31 @@
 //
 //   cameras   slots in LDS as in solver_lds.hpp (Pv, XI, LO, HI, X, rotation records; also g and h
 //             of the Polak-Ribiere recurrence);
-//   points    one 72-byte record per point block in HBM: p[3], xi[3] (doubles) and its bounds as six floats rounded
-//             INWARD (lo32 >= lo, hi32 <= hi): a trial value strictly inside them is inside the bounds and is its
-//             own clamp; only a lane whose value is not (an active bound: rare) fetches the block's exact bounds
-//             from a third array and clamps as ever -- the same bits either way, 24 bytes less per block and trial.
-//             The blocks stand in order of their number of factors (descending) and are taken 64 at a time, a
-//             wave-chunk: a lane takes a block, loads its record ONCE, forms clamp(p + a xi) in
-//             registers and evaluates the block's factors one after the other against the cameras in
-//             LDS.  The trial point of a point variable is never stored.
+//   points    one 48-byte record per point block in HBM: p[3], xi[3].  The blocks stand in camera-lexicographic order
+//             (blocks seen by the same cameras are neighbours), dealt out PTM_SPREAD chunks apart so that a chunk's
+//             blocks keep differing in their cameras, and are taken 64 at a time, a wave-chunk.  Per CHUNK a box of six
+//             floats rounded INWARD that lies inside every block's domain: a trial value strictly inside it is inside
+//             the block's bounds and is its own clamp; only a lane whose value is not (an active bound: rare) fetches
+//             the block's exact bounds from a second array and clamps as ever -- the same bits either way, 48 bytes less
+//             per block and trial than bounds in the record.  A lane takes a block, loads its record ONCE, forms
+//             clamp(p + a xi) in registers and evaluates the block's factors one after the other against the cameras
+//             in LDS.  The trial point of a point variable is never stored.
 //   factors   slot-major per wave-chunk: entry cptr[chunk] + 64 t + lane is the t-th listed factor of the
 //             lane's block (camera block 2 B + observation 16 B; camera -1 = the block has fewer
 //             factors).  A wave's loads of a slot are 64 neighbours, and their addresses depend on
 //             nothing the wave has loaded before.
 //
-// Nothing a wave needs is asked for when it is needed (round 4).  A chunk's entry range comes through the scalar
-// cache; its point records (and their float bounds, all six at once: the short-circuit form was three dependent
-// round trips) are loaded while the chunk BEFORE it is evaluated, slot t + 1 while slot t is evaluated, and the
-// first slot of the next chunk during the last slot of this one.  Before, every chunk began with five dependent
+// Nothing a wave needs is asked for when it is needed (round 4).  A chunk's entry range is read two chunks ahead;
+// its point records and its box are loaded while the chunk BEFORE it is evaluated, the slots of block t + 1 while
+// block t (PTM_BLK slots) is evaluated, and the first block of the next chunk during the last block of this one.  Before, every chunk began with five dependent
 // memory round trips (range -> records -> bounds x 3) in front of four slots' arithmetic, and three waves per SIMD
 // do not hide that: 62 % of all wave-cycles were parked (profiles/r03_c_pmc_sq_synthL.txt).
 //
-// HBM bytes per value+slope trial: 24 per point variable + 18 per factor (SURVEY 8d counts 16 + 24:
+// A trial's cameras are prepared once per trial point: rotation matrix R(w) and, for the slope, dR along the direction
+// (factors.hpp: ba_camera_trial, 16 doubles a camera in LDS, read as 16-byte pairs at a stride of 10 slots); a factor
+// is then R p + t, the projection and the radial term -- 88 instead of 164 fp64 operations for value and slope.
+//
+// HBM bytes per value+slope trial: 16 per point variable + 18 per factor (SURVEY 8d counts 16 + 24:
 // x and g once per variable, observation + two indices per factor), no write traffic at all.
 //
 // The full gradient, once per CG iteration, is ONE point-major pass like a trial (forward + adjoint; a block's
@@ -98,12 +102,14 @@ struct PtmEnv {
     const int* svid;          // variable id of a slot (cameras, then points)
     const int* sfree;         // local free index of a slot, -1 = constant (global copy; the cameras' also in SF)
     double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR;   // LDS, cameras (GC, HC: g and h of the recurrence)
-    double *CTR, *CDR;        // LDS [ncb][16] each: the cameras' trial records at the trial point at hand (factors.hpp: CAM_TRIAL)
+    double *CTR, *CDR;        // LDS [ncb][PTM_TS] each: the cameras' trial records at the trial point at hand (factors.hpp: CAM_TRIAL)
     double* STG;              // LDS [nt + 1][9]: the camera partials of a round's factors, grouped by camera (a factor's row: grow); a row of zeros
     unsigned short* RL;       // LDS [2][rl_cap]: round tables (per camera the first row of its segment)
     int rl_cap;
     int* SF;                  // LDS: local free index of a camera slot
-    double* PT;               // [npb][6] point records: p, xi
+    double* PT;               // [6][npb] the point blocks' p[3], xi[3], a plane each (six loads a lane that no pass of the compiler
+                              // can put together: the halves of a wider load are copied out right behind it, i.e. waited for at once)
+    long long pstr;           // ... a plane's length (npb)
     float* CBX;               // [npc][8] per wave-chunk a box inside the domains of all its blocks (lo[3], hi[3] as floats rounded inward)
     double* PE;               // [npb][6] the blocks' exact bounds (lo[3], hi[3])
     const int* cptr;          // [npc + 1] a point chunk's entries ...
@@ -112,7 +118,9 @@ struct PtmEnv {
     const unsigned short* grow;     // ... the staging row of their camera partials in the gradient's rounds
     const unsigned short* rounds;   // this workgroup's round tables (per camera the first row of its segment), rl_stride 16-bit words each ...
     int nrounds, rl_stride;         // ... and their number
-    double* PG;               // [npb][6] g and h of the recurrence for the blocks' variables
+    const int* segs;                // a trial's work by wave: rows (wave-chunk, first entry, end entry), wave w's at w, w + waves, ...;
+    int seg_rows;                   // three planes of seg_rows ints (three loads no pass of the compiler can put together, see PT)
+    double* PG;               // [6][npb] g[3] and h[3] of the recurrence for the blocks' variables, likewise
     double (*red)[3][MAX_WAVES];
     int parity;
     double* tr;
@@ -197,12 +205,12 @@ struct PtmEnv {
             BaFwd rot;
             ba_rotation(xc[0], xc[1], xc[2], rot);
             if constexpr (TRIAL) {
-                ba_camera_trial(rot, xc, CTR + CAM_TRIAL * c);
+                ba_camera_trial(rot, xc, CTR + PTM_TS * c);
                 if constexpr (SLOPE) {
                     double dc[9];
 #pragma unroll
                     for (int k = 0; k < 9; ++k) dc[k] = XI[s0 + ptm_slot_of(k)];   // (a constant's entry is zero)
-                    ba_camera_trial_dir(rot, dc, CDR + CAM_TRIAL * c);
+                    ba_camera_trial_dir(rot, dc, CDR + PTM_TS * c);
                 }
             } else {
                 double* rr = ROTR + PTM_RS * c;
@@ -236,13 +244,12 @@ struct PtmEnv {
     template <bool GRAD = false>
     __device__ __forceinline__ void load_recs(int c, PtRecs& R) const {
         const long long ps = min(64 * c + (tid & 63), npb - 1);
-        const double* rec = PT + PT_REC * ps;
         const float* bq = CBX + 8 * c;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { R.p[k] = rec[k]; R.xi[k] = rec[3 + k]; R.lo[k] = bq[k]; R.hi[k] = bq[4 + k]; }
+        for (int k = 0; k < 3; ++k) { R.p[k] = PT[k * pstr + ps]; R.xi[k] = PT[(3 + k) * pstr + ps]; R.lo[k] = bq[k]; R.hi[k] = bq[4 + k]; }
         if constexpr (GRAD) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) R.g[k] = PG[PT_REC * ps + k];
+            for (int k = 0; k < 3; ++k) R.g[k] = PG[k * pstr + ps];
         }
     }
     // exact clamp of a block's three values that are not all strictly inside the inward-rounded bounds
@@ -279,12 +286,11 @@ struct PtmEnv {
     }
     // clamp(x_start): the rollback's point (rare: loads where it stands)
     __device__ __forceinline__ void point_start(int ps, double (&x)[3]) const {
-        const double* rec = PT + (long long)PT_REC * ps;
         const double* be = PE + (long long)PT_BND * ps;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
-            x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : rec[k];
+            x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : PT[k * pstr + ps];
         }
     }
     __device__ __forceinline__ double forward(int c, double2 o, const double (&x)[3], double (&v)[12], BaFwd& t) const {
@@ -312,14 +318,14 @@ struct PtmEnv {
         slope = false;
 #endif
         double TR[CAM_TRIAL], DR[CAM_TRIAL];
-        const double2* tc = reinterpret_cast<const double2*>(CTR + CAM_TRIAL * cc);
+        const double2* tc = reinterpret_cast<const double2*>(CTR + PTM_TS * cc);
 #pragma unroll
         for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = tc[k]; TR[2 * k] = v.x; TR[2 * k + 1] = v.y; }
         BaTrial t;
         af += ba_trial_value(TR, x, o.x, o.y, t);
         if (slope) {
             if constexpr (ROT != ROT_CAMFIX) {
-                const double2* dc = reinterpret_cast<const double2*>(CDR + CAM_TRIAL * cc);
+                const double2* dc = reinterpret_cast<const double2*>(CDR + PTM_TS * cc);
 #pragma unroll
                 for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
             } else {
@@ -343,54 +349,68 @@ struct PtmEnv {
             if constexpr (ROWS) B.r[k] = grow[e + 64 * k + lane];
         }
     }
+    // holds a block of slots in registers at this point of the program (no instruction)
+    static __device__ __forceinline__ void pin_block(SlotBlock& B) {
+#pragma unroll
+        for (int k = 0; k < PTM_BLK; ++k) asm volatile("" : "+v"(B.c[k]), "+v"(B.o[k].x), "+v"(B.o[k].y));
+    }
     // This workgroup's share of the sums at clamp(p + a xi): its point chunks, a block per lane, the block's factors
     // PTM_BLK slots at a time.  Everything is asked for a block of slots before it is used: while one block of slots is
     // evaluated the next one's cameras and observations are in flight (the next chunk's first block during a chunk's last),
     // from a chunk's first block on the next chunk's point records, and the entry range of the chunk after that.
-    // (Chunks stand in descending order of their blocks' factor counts: behind a chunk without factors there is none with.)
+    // The waves' shares are equal runs of blocks of slots in chunk order (the plan's rows, rdis_hip.hip: ptm_build_segments): a
+    // wave evaluates some whole chunks and at most part of the slots of one more at either end.
     // The workgroup's barrier behind assign_cameras<.., false> stands in here, behind the first loads: the wave that forms
     // the cameras' records is the last to arrive, and what the others asked for is on its way meanwhile.
     template <bool SLOPE>
     __device__ __forceinline__ void eval_line(double a, double& af, double& as) {
-        const int lane = tid & 63, cs = chunk_step();
-        int cu = __builtin_amdgcn_readfirstlane(first_chunk());
-        int e = 0, e1 = 0;
-        if (cu < npc) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
+        const int lane = tid & 63, cs = nwaves;
+        // this wave's share: runs of whole blocks of slots of a chunk (the plan's rows; two rows of nothing behind the last)
+        const int* sp = segs + (tid >> 6);
+        const int sr = seg_rows;
+        int cu = __builtin_amdgcn_readfirstlane(sp[0]), e = __builtin_amdgcn_readfirstlane(sp[sr]), e1 = __builtin_amdgcn_readfirstlane(sp[2 * sr]);
         const bool work = e < e1;
-        int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
+        int cx = 0, ne = 0, ne1 = 0, vc = 0, v0 = 0, v1 = 0;
         PtRecs R = {};
         SlotBlock N = {};
         if (work) {
-            if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
-            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+            cx = __builtin_amdgcn_readfirstlane(sp[cs]); ne = __builtin_amdgcn_readfirstlane(sp[sr + cs]); ne1 = __builtin_amdgcn_readfirstlane(sp[2 * sr + cs]);
+            sp += 2 * cs;
+            vc = sp[0]; v0 = sp[sr]; v1 = sp[2 * sr];
             load_recs(cu, R);
             load_block(e, N);
         }
         __syncthreads();   // the cameras' records of this trial point
         if (!work) return;
-        bool fresh = true;
         double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0};
-        for (;;) {
-            const SlotBlock B = N;
-            const int bn = min(PTM_BLK, (e1 - e) >> 6);
-            if (fresh) {   // a chunk's first block: its trial point from the records; the next chunk's records
-                point_line(R, min(64 * cu + lane, npb - 1), a, x, dp);
-                if (ne < ne1) load_recs(cx, R);
-                fresh = false;
-            }
-            const int en = e + 64 * PTM_BLK;
-            if (en < e1) load_block(en, N);
-            else if (ne < ne1) load_block(ne, N);
+        // Where the loop waits for memory: only where a block of slots is taken over from the registers it was loaded into (B = N,
+        // pinned to its place in the program), i.e. behind a block's arithmetic.  The counter of loads in flight is kept in order
+        // of issue, so nothing may be asked for between a wait and the loads it is for; a load under a condition, or registers
+        // that one path of a loop writes and another keeps, are waited for where the paths join (hence two loops, and
+        // unconditional loads: behind the last run the first row of nothing names chunk 0 -- loaded, never looked at).
+        SlotBlock B = N;
+        pin_block(B);
+        for (;;) {   // a run: its trial point from the records; the next run's records
+            point_line(R, min(64 * cu + lane, npb - 1), a, x, dp);
+            load_recs(cx, R);
+            for (;;) {   // its blocks of slots
+                const int bn = min(PTM_BLK, (e1 - e) >> 6);
+                const int en = e + 64 * PTM_BLK;
+                const bool more = en < e1;
+                load_block(more ? en : ne < ne1 ? ne : e, N);
 #pragma unroll
-            for (int k = 0; k < PTM_BLK; ++k)
-                if (k < bn && B.c[k] >= 0) factor_trial(B.c[k], B.o[k], x, dp, SLOPE, af, as);
-            if (en < e1) { e = en; continue; }
+                for (int k = 0; k < PTM_BLK; ++k)
+                    if (k < bn && B.c[k] >= 0) factor_trial(B.c[k], B.o[k], x, dp, SLOPE, af, as);
+                B = N;
+                pin_block(B);
+                if (!more) break;
+                e = en;
+            }
             if (ne >= ne1) break;
-            cu = cx; e = ne; e1 = ne1; fresh = true;
-            cx += cs;
-            ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);   // (asked for a chunk ago)
-            v0 = v1 = 0;
-            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+            cu = cx; e = ne; e1 = ne1;
+            cx = __builtin_amdgcn_readfirstlane(vc); ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);   // (asked for a run ago)
+            sp += cs;
+            vc = sp[0]; v0 = sp[sr]; v1 = sp[2 * sr];
         }
     }
     // ... at clamp(x_start) (the rollback; value only)
@@ -473,12 +493,11 @@ struct PtmEnv {
         }
         my_point_vars([&](int ps, int k) {
             const int s = PTM_CS * ncb + 3 * ps + k, fi = sfree[s], v = svid[s];
-            double* rec = PT + (long long)PT_REC * ps + k;
             double lo = -__builtin_inf(), hi = __builtin_inf();
-            if (fi >= 0) { rec[0] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
-            else rec[0] = P.x[v];
-            rec[3] = 0.0;
-            PG[(long long)PT_REC * ps + k] = 0.0; PG[(long long)PT_REC * ps + 3 + k] = 0.0;
+            if (fi >= 0) { PT[k * pstr + ps] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
+            else PT[k * pstr + ps] = P.x[v];
+            PT[(3 + k) * pstr + ps] = 0.0;
+            PG[k * pstr + ps] = 0.0; PG[(3 + k) * pstr + ps] = 0.0;
             PE[(long long)PT_BND * ps + k] = lo; PE[(long long)PT_BND * ps + 3 + k] = hi;
         });
         // a chunk's box: the largest inner lower bound and the smallest inner upper bound of its blocks (a value strictly
@@ -513,9 +532,9 @@ struct PtmEnv {
             store_rotation(xc[0], xc[1], xc[2], ROTR + PTM_RS * c);
             BaFwd rot;
             ba_load_rotation(ROTR + PTM_RS * c, rot);
-            ba_camera_trial(rot, xc, CTR + CAM_TRIAL * c);
+            ba_camera_trial(rot, xc, CTR + PTM_TS * c);
 #pragma unroll
-            for (int k = 0; k < CAM_TRIAL; ++k) CDR[CAM_TRIAL * c + k] = 0.0;
+            for (int k = 0; k < CAM_TRIAL; ++k) CDR[PTM_TS * c + k] = 0.0;
         }
         __syncthreads();
     }
@@ -573,12 +592,11 @@ struct PtmEnv {
         // a block's entries are known: its record (new p, gradient), its terms of the sums
         auto finish_block = [&](int ps, const double (&pnew)[3], const double (&gold)[3], double e0, double e1_, double e2) {
             const int* sf = sfree + PTM_CS * ncb + 3 * ps;
-            double* rec = PT + (long long)PT_REC * ps;
             const double en[3] = {sf[0] >= 0 ? e0 : 0.0, sf[1] >= 0 ? e1_ : 0.0, sf[2] >= 0 ? e2 : 0.0};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                if (LE) rec[k] = pnew[k];
-                rec[3 + k] = en[k];
+                if (LE) PT[k * pstr + ps] = pnew[k];
+                PT[(3 + k) * pstr + ps] = en[k];
                 if (RED) reduce_term(pnew[k], en[k], gold[k], den, ra, rb, rt);
             }
         };
@@ -725,12 +743,19 @@ struct PtmEnv {
     template <bool WREC, bool WGH, class Fn>
     __device__ __forceinline__ void point_pass(Fn fn) {
         my_points([&](int ps) {
-            double2* rec = reinterpret_cast<double2*>(PT + (long long)PT_REC * ps);
-            double2* gh = reinterpret_cast<double2*>(PG + (long long)PT_REC * ps);
-            double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], g0 = gh[0], g1 = gh[1], g2 = gh[2];
-            fn(r0.x, r1.y, g0.x, g1.y); fn(r0.y, r2.x, g0.y, g2.x); fn(r1.x, r2.y, g1.x, g2.y);
-            if constexpr (WREC) { rec[0] = r0; rec[1] = r1; rec[2] = r2; }
-            if constexpr (WGH) { gh[0] = g0; gh[1] = g1; gh[2] = g2; }
+            double rc[6], gh[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { rc[k] = PT[k * pstr + ps]; gh[k] = PG[k * pstr + ps]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fn(rc[k], rc[3 + k], gh[k], gh[3 + k]);
+            if constexpr (WREC) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) PT[k * pstr + ps] = rc[k];
+            }
+            if constexpr (WGH) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) PG[k * pstr + ps] = gh[k];
+            }
         });
     }
     __device__ void cg_start() {
@@ -747,7 +772,7 @@ struct PtmEnv {
                     if (SF[s] >= 0) { d[SF[s]] = Pv[s]; d[n + SF[s]] = XI[s]; }
             my_point_vars([&](int ps, int k) {
                 const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
-                if (fi >= 0) { d[fi] = PT[(long long)PT_REC * ps + k]; d[n + fi] = PT[(long long)PT_REC * ps + 3 + k]; }
+                if (fi >= 0) { d[fi] = PT[k * pstr + ps]; d[n + fi] = PT[(3 + k) * pstr + ps]; }
             });
         }
         ++lm_count;
@@ -812,7 +837,7 @@ struct PtmEnv {
                 if (SF[s] >= 0) out(SF[s], Pv[s]);
         my_point_vars([&](int ps, int k) {
             const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
-            if (fi >= 0) out(fi, PT[(long long)PT_REC * ps + k]);
+            if (fi >= 0) out(fi, PT[k * pstr + ps]);
         });
     }
 };
@@ -829,8 +854,8 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
     const int sc = PTM_CS * ncb_cap, nt = (int)blockDim.x;
     double* ROTR = lds + PTM_CAM_VECTORS * sc;
     double* CTR = ROTR + PTM_RS * ncb_cap;
-    double* CDR = CTR + CAM_TRIAL * ncb_cap;
-    double* STG = CDR + CAM_TRIAL * ncb_cap;
+    double* CDR = CTR + PTM_TS * ncb_cap;
+    double* STG = CDR + PTM_TS * ncb_cap;
     unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * (nt + 1));
     const int rl_cap = ptm_round_stride(ncb_cap);
     int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
@@ -849,9 +874,10 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR, CTR, CDR,
                               STG, RL, rl_cap, SF,
-                              L.pm_rec + (long long)PT_REC * pb0, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
+                              L.pm_rec + (long long)PT_REC * pb0, (long long)npb, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
                               L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_grow,
                               rounds, nrounds, ptm_round_stride(ncb),
+                              L.pm_segs + L.pm_sg_off[(long long)comp * K + r] + 4, L.pm_segs[L.pm_sg_off[(long long)comp * K + r]],
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
