@@ -31,27 +31,37 @@ namespace rdis_hip {
 // and the fdlibm minimax kernels on [-pi/4, pi/4] with the reduction's tail carried through --
 // below 1 ulp, like the library routine it replaces, at about a third of its instructions and
 // without its large-argument branch.  Beyond the exact range the library is used.
+// A 64-bit constant where it is used, in scalar registers.  Left to itself the compiler forms the polynomials' constants
+// once per kernel in vector registers; in a large kernel they do not stay there (they cannot be re-formed by one
+// instruction, so they are spilled) and every use becomes a load from scratch memory with a wait of its own -- twenty of
+// them in a row made the cameras' records of a trial point three times as slow as their arithmetic (solver_ptm.hpp).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double kconst(double v) { asm volatile("" : "+s"(v)); return v; }
+#define KC(x) ::rdis_hip::kconst(x)
+#else
+#define KC(x) (x)
+#endif
 __host__ __device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
 RDIS_FACTORS_FP_CONTRACT
     if (!(x < 1.0e6)) { sincos(x, sn, cs); return; }
-    const double fn = rint(x * 6.36619772367581382433e-01);
+    const double fn = rint(x * KC(6.36619772367581382433e-01));
     const int n = (int)fn;
     // x - fn*pi/2 as y + yt: pi/2 = 1.57079632673412561417 + 6.07710050630396597660e-11 + 2.02226624879595063154e-21
-    double t = __builtin_fma(-fn, 1.57079632673412561417e+00, x);       // exact (33-bit constant)
-    double w = fn * 6.07710050630396597660e-11;
+    double t = __builtin_fma(-fn, KC(1.57079632673412561417e+00), x);       // exact (33-bit constant)
+    double w = fn * KC(6.07710050630396597660e-11);
     const double r = t - w;
-    w = __builtin_fma(fn, 2.02226624879595063154e-21, -((t - r) - w));
+    w = __builtin_fma(fn, KC(2.02226624879595063154e-21), -((t - r) - w));
     const double y = r - w;
     const double yt = (r - y) - w;
     const double z = y * y, z2 = z * z;
     // sine kernel
-    const double sr = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06)
-                    + z * z2 * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
+    const double sr = KC(8.33333333332248946124e-03) + z * (KC(-1.98412698298579493134e-04) + z * KC(2.75573137070700676789e-06))
+                    + z * z2 * (KC(-2.50507602534068634195e-08) + z * KC(1.58969099521155010221e-10));
     const double v = z * y;
-    const double ks = y - ((z * (0.5 * yt - v * sr) - yt) - v * -1.66666666666666324348e-01);
+    const double ks = y - ((z * (0.5 * yt - v * sr) - yt) - v * KC(-1.66666666666666324348e-01));
     // cosine kernel
-    const double cr = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05))
-                    + (z2 * z2) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    const double cr = z * (KC(4.16666666666666019037e-02) + z * (KC(-1.38888888888741095749e-03) + z * KC(2.48015872894767294178e-05)))
+                    + (z2 * z2) * (KC(-2.75573143513906633035e-07) + z * (KC(2.08757232129817482790e-09) + z * KC(-1.13596475577881948265e-11)));
     const double hz = 0.5 * z, wc = 1.0 - hz;
     const double kc = wc + (((1.0 - wc) - hz) + (z * cr - y * yt));
     // quadrant n mod 4: (s, c), (c, -s), (-s, -c), (-c, s)

@@ -120,6 +120,7 @@ struct PtmEnv {
     int nrounds, rl_stride;         // ... and their number
     const int* segs;                // a trial's work by wave: rows (wave-chunk, first entry, end entry), wave w's at w, w + waves, ...;
     int seg_rows;                   // three planes of seg_rows ints (three loads no pass of the compiler can put together, see PT)
+    int sg[9];                      // this wave's first three rows (the same for every trial point of the solve: scalar registers)
     double* PG;               // [6][npb] g[3] and h[3] of the recurrence for the blocks' variables, likewise
     double (*red)[3][MAX_WAVES];
     int parity;
@@ -366,17 +367,14 @@ struct PtmEnv {
     __device__ __forceinline__ void eval_line(double a, double& af, double& as) {
         const int lane = tid & 63, cs = nwaves;
         // this wave's share: runs of whole blocks of slots of a chunk (the plan's rows; two rows of nothing behind the last)
-        const int* sp = segs + (tid >> 6);
+        const int* sp = segs + (tid >> 6) + 2 * cs;
         const int sr = seg_rows;
-        int cu = __builtin_amdgcn_readfirstlane(sp[0]), e = __builtin_amdgcn_readfirstlane(sp[sr]), e1 = __builtin_amdgcn_readfirstlane(sp[2 * sr]);
+        int cu = sg[0], e = sg[1], e1 = sg[2];
         const bool work = e < e1;
-        int cx = 0, ne = 0, ne1 = 0, vc = 0, v0 = 0, v1 = 0;
+        int cx = sg[3], ne = sg[4], ne1 = sg[5], vc = sg[6], v0 = sg[7], v1 = sg[8];
         PtRecs R = {};
         SlotBlock N = {};
         if (work) {
-            cx = __builtin_amdgcn_readfirstlane(sp[cs]); ne = __builtin_amdgcn_readfirstlane(sp[sr + cs]); ne1 = __builtin_amdgcn_readfirstlane(sp[2 * sr + cs]);
-            sp += 2 * cs;
-            vc = sp[0]; v0 = sp[sr]; v1 = sp[2 * sr];
             load_recs(cu, R);
             load_block(e, N);
         }
@@ -862,6 +860,12 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
     for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     const int pb0 = L.pm_pt0[comp];
+    const int* segs = L.pm_segs + L.pm_sg_off[(long long)comp * K + r];
+    const int seg_rows = segs[0];
+    segs += 4;
+    int sg[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sg[q] = __builtin_amdgcn_readfirstlane(segs[(q % 3) * seg_rows + (q / 3) * (nt >> 6) + (threadIdx.x >> 6)]);
     const unsigned short* rounds = nullptr;
     int nrounds = 0;
     if constexpr (ROT != ROT_CAMFIX) {
@@ -877,7 +881,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               L.pm_rec + (long long)PT_REC * pb0, (long long)npb, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
                               L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_grow,
                               rounds, nrounds, ptm_round_stride(ncb),
-                              L.pm_segs + L.pm_sg_off[(long long)comp * K + r] + 4, L.pm_segs[L.pm_sg_off[(long long)comp * K + r]],
+                              segs, seg_rows, {sg[0], sg[1], sg[2], sg[3], sg[4], sg[5], sg[6], sg[7], sg[8]},
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
