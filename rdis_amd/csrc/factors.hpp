@@ -355,6 +355,94 @@ RDIS_FACTORS_FP_CONTRACT
     return t.res0 * dpix0 + t.res1 * dpix1;
 }
 
+// ... for W factors of ONE point at a time, statement by statement (the streaming solver's trial loop).  A factor's evaluation
+// is one long chain of dependent fp64 operations (nine cycles from one to the next, four to issue one), and the three waves
+// that fit a SIMD do not fill its issue slots between them; W independent chains side by side in one wave do.  Same
+// expressions as ba_trial_value / ba_trial_slope, operation for operation (the same bits: tests/cpp/factors_forms_test.hip);
+// the records are read row by row where they are used -- [R_i0 R_i1 R_i2 t_i] and its derivative give P_i and dP_i and are
+// dead -- so that W factors' state is 12 doubles each instead of two whole records.
+// TRp / DRp: the W cameras' records (16-byte aligned; DRp is not read under CAMFIX or without SLOPE).
+template <int W, bool SLOPE, bool CAMFIX>
+__host__ __device__ __forceinline__ void ba_trial_lockstep(const double* const (&TRp)[W], const double* const (&DRp)[W], const double (&q)[3],
+                                                           const double (&e)[3], const double (&ox)[W], const double (&oy)[W],
+                                                           double (&val)[W], double (&slp)[W]) {
+RDIS_FACTORS_FP_CONTRACT
+    struct D2 { double x, y; };
+    double P[W][3], dP[W][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        D2 a[W], b[W], c[W], d[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const D2* tr = reinterpret_cast<const D2*>(TRp[k]) + 2 * i;
+            a[k] = tr[0]; b[k] = tr[1];
+        }
+        if constexpr (SLOPE && !CAMFIX) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const D2* dr = reinterpret_cast<const D2*>(DRp[k]) + 2 * i;
+                c[k] = dr[0]; d[k] = dr[1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) P[k][i] = a[k].x * q[0] + (a[k].y * q[1] + (b[k].x * q[2] + b[k].y));
+        if constexpr (SLOPE) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dP[k][i] = a[k].x * e[0] + (a[k].y * e[1] + b[k].x * e[2]);
+            if constexpr (!CAMFIX) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) dP[k][i] += c[k].x * q[0] + (c[k].y * q[1] + (d[k].x * q[2] + d[k].y));
+            }
+        }
+    }
+    double f[W], k1[W], k2[W], iz[W], pp0[W], pp1[W], r2[W], dstn[W], fd[W], res0[W], res1[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const D2* tr = reinterpret_cast<const D2*>(TRp[k]) + 6;
+        const D2 u = tr[0];
+        f[k] = u.x; k1[k] = u.y; k2[k] = TRp[k][14];
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) iz[k] = 1.0 / P[k][2];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { pp0[k] = -P[k][0] * iz[k]; pp1[k] = -P[k][1] * iz[k]; }
+#pragma unroll
+    for (int k = 0; k < W; ++k) r2[k] = pp0[k] * pp0[k] + pp1[k] * pp1[k];
+#pragma unroll
+    for (int k = 0; k < W; ++k) dstn[k] = 1.0 + r2[k] * (k1[k] + k2[k] * r2[k]);
+#pragma unroll
+    for (int k = 0; k < W; ++k) fd[k] = f[k] * dstn[k];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { res0[k] = fd[k] * pp0[k] - ox[k]; res1[k] = fd[k] * pp1[k] - oy[k]; }
+#pragma unroll
+    for (int k = 0; k < W; ++k) val[k] = (res0[k] * res0[k] + res1[k] * res1[k]) * 0.5;
+    if constexpr (SLOPE) {
+        double dpp0[W], dpp1[W], dr2[W], ddst[W], scale[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { dpp0[k] = -(dP[k][0] + pp0[k] * dP[k][2]) * iz[k]; dpp1[k] = -(dP[k][1] + pp1[k] * dP[k][2]) * iz[k]; }
+#pragma unroll
+        for (int k = 0; k < W; ++k) dr2[k] = 2.0 * (pp0[k] * dpp0[k] + pp1[k] * dpp1[k]);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { ddst[k] = dr2[k] * (k1[k] + 2.0 * k2[k] * r2[k]); scale[k] = f[k] * ddst[k]; }
+        if constexpr (!CAMFIX) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const D2* dr = reinterpret_cast<const D2*>(DRp[k]) + 6;
+                const D2 u = dr[0];
+                const double dk2 = DRp[k][14];
+                ddst[k] += r2[k] * (u.y + dk2 * r2[k]);
+                scale[k] = u.x * dstn[k] + f[k] * ddst[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const double dpix0 = scale[k] * pp0[k] + fd[k] * dpp0[k];
+            const double dpix1 = scale[k] * pp1[k] + fd[k] * dpp1[k];
+            slp[k] = res0[k] * dpix0 + res1[k] * dpix1;
+        }
+    }
+}
+
 // value + the 12 partials
 __device__ __forceinline__ double ba_eval_grad(const double (&x)[12], double ox, double oy,
                                                double (&g)[12]) {

@@ -133,6 +133,9 @@ struct PtmEnv {
     int xch_stride, gpar;
 #ifdef RDIS_COOP_TIMING
     long long tmv[32];
+    long long wv[32];
+    long long tbar;   // (-DRDIS_COOP_TIMING=2: a wave's clock behind eval_line's barrier; slots 0..15 / 16..31 then hold, per wave,
+                      // the cycles from there to the end of its factors / from the trial's start to there, summed over the trials)
 #endif
 
     // the wave-chunks of point blocks this wave takes: chunk c belongs to workgroup c mod K, wave (c / K) mod nwaves
@@ -350,6 +353,38 @@ struct PtmEnv {
             if constexpr (ROWS) B.r[k] = grow[e + 64 * k + lane];
         }
     }
+    // the first W slots of a block: the lane's point against W cameras, in lockstep (factors.hpp).  A lane without a factor
+    // in a slot evaluates camera 0 and adds nothing.
+    template <int W, bool SLOPE>
+    __device__ __forceinline__ void factors_lockstep(const SlotBlock& B, const double (&x)[3], const double (&dp)[3], double& af, double& as) const {
+        const double* tp[W];
+        const double* dq[W];
+        double ox[W], oy[W], v[W], sl[W];
+        bool ok[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            ok[k] = B.c[k] >= 0;
+            int cc = ok[k] ? B.c[k] : 0;
+#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 2
+            cc = 0;
+#endif
+            tp[k] = CTR + PTM_TS * cc; dq[k] = CDR + PTM_TS * cc;
+            ox[k] = B.o[k].x; oy[k] = B.o[k].y;
+            sl[k] = 0.0;
+        }
+        const double* const (&tpc)[W] = tp;
+        const double* const (&dqc)[W] = dq;
+#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 1
+        ba_trial_lockstep<W, false, ROT == ROT_CAMFIX>(tpc, dqc, x, dp, ox, oy, v, sl);
+#else
+        ba_trial_lockstep<W, SLOPE, ROT == ROT_CAMFIX>(tpc, dqc, x, dp, ox, oy, v, sl);
+#endif
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            af += ok[k] ? v[k] : 0.0;
+            if constexpr (SLOPE) as += ok[k] ? sl[k] : 0.0;
+        }
+    }
     // holds a block of slots in registers at this point of the program (no instruction)
     static __device__ __forceinline__ void pin_block(SlotBlock& B) {
 #pragma unroll
@@ -379,6 +414,9 @@ struct PtmEnv {
             load_block(e, N);
         }
         __syncthreads();   // the cameras' records of this trial point
+#ifdef RDIS_COOP_TIMING
+        tbar = clock64();
+#endif
         if (!work) return;
         double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0};
         // Where the loop waits for memory: only where a block of slots is taken over from the registers it was loaded into (B = N,
@@ -396,9 +434,14 @@ struct PtmEnv {
                 const int en = e + 64 * PTM_BLK;
                 const bool more = en < e1;
                 load_block(more ? en : ne < ne1 ? ne : e, N);
+#ifdef RDIS_PTM_LOCKSTEP   // (an experiment's build: the block's factors side by side, statement by statement -- the same bits, no faster)
+                if (bn == PTM_BLK) factors_lockstep<PTM_BLK, SLOPE>(B, x, dp, af, as);
+                else factors_lockstep<1, SLOPE>(B, x, dp, af, as);
+#else
 #pragma unroll
                 for (int k = 0; k < PTM_BLK; ++k)
                     if (k < bn && B.c[k] >= 0) factor_trial(B.c[k], B.o[k], x, dp, SLOPE, af, as);
+#endif
                 B = N;
                 pin_block(B);
                 if (!more) break;
@@ -462,7 +505,7 @@ struct PtmEnv {
         eval_line<true>(a, af, as);
         const long long t2 = clock();
 #ifdef RDIS_COOP_TIMING
-        if ((tid & 63) == 0) wave_cycles()[tid >> 6] = t2 - t1;   // (read after the barrier of the sums)
+        if ((tid & 63) == 0) { wave_cycles()[tid >> 6] = t2 - t1; wave_cycles()[16 + (tid >> 6)] = tbar - t0; wave_cycles()[32 + (tid >> 6)] = t2 - tbar; }   // (read after the barrier of the sums)
 #endif
         sumk<2>(af, as, dummy);
         f = af; s = as;
@@ -472,6 +515,9 @@ struct PtmEnv {
             long long mx = 0, mn = 1ll << 62, sm = 0;
             for (int w = 0; w < nwaves; ++w) { const long long v = wave_cycles()[w]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
             tick(20, mx); tick(6, mn); tick(21, sm / nwaves);
+#pragma unroll
+            for (int w = 0; w < 16; ++w)   // (constant indices: an array of the environment indexed by a variable would move it to memory)
+                if (w < nwaves) { wv[w] += wave_cycles()[32 + w]; wv[16 + w] += wave_cycles()[16 + w]; }
         }
 #endif
     }
@@ -913,7 +959,8 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
 #ifdef RDIS_COOP_TIMING
         if (blockIdx.x == 0 && L.timing) {
             E.tmv[7] = E.clock() - tk0;
-            for (int i = 0; i < 32; ++i) L.timing[i] = E.tmv[i];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) L.timing[i] = RDIS_COOP_TIMING == 2 ? E.wv[i] : E.tmv[i];
         }
 #endif
     }
@@ -948,6 +995,7 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
         if (grp == 0 && L.timing) {
             E.tmv[7] = E.clock() - tk0;
             E.tmv[28] = E.GX.tm[5]; E.tmv[29] = E.GX.tm[2]; E.tmv[30] = E.GX.tm[3]; E.tmv[31] = E.GX.tm[4];
+#pragma unroll
             for (int i = 0; i < 32; ++i) L.timing[i] = E.tmv[i];
         }
 #endif

@@ -39,6 +39,10 @@ for opts in sets:
         print("%-40s kernel %8.3f ms  %6.1f GB/s algorithmic (%.3f of 8 TB/s)  group %d  evals/comp %.1f  objective %.10g  exits %s" % (
             opts, best, ab / best / 1e6, ab / best / 1e6 / 8000.0, plan.info("point_major_group"), r.nfeval.mean(), r.fret.sum(),
             dict(zip(*np.unique(r.status & 0xFF, return_counts=True)))), flush=True)
+        if "--waves" in sys.argv:    # a -DRDIS_COOP_TIMING=2 build: per wave, cycles of its factors and from the trial's start to the barrier
+            tm = plan.debug_counters()
+            print("   factors by wave (kilo-cycles over the solve): " + " ".join("%d" % (v // 1000) for v in tm[:16] if v))
+            print("   start -> barrier by wave:                      " + " ".join("%d" % (v // 1000) for v in tm[16:] if v), flush=True)
         if "--stamps" in sys.argv:   # a -DRDIS_COOP_TIMING build: cycle stamps of the launch's first workgroup (solver_ptm.hpp)
             tm = plan.debug_counters()
             n = max(int(tm[3]), 1)
