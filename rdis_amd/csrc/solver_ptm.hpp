@@ -390,10 +390,6 @@ struct PtmEnv {
 #pragma unroll
         for (int k = 0; k < PTM_BLK; ++k) asm volatile("" : "+v"(B.c[k]), "+v"(B.o[k].x), "+v"(B.o[k].y));
     }
-    static __device__ __forceinline__ void pin_block_rows(SlotBlock& B) {   // (the gradient's: with the factors' staging rows)
-#pragma unroll
-        for (int k = 0; k < PTM_BLK; ++k) asm volatile("" : "+v"(B.c[k]), "+v"(B.o[k].x), "+v"(B.o[k].y), "+v"(B.r[k]));
-    }
     // This workgroup's share of the sums at clamp(p + a xi): its point chunks, a block per lane, the block's factors
     // PTM_BLK slots at a time.  Everything is asked for a block of slots before it is used: while one block of slots is
     // evaluated the next one's cameras and observations are in flight (the next chunk's first block during a chunk's last),
@@ -619,27 +615,89 @@ struct PtmEnv {
                 if (tid + nt < nd) lv1 = rsrc[tid + nt];
             }
         }
-        // this wave's chunks (whole ones, chunk c to wave c mod waves), as in eval_line: a block of slots, the next chunk's records and
-        // the range of the chunk after that are asked for a block / a chunk ahead, unconditionally and in straight-line code (a load
-        // under a condition is waited for where the paths join); a round evaluates ONE slot
+        // this wave's chunks, as in eval_line: a block of slots, the next chunk's records and the range of the chunk after
+        // that are asked for a block / a chunk ahead; a round evaluates ONE slot (slot ks of the block at hand)
         int cu = __builtin_amdgcn_readfirstlane(first_chunk());
         int e = 0, e1 = 0;
         if (cu < npc) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
-        const bool have = e < e1;
-        const int* cptr1 = cptr + 1;
-        asm volatile("" : "+s"(cptr1));   // (cptr[i] and cptr[i + 1] as two loads: put together, their halves are copied out at once)
+        bool have = e < e1;
         int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
         PtRecs R = {};
-        SlotBlock N = {};
+        SlotBlock B = {}, N = {};
         if (have) {
             if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
-            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr1[cx + cs]; }
+            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
             load_recs<true>(cu, R);
             load_block<CAMS>(e, N);
         }
-        int rr = 0;
-        // a round's second half: the round's camera partials into the staging area, summed into the cameras' entries
-        auto stage_and_sum = [&](int cc, int row, const double (&gq)[12]) {
+        bool fresh = true;
+        int ks = 0;
+        double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0, pn[3] = {0.0, 0.0, 0.0}, go[3] = {0.0, 0.0, 0.0};
+        // a block's entries are known: its record (new p, gradient), its terms of the sums
+        auto finish_block = [&](int ps, const double (&pnew)[3], const double (&gold)[3], double e0, double e1_, double e2) {
+            const int* sf = sfree + PTM_CS * ncb + 3 * ps;
+            const double en[3] = {sf[0] >= 0 ? e0 : 0.0, sf[1] >= 0 ? e1_ : 0.0, sf[2] >= 0 ? e2 : 0.0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (LE) PT[k * pstr + ps] = pnew[k];
+                PT[(3 + k) * pstr + ps] = en[k];
+                if (RED) reduce_term(pnew[k], en[k], gold[k], den, ra, rb, rt);
+            }
+        };
+        auto line_point = [&](const PtRecs& Rc, int psc, double (&pnew)[3], double (&xx)[3]) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double t = Rc.xi[k] * amin;
+                pnew[k] = LE ? Rc.p[k] + t : Rc.p[k];
+                xx[k] = pnew[k];
+            }
+            if (!inside32(Rc, xx)) clamp_exact(psc, xx);
+        };
+        for (int rr = 0; CAMS ? rr < nrounds : have; ++rr) {
+            double gq[12];
+            int cc = -1, row = 0;
+            if (have) {
+                const bool first = fresh;
+                if (ks == 0) {   // a block's first slot
+                    B = N;
+                    if (fresh) {   // ... a chunk's: its blocks' position from the records; the next chunk's records
+                        line_point(R, min(64 * cu + lane, npb - 1), pn, x);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) go[k] = R.g[k];
+                        s0 = s1 = s2 = 0.0;
+                        if (ne < ne1) load_recs<true>(cx, R);
+                        fresh = false;
+                    }
+                    if (e + 64 * PTM_BLK < e1) load_block<CAMS>(e + 64 * PTM_BLK, N);
+                    else if (ne < ne1) load_block<CAMS>(ne, N);
+                }
+                cc = B.c[0]; row = B.r[0];
+                double2 o = B.o[0];
+#pragma unroll
+                for (int k = 1; k < PTM_BLK; ++k) {
+                    cc = ks == k ? B.c[k] : cc; row = ks == k ? B.r[k] : row;
+                    o.x = ks == k ? B.o[k].x : o.x; o.y = ks == k ? B.o[k].y : o.y;
+                }
+                if (cc >= 0) {
+                    double v[12];
+                    BaFwd t;
+                    forward(cc, o, x, v, t);
+                    ba_adjoint(t, v, t.res0, t.res1, gq);
+                    s0 = first ? gq[9] : s0 + gq[9]; s1 = first ? gq[10] : s1 + gq[10]; s2 = first ? gq[11] : s2 + gq[11];
+                }
+                ++ks;
+                if (e + 64 * ks >= e1) {   // the chunk's last slot: its blocks' point entries
+                    const int ps = 64 * cu + lane;
+                    if (ps < npb) finish_block(ps, pn, go, s0, s1, s2);
+                    have = ne < ne1;
+                    cu = cx; e = ne; e1 = ne1; fresh = true; ks = 0;
+                    cx += cs;
+                    ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);
+                    v0 = v1 = 0;
+                    if (have && cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+                } else if (ks == PTM_BLK) { e += 64 * PTM_BLK; ks = 0; }
+            }
             if constexpr (CAMS) {
                 __syncthreads();   // the sums of the round before have read the staging area
                 if (cc >= 0) {     // (its row: the factor's rank among the round's factors in camera order)
@@ -678,84 +736,6 @@ struct PtmEnv {
                     XI[s] = sm;
                 }
             }
-            ++rr;
-        };
-        // a block's entries are known: its record (new p, gradient), its terms of the sums
-        auto finish_block = [&](int ps, const double (&pnew)[3], const double (&gold)[3], double e0, double e1_, double e2) {
-            const int* sf = sfree + PTM_CS * ncb + 3 * ps;
-            const double en[3] = {sf[0] >= 0 ? e0 : 0.0, sf[1] >= 0 ? e1_ : 0.0, sf[2] >= 0 ? e2 : 0.0};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (LE) PT[k * pstr + ps] = pnew[k];
-                PT[(3 + k) * pstr + ps] = en[k];
-                if (RED) reduce_term(pnew[k], en[k], gold[k], den, ra, rb, rt);
-            }
-        };
-        auto line_point = [&](const PtRecs& Rc, int psc, double (&pnew)[3], double (&xx)[3]) {
-#pragma clang fp contract(off)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double t = Rc.xi[k] * amin;
-                pnew[k] = LE ? Rc.p[k] + t : Rc.p[k];
-                xx[k] = pnew[k];
-            }
-            if (!inside32(Rc, xx)) clamp_exact(psc, xx);
-        };
-        if (have) {
-            double x[3], pn[3], go[3];
-            SlotBlock B = N;
-            pin_block_rows(B);
-            for (;;) {   // a chunk: its blocks' position from the records; the next chunk's records
-                line_point(R, min(64 * cu + lane, npb - 1), pn, x);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) go[k] = R.g[k];
-                load_recs<true>(min(cx, npc - 1), R);
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                bool first = true;
-                for (;;) {   // its blocks of slots, a round each slot
-                    const int bn = min(PTM_BLK, (e1 - e) >> 6);
-                    const int en = e + 64 * PTM_BLK;
-                    const bool more = en < e1;
-                    load_block<CAMS>(more ? en : ne < ne1 ? ne : e, N);
-#pragma unroll
-                    for (int ks = 0; ks < PTM_BLK; ++ks) {
-                        if (ks < bn) {
-                            double gq[12];
-                            const int cc = B.c[ks];
-                            if (cc >= 0) {
-                                double v[12];
-                                BaFwd t;
-                                forward(cc, B.o[ks], x, v, t);
-                                ba_adjoint(t, v, t.res0, t.res1, gq);
-                                s0 = first ? gq[9] : s0 + gq[9]; s1 = first ? gq[10] : s1 + gq[10]; s2 = first ? gq[11] : s2 + gq[11];
-                            }
-                            first = false;
-                            stage_and_sum(cc, B.r[ks], gq);
-                        }
-                    }
-                    B = N;
-                    pin_block_rows(B);
-                    if (!more) break;
-                    e = en;
-                }
-                {   // the chunk's last slot is done: its blocks' point entries
-                    const int ps = 64 * cu + lane;
-                    if (ps < npb) finish_block(ps, pn, go, s0, s1, s2);
-                }
-                if (ne >= ne1) break;
-                cu = cx; e = ne; e1 = ne1;
-                cx += cs;
-                ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);   // (asked for a chunk ago)
-                {
-                    const int i = min(cx + cs, npc - 1);
-                    const int w0 = cptr[i], w1 = cptr1[i];
-                    v0 = cx + cs < npc ? w0 : 0; v1 = cx + cs < npc ? w1 : 0;
-                }
-            }
-        }
-        {   // (the rounds of waves with more slots)
-            const double none[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            while (CAMS && rr < nrounds) stage_and_sum(-1, 0, none);
         }
         // blocks no listed factor reads (free variables only; their chunks stand last): zero entries
         for (int c = first_chunk(); c < npc; c += cs) {
