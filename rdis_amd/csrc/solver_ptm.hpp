@@ -655,6 +655,7 @@ struct PtmEnv {
             if (!inside32(Rc, xx)) clamp_exact(psc, xx);
         };
         for (int rr = 0; CAMS ? rr < nrounds : have; ++rr) {
+            const long long tr0 = clock();
             double gq[12];
             int cc = -1, row = 0;
             if (have) {
@@ -698,8 +699,10 @@ struct PtmEnv {
                     if (have && cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
                 } else if (ks == PTM_BLK) { e += 64 * PTM_BLK; ks = 0; }
             }
+            const long long tr1 = clock();
             if constexpr (CAMS) {
                 __syncthreads();   // the sums of the round before have read the staging area
+                const long long tr2 = clock();
                 if (cc >= 0) {     // (its row: the factor's rank among the round's factors in camera order)
                     double* dst = STG + 9 * row;
 #pragma unroll
@@ -716,7 +719,9 @@ struct PtmEnv {
                         if (tid + nt < nd) lv1 = nx[tid + nt];
                     }
                 }
+                const long long tr3 = clock();
                 __syncthreads();
+                const long long tr4 = clock();
                 // lane (camera c, entry k of its nine): the rows [seg[c], seg[c + 1]) in order, eight loads in flight at a time
                 const unsigned short* seg = RL + (rr & 1) * rl_cap;
                 for (int j = tid; j < 9 * ncb; j += nt) {
@@ -735,6 +740,8 @@ struct PtmEnv {
                     }
                     XI[s] = sm;
                 }
+                // (stamps 15, 16, 18, 19, 11 of the first wave: a round's factor, the wait for the others, staging + table, the wait, the sums)
+                tick(15, tr1 - tr0); tick(16, tr2 - tr1); tick(18, tr3 - tr2); tick(19, tr4 - tr3); tick(11, clock() - tr4);
             }
         }
         // blocks no listed factor reads (free variables only; their chunks stand last): zero entries

@@ -51,6 +51,8 @@ for opts in sets:
             steps = max(int(tm[22] + tm[23] + tm[24] + tm[27]), 1)
             ng = max(int(tm[10]), 1)
             print("   control step %.0f cycles, hand-over %.0f (x%d requests); gradient (x%d): rounds %.0f, after %.0f cycles" % (tm[8] / steps, tm[9] / steps, steps, tm[10], tm[4] / ng, tm[5] / ng))
+            nr = 44   # (rounds of a gradient at the bench's shape, 768 lanes: the longest wave's slots)
+            print("   a gradient's round (first wave, %d rounds a gradient): its factor %.0f, wait for the others %.0f, staging + table %.0f, wait %.0f, sums %.0f cycles" % ((nr,) + tuple(tm[i] / max(ng * nr, 1) for i in (15, 16, 18, 19, 11))))
             print("   per request kind: " + "  ".join("%s %d x %.0f" % (nm, tm[22 + i], tm[12 + i] / max(int(tm[22 + i]), 1)) for i, nm in ((0, "value"), (1, "value+slope"), (2, "gradient"), (5, "line end"))), flush=True)
     except Exception as e:   # an option this build does not know
         print("%-40s failed: %s" % (opts, e), flush=True)
