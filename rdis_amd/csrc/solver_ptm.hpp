@@ -322,14 +322,15 @@ struct PtmEnv {
         slope = false;
 #endif
         double TR[CAM_TRIAL], DR[CAM_TRIAL];
-        const double2* tc = reinterpret_cast<const double2*>(CTR + PTM_TS * cc);
+        const int off = __mul24(cc, PTM_TS);   // (cameras < 2^12: the 24-bit product is exact and full rate, the 32-bit one a quarter of it)
+        const double2* tc = reinterpret_cast<const double2*>(CTR + off);
 #pragma unroll
         for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = tc[k]; TR[2 * k] = v.x; TR[2 * k + 1] = v.y; }
         BaTrial t;
         af += ba_trial_value(TR, x, o.x, o.y, t);
         if (slope) {
             if constexpr (ROT != ROT_CAMFIX) {
-                const double2* dc = reinterpret_cast<const double2*>(CDR + PTM_TS * cc);
+                const double2* dc = reinterpret_cast<const double2*>(CDR + off);
 #pragma unroll
                 for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
             } else {
