@@ -307,7 +307,7 @@ def replay_reference_schedule(nodes: List[Node], trace, pp, slo, shi, steptol=1e
                 kind = 1                                                               # "iterative improvement" (:1131-1133)
             else:
                 kind = 2                                                               # sampleRandomState (:1134-1136)
-            success = False
+            success, redo = False, False
             while True:                                                                # do ... while ( redoGD && !success ) (:1032-1106)
                 restart_no = nrr
                 if kind != 1:
@@ -322,7 +322,7 @@ def replay_reference_schedule(nodes: List[Node], trace, pp, slo, shi, steptol=1e
                 if have_prev and delta >= 0.0 - steptol:                               # approxgeq( deltafval, 0.0, ftol ) (:1086; common.h:74-76)
                     assert np.isnan(row[6]) and int(row[3]) == va, row
                     if nrr < num_restarts:                                             # :1087-1094: try again from a random position
-                        kind = 2
+                        kind, redo = 2, True                                           # doAlternatingMin = false (:1089)
                         continue
                     return                                                             # :1095-1099: failure -> getValueFromDomain returns false
                 success = True
@@ -331,8 +331,13 @@ def replay_reference_schedule(nodes: List[Node], trace, pp, slo, shi, steptol=1e
             assigned = True                                                            # assign (:282)
             va += 1                                                                    # Component::onVarsAssigned (src/Component.cpp:221)
             assert int(row[3]) == va, ("node %d: assignments since the last restart" % n, row[:4], va)
+            # success && doAlternatingMin && sdprev -> setInitialValFromChildren( *sdprev ) (:1112-1114, 1713-1724): the children
+            # get the values of the previous subdomain as their initial values -- also after a FORCED restart that made
+            # progress at once (forceRR leaves doAlternatingMin set); only a restart after no progress (:1088-1091) or a
+            # first visit from a random state leaves them with random initial values (:1162-1171)
+            inherit = have_prev and not redo
             for c in children[n]:                                                      # decompose, children in their order (:289-314)
-                do_optimization(c, kind == 2)   # (their initial values were used up at their first visit of this start, :1127, 1134)
+                do_optimization(c, kind == 2 and not inherit)
             value = float(row[6])                                                      # newsd->fx (:1515)
             if nd.leaf:
                 assert value == fret

@@ -73,6 +73,11 @@ int fail(rdis_hip_ctx* c, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e__));                 \
     } while (0)
 
+// Every entry point makes its context's device the calling thread's current one first: a host that drives several
+// contexts from one thread (rdis::OptimizableFunction::setDevices) would otherwise allocate, create events and launch
+// on whichever device its previous call left current.
+#define USE_DEVICE(ctx) HIPCHK((ctx), hipSetDevice((ctx)->device))
+
 int dalloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
     b.release();
     if (bytes == 0) bytes = 8;
@@ -347,6 +352,7 @@ extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
 
 extern "C" void rdis_hip_destroy(rdis_hip_ctx* c) {
     if (!c) return;
+    (void)hipSetDevice(c->device);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -358,6 +364,7 @@ extern "C" const char* rdis_hip_last_error(const rdis_hip_ctx* c) { return c ? c
 
 extern "C" int rdis_hip_set_stream(rdis_hip_ctx* c, void* s) {
     if (!c) return RDIS_HIP_EINVAL;
+    USE_DEVICE(c);
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
     else {
@@ -369,6 +376,7 @@ extern "C" int rdis_hip_set_stream(rdis_hip_ctx* c, void* s) {
 
 extern "C" int rdis_hip_synchronize(rdis_hip_ctx* c) {
     if (!c) return RDIS_HIP_EINVAL;
+    USE_DEVICE(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -376,6 +384,7 @@ extern "C" int rdis_hip_synchronize(rdis_hip_ctx* c) {
 extern "C" int rdis_hip_copy_to_host(rdis_hip_ctx* c, void* dst, const void* src, int64_t bytes) {
     if (!c || bytes < 0 || (bytes && (!dst || !src))) return RDIS_HIP_EINVAL;
     if (bytes == 0) return 0;
+    USE_DEVICE(c);
     HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -494,6 +503,7 @@ extern "C" int rdis_hip_upload_nlp(rdis_hip_ctx* c, int64_t nvars, const double*
 
 extern "C" void rdis_hip_free_problem(rdis_hip_problem* p) {
     if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     delete p;
 }
@@ -522,6 +532,7 @@ extern "C" int rdis_hip_set_x(rdis_hip_problem* p, int64_t n, const int64_t* vid
     if (!p || n < 0 || (n && !val)) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
     if (n == 0) return 0;
+    USE_DEVICE(c);
     if (!vid) {
         if (n > p->N) return fail(c, RDIS_HIP_EINVAL, "set_x: n > nvars");
         HIPCHK(c, hipMemcpyAsync(p->x.p, val, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -543,6 +554,7 @@ extern "C" int rdis_hip_get_x(rdis_hip_problem* p, int64_t n, const int64_t* vid
     if (!p || n < 0 || (n && !out)) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
     if (n == 0) return 0;
+    USE_DEVICE(c);
     if (!vid) {
         if (n > p->N) return fail(c, RDIS_HIP_EINVAL, "get_x: n > nvars");
         HIPCHK(c, hipMemcpyAsync(out, p->x.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -608,6 +620,7 @@ extern "C" int rdis_hip_eval(rdis_hip_problem* p, int64_t nf, const int64_t* fac
     rdis_hip_ctx* c = p->ctx;
     int rc = check_list(p, nf, fac);
     if (rc) return rc;
+    USE_DEVICE(c);
     if (nf == 0) { *f = 0.0; return 0; }
     const int* dfac;
     if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
@@ -624,6 +637,7 @@ extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t
     rdis_hip_ctx* c = p->ctx;
     int rc = check_list(p, nf, fac);
     if (rc) return rc;
+    USE_DEVICE(c);
     if (nf == 0) { *f = 0.0; std::fill(g, g + p->N, 0.0); return 0; }
     const int* dfac;
     if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
@@ -666,6 +680,7 @@ extern "C" int rdis_hip_eval_each(rdis_hip_problem* p, int64_t nf, const int64_t
     rdis_hip_ctx* c = p->ctx;
     int rc = check_list(p, nf, fac);
     if (rc) return rc;
+    USE_DEVICE(c);
     if (nf == 0) return 0;
     const int* dfac;
     if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
@@ -686,6 +701,7 @@ extern "C" int rdis_hip_grad_each_ba(rdis_hip_problem* p, int64_t nf, const int6
     if (p->kind != KIND_BA) return fail(c, RDIS_HIP_EINVAL, "grad_each_ba: not a bundle-adjustment problem");
     int rc = check_list(p, nf, fac);
     if (rc) return rc;
+    USE_DEVICE(c);
     if (nf == 0) return 0;
     const int* dfac;
     if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
@@ -975,6 +991,7 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
 
 extern "C" void rdis_hip_plan_destroy(rdis_hip_plan* L) {
     if (!L) return;
+    if (L->prob) (void)hipSetDevice(L->prob->ctx->device);
     if (L->prob && !L->transient) (void)hipStreamSynchronize(L->prob->ctx->stream);
     delete L;
 }
@@ -982,6 +999,7 @@ extern "C" void rdis_hip_plan_destroy(rdis_hip_plan* L) {
 extern "C" int rdis_hip_plan_set_start(rdis_hip_plan* L, const double* xs) {
     if (!L) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     if (L->nfree == 0) { L->have_start = true; return 0; }
     if (xs) {
         const size_t bytes = (size_t)L->nfree * sizeof(double);
@@ -1012,6 +1030,7 @@ extern "C" int rdis_hip_plan_set_start(rdis_hip_plan* L, const double* xs) {
 extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int64_t value) {
     if (!L || !name) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     const std::string n(name);
     if (n == "block_threads") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)
@@ -1725,7 +1744,8 @@ static int ptm_build_segments(rdis_hip_plan* L, int threads, int K) {
                 depth = std::max(depth, sh.size() / 4);
             }
             // (two rows of nothing behind every wave's last: the loop asks for its rows two ahead)
-            const size_t base = rows.size(), R = (depth + 2) * (size_t)nw;
+            // (and at least one row of work: a rank with no chunks still has the three rows a wave reads up front)
+            const size_t base = rows.size(), R = (std::max<size_t>(depth, 1) + 2) * (size_t)nw;
             off[(size_t)cc * K + rk] = (long long)base;
             rows.resize(base + 4 + 3 * R, 0);
             rows[base] = (int)R;
@@ -1745,9 +1765,11 @@ static int ptm_build_segments(rdis_hip_plan* L, int threads, int K) {
 int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     rdis_hip_ctx* c = L->prob->ctx;
     if (L->rounds_threads == threads && L->rounds_K == K) return 0;
-    L->rounds_threads = threads; L->rounds_K = K;
-    { const int rc = ptm_build_segments(L, threads, K); if (rc) { L->rounds_threads = L->rounds_K = 0; return rc; } }
-    if (L->ptm_rot_mode == ROT_CAMFIX) return 0;
+    // (the key is set when everything below has succeeded: a caller that frees memory and solves again after ENOMEM
+    // must find the tables either complete or absent, never "already built" with buffers missing)
+    L->rounds_threads = L->rounds_K = 0;
+    { const int rc = ptm_build_segments(L, threads, K); if (rc) return rc; }
+    if (L->ptm_rot_mode == ROT_CAMFIX) { L->rounds_threads = threads; L->rounds_K = K; return 0; }
     const int nw = threads / 64;
     const int* li = L->h_lds_ints.data();
     const int* ls_ptr = li + L->off_ls_ptr;
@@ -1813,6 +1835,7 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_off.p, off.data(), nwg * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_n.p, nr.data(), nwg * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host tables go out of scope; a launch on another stream follows)
+    L->rounds_threads = threads; L->rounds_K = K;
     return 0;
 }
 int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
@@ -2078,6 +2101,7 @@ extern "C" int rdis_hip_plan_fetch(rdis_hip_plan* L, double* x_out, double* fret
     if (!L) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
     const size_t nc = (size_t)L->ncomp, nf = (size_t)L->nfree;
+    USE_DEVICE(c);
     if (L->out_bytes == 0) return 0;
     // one D2H copy of the whole results block (x first: skipped when not wanted) -- or, for a long x, two: x straight
     // into the caller's array (no pass through the staging block and no host copy of it: 190 MB for the 1000-component
@@ -2110,6 +2134,7 @@ extern "C" int rdis_hip_plan_objective_device(rdis_hip_plan* L, void** dev_ptr) 
 extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_t* value) {
     if (!L || !name || !value) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     if (L->partition_dirty) { int rc = prepare_partition(L); if (rc) return rc; }
     const std::string n(name);
     const int64_t rest = (int64_t)L->h_rest.size() - L->rest_tiny - L->rest_lds - L->rest_ptm;
@@ -2127,6 +2152,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
 
 extern "C" int rdis_hip_plan_device_bytes(rdis_hip_plan* L, int64_t* bytes) {
     if (!L || !bytes) return RDIS_HIP_EINVAL;
+    USE_DEVICE(L->prob->ctx);
     // (the solvers' tables are built on demand: counted once they exist -- built here if they do not yet; what a first
     // solve adds for its launch shape, e.g. the streaming solver's round tables, shows in a query after that solve)
     if (L->partition_dirty && !L->transient) { int rc = prepare_partition(L); if (rc) return rc; }
@@ -2139,6 +2165,7 @@ extern "C" int rdis_hip_plan_last_kernel_ms(rdis_hip_plan* L, double* ms, int32_
     rdis_hip_problem* p = L->prob;
     rdis_hip_ctx* c = p->ctx;
     *ms = 0.0;
+    USE_DEVICE(c);
     if (launches) *launches = L->last_launches;
     if (!L->timed || p->last_timed_plan != L) return 0;  // the events belong to the problem's last solve
     HIPCHK(c, hipEventSynchronize(p->ev1));
@@ -2151,6 +2178,7 @@ extern "C" int rdis_hip_plan_last_kernel_ms(rdis_hip_plan* L, double* ms, int32_
 extern "C" int rdis_hip_plan_get_trace(rdis_hip_plan* L, int64_t comp, double* rec4, int64_t cap, int64_t* nrec) {
     if (!L || !nrec || comp < 0 || comp >= L->ncomp) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     if (L->trace_records <= 0) { *nrec = 0; return 0; }
     int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, L->view().trace_n + comp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2243,6 +2271,7 @@ extern "C" int rdis_hip_components_fetch(rdis_hip_problem* p, int64_t* free_ptr,
 extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out32) {
     if (!L || !out32) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     HIPCHK(c, hipMemcpyAsync(out32, L->prob->coop_timing.p, COOP_TM * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -2251,6 +2280,7 @@ extern "C" int rdis_hip_plan_debug_counters(rdis_hip_plan* L, int64_t* out32) {
 extern "C" int rdis_hip_plan_get_vectors(rdis_hip_plan* L, int64_t comp, double* out, int64_t cap_doubles) {
     if (!L || !out || comp < 0 || comp >= L->ncomp) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
+    USE_DEVICE(c);
     if (L->dump_iters <= 0) return fail(c, RDIS_HIP_EINVAL, "get_vectors: dump_iters is 0");
     const int64_t n = L->h_free_ptr[(size_t)comp + 1] - L->h_free_ptr[(size_t)comp];
     const int64_t want = 2ll * L->dump_iters * n;

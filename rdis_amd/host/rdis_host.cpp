@@ -447,40 +447,48 @@ bool PolynomialFunction::load(const std::string& file) {
     return !variables.empty() && !factors.empty();
 }
 
-std::unique_ptr<PolynomialFunction> PolynomialFunction::makeHighDimSinusoid(VariableCount h, VariableCount k,
-        VariableCount maxArity, bool allowOdd) {
-    const double twopi = 2.000001 * 3.141592653;
-    char buf[64];
-    std::snprintf(buf, sizeof buf, "%g", 10 * twopi);  // boost::format("%1%") prints 6 significant digits
-    const double bound = std::strtod(buf, nullptr);
-    // (domain +-10 tp, random states sampled from +-tp: src/OptimizableFunctionGenerator.cpp:660-760)
-    std::unique_ptr<PolynomialFunction> poly(new PolynomialFunction(VariableDomain(-bound, bound, -twopi, twopi)));
-    maxArity = std::min(maxArity, h + 1);
-    const VariableCount nvars = k == 1 ? h + 1 : (VariableCount)((std::llround(std::pow((double)k, (double)h + 1)) - 1) / (k - 1));
-    VariableID id = 0;
-    for (VariableCount i = 0; i < nvars; ++i) { std::snprintf(buf, sizeof buf, "x%lld", (long long)i); poly->addVariable(buf, poly->defaultDomain, id); }
-    for (VariableCount ar = 1; ar <= maxArity; ++ar) {
-        if (ar > 1 && (ar & 1) && !allowOdd) continue;
-        VariableCount lasth = h;
-        for (VariableID vid = nvars - 1; vid >= 0; --vid) {
-            const VariableID lastAtNext = k == 1 ? lasth - 1
-                : (VariableID)((std::round(std::pow((double)k, (double)lasth)) - 1.0) / (k - 1.0) - 1.0);
-            const VariableCount varheight = vid > lastAtNext ? lasth : --lasth;
-            if (varheight + 1 < ar) continue;
-            std::vector<VariableID> chain;
-            VariableID cur = vid;
-            for (VariableCount c = 0; c < ar; ++c) { chain.push_back(cur); cur = (VariableID)std::floor(((double)cur - 1.0) / (double)k); }
-            NonlinearProductFactor* f = new NonlinearProductFactor((FactorID)poly->factors.size(), ar > 1 ? 12 : 0.6);
-            poly->addFactor(f);
-            for (size_t c = chain.size(); c-- > 0;) f->addVariable(poly->variables[(size_t)chain[c]], 1, 0, ar > 1);
+// A complete k-ary tree of variables numbered level by level (the root is 0, node v's parent is (v - 1) / k).  For every
+// allowed arity a -- 1, and the even ones up to maxArity unless odd ones are allowed -- each node at depth >= a - 1 carries
+// one factor over itself and its a - 1 nearest ancestors, listed from the highest ancestor down: 12 * prod sin(x) for
+// a > 1, 0.6 * x for a = 1; nodes are visited from the last to the first (what fixes the factor ids).
+// Then 0.1 * x^2 per node.  Same function as src/OptimizableFunctionGenerator.cpp:660-760; rdis_amd/problems.py builds
+// the packed form of it independently and the tests compare the two.
+std::unique_ptr<PolynomialFunction> PolynomialFunction::makeHighDimSinusoid(VariableCount treeHeight, VariableCount branches,
+        VariableCount maxArity, bool allowOddArityFactors) {
+    const double period = 2.000001 * 3.141592653;
+    // the generator writes the domain through a six-significant-digit text form ("%g") and reads it back
+    char text[64];
+    std::snprintf(text, sizeof text, "%g", 10 * period);
+    const double edge = std::strtod(text, nullptr);
+    std::unique_ptr<PolynomialFunction> fn(new PolynomialFunction(VariableDomain(-edge, edge, -period, period)));
+
+    // depth of every node from its parent's (nodes of one level are consecutive)
+    std::vector<VariableCount> depth;
+    for (VariableCount level = 0, width = 1; level <= treeHeight; ++level, width *= branches)
+        depth.insert(depth.end(), (size_t)width, level);
+    const VariableCount nodes = (VariableCount)depth.size();
+    VariableID next = 0;
+    for (VariableCount v = 0; v < nodes; ++v) fn->addVariable("x" + std::to_string(v), fn->defaultDomain, next);
+
+    auto newFactor = [&](Numeric coefficient) {
+        NonlinearProductFactor* fac = new NonlinearProductFactor((FactorID)fn->factors.size(), coefficient);
+        fn->addFactor(fac);
+        return fac;
+    };
+    std::vector<VariableID> path;
+    for (VariableCount arity = 1; arity <= std::min(maxArity, treeHeight + 1); ++arity) {
+        if (arity > 1 && arity % 2 == 1 && !allowOddArityFactors) continue;
+        const bool sines = arity > 1;
+        for (VariableID leaf = nodes - 1; leaf >= 0; --leaf) {
+            if (depth[(size_t)leaf] < arity - 1) continue;   // not enough ancestors
+            path.assign(1, leaf);
+            while ((VariableCount)path.size() < arity) path.push_back((path.back() - 1) / branches);
+            NonlinearProductFactor* fac = newFactor(sines ? 12 : 0.6);
+            for (auto it = path.rbegin(); it != path.rend(); ++it) fac->addVariable(fn->variables[(size_t)*it], 1, 0, sines);
         }
     }
-    for (VariableID vid = 0; vid < nvars; ++vid) {
-        NonlinearProductFactor* f = new NonlinearProductFactor((FactorID)poly->factors.size(), 0.1);
-        poly->addFactor(f);
-        f->addVariable(poly->variables[(size_t)vid], 2, 0, false);
-    }
-    return poly;
+    for (VariableID v = 0; v < nodes; ++v) newFactor(0.1)->addVariable(fn->variables[(size_t)v], 2, 0, false);
+    return fn;
 }
 
 // ------------------------------------------------------------------ SubspaceOptimizer
@@ -506,7 +514,7 @@ struct HipCGDSubspaceOptimizer::CachedPlan {
 HipCGDSubspaceOptimizer::HipCGDSubspaceOptimizer(OptimizableFunction& f_)
     : SubspaceOptimizer(f_), last_iters_(0), last_status_(0), last_nfeval_(0), last_ngeval_(0),
       cache_cap_(256), cache_hits_(0), cache_misses_(0), cache_tick_(0),
-      cache_byte_cap_((size_t)4 << 30), cache_bytes_(0), cache_fallbacks_(0), function_alive_(true) {
+      cache_byte_cap_((size_t)4 << 30), cache_bytes_(0), cache_fallbacks_(0), function_alive_(true), stamp_(0) {
     if (doAscent) throw std::invalid_argument("HipCGDSubspaceOptimizer: only the MinSum (descent) semiring is supported");
     f.plan_holders_.push_back(this);
 }
@@ -541,10 +549,15 @@ void HipCGDSubspaceOptimizer::forget(CachedPlan* e) {
         }
 }
 
-bool HipCGDSubspaceOptimizer::evictOne(const CachedPlan* keep) {   // least recently used goes (never `keep`)
+// the least recently used plan goes -- never `keep`, never one a call in progress uses.  gpu >= 0: only plans that live on
+// that GPU (a shortage of device memory is not helped by dropping what other GPUs hold)
+bool HipCGDSubspaceOptimizer::evictOne(const CachedPlan* keep, int gpu) {
     size_t lru = cache_.size();
-    for (size_t i = 0; i < cache_.size(); ++i)
-        if (cache_[i] != keep && !cache_[i]->busy && (lru == cache_.size() || cache_[i]->used < cache_[lru]->used)) lru = i;
+    for (size_t i = 0; i < cache_.size(); ++i) {
+        const CachedPlan* e = cache_[i];
+        if (e == keep || e->busy || (gpu >= 0 && f.deviceOrdinal(e->dev) != gpu)) continue;
+        if (lru == cache_.size() || e->used < cache_[lru]->used) lru = i;
+    }
     if (lru == cache_.size()) return false;
     if (cache_[lru]->plan) rdis_hip_plan_destroy(cache_[lru]->plan);
     cache_bytes_ -= std::min<size_t>(cache_bytes_, (size_t)cache_[lru]->bytes);
@@ -590,7 +603,7 @@ HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const s
     for (;;) {
         rc = rdis_hip_plan_create(f.deviceProblem(dev), (int64_t)free_ptr.size() - 1, free_ptr.data(), free_vid.data(),
                                   fac_ptr.data(), fac_id.data(), &e->plan);
-        if (rc != RDIS_HIP_ENOMEM || !evictOne()) break;
+        if (rc != RDIS_HIP_ENOMEM || !evictOne(nullptr, f.deviceOrdinal(dev))) break;
     }
     if (rc == RDIS_HIP_ENOMEM) { delete e; ++cache_fallbacks_; return nullptr; }
     if (rc != 0) { delete e; check(f.deviceContext(dev), rc, "rdis_hip_plan_create"); }
@@ -629,12 +642,26 @@ struct HipCGDSubspaceOptimizer::Shard {
     std::vector<int32_t> iters, status;
     std::vector<int64_t> nfe, nge;
     CachedPlan* cp = nullptr;
+    bool launched = false;       // its plan's solve has been issued and not yet fetched
 };
 
 // Every shard's plan is found (or made), then every device gets its start values and its launch -- nothing here waits
 // for a device, so the launches of all devices are in flight together -- and only then are the results fetched, device
 // by device.  A shard whose plan cannot be kept is served by the transient path after the others have been launched.
+// Whatever goes wrong on one device (check() throws), every launch already issued on the others is waited for and no
+// plan stays marked as in use: the caller may catch the error and carry on with the optimiser.
 void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
+    struct Settle {
+        HipCGDSubspaceOptimizer& self;
+        std::vector<Shard>& shards;
+        bool completed = false;
+        ~Settle() {
+            for (Shard& S : shards) {
+                if (!completed && S.launched) (void)rdis_hip_synchronize(self.f.deviceContext(S.dev));
+                if (S.cp) S.cp->busy = false;
+            }
+        }
+    } settle{*this, shards};
     for (Shard& S : shards) {
         S.cp = S.fac_id.empty() ? nullptr : cachedPlan(S.free_ptr, S.free_vid, S.fac_ptr, S.fac_id, S.dev);
         if (S.cp) S.cp->busy = true;   // (a later shard's plan must not push this one out)
@@ -645,14 +672,15 @@ void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
         (void)f.deviceProblem(S.dev);   // (pending assignments of constants reach this device)
         check(ctx, rdis_hip_plan_set_start(S.cp->plan, S.x.data()), "rdis_hip_plan_set_start");
         // A solve may still allocate (tables built for the launch shape it picks).  Out of device memory: the other
-        // plans go, least recently used first, and it is tried again; with nothing left to drop this plan goes too and
-        // the shard is served by the transient path like an uncached one.
+        // plans on that GPU go, least recently used first, and it is tried again; with nothing left to drop this plan
+        // goes too and the shard is served by the transient path like an uncached one.
         int rc;
         for (;;) {
             rc = rdis_hip_plan_solve(S.cp->plan, (int32_t)maxiters, ftol);
-            if (rc != RDIS_HIP_ENOMEM || !evictOne(S.cp)) break;
+            if (rc != RDIS_HIP_ENOMEM || !evictOne(S.cp, f.deviceOrdinal(S.dev))) break;
         }
         if (rc == RDIS_HIP_ENOMEM) { forget(S.cp); S.cp = nullptr; ++cache_fallbacks_; continue; }
+        S.launched = true;   // (also when the solve failed half way: some of its launches may be queued)
         check(ctx, rc, "rdis_hip_plan_solve");
     }
     for (Shard& S : shards) {
@@ -662,6 +690,7 @@ void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
         if (S.cp) {
             check(ctx, rdis_hip_plan_fetch(S.cp->plan, S.x.data(), S.fret.data(), S.delta.data(), S.iters.data(), S.status.data(), S.nfe.data(), S.nge.data()),
                   "rdis_hip_plan_fetch");
+            S.launched = false;
             S.cp->busy = false;
             int64_t now = S.cp->bytes;   // (what the first solve added belongs to the plan's account)
             (void)rdis_hip_plan_device_bytes(S.cp->plan, &now);
@@ -677,22 +706,23 @@ void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
             check(ctx, rc, "rdis_hip_cgd_batch");
         }
     }
+    settle.completed = true;
 }
 
 Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, const bool printdbg) {
     const size_t nc = comps.size();
+    // every variable of every listed factor must be assigned or free in this call (the caller guarantees it,
+    // src/RDISOptimizer.cpp:1042, :1049-1059); a component's free set is a mark per variable id, valid for one stamp
+    if (free_stamp_.size() != (size_t)f.getNumVars()) free_stamp_.assign((size_t)f.getNumVars(), 0);
     for (size_t c = 0; c < nc; ++c) {
         Component& C = comps[c];
         if (C.xval.size() != C.vars.size()) throw std::invalid_argument("optimizeBatch: xval.size() != vars.size()");
-        // every variable of every listed factor must be assigned or free in this call
-        // (the caller guarantees it, src/RDISOptimizer.cpp:1042, :1049-1059)
+        if (++stamp_ == 0) { std::fill(free_stamp_.begin(), free_stamp_.end(), 0u); stamp_ = 1; }
+        for (const Variable* u : C.vars) free_stamp_[(size_t)u->getID()] = stamp_;
         for (const Factor* fa : C.factors)
             for (const Variable* v : fa->getVariables())
-                if (!v->isAssigned()) {
-                    bool fr = false;
-                    for (const Variable* u : C.vars) if (u == v) { fr = true; break; }
-                    if (!fr) throw std::logic_error("optimize: factor " + std::to_string(fa->getID()) + " reads the unassigned variable " + v->getName());
-                }
+                if (!v->isAssigned() && free_stamp_[(size_t)v->getID()] != stamp_)
+                    throw std::logic_error("optimize: factor " + std::to_string(fa->getID()) + " reads the unassigned variable " + v->getName());
     }
     // Which device solves which component: sibling components share no free variable and no factor (src/Component.cpp:
     // 508-549), so a batch is shared out whole components at a time -- heaviest first, always onto the device with the

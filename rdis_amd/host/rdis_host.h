@@ -197,6 +197,7 @@ public:
     // GPU: what the tests do).  To be called before the first use of the device; replicas are uploaded when first used.
     void setDevices(const std::vector<int>& devices);
     size_t numDevices() const { return 1 + replicas_.size(); }
+    int deviceOrdinal(size_t d) const { return d == 0 ? device_ : replicas_.at(d - 1).device; }   // the GPU behind entry d
     rdis_hip_problem* deviceProblem(size_t d) const;   // d = 0: the primary
     rdis_hip_ctx* deviceContext(size_t d) const;
 
@@ -365,7 +366,7 @@ private:
     struct Shard;
     void solveShards(std::vector<Shard>& shards);
     void dropPlans();
-    bool evictOne(const CachedPlan* keep = nullptr);   // the least recently used plan other than `keep` goes
+    bool evictOne(const CachedPlan* keep = nullptr, int gpu = -1);   // the least recently used plan other than `keep` goes (gpu >= 0: on that GPU)
     void forget(CachedPlan* e);
     friend class OptimizableFunction;
     void functionGone();   // the function is being destroyed: its device problem goes, and the plans with it
@@ -376,6 +377,8 @@ private:
     unsigned long long cache_tick_;
     size_t cache_byte_cap_, cache_bytes_, cache_fallbacks_;
     bool function_alive_;
+    std::vector<unsigned> free_stamp_;   // optimizeBatch: variable id -> stamp of the component it is free in
+    unsigned stamp_;
 };
 
 // The drop-in for LMSubspaceOptimizer (src/optimizers/LMSubspaceOptimizer.h): same contract and

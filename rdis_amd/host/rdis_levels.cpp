@@ -389,6 +389,7 @@ struct HipRDISLevelOptimizer::NodeState {
     double opt = 0.0;
     std::vector<double> optx;        // the node's variables at its best evaluation (the optimum subdomain)
     bool randomInit = false;         // its initial values have been used up by an ancestor's restart (:1127, 1134-1136)
+    bool redo = false;               // this step was made again from a random state after no progress (doAlternatingMin = false, :1088-1091)
     int kind = 0;
     double fret = 0.0, delta = 0.0;
     unsigned long long hash = 0;
@@ -444,6 +445,7 @@ void HipRDISLevelOptimizer::runSet(const std::vector<int>& set, const std::vecto
             else if (s.assigned && !forceRR) { s.kind = 1; for (VariableID v : V) x0.push_back(vars[(size_t)v]->eval()); }        // :1131-1133
             else { s.kind = 2; for (VariableID v : V) x0.push_back(restartValue(restart_seed_, n, (int)s.nrr, v, vars[(size_t)v]->getDomain())); }   // :1134-1136
             if (s.kind != 1) { ++s.nrr; s.va = 0; }                                                     // :1047, Component.h:190-194
+            s.redo = false;
             pending.push_back(n);
         }
         // the subspace optimizer, and again from a random state where it made no progress (:1032-1106)
@@ -476,6 +478,7 @@ void HipRDISLevelOptimizer::runSet(const std::vector<int>& set, const std::vecto
                         x0.clear();
                         for (VariableID v : valued(n)) x0.push_back(restartValue(restart_seed_, n, (int)s.nrr, v, vars[(size_t)v]->getDomain()));
                         ++s.nrr; s.va = 0;
+                        s.redo = true;
                         again.push_back(n);
                     } else {
                         finish(n);                                // :1095-1099: a failure ends the node's loop (:279)
@@ -494,7 +497,13 @@ void HipRDISLevelOptimizer::runSet(const std::vector<int>& set, const std::vecto
             NodeState& s = st[(size_t)n];
             s.assigned = true;
             ++s.va;                                               // Component.cpp:221
-            for (int c : children_[(size_t)n]) { kids.push_back(c); kidsRandom.push_back(s.kind == 2 ? 1 : 0); }
+            // Where do the children start?  A step that succeeded with doAlternatingMin still set and a previous subdomain
+            // -- every iterative improvement, and a FORCED restart that made progress at once -- hands the children the
+            // values they had in that subdomain (setInitialValFromChildren, :1112-1114, 1713-1724): they start from where
+            // they stand.  A restart after no progress (:1088-1091) and a first visit from a random state have nothing to
+            // hand down: their children's initial values are random ones (:1162-1171).
+            const bool inherit = s.havePrev && !s.redo;
+            for (int c : children_[(size_t)n]) { kids.push_back(c); kidsRandom.push_back(s.kind == 2 && !inherit ? 1 : 0); }
         }
         if (!kids.empty()) runSet(kids, kidsRandom, st, printInfo);
         // updateDomain (:1507-1577)

@@ -77,8 +77,9 @@ public:
     //   * when a step makes no progress the node is restarted from a random state (:1088-1094, sampleRandomState
     //     :1196-1216: uniform over each variable's sampling interval), at most numRestarts = max(minRR, nRRperLvl >>
     //     depth) times (nRRatTop at depth 0; :978-983), and after maxNAtoRR assignments without one a restart is forced
-    //     below the top (:992-994); a restarted node's children start from random states too (their initial values have
-    //     been used up, :1127);
+    //     below the top (:992-994); the children of a node restarted after NO PROGRESS start from random states too
+    //     (:1162-1171), those of a node whose FORCED restart made progress start from the values they had in the
+    //     node's previous evaluation (setInitialValFromChildren, :1112-1114, 1713-1724);
     //   * every evaluation of a node is compared with its best so far (updateDomain :1507-1577: a new minimum only beyond
     //     steptol), a node is done when its last evaluation was no new minimum and its restarts are spent (:997-999),
     //     and it is left at its best.
