@@ -107,13 +107,22 @@ int rdis_hip_get_x(rdis_hip_problem *p, int64_t n, const int64_t *vid, double *o
 /* ---- batched factor evaluation at the currently assigned x ----------------------
  * fac == NULL: all factors 0..nf-1 (nf must then equal the factor count).
  * eval      : OptimizableFunction::evalFactors (src/OptimizableFunction.cpp:95-135)
- * eval_grad : ... + computeGradient(facs, pg) (src/OptimizableFunction.cpp:234-262);
- *             g is dense over all N variables (0 where no listed factor touches it);
- *             each g[v] is accumulated in factor-list order like the reference.
+ * eval_grad : ... + computeGradient(facs, pg) (src/OptimizableFunction.cpp:234-262, the merge of src/State.h:157-210);
+ *             g is dense over all N variables (0 where no listed factor touches it).  Bundle adjustment: one
+ *             pass over the factors, no per-factor partial leaves the compute unit (rdis_amd/csrc/grad_fused.hpp);
+ *             a point variable's contributions are added in factor-list order like the reference's merge, a camera
+ *             variable's in factor-list order within a tile of the list and then tile by tile -- a fixed order, the
+ *             same bits run to run; the value is bit for bit what eval returns for the same list.  The tables of
+ *             a list are built at its first use and kept (the last four lists; all factors: fac == NULL).
+ *             Nonlinear-product functions: per-factor partials, then each g[v] in factor-list order.
+ * eval_grad_device : the same, results left on the device: *f_dev points to one double, *g_dev to N doubles,
+ *             valid until the next evaluation call on this problem; asynchronous on the context's stream
+ *             (rdis_hip_synchronize / rdis_hip_copy_to_host order after it).
  * eval_each / grad_each_ba: per-factor values / 12 partials, for kernel parity tests
  *             (Factor::eval, BundleAdjustmentFactor::computeGradient). */
 int rdis_hip_eval(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f);
 int rdis_hip_eval_grad(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f, double *g);
+int rdis_hip_eval_grad_device(rdis_hip_problem *p, int64_t nf, const int64_t *fac, void **f_dev, void **g_dev);
 int rdis_hip_eval_each(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *fvals);
 int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *g12);
 

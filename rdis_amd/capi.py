@@ -66,6 +66,7 @@ SYMBOLS = {
     "rdis_hip_get_x": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rdis_hip_eval": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_double)]),
     "rdis_hip_eval_grad": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_double), _vp]),
+    "rdis_hip_eval_grad_device": (C.c_int, [_vp, _i64, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "rdis_hip_eval_each": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rdis_hip_grad_each_ba": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rdis_hip_cgd_batch": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_double,
@@ -331,6 +332,14 @@ class Problem:
         g = np.empty(self.nvars)
         self.ctx.check(self.ctx.lib.rdis_hip_eval_grad(self.h, nf, _ptr(fac), C.byref(f), _ptr(g)))
         return f.value, g
+
+    def eval_grad_device(self, fac=None):
+        """value and gradient left on the device: (pointer to one double, pointer to nvars doubles), valid until the
+        next evaluation call on this problem; asynchronous on the context's stream"""
+        fac, nf = self._nf(fac)
+        fd, gd = _vp(), _vp()
+        self.ctx.check(self.ctx.lib.rdis_hip_eval_grad_device(self.h, nf, _ptr(fac), C.byref(fd), C.byref(gd)))
+        return fd.value, gd.value
 
     def eval_each(self, fac=None) -> np.ndarray:
         fac, nf = self._nf(fac)

@@ -88,7 +88,15 @@ __global__ void __launch_bounds__(256)
 final_sum_kernel(int n, const double* __restrict__ partial, double* __restrict__ out) {
     __shared__ double red[MAX_WAVES];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    // (eight loads in flight, added in index order: the bits of the plain loop without its round trip per element)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (i0 + j * (int)blockDim.x < n) ? partial[i0 + j * (int)blockDim.x] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * (int)blockDim.x < n) acc += t[j];
+    }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = acc;
 }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <numeric>
 #include <string>
@@ -20,6 +21,7 @@
 #include "components.hpp"
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
+#include "grad_fused.hpp"
 #include "solver_coop.hpp"
 #include "solver_lds.hpp"
 #include "ptm_api.hpp"
@@ -117,6 +119,15 @@ int grid_for(const rdis_hip_ctx* c, long long work, int threads) {
 
 struct VarMark { int stamp, owner, gidx, pad; };
 
+// the fused gradient pass's tables for one factor list (grad_fused.hpp), kept by the problem
+struct GradPlan {
+    unsigned long long key0 = 0, key1 = 0, used = 0;   // two hashes of the id list (0, 0: all factors); last use
+    int64_t nf = 0;
+    DevBuf ints, shorts, fac;      // one int32 block, one 16-bit block, the list as int32 (explicit lists)
+    DevBuf cstage, pstage, partial;
+    rdis_hip::GradTables T{};
+};
+
 struct rdis_hip_problem {
     rdis_hip_ctx* ctx = nullptr;
     int kind = KIND_BA;
@@ -132,6 +143,11 @@ struct rdis_hip_problem {
     DevBuf gfac, partial, scalar, tmp_idx, tmp_val, tmp_out, g_all;
     DevBuf all_v2s_ptr, all_v2s_idx;  // gather lists for "all factors"
     bool have_all_v2s = false;
+    // fused value + gradient (bundle adjustment with disjoint blocks): per-call camera records, the lists' tables
+    DevBuf camrec;
+    ivec h_cam_ord;                   // [N] ordinal of the camera block that starts at a variable id, -1 = none
+    std::vector<std::unique_ptr<GradPlan>> grad_plans;
+    unsigned long long grad_tick = 0;
     // shared by the plans of this problem (solves on a context are serialised)
     DevBuf dir, coop_state, coop_timing;   // search direction by variable id (kept zero between solves), ...
     int coop_state_gen = 0;                // bumped whenever coop_state moves: plans re-derive the pointers they baked in
@@ -615,30 +631,257 @@ int launch_eval_sum(rdis_hip_problem* p, int nf, const int* dfac, int blocks) {
 }
 }  // namespace
 
-extern "C" int rdis_hip_eval(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f) {
-    if (!p || !f) return RDIS_HIP_EINVAL;
+namespace {
+
+constexpr size_t GRAD_PLAN_CACHE = 4;   // factor lists whose tables the problem keeps (least recently used goes)
+
+bool fused_path(const rdis_hip_problem* p) { return p->kind == KIND_BA && p->ncam_blocks > 0; }
+
+// The tables of grad_fused.hpp for one factor list, built once per list.  Everything here is index work over the list:
+// cut it into chunks and tiles, number a tile's cameras, rank a chunk's entries by camera and by point block (list order
+// within a block: the order of the sums), decide per block whether one chunk / tile holds all its listed factors (straight to
+// g) or several do (a staging slot each, a block's slots consecutive in chunk / tile order).
+int build_grad_plan(rdis_hip_problem* p, int64_t nf64, const int64_t* fac, GradPlan& G) {
     rdis_hip_ctx* c = p->ctx;
-    int rc = check_list(p, nf, fac);
-    if (rc) return rc;
-    USE_DEVICE(c);
-    if (nf == 0) { *f = 0.0; return 0; }
-    const int* dfac;
-    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
-    const int blocks = grid_for(c, nf, 256);
-    if ((rc = ensure(c, p->partial, (size_t)blocks * sizeof(double)))) return rc;
-    if ((rc = launch_eval_sum<false>(p, (int)nf, dfac, blocks))) return rc;
-    HIPCHK(c, hipMemcpyAsync(f, p->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int nf = (int)nf64, GW = GRAD_LANES;
+    const int nchunks = (nf + GW - 1) / GW;
+    const size_t N = (size_t)p->N, ncb = (size_t)p->ncam_blocks;
+    if (p->h_cam_ord.empty()) {   // (camera blocks are the distinct values of h_cam, ascending: their ordinal = their rank)
+        p->h_cam_ord.assign(N, -1);
+        ivec blocks(p->h_cam);
+        std::sort(blocks.begin(), blocks.end());
+        blocks.erase(std::unique(blocks.begin(), blocks.end()), blocks.end());
+        for (size_t i = 0; i < blocks.size(); ++i) p->h_cam_ord[(size_t)blocks[i]] = (int)i;
+    }
+    auto fid_of = [&](int j) { return fac ? (int)fac[j] : j; };
+    // how many listed factors read each block
+    ivec cnt_cam(ncb, 0), cnt_pt(N, 0);
+    for (int j = 0; j < nf; ++j) { const int f = fid_of(j); ++cnt_cam[(size_t)p->h_cam_ord[(size_t)p->h_cam[(size_t)f]]]; ++cnt_pt[(size_t)p->h_pt[(size_t)f]]; }
+    // tiles: up to tile_chunks chunks, fewer where their cameras would not fit (a chunk alone always does)
+    const int want_tiles = 8 * std::max(1, c->num_cus);
+    int tile_chunks = std::max(1, std::min(GRAD_MAX_TILE_CHUNKS, nchunks / want_tiles));
+    if (const char* ev = std::getenv("RDIS_HIP_GRAD_TILE_CHUNKS")) tile_chunks = std::max(1, std::min(64, std::atoi(ev)));   // (tuning)
+    const int cam_soft = 192;
+    const size_t npad = (size_t)nchunks * GW;
+    std::vector<unsigned short> sh(3 * npad, GRAD_NO_ENTRY);   // cl | rc | rp
+    unsigned short* const cl = sh.data();
+    unsigned short* const rc = cl + npad;
+    unsigned short* const rp = rc + npad;
+    ivec ptv(npad, 0), tile_chunk0, tile_cam0, chunk_cseg0((size_t)nchunks + 1, 0), chunk_pseg0((size_t)nchunks + 1, 0);
+    std::vector<int2> tile_cam, cseg, pseg;
+    ivec cam_tile(ncb, -1), cam_local(ncb, 0);           // camera ordinal -> tile it was last numbered in, its number there
+    ivec tcnt;                                            // listed factors of a tile's camera inside the tile
+    std::vector<std::pair<int, int>> cstaged, pstaged;    // (block, index of the table entry to patch), in tile / chunk order
+    ivec pt_chunk(N, -1), pt_seg(N, 0);                   // point block -> chunk it was last seen in, its segment there
+    ivec segcnt, segrow, seg_of((size_t)GW), cam_seg_chunk, cam_seg;
+    int ncam_cap = 1;
+    tile_chunk0.push_back(0); tile_cam0.push_back(0);
+    for (int ch0 = 0; ch0 < nchunks;) {
+        const int tile = (int)tile_chunk0.size() - 1;
+        const size_t tc0 = tile_cam.size();
+        int ch1 = ch0;
+        while (ch1 < nchunks && ch1 - ch0 < tile_chunks) {
+            // the cameras this chunk would add
+            const size_t before = tile_cam.size();
+            const int j0 = ch1 * GW, j1 = std::min(nf, j0 + GW);
+            for (int j = j0; j < j1; ++j) {
+                const int o = p->h_cam_ord[(size_t)p->h_cam[(size_t)fid_of(j)]];
+                if (cam_tile[(size_t)o] != tile) { cam_tile[(size_t)o] = tile; cam_local[(size_t)o] = (int)(tile_cam.size() - tc0); tile_cam.push_back(int2{o, 0}); }
+            }
+            if (ch1 > ch0 && tile_cam.size() - tc0 > (size_t)cam_soft) {   // too many: the chunk starts the next tile
+                for (size_t k = before; k < tile_cam.size(); ++k) cam_tile[(size_t)tile_cam[k].x] = -1;
+                tile_cam.resize(before);
+                break;
+            }
+            ++ch1;
+        }
+        const int nc = (int)(tile_cam.size() - tc0);
+        ncam_cap = std::max(ncam_cap, nc);
+        tcnt.assign((size_t)nc, 0);
+        cam_seg_chunk.assign((size_t)nc, -1); cam_seg.assign((size_t)nc, 0);
+        for (int ch = ch0; ch < ch1; ++ch) {
+            const int j0 = ch * GW, j1 = std::min(nf, j0 + GW);
+            // segments by camera, in order of first appearance; list order within a segment
+            segcnt.clear();
+            for (int j = j0; j < j1; ++j) {
+                const int f = fid_of(j);
+                const int l = cam_local[(size_t)p->h_cam_ord[(size_t)p->h_cam[(size_t)f]]];
+                cl[j] = (unsigned short)l;
+                ptv[(size_t)j] = p->h_pt[(size_t)f];
+                ++tcnt[(size_t)l];
+                if (cam_seg_chunk[(size_t)l] != ch) { cam_seg_chunk[(size_t)l] = ch; cam_seg[(size_t)l] = (int)segcnt.size(); segcnt.push_back(0); cseg.push_back(int2{l, 0}); }
+                seg_of[(size_t)(j - j0)] = cam_seg[(size_t)l];
+                ++segcnt[(size_t)cam_seg[(size_t)l]];
+            }
+            {
+                const size_t s0 = cseg.size() - segcnt.size();
+                segrow.assign(segcnt.size() + 1, 0);
+                for (size_t k = 0; k < segcnt.size(); ++k) { segrow[k + 1] = segrow[k] + segcnt[k]; cseg[s0 + k].y = segrow[k]; }
+                for (int j = j0; j < j1; ++j) rc[j] = (unsigned short)segrow[(size_t)seg_of[(size_t)(j - j0)]]++;
+                cseg.push_back(int2{0, j1 - j0});
+                chunk_cseg0[(size_t)ch + 1] = (int)cseg.size();
+            }
+            // ... and by point block
+            segcnt.clear();
+            for (int j = j0; j < j1; ++j) {
+                const int q = ptv[(size_t)j];
+                if (pt_chunk[(size_t)q] != ch) { pt_chunk[(size_t)q] = ch; pt_seg[(size_t)q] = (int)segcnt.size(); segcnt.push_back(0); pseg.push_back(int2{q, 0}); }
+                seg_of[(size_t)(j - j0)] = pt_seg[(size_t)q];
+                ++segcnt[(size_t)pt_seg[(size_t)q]];
+            }
+            {
+                const size_t s0 = pseg.size() - segcnt.size();
+                segrow.assign(segcnt.size() + 1, 0);
+                for (size_t k = 0; k < segcnt.size(); ++k) {
+                    segrow[k + 1] = segrow[k] + segcnt[k];
+                    pseg[s0 + k].y = segrow[k];
+                    // all the block's listed factors in this chunk: its sum goes straight to g (destination = its id, as set)
+                    if (segcnt[k] != cnt_pt[(size_t)pseg[s0 + k].x]) pstaged.emplace_back(pseg[s0 + k].x, (int)(s0 + k));
+                }
+                for (int j = j0; j < j1; ++j) rp[j] = (unsigned short)segrow[(size_t)seg_of[(size_t)(j - j0)]]++;
+                pseg.push_back(int2{0, j1 - j0});
+                chunk_pseg0[(size_t)ch + 1] = (int)pseg.size();
+            }
+        }
+        for (int l = 0; l < nc; ++l) {
+            int2& e = tile_cam[tc0 + (size_t)l];
+            const int o = e.x;
+            if (tcnt[(size_t)l] == cnt_cam[(size_t)o]) e.y = -1;   // (patched below: the block's first variable id)
+            else { e.y = -2; cstaged.emplace_back(o, (int)(tc0 + (size_t)l)); }
+        }
+        tile_chunk0.push_back(ch1);
+        tile_cam0.push_back((int)tile_cam.size());
+        ch0 = ch1;
+    }
+    // camera ordinal -> first variable id
+    ivec cam_first(ncb, 0);
+    for (size_t v = 0; v < N; ++v) if (p->h_cam_ord[v] >= 0) cam_first[(size_t)p->h_cam_ord[v]] = (int)v;
+    for (int2& e : tile_cam) if (e.y == -1) e.y = cam_first[(size_t)e.x];
+    // staging slots: a block's partial sums consecutive, in the order they were made
+    ivec cs_var, cs_ptr(1, 0), ps_var, ps_ptr(1, 0);
+    {
+        ivec n_of(ncb, 0), base(ncb, 0);
+        for (const auto& e : cstaged) ++n_of[(size_t)e.first];
+        for (size_t o = 0; o < ncb; ++o)
+            if (n_of[o] > 0) { base[o] = cs_ptr.back(); cs_var.push_back(cam_first[o]); cs_ptr.push_back(cs_ptr.back() + n_of[o]); }
+        for (const auto& e : cstaged) tile_cam[(size_t)e.second].y = ~(base[(size_t)e.first]++);
+    }
+    {
+        ivec& n_of = pt_seg;    // (scratch: the per-chunk segment numbers are not needed any more)
+        ivec& base = pt_chunk;
+        for (const auto& e : pstaged) n_of[(size_t)e.first] = 0;
+        for (const auto& e : pstaged) ++n_of[(size_t)e.first];
+        ivec blocks;
+        for (const auto& e : pstaged) if (n_of[(size_t)e.first] > 0) { blocks.push_back(e.first); n_of[(size_t)e.first] = -n_of[(size_t)e.first]; }
+        std::sort(blocks.begin(), blocks.end());
+        for (int q : blocks) { base[(size_t)q] = ps_ptr.back(); ps_var.push_back(q); ps_ptr.push_back(ps_ptr.back() - n_of[(size_t)q]); }
+        for (const auto& e : pstaged) pseg[(size_t)e.second].x = ~(base[(size_t)e.first]++);
+    }
+    // variables no listed factor reads
+    ivec zvar;
+    {
+        cvec touched(N, 0);
+        for (size_t o = 0; o < ncb; ++o) if (cnt_cam[o] > 0) for (int k = 0; k < 9; ++k) touched[(size_t)cam_first[o] + k] = 1;
+        for (size_t v = 0; v < N; ++v) if (cnt_pt[v] > 0) for (int k = 0; k < 3; ++k) touched[v + k] = 1;
+        for (size_t v = 0; v < N; ++v) if (!touched[v]) zvar.push_back((int)v);
+    }
+    // one int32 block, one 16-bit block
+    ivec blk;
+    auto put = [&](const int* v, size_t n) { const size_t off = blk.size(); blk.insert(blk.end(), v, v + n); if (blk.size() & 1) blk.push_back(0); return off; };
+    const size_t o_ptv = put(ptv.data(), ptv.size()), o_tc0 = put(tile_chunk0.data(), tile_chunk0.size()), o_tm0 = put(tile_cam0.data(), tile_cam0.size());
+    const size_t o_tcam = put(reinterpret_cast<const int*>(tile_cam.data()), 2 * tile_cam.size());
+    const size_t o_cs0 = put(chunk_cseg0.data(), chunk_cseg0.size()), o_cseg = put(reinterpret_cast<const int*>(cseg.data()), 2 * cseg.size());
+    const size_t o_ps0 = put(chunk_pseg0.data(), chunk_pseg0.size()), o_pseg = put(reinterpret_cast<const int*>(pseg.data()), 2 * pseg.size());
+    const size_t o_csv = put(cs_var.data(), cs_var.size()), o_csp = put(cs_ptr.data(), cs_ptr.size());
+    const size_t o_psv = put(ps_var.data(), ps_var.size()), o_psp = put(ps_ptr.data(), ps_ptr.size());
+    const size_t o_z = put(zvar.data(), zvar.size());
+    int rc_ = upload(c, G.ints, blk);
+    if (!rc_) rc_ = upload(c, G.shorts, sh.data(), sh.size());
+    if (!rc_ && fac) {
+        ivec f32((size_t)nf);
+        for (int j = 0; j < nf; ++j) f32[(size_t)j] = (int)fac[j];
+        rc_ = upload(c, G.fac, f32);
+        if (!rc_) HIPCHK(c, hipStreamSynchronize(c->stream));   // (f32 goes out of scope)
+    }
+    if (!rc_) rc_ = dalloc(c, G.cstage, (size_t)std::max(cs_ptr.back(), 1) * 9 * sizeof(double));
+    if (!rc_) rc_ = dalloc(c, G.pstage, (size_t)std::max(ps_ptr.back(), 1) * 3 * sizeof(double));
+    if (!rc_) rc_ = dalloc(c, G.partial, (size_t)std::max(nchunks, 1) * sizeof(double));
+    if (rc_) return rc_;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host images go out of scope)
+    const int* I = G.ints.as<int>();
+    const unsigned short* S = G.shorts.as<unsigned short>();
+    GradTables& T = G.T;
+    T.nf = nf; T.nchunks = nchunks; T.ntiles = (int)tile_chunk0.size() - 1; T.ncam_cap = ncam_cap;
+    T.fac = fac ? G.fac.as<int>() : nullptr;
+    T.cl = S; T.rc = S + npad; T.rp = S + 2 * npad;
+    T.ptv = I + o_ptv; T.tile_chunk0 = I + o_tc0; T.tile_cam0 = I + o_tm0; T.tile_cam = reinterpret_cast<const int2*>(I + o_tcam);
+    T.chunk_cseg0 = I + o_cs0; T.cseg = reinterpret_cast<const int2*>(I + o_cseg);
+    T.chunk_pseg0 = I + o_ps0; T.pseg = reinterpret_cast<const int2*>(I + o_pseg);
+    T.ncs = (int)cs_var.size(); T.nps = (int)ps_var.size(); T.nz = (int)zvar.size();
+    T.cs_var = I + o_csv; T.cs_ptr = I + o_csp; T.ps_var = I + o_psv; T.ps_ptr = I + o_psp; T.zvar = I + o_z;
+    G.nf = nf64;
     return 0;
 }
 
-extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f, double* g) {
-    if (!p || !f || !g) return RDIS_HIP_EINVAL;
-    rdis_hip_ctx* c = p->ctx;
-    int rc = check_list(p, nf, fac);
+// the tables of a list: found among the problem's (by two hashes of the ids) or built
+int grad_plan_for(rdis_hip_problem* p, int64_t nf, const int64_t* fac, GradPlan** out) {
+    unsigned long long k0 = 0, k1 = 0;
+    if (fac) {
+        k0 = 1469598103934665603ull; k1 = 0x9E3779B97F4A7C15ull;
+        for (int64_t i = 0; i < nf; ++i) {
+            const unsigned long long v = (unsigned long long)fac[i];
+            if (fac[i] < 0 || fac[i] >= p->F) return fail(p->ctx, RDIS_HIP_EINVAL, "id out of range");
+            k0 = (k0 ^ v) * 1099511628211ull;
+            k1 = (k1 + v + 0x632BE59BD9B4E019ull) * 0xFF51AFD7ED558CCDull; k1 ^= k1 >> 29;
+        }
+        if (k0 == 0 && k1 == 0) k1 = 1;
+    }
+    for (auto& g : p->grad_plans)
+        if (g->nf == nf && g->key0 == k0 && g->key1 == k1) { g->used = ++p->grad_tick; *out = g.get(); return 0; }
+    if (p->grad_plans.size() >= GRAD_PLAN_CACHE) {
+        size_t lru = 0;
+        for (size_t i = 1; i < p->grad_plans.size(); ++i) if (p->grad_plans[i]->used < p->grad_plans[lru]->used) lru = i;
+        HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream));   // (a launch that reads its tables may be in flight)
+        p->grad_plans.erase(p->grad_plans.begin() + (long)lru);
+    }
+    std::unique_ptr<GradPlan> G(new (std::nothrow) GradPlan);
+    if (!G) return fail(p->ctx, RDIS_HIP_ENOMEM, "eval_grad: host allocation");
+    int rc;
+    try { rc = build_grad_plan(p, nf, fac, *G); } catch (const std::bad_alloc&) { return fail(p->ctx, RDIS_HIP_ENOMEM, "eval_grad: host allocation"); }
     if (rc) return rc;
-    USE_DEVICE(c);
-    if (nf == 0) { *f = 0.0; std::fill(g, g + p->N, 0.0); return 0; }
+    G->key0 = k0; G->key1 = k1; G->used = ++p->grad_tick;
+    *out = G.get();
+    p->grad_plans.push_back(std::move(G));
+    return 0;
+}
+
+// value and gradient of a list, left on the device: p->scalar[0] and p->g_all[N] (asynchronous on the context's stream)
+int eval_grad_fused(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    rdis_hip_ctx* c = p->ctx;
+    GradPlan* G = nullptr;
+    int rc = grad_plan_for(p, nf, fac, &G);
+    if (rc) return rc;
+    if ((rc = ensure(c, p->g_all, (size_t)p->N * sizeof(double)))) return rc;
+    if ((rc = ensure(c, p->camrec, (size_t)p->ncam_blocks * GRAD_REC * sizeof(double)))) return rc;
+    const GradTables& T = G->T;
+    const size_t dyn = grad_lds_bytes(T.ncam_cap);
+    if (dyn > (size_t)160 * 1024) return fail(c, RDIS_HIP_EINVAL, "eval_grad: a tile's cameras do not fit the LDS");
+    HIPCHK(c, grad_camera_records_launch(c->stream, (int)((p->ncam_blocks + 255) / 256), p->x.as<double>(), p->cam_blocks.as<int>(),
+                                         (int)p->ncam_blocks, p->camrec.as<double>()));
+    HIPCHK(c, grad_fused_launch(c->stream, T.ntiles, dyn, T, p->x.as<double>(), p->obs.as<double2>(), p->camrec.as<double>(),
+                                G->cstage.as<double>(), G->pstage.as<double>(), G->partial.as<double>(), p->g_all.as<double>()));
+    const long long items = 9ll * T.ncs + 3ll * T.nps + T.nz;
+    if (items > 0) HIPCHK(c, grad_combine_launch(c->stream, grid_for(c, items, 256), T, G->cstage.as<double>(), G->pstage.as<double>(), p->g_all.as<double>()));
+    final_sum_kernel<<<1, 256, 0, c->stream>>>(T.nchunks, G->partial.as<double>(), p->scalar.as<double>());
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// the two-pass form (nonlinear-product functions; bundle adjustment whose blocks overlap): per-factor partials, then one
+// lane per variable adds its slots in factor-list order
+int eval_grad_two_pass(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    rdis_hip_ctx* c = p->ctx;
+    int rc;
     const int* dfac;
     if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
     // gather lists: cached for the all-factors case
@@ -669,9 +912,73 @@ extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t
     if ((rc = launch_eval_sum<true>(p, (int)nf, dfac, blocks))) return rc;
     gather_grad_kernel<<<grid_for(c, p->N, 256), 256, 0, c->stream>>>((int)p->N, dptr, didx, p->gfac.as<double>(), p->g_all.as<double>());
     HIPCHK(c, hipGetLastError());
+    if (fac) HIPCHK(c, hipStreamSynchronize(c->stream));   // (lptr / lidx go out of scope)
+    return 0;
+}
+
+int eval_grad_on_device(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    if (nf == 0) {
+        rdis_hip_ctx* c = p->ctx;
+        int rc = ensure(c, p->g_all, (size_t)p->N * sizeof(double));
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(p->g_all.p, 0, (size_t)p->N * sizeof(double), c->stream));
+        HIPCHK(c, hipMemsetAsync(p->scalar.p, 0, sizeof(double), c->stream));
+        return 0;
+    }
+    return fused_path(p) ? eval_grad_fused(p, nf, fac) : eval_grad_two_pass(p, nf, fac);
+}
+
+}  // namespace
+
+extern "C" int rdis_hip_eval(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f) {
+    if (!p || !f) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    USE_DEVICE(c);
+    if (nf == 0) { *f = 0.0; return 0; }
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    if (fused_path(p)) {
+        // chunk by chunk, the chunks' sums added in a fixed order: the value rdis_hip_eval_grad returns, bit for bit
+        const int nchunks = (int)((nf + GRAD_LANES - 1) / GRAD_LANES);
+        if ((rc = ensure(c, p->partial, (size_t)nchunks * sizeof(double)))) return rc;
+        HIPCHK(c, eval_chunks_launch(c->stream, std::min(nchunks, 16 * std::max(1, c->num_cus)), p->view(), (int)nf, dfac, p->partial.as<double>()));
+        final_sum_kernel<<<1, 256, 0, c->stream>>>(nchunks, p->partial.as<double>(), p->scalar.as<double>());
+        HIPCHK(c, hipGetLastError());
+    } else {
+        const int blocks = grid_for(c, nf, 256);
+        if ((rc = ensure(c, p->partial, (size_t)blocks * sizeof(double)))) return rc;
+        if ((rc = launch_eval_sum<false>(p, (int)nf, dfac, blocks))) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(f, p->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_eval_grad(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* f, double* g) {
+    if (!p || !f || !g) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    USE_DEVICE(c);
+    if (nf == 0) { *f = 0.0; std::fill(g, g + p->N, 0.0); return 0; }
+    if ((rc = eval_grad_on_device(p, nf, fac))) return rc;
     HIPCHK(c, hipMemcpyAsync(f, p->scalar.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(g, p->g_all.p, (size_t)p->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rdis_hip_eval_grad_device(rdis_hip_problem* p, int64_t nf, const int64_t* fac, void** f_dev, void** g_dev) {
+    if (!p || !f_dev || !g_dev) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    int rc = check_list(p, nf, fac);
+    if (rc) return rc;
+    USE_DEVICE(c);
+    if ((rc = eval_grad_on_device(p, nf, fac))) return rc;
+    *f_dev = p->scalar.p;
+    *g_dev = p->g_all.p;
     return 0;
 }
 

@@ -175,3 +175,39 @@ def test_abi_error_codes(gctx):
     bad.pt_vid0[3] = bad.nvars - 1                  # point block would run past the last variable
     with pytest.raises(capi.RdisHipError):
         capi.Problem(gctx, bad)
+
+
+def test_fused_gradient_on_any_list_and_on_the_device(gctx):
+    """rdis_hip_eval_grad's one-pass form (rdis_amd/csrc/grad_fused.hpp) builds per-list tables: lists in another
+    order than the loader's point-major one, with repeated factors, cut at odd lengths, a single factor; several
+    lists in turn (the problem keeps the tables of the last four), and the device-resident variant."""
+    pp = CASES["ladybug_full"]
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    rng = np.random.default_rng(3)
+    lists = [rng.permutation(pp.nfac)[:20000].astype(np.int64),                      # scattered: every block is staged
+             np.sort(rng.choice(pp.nfac, 777, replace=False)).astype(np.int64),
+             np.concatenate([np.arange(1000), np.arange(500, 1500)]).astype(np.int64),  # 500 factors listed twice
+             np.array([31842], dtype=np.int64),
+             np.argsort(pp.cam_vid0, kind="stable").astype(np.int64),                  # camera-major
+             np.arange(513, dtype=np.int64)]                                           # one entry past a chunk
+    for rep in range(2):                                                               # second round: tables rebuilt or found
+        for fl in lists:
+            f, gg = g.eval_grad(fl)
+            go = o.gradient(fl)
+            assert f == g.eval(fl)
+            assert abs(f - o.eval(fl)) <= 1e-12 * np.sum(np.abs(o.eval_each(fl)))
+            assert np.max(np.abs(gg - go)) <= 1e-12 * np.max(np.abs(go))
+            assert np.all(gg[go == 0.0] == 0.0)                                        # untouched variables: exactly zero
+            f2, g2 = g.eval_grad(fl)
+            assert f2 == f and np.array_equal(g2, gg)                                  # fixed order of every sum
+    f, gg = g.eval_grad()
+    fd, gd = g.eval_grad_device()
+    assert np.frombuffer(gctx.copy_to_host(fd, 8), dtype=np.float64)[0] == f
+    assert np.array_equal(np.frombuffer(gctx.copy_to_host(gd, 8 * pp.nvars), dtype=np.float64), gg)
+    # constants changed between calls: the tables are index work only, the camera records are formed per call
+    x1 = pp.x0 * (1 + 1e-3 * rng.standard_normal(pp.nvars))
+    g.set_x(x1)
+    o.assign(np.arange(pp.nvars, dtype=np.int64), x1)
+    f, gg = g.eval_grad()
+    go = o.gradient()
+    assert np.max(np.abs(gg - go)) <= 1e-12 * np.max(np.abs(go)) and abs(f - o.eval()) <= 1e-12 * f
