@@ -460,6 +460,9 @@ void HipRDISLevelOptimizer::runSet(const std::vector<int>& set, const std::vecto
             }
             ss_.optimizeBatch(comps, false);
             ref_calls_ += (long long)pending.size();
+            ++ref_batches_;
+            for (const HipCGDSubspaceOptimizer::Component& C : comps)
+                if ((C.status & 0xff) != RDIS_HIP_EXIT_EMPTY) { ref_iters_ += C.iters + 1; ref_fevals_ += C.nfeval; }
             std::vector<int> again;
             const double ftol = steptol_;   // :1083-1084
             for (size_t i = 0; i < pending.size(); ++i) {
@@ -547,7 +550,7 @@ Numeric HipRDISLevelOptimizer::optimizeReferenceSchedule(bool printInfo) {
         if (nodes_[i].parent >= 0) children_[(size_t)nodes_[i].parent].push_back((int)i); else roots.push_back((int)i);
     }
     ref_trace_.clear();
-    ref_calls_ = 0;
+    ref_calls_ = ref_iters_ = ref_fevals_ = ref_batches_ = 0;
     std::vector<NodeState> st(nodes_.size());
     runSet(roots, std::vector<char>(roots.size(), 0), st, printInfo);
     return f_.eval();

@@ -103,6 +103,12 @@ public:
     };
     Numeric optimizeReferenceSchedule(bool printInfo = false);
     const std::vector<RefStep>& refTrace() const { return ref_trace_; }
+    // of the last optimizeReferenceSchedule: subspace-optimizer calls (ssopt.optimize, src/RDISOptimizer.cpp:1067), their CG
+    // iterations (Frprmn outer iterations) and objective evaluations, and the optimizeBatch launches that carried them
+    long long refCalls() const { return ref_calls_; }
+    long long refIterations() const { return ref_iters_; }
+    long long refFEvals() const { return ref_fevals_; }
+    long long refBatches() const { return ref_batches_; }
     static double restartValue(unsigned long long seed, int node, int restart, VariableID vid, const VariableDomain& dom);
 
     // The decomposition alone -- tree and per-depth plans, nothing solved (what optimize() does first): for callers
@@ -156,6 +162,7 @@ private:
     unsigned nrr_per_lvl_, nrr_at_top_, min_rr_, max_na_to_rr_;
     bool no_assign_limit_at_top_, nrr_at_top_set_;
     unsigned long long restart_seed_;
+    long long ref_iters_ = 0, ref_fevals_ = 0, ref_batches_ = 0;
     long long max_calls_, ref_calls_;   // budget of subspace-optimizer calls (the reference: a time limit, :317-321), calls so far
     std::vector<std::vector<int> > children_;
     std::vector<RefStep> ref_trace_;

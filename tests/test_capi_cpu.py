@@ -99,3 +99,22 @@ def test_matrix_form_of_a_trial_agrees_with_the_vector_form(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "worst relative deviation" in out.stdout
+
+
+def test_optba_entry_of_the_host_library():
+    """include/rdis_optba.h: the caller-side C entry (optBA's core over the level driver) is exported by librdis_host.so and
+    rejects bad calls without touching a device."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "rdis_amd", "host")], stdout=subprocess.DEVNULL)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rdis_optba.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(rdis_optba_[a-z_0-9]+)\s*\(", text)))
+    assert names == ["rdis_optba_run"]
+    lib = C.CDLL(os.path.join(ROOT, "rdis_amd", "lib", "librdis_host.so"))
+    for n in names:
+        assert getattr(lib, n) is not None
+    out = (C.c_double * 10)()
+    run = lib.rdis_optba_run
+    run.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    assert run(None, 0, 0, 1, 0, None, None, 0, out, None) == -3              # no file name
+    assert run(b"x", 0, 0, 7, 0, None, None, 0, out, None) == -3              # no such schedule
+    assert run(b"/nonexistent/problem.txt", 0, 0, 1, 0, None, None, 0, out, None) == -1   # cannot be loaded

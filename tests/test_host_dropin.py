@@ -569,6 +569,37 @@ def test_reference_schedule_of_the_level_driver(harness, bal_path, nc, npnt, pct
 
 
 @pytest.mark.gpu
+def test_optba_entry_runs_the_reference_schedule(harness, bal_path):
+    """include/rdis_optba.h (what bench.py's all_components block calls): the same run as the harness's, through the C
+    entry of librdis_host.so -- same end value and variables bit for bit, the calls and CG iterations it reports are the
+    trace's, and the schedule-0 run (level sweeps) is monotone and ends lower than it started."""
+    lib = C.CDLL(os.path.join(ROOT, "rdis_amd", "lib", "librdis_host.so"))
+    lib.rdis_optba_run.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                   C.c_int32, C.c_void_p, C.c_void_p]
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    names = [b"SSmaxit", b"AVblkpct", b"sepPiecePct", b"nRRperLvl", b"maxNAtoRR", b"restartSeed", b"maxCalls", b"steptol"]
+    vals = [25.0, 0.2, 0.0, 2.0, 10.0, 12345.0, 300000.0, 1e-2]
+    out, x = np.zeros(10), np.zeros(135)
+    assert lib.rdis_optba_run(bal_path, 5, 30, 1, len(names), (C.c_char_p * len(names))(*names), (C.c_double * len(vals))(*vals), 0, v(out), v(x)) == 0
+    ho, tr, hx = np.zeros(4), np.zeros((300000, 10)), np.zeros(135)
+    harness.harness_level_reference.restype = C.c_longlong
+    n = harness.harness_level_reference(bal_path, C.c_longlong(5), C.c_longlong(30), 25, C.c_double(0.2), C.c_double(0.0), 2, 10, C.c_double(12345.0), 1,
+                                        C.c_double(300000.0), C.c_double(1e-2), v(ho), v(tr), C.c_longlong(len(tr)), v(hx))
+    assert n > 0 and out[0] == ho[0] and out[1] == ho[1] and np.array_equal(x, hx)
+    assert out[2] == n == out[9] and out[3] >= out[2] and out[4] < out[2] and out[5] > 0 and out[7] == ho[2]
+    pp = P.load_bal(ncams=5, npts=30)
+    o = O.OracleProblem(pp)
+    assert abs(out[1] - o.eval()) <= 1e-12 * out[1]
+    o.assign(np.arange(pp.nvars, dtype=np.int64), x)
+    assert abs(o.eval() - out[0]) <= 1e-10 * abs(out[0]) and out[0] < out[1]
+    out0 = np.zeros(10)
+    assert lib.rdis_optba_run(bal_path, 5, 30, 0, 1, (C.c_char_p * 1)(b"SSmaxit"), (C.c_double * 1)(25.0), 0, v(out0), None) == 0
+    assert out0[0] < out0[1] == out[1] and out0[2] > 0 and out0[3] >= out0[2]
+    bad = (C.c_char_p * 1)(b"noSuchOption")
+    assert lib.rdis_optba_run(bal_path, 5, 30, 0, 1, bad, (C.c_double * 1)(1.0), 0, v(out0), None) == -3
+
+
+@pytest.mark.gpu
 def test_plan_cache_is_bounded_and_never_changes_a_bit(harness, bal_path):
     """The host-side cache of resident plans: bounded by entries AND by device bytes, least recently used
     first; a call whose plan does not fit the budget at all is served by the transient path.  Whatever the bounds,
