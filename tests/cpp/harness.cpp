@@ -202,8 +202,8 @@ int harness_ba_children_batch(const char* path, long long ncams, long long npts,
     } catch (const std::exception& e) { std::cerr << "harness_ba_children_batch: " << e.what() << std::endl; return -2; }
 }
 
-// The same over SEVERAL devices from one process (OptimizableFunction::setDevices; here ndev contexts on device 0 --
-// what one GPU can test): which = 0 the point components (cameras assigned), 1 the camera components (points assigned).
+// The same over SEVERAL devices from one process (OptimizableFunction::setDevices; ndev > 0: ndev contexts on device 0 --
+// what one GPU can test; ndev < 0: -ndev distinct GPUs): which = 0 the point components (cameras assigned), 1 the camera components (points assigned).
 // out = {sum fret, ncomp, f_before, f_after, plan cache entries}; per component (in createChildren's order): fret, iters,
 // f-evaluations; x_out: every variable's value afterwards
 int harness_ba_children_batch_devices(const char* path, long long ncams, long long npts, int maxit, int which, int ndev, int rounds,
@@ -212,6 +212,11 @@ int harness_ba_children_batch_devices(const char* path, long long ncams, long lo
         BundleAdjustmentFunction f;
         if (!f.load(path, ncams, npts)) return -1;
         if (ndev > 1) f.setDevices(std::vector<int>((size_t)ndev, 0));
+        if (ndev < -1) {   // ndev < 0: -ndev DISTINCT GPUs (a multi-GPU node)
+            std::vector<int> devs;
+            for (int d = 0; d < -ndev; ++d) devs.push_back(d);
+            f.setDevices(devs);
+        }
         const NumericVec x0 = f.getInitialState();
         f.assignAll(x0);
         const Numeric before = f.eval();

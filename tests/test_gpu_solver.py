@@ -48,7 +48,7 @@ def solve(gctx, pp, maxiters=25, ftol=3e-8, free_vid=None, fac_id=None, x=None, 
     return g, r, tr
 
 
-def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None, iter_tol=1e-11, far_tol=1e-6):
+def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=None, iter_tol=1e-11, far_tol=1e-6, near_scale=1.0, vec_tol=1e-8):
     """The oracle re-runs the solve, (a) fed the scalars the device's control logic saw and
     (b) restarted at every line search from the device's own point and direction, so both
     sides evaluate at bit-identical points.  Then over the WHOLE run:
@@ -73,10 +73,10 @@ def check_replay(pp, trv, r, maxiters, ftol=3e-8, free_vid=None, fac_id=None, x=
     # depending on where the chaotic trajectory happens to step) and 1e-6 is the bar.
     # rep.max_f_bound / max_slope_bound report every difference in units of eps x a first-order
     # rounding bound of the sum at that point (below 1 at ordinary points, up to ~1e3 far out).
-    assert rep.max_f_rel_near <= 1e-12 and rep.max_slope_rel_near <= 1e-11, rep
+    assert rep.max_f_rel_near <= 1e-12 * near_scale and rep.max_slope_rel_near <= 1e-11 * near_scale, rep
     assert rep.max_f_rel <= far_tol and rep.max_slope_rel <= far_tol, rep
     assert rep.max_iter_rel <= iter_tol, rep    # gg, dgg, gradient test
-    assert rep.max_vec_rel <= 1e-8, rep         # one iteration of drift in p / xi (inf-norm relative)
+    assert rep.max_vec_rel <= vec_tol, rep      # one iteration of drift in p / xi (inf-norm relative)
     if not (r.status[0] & capi.STATUS_ROLLED_BACK):
         assert rep.fret == r.fret[0]
     # without the re-sync the decisions are still bit-identical (they only depend on the scalars)

@@ -223,6 +223,27 @@ def test_batch_shared_out_over_several_devices(harness, bal_path, which):
 
 
 @pytest.mark.gpu
+def test_batch_shared_out_over_distinct_gpus(harness, bal_path):
+    """The same on DISTINCT GPUs (a node with at least two): one thread drives a context per GPU, so every C-ABI entry
+    must make its context's device current before it allocates, records an event or launches -- with
+    several contexts on one GPU that cannot fail, here it would.  Bit-identical to the one-device batch."""
+    ngpu = capi.load_library().rdis_hip_device_count()
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs (%d visible)" % ngpu)
+    nc, npnt = 49, 500
+    res = {}
+    for ndev in (1, -min(ngpu, 4)):
+        out, fret = np.zeros(5), np.zeros(600)
+        iters, nfe, x = np.zeros(600, dtype=np.int64), np.zeros(600, dtype=np.int64), np.zeros(9 * nc + 3 * npnt)
+        v = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert harness.harness_ba_children_batch_devices(bal_path, C.c_longlong(nc), C.c_longlong(npnt), 25, 0, ndev, 2,
+                                                         v(out), v(fret), v(iters), v(nfe), v(x)) == 0
+        res[ndev] = (out.copy(), fret.copy(), iters.copy(), x.copy())
+    a, b = res[1], res[-min(ngpu, 4)]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[0][3] == b[0][3]
+
+
+@pytest.mark.gpu
 def test_level_driver_over_several_devices(harness, bal_path):
     """HipRDISLevelOptimizer on a function replicated over two contexts: every level's components go through
     optimizeBatch's sharing-out; the sweeps, the final value and every variable are those of the one-device run."""
