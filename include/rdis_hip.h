@@ -260,6 +260,13 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups
  * that share one such component when the launch has fewer components than compute units: 0 = auto,
  * 1 = never, k <= 16 = k),
+ * "factor_rounding" (how the factor arithmetic rounds a * b + c: 0 = one fused multiply-add; 1 = the product is rounded before
+ * it is added, like the reference's x86-64 build (g++ emits no fused multiply-add) -- and, in the LDS-resident batch solver, a
+ * line-search trial's slope is formed the reference's way too: the gradient at the trial point, then gradient times direction
+ * variable by variable (Df1dim::df), a full gradient per trial, seven times slower; the cooperative solvers and the LDS-resident
+ * batch solver have a second instantiation for it, refused where other solvers would run; -1 = default: the cooperative solvers
+ * round like the reference (4 % slower), the batch solvers fuse.  After 25 unconverged CG iterations the DISTRIBUTION of end
+ * values over one-ulp starts depends on both: DESIGN.md section 6),
  * "emulate_stale_cache" (default 0; 1 = the reference's factor cache, Variable.cpp:66-76 and
  * Factor.h:228-234 -- a factor keeps its value while its variables have moved by less than 1e-12 since
  * it was computed -- emulated in the LDS-resident batch solver; refused where other solvers would run),

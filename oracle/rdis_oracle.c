@@ -38,8 +38,12 @@ typedef struct {
 /* An experiment's switch (process-wide; tests/golden/make_end_values.py and nothing else): bit 0 = the unit axis and the
  * perspective divide through ONE reciprocal each (x * (1 / y) in place of x / y), the device's form (rdis_amd/csrc/
  * factors.hpp) -- an equally valid rounding, not the reference's. */
+/* bit 1 (value 2) = the slope of a line-search trial summed FACTOR by factor -- sum_f (sum_k partial_fk xi_k), the association
+ * the device's fused trial uses -- in place of the reference's gradient-times-direction sum over the variables (Df1dim::df).  Also
+ * an experiment's switch (round 5: where ladybug 5 / 30's population of end values parts from the device's). */
 static int g_experiment = 0;
 void ro_set_experiment(int flags) { g_experiment = flags; }
+static double (*g_slope_by_factor)(void *ctx, const double *xi) = 0;
 
 static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
 {
@@ -742,6 +746,7 @@ static double line_df(line_t *L)
     double s = 0.0;
     L->df(L->ctx, L->xt, L->dft);
     for (int j = 0; j < L->n; ++j) s += L->dft[j] * L->xi[j];
+    if ((g_experiment & 2) && g_slope_by_factor) s = g_slope_by_factor(L->ctx, L->xi);
     if (L->hk && L->hk->on_slope) {
         double sabs = 0.0;
         for (int j = 0; j < L->n; ++j) sabs += fabs(L->dft[j] * L->xi[j]);
@@ -969,6 +974,24 @@ static double sub_f(void *ctx, const double *x)
     return ro_eval_factors(S->p, S->nf, S->fac);
 }
 
+/* (experiment, ro_set_experiment bit 1) the slope at the assigned point, factor by factor in list order; bundle adjustment only */
+static double sub_slope_by_factor(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    int64_t vids[64]; double vals[64];
+    double *dir = calloc((size_t)S->p->nvars + 1, sizeof(double));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    double s = 0.0;
+    for (int64_t i = 0; i < S->nf; ++i) {
+        const int n = factor_partials(S->p, S->fac ? S->fac[i] : i, vids, vals);
+        double t = 0.0;
+        for (int k = 0; k < n && k < 64; ++k) t += vals[k] * dir[vids[k]];
+        s += t;
+    }
+    free(dir);
+    return s;
+}
+
 /* SubfunctionFD::df (.cpp:135-157) */
 static void sub_df(void *ctx, const double *x, double *deriv)
 {
@@ -987,6 +1010,7 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     if (nf == 0) { out->status = RO_EXIT_EMPTY; return; } /* .cpp:26-29 */
 
     sub_t S = { p, nfree, nf, free_vid, fac, NULL, merge, 0, 0, 0 };
+    g_slope_by_factor = p->kind == RO_KIND_BA ? sub_slope_by_factor : 0;
     S.gdense = malloc(sizeof(double) * (size_t)(p->nvars + 1));
     double *xinit = malloc(sizeof(double) * (size_t)(nfree + 1));
     double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));

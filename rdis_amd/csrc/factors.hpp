@@ -41,8 +41,14 @@ __device__ __forceinline__ double kconst(double v) { asm volatile("" : "+s"(v));
 #else
 #define KC(x) (x)
 #endif
+// (Measurement builds, one switch at a time, for tracing where the device's population of end values parts from the oracle's --
+// tools/gpu_probe_population.py, DESIGN.md section 6: -DRDIS_BISECT_LIBM_SINCOS the library's sincos in place of this routine;
+// -DRDIS_BISECT_IEEE_DIV quotients where the unit axis and the perspective divide use one reciprocal each.)
 __host__ __device__ __forceinline__ void sincos_angle(double x, double* sn, double* cs) {
 RDIS_FACTORS_FP_CONTRACT
+#ifdef RDIS_BISECT_LIBM_SINCOS
+    sincos(x, sn, cs); return;
+#endif
     if (!(x < 1.0e6)) { sincos(x, sn, cs); return; }
     const double fn = rint(x * KC(6.36619772367581382433e-01));
     const int n = (int)fn;
@@ -88,9 +94,15 @@ RDIS_FACTORS_FP_CONTRACT
     const bool rot = t.theta > 0.0;
     // unit axis (reference BundleAdjustmentCommon.h:81-93); one reciprocal instead of three quotients
     t.itheta = 1.0 / t.theta;
+#ifdef RDIS_BISECT_IEEE_DIV
+    t.v0 = rot ? r0 / t.theta : r0;
+    t.v1 = rot ? r1 / t.theta : r1;
+    t.v2 = rot ? r2 / t.theta : r2;
+#else
     t.v0 = rot ? r0 * t.itheta : r0;
     t.v1 = rot ? r1 * t.itheta : r1;
     t.v2 = rot ? r2 * t.itheta : r2;
+#endif
     if (rot) {
         sincos_angle(t.theta, &t.s, &t.c);
     } else {
@@ -118,8 +130,13 @@ RDIS_FACTORS_FP_CONTRACT
     }
     t.P0 += x[3]; t.P1 += x[4]; t.P2 += x[5];
     t.iz = 1.0 / t.P2;
+#ifdef RDIS_BISECT_IEEE_DIV
+    t.pp0 = -t.P0 / t.P2;
+    t.pp1 = -t.P1 / t.P2;
+#else
     t.pp0 = -t.P0 * t.iz;
     t.pp1 = -t.P1 * t.iz;
+#endif
     t.r2 = t.pp0 * t.pp0 + t.pp1 * t.pp1;
     t.dstn = 1.0 + t.r2 * (x[7] + x[8] * t.r2);
     t.res0 = x[6] * t.dstn * t.pp0 - ox;
@@ -154,7 +171,7 @@ __device__ __forceinline__ double ba_eval(const double (&x)[12], double ox, doub
 // Adjoint (reverse) sweep of the projection: g = d(s0 * pix_x + s1 * pix_y) / dx for the forward
 // state t.  With (s0, s1) = the residual this is the gradient of E = |res|^2 / 2; with unit
 // seeds it yields the two rows of the residual's Jacobian.
-__device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12], double s0, double s1, double (&g)[12]) {
+__host__ __device__ __forceinline__ void ba_adjoint(const BaFwd& t, const double (&x)[12], double s0, double s1, double (&g)[12]) {
 RDIS_FACTORS_FP_CONTRACT
     const double q0 = x[9], q1 = x[10], q2 = x[11];
     const double f = x[6];
@@ -353,6 +370,50 @@ RDIS_FACTORS_FP_CONTRACT
     const double dpix0 = scale * t.pp0 + t.fd * dpp0;
     const double dpix1 = scale * t.pp1 + t.fd * dpp1;
     return t.res0 * dpix0 + t.res1 * dpix1;
+}
+
+// The factor's GRADIENT in matrix form (solver_ptm.hpp's gradient pass; round 5), from the value's evaluation t against the
+// camera record TR at point q.  With a = dE/dP (the adjoint of the projection, the same expressions as ba_adjoint's):
+//   the point's entries   dE/dq = R^T a                                        (nine multiply-adds)
+//   the camera's          dE/dR = a q^T (nine products), dE/dt = a, dE/df, dE/dk1, dE/dk2 -- fifteen numbers that are
+//                         LINEAR in the factor, so a camera's factors are summed first and the chain from dE/dR to the three
+//                         rotation variables (dE/dr_k = <sum a q^T, dR/dr_k>, ba_rotation_gradient) is applied once per
+//                         camera and gradient instead of once per factor: about 75 fp64 operations a factor where the adjoint
+//                         sweep of the vector form (ba_project + ba_adjoint) takes about 185.
+// gc = [a0 q0, a0 q1, a0 q2, a1 q0, ... a2 q2 | a0 a1 a2 | dE/df dE/dk1 dE/dk2]
+constexpr int CAM_GRAD = 15;
+__host__ __device__ __forceinline__ void ba_trial_adjoint(const BaTrial& t, const double (&TR)[CAM_TRIAL], const double (&q)[3],
+                                                          double (&gq)[3], double (&gc)[CAM_GRAD]) {
+RDIS_FACTORS_FP_CONTRACT
+    const double rp = t.res0 * t.pp0 + t.res1 * t.pp1;
+    gc[12] = t.dstn * rp;
+    const double adst = TR[12] * rp;
+    gc[13] = adst * t.r2;
+    gc[14] = adst * t.r2 * t.r2;
+    const double ar2 = adst * (TR[13] + 2.0 * TR[14] * t.r2);
+    const double app0 = t.fd * t.res0 + 2.0 * ar2 * t.pp0;
+    const double app1 = t.fd * t.res1 + 2.0 * ar2 * t.pp1;
+    const double a0 = -app0 * t.iz, a1 = -app1 * t.iz;
+    const double a2 = -(app0 * t.pp0 + app1 * t.pp1) * t.iz;
+    gq[0] = TR[0] * a0 + (TR[4] * a1 + TR[8] * a2);
+    gq[1] = TR[1] * a0 + (TR[5] * a1 + TR[9] * a2);
+    gq[2] = TR[2] * a0 + (TR[6] * a1 + TR[10] * a2);
+    gc[0] = a0 * q[0]; gc[1] = a0 * q[1]; gc[2] = a0 * q[2];
+    gc[3] = a1 * q[0]; gc[4] = a1 * q[1]; gc[5] = a1 * q[2];
+    gc[6] = a2 * q[0]; gc[7] = a2 * q[1]; gc[8] = a2 * q[2];
+    gc[9] = a0; gc[10] = a1; gc[11] = a2;
+}
+// ... and the chain for one camera: M = the sum of its factors' a q^T (row-major 3 x 3), rot = ba_rotation of its angle-axis
+// vector; gr[k] = sum_ij M_ij dR_ij/dr_k (the derivative of the rotation matrix along the k-th unit vector: ba_camera_trial_dir)
+__host__ __device__ __forceinline__ void ba_rotation_gradient(const BaFwd& rot, const double (&M)[9], double (&gr)[3]) {
+RDIS_FACTORS_FP_CONTRACT
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double d[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, DR[CAM_TRIAL];
+        d[k] = 1.0;
+        ba_camera_trial_dir(rot, d, DR);
+        gr[k] = (M[0] * DR[0] + M[1] * DR[1] + M[2] * DR[2]) + (M[3] * DR[4] + M[4] * DR[5] + M[5] * DR[6]) + (M[6] * DR[8] + M[7] * DR[9] + M[8] * DR[10]);
+    }
 }
 
 // ... for W factors of ONE point at a time, statement by statement (the streaming solver's trial loop).  A factor's evaluation

@@ -22,6 +22,7 @@
 #include "lm_solver.hpp"
 #include "eval_kernels.hpp"
 #include "grad_fused.hpp"
+#include "refround_api.hpp"
 #include "solver_coop.hpp"
 #include "solver_lds.hpp"
 #include "ptm_api.hpp"
@@ -42,6 +43,7 @@ struct rdis_hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // resident-workgroup caps of the cooperative layouts on THIS device (occupancy queries, asked once per context)
     int cap_pipe = -1, cap_coop[3] = {-1, -1, -1};
+    int cap_pipe_rr = -1, cap_coop_rr[3] = {-1, -1, -1};   // ... of the reference-rounding instantiations (refround_api.hpp)
     // dynamic LDS a launch may ask for on THIS device: what a compute unit has, less the solvers' static share (at most
     // solver_lds.hpp's LDS_MAX_BYTES, which is gfx950's); components that do not fit go to the solvers that need none
     size_t lds_limit = LDS_MAX_BYTES;
@@ -267,6 +269,11 @@ struct rdis_hip_plan {
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
     int lds_camera_sums = 1;          // option "lds_camera_sums": 0 = camera partials through gfac[] like the plain batch solver
     int emulate_stale = 0;            // option "emulate_stale_cache": the reference's factor cache, emulated (solver_lds.hpp; that solver only)
+    int factor_rounding = -1;         // option "factor_rounding": -1 = auto (the cooperative solvers round like the reference's build -- it costs them 4 % --, the batch
+                                      // solvers use fused multiply-adds), 0 = fused multiply-adds everywhere, 1 = the reference's rounding (and, in the LDS-resident
+                                      // solver, its association of a trial's slope) everywhere: refround_api.hpp
+    bool coop_reference_rounding() const { return factor_rounding != 0; }
+    bool batch_reference_rounding() const { return factor_rounding == 1; }
     DevBuf st_ev, st_val;
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
@@ -1393,6 +1400,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->ptm_threads = (int)value;
     } else if (n == "emulate_stale_cache") {
         L->emulate_stale = value != 0;
+    } else if (n == "factor_rounding") {
+        if (value < -1 || value > 1) return fail(c, RDIS_HIP_EINVAL, "factor_rounding must be -1 (auto), 0 (fused multiply-adds) or 1 (the reference's rounding)");
+        L->factor_rounding = (int)value;
     } else if (n == "lds_camera_sums") {
         L->lds_camera_sums = value != 0;
     } else if (n == "lds_rot") {
@@ -1477,10 +1487,13 @@ int prepare_partition(rdis_hip_plan* L) {
     auto cap_of = [&]() {
         // (the occupancy queries behind these are not free: asked once per context -- a device -- and layout;
         // calls on a context are serialised, include/rdis_hip.h)
-        int& kc = c->cap_coop[L->coop_threads == 128 ? 0 : L->coop_threads == 256 ? 1 : 2];
-        if (L->pipelined() && c->cap_pipe < 0) c->cap_pipe = pipe_max_workgroups(c->num_cus);
-        if (!L->pipelined() && kc < 0) kc = coop_max_workgroups(L->coop_threads, c->num_cus);
-        int k = L->pipelined() ? c->cap_pipe : kc;
+        const int ti = L->coop_threads == 128 ? 0 : L->coop_threads == 256 ? 1 : 2;
+        const bool rr = L->coop_reference_rounding();
+        int& kc = rr ? c->cap_coop_rr[ti] : c->cap_coop[ti];
+        int& kp = rr ? c->cap_pipe_rr : c->cap_pipe;
+        if (L->pipelined() && kp < 0) kp = rr ? refround_pipe_max_workgroups(c->num_cus) : pipe_max_workgroups(c->num_cus);
+        if (!L->pipelined() && kc < 0) kc = rr ? refround_coop_max_workgroups(L->coop_threads, c->num_cus) : coop_max_workgroups(L->coop_threads, c->num_cus);
+        int k = L->pipelined() ? kp : kc;
         if (L->coop_workgroups > 0) k = std::min(k, L->coop_workgroups);
         return k;
     };
@@ -2132,6 +2145,22 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
             }
         }
     }
+    if (std::getenv("RDIS_HIP_ROUND_STATS") && nwg > 0) {   // (tuning: how uneven are a round's camera segments?)
+        const int cc = L->h_rest[r_ptm];
+        const int ncb = ls_ncb[cc];
+        const size_t stride = (size_t)ptm_round_stride(ncb);
+        const unsigned short* t0 = tab.data() + off[(size_t)cc * K];
+        long long sum_max = 0, worst = 0, rows = 0, active = 0;
+        const int nrd = nr[(size_t)cc * K];
+        for (int rr = 0; rr < nrd; ++rr) {
+            const unsigned short* rec = t0 + (size_t)rr * stride;
+            int mx = 0;
+            for (int k = 0; k < ncb; ++k) { const int len = rec[k + 1] - rec[k]; mx = std::max(mx, len); active += len > 0; }
+            sum_max += mx; worst = std::max<long long>(worst, mx); rows += rec[ncb];
+        }
+        std::fprintf(stderr, "ptm rounds (threads %d, K %d): first workgroup %d rounds, %d cameras; rows per round %.1f, active cameras per round %.1f, longest segment: mean %.1f, worst %lld\n",
+                     threads, K, nrd, ncb, (double)rows / std::max(nrd, 1), (double)active / std::max(nrd, 1), (double)sum_max / std::max(nrd, 1), worst);
+    }
     int rc = plan_alloc(L, L->pm_rounds, std::max<size_t>(tab.size(), 2) * sizeof(unsigned short));
     if (!rc) rc = plan_alloc(L, L->pm_grow, grow.size() * sizeof(unsigned short));
     if (!rc) rc = plan_alloc(L, L->pm_rd_off, nwg * sizeof(long long));
@@ -2222,6 +2251,15 @@ int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int firs
 }
 int launch_lds(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
     if (L->emulate_stale) return launch_lds_stale(L, stream, threads, first, grid, maxiters, ftol);
+    if (L->batch_reference_rounding()) {
+        rdis_hip_ctx* c = L->prob->ctx;
+        ProblemView P = L->prob->view();
+        PlanView V = L->view();
+        V.order += first;
+        HIPCHK(c, refround_launch_lds(L->lds_rot_mode, threads, grid, lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap), stream, &P, &V,
+                                      maxiters, ftol, L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap));
+        return 0;
+    }
     switch (L->lds_rot_mode) {
         case ROT_CAMFIX: return launch_lds_rot<ROT_CAMFIX>(L, stream, threads, first, grid, maxiters, ftol);
         case ROT_RECORDS: return launch_lds_rot<ROT_RECORDS>(L, stream, threads, first, grid, maxiters, ftol);
@@ -2256,6 +2294,12 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             if (rc) return rc;
         }
     }
+    if (L->factor_rounding == 1) {
+        // instantiated for the solvers BASELINE's configs 3 - 5 reach: the cooperative ones and the LDS-resident batch solver
+        if ((size_t)L->rest_lds != L->h_rest.size() || !L->stream.empty() || L->emulate_stale || p->kind != KIND_BA)
+            return fail(c, RDIS_HIP_EINVAL, "factor_rounding = 1: every component of the plan must run on a cooperative solver or on the "
+                                            "LDS-resident batch solver (bundle adjustment; no streaming, tiny-component or plain launches)");
+    }
     PlanView V = L->view();
     HIPCHK(c, hipEventRecord(p->ev0, c->stream));
     // The batched launch is independent of the cooperative ones (disjoint components): it goes to a
@@ -2282,10 +2326,18 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     }
     for (size_t l = 0; l < L->coop_launches.size(); ++l) {
         const CoopLaunch& cl = L->coop_launches[l];
-        int rc = L->pipelined()
-                     ? launch_pipe(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+        const ProblemView PVc = p->view();
+        int rc;
+        if (L->coop_reference_rounding())
+            rc = L->pipelined()
+                     ? refround_launch_pipe(c->stream, p->kind, &PVc, &V, &L->h_coop_groups[l][0], cl.groups.p, cl.wg_group.as<int>(), cl.count, cl.total_wg, maxiters, ftol)
+                     : refround_launch_coop(c->stream, p->kind, &PVc, &V, &L->h_coop_groups[l][0], cl.groups.p, cl.wg_group.as<int>(), cl.count, cl.total_wg,
+                                            L->coop_threads, maxiters, ftol);
+        else
+            rc = L->pipelined()
+                     ? launch_pipe(c->stream, p->kind, PVc, V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
                                    cl.count, cl.total_wg, maxiters, ftol)
-                     : launch_coop(c->stream, p->kind, p->view(), V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
+                     : launch_coop(c->stream, p->kind, PVc, V, L->h_coop_groups[l][0], cl.groups.as<CoopGroup>(), cl.wg_group.as<int>(),
                                    cl.count, cl.total_wg, L->coop_threads, maxiters, ftol);
         if (rc != 0) return fail(c, RDIS_HIP_EDEVICE, std::string("cooperative solver launch: ") + hipGetErrorString((hipError_t)rc));
         ++L->last_launches;

@@ -220,7 +220,15 @@ struct LdsEnv {
                 for (int k = 0; k < 9; ++k) d[k] = (ROT == ROT_CAMFIX) ? 0.0 : XI[cb + k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) d[9 + k] = XI[pb + k];
+#ifdef RDIS_BISECT_ADJOINT_SLOPE   // (measurement build: the slope as the factor's twelve partials times the direction, like Df1dim::df)
+                double gq[12], acc = 0.0;
+                ba_adjoint(t, v, t.res0, t.res1, gq);
+#pragma unroll
+                for (int k = (ROT == ROT_CAMFIX ? 9 : 0); k < 12; ++k) acc += gq[k] * d[k];
+                as += acc;
+#else
                 as += ba_slope_dir<ROT == ROT_CAMFIX>(t, v, d);
+#endif
             }
         }
     }
@@ -256,11 +264,67 @@ struct LdsEnv {
         eval_sum<false>(f, s);
         return f;
     }
+#ifdef RDIS_REFERENCE_SLOPE
+    // The slope of a trial the way the reference forms it (Df1dim::df, minimize_nrc.h:439-447, over SubfunctionFD::df,
+    // CGDSubspaceOptimizer.cpp:135-157): the GRADIENT at the trial point -- every variable's partials added in factor-list order
+    // (src/State.h:157-210) -- and then gradient times direction, variable by variable in list order, every product rounded
+    // before it is added.  The solvers' own form adds factor by factor (sum_f sum_k partial_fk xi_k: no scatter, no gradient
+    // per trial).  The two differ in the last place only -- and that decides a population: on ladybug 5 / 30 Dbrent takes secant
+    // steps between trial points 1e-17 apart, where the difference of two slopes cancels ten digits, and the association of the
+    // sum moves every such step the same way (found with the oracle's switch ro_set_experiment(2)).
+    // Compiled into the reference-rounding instantiation only (refround_kernels.hip); costs a full gradient per trial.
+    __device__ double slope_reference() {
+#pragma clang fp contract(off)
+        for (int j = tid; j < m; j += nt) {
+            double v[12], gq[12];
+            BaFwd t;
+            int cb, pb;
+            forward(fidx[j], fobs[j], v, t, cb, pb);
+            ba_adjoint(t, v, t.res0, t.res1, gq);
+            const int* sp = L.slot_pos + L.slot_base[c0 + j];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int u = sp[k]; if (u >= 0) L.gfac[u] = gq[k]; }
+        }
+        __syncthreads();
+        double* GT = L.ws + 5ll * f0;   // [n] by free index (the workspace's first vector: this solver keeps p in LDS)
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const int b = vptr[fi], e = vptr[fi + 1];
+            GT[fi] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
+        }
+        __syncthreads();
+        if (tid == 0) {   // (slots in order = variable ids ascending = the order of `vars`)
+            double acc = 0.0;
+            for (int s = 0; s < ns; ++s) {
+                const int fi = SF[s];
+                if (fi < 0) continue;
+                const double t = GT[fi] * XI[s];
+                acc = acc + t;
+            }
+            red[parity][0][0] = acc;
+        }
+        __syncthreads();
+        const double r = red[parity][0][0];
+        parity ^= 1;
+        __syncthreads();
+        return r;
+    }
+#endif
     __device__ void eval_value_slope(double a, double& f, double& s) {
         const long long t0 = clock();
         assign_line(a);
         const long long t1 = clock();
         double af = 0.0, as = 0.0, dummy = 0.0;
+#ifdef RDIS_REFERENCE_SLOPE
+        if constexpr (!STALE) {
+            eval_partial<false>(af, as);
+            sumk<1>(af, as, dummy);
+            f = af;
+            s = slope_reference();
+            return;
+        }
+#endif
         eval_partial<true>(af, as);
         const long long t2 = clock();
         sumk<2>(af, as, dummy);

@@ -13,7 +13,7 @@ static uint64_t st = 0x9E3779B97F4A7C15ull;
 static double U() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; }
 
 int main() {
-    double worst_f = 0.0, worst_s = 0.0;
+    double worst_f = 0.0, worst_s = 0.0, worst_g = 0.0;
     for (int it = 0; it < 200000; ++it) {
         double x[12], d[12];
         const bool zero_rot = it % 1000 == 999;
@@ -66,6 +66,29 @@ int main() {
             }
             for (int k = 0; k < CAM_TRIAL; ++k) { TRprev[k] = TR[k]; DRprev[k] = DR[k]; }
         }
+        // the gradient in matrix form (ba_trial_adjoint + the rotation chain once per camera) against the adjoint sweep
+        {
+            double g[12], gq[3], gc[CAM_GRAD], gr[3];
+            ba_adjoint(t, x, t.res0, t.res1, g);
+            ba_trial_adjoint(bt, TR, q, gq, gc);
+            const double M[9] = {gc[0], gc[1], gc[2], gc[3], gc[4], gc[5], gc[6], gc[7], gc[8]};
+            ba_rotation_gradient(rot, M, gr);
+            const double m12[12] = {gr[0], gr[1], gr[2], gc[9], gc[10], gc[11], gc[12], gc[13], gc[14], gq[0], gq[1], gq[2]};
+            // (measured like the device's partials against the oracle's: against the row's largest entry -- the point's entries
+            // are sums of products that cancel -- and the three rotation entries, sums of nine such products, against those)
+            double rs = 0.0, rowmax = 1e-300;
+            for (int k = 0; k < 9; ++k) rs = std::fmax(rs, std::fabs(M[k]));
+            for (int k = 0; k < 12; ++k) rowmax = std::fmax(rowmax, std::fabs(g[k]));
+            for (int k = 0; k < 12; ++k) {
+                const double sc = k < 3 ? std::fmax(rowmax, rs) : rowmax;
+                const double dg = std::fabs(m12[k] - g[k]) / sc;
+                if (dg > worst_g) worst_g = dg;
+                if (!(dg <= 1e-12)) {
+                    std::printf("case %d: partial %d  %.17g (matrix form) vs %.17g (adjoint), rel %.3g, theta %.3g\n", it, k, m12[k], g[k], dg, th);
+                    return 1;
+                }
+            }
+        }
         const double df = std::fabs(f1 - f0) / std::fmax(std::fabs(f0), 1e-300);
         // the slope is a sum of terms that cancel: measured against the size of its terms (|res| times the pixel speed)
         double dn = 0.0;
@@ -79,6 +102,6 @@ int main() {
             return 1;
         }
     }
-    std::printf("matrix form against vector form over 200000 cases: worst relative deviation of the value %.3g, of the slope %.3g\n", worst_f, worst_s);
+    std::printf("matrix form against vector form over 200000 cases: worst relative deviation of the value %.3g, of the slope %.3g, of a partial %.3g\n", worst_f, worst_s, worst_g);
     return 0;
 }

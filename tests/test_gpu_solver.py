@@ -198,10 +198,12 @@ def oracle_end_values(pp, starts, maxiters, threads=8):
         return np.array(list(ex.map(run, starts)))
 
 
-def device_end_values(gctx, pp, starts, maxiters):
+def device_end_values(gctx, pp, starts, maxiters, opts=None):
     g = capi.Problem(gctx, pp)
     fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
     plan = capi.Plan(g, np.array([0, len(fv)]), fv, np.array([0, len(fc)]), fc)
+    for k, v in (opts or {}).items():
+        plan.set_option(k, v)
     out = []
     for x in starts:
         plan.set_start(x)
@@ -232,30 +234,33 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     """BASELINE configs 3 and 4.  25 unconverged CG iterations are a chaotic map of the start (a one-ulp
     change of x0 moves the end value by percents, for the reference itself too), so the end value of ONE
     run cannot be compared to 1e-6 between implementations that round differently.  What can: the
-    DISTRIBUTION of end values over one-ulp-perturbed starts -- with one qualification the round-3 review
-    asked to be settled (n >= 256, alpha = 0.05): that distribution is a property of the evaluator's
-    ROUNDING, not of the algorithm alone.  The committed fixture (tests/golden/end_values.json,
+    DISTRIBUTION of end values over one-ulp-perturbed starts -- and that distribution is a property of the
+    evaluator's ROUNDING, not of the algorithm alone.  The committed fixture (tests/golden/end_values.json,
     tests/golden/make_end_values.py) holds two samples of the reference-faithful oracle over the same 320 / 512
     starts: compiled like the reference (no fused multiply-add: its unperturbed entry IS the reference's
-    recorded end value) and compiled with contraction -- the same algorithm, the same sums, an equally valid
-    rounding.  On full ladybug the two part with KS 0.21 (p = 1e-5): quartiles 85924 / 87978 / 89600 against
-    85301 / 87960 / 88995.  (Not the cause, measured the same way: the order of the objective's sum -- end values
-    equal to 1e-15 --, the stale-cache rule, the derivative formula: p = 0.9 / 0.2.)  The device contracts its
-    factor arithmetic too (factors.hpp), in its own pattern, and draws a third distribution: median 89130 on the
-    cooperative solver; built with -DRDIS_FACTORS_NO_CONTRACT the same solver draws median 87820 against the oracle's
-    87978 (profiles/r04_a_population_by_solver*.txt).
-    On ladybug 5/30 contraction moves nothing (oracle against contracted oracle: KS 0.05, p = 0.6; nor do the stale-cache
-    rule, the derivative formula, the order of the sum or reciprocals in place of the projection's divisions, each tried
-    in the oracle: p > 0.3), yet the device's sample sits 0.1 % higher (quartiles 25.156 / 25.222 / 25.427 against 25.113 /
-    25.196 / 25.409: KS 0.15 at n = 512, with and without contraction) -- the sum of the device's roundings, not traced to
-    one of them; recorded as measured, bounded below.
-    Asserted, with as many device draws as the fixture has oracle draws, from OTHER one-ulp starts:
-      * KS(device, nearer oracle sample) <= KS(oracle, oracle contracted) + the alpha = 0.05 critical value + 0.07 (what
-        the device's own roundings were measured to add: 0.15 on 5/30 where the oracle's two are 0.05 apart);
-      * locations: each quartile of the device's sample within 1.5 % of the oracle's, and the device's median between the
-        25 % and 75 % quantiles of BOTH oracle samples;
-      * the reference's recorded value lies inside the device's range, and the device's sample is spread (chaos on
-        the device's side too)."""
+    recorded end value) and compiled with contraction -- the same algorithm, an equally valid rounding.  On full
+    ladybug the two part with KS 0.21 (p = 1e-5).  Two things move the device's population, both found by
+    changing one thing at a time (round 4: in the oracle; round 5: on the device, profiles/r05_*_population*.txt):
+      * fused multiply-adds in the factor arithmetic (full ladybug: device median 89130 with them, 87820 without,
+        oracle 87978);
+      * the ASSOCIATION of a trial's slope (ladybug 5 / 30): the solvers add factor by factor, sum_f (sum_k partial_fk
+        xi_k), the reference forms the gradient and then gradient times direction, sum_v (sum_f partial_fv) xi_v
+        (Df1dim::df).  Last-place differences -- but Dbrent takes secant steps between trial points 1e-17 apart, the
+        difference of the two slopes cancels ten digits, and the association moves every such step the same way: the
+        first line minimisation ends 6e-9 lower on 88 % of the starts, and after 25 iterations the lower quartile
+        sits 0.17 % higher (KS 0.15 at n = 512).  The ORACLE with the device's association (ro_set_experiment(2))
+        draws the device's population (quartiles 25.152 / 25.219 / 25.412 against the device's 25.156 / 25.222 / 25.427);
+        sincos, reciprocals, forward-mode slope, contraction: none of them does (KS 0.14 .. 0.16 each).
+    Plan option factor_rounding = 1 runs the solvers these configs reach with the reference's rounding AND its slope
+    association (refround_api.hpp).  Asserted for it, with as many device draws as the fixture has oracle draws,
+    from OTHER one-ulp starts, at alpha = 0.05:
+      * KS(device, oracle) <= KS(oracle, oracle contracted) + the critical value -- no allowance (measured: 0.045 on
+        5 / 30, p = 0.7; 0.125 on full ladybug, where the cooperative solvers keep their own association);
+      * every quartile within 1.5 % of the oracle's, the median between the 25 % and 75 % quantiles of both oracle samples,
+        the reference's recorded value inside the device's range, the sample spread (chaos on the device's side too).
+    The default arithmetic (fused multiply-adds and the factor-by-factor slope in the batch solvers; the cooperative
+    solvers round like the reference by default) is a different population by the causes named above: asserted for
+    it are the locations and the looser bound that covers the 0.15 measured on 5 / 30."""
     c = golden["cgd"][key]
     fx = _end_value_fixture()
     oe, oc = np.array(fx[key]["end_values"]), np.array(fx[key]["end_values_contracted"])
@@ -263,21 +268,25 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     pp = P.load_bal(ncams=c["ncams"], npts=c["npts"])
     n = len(oe)
     dstarts = [ulp_perturbed(pp.x0, np.random.default_rng([fx["seed"], 100000 + k])) for k in range(n)]
-    de = device_end_values(gctx, pp, dstarts, c["maxiters"])
-    (d_o, crit), (d_c, _), (d_self, _) = _ks2(de, oe), _ks2(de, oc), _ks2(oc, oe)
     q = lambda v: np.quantile(v, [0.25, 0.5, 0.75])
     from scipy import stats
-    print("%s end values after %d iterations (n = %d each): oracle quartiles %s, oracle contracted %s, device %s; KS device-oracle %.3f, "
-          "device-contracted %.3f, oracle-contracted %.3f (critical at 0.05: %.3f); Mann-Whitney p device-oracle %.3f, device-contracted %.3f; "
-          "reference %.6g, device range [%.6g, %.6g]" % (key, c["maxiters"], n, q(oe), q(oc), q(de), d_o, d_c, d_self, crit,
-                                                         stats.mannwhitneyu(de, oe).pvalue, stats.mannwhitneyu(de, oc).pvalue,
-                                                         c["fret"], de.min(), de.max()))
-    assert de.max() - de.min() > 1e-4 * de.min()                  # chaos on the device's side too
-    assert min(d_o, d_c) <= d_self + crit + 0.07, (d_o, d_c, d_self, crit)
-    assert np.all(np.abs(q(de) - q(oe)) <= 0.015 * q(oe)), (q(de), q(oe))
-    lo, hi = min(q(oe)[0], q(oc)[0]), max(q(oe)[2], q(oc)[2])
-    assert lo <= q(de)[1] <= hi, (q(oe), q(oc), q(de))
-    assert de.min() <= c["fret"] <= de.max(), (c["fret"], de.min(), de.max())
+    (d_self, crit) = _ks2(oc, oe)
+    for name, opts, slack in (("reference rounding", {"factor_rounding": 1}, 0.0), ("default", {}, 0.07)):
+        de = device_end_values(gctx, pp, dstarts, c["maxiters"], opts)
+        (d_o, _), (d_c, _) = _ks2(de, oe), _ks2(de, oc)
+        print("%s, %s: end values after %d iterations (n = %d each): oracle quartiles %s, oracle contracted %s, device %s; KS device-oracle %.3f, "
+              "device-contracted %.3f, oracle-contracted %.3f (critical at 0.05: %.3f); Mann-Whitney p device-oracle %.3f; "
+              "reference %.6g, device range [%.6g, %.6g]" % (key, name, c["maxiters"], n, q(oe), q(oc), q(de), d_o, d_c, d_self, crit,
+                                                             stats.mannwhitneyu(de, oe).pvalue, c["fret"], de.min(), de.max()))
+        assert de.max() - de.min() > 1e-4 * de.min()                  # chaos on the device's side too
+        if slack == 0.0:
+            assert d_o <= d_self + crit, (name, d_o, d_self, crit)    # against the reference-faithful oracle itself, no allowance
+        else:
+            assert min(d_o, d_c) <= d_self + crit + slack, (name, d_o, d_c, d_self, crit)
+        assert np.all(np.abs(q(de) - q(oe)) <= 0.015 * q(oe)), (name, q(de), q(oe))
+        lo, hi = min(q(oe)[0], q(oc)[0]), max(q(oe)[2], q(oc)[2])
+        assert lo <= q(de)[1] <= hi, (name, q(oe), q(oc), q(de))
+        assert de.min() <= c["fret"] <= de.max(), (name, c["fret"], de.min(), de.max())
 
 
 def test_prefix_values_part_from_the_oracle_at_the_rate_of_chaos(gctx):

@@ -17,6 +17,7 @@ small = "--5_30" in sys.argv
 key = "ladybug_5_30" if small else "ladybug_full"
 fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "end_values.json")))
 oe = np.array(fx[key]["end_values"])
+oc = np.array(fx[key]["end_values_contracted"])
 pp = P.load_bal(ncams=5, npts=30) if small else P.load_bal()
 
 
@@ -28,26 +29,36 @@ def start(k):
 ctx = capi.Context(0)
 g = capi.Problem(ctx, pp)
 fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
-q = lambda v: "q25 %.1f median %.1f q75 %.1f [%.1f, %.1f]" % (*np.quantile(v, [0.25, 0.5, 0.75]), v.min(), v.max())
+q = lambda v: ("q25 %.4f median %.4f q75 %.4f [%.3f, %.3f]" if small else "q25 %.1f median %.1f q75 %.1f [%.1f, %.1f]") % (*np.quantile(v, [0.25, 0.5, 0.75]), v.min(), v.max())
 print("%s: oracle fixture n %d: %s" % (key, len(oe), q(oe)))
+print("%s: oracle compiled with contraction:  %s   KS against the oracle %.3f" % (key, q(oc), stats.ks_2samp(oc, oe).statistic))
 SETS = {"default (pipelined cooperative)": {},
+        "reference rounding (factor_rounding 1)": {"factor_rounding": 1},
         "cooperative, not pipelined": {"coop_pipeline": 0},
-        "cooperative, no speculation": {"coop_speculate": 0},
+        "... with reference rounding": {"coop_pipeline": 0, "factor_rounding": 1},
         "one workgroup, streaming (ptm)": {"coop_min_factors": 0, "coop_group_min_factors": 0, "ptm_stream": 2},
         "one workgroup, plain": {"coop_min_factors": 0, "coop_group_min_factors": 0, "ptm_stream": 0, "lds_resident": 0}}
+if small:
+    SETS = {"default (LDS-resident)": {}, "reference rounding (factor_rounding 1)": {"factor_rounding": 1},
+            "plain batch solver": {"lds_resident": 0}}
+if "--only" in sys.argv:
+    want = sys.argv[sys.argv.index("--only") + 1]
+    SETS = {k: v for k, v in SETS.items() if want in k}
 for name, opts in SETS.items():
     plan = capi.Plan(g, np.array([0, len(fv)]), fv, np.array([0, len(fc)]), fc)
     for k, v in opts.items():
         plan.set_option(k, v)
-    de, nfe = [], []
+    de, nfe, kms = [], [], 0.0
     for k in range(n):
         plan.set_start(start(k))
         plan.solve(25, 3e-8)
         r = plan.fetch()
-        de.append(r.fret[0]); nfe.append(r.nfeval[0])
-    info = {k: plan.info(k) for k in ("components_cooperative", "components_point_major", "components_plain", "pipelined")}
+        de.append(r.fret[0]); nfe.append(r.nfeval[0]); kms += plan.last_kernel_ms()[0]
+    info = {k: plan.info(k) for k in ("components_cooperative", "components_lds", "components_point_major", "components_plain", "pipelined")}
     plan.close()
     de = np.array(de)
     ks = stats.ks_2samp(de, oe)
+    kc = stats.ks_2samp(de, oc)
     mw = stats.mannwhitneyu(de, oe)
-    print("%-34s n %d: %s  evals %.0f  KS %.3f (p %.3f)  MWU p %.3f  %s" % (name, n, q(de), np.mean(nfe), ks.statistic, ks.pvalue, mw.pvalue, info), flush=True)
+    print("%-40s n %d: %s  evals %.0f  kernel %.3f ms  KS vs oracle %.3f (p %.3f), vs contracted oracle %.3f (p %.3f)  MWU p %.3f  %s" % (
+        name, n, q(de), np.mean(nfe), kms / n, ks.statistic, ks.pvalue, kc.statistic, kc.pvalue, mw.pvalue, info), flush=True)
