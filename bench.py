@@ -272,13 +272,21 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
     def ulp(x, k):
         rng = np.random.default_rng([fx["seed"], 200000 + k])
         return np.nextafter(x, np.where(rng.random(x.shape) < 0.5, -np.inf, np.inf))
-    de = []
-    for k in range(k_dev):
-        plan.set_start((pp.x0 if k == 0 else ulp(pp.x0, k))[pp.comp_free_vid])
-        plan.solve(maxiters, 3e-8)
-        de.append(float(plan.fetch().fret.sum()))
+    def draw(opts):
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        out, kms = [], 0.0
+        for k in range(k_dev):
+            plan.set_start((pp.x0 if k == 0 else ulp(pp.x0, k))[pp.comp_free_vid])
+            plan.solve(maxiters, 3e-8)
+            out.append(float(plan.fetch().fret.sum()))
+            kms += plan.last_kernel_ms()[0]
+        return np.array(out), kms / k_dev
+    # the default (the cooperative solvers round like the reference's build) and the same solver with fused multiply-adds
+    de, ms_ref = draw({"factor_rounding": -1})
+    df, ms_fma = draw({"factor_rounding": 0})
+    plan.set_option("factor_rounding", -1)
     plan.set_start(pp.x0[pp.comp_free_vid])
-    de = np.array(de)
 
     def ks(a, b):
         a, b = np.sort(a), np.sort(b)
@@ -287,7 +295,11 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
     q = lambda v: {"n": int(len(v)), "min": float(v.min()), "q25": float(np.quantile(v, 0.25)), "median": float(np.median(v)),
                    "q75": float(np.quantile(v, 0.75)), "max": float(v.max())}
     out = {"what": "final objective over starts moved by one unit in the last place (first entry: the unperturbed start)",
-           "device": q(de), "oracle_fixture": dict(q(oe), unperturbed=float(oe[0]), file="tests/golden/end_values.json"),
+           "device": dict(q(de), rounding="products rounded before they are added, like the reference's build (plan option factor_rounding: the default "
+                                          "of the cooperative solvers)", kernel_ms=ms_ref),
+           "device_fused_multiply_add": dict(q(df), rounding="factor_rounding = 0", kernel_ms=ms_fma, ks_vs_oracle=ks(df, oe),
+                                             ks_vs_oracle_contracted=ks(df, oc) if len(oc) else None),
+           "oracle_fixture": dict(q(oe), unperturbed=float(oe[0]), file="tests/golden/end_values.json"),
            "ks_device_vs_oracle": ks(de, oe),
            "ks_critical_alpha_0.05": float(1.358 * np.sqrt((len(de) + len(oe)) / (len(de) * len(oe)))),
            "reference_recorded": 83227.604227756252}

@@ -255,6 +255,9 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * slots are the free variables), "lds_threads" / "lds_rot" / "lds_camera_sums" (its workgroup size,
  * 0 = auto; rotation records in it, -1 = auto; 0 = camera partials through memory like the plain
  * solver, for bit-for-bit comparisons),
+ * "lds_matrix" (default 0; 1 = the LDS-resident solver's line-search trials in matrix form, a camera's rotation matrix and its
+ * derivative along the direction formed once per camera and trial point -- what the point-major streaming solver does; measured
+ * slower here, where a component has a few hundred factors per camera: the records are one lane's chain in front of every trial),
  * "ptm_stream" (default 1: components too large for the LDS whose CAMERA blocks fit it stream their
  * point blocks from HBM once per trial point, solver_ptm.hpp; 0 = never, 2 = every component whose
  * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups

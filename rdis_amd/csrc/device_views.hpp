@@ -73,6 +73,9 @@ struct PlanView {
     const int* ls_ncb;    // [ncomp] camera blocks of the component
     const double2* ls_obs;    // [nfac_total] observation of every listed factor (copy in listed order: no indirection in the trial loop)
     int ls_cam_gfac;          // option lds_camera_sums = 0: camera partials through gfac[] like solver_wg.hpp (bit-for-bit comparisons)
+    int ls_matrix;            // 1: line-search trials in matrix form (factors.hpp: ba_camera_trial / ba_trial_value / ba_trial_slope) -- a camera's
+                              // rotation matrix and its derivative along the direction once per camera and trial, 16 + 16 doubles in LDS behind
+                              // the solver's other arrays; 0: the vector form per factor (the bits of solver_wg.hpp)
     const int* ls_gptr;       // [ncomp + 1] wave-chunks (64 entries) of ls_gperm, per component
     const int* ls_gperm;      // per component: local indices of its listed factors grouped by camera block (listed order inside a
                           // group), every group padded to whole chunks with -1

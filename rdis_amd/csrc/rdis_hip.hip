@@ -268,6 +268,17 @@ struct rdis_hip_plan {
     int lds_rot = -1;                 // option "lds_rot": rotation records in that solver, -1 = auto, 0 = per factor, 1 = records
     int lds_threads = 0;              // option "lds_threads": its workgroup size, 0 = auto
     int lds_camera_sums = 1;          // option "lds_camera_sums": 0 = camera partials through gfac[] like the plain batch solver
+    int lds_matrix = 0;               // option "lds_matrix": 1 = line-search trials in matrix form where the cameras' trial records fit the LDS too (solver_lds.hpp);
+                                      // measured slower there (a camera's records are a lone lane's chain in front of every trial: 1000 x 2048 factors 16.6 against 10.7 ms)
+    // the dynamic LDS of the LDS-resident launch, and whether its trials run in matrix form (the records must fit behind the other arrays)
+    bool lds_matrix_on(const rdis_hip_ctx* c) const {
+        return lds_matrix != 0 && !emulate_stale && factor_rounding != 1 &&
+               lds_matrix_offset(lds_bytes_for(lds_ns_cap, lds_ncb_cap, lds_chunk_cap)) + lds_matrix_bytes(lds_ncb_cap) <= c->lds_limit;
+    }
+    size_t lds_dyn_bytes(const rdis_hip_ctx* c) const {
+        const size_t base = lds_bytes_for(lds_ns_cap, lds_ncb_cap, lds_chunk_cap);
+        return lds_matrix_on(c) ? lds_matrix_offset(base) + lds_matrix_bytes(lds_ncb_cap) : base;
+    }
     int emulate_stale = 0;            // option "emulate_stale_cache": the reference's factor cache, emulated (solver_lds.hpp; that solver only)
     int factor_rounding = -1;         // option "factor_rounding": -1 = auto (the cooperative solvers round like the reference's build -- it costs them 4 % --, the batch
                                       // solvers use fused multiply-adds), 0 = fused multiply-adds everywhere, 1 = the reference's rounding (and, in the LDS-resident
@@ -317,6 +328,7 @@ struct rdis_hip_plan {
         v.ls_obs = lds_obs.as<double2>();
         v.ls_gperm = li + off_ls_gperm; v.ls_gptr = li + off_ls_gptr;
         v.ls_cam_gfac = lds_camera_sums ? 0 : 1;
+        v.ls_matrix = lds_matrix_on(prob->ctx) ? 1 : 0;
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
         v.pm_rec = pm_rec.as<double>(); v.pm_gh = pm_gh.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
@@ -1405,6 +1417,9 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         L->factor_rounding = (int)value;
     } else if (n == "lds_camera_sums") {
         L->lds_camera_sums = value != 0;
+    } else if (n == "lds_matrix") {
+        L->lds_matrix = value != 0;
+        return 0;   // (no table depends on it)
     } else if (n == "lds_rot") {
         if (value < -1 || value > 1) return fail(c, RDIS_HIP_EINVAL, "lds_rot must be -1, 0 or 1");
         L->lds_rot = (int)value;
@@ -1995,7 +2010,7 @@ int launch_lds_rot(rdis_hip_plan* L, hipStream_t stream, int threads, int first,
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    const size_t dyn = lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap);
+    const size_t dyn = L->lds_dyn_bytes(c);
     const int nsc = L->lds_ns_cap, ncc = L->lds_ncb_cap, chc = L->lds_chunk_cap;
 #define RDIS_LDS_LAUNCH(T)                                                                                              \
     do {                                                                                                                \

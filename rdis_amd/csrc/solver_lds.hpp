@@ -35,6 +35,11 @@ namespace rdis_hip {
 
 constexpr int LDS_MAX_BYTES = 160 * 1024 - 4096;   // dynamic LDS a launch may ask for (static: machine, requests, reduction slots)
 constexpr int LDS_DOUBLES_PER_SLOT = 5;            // Pv, XI, LO, HI, X
+// Trials in matrix form (round 5; PlanView::ls_matrix): per camera block two records of factors.hpp's CAM_TRIAL = 16 doubles at a
+// stride of 18 (an odd number of 16-byte units: lanes that read different cameras stand on different banks), behind the other arrays
+constexpr int LDS_TS = 18;
+__host__ __device__ inline size_t lds_matrix_offset(size_t base_bytes) { return (base_bytes + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t lds_matrix_bytes(int ncb) { return (size_t)ncb * 2 * LDS_TS * sizeof(double); }
 __host__ __device__ inline size_t lds_bytes_for(int ns, int ncb, int nchunk) {
     // (per slot two ints: the local free index, and the assignment at which the slot last changed by 1e-12 or more --
     // the latter used by the stale-cache emulation only)
@@ -68,6 +73,7 @@ struct LdsEnv {
     const int* vptr;          // v2s_ptr + free offset
     const int* svid;          // variable id of a slot
     double *Pv, *XI, *LO, *HI, *X, *ROTR;   // LDS
+    double *CTR, *CDR;        // LDS [ncb][LDS_TS] each (ls_matrix): the cameras' trial records at the trial point at hand, and their derivative along the direction
     int* SF;                  // LDS: local free index of a slot, -1 = constant
     int* CHE;                 // LDS (STALE): the assignment that last moved the slot by 1e-12 or more
     int* fev;                 // (STALE) per listed factor: the assignment of its last value evaluation, -1 = never
@@ -128,19 +134,57 @@ struct LdsEnv {
         }
         X[s] = xn;
     }
+    // ... and in matrix form (ls_matrix): a camera block with a free variable gets its trial records at the trial point -- rotation
+    // matrix, translation, f, k1, k2, and with SLOPE their derivative along the direction (factors.hpp) --, one lane per camera,
+    // the workgroup's last lanes; a constant camera keeps what init_vectors gave it
+    template <bool SLOPE, class At>
+    __device__ void refresh_trial_records(At at) {
+        if constexpr (ROT == ROT_CAMFIX) return;
+        for (int c = nt - 1 - tid; c < ncb; c += nt) {
+            const int s0 = 9 * c;
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) any = any || SF[s0 + q] >= 0;
+            if (!any) continue;
+            double xc[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) xc[k] = SF[s0 + k] >= 0 ? at(s0 + k) : Pv[s0 + k];
+            BaFwd rot;
+            ba_rotation(xc[0], xc[1], xc[2], rot);
+            ba_camera_trial(rot, xc, CTR + LDS_TS * c);
+            if constexpr (SLOPE) {
+                double dc[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dc[k] = XI[s0 + k];   // (a constant's entry is zero)
+                ba_camera_trial_dir(rot, dc, CDR + LDS_TS * c);
+            }
+        }
+    }
+    // RECS: 0 = rotation records where the launch uses them (the vector form), 1 / 2 = trial records for a value / a value + slope trial
+    template <int RECS = 0>
     __device__ void assign_line(double a) {
 #pragma clang fp contract(off)
         if constexpr (STALE) ++epoch;
-        for (int s = tid; s < ns; s += nt) {
-            if (SF[s] < 0) continue;
-            const double t = a * XI[s];
-            set_x(s, clampd(Pv[s] + t, LO[s], HI[s]));
-        }
-        refresh_records([&](int s) {
+        auto at = [&](int s) {
 #pragma clang fp contract(off)
             const double t = a * XI[s];
             return clampd(Pv[s] + t, LO[s], HI[s]);
-        });
+        };
+        if constexpr (RECS == 0) {
+            for (int s = tid; s < ns; s += nt) {
+                if (SF[s] < 0) continue;
+                const double t = a * XI[s];
+                set_x(s, clampd(Pv[s] + t, LO[s], HI[s]));
+            }
+            refresh_records(at);
+        } else {   // (the cameras' own slots of X are not read by a trial in matrix form: point slots only)
+            for (int s = 9 * ncb + tid; s < ns; s += nt) {
+                if (SF[s] < 0) continue;
+                const double t = a * XI[s];
+                X[s] = clampd(Pv[s] + t, LO[s], HI[s]);
+            }
+            refresh_trial_records<RECS == 2>(at);
+        }
         __syncthreads();
     }
     __device__ void assign_p() {
@@ -232,6 +276,46 @@ struct LdsEnv {
             }
         }
     }
+    // ... in matrix form: the factor against its camera's trial records (88 fp64 operations for value and slope where the vector form
+    // takes 164; same model, another association of the same sums: values agree to 1e-13, slopes to 1e-11 of their terms,
+    // tests/cpp/factors_forms_test.hip; the replay against the oracle holds as for the vector form)
+    template <bool SLOPE>
+    __device__ __forceinline__ void eval_partial_matrix(double& af, double& as) {
+        int j = tid;
+        unsigned wn = 0u;
+        double2 on = make_double2(0.0, 0.0);
+        if (PREFETCH && j < m) { wn = fidx[j]; on = fobs[j]; }
+        for (; j < m; j += nt) {
+            unsigned w;
+            double2 o;
+            if constexpr (PREFETCH) {
+                w = wn; o = on;
+                if (j + nt < m) { wn = fidx[j + nt]; on = fobs[j + nt]; }
+            } else {
+                w = fidx[j]; o = fobs[j];
+            }
+            const int off = __mul24((int)(w & 0xFFFu), LDS_TS), pb = 9 * ncb + 3 * (int)(w >> 12);
+            double TR[CAM_TRIAL], DR[CAM_TRIAL];
+            const double2* tc = reinterpret_cast<const double2*>(CTR + off);
+#pragma unroll
+            for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = tc[k]; TR[2 * k] = v.x; TR[2 * k + 1] = v.y; }
+            const double x[3] = {X[pb], X[pb + 1], X[pb + 2]};
+            BaTrial t;
+            af += ba_trial_value(TR, x, o.x, o.y, t);
+            if constexpr (SLOPE) {
+                const double e[3] = {XI[pb], XI[pb + 1], XI[pb + 2]};
+                if constexpr (ROT != ROT_CAMFIX) {
+                    const double2* dc = reinterpret_cast<const double2*>(CDR + off);
+#pragma unroll
+                    for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CAM_TRIAL; ++k) DR[k] = 0.0;
+                }
+                as += ba_trial_slope<ROT == ROT_CAMFIX>(t, TR, DR, x, e);
+            }
+        }
+    }
     template <bool SLOPE>
     __device__ void eval_sum(double& f, double& s) {
         double af = 0.0, as = 0.0, dummy = 0.0;
@@ -258,7 +342,19 @@ struct LdsEnv {
     __device__ void tick(int, long long) {}
     __device__ long long clock() const { return 0; }
 #endif
+#ifdef RDIS_REFERENCE_SLOPE
+    __device__ bool matrix() const { return false; }
+#else
+    __device__ bool matrix() const { return !STALE && L.ls_matrix != 0; }
+#endif
     __device__ double eval_value(double a, bool restore) {
+        if (!restore && matrix()) {
+            assign_line<1>(a);
+            double af = 0.0, as = 0.0, dummy = 0.0;
+            eval_partial_matrix<false>(af, as);
+            sumk<1>(af, as, dummy);
+            return af;
+        }
         if (restore) assign_start(); else assign_line(a);
         double f, s;
         eval_sum<false>(f, s);
@@ -313,9 +409,21 @@ struct LdsEnv {
 #endif
     __device__ void eval_value_slope(double a, double& f, double& s) {
         const long long t0 = clock();
+        double af = 0.0, as = 0.0, dummy = 0.0;
+#ifndef RDIS_REFERENCE_SLOPE
+        if (matrix()) {
+            assign_line<2>(a);
+            const long long t1m = clock();
+            eval_partial_matrix<true>(af, as);
+            const long long t2m = clock();
+            sumk<2>(af, as, dummy);
+            f = af; s = as;
+            tick(0, t1m - t0); tick(1, t2m - t1m); tick(2, clock() - t2m); tick(3, 1);
+            return;
+        }
+#endif
         assign_line(a);
         const long long t1 = clock();
-        double af = 0.0, as = 0.0, dummy = 0.0;
 #ifdef RDIS_REFERENCE_SLOPE
         if constexpr (!STALE) {
             eval_partial<false>(af, as);
@@ -353,6 +461,19 @@ struct LdsEnv {
         __syncthreads();
         if constexpr (ROT != ROT_PER_FACTOR) {   // every camera block's record at the start (those of constant cameras stay)
             for (int c = tid; c < ncb; c += nt) store_rotation(X[9 * c], X[9 * c + 1], X[9 * c + 2], ROTR + 7 * c);
+            __syncthreads();
+        }
+        if (matrix()) {   // ... and its trial records (a constant camera's direction record is zero)
+            for (int c = tid; c < ncb; c += nt) {
+                double xc[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) xc[k] = X[9 * c + k];
+                BaFwd rot;
+                ba_rotation(xc[0], xc[1], xc[2], rot);
+                ba_camera_trial(rot, xc, CTR + LDS_TS * c);
+#pragma unroll
+                for (int k = 0; k < CAM_TRIAL; ++k) CDR[LDS_TS * c + k] = 0.0;
+            }
             __syncthreads();
         }
     }
@@ -539,13 +660,15 @@ cgd_lds_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ns_cap,
     int* CGC = (int*)(CG + 9 * chunk_cap);
     int* SF = CGC + chunk_cap;
     int* CHE = SF + ns_cap;
+    double* CTR = reinterpret_cast<double*>(reinterpret_cast<char*>(lds_dyn) + lds_matrix_offset(lds_bytes_for(ns_cap, ncb_cap, chunk_cap)));
+    double* CDR = CTR + LDS_TS * ncb_cap;   // (behind the launch's other arrays; allocated only when ls_matrix is set)
     for (int s = threadIdx.x; s < ns; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
     __syncthreads();
     double* ws = L.ws + 5ll * f0;
     LdsEnv<ROT, (THREADS <= 512), STALE> E{P, L, comp, n, m, f0, c0, (int)threadIdx.x, (int)blockDim.x, (int)(blockDim.x >> 6),
                   ns, ncb, L.ls_obs + c0, L.ls_fidx + c0, L.ls_gperm + 64ll * L.ls_gptr[comp], L.ls_gptr[comp + 1] - L.ls_gptr[comp], CG, CGC, L.v2s_ptr + f0, L.ls_vid + s0,
                   base, base + ns_cap, base + 2 * ns_cap, base + 3 * ns_cap, base + 4 * ns_cap, base + LDS_DOUBLES_PER_SLOT * ns_cap,
-                  SF, CHE, STALE ? L.st_ev + c0 : nullptr, STALE ? L.st_val + c0 : nullptr, 0, ws + 2ll * n, ws + 3ll * n,
+                  CTR, CDR, SF, CHE, STALE ? L.st_ev + c0 : nullptr, STALE ? L.st_val + c0 : nullptr, 0, ws + 2ll * n, ws + 3ll * n,
                   red, 0,
                   L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0
 #ifdef RDIS_COOP_TIMING

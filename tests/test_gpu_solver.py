@@ -1181,19 +1181,23 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
             ra, xa, _, _ = run({"lds_resident": 0, "ptm_stream": 0, "block_threads": threads, "camera_records": rot})
             # (lds_camera_sums 0: a camera variable's gradient entry summed as the plain solver sums it -- by default
             # the LDS solver sums camera partials across waves that share a camera, another grouping)
-            rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0, "lds_camera_sums": 0})
+            # (lds_matrix 0: trials in the vector form per factor, the plain solver's arithmetic -- by default the LDS solver's
+            # trials run in matrix form, another association of the same sums: replayed against the oracle below)
+            rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0, "lds_camera_sums": 0, "lds_matrix": 0})
             assert nb == 1
             assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (threads, rot)
             assert np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.status, rb.status), (threads, rot)
             assert np.array_equal(ra.nfeval, rb.nfeval) and np.array_equal(ra.ngeval, rb.ngeval), (threads, rot)
     assert np.all(ra.delta < 0)
-    # the default (camera partials summed across waves): same problem, replayed against the oracle
-    rc, xc, _, trc = run({"lds_resident": 1}, trace=4096)
-    assert np.all(rc.delta < 0) and abs(rc.fret.sum() - ra.fret.sum()) <= 0.05 * ra.fret.sum()
-    for c in (0, 17, 39):
-        fv, fc = syn.component(c)
-        sub = type("R", (), {"status": rc.status[c:c + 1], "iters": rc.iters[c:c + 1], "fret": rc.fret[c:c + 1]})
-        check_replay(syn, trc[c], sub, 25, free_vid=fv, fac_id=fc, x=syn.x0[fv])
+    # the default (camera partials summed across waves): same problem, replayed against the oracle; and with the trials in
+    # matrix form (option lds_matrix: another association of a factor's sums; built, correct, slower here -- not the default)
+    for extra in ({}, {"lds_matrix": 1}):
+        rc, xc, _, trc = run({"lds_resident": 1, **extra}, trace=4096)
+        assert np.all(rc.delta < 0) and abs(rc.fret.sum() - ra.fret.sum()) <= 0.05 * ra.fret.sum()
+        for c in (0, 17, 39):
+            fv, fc = syn.component(c)
+            sub = type("R", (), {"status": rc.status[c:c + 1], "iters": rc.iters[c:c + 1], "fret": rc.fret[c:c + 1]})
+            check_replay(syn, trc[c], sub, 25, free_vid=fv, fac_id=fc, x=syn.x0[fv])
     # constants among the slots
     lb = P.load_bal(ncams=49, npts=500)
     cams, pts = P.ba_alternation_plans(lb)

@@ -24,7 +24,7 @@ def run(g, csr, x0, opts, reps=3, iters=25):
 
 
 VARIANTS = [("plain wg", {"lds_resident": 0}),
-            ("lds auto", {}),
+            ("lds auto", {}), ("lds vector form", {"lds_matrix": 0}),
             ("lds rot0", {"lds_rot": 0}), ("lds rot1", {"lds_rot": 1}),
             ("lds 512 rot0", {"lds_threads": 512, "lds_rot": 0}), ("lds 512 rot1", {"lds_threads": 512, "lds_rot": 1}),
             ("lds 1024 rot0", {"lds_threads": 1024, "lds_rot": 0}), ("lds 1024 rot1", {"lds_threads": 1024, "lds_rot": 1}),
@@ -47,7 +47,7 @@ if "small" in which:
     g = capi.Problem(ctx, pp)
     csr = (pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id)
     ref = None
-    for name, o in [("plain wg", {"lds_resident": 0}), ("lds auto", {}), ("lds rot1", {"lds_rot": 1}), ("lds 64", {"lds_threads": 64}), ("lds 256", {"lds_threads": 256})]:
+    for name, o in [("plain wg", {"lds_resident": 0}), ("lds auto", {}), ("lds vector", {"lds_matrix": 0}), ("lds rot1", {"lds_rot": 1}), ("lds 64", {"lds_threads": 64}), ("lds 256", {"lds_threads": 256})]:
         ms, r, nl = run(g, csr, pp.x0[csr[1]], o)
         if ref is None: ref = r
         same = np.array_equal(ref.fret, r.fret) and np.array_equal(ref.x, r.x)
@@ -60,7 +60,7 @@ if "cams" in which or "points" in which:
     for label, csr, base in (("ladybug 49 camera comps", cams, {"coop_group_min_factors": 0, "coop_min_factors": 0}), ("ladybug 7776 point comps", pts, {"row_min_components": 1 << 30, "quad_min_components": 1 << 30})):
         if ("cams" in label and "cams" not in which) or ("point" in label and "points" not in which): continue
         ref = None
-        for name, o in [("plain wg", {"lds_resident": 0}), ("lds auto", {}), ("lds 1024", {"lds_threads": 1024}), ("lds 512", {"lds_threads": 512})]:
+        for name, o in [("plain wg", {"lds_resident": 0}), ("lds auto", {}), ("lds vector", {"lds_matrix": 0}), ("lds 1024", {"lds_threads": 1024}), ("lds 512", {"lds_threads": 512})]:
             g.set_x(pp.x0)
             ms, r, nl = run(g, csr, pp.x0[csr[1]], {**base, **o})
             if ref is None: ref = r
