@@ -199,8 +199,9 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
            # (1.4 MB streamed per component and trial point), HIP events around the solver kernel
            "roofline": {"bound": "hbm", "achieved": abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0) / HBM_PEAK_GBS,
-                        "traffic": measured_traffic("synthetic-L") if STRONG["npts"] == 7776 and world == 1 else None,
-                        "traffic_is": "per launch of 256 such components (bench.py --workload synthetic-L in the profile round), not of this launch",
+                        "traffic": measured_traffic("synthetic-L-1000") if STRONG["npts"] == 7776 and world == 1 else None,
+                        "traffic_is": "counter passes of this launch's own shape -- 1000 such components, bench.py --workload synthetic-L --components 1000 in the "
+                                      "profile round (profiles/traffic.json); not collected in this run",
                         "kernel": "cgd_ptm_kernel / cgd_ptmg_kernel (solver_ptm.hpp)", "kernel_ms_avg": kms / max(steps, 1),
                         "algorithmic_bytes_per_launch": abytes / max(steps, 1), "rank": 0}}
     plan.close()

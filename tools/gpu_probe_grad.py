@@ -7,6 +7,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from rdis_amd import problems as P, capi
+if os.environ.get("RDIS_PROBE_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["RDIS_PROBE_LIB"])
 
 ncomp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 REPS = 10

@@ -14,11 +14,22 @@ for w in ladybug-full synthetic-S synthetic-L; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/$w -o fetch -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/$w -o write -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -o strong -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_strong.json 2>> $D/err.txt
+# the strong-scaling block's own launch (1000 components of ladybug's size): counter passes of its own
+mkdir -p $D/synthetic-L-1000
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/synthetic-L-1000 -o fetch -- python bench.py --workload synthetic-L --components 1000 --steps 2 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/synthetic-L-1000 -o write -- python bench.py --workload synthetic-L --components 1000 --steps 2 --warmup 1 --no-cpu-baseline --no-strong-scaling > /dev/null 2>> $D/err.txt
+# the public gradient entry point in its streaming regime (8.0e6 factors): kernel trace and counter passes
+mkdir -p $D/eval-grad
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o grad -- python tools/gpu_probe_grad.py > $D/grad_probe.txt 2>> $D/err.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/eval-grad -o fetch -- python tools/gpu_probe_grad.py > /dev/null 2>> $D/err.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/eval-grad -o write -- python tools/gpu_probe_grad.py > /dev/null 2>> $D/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o strong -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-all-components > $D/bench_strong.json 2>> $D/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kernels -- python tools/profile_kernels.py > $D/kernels.txt 2>> $D/err.txt
 python tools/collect_traffic.py $D/ladybug-full ladybug-full cgd_pipe_
 python tools/collect_traffic.py $D/synthetic-S synthetic-S cgd_lds_kernel
 python tools/collect_traffic.py $D/synthetic-L synthetic-L cgd_ptm
+python tools/collect_traffic.py $D/synthetic-L-1000 synthetic-L-1000 cgd_ptm
+python tools/collect_traffic.py $D/eval-grad eval-grad grad_fused_kernel
 cp profiles/traffic.json $D/
 tail -1 $D/bench_ladybug_full.json
 head -3 $D/ladybug_kernel_stats.csv
