@@ -67,6 +67,7 @@ struct GradEntry {
     unsigned rc, rp;      // rows
     int2 cs, ps;          // this lane's camera / point segment of the chunk: {camera | destination, first row} ...
     int cs_end, ps_end;   // ... and the row behind it
+    int extra;            // (uniform) the chunk has more segments than lanes / 9 (/ 3): a list in no order; the further ones come from the tables
     double2 o;
     double x0, x1, x2;
 };
@@ -85,6 +86,7 @@ __device__ __forceinline__ void grad_stage1(const GradTables& T, int ch, int tid
     e.ps = T.pseg[ps0 + (hp ? sp : 0)]; e.ps_end = hp ? T.pseg[ps0 + sp + 1].y : 0;
     if (!hc) e.cs.y = 0;
     if (!hp) e.ps.y = 0;
+    e.extra = (cns * 9 > GRAD_CSEG_LANES || pns * 3 > GRAD_PSEG_LANES) ? 1 : 0;
 }
 __device__ __forceinline__ void grad_stage2(const double* __restrict__ x, const double2* __restrict__ obs, GradEntry& e) {
     if (e.cl != GRAD_NO_ENTRY) {
@@ -150,7 +152,7 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                 double* a = acc + cur.cs.x * 9 + kc;
                 *a = add_rows<9>(*a, crow, cur.cs.y, cur.cs_end, kc);
             }
-            {
+            if (cur.extra) {   // (else nothing here waits for global memory: the list bounds are not even looked at)
                 const int s0 = T.chunk_cseg0[ch], ns = T.chunk_cseg0[ch + 1] - s0 - 1;
                 for (int w = tid + GRAD_CSEG_LANES; w < ns * 9 && tid < GRAD_CSEG_LANES; w += GRAD_CSEG_LANES) {
                     const int sidx = w / 9;
@@ -165,7 +167,7 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                 const double sum = add_rows<3>(0.0, prow, cur.ps.y, cur.ps_end, kp);
                 if (cur.ps.x >= 0) g[cur.ps.x + kp] = sum; else pstage[(size_t)(~cur.ps.x) * 3 + kp] = sum;
             }
-            {
+            if (cur.extra) {
                 const int s0 = T.chunk_pseg0[ch], ns = T.chunk_pseg0[ch + 1] - s0 - 1;
                 for (int w = tid + GRAD_PSEG_LANES; w < ns * 3 && tid < GRAD_PSEG_LANES; w += GRAD_PSEG_LANES) {
                     const int sidx = w / 3;
