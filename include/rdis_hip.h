@@ -97,6 +97,11 @@ int rdis_hip_upload_nlp(rdis_hip_ctx *ctx, int64_t nvars, const double *x0, cons
                         const double *hi, int64_t nfac, const double *coeff,
                         const int64_t *rowptr, const int64_t *vid, const double *expo,
                         const double *cons, const uint8_t *sine, rdis_hip_problem **out);
+/* NonlinearProductFactor's useExponential (src/NonlinearProductFactor.h:62, 113): factor i with use_exp[i] != 0
+ * evaluates to coeff[i] * exp(-product) (src/NonlinearProductFactor.cpp:140, 204).  Values only: the reference's
+ * computeGradient asserts the flag off (.cpp:110), so eval_grad, plan_create and cgd_batch over a list that holds
+ * such a factor return RDIS_HIP_EINVAL.  use_exp == NULL or all zero: cleared (the state after upload_nlp). */
+int rdis_hip_nlp_set_exponential(rdis_hip_problem *p, const uint8_t *use_exp);
 void rdis_hip_free_problem(rdis_hip_problem *p);
 
 /* Variable::assign for already-assigned variables (src/Variable.cpp:66-88): the

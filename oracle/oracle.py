@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
         L.ro_create_nlp.restype = C.c_void_p
         L.ro_create_nlp.argtypes = [C.c_int64, _f64p, _f64p, _f64p, C.c_int64, _f64p, _i64p,
                                     _i64p, _f64p, _f64p, _u8p]
+        L.ro_nlp_set_exponential.restype = C.c_int
+        L.ro_nlp_set_exponential.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_destroy.argtypes = [C.c_void_p]
         L.ro_set_emulate_stale_cache.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_sum_order.argtypes = [C.c_void_p, C.c_int]
@@ -143,6 +145,12 @@ class OracleProblem:
         L.ro_set_emulate_stale_cache(self.h, int(emulate_stale_cache))
         L.ro_set_sum_order(self.h, {"list": 0, "pairwise": 1}[sum_order])   # (an experiment's switch; "list" is the reference's)
         self.set_derivative(derivative)
+
+    def set_exponential(self, use_exp) -> None:
+        """useExponential per factor (NonlinearProductFactor.cpp:140); values only, None clears"""
+        u = None if use_exp is None else np.ascontiguousarray(use_exp, dtype=np.uint8)
+        if lib().ro_nlp_set_exponential(self.h, None if u is None else u.ctypes.data_as(C.c_void_p)):
+            raise ValueError("not a nonlinear-product problem")
 
     def set_derivative(self, derivative: str) -> None:
         lib().ro_set_ba_derivative(self.h, {"refchain": 0, "adjoint": 1}[derivative])

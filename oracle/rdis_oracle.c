@@ -288,6 +288,7 @@ struct ro_problem {
     double *coeff, *expo, *cons;
     int64_t *rowptr, *vid;
     uint8_t *sine;
+    uint8_t *useexp;  /* NULL, or per factor: NonlinearProductFactor::useExponential */
     /* cached factor values + variable->factor adjacency (Factor.h:228-234,
      * Variable.cpp:66-88) */
     int emulate;
@@ -381,8 +382,20 @@ void ro_destroy(ro_problem *p)
     if (!p) return;
     free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
-    free(p->sine); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
+    free(p->sine); free(p->useexp); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
     free(p);
+}
+
+/* NonlinearProductFactor's constructor argument useExponential (src/NonlinearProductFactor.cpp:14-19), per
+ * factor.  Only values may then be asked for: the reference's computeGradient asserts the flag off (.cpp:110),
+ * and this restatement's derivative entry points return NaN for such a factor. */
+int ro_nlp_set_exponential(ro_problem *p, const uint8_t *use_exp)
+{
+    if (!p || p->kind != RO_KIND_NLP) return -1;
+    free(p->useexp);
+    p->useexp = use_exp ? dup_mem(use_exp, (size_t)p->nfac) : NULL;
+    if (p->fdirty) memset(p->fdirty, 1, (size_t)p->nfac);
+    return 0;
 }
 
 void ro_set_ba_derivative(ro_problem *p, int which)
@@ -444,8 +457,8 @@ static void gather_ba(const ro_problem *p, int64_t f, double vals[12])
     vals[9] = q[0]; vals[10] = q[1]; vals[11] = q[2];
 }
 
-/* NonlinearProductFactor::evalFactor (src/NonlinearProductFactor.cpp:186-209);
- * useExponential is never set on this path (.cpp:110 asserts it off). */
+/* NonlinearProductFactor::evalFactor (src/NonlinearProductFactor.cpp:186-209; the same arithmetic as
+ * evalFactorNoCache, :119-145), with useExponential (:140, :204) */
 static double nlp_eval(const ro_problem *p, int64_t f)
 {
     double prod = 1;
@@ -456,12 +469,14 @@ static double nlp_eval(const ro_problem *p, int64_t f)
         if (p->sine[k]) val = sin(val);
         prod *= val;
     }
+    if (p->useexp && p->useexp[f]) prod = exp(-prod);
     return prod * p->coeff[f];
 }
 
 /* NonlinearProductFactor::getDerivative (src/NonlinearProductFactor.cpp:149-178) */
 static double nlp_deriv(const ro_problem *p, int64_t f, int64_t wrt)
 {
+    if (p->useexp && p->useexp[f]) return NAN; /* the reference asserts here (.cpp:110) */
     double prod = 1;
     for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) {
         double val = p->x[p->vid[k]];

@@ -70,6 +70,9 @@ ro_problem *ro_create_nlp(int64_t nvars, const double *x0, const double *lo,
                           const int64_t *rowptr, const int64_t *vid,
                           const double *expo, const double *cons,
                           const uint8_t *sine);
+/* useExponential per factor (src/NonlinearProductFactor.h:62): value = coeff * exp(-product); values only
+ * (the reference's gradient asserts it off, src/NonlinearProductFactor.cpp:110).  NULL clears.  0 on success. */
+int ro_nlp_set_exponential(ro_problem *p, const uint8_t *use_exp);
 void ro_destroy(ro_problem *p);
 
 /* emulate Variable::assign's "|delta| < 1e-12 => factors not notified" rule

@@ -61,6 +61,7 @@ SYMBOLS = {
     "rdis_hip_copy_to_host": (C.c_int, [_vp, _vp, _vp, _i64]),
     "rdis_hip_upload_ba": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "rdis_hip_upload_nlp": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "rdis_hip_nlp_set_exponential": (C.c_int, [_vp, _vp]),
     "rdis_hip_free_problem": (None, [_vp]),
     "rdis_hip_set_x": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rdis_hip_get_x": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -271,6 +272,13 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    def set_exponential(self, use_exp):
+        """NonlinearProductFactor's useExponential per factor (values only; None clears)"""
+        u = None if use_exp is None else np.ascontiguousarray(use_exp, dtype=np.uint8)
+        if u is not None and u.shape[0] != self.nfac:
+            raise ValueError("one flag per factor")
+        self.ctx.check(self.ctx.lib.rdis_hip_nlp_set_exponential(self.h, _ptr(u)))
 
     def set_x(self, val, vid=None):
         val, vid = _f(val), _i(vid)

@@ -50,6 +50,7 @@ struct ProblemView {
     const double* expo;
     const double* cons;
     const uint8_t* sine;
+    const uint8_t* useexp;  // null, or per factor: value = coeff * exp(-product) (NonlinearProductFactor.cpp:140)
 };
 
 struct PlanView {

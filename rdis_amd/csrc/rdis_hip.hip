@@ -135,6 +135,8 @@ struct rdis_hip_problem {
     int kind = KIND_BA;
     int64_t N = 0, F = 0, nnz = 0;
     DevBuf x, lo, hi, cam, pt, obs, coeff, rowptr, vid, expo, cons, sine;
+    DevBuf useexp;                     // per factor: value = coeff * exp(-product) (rdis_hip_nlp_set_exponential)
+    std::vector<uint8_t> h_useexp;     // empty: no factor has it
     DevBuf cam_blocks, xrot;                        // distinct camera blocks; their rotation records (shadow of x)
     int64_t ncam_blocks = 0;
     ivec h_block_of;                    // [N] first variable id of the camera block a variable belongs to, -1 = none
@@ -177,6 +179,7 @@ struct rdis_hip_problem {
         v.xrot = nullptr; v.rot_mode = ROT_PER_FACTOR;
         v.coeff = coeff.as<double>(); v.rowptr = rowptr.as<int>(); v.vid = vid.as<int>();
         v.expo = expo.as<double>(); v.cons = cons.as<double>(); v.sine = sine.as<uint8_t>();
+        v.useexp = h_useexp.empty() ? nullptr : useexp.as<uint8_t>();
         return v;
     }
     int64_t nslots() const { return kind == KIND_BA ? 12 * F : nnz; }
@@ -536,6 +539,25 @@ extern "C" int rdis_hip_upload_nlp(rdis_hip_ctx* c, int64_t nvars, const double*
     return 0;
 }
 
+extern "C" int rdis_hip_nlp_set_exponential(rdis_hip_problem* p, const uint8_t* use_exp) {
+    if (!p) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = p->ctx;
+    if (p->kind != KIND_NLP) return fail(c, RDIS_HIP_EINVAL, "nlp_set_exponential: not a nonlinear-product problem");
+    USE_DEVICE(c);
+    bool any = false;
+    for (int64_t i = 0; use_exp && i < p->F; ++i) any |= use_exp[i] != 0;
+    if (!any) { p->h_useexp.clear(); return 0; }
+    // (a kernel of an earlier call may still read the old flags: the copy is ordered after it on the stream)
+    if (p->useexp.bytes < (size_t)p->F) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rc = dalloc(c, p->useexp, (size_t)p->F)) return rc;
+    }
+    p->h_useexp.assign(use_exp, use_exp + p->F);
+    HIPCHK(c, hipMemcpyAsync(p->useexp.p, p->h_useexp.data(), (size_t)p->F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" void rdis_hip_free_problem(rdis_hip_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
@@ -632,6 +654,19 @@ void build_v2s(const rdis_hip_problem* p, int64_t nf, const int64_t* fac, ivec& 
 int check_list(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
     if (nf < 0) return fail(p->ctx, RDIS_HIP_EINVAL, "negative factor count");
     if (!fac && nf != p->F) return fail(p->ctx, RDIS_HIP_EINVAL, "fac == NULL requires nf == factor count");
+    return 0;
+}
+
+// NonlinearProductFactor::computeGradient asserts its factor has no exponential (src/NonlinearProductFactor.cpp:110):
+// a gradient or a solve over a list that holds such a factor is refused, not computed from the plain product
+int refuse_exponential(rdis_hip_problem* p, int64_t nf, const int64_t* fac, const char* who) {
+    if (p->h_useexp.empty()) return 0;
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i;
+        if (f >= 0 && f < p->F && p->h_useexp[(size_t)f])
+            return fail(p->ctx, RDIS_HIP_EINVAL, std::string(who) + ": factor " + std::to_string(f) +
+                        " is exponential; the reference's gradient asserts it is not (NonlinearProductFactor.cpp:110)");
+    }
     return 0;
 }
 
@@ -936,6 +971,7 @@ int eval_grad_two_pass(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
 }
 
 int eval_grad_on_device(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    if (int rc = refuse_exponential(p, nf, fac, "eval_grad")) return rc;
     if (nf == 0) {
         rdis_hip_ctx* c = p->ctx;
         int rc = ensure(c, p->g_all, (size_t)p->N * sizeof(double));
@@ -1108,6 +1144,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
     if (free_ptr[0] != 0 || fac_ptr[0] != 0 || nfree < 0 || nfac < 0 || (nfree && !free_vid) || (nfac && !fac_id))
         return fail(c, RDIS_HIP_EINVAL, "plan_create: bad CSR");
     if (nfree >= (1ll << 31) / 5 || nfac >= ((1ll << 31) - 16) / 12) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
+    if (int rc = refuse_exponential(p, nfac, fac_id, "plan_create")) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_problem_scratch(p);
     if (rc) return rc;

@@ -209,6 +209,9 @@ __device__ __forceinline__ void factor_value(const ProblemView& P, const double*
         const int b = P.rowptr[fid], e = P.rowptr[fid + 1];
         double prod = 1.0;
         for (int k = b; k < e; ++k) prod *= nlp_term(P.x[P.vid[k]], P.expo[k], P.cons[k], P.sine[k] != 0);
+        // useExponential (NonlinearProductFactor.cpp:140, 204): values only -- the library refuses a gradient or a
+        // solve over such a factor (the reference's computeGradient asserts it off, :110)
+        if (!SLOPE && P.useexp && P.useexp[fid]) prod = exp(-prod);
         f = prod * P.coeff[fid];
         s = 0.0;
         if constexpr (SLOPE) {

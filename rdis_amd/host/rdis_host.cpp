@@ -163,6 +163,7 @@ const OptimizableFunction::Packed& OptimizableFunction::packed() const {
             const NonlinearProductFactor* nf = dynamic_cast<const NonlinearProductFactor*>(factors[i]);
             if (!nf) throw std::logic_error("packed: unsupported factor kind (no device descriptor)");
             P->coeff.push_back(nf->getCoeff());
+            if (nf->usesExponential()) { P->useexp.resize(F, 0); P->useexp[i] = 1; }
             for (size_t k = 0; k < nf->terms().size(); ++k) {
                 P->vid.push_back(nf->getVariables()[k]->getID());
                 P->expo.push_back(nf->terms()[k].exponent);
@@ -196,6 +197,7 @@ void OptimizableFunction::uploadTo(int device, rdis_hip_ctx*& ctx, rdis_hip_prob
                                  P.coeff.data(), P.rowptr.data(), P.vid.data(), P.expo.data(), P.cons.data(),
                                  P.sine.data(), &prob);
     check(ctx, rc, "upload");
+    if (P.kind != 0 && !P.useexp.empty()) check(ctx, rdis_hip_nlp_set_exponential(prob, P.useexp.data()), "nlp_set_exponential");
 }
 
 void OptimizableFunction::ensureUploaded() const {

@@ -144,14 +144,20 @@ private:
 class NonlinearProductFactor : public Factor {
 public:
     struct Term { Numeric exponent, constant; bool useSine; };
-    explicit NonlinearProductFactor(FactorID id, Numeric coefficient = 1) : Factor(id), coeff_(coefficient) {}
+    // (the reference's signature, src/NonlinearProductFactor.h:61-63; totalNVars only reserves)
+    explicit NonlinearProductFactor(FactorID id, Numeric coefficient = 1, bool useExponential = false, VariableCount totalNVars = 0)
+        : Factor(id), coeff_(coefficient), useExponential_(useExponential) { terms_.reserve((size_t)totalNVars); }
     // exponent 0 is dropped and a repeated variable ignored (src/NonlinearProductFactor.cpp:27-52)
     void addVariable(Variable* v, Numeric exponent = 1, Numeric constant = 0, bool useSine = false);
     void setCoeff(Numeric c) { coeff_ = c; }
     Numeric getCoeff() const { return coeff_; }
+    // value = coeff * exp(-product) (src/NonlinearProductFactor.cpp:140); such a factor has no gradient in the reference
+    // (computeGradient asserts, :110) and the device library refuses to form one
+    bool usesExponential() const { return useExponential_; }
     const std::vector<Term>& terms() const { return terms_; }
 private:
     Numeric coeff_;
+    bool useExponential_;
     std::vector<Term> terms_;
 };
 
@@ -210,6 +216,7 @@ public:
         std::vector<double> coeff, expo, cons;
         std::vector<int64_t> rowptr, vid;
         std::vector<uint8_t> sine;
+        std::vector<uint8_t> useexp;  // empty, or one flag per factor (NonlinearProductFactor::usesExponential)
     };
     const Packed& packed() const;
 

@@ -544,4 +544,44 @@ long long harness_level_tree(int which, const char* path, long long ncams, long 
     } catch (const std::exception& e) { std::cerr << "harness_level_tree: " << e.what() << std::endl; return -2; }
 }
 
+// ---- GPU: a function built factor by factor through the mirrored classes, one factor exponential
+// (NonlinearProductFactor's constructor argument useExponential, src/NonlinearProductFactor.h:61-63).
+// f0 = 2 sin((x0 - 0.5)^3) x1, f1 = 1.5 exp(-(x1^2 x2)), f2 = -0.75 x2.  out = {eval(), f1 alone, gradient refused (1/0),
+// gradient of {f0, f2} wrt x0, x1, x2}
+namespace {
+struct SmallFunction : OptimizableFunction {
+    SmallFunction() {
+        VariableID id = 0;
+        Variable* x0 = addVariable("x0", VariableDomain(-5, 5), id);
+        Variable* x1 = addVariable("x1", VariableDomain(-5, 5), id);
+        Variable* x2 = addVariable("x2", VariableDomain(-5, 5), id);
+        NonlinearProductFactor* f0 = new NonlinearProductFactor(0, 2.0);
+        f0->addVariable(x0, 3.0, 0.5, true); f0->addVariable(x1);
+        NonlinearProductFactor* f1 = new NonlinearProductFactor(1, 1.5, /*useExponential=*/true, 2);
+        f1->addVariable(x1, 2.0); f1->addVariable(x2);
+        NonlinearProductFactor* f2 = new NonlinearProductFactor(2, -0.75);
+        f2->addVariable(x2);
+        addFactor(f0); addFactor(f1); addFactor(f2);
+    }
+};
+}  // namespace
+
+int harness_nlp_exponential(const double* x, double* out) {
+    try {
+        SmallFunction f;
+        f.assignAll(NumericVec(x, x + 3));
+        out[0] = f.eval();
+        Numeric ferr = 0;
+        out[1] = f.evalFactors(FactorPtrVec(1, f.getFactors()[1]), ferr, true);
+        out[2] = 0;
+        try { NumericVec g; f.computeGradient(g); } catch (const HipError&) { out[2] = 1; }
+        FactorPtrVec rest; rest.push_back(f.getFactors()[0]); rest.push_back(f.getFactors()[2]);
+        PartialGradient pg;
+        f.computeGradient(rest, pg);
+        out[3] = out[4] = out[5] = 0;
+        for (const auto& kv : pg) out[3 + kv.first] = kv.second;
+        return 0;
+    } catch (const std::exception& e) { std::cerr << "harness_nlp_exponential: " << e.what() << std::endl; return -2; }
+}
+
 }  // extern "C"

@@ -133,6 +133,46 @@ def test_theta_zero_and_nlp_edge_cases(gctx):
     assert abs(f - o.eval()) <= 1e-13 * 10 and np.max(np.abs(gg - o.gradient())) <= 1e-13 * 10
 
 
+def test_nlp_exponential_values_and_refusals(gctx):
+    """useExponential of NonlinearProductFactor (src/NonlinearProductFactor.cpp:140, 204): flagged factors evaluate to
+    coeff * exp(-product), like the oracle; a gradient or a solve over a list holding one is refused (the
+    reference's computeGradient asserts the flag off, :110), over a list without one it runs as before."""
+    s = P.make_high_dim_sinusoid()
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-3.0, 3.0, s.nvars)
+    o, g = O.OracleProblem(s), capi.Problem(gctx, s)
+    o.assign(None, x)
+    g.set_x(x)
+    idx = np.arange(s.nfac, dtype=np.int64)
+    plain = g.eval_each(idx)
+    flags = (rng.random(s.nfac) < 0.4).astype(np.uint8)
+    o.set_exponential(flags)
+    g.set_exponential(flags)
+    e_dev, e_orc = g.eval_each(idx), o.eval_each(idx)
+    assert np.array_equal(e_dev[flags == 0], plain[flags == 0])
+    assert np.max(np.abs(e_dev - e_orc) / np.maximum(np.abs(e_orc), 1e-300)) <= 8e-16
+    assert abs(g.eval() - o.eval()) <= 1e-13 * np.sum(np.abs(e_orc))
+    sub = np.flatnonzero(flags)[:7].astype(np.int64)
+    assert abs(g.eval(sub) - float(np.sum(e_orc[sub]))) <= 1e-13 * np.sum(np.abs(e_orc[sub]))
+    with pytest.raises(capi.RdisHipError, match="exponential"):
+        g.eval_grad()
+    clean = np.flatnonzero(flags == 0).astype(np.int64)
+    f_c, g_c = g.eval_grad(clean)                       # no flagged factor in the list: allowed
+    o.set_exponential(None)
+    g_o = o.gradient(clean)
+    assert np.max(np.abs(g_c - g_o)) <= 1e-13 * max(1.0, np.max(np.abs(g_o)))
+    comps = (np.array([0, s.nvars]), np.arange(s.nvars), np.array([0, s.nfac]), idx)    # one component: everything
+    with pytest.raises(capi.RdisHipError, match="exponential"):
+        capi.Plan(g, *comps)
+    with pytest.raises(capi.RdisHipError, match="exponential"):
+        g.cgd_batch(*comps, x, maxiters=5, ftol=3e-8)
+    g.set_exponential(None)
+    assert np.array_equal(g.eval_each(idx), plain)
+    f2, g2 = g.eval_grad()
+    assert np.all(np.isfinite(g2))
+    capi.Plan(g, *comps).close()
+
+
 def test_rotation_angles_over_the_whole_domain(gctx):
     """The device evaluates sin/cos of the rotation angle with its own routine (factors.hpp
     sincos_angle).  Rotation vectors from 1e-9 rad to the edge of their domain (1000 pi,

@@ -646,3 +646,19 @@ def test_plan_cache_is_bounded_and_never_changes_a_bit(harness, bal_path):
     for o, x in ((full, xf), (small, xs), (tight, xt), (none, xn)):
         assert o[2] == base[2] and o[3] == base[3] and np.array_equal(x, xb)
     assert harness.harness_optimizer_outlives_function(bal_path) == 4
+
+
+@pytest.mark.gpu
+def test_exponential_factor_through_the_mirrored_classes(harness):
+    """NonlinearProductFactor(id, coefficient, useExponential) as the reference constructs it
+    (src/NonlinearProductFactor.h:61-63): values include exp(-product) (.cpp:140), a gradient over the flagged factor
+    is refused (.cpp:110 asserts), over the other factors it is the plain one."""
+    x = np.array([1.3, -0.7, 0.9])
+    out = np.zeros(6)
+    assert harness.harness_nlp_exponential(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    u = (x[0] - 0.5) ** 3
+    f0, f1, f2 = 2.0 * np.sin(u) * x[1], 1.5 * np.exp(-(x[1] ** 2 * x[2])), -0.75 * x[2]
+    assert out[0] == pytest.approx(f0 + f1 + f2, rel=1e-14) and out[1] == pytest.approx(f1, rel=1e-15)
+    assert out[2] == 1
+    want = [2.0 * np.cos(u) * 3 * (x[0] - 0.5) ** 2 * x[1], 2.0 * np.sin(u), -0.75]
+    assert np.allclose(out[3:6], want, rtol=1e-14, atol=0)

@@ -462,3 +462,25 @@ def test_slope_association_moves_the_population():
     assert ks(base25, oe) <= crit                    # the oracle as it is: the fixture's population (other starts)
     assert ks(alt25, oe) > crit                      # with the device's association: another one
     assert np.quantile(alt25, 0.25) > np.quantile(base25, 0.25) + 0.02
+
+
+def test_nlp_exponential_values_only():
+    """useExponential (NonlinearProductFactor.cpp:140, 204): a flagged factor is coeff * exp(-product); the
+    reference's computeGradient asserts the flag off (:110), the restatement's derivative is NaN there."""
+    s = P.make_high_dim_sinusoid()
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-3.0, 3.0, s.nvars)
+    o = O.OracleProblem(s)
+    o.assign(None, x)
+    idx = np.arange(s.nfac, dtype=np.int64)
+    plain = o.eval_each(idx)
+    flags = (rng.random(s.nfac) < 0.4).astype(np.uint8)
+    o.set_exponential(flags)
+    e = o.eval_each(idx)
+    want = np.where(flags != 0, s.coeff * np.exp(-plain / s.coeff), plain)
+    assert np.array_equal(e[flags == 0], plain[flags == 0])
+    assert np.allclose(e, want, rtol=4e-16 * 8, atol=0)
+    assert o.eval() == pytest.approx(float(np.sum(want)), rel=1e-13)
+    assert np.any(np.isnan(o.gradient()))
+    o.set_exponential(None)
+    assert np.array_equal(o.eval_each(idx), plain) and np.all(np.isfinite(o.gradient()))
