@@ -276,15 +276,21 @@ RDIS_FACTORS_FP_CONTRACT
 // I + [r]x at theta = 0, the reference's first-order branch, BundleAdjustmentFactor.cpp:304-329) and, for the slope of a
 // line search, the derivative dR of that matrix along the camera's part of the search direction.  A factor then costs
 //   P = R q + t (9 fused multiply-adds) ... E                                  about 30 fp64 operations + one division,
-//   dP = dR q + R e + dt (18) ... dE/da                                        about 40,
+//   dP = w x (R q) + R e + dt (24) ... dE/da                                   about 45,
+// with dR q written as a cross product: the derivative of a rotation along a direction rho of its angle-axis vector is
+// dR = [w]x R, w = J rho (J the left Jacobian of the rotation group: (s/theta) I + (1 - s/theta) v v^T + ((1 - c)/theta) [v]x),
+// so a camera's direction record is three numbers instead of a matrix: ten doubles -- five 16-byte LDS reads a factor
+// instead of eight, which is what bounds the trial loop (tools/microbench/trial_loop.hip: 13 reads instead of 16 a factor,
+// the SIMD takes a slot of 64 factors every 474 instead of 511 cycles at three waves, 531 instead of 604 at two),
 // where the vector form above (ba_project + ba_slope_dir: cross products, dot products and the chain through the unit
 // axis, per factor) takes about 150: the streaming solver's trials are bound by dependent fp64 issue, not by bytes.
 // Same model, other association of the same sums: values and slopes agree with the vector form to a few ulp of their
 // terms (tests/cpp/factors_forms_test.hip), far inside the 1e-12 the parity tests allow per evaluation.
-// Records (16 doubles each, read by the factors as 16-byte pairs):
-//   TR = [R00 R01 R02 t0 | R10 R11 R12 t1 | R20 R21 R22 t2 | f k1 k2 -]
-//   DR = [dR00 dR01 dR02 dt0 | dR10 ... dt1 | dR20 ... dt2 | df dk1 dk2 -]
+// Records (read by the factors as 16-byte pairs):
+//   TR = [R00 R01 R02 t0 | R10 R11 R12 t1 | R20 R21 R22 t2 | f k1 k2 -]        16 doubles
+//   DR = [w0 w1 | w2 dt0 | dt1 dt2 | df dk1 | dk2 -]                           10 doubles
 constexpr int CAM_TRIAL = 16;
+constexpr int CAM_DIR = 10;
 // x: the camera's nine values at the trial point [r t f k1 k2]; rot: ba_rotation(x[0..2])
 __host__ __device__ __forceinline__ void ba_camera_trial(const BaFwd& rot, const double (&x)[9], double* __restrict__ TR) {
 RDIS_FACTORS_FP_CONTRACT
@@ -306,25 +312,40 @@ RDIS_FACTORS_FP_CONTRACT
 // d: the camera's nine entries of the search direction
 __host__ __device__ __forceinline__ void ba_camera_trial_dir(const BaFwd& rot, const double (&d)[9], double* __restrict__ DR) {
 RDIS_FACTORS_FP_CONTRACT
+    const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2;
+    if (rot.theta > 0.0) {
+        const double dth = v0 * d[0] + v1 * d[1] + v2 * d[2];          // d theta = v . dr
+        const double a = rot.s * rot.itheta, b = (1.0 - rot.c) * rot.itheta;
+        const double l = (1.0 - a) * dth;
+        DR[0] = a * d[0] + (l * v0 + b * (v1 * d[2] - v2 * d[1]));
+        DR[1] = a * d[1] + (l * v1 + b * (v2 * d[0] - v0 * d[2]));
+        DR[2] = a * d[2] + (l * v2 + b * (v0 * d[1] - v1 * d[0]));
+    } else {   // R = I + [r]x at r = 0: d(r x q) = dr x q
+        DR[0] = d[0]; DR[1] = d[1]; DR[2] = d[2];
+    }
+    DR[3] = d[3]; DR[4] = d[4]; DR[5] = d[5];
+    DR[6] = d[6]; DR[7] = d[7]; DR[8] = d[8]; DR[9] = 0.0;
+}
+// the derivative of the rotation matrix itself along d (row-major 3 x 3; the gradient's chain, ba_rotation_gradient)
+__host__ __device__ __forceinline__ void ba_rotation_matrix_dir(const BaFwd& rot, const double (&d)[3], double (&M)[9]) {
+RDIS_FACTORS_FP_CONTRACT
     const double v0 = rot.v0, v1 = rot.v1, v2 = rot.v2, s = rot.s, c = rot.c;
     if (rot.theta > 0.0) {
         const double omc = 1.0 - c;
-        const double dth = v0 * d[0] + v1 * d[1] + v2 * d[2];          // d theta = v . dr
+        const double dth = v0 * d[0] + v1 * d[1] + v2 * d[2];
         const double u0 = (d[0] - v0 * dth) * rot.itheta, u1 = (d[1] - v1 * dth) * rot.itheta, u2 = (d[2] - v2 * dth) * rot.itheta;   // dv
         const double ds = c * dth, dc = -(s * dth), domc = s * dth;
         const double a0 = omc * v0, a1 = omc * v1, a2 = omc * v2;
         const double b0 = domc * v0 + omc * u0, b1 = domc * v1 + omc * u1, b2 = domc * v2 + omc * u2;   // d(a)
         const double w0 = ds * v0 + s * u0, w1 = ds * v1 + s * u1, w2 = ds * v2 + s * u2;               // d(s v)
-        DR[0] = dc + b0 * v0 + a0 * u0;    DR[1] = b0 * v1 + a0 * u1 - w2;  DR[2] = b0 * v2 + a0 * u2 + w1;
-        DR[4] = b1 * v0 + a1 * u0 + w2;    DR[5] = dc + b1 * v1 + a1 * u1;  DR[6] = b1 * v2 + a1 * u2 - w0;
-        DR[8] = b2 * v0 + a2 * u0 - w1;    DR[9] = b2 * v1 + a2 * u1 + w0;  DR[10] = dc + b2 * v2 + a2 * u2;
-    } else {   // d(r x q) = dr x q
-        DR[0] = 0.0;   DR[1] = -d[2]; DR[2] = d[1];
-        DR[4] = d[2];  DR[5] = 0.0;   DR[6] = -d[0];
-        DR[8] = -d[1]; DR[9] = d[0];  DR[10] = 0.0;
+        M[0] = dc + b0 * v0 + a0 * u0;    M[1] = b0 * v1 + a0 * u1 - w2;  M[2] = b0 * v2 + a0 * u2 + w1;
+        M[3] = b1 * v0 + a1 * u0 + w2;    M[4] = dc + b1 * v1 + a1 * u1;  M[5] = b1 * v2 + a1 * u2 - w0;
+        M[6] = b2 * v0 + a2 * u0 - w1;    M[7] = b2 * v1 + a2 * u1 + w0;  M[8] = dc + b2 * v2 + a2 * u2;
+    } else {
+        M[0] = 0.0;   M[1] = -d[2]; M[2] = d[1];
+        M[3] = d[2];  M[4] = 0.0;   M[5] = -d[0];
+        M[6] = -d[1]; M[7] = d[0];  M[8] = 0.0;
     }
-    DR[3] = d[3]; DR[7] = d[4]; DR[11] = d[5];
-    DR[12] = d[6]; DR[13] = d[7]; DR[14] = d[8]; DR[15] = 0.0;
 }
 struct BaTrial {   // what the slope needs of the value's evaluation
     double iz, pp0, pp1, r2, dstn, fd, res0, res1;
@@ -347,16 +368,21 @@ RDIS_FACTORS_FP_CONTRACT
 }
 // ... and its slope along (camera direction as DR, point direction e); CAMFIX: the camera does not move (DR is not read)
 template <bool CAMFIX>
-__host__ __device__ __forceinline__ double ba_trial_slope(const BaTrial& t, const double (&TR)[CAM_TRIAL], const double (&DR)[CAM_TRIAL],
+__host__ __device__ __forceinline__ double ba_trial_slope(const BaTrial& t, const double (&TR)[CAM_TRIAL], const double (&DR)[CAM_DIR],
                                                           const double (&q)[3], const double (&e)[3]) {
 RDIS_FACTORS_FP_CONTRACT
-    double dP0 = TR[0] * e[0] + (TR[1] * e[1] + TR[2] * e[2]);
-    double dP1 = TR[4] * e[0] + (TR[5] * e[1] + TR[6] * e[2]);
-    double dP2 = TR[8] * e[0] + (TR[9] * e[1] + TR[10] * e[2]);
-    if constexpr (!CAMFIX) {
-        dP0 += DR[0] * q[0] + (DR[1] * q[1] + (DR[2] * q[2] + DR[3]));
-        dP1 += DR[4] * q[0] + (DR[5] * q[1] + (DR[6] * q[2] + DR[7]));
-        dP2 += DR[8] * q[0] + (DR[9] * q[1] + (DR[10] * q[2] + DR[11]));
+    double dP0, dP1, dP2;
+    if constexpr (CAMFIX) {
+        dP0 = TR[0] * e[0] + (TR[1] * e[1] + TR[2] * e[2]);
+        dP1 = TR[4] * e[0] + (TR[5] * e[1] + TR[6] * e[2]);
+        dP2 = TR[8] * e[0] + (TR[9] * e[1] + TR[10] * e[2]);
+    } else {
+        const double Q0 = TR[0] * q[0] + (TR[1] * q[1] + TR[2] * q[2]);      // R q
+        const double Q1 = TR[4] * q[0] + (TR[5] * q[1] + TR[6] * q[2]);
+        const double Q2 = TR[8] * q[0] + (TR[9] * q[1] + TR[10] * q[2]);
+        dP0 = TR[0] * e[0] + (TR[1] * e[1] + (TR[2] * e[2] + (DR[1] * Q2 + (DR[3] - DR[2] * Q1))));
+        dP1 = TR[4] * e[0] + (TR[5] * e[1] + (TR[6] * e[2] + (DR[2] * Q0 + (DR[4] - DR[0] * Q2))));
+        dP2 = TR[8] * e[0] + (TR[9] * e[1] + (TR[10] * e[2] + (DR[0] * Q1 + (DR[5] - DR[1] * Q0))));
     }
     const double dpp0 = -(dP0 + t.pp0 * dP2) * t.iz;
     const double dpp1 = -(dP1 + t.pp1 * dP2) * t.iz;
@@ -364,8 +390,8 @@ RDIS_FACTORS_FP_CONTRACT
     double ddst = dr2 * (TR[13] + 2.0 * TR[14] * t.r2);
     double scale = TR[12] * ddst;          // d(f dstn) = df dstn + f ddstn
     if constexpr (!CAMFIX) {
-        ddst += t.r2 * (DR[13] + DR[14] * t.r2);
-        scale = DR[12] * t.dstn + TR[12] * ddst;
+        ddst += t.r2 * (DR[7] + DR[8] * t.r2);
+        scale = DR[6] * t.dstn + TR[12] * ddst;
     }
     const double dpix0 = scale * t.pp0 + t.fd * dpp0;
     const double dpix1 = scale * t.pp1 + t.fd * dpp1;
@@ -404,103 +430,15 @@ RDIS_FACTORS_FP_CONTRACT
     gc[9] = a0; gc[10] = a1; gc[11] = a2;
 }
 // ... and the chain for one camera: M = the sum of its factors' a q^T (row-major 3 x 3), rot = ba_rotation of its angle-axis
-// vector; gr[k] = sum_ij M_ij dR_ij/dr_k (the derivative of the rotation matrix along the k-th unit vector: ba_camera_trial_dir)
+// vector; gr[k] = sum_ij M_ij dR_ij/dr_k (the derivative of the rotation matrix along the k-th unit vector: ba_rotation_matrix_dir)
 __host__ __device__ __forceinline__ void ba_rotation_gradient(const BaFwd& rot, const double (&M)[9], double (&gr)[3]) {
 RDIS_FACTORS_FP_CONTRACT
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        double d[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, DR[CAM_TRIAL];
+        double d[3] = {0.0, 0.0, 0.0}, D[9];
         d[k] = 1.0;
-        ba_camera_trial_dir(rot, d, DR);
-        gr[k] = (M[0] * DR[0] + M[1] * DR[1] + M[2] * DR[2]) + (M[3] * DR[4] + M[4] * DR[5] + M[5] * DR[6]) + (M[6] * DR[8] + M[7] * DR[9] + M[8] * DR[10]);
-    }
-}
-
-// ... for W factors of ONE point at a time, statement by statement (the streaming solver's trial loop).  A factor's evaluation
-// is one long chain of dependent fp64 operations (nine cycles from one to the next, four to issue one), and the three waves
-// that fit a SIMD do not fill its issue slots between them; W independent chains side by side in one wave do.  Same
-// expressions as ba_trial_value / ba_trial_slope, operation for operation (the same bits: tests/cpp/factors_forms_test.hip);
-// the records are read row by row where they are used -- [R_i0 R_i1 R_i2 t_i] and its derivative give P_i and dP_i and are
-// dead -- so that W factors' state is 12 doubles each instead of two whole records.
-// TRp / DRp: the W cameras' records (16-byte aligned; DRp is not read under CAMFIX or without SLOPE).
-template <int W, bool SLOPE, bool CAMFIX>
-__host__ __device__ __forceinline__ void ba_trial_lockstep(const double* const (&TRp)[W], const double* const (&DRp)[W], const double (&q)[3],
-                                                           const double (&e)[3], const double (&ox)[W], const double (&oy)[W],
-                                                           double (&val)[W], double (&slp)[W]) {
-RDIS_FACTORS_FP_CONTRACT
-    struct D2 { double x, y; };
-    double P[W][3], dP[W][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        D2 a[W], b[W], c[W], d[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            const D2* tr = reinterpret_cast<const D2*>(TRp[k]) + 2 * i;
-            a[k] = tr[0]; b[k] = tr[1];
-        }
-        if constexpr (SLOPE && !CAMFIX) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const D2* dr = reinterpret_cast<const D2*>(DRp[k]) + 2 * i;
-                c[k] = dr[0]; d[k] = dr[1];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) P[k][i] = a[k].x * q[0] + (a[k].y * q[1] + (b[k].x * q[2] + b[k].y));
-        if constexpr (SLOPE) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) dP[k][i] = a[k].x * e[0] + (a[k].y * e[1] + b[k].x * e[2]);
-            if constexpr (!CAMFIX) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) dP[k][i] += c[k].x * q[0] + (c[k].y * q[1] + (d[k].x * q[2] + d[k].y));
-            }
-        }
-    }
-    double f[W], k1[W], k2[W], iz[W], pp0[W], pp1[W], r2[W], dstn[W], fd[W], res0[W], res1[W];
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-        const D2* tr = reinterpret_cast<const D2*>(TRp[k]) + 6;
-        const D2 u = tr[0];
-        f[k] = u.x; k1[k] = u.y; k2[k] = TRp[k][14];
-    }
-#pragma unroll
-    for (int k = 0; k < W; ++k) iz[k] = 1.0 / P[k][2];
-#pragma unroll
-    for (int k = 0; k < W; ++k) { pp0[k] = -P[k][0] * iz[k]; pp1[k] = -P[k][1] * iz[k]; }
-#pragma unroll
-    for (int k = 0; k < W; ++k) r2[k] = pp0[k] * pp0[k] + pp1[k] * pp1[k];
-#pragma unroll
-    for (int k = 0; k < W; ++k) dstn[k] = 1.0 + r2[k] * (k1[k] + k2[k] * r2[k]);
-#pragma unroll
-    for (int k = 0; k < W; ++k) fd[k] = f[k] * dstn[k];
-#pragma unroll
-    for (int k = 0; k < W; ++k) { res0[k] = fd[k] * pp0[k] - ox[k]; res1[k] = fd[k] * pp1[k] - oy[k]; }
-#pragma unroll
-    for (int k = 0; k < W; ++k) val[k] = (res0[k] * res0[k] + res1[k] * res1[k]) * 0.5;
-    if constexpr (SLOPE) {
-        double dpp0[W], dpp1[W], dr2[W], ddst[W], scale[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) { dpp0[k] = -(dP[k][0] + pp0[k] * dP[k][2]) * iz[k]; dpp1[k] = -(dP[k][1] + pp1[k] * dP[k][2]) * iz[k]; }
-#pragma unroll
-        for (int k = 0; k < W; ++k) dr2[k] = 2.0 * (pp0[k] * dpp0[k] + pp1[k] * dpp1[k]);
-#pragma unroll
-        for (int k = 0; k < W; ++k) { ddst[k] = dr2[k] * (k1[k] + 2.0 * k2[k] * r2[k]); scale[k] = f[k] * ddst[k]; }
-        if constexpr (!CAMFIX) {
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const D2* dr = reinterpret_cast<const D2*>(DRp[k]) + 6;
-                const D2 u = dr[0];
-                const double dk2 = DRp[k][14];
-                ddst[k] += r2[k] * (u.y + dk2 * r2[k]);
-                scale[k] = u.x * dstn[k] + f[k] * ddst[k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            const double dpix0 = scale[k] * pp0[k] + fd[k] * dpp0[k];
-            const double dpix1 = scale[k] * pp1[k] + fd[k] * dpp1[k];
-            slp[k] = res0[k] * dpix0 + res1[k] * dpix1;
-        }
+        ba_rotation_matrix_dir(rot, d, D);
+        gr[k] = (M[0] * D[0] + M[1] * D[1] + M[2] * D[2]) + (M[3] * D[3] + M[4] * D[4] + M[5] * D[5]) + (M[6] * D[6] + M[7] * D[7] + M[8] * D[8]);
     }
 }
 

@@ -295,7 +295,7 @@ struct LdsEnv {
                 w = fidx[j]; o = fobs[j];
             }
             const int off = __mul24((int)(w & 0xFFFu), LDS_TS), pb = 9 * ncb + 3 * (int)(w >> 12);
-            double TR[CAM_TRIAL], DR[CAM_TRIAL];
+            double TR[CAM_TRIAL], DR[CAM_DIR];
             const double2* tc = reinterpret_cast<const double2*>(CTR + off);
 #pragma unroll
             for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = tc[k]; TR[2 * k] = v.x; TR[2 * k + 1] = v.y; }
@@ -307,10 +307,10 @@ struct LdsEnv {
                 if constexpr (ROT != ROT_CAMFIX) {
                     const double2* dc = reinterpret_cast<const double2*>(CDR + off);
 #pragma unroll
-                    for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
+                    for (int k = 0; k < CAM_DIR / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < CAM_TRIAL; ++k) DR[k] = 0.0;
+                    for (int k = 0; k < CAM_DIR; ++k) DR[k] = 0.0;
                 }
                 as += ba_trial_slope<ROT == ROT_CAMFIX>(t, TR, DR, x, e);
             }

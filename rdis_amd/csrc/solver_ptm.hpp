@@ -321,7 +321,7 @@ struct PtmEnv {
 #if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 1
         slope = false;
 #endif
-        double TR[CAM_TRIAL], DR[CAM_TRIAL];
+        double TR[CAM_TRIAL], DR[CAM_DIR];
         const int off = __mul24(cc, PTM_TS);   // (cameras < 2^12: the 24-bit product is exact and full rate, the 32-bit one a quarter of it)
         const double2* tc = reinterpret_cast<const double2*>(CTR + off);
 #pragma unroll
@@ -332,10 +332,10 @@ struct PtmEnv {
             if constexpr (ROT != ROT_CAMFIX) {
                 const double2* dc = reinterpret_cast<const double2*>(CDR + off);
 #pragma unroll
-                for (int k = 0; k < CAM_TRIAL / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
+                for (int k = 0; k < CAM_DIR / 2; ++k) { const double2 v = dc[k]; DR[2 * k] = v.x; DR[2 * k + 1] = v.y; }
             } else {
 #pragma unroll
-                for (int k = 0; k < CAM_TRIAL; ++k) DR[k] = 0.0;
+                for (int k = 0; k < CAM_DIR; ++k) DR[k] = 0.0;
             }
             as += ba_trial_slope<ROT == ROT_CAMFIX>(t, TR, DR, x, dp);
         }
@@ -352,38 +352,6 @@ struct PtmEnv {
         for (int k = 0; k < PTM_BLK; ++k) {
             B.c[k] = pcam[e + 64 * k + lane]; B.o[k] = pobs[e + 64 * k + lane];
             if constexpr (ROWS) B.r[k] = grow[e + 64 * k + lane];
-        }
-    }
-    // the first W slots of a block: the lane's point against W cameras, in lockstep (factors.hpp).  A lane without a factor
-    // in a slot evaluates camera 0 and adds nothing.
-    template <int W, bool SLOPE>
-    __device__ __forceinline__ void factors_lockstep(const SlotBlock& B, const double (&x)[3], const double (&dp)[3], double& af, double& as) const {
-        const double* tp[W];
-        const double* dq[W];
-        double ox[W], oy[W], v[W], sl[W];
-        bool ok[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            ok[k] = B.c[k] >= 0;
-            int cc = ok[k] ? B.c[k] : 0;
-#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 2
-            cc = 0;
-#endif
-            tp[k] = CTR + PTM_TS * cc; dq[k] = CDR + PTM_TS * cc;
-            ox[k] = B.o[k].x; oy[k] = B.o[k].y;
-            sl[k] = 0.0;
-        }
-        const double* const (&tpc)[W] = tp;
-        const double* const (&dqc)[W] = dq;
-#if defined(RDIS_PTM_ABLATE) && RDIS_PTM_ABLATE == 1
-        ba_trial_lockstep<W, false, ROT == ROT_CAMFIX>(tpc, dqc, x, dp, ox, oy, v, sl);
-#else
-        ba_trial_lockstep<W, SLOPE, ROT == ROT_CAMFIX>(tpc, dqc, x, dp, ox, oy, v, sl);
-#endif
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            af += ok[k] ? v[k] : 0.0;
-            if constexpr (SLOPE) as += ok[k] ? sl[k] : 0.0;
         }
     }
     // holds a block of slots in registers at this point of the program (no instruction)
@@ -435,14 +403,9 @@ struct PtmEnv {
                 const int en = e + 64 * PTM_BLK;
                 const bool more = en < e1;
                 load_block(more ? en : ne < ne1 ? ne : e, N);
-#ifdef RDIS_PTM_LOCKSTEP   // (an experiment's build: the block's factors side by side, statement by statement -- the same bits, no faster)
-                if (bn == PTM_BLK) factors_lockstep<PTM_BLK, SLOPE>(B, x, dp, af, as);
-                else factors_lockstep<1, SLOPE>(B, x, dp, af, as);
-#else
 #pragma unroll
                 for (int k = 0; k < PTM_BLK; ++k)
                     if (k < bn && B.c[k] >= 0) factor_trial(B.c[k], B.o[k], x, dp, SLOPE, af, as);
-#endif
                 B = N;
                 pin_block(B);
                 if (!more) break;

@@ -35,7 +35,7 @@ int main() {
         // matrix form
         BaFwd rot;
         ba_rotation(x[0], x[1], x[2], rot);
-        double xc[9], dc[9], TR[CAM_TRIAL], DR[CAM_TRIAL];
+        double xc[9], dc[9], TR[CAM_TRIAL], DR[CAM_DIR];
         for (int k = 0; k < 9; ++k) { xc[k] = x[k]; dc[k] = d[k]; }
         ba_camera_trial(rot, xc, TR);
         ba_camera_trial_dir(rot, dc, DR);
@@ -43,29 +43,6 @@ int main() {
         BaTrial bt;
         const double f1 = ba_trial_value(TR, q, ox, oy, bt);
         const double s1 = camfix ? ba_trial_slope<true>(bt, TR, DR, q, e) : ba_trial_slope<false>(bt, TR, DR, q, e);
-        // two factors of the point in lockstep (this camera and the one of the case before): the same bits as one by one
-        {
-            alignas(16) static double TRprev[CAM_TRIAL], DRprev[CAM_TRIAL];
-            alignas(16) double TRa[CAM_TRIAL], DRa[CAM_TRIAL];
-            for (int k = 0; k < CAM_TRIAL; ++k) { TRa[k] = TR[k]; DRa[k] = DR[k]; }
-            if (it > 0) {
-                BaTrial b2;
-                const double ox2 = ox + 1.5, oy2 = oy - 2.5;
-                const double f2 = ba_trial_value(TRprev, q, ox2, oy2, b2);
-                const double s2 = camfix ? ba_trial_slope<true>(b2, TRprev, DRprev, q, e) : ba_trial_slope<false>(b2, TRprev, DRprev, q, e);
-                const double* const tp[2] = {TRa, TRprev};
-                const double* const dp[2] = {DRa, DRprev};
-                const double oxs[2] = {ox, ox2}, oys[2] = {oy, oy2};
-                double v[2], sl[2];
-                if (camfix) ba_trial_lockstep<2, true, true>(tp, dp, q, e, oxs, oys, v, sl);
-                else ba_trial_lockstep<2, true, false>(tp, dp, q, e, oxs, oys, v, sl);
-                if (v[0] != f1 || v[1] != f2 || sl[0] != s1 || sl[1] != s2) {
-                    std::printf("case %d: lockstep (%.17g %.17g | %.17g %.17g) against one by one (%.17g %.17g | %.17g %.17g)\n", it, v[0], sl[0], v[1], sl[1], f1, s1, f2, s2);
-                    return 1;
-                }
-            }
-            for (int k = 0; k < CAM_TRIAL; ++k) { TRprev[k] = TR[k]; DRprev[k] = DR[k]; }
-        }
         // the gradient in matrix form (ba_trial_adjoint + the rotation chain once per camera) against the adjoint sweep
         {
             double g[12], gq[3], gc[CAM_GRAD], gr[3];

@@ -6,7 +6,9 @@
 // (LDS broadcast); 3 the records of ONE camera held in registers (no LDS reads in the loop); 4 as 0 with the reciprocal by
 // v_rcp_f64 + two Newton steps instead of the IEEE division; 5 value only (no slope); 6 no stream, every lane of a wave the
 // same camera, another one each slot (LDS broadcast); 7 no stream, ten lanes a camera, neighbours consecutive cameras (what
-// the plan's order gives the solver on the bench's components: no bank conflicts); 8 as 7 with the stream.
+// the plan's order gives the solver on the bench's components: no bank conflicts); 8 as 7 with the stream; 9 as 0 with round
+// 4's direction record (the matrix dR: sixteen doubles, eight reads -- the library's is [w dt df dk1 dk2], ten doubles, five
+// reads, since round 5); 10 as 8 with that record; 11 as 8 with the stream asked for two blocks (four slots) ahead.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -38,26 +40,33 @@ __global__ void __launch_bounds__(1024) run(long long* out, double* sink, const 
     auto load = [&](int s, int& a, int& b, double2& oa, double2& ob) {
         if (MODE == 6) { a = (7 * s) % NCAM; b = (7 * s + 3) % NCAM; oa = make_double2(1.0, 2.0); ob = make_double2(-1.0, 0.5); }
         else if (MODE == 7) { a = (lane / 10 + s) % NCAM; b = (lane / 10 + s + 1) % NCAM; oa = make_double2(1.0, 2.0); ob = make_double2(-1.0, 0.5); }
-        else if (MODE == 8) { a = (lane / 10 + s) % NCAM; b = (lane / 10 + s + 1) % NCAM; oa = pobs[base + 64 * s + lane]; ob = pobs[base + 64 * (s + 1) + lane];
+        else if (MODE == 8 || MODE >= 10) { a = (lane / 10 + s) % NCAM; b = (lane / 10 + s + 1) % NCAM; oa = pobs[base + 64 * s + lane]; ob = pobs[base + 64 * (s + 1) + lane];
                               a += pcam[base + 64 * s + lane] >> 12; b += pcam[base + 64 * (s + 1) + lane] >> 12; }
         else if (MODE == 1) { a = (lane + s) % NCAM; b = (lane + 7 * s + 3) % NCAM; oa = make_double2(1.0, 2.0); ob = make_double2(-1.0, 0.5); }
         else { a = pcam[base + 64 * s + lane]; b = pcam[base + 64 * (s + 1) + lane]; oa = pobs[base + 64 * s + lane]; ob = pobs[base + 64 * (s + 1) + lane]; }
     };
     load(0, c0, c1, o0, o1);
-    double TRr[CAM_TRIAL], DRr[CAM_TRIAL];
-    if (MODE == 3) { for (int k = 0; k < CAM_TRIAL; ++k) { TRr[k] = CTR[TS * (lane % NCAM) + k]; DRr[k] = CDR[TS * (lane % NCAM) + k]; } }
+    int c2 = 0, c3 = 0; double2 o2 = o0, o3 = o1;
+    if (MODE == 11) load(2, c2, c3, o2, o3);
+    double TRr[CAM_TRIAL], DRr[CAM_DIR];
+    if (MODE == 3) { for (int k = 0; k < CAM_TRIAL; ++k) TRr[k] = CTR[TS * (lane % NCAM) + k]; for (int k = 0; k < CAM_DIR; ++k) DRr[k] = CDR[TS * (lane % NCAM) + k]; }
     const long long t0 = clock64();
     for (int s = 0; s < SLOTS; s += 2) {
         int b0 = c0, b1 = c1; double2 p0 = o0, p1 = o1;
         asm volatile("" : "+v"(b0), "+v"(b1), "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y));
+        if (MODE == 11) {
+            c0 = c2; c1 = c3; o0 = o2; o1 = o3;
+            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(o0.x), "+v"(o0.y), "+v"(o1.x), "+v"(o1.y));
+            load(s + 4 < SLOTS ? s + 4 : s, c2, c3, o2, o3);
+        } else
         load(s + 2 < SLOTS ? s + 2 : s, c0, c1, o0, o1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             int cc = k ? b1 : b0;
             const double2 o = k ? p1 : p0;
             if (MODE == 2) cc = 0;
-            double TR[CAM_TRIAL], DR[CAM_TRIAL];
-            if (MODE == 3) { for (int q = 0; q < CAM_TRIAL; ++q) { TR[q] = TRr[q]; DR[q] = DRr[q]; } TR[3] += 1e-9 * cc; }
+            double TR[CAM_TRIAL], DR[CAM_DIR];
+            if (MODE == 3) { for (int q = 0; q < CAM_TRIAL; ++q) TR[q] = TRr[q]; for (int q = 0; q < CAM_DIR; ++q) DR[q] = DRr[q]; TR[3] += 1e-9 * cc; }
             else {
                 const double2* tc = reinterpret_cast<const double2*>(CTR + TS * cc);
 #pragma unroll
@@ -79,11 +88,32 @@ __global__ void __launch_bounds__(1024) run(long long* out, double* sink, const 
                 t.res0 = t.fd * t.pp0 - o.x; t.res1 = t.fd * t.pp1 - o.y;
                 af += (t.res0 * t.res0 + t.res1 * t.res1) * 0.5;
             } else af += ba_trial_value(TR, x, o.x, o.y, t);
-            if (MODE != 5) {
+            if (MODE == 9 || MODE == 10) {   // round 4's direction record: the matrix dR and dt, sixteen doubles -- eight reads
+                RDIS_FACTORS_FP_CONTRACT
+                const double2* dc = reinterpret_cast<const double2*>(CDR + TS * cc);
+                double D[16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double2 v = dc[q]; D[2 * q] = v.x; D[2 * q + 1] = v.y; }
+                double dP0 = TR[0] * dp[0] + (TR[1] * dp[1] + TR[2] * dp[2]);
+                double dP1 = TR[4] * dp[0] + (TR[5] * dp[1] + TR[6] * dp[2]);
+                double dP2 = TR[8] * dp[0] + (TR[9] * dp[1] + TR[10] * dp[2]);
+                dP0 += D[0] * x[0] + (D[1] * x[1] + (D[2] * x[2] + D[3]));
+                dP1 += D[4] * x[0] + (D[5] * x[1] + (D[6] * x[2] + D[7]));
+                dP2 += D[8] * x[0] + (D[9] * x[1] + (D[10] * x[2] + D[11]));
+                const double dpp0 = -(dP0 + t.pp0 * dP2) * t.iz;
+                const double dpp1 = -(dP1 + t.pp1 * dP2) * t.iz;
+                const double dr2 = 2.0 * (t.pp0 * dpp0 + t.pp1 * dpp1);
+                double ddst = dr2 * (TR[13] + 2.0 * TR[14] * t.r2);
+                ddst += t.r2 * (D[13] + D[14] * t.r2);
+                const double scale = D[12] * t.dstn + TR[12] * ddst;
+                const double dpix0 = scale * t.pp0 + t.fd * dpp0;
+                const double dpix1 = scale * t.pp1 + t.fd * dpp1;
+                as += t.res0 * dpix0 + t.res1 * dpix1;
+            } else if (MODE != 5) {
                 if (MODE != 3) {
                     const double2* dc = reinterpret_cast<const double2*>(CDR + TS * cc);
 #pragma unroll
-                    for (int q = 0; q < CAM_TRIAL / 2; ++q) { const double2 v = dc[q]; DR[2 * q] = v.x; DR[2 * q + 1] = v.y; }
+                    for (int q = 0; q < CAM_DIR / 2; ++q) { const double2 v = dc[q]; DR[2 * q] = v.x; DR[2 * q + 1] = v.y; }
                 }
                 as += ba_trial_slope<false>(t, TR, DR, x, dp);
             }
@@ -129,5 +159,8 @@ int main() {
     go<6>("no stream, a camera per wave", d_out, d_sink, pcam, pobs);
     go<7>("no stream, neighbouring cameras", d_out, d_sink, pcam, pobs);
     go<8>("neighbouring cameras", d_out, d_sink, pcam, pobs);
+    go<9>("round 4's direction record (8 reads)", d_out, d_sink, pcam, pobs);
+    go<10>("... neighbouring cameras", d_out, d_sink, pcam, pobs);
+    go<11>("neighbouring cameras, stream 2 ahead", d_out, d_sink, pcam, pobs);
     return 0;
 }
