@@ -268,13 +268,15 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups
  * that share one such component when the launch has fewer components than compute units: 0 = auto,
  * 1 = never, k <= 16 = k),
- * "factor_rounding" (how the factor arithmetic rounds a * b + c: 0 = one fused multiply-add; 1 = the product is rounded before
- * it is added, like the reference's x86-64 build (g++ emits no fused multiply-add) -- and, in the LDS-resident batch solver, a
- * line-search trial's slope is formed the reference's way too: the gradient at the trial point, then gradient times direction
- * variable by variable (Df1dim::df), a full gradient per trial, seven times slower; the cooperative solvers and the LDS-resident
- * batch solver have a second instantiation for it, refused where other solvers would run; -1 = default: the cooperative solvers
- * round like the reference (4 % slower), the batch solvers fuse.  After 25 unconverged CG iterations the DISTRIBUTION of end
- * values over one-ulp starts depends on both: DESIGN.md section 6),
+ * "factor_rounding" (how the factor arithmetic rounds a * b + c: 0 = one fused multiply-add; 1 = the PARITY option: the product
+ * is rounded before it is added, like the reference's x86-64 build (g++ emits no fused multiply-add), and a line-search trial's
+ * slope is formed the reference's way -- the gradient at the trial point, every variable's partials in factor-list order, then
+ * gradient times direction over the variables in list order (Df1dim::df): a full gradient per trial in the LDS-resident batch
+ * solver (seven times slower) and, for a cooperative group, in the plain layout with one sequential sum per trial (full ladybug:
+ * 0.26 s a solve instead of 2.5 ms); with it the end values over one-ulp starts pass the plain two-sample test against the
+ * reference-faithful oracle on BASELINE configs 3 and 4; refused where other solvers would run; -1 = default: the cooperative
+ * solvers round like the reference (4 % slower) and keep their parallel slope, the batch solvers fuse.  After 25 unconverged
+ * CG iterations the DISTRIBUTION of end values over one-ulp starts depends on all of that: DESIGN.md section 6),
  * "emulate_stale_cache" (default 0; 1 = the reference's factor cache, Variable.cpp:66-76 and
  * Factor.h:228-234 -- a factor keeps its value while its variables have moved by less than 1e-12 since
  * it was computed -- emulated in the LDS-resident batch solver; refused where other solvers would run),

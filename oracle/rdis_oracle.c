@@ -989,6 +989,18 @@ static double sub_f(void *ctx, const double *x)
     return ro_eval_factors(S->p, S->nf, S->fac);
 }
 
+static double sum_tree(const double *t, int64_t lo, int64_t hi)
+{
+    if (hi - lo <= 8) {
+        double s = 0.0;
+        for (int64_t i = lo; i < hi; ++i) s += t[i];
+        return s;
+    }
+    const int64_t mid = lo + (hi - lo) / 2;
+    const double a = sum_tree(t, lo, mid);
+    return a + sum_tree(t, mid, hi);
+}
+
 /* (experiment, ro_set_experiment bit 1) the slope at the assigned point, factor by factor in list order; bundle adjustment only */
 static double sub_slope_by_factor(void *ctx, const double *xi)
 {
@@ -997,11 +1009,16 @@ static double sub_slope_by_factor(void *ctx, const double *xi)
     double *dir = calloc((size_t)S->p->nvars + 1, sizeof(double));
     for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
     double s = 0.0;
+    double *terms = (g_experiment & 4) ? malloc(sizeof(double) * (size_t)(S->nf + 1)) : NULL;
     for (int64_t i = 0; i < S->nf; ++i) {
         const int n = factor_partials(S->p, S->fac ? S->fac[i] : i, vids, vals);
         double t = 0.0;
         for (int k = 0; k < n && k < 64; ++k) t += vals[k] * dir[vids[k]];
-        s += t;
+        if (terms) terms[i] = t; else s += t;
+    }
+    if (terms) {   /* bit 2: the factors' terms added as a tree (a device's reduction) instead of in list order */
+        s = sum_tree(terms, 0, S->nf);
+        free(terms);
     }
     free(dir);
     return s;

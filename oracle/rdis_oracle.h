@@ -93,7 +93,8 @@ void ro_set_sum_order(ro_problem *p, int which);
  * device's form.  bit 1 (round 5): the slope of a line-search trial added factor by factor, sum_f (sum_k partial_fk xi_k) -- the
  * association the device's fused trials use -- in place of the reference's gradient times direction (Df1dim::df,
  * minimize_nrc.h:439-447); bundle adjustment only.  This is the switch that turns the oracle's population of end values on
- * ladybug 5 / 30 into the device's (tests/test_oracle.py::test_slope_association_moves_the_population). */
+ * ladybug 5 / 30 into the device's (tests/test_oracle.py::test_slope_association_moves_the_population).  bit 2 (with bit 1): those
+ * per-factor terms added as a balanced tree instead of in list order -- the shape of a device's reduction. */
 void ro_set_experiment(int flags);
 
 void ro_assign(ro_problem *p, int64_t nvid, const int64_t *vid, const double *val);

@@ -1552,7 +1552,9 @@ int prepare_partition(rdis_hip_plan* L) {
     // The pipelined layout (solver_pipe.hpp) has half the factor lanes per workgroup: it is used when
     // everything that gets a cooperative group with the plain layout also gets one with it.
     L->use_pipe = false;
-    if (coop_on && L->coop_pipeline != 0 && L->coop_threads == PIPE_THREADS) {
+    // (factor_rounding = 1, the parity option: the reference's slope -- a gradient pass of the whole group per trial and one
+    // sequential sum -- exists in the plain cooperative layout only, solver_coop.hpp)
+    if (coop_on && L->coop_pipeline != 0 && L->factor_rounding != 1 && L->coop_threads == PIPE_THREADS) {
         auto census = [&](int64_t& group_total, int64_t& group_count, int64_t& big_unfit) {
             const int k = cap_of();
             group_total = group_count = big_unfit = 0;

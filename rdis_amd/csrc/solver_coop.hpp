@@ -79,7 +79,11 @@ struct CoopEnv {
     }
     static constexpr bool UNIFORM = true;
     static constexpr int SPEC = COOP_SPEC;   // trial steps per exchange (minimizer.hpp: speculation)
+#ifdef RDIS_REFERENCE_SLOPE
+    __device__ bool spec_on() const { return false; }   // (a trial's slope is a gradient pass of the whole group: one at a time)
+#else
     __device__ bool spec_on() const { return A.speculate != 0; }
+#endif
     __device__ bool stepper() const { return threadIdx.x < 64; }
     __device__ bool writer() const { return (threadIdx.x & 63) == 0; }
     __device__ void sync() const { __syncthreads(); }
@@ -110,19 +114,80 @@ struct CoopEnv {
             if constexpr (SLOPE) {
                 double g[12];
                 fj = ba_eval_grad(v, ox, oy, g);
+#ifdef RDIS_REFERENCE_SLOPE
+                scatter_partials(g);
+#else
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < 12; ++k) acc += g[k] * dirv[k];
                 sj = acc;
+#endif
             } else {
                 fj = ba_eval(v, ox, oy);
             }
         }
+#ifdef RDIS_REFERENCE_SLOPE
+        if constexpr (SLOPE) sj = slope_reference();
+#endif
         X.tm[0] += coop_clock() - tc0;
         X.to_wave0<SLOPE ? 2 : 1>(fj, sj, dummy, SYNC_NONE);  // only the stepping wave consumes a line-search value
         X.finish_wave0(SYNC_NONE);
         f = fj; s = sj;
     }
+#ifdef RDIS_REFERENCE_SLOPE
+    // The slope of a trial the way the reference forms it (Df1dim::df, minimize_nrc.h:439-447, over SubfunctionFD::df,
+    // CGDSubspaceOptimizer.cpp:135-157; solver_lds.hpp's slope_reference has the history): the GRADIENT at the trial point --
+    // every variable's partials added in factor-list order (src/State.h:157-210), a camera's 900 too, by ONE lane -- and then
+    // gradient times direction over the n variables in list order, every product rounded before it is added, by ONE lane of
+    // the group: a sequential sum of 23 769 terms on full ladybug.  Nothing a reduction over 256 compute units can reproduce
+    // (on this problem the population of end values follows the ORDER of that sum), so this instantiation
+    // (refround_kernels.hip, plan option factor_rounding = 1) pays for it: about 0.1 ms a trial.  The products travel through
+    // xi_glob, which nothing reads between line_begin and the next publish_xi.
+    __device__ void scatter_partials(const double (&g)[12]) {
+        const int* sp = L.slot_pos + L.slot_base[c0 + gt];
+        int t[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) t[k] = sp[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (t[k] >= 0) store_f64<true>(L.gfac + t[k], g[k]);
+    }
+    // g[b .. e) added in order by a whole wave: 64 entries per (coalesced, coherent) load, the next 64 in flight, lane after
+    // lane read out of the register and added -- one dependent chain, the bits of the plain loop; the same value in all lanes
+    static __device__ __forceinline__ double wave_sum_in_order(const double* g, int b, int e, int lane) {
+#pragma clang fp contract(off)
+        double acc = 0.0;
+        double cur = b + lane < e ? load_f64<true>(g + b + lane) : 0.0;
+        for (int j0 = b; j0 < e; j0 += 64) {
+            const double nxt = j0 + 64 + lane < e ? load_f64<true>(g + j0 + 64 + lane) : 0.0;
+            const int lo = __double2loint(cur), hi = __double2hiint(cur);
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {   // (entries past the end are zeros: adding them changes nothing)
+                const double t = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                acc = acc + t;
+            }
+            cur = nxt;
+        }
+        return acc;
+    }
+    __device__ double slope_reference() {
+#pragma clang fp contract(off)
+        X.barrier(SYNC_DRAIN);
+        const int* vp = L.v2s_ptr + f0;
+        if (lv.li >= 0) {
+            const double t = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]) * lv.xi;
+            store_f64<true>(A.xi_glob + lv.li, t);
+        }
+        if (wv.li >= 0) {
+            const double t = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63) * wv.xi;
+            if ((tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, t);
+        }
+        X.barrier(SYNC_DRAIN);
+        double acc = 0.0;
+        if (gt < 64) acc = wave_sum_in_order(A.xi_glob, 0, n, tid & 63);   // (the group's first wave)
+        return gt == 0 ? acc : 0.0;   // (the exchange's tree adds zeros to it)
+    }
+#endif
     // SPEC trial steps at once: the evaluations are independent chains in one instruction stream
     // (this wave is alone on its SIMD; a single evaluation is bound by instruction latency), and
     // they share one exchange
@@ -219,9 +284,15 @@ struct CoopEnv {
         if (lv.li >= 0) {  // few partials: serial, in factor-list order (src/State.h:157-210)
             lv.xi = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         }
+#ifdef RDIS_REFERENCE_SLOPE
+        if (wv.li >= 0) {  // (this instantiation: in factor-list order too)
+            wv.xi = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63);
+        }
+#else
         if (wv.li >= 0) {  // many partials: the wave strides over the run, then a butterfly (fixed order)
             wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
         }
+#endif
         tick(20, tg1 - tg0); tick(21, tg2 - tg1); tick(30, coop_clock() - tg2);
     }
     __device__ void publish_xi() {

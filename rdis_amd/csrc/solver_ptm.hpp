@@ -395,10 +395,22 @@ struct PtmEnv {
         // unconditional loads: behind the last run the first row of nothing names chunk 0 -- loaded, never looked at).
         SlotBlock B = N;
         pin_block(B);
+        int nblk = 0;
         for (;;) {   // a run: its trial point from the records; the next run's records
             point_line(R, min(64 * cu + lane, npb - 1), a, x, dp);
             load_recs(cx, R);
             for (;;) {   // its blocks of slots
+                // The waves of a SIMD are not served alike -- the arbiter prefers one, and at two waves a SIMD a slot took 737 .. 1039
+                // cycles by wave (tools/microbench/trial_loop.hip) --, while their shares are equal: the phase waited for the
+                // wave served last.  Issue priority from the count of blocks done, mod 4: a wave one block behind its
+                // neighbours is one level above them.  Scheduling only, the same bits (round 5: 125 components as pairs 14.45
+                // -> 14.05 ms, 1000 components 85.8 -> 84.3).
+                {
+                    const int lv = (0 - nblk) & 3;
+                    if (lv == 3) __builtin_amdgcn_s_setprio(3); else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                    ++nblk;
+                }
                 const int bn = min(PTM_BLK, (e1 - e) >> 6);
                 const int en = e + 64 * PTM_BLK;
                 const bool more = en < e1;
@@ -417,6 +429,7 @@ struct PtmEnv {
             sp += cs;
             vc = sp[0]; v0 = sp[sr]; v1 = sp[2 * sr];
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     // ... at clamp(x_start) (the rollback; value only)
     __device__ void eval_start(double& af) {

@@ -18,6 +18,7 @@ key = "ladybug_5_30" if small else "ladybug_full"
 fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "end_values.json")))
 oe = np.array(fx[key]["end_values"])
 oc = np.array(fx[key]["end_values_contracted"])
+osf = np.array(fx[key]["end_values_slope_by_factor"])   # (tests/golden/make_end_values_slope.py)
 pp = P.load_bal(ncams=5, npts=30) if small else P.load_bal()
 
 
@@ -32,6 +33,7 @@ fv, fc = np.arange(pp.nvars, dtype=np.int64), np.arange(pp.nfac, dtype=np.int64)
 q = lambda v: ("q25 %.4f median %.4f q75 %.4f [%.3f, %.3f]" if small else "q25 %.1f median %.1f q75 %.1f [%.1f, %.1f]") % (*np.quantile(v, [0.25, 0.5, 0.75]), v.min(), v.max())
 print("%s: oracle fixture n %d: %s" % (key, len(oe), q(oe)))
 print("%s: oracle compiled with contraction:  %s   KS against the oracle %.3f" % (key, q(oc), stats.ks_2samp(oc, oe).statistic))
+print("%s: oracle, slope factor by factor:    %s   KS against the oracle %.3f" % (key, q(osf), stats.ks_2samp(osf, oe).statistic))
 SETS = {"default (pipelined cooperative)": {},
         "reference rounding (factor_rounding 1)": {"factor_rounding": 1},
         "cooperative, not pipelined": {"coop_pipeline": 0},
@@ -60,5 +62,11 @@ for name, opts in SETS.items():
     ks = stats.ks_2samp(de, oe)
     kc = stats.ks_2samp(de, oc)
     mw = stats.mannwhitneyu(de, oe)
-    print("%-40s n %d: %s  evals %.0f  kernel %.3f ms  KS vs oracle %.3f (p %.3f), vs contracted oracle %.3f (p %.3f)  MWU p %.3f  %s" % (
-        name, n, q(de), np.mean(nfe), kms / n, ks.statistic, ks.pvalue, kc.statistic, kc.pvalue, mw.pvalue, info), flush=True)
+    kf = stats.ks_2samp(de, osf)
+    if os.environ.get("RDIS_PROBE_SAMPLE"):   # (another sample of end values, a JSON list: an experiment's oracle run)
+        for path in os.environ["RDIS_PROBE_SAMPLE"].split(":"):
+            ox = np.array(json.load(open(path)))
+            kx = stats.ks_2samp(de, ox)
+            print("   against %s (n %d: %s): KS %.3f (p %.3f); that sample against the oracle's: KS %.3f" % (path, len(ox), q(ox), kx.statistic, kx.pvalue, stats.ks_2samp(ox, oe).statistic))
+    print("%-40s n %d: %s  evals %.0f  kernel %.3f ms  KS vs oracle %.3f (p %.3f), vs contracted oracle %.3f (p %.3f), vs by-factor oracle %.3f (p %.3f)  MWU p %.3f  %s" % (
+        name, n, q(de), np.mean(nfe), kms / n, ks.statistic, ks.pvalue, kc.statistic, kc.pvalue, kf.statistic, kf.pvalue, mw.pvalue, info), flush=True)

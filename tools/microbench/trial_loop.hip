@@ -8,7 +8,8 @@
 // same camera, another one each slot (LDS broadcast); 7 no stream, ten lanes a camera, neighbours consecutive cameras (what
 // the plan's order gives the solver on the bench's components: no bank conflicts); 8 as 7 with the stream; 9 as 0 with round
 // 4's direction record (the matrix dR: sixteen doubles, eight reads -- the library's is [w dt df dk1 dk2], ten doubles, five
-// reads, since round 5); 10 as 8 with that record; 11 as 8 with the stream asked for two blocks (four slots) ahead.
+// reads, since round 5); 10 as 8 with that record; 11 as 8 with the stream asked for two blocks (four slots) ahead;
+// 12 as 8 with the wave's priority set by the work it has left (s_setprio: four levels), 13 as 12 with eight steps (level = step & 3... no: two bits of the count).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -52,6 +53,16 @@ __global__ void __launch_bounds__(1024) run(long long* out, double* sink, const 
     if (MODE == 3) { for (int k = 0; k < CAM_TRIAL; ++k) TRr[k] = CTR[TS * (lane % NCAM) + k]; for (int k = 0; k < CAM_DIR; ++k) DRr[k] = CDR[TS * (lane % NCAM) + k]; }
     const long long t0 = clock64();
     for (int s = 0; s < SLOTS; s += 2) {
+        if (MODE == 12) {   // the more slots are left, the higher the wave's priority: the SIMD's laggard goes first
+            const int left = (SLOTS - s) * 4 / (SLOTS + 1);
+            if (left >= 3) __builtin_amdgcn_s_setprio(3); else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+        if (MODE == 13) {   // ... by the low bits of the count of blocks left: a wave one block behind is one level up (mod 4)
+            const int left = ((SLOTS - s) >> 1) & 3;
+            if (left == 3) __builtin_amdgcn_s_setprio(3); else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         int b0 = c0, b1 = c1; double2 p0 = o0, p1 = o1;
         asm volatile("" : "+v"(b0), "+v"(b1), "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y));
         if (MODE == 11) {
@@ -162,5 +173,7 @@ int main() {
     go<9>("round 4's direction record (8 reads)", d_out, d_sink, pcam, pobs);
     go<10>("... neighbouring cameras", d_out, d_sink, pcam, pobs);
     go<11>("neighbouring cameras, stream 2 ahead", d_out, d_sink, pcam, pobs);
+    go<12>("... priority by the work left", d_out, d_sink, pcam, pobs);
+    go<13>("... priority by blocks left mod 4", d_out, d_sink, pcam, pobs);
     return 0;
 }
