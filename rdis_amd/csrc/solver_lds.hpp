@@ -234,7 +234,18 @@ struct LdsEnv {
         unsigned wn = 0u;
         double2 on = make_double2(0.0, 0.0);
         if (PREFETCH && j < m) { wn = fidx[j]; on = fobs[j]; }
+        // (a workgroup with several passes over its lanes: issue priority from the count of passes done, as in solver_ptm.hpp's trial
+        // loop -- the SIMD's arbiter does not serve its waves alike, and the sums wait for the last; ladybug's 49 camera components
+        // 23.7 -> 22.5 ms.  Not for one or two passes: with many small workgroups on a compute unit it only costs, +1 .. 4 %)
+        const bool prio = m > 2 * nt;
+        int nit = 0;
         for (; j < m; j += nt) {
+            if (prio) {
+                const int lv = (0 - nit) & 3;
+                if (lv == 3) __builtin_amdgcn_s_setprio(3); else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+                else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                ++nit;
+            }
             unsigned w;
             double2 o;
             if constexpr (PREFETCH) {
@@ -275,6 +286,7 @@ struct LdsEnv {
 #endif
             }
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
     }
     // ... in matrix form: the factor against its camera's trial records (88 fp64 operations for value and slope where the vector form
     // takes 164; same model, another association of the same sums: values agree to 1e-13, slopes to 1e-11 of their terms,
