@@ -1986,7 +1986,7 @@ int prepare_partition(rdis_hip_plan* L) {
                            L->coop_ints.as<int>() + it.lane_var, L->coop_ints.as<int>() + it.wave_var, L->xi_glob.as<double>() + it.xi_off, it.comp,
                            // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
                            it.nwg * (L->coop_lanes() / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay,
-                           L->coop_speculate};
+                           L->coop_speculate, L->factor_rounding == 1 ? 1 : 0};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
             hg.push_back(g);
             hw.insert(hw.end(), (size_t)it.nwg, cl.count);

@@ -46,6 +46,8 @@ struct CoopArgs {
     int comp;
     int poll_delay;        // x64 cycles between publishing and the first sweep (a store needs about that long to land)
     int speculate;         // evaluate guesses at the following trial steps with every line-search trial (minimizer.hpp)
+    int reference_slope;   // plan option factor_rounding = 1: a trial's slope formed the reference's way (slope_reference, below;
+                           // looked at by the reference-rounding instantiation only, refround_kernels.hip)
 };
 
 // the CG recurrence of one free variable
@@ -80,7 +82,7 @@ struct CoopEnv {
     static constexpr bool UNIFORM = true;
     static constexpr int SPEC = COOP_SPEC;   // trial steps per exchange (minimizer.hpp: speculation)
 #ifdef RDIS_REFERENCE_SLOPE
-    __device__ bool spec_on() const { return false; }   // (a trial's slope is a gradient pass of the whole group: one at a time)
+    __device__ bool spec_on() const { return A.speculate != 0 && A.reference_slope == 0; }   // (the reference's slope is a gradient pass of the whole group: one trial at a time)
 #else
     __device__ bool spec_on() const { return A.speculate != 0; }
 #endif
@@ -115,19 +117,21 @@ struct CoopEnv {
                 double g[12];
                 fj = ba_eval_grad(v, ox, oy, g);
 #ifdef RDIS_REFERENCE_SLOPE
-                scatter_partials(g);
-#else
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 12; ++k) acc += g[k] * dirv[k];
-                sj = acc;
+                if (A.reference_slope) scatter_partials(g);
+                else
 #endif
+                {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) acc += g[k] * dirv[k];
+                    sj = acc;
+                }
             } else {
                 fj = ba_eval(v, ox, oy);
             }
         }
 #ifdef RDIS_REFERENCE_SLOPE
-        if constexpr (SLOPE) sj = slope_reference();
+        if constexpr (SLOPE) { if (A.reference_slope) sj = slope_reference(); }
 #endif
         X.tm[0] += coop_clock() - tc0;
         X.to_wave0<SLOPE ? 2 : 1>(fj, sj, dummy, SYNC_NONE);  // only the stepping wave consumes a line-search value
@@ -140,8 +144,9 @@ struct CoopEnv {
     // every variable's partials added in factor-list order (src/State.h:157-210), a camera's 900 too, by ONE lane -- and then
     // gradient times direction over the n variables in list order, every product rounded before it is added, by ONE lane of
     // the group: a sequential sum of 23 769 terms on full ladybug.  Nothing a reduction over 256 compute units can reproduce
-    // (on this problem the population of end values follows the ORDER of that sum), so this instantiation
-    // (refround_kernels.hip, plan option factor_rounding = 1) pays for it: about 0.1 ms a trial.  The products travel through
+    // (on this problem the population of end values follows the ORDER of that sum), so the parity option
+    // (plan option factor_rounding = 1 -> CoopArgs::reference_slope, in the instantiation of refround_kernels.hip) pays for it:
+    // about 0.3 ms a trial.  The products travel through
     // xi_glob, which nothing reads between line_begin and the next publish_xi.
     __device__ void scatter_partials(const double (&g)[12]) {
         const int* sp = L.slot_pos + L.slot_base[c0 + gt];
@@ -285,14 +290,13 @@ struct CoopEnv {
             lv.xi = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]);
         }
 #ifdef RDIS_REFERENCE_SLOPE
-        if (wv.li >= 0) {  // (this instantiation: in factor-list order too)
+        if (wv.li >= 0 && A.reference_slope) {  // (the parity option: in factor-list order too)
             wv.xi = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63);
-        }
-#else
+        } else
+#endif
         if (wv.li >= 0) {  // many partials: the wave strides over the run, then a butterfly (fixed order)
             wv.xi = wave_sum(run_sum_strided<true>(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63));
         }
-#endif
         tick(20, tg1 - tg0); tick(21, tg2 - tg1); tick(30, coop_clock() - tg2);
     }
     __device__ void publish_xi() {

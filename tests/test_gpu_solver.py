@@ -1036,6 +1036,48 @@ def test_cooperative_groups_side_by_side(gctx):
     assert abs(np.sum(r1.fret) - np.sum(rw.fret)) <= 0.05 * np.sum(rw.fret)     # same algorithm, sums in another order, 25 unconverged iterations
 
 
+def test_cooperative_groups_side_by_side_with_the_reference_slope(gctx):
+    """the parity option (factor_rounding = 1) where several cooperative groups share a launch: every group forms its trials'
+    slopes the reference's way in its own part of the exchange arrays (solver_coop.hpp: slope_reference).  Members replay
+    against the oracle; the same groups packed into smaller launches give the same bits; and the option is another
+    trajectory than the default's."""
+    pp = P.load_bal()
+    cams, _ = P.ba_alternation_plans(pp)
+    free_ptr, free_vid, fac_ptr, fac_id = cams
+    g = capi.Problem(gctx, pp)
+    out = {}
+    for mode in ("one launch", "chunks", "default rounding"):
+        g.set_x(pp.x0)
+        plan = capi.Plan(g, *cams)
+        if mode != "default rounding":
+            plan.set_option("factor_rounding", 1)
+        plan.set_option("lds_resident", 0)                     # (the cooperative groups, not the LDS-resident batch solver)
+        if mode == "chunks":
+            plan.set_option("coop_workgroups", 16)
+            plan.set_option("coop_min_factors", 300)
+            plan.set_option("coop_max_components", 49)
+        plan.set_option("trace_records", 4096)
+        plan.set_option("dump_iters", 12)
+        plan.set_start(None)
+        plan.solve(12, 3e-8)
+        r = plan.fetch()
+        assert plan.info("components_cooperative") == 49, (mode, plan.info("components_cooperative"))
+        if mode != "default rounding":
+            assert plan.info("pipelined") == 0, mode                     # (the reference's slope exists in the plain layout)
+        out[mode] = r
+        assert np.all(r.delta <= 0) and np.array_equal(g.get_x()[free_vid], r.x)
+        if mode == "one launch":
+            for c in (0, 17, 48):
+                fv, fc = free_vid[free_ptr[c]:free_ptr[c + 1]], fac_id[fac_ptr[c]:fac_ptr[c + 1]]
+                sub = type("R", (), {"status": r.status[c:c + 1], "iters": r.iters[c:c + 1], "fret": r.fret[c:c + 1]})
+                # (a camera component's gg / dgg are sums of nine terms that cancel: 1e-8, as for the other solvers' camera members)
+                check_replay(pp, (plan.get_trace(c, 4096)[0], plan.get_vectors(c, 12)), sub, 12, free_vid=fv, fac_id=fc, x=pp.x0[fv], iter_tol=1e-8)
+        plan.close()
+    r1, rc, rd = out["one launch"], out["chunks"], out["default rounding"]
+    assert np.array_equal(r1.fret, rc.fret) and np.array_equal(r1.x, rc.x) and np.array_equal(r1.nfeval, rc.nfeval)
+    assert not np.array_equal(r1.fret, rd.fret) and abs(np.sum(r1.fret) - np.sum(rd.fret)) <= 0.05 * np.sum(rd.fret)
+
+
 @pytest.mark.parametrize("lanes", [4, 16])
 def test_persistent_groups_take_components_off_the_list(gctx, lanes):
     """the tiny-component kernels are persistent: with the grid capped at one block (64 or 4
