@@ -304,7 +304,7 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
            "ks_device_vs_oracle": ks(de, oe),
            "ks_critical_alpha_0.05": float(1.358 * np.sqrt((len(de) + len(oe)) / (len(de) * len(oe)))),
            "reference_recorded": 83227.604227756252,
-           "parity_option": "plan option factor_rounding = 1 adds a trial's slope in the reference's order too (one sequential sum per trial: 0.26 s a solve, "
+           "parity_option": "plan option factor_rounding = 1 adds a trial's slope in the reference's order too (one sequential sum per trial: 0.18 s a solve, "
                             "so not drawn here); under -m gpu, tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle asserts the plain two-sample "
                             "test for it on this workload (measured KS 0.056 at n = 320, critical 0.107) and, for the default drawn here, that the device is no "
                             "further from the oracle than the oracle's own rounding variants are from one another (DESIGN.md section 6)"}

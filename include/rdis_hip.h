@@ -273,7 +273,7 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * slope is formed the reference's way -- the gradient at the trial point, every variable's partials in factor-list order, then
  * gradient times direction over the variables in list order (Df1dim::df): a full gradient per trial in the LDS-resident batch
  * solver (seven times slower) and, for a cooperative group, in the plain layout with one sequential sum per trial (full ladybug:
- * 0.26 s a solve instead of 2.5 ms); with it the end values over one-ulp starts pass the plain two-sample test against the
+ * 0.18 s a solve instead of 2.5 ms); with it the end values over one-ulp starts pass the plain two-sample test against the
  * reference-faithful oracle on BASELINE configs 3 and 4; refused where other solvers would run; -1 = default: the cooperative
  * solvers round like the reference (4 % slower) and keep their parallel slope, the batch solvers fuse.  After 25 unconverged
  * CG iterations the DISTRIBUTION of end values over one-ulp starts depends on all of that: DESIGN.md section 6),

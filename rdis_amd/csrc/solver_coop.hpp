@@ -146,7 +146,7 @@ struct CoopEnv {
     // the group: a sequential sum of 23 769 terms on full ladybug.  Nothing a reduction over 256 compute units can reproduce
     // (on this problem the population of end values follows the ORDER of that sum), so the parity option
     // (plan option factor_rounding = 1 -> CoopArgs::reference_slope, in the instantiation of refround_kernels.hip) pays for it:
-    // about 0.3 ms a trial.  The products travel through
+    // about 0.2 ms a trial.  The products travel through
     // xi_glob, which nothing reads between line_begin and the next publish_xi.
     __device__ void scatter_partials(const double (&g)[12]) {
         const int* sp = L.slot_pos + L.slot_base[c0 + gt];
@@ -157,23 +157,35 @@ struct CoopEnv {
         for (int k = 0; k < 12; ++k)
             if (t[k] >= 0) store_f64<true>(L.gfac + t[k], g[k]);
     }
-    // g[b .. e) added in order by a whole wave: 64 entries per (coalesced, coherent) load, the next 64 in flight, lane after
-    // lane read out of the register and added -- one dependent chain, the bits of the plain loop; the same value in all lanes
-    static __device__ __forceinline__ double wave_sum_in_order(const double* g, int b, int e, int lane) {
+    // g[b .. e) added in order by a whole wave: 64 entries per (coalesced, coherent) load, the next 64 in flight; the wave parks
+    // them in LDS and its first lane reads them back sixteen at a time and adds them -- one dependent chain, the bits of the
+    // plain loop (entries past the end are zeros: adding them changes nothing); the same value in all lanes
+    static __device__ __forceinline__ double wave_sum_in_order(const double* g, int b, int e, int tid) {
 #pragma clang fp contract(off)
+        __shared__ __attribute__((aligned(16))) double park[16][64];
+        const int lane = tid & 63;
+        double* mine = park[(tid >> 6) & 15];
         double acc = 0.0;
         double cur = b + lane < e ? load_f64<true>(g + b + lane) : 0.0;
         for (int j0 = b; j0 < e; j0 += 64) {
             const double nxt = j0 + 64 + lane < e ? load_f64<true>(g + j0 + 64 + lane) : 0.0;
-            const int lo = __double2loint(cur), hi = __double2hiint(cur);
+            mine[lane] = cur;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                const double2* q = reinterpret_cast<const double2*>(mine);
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {   // (entries past the end are zeros: adding them changes nothing)
-                const double t = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
-                acc = acc + t;
+                for (int j = 0; j < 32; j += 8) {
+                    double2 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = q[j + k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { acc = acc + t[k].x; acc = acc + t[k].y; }
+                }
             }
+            __builtin_amdgcn_wave_barrier();
             cur = nxt;
         }
-        return acc;
+        return __shfl(acc, 0);
     }
     __device__ double slope_reference() {
 #pragma clang fp contract(off)
@@ -184,12 +196,12 @@ struct CoopEnv {
             store_f64<true>(A.xi_glob + lv.li, t);
         }
         if (wv.li >= 0) {
-            const double t = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63) * wv.xi;
+            const double t = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid) * wv.xi;
             if ((tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, t);
         }
         X.barrier(SYNC_DRAIN);
         double acc = 0.0;
-        if (gt < 64) acc = wave_sum_in_order(A.xi_glob, 0, n, tid & 63);   // (the group's first wave)
+        if (gt < 64) acc = wave_sum_in_order(A.xi_glob, 0, n, tid);   // (the group's first wave)
         return gt == 0 ? acc : 0.0;   // (the exchange's tree adds zeros to it)
     }
 #endif
@@ -291,7 +303,7 @@ struct CoopEnv {
         }
 #ifdef RDIS_REFERENCE_SLOPE
         if (wv.li >= 0 && A.reference_slope) {  // (the parity option: in factor-list order too)
-            wv.xi = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid & 63);
+            wv.xi = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid);
         } else
 #endif
         if (wv.li >= 0) {  // many partials: the wave strides over the run, then a butterfly (fixed order)

@@ -254,7 +254,7 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     Plan option factor_rounding = 1 runs the solvers these configs reach with the reference's rounding AND its slope: the
     gradient at the trial point, every variable's partials in factor-list order, then gradient times direction over the
     variables in list order -- on full ladybug one sequential sum of 23 769 terms by one wave (solver_coop.hpp:
-    slope_reference; 0.26 s a solve instead of 2.5 ms: a parity option).  Asserted for it, with as many device draws as the
+    slope_reference; 0.18 s a solve instead of 2.5 ms: a parity option).  Asserted for it, with as many device draws as the
     fixture has oracle draws, from OTHER one-ulp starts, at alpha = 0.05:
       * the PLAIN two-sample test, KS(device, oracle) <= the critical value, on both configs (measured: 0.045 on 5 / 30,
         p = 0.7; 0.056 on full ladybug, p = 0.7 -- round 5; before the slope's order was the reference's: 0.125 .. 0.133);
