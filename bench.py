@@ -273,19 +273,22 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
     def ulp(x, k):
         rng = np.random.default_rng([fx["seed"], 200000 + k])
         return np.nextafter(x, np.where(rng.random(x.shape) < 0.5, -np.inf, np.inf))
-    def draw(opts):
+    def draw(opts, n=None):
         for k, v in opts.items():
             plan.set_option(k, v)
         out, kms = [], 0.0
-        for k in range(k_dev):
+        for k in range(k_dev if n is None else n):
             plan.set_start((pp.x0 if k == 0 else ulp(pp.x0, k))[pp.comp_free_vid])
             plan.solve(maxiters, 3e-8)
             out.append(float(plan.fetch().fret.sum()))
             kms += plan.last_kernel_ms()[0]
-        return np.array(out), kms / k_dev
+        return np.array(out), kms / len(out)
     # the default (the cooperative solvers round like the reference's build) and the same solver with fused multiply-adds
     de, ms_ref = draw({"factor_rounding": -1})
     df, ms_fma = draw({"factor_rounding": 0})
+    # ... and a short sample of the parity option (the reference's slope: one sequential sum per trial, 0.18 s a solve; the full
+    # sample and the plain two-sample test are tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle)
+    dp, ms_par = draw({"factor_rounding": 1}, n=48)
     plan.set_option("factor_rounding", -1)
     plan.set_start(pp.x0[pp.comp_free_vid])
 
@@ -304,8 +307,11 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
            "ks_device_vs_oracle": ks(de, oe),
            "ks_critical_alpha_0.05": float(1.358 * np.sqrt((len(de) + len(oe)) / (len(de) * len(oe)))),
            "reference_recorded": 83227.604227756252,
+           "device_parity_option": dict(q(dp), rounding="factor_rounding = 1: the reference's rounding AND a trial's slope added in the reference's order",
+                                        kernel_ms=ms_par, ks_vs_oracle=ks(dp, oe),
+                                        ks_critical_alpha_0_05=float(1.358 * np.sqrt((len(dp) + len(oe)) / (len(dp) * len(oe))))),
            "parity_option": "plan option factor_rounding = 1 adds a trial's slope in the reference's order too (one sequential sum per trial: 0.18 s a solve, "
-                            "so not drawn here); under -m gpu, tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle asserts the plain two-sample "
+                            "so only 48 draws here: device_parity_option); under -m gpu, tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle asserts the plain two-sample "
                             "test for it on this workload (measured KS 0.056 at n = 320, critical 0.107) and, for the default drawn here, that the device is no "
                             "further from the oracle than the oracle's own rounding variants are from one another (DESIGN.md section 6)"}
     if len(oc):
