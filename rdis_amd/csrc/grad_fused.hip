@@ -25,7 +25,9 @@ __device__ __forceinline__ double chunk_sum_of(const double* red) {
     return r;
 }
 
-template <int KIND>
+// ROT = ROT_CAMFIX: the cameras' rotation records (P.xrot, camera_rotations_kernel) are current for the assigned x -- the factor
+// reads angle, axis, sine and cosine instead of forming them (the same arithmetic once per camera: the same bits)
+template <int KIND, int ROT = ROT_PER_FACTOR>
 __global__ void __launch_bounds__(GRAD_LANES)
 eval_chunks_kernel(ProblemView P, int nf, const int* __restrict__ fac, double* __restrict__ partial) {
     __shared__ double red[GRAD_LANES / 64];
@@ -33,7 +35,7 @@ eval_chunks_kernel(ProblemView P, int nf, const int* __restrict__ fac, double* _
     for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
         const int j = ch * GRAD_LANES + (int)threadIdx.x;
         double f = 0.0, s;
-        if (j < nf) factor_value<KIND, false>(P, nullptr, fac ? fac[j] : j, f, s);
+        if (j < nf) factor_value<KIND, false, ROT>(P, nullptr, fac ? fac[j] : j, f, s);
         f = wave_sum(f);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = f;
         __syncthreads();
@@ -225,7 +227,8 @@ hipError_t grad_combine_launch(hipStream_t s, int grid, const GradTables& T, con
     return hipGetLastError();
 }
 hipError_t eval_chunks_launch(hipStream_t s, int grid, const ProblemView& P, int nf, const int* fac, double* partial) {
-    if (P.kind == KIND_BA) eval_chunks_kernel<KIND_BA><<<grid, GRAD_LANES, 0, s>>>(P, nf, fac, partial);
+    if (P.kind == KIND_BA && P.rot_mode == ROT_CAMFIX && P.xrot != nullptr) eval_chunks_kernel<KIND_BA, ROT_CAMFIX><<<grid, GRAD_LANES, 0, s>>>(P, nf, fac, partial);
+    else if (P.kind == KIND_BA) eval_chunks_kernel<KIND_BA><<<grid, GRAD_LANES, 0, s>>>(P, nf, fac, partial);
     else eval_chunks_kernel<KIND_NLP><<<grid, GRAD_LANES, 0, s>>>(P, nf, fac, partial);
     return hipGetLastError();
 }

@@ -998,7 +998,13 @@ extern "C" int rdis_hip_eval(rdis_hip_problem* p, int64_t nf, const int64_t* fac
         // chunk by chunk, the chunks' sums added in a fixed order: the value rdis_hip_eval_grad returns, bit for bit
         const int nchunks = (int)((nf + GRAD_LANES - 1) / GRAD_LANES);
         if ((rc = ensure(c, p->partial, (size_t)nchunks * sizeof(double)))) return rc;
-        HIPCHK(c, eval_chunks_launch(c->stream, std::min(nchunks, 16 * std::max(1, c->num_cus)), p->view(), (int)nf, dfac, p->partial.as<double>()));
+        ProblemView V = p->view();
+        if (nf >= 4 * p->ncam_blocks) {   // a long list: the cameras' rotation records once per camera instead of once per factor (the same bits)
+            camera_rotations_kernel<<<(int)((p->ncam_blocks + 255) / 256), 256, 0, c->stream>>>(p->x.as<double>(), p->cam_blocks.as<int>(), (int)p->ncam_blocks,
+                                                                                                p->xrot.as<double>());
+            V.xrot = p->xrot.as<double>(); V.rot_mode = ROT_CAMFIX;
+        }
+        HIPCHK(c, eval_chunks_launch(c->stream, std::min(nchunks, 16 * std::max(1, c->num_cus)), V, (int)nf, dfac, p->partial.as<double>()));
         final_sum_kernel<<<1, 256, 0, c->stream>>>(nchunks, p->partial.as<double>(), p->scalar.as<double>());
         HIPCHK(c, hipGetLastError());
     } else {
