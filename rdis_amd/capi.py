@@ -334,10 +334,14 @@ class Problem:
         self.ctx.check(self.ctx.lib.rdis_hip_eval(self.h, nf, _ptr(fac), C.byref(f)))
         return f.value
 
-    def eval_grad(self, fac=None):
+    def eval_grad(self, fac=None, out=None):
+        """(value, gradient); out: a float64 array of nvars to receive the gradient (a caller that evaluates repeatedly keeps
+        one: a fresh 49 MB array costs more in page faults than the copy from the device)"""
         fac, nf = self._nf(fac)
         f = C.c_double()
-        g = np.empty(self.nvars)
+        g = np.empty(self.nvars) if out is None else out
+        if g.dtype != np.float64 or g.shape != (self.nvars,) or not g.flags.c_contiguous:
+            raise ValueError("out must be a contiguous float64 array of nvars")
         self.ctx.check(self.ctx.lib.rdis_hip_eval_grad(self.h, nf, _ptr(fac), C.byref(f), _ptr(g)))
         return f.value, g
 

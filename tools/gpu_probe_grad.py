@@ -19,7 +19,9 @@ g.set_x(huge.x0)
 t0 = time.perf_counter(); f0, g0 = g.eval_grad(); t1 = time.perf_counter()
 print("first call (tables built): %.1f ms" % ((t1 - t0) * 1e3))
 alg = 24 * huge.nfac + 16 * huge.nvars + 8
-for name, fn in (("rdis_hip_eval (value)", g.eval), ("rdis_hip_eval_grad (g copied to the host)", g.eval_grad)):
+gbuf = np.empty(huge.nvars)
+for name, fn in (("rdis_hip_eval (value)", g.eval), ("rdis_hip_eval_grad (g copied to the host, a fresh array per call)", g.eval_grad),
+                 ("rdis_hip_eval_grad (g copied to the host, the caller's array reused)", lambda: g.eval_grad(out=gbuf))):
     t0 = time.perf_counter()
     for _ in range(REPS): fn()
     dt = (time.perf_counter() - t0) / REPS
