@@ -129,6 +129,11 @@ int rdis_hip_eval(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f
 int rdis_hip_eval_grad(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *f, double *g);
 int rdis_hip_eval_grad_device(rdis_hip_problem *p, int64_t nf, const int64_t *fac, void **f_dev, void **g_dev);
 int rdis_hip_eval_each(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *fvals);
+/* how eval_each / grad_each_ba round a bundle-adjustment factor's arithmetic: 0 (default) = one fused multiply-add where the
+ * model has a * b + c, 1 = every product rounded before it is added, like the reference's x86-64 build -- the arithmetic of the
+ * solvers' parity option (plan option "factor_rounding" = 1), so that tests can compare it factor by factor, bit for bit,
+ * with a CPU restatement (BundleAdjustmentFactor.cpp:160-185, 266-335) */
+int rdis_hip_set_factor_rounding(rdis_hip_problem *p, int32_t mode);
 int rdis_hip_grad_each_ba(rdis_hip_problem *p, int64_t nf, const int64_t *fac, double *g12);
 
 /* ---- a second subspace solver: Levenberg-Marquardt (bundle adjustment) ---------------
@@ -269,17 +274,24 @@ int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
  * that share one such component when the launch has fewer components than compute units: 0 = auto,
  * 1 = never, k <= 16 = k),
  * "factor_rounding" (how the factor arithmetic rounds a * b + c: 0 = one fused multiply-add; 1 = the PARITY option: the product
- * is rounded before it is added, like the reference's x86-64 build (g++ emits no fused multiply-add), and a line-search trial's
- * slope is formed the reference's way -- the gradient at the trial point, every variable's partials in factor-list order, then
- * gradient times direction over the variables in list order (Df1dim::df): a full gradient per trial in the LDS-resident batch
- * solver (seven times slower) and, for a cooperative group, in the plain layout with one sequential sum per trial (full ladybug:
- * 0.18 s a solve instead of 2.5 ms); with it the end values over one-ulp starts pass the plain two-sample test against the
- * reference-faithful oracle on BASELINE configs 3 and 4; refused where other solvers would run; -1 = default: the cooperative
- * solvers round like the reference (4 % slower) and keep their parallel slope, the batch solvers fuse.  After 25 unconverged
- * CG iterations the DISTRIBUTION of end values over one-ulp starts depends on all of that: DESIGN.md section 6),
+ * is rounded before it is added, like the reference's x86-64 build (g++ emits no fused multiply-add), and EVERY sum of a solve is
+ * added in the reference's order by one lane (or one wave feeding one lane): the objective over the listed factors
+ * (OptimizableFunction.cpp:95-135), every variable's partials in factor-list order (State.h:157-210), a trial's slope as gradient
+ * times direction over the variables in list order (Df1dim::df, minimize_nrc.h:439-447), gg and dgg of the Polak-Ribiere step
+ * (minimize_nrc.h:665-672).  With it -- and "emulate_stale_cache" -- a solve returns, bit for bit (==: fret, x, iterations, call
+ * counts), what the CPU oracle returns when its three named switches for the device's factor arithmetic are on (its own sine /
+ * cosine of the rotation angle, two reciprocals in place of five quotients, the adjoint sweep in place of the reference's forward
+ * chain: oracle/rdis_oracle.h RO_ARITH_*, RO_BA_DERIV_ADJOINT_DEVICE), on BASELINE configs 3 and 4, from x0, 25 iterations, no
+ * re-synchronisation (tests/test_gpu_parity.py); and the end values over one-ulp starts pass the plain two-sample test against the
+ * reference-faithful oracle.  A parity option, not a fast path: the LDS-resident batch solver pays a full gradient and four
+ * sequential sums per trial, a cooperative group runs in the plain layout with two sequential sums per trial (full ladybug: 0.4 s a
+ * solve instead of 2.5 ms); refused where other solvers would run; -1 = default: the cooperative solvers round like the reference
+ * (4 % slower) and keep their parallel sums, the batch solvers fuse.  After 25 unconverged CG iterations the DISTRIBUTION of end
+ * values over one-ulp starts depends on all of that: DESIGN.md section 6),
  * "emulate_stale_cache" (default 0; 1 = the reference's factor cache, Variable.cpp:66-76 and
  * Factor.h:228-234 -- a factor keeps its value while its variables have moved by less than 1e-12 since
- * it was computed -- emulated in the LDS-resident batch solver; refused where other solvers would run),
+ * it was computed -- emulated in the LDS-resident batch solver and, with factor_rounding = 1, in the cooperative solver's plain
+ * layout; refused where other solvers would run),
  * "trace_records" (per-component trace capacity, 0 = off), "dump_iters" (record p and
  * the search direction at the start of the first k line minimisations, 0 = off). */
 int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t value);

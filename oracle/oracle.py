@@ -80,6 +80,10 @@ def lib() -> C.CDLL:
         L.ro_ba_factor_grad_ref.restype = C.c_double
         L.ro_ba_factor_grad_ref.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
         L.ro_set_ba_derivative.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+        L.ro_ba_factor_grad_device.restype = C.c_double
+        L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
+        L.ro_sincos_angle.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ro_create_ba.restype = C.c_void_p
         L.ro_create_ba.argtypes = [C.c_int64, _f64p, _f64p, _f64p, C.c_int64, _i64p, _i64p, _f64p]
         L.ro_create_nlp.restype = C.c_void_p
@@ -126,10 +130,15 @@ def _opt_i64(a):
 class OracleProblem:
     """CPU oracle instance for one rdis_amd.problems.PackedProblem."""
 
-    def __init__(self, pp, emulate_stale_cache: bool = True, derivative: str = "refchain", sum_order: str = "list"):
+    def __init__(self, pp, emulate_stale_cache: bool = True, derivative: str = "refchain", sum_order: str = "list",
+                 arithmetic: str = "reference"):
         """derivative: "refchain" = the reference's forward chain operation by operation
         (BundleAdjustmentFactor.cpp:351-554; reproduces the reference's recorded runs bit for bit),
-        "adjoint" = the independent reverse sweep (the derivation the device kernels use)"""
+        "adjoint" = the independent reverse sweep (the derivation the device kernels use),
+        "adjoint_device" = that sweep in the device's association (RO_BA_DERIV_ADJOINT_DEVICE).
+        arithmetic: "reference" (every pin is made with it) or "device" = the named switches of rdis_oracle.h
+        (RO_ARITH_RECIPROCAL | RO_ARITH_SINCOS_ANGLE) -- with derivative "adjoint_device" the factor arithmetic of the
+        device's parity option (plan option factor_rounding = 1), bit for bit."""
         L = lib()
         self.pp = pp
         x0 = np.ascontiguousarray(pp.x0, dtype=np.float64)
@@ -145,6 +154,17 @@ class OracleProblem:
         L.ro_set_emulate_stale_cache(self.h, int(emulate_stale_cache))
         L.ro_set_sum_order(self.h, {"list": 0, "pairwise": 1}[sum_order])   # (an experiment's switch; "list" is the reference's)
         self.set_derivative(derivative)
+        self.set_arithmetic(arithmetic)
+
+    @classmethod
+    def device_parity(cls, pp, emulate_stale_cache: bool = True):
+        """the CPU side of the end-to-end == tests: the reference's algorithm, sums and stale factor cache with the three
+        named last-place differences of the device's factor arithmetic switched on"""
+        return cls(pp, emulate_stale_cache=emulate_stale_cache, derivative="adjoint_device", arithmetic="device")
+
+    def set_arithmetic(self, arithmetic) -> None:
+        flags = {"reference": 0, "device": 3, "reciprocal": 1, "sincos_angle": 2}.get(arithmetic, arithmetic)
+        lib().ro_set_arithmetic(self.h, int(flags))
 
     def set_exponential(self, use_exp) -> None:
         """useExponential per factor (NonlinearProductFactor.cpp:140); values only, None clears"""
@@ -153,7 +173,7 @@ class OracleProblem:
             raise ValueError("not a nonlinear-product problem")
 
     def set_derivative(self, derivative: str) -> None:
-        lib().ro_set_ba_derivative(self.h, {"refchain": 0, "adjoint": 1}[derivative])
+        lib().ro_set_ba_derivative(self.h, {"refchain": 0, "adjoint": 1, "adjoint_device": 2}[derivative])
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -271,6 +291,13 @@ def ba_factor_eval(vals, ox, oy) -> float:
 def ba_factor_grad(vals, ox, oy):
     g = np.empty(12)
     e = lib().ro_ba_factor_grad(np.ascontiguousarray(vals, dtype=np.float64), ox, oy, g)
+    return e, g
+
+
+def ba_factor_grad_device(vals, ox, oy):
+    """value + partials in the device's parity-option arithmetic (all three named switches on)"""
+    g = np.empty(12)
+    e = lib().ro_ba_factor_grad_device(np.ascontiguousarray(vals, dtype=np.float64), ox, oy, g)
     return e, g
 
 

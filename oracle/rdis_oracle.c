@@ -27,6 +27,7 @@ typedef struct {
     double pp[2];     /* -P.xy / P.z */
     double r2, dstn;  /* |pp|^2 and 1 + k1 r2 + k2 r2^2 */
     double res[2];    /* pixel residual */
+    double it, iz;    /* 1 / theta and 1 / P_z (the device's form, RO_ARITH_RECIPROCAL) */
 } ba_fwd;
 
 /* Forward projection.  Snavely camera: angle-axis rotation (Rodrigues),
@@ -45,14 +46,49 @@ static int g_experiment = 0;
 void ro_set_experiment(int flags) { g_experiment = flags; }
 static double (*g_slope_by_factor)(void *ctx, const double *xi) = 0;
 
-static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
+/* RO_ARITH_SINCOS_ANGLE: sine and cosine of the rotation angle by the DEVICE's routine (rdis_amd/csrc/factors.hpp
+ * sincos_angle) instead of the C library's: one Cody-Waite reduction by pi/2 in three pieces (the first product exact in a
+ * fused multiply-add, the tail carried along) and the fdlibm minimax kernels on [-pi/4, pi/4].  Restated operation by operation
+ * -- with -ffp-contract=off this file rounds every other product before it is added, like the device's reference-rounding
+ * instantiation (refround_kernels.hip) -- so that it returns the device's bits.  Below 1 ulp like the library's, and not the
+ * reference's: one of the three named last-place differences between the device's parity option and the reference
+ * (DESIGN.md section 6).  x >= 0; beyond 1e6 (never a rotation angle) the library is used, as on the device. */
+void ro_sincos_angle(double x, double *sn, double *cs)
+{
+    if (!(x < 1.0e6)) { *sn = sin(x); *cs = cos(x); return; }
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    const int n = (int)fn;
+    double t = fma(-fn, 1.57079632673412561417e+00, x);
+    double w = fn * 6.07710050630396597660e-11;
+    const double r = t - w;
+    w = fma(fn, 2.02226624879595063154e-21, -((t - r) - w));
+    const double y = r - w;
+    const double yt = (r - y) - w;
+    const double z = y * y, z2 = z * z;
+    const double sr = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * 2.75573137070700676789e-06)
+                    + z * z2 * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10);
+    const double v = z * y;
+    const double ks = y - ((z * (0.5 * yt - v * sr) - yt) - v * -1.66666666666666324348e-01);
+    const double cr = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05))
+                    + (z2 * z2) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+    const double hz = 0.5 * z, wc = 1.0 - hz;
+    const double kc = wc + (((1.0 - wc) - hz) + (z * cr - y * yt));
+    const double s0 = (n & 1) ? kc : ks, c0 = (n & 1) ? ks : kc;
+    *sn = (n & 2) ? -s0 : s0;
+    *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
+/* arith: RO_ARITH_* flags (0 = the reference's arithmetic) */
+static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t, int arith)
 {
     const double *r = x, *tr = x + 3, *q = x + 9;
     const double f = x[6], k1 = x[7], k2 = x[8];
+    if (g_experiment & 1) arith |= RO_ARITH_RECIPROCAL;
 
     t->theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (t->theta != 0.0 && (g_experiment & 1)) {
-        const double it = 1.0 / t->theta;
+    t->it = 1.0 / t->theta;
+    if (t->theta != 0.0 && (arith & RO_ARITH_RECIPROCAL)) {
+        const double it = t->it;
         t->v[0] = r[0] * it; t->v[1] = r[1] * it; t->v[2] = r[2] * it;
     } else if (t->theta != 0.0) {
         t->v[0] = r[0] / t->theta; t->v[1] = r[1] / t->theta; t->v[2] = r[2] / t->theta;
@@ -64,8 +100,8 @@ static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
     t->w[1] = v[2] * q[0] - v[0] * q[2];
     t->w[2] = v[0] * q[1] - v[1] * q[0];
     if (t->theta > 0.0) {
-        t->c = cos(t->theta);
-        t->s = sin(t->theta);
+        if (arith & RO_ARITH_SINCOS_ANGLE) ro_sincos_angle(t->theta, &t->s, &t->c);
+        else { t->c = cos(t->theta); t->s = sin(t->theta); }
         const double omc = 1 - t->c;
         t->d = v[0] * q[0] + v[1] * q[1] + v[2] * q[2];
         for (int i = 0; i < 3; ++i)
@@ -77,8 +113,9 @@ static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
     }
     for (int i = 0; i < 3; ++i) t->P[i] += tr[i];
 
-    if (g_experiment & 1) {
-        const double iz = 1.0 / t->P[2];
+    t->iz = 1.0 / t->P[2];
+    if (arith & RO_ARITH_RECIPROCAL) {
+        const double iz = t->iz;
         t->pp[0] = -t->P[0] * iz;
         t->pp[1] = -t->P[1] * iz;
     } else {
@@ -98,7 +135,7 @@ static double ba_forward(const double x[12], double ox, double oy, ba_fwd *t)
 double ro_ba_factor_eval(const double vals[12], double obsx, double obsy)
 {
     ba_fwd t;
-    return ba_forward(vals, obsx, obsy, &t);
+    return ba_forward(vals, obsx, obsy, &t, 0);
 }
 
 /* Analytic gradient of one reprojection factor.  The reference
@@ -164,12 +201,72 @@ static void ba_adjoint(const ba_fwd *tp, const double x[12], double s0, double s
     }
 }
 
-double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
+static double ba_grad_adjoint(const double x[12], double ox, double oy, double g[12], int arith)
 {
     ba_fwd t;
-    const double E = ba_forward(x, ox, oy, &t);
+    const double E = ba_forward(x, ox, oy, &t, arith);
     ba_adjoint(&t, x, t.res[0], t.res[1], g);
     return E;
+}
+
+double ro_ba_factor_grad(const double x[12], double ox, double oy, double g[12])
+{
+    return ba_grad_adjoint(x, ox, oy, g, 0);
+}
+
+/* RO_BA_DERIV_ADJOINT_DEVICE: the same adjoint sweep with the DEVICE's association of every sum and product
+ * (rdis_amd/csrc/factors.hpp ba_adjoint, restated statement by statement: the reciprocals 1 / P_z and 1 / theta of the forward
+ * pass in place of quotients, (1 - c) (a . v) formed once, ((a . v) d - a . q) s + (a . w) c): the bits of the device's
+ * reference-rounding instantiation.  Meant to be used with RO_ARITH_RECIPROCAL | RO_ARITH_SINCOS_ANGLE. */
+static double ba_grad_adjoint_device(const double x[12], double ox, double oy, double g[12], int arith)
+{
+    ba_fwd t;
+    const double E = ba_forward(x, ox, oy, &t, arith);
+    const double q0 = x[9], q1 = x[10], q2 = x[11];
+    const double v0 = t.v[0], v1 = t.v[1], v2 = t.v[2];
+    const double f = x[6], s0 = t.res[0], s1 = t.res[1];
+    const double pp0 = t.pp[0], pp1 = t.pp[1];
+    const double rp = s0 * pp0 + s1 * pp1;
+    g[6] = t.dstn * rp;
+    const double adst = f * rp;
+    g[7] = adst * t.r2;
+    g[8] = adst * t.r2 * t.r2;
+    const double ar2 = adst * (x[7] + 2.0 * x[8] * t.r2);
+    const double fd = f * t.dstn;
+    const double app0 = fd * s0 + 2.0 * ar2 * pp0;
+    const double app1 = fd * s1 + 2.0 * ar2 * pp1;
+    const double a0 = -app0 * t.iz, a1 = -app1 * t.iz;
+    const double a2 = -(app0 * pp0 + app1 * pp1) * t.iz;
+    g[3] = a0; g[4] = a1; g[5] = a2;
+    const double av = a0 * v0 + a1 * v1 + a2 * v2;
+    const double qxa0 = q1 * a2 - q2 * a1, qxa1 = q2 * a0 - q0 * a2, qxa2 = q0 * a1 - q1 * a0;
+    const double vxa0 = v1 * a2 - v2 * a1, vxa1 = v2 * a0 - v0 * a2, vxa2 = v0 * a1 - v1 * a0;
+    if (t.theta > 0.0) {
+        const double omc = 1.0 - t.c;
+        const double k = omc * av;
+        g[9] = a0 * t.c - vxa0 * t.s + v0 * k;
+        g[10] = a1 * t.c - vxa1 * t.s + v1 * k;
+        g[11] = a2 * t.c - vxa2 * t.s + v2 * k;
+        const double aq = a0 * q0 + a1 * q1 + a2 * q2;
+        const double aw = a0 * t.w[0] + a1 * t.w[1] + a2 * t.w[2];
+        const double gth = (av * t.d - aq) * t.s + aw * t.c;
+        const double gv0 = t.s * qxa0 + omc * (a0 * t.d + q0 * av);
+        const double gv1 = t.s * qxa1 + omc * (a1 * t.d + q1 * av);
+        const double gv2 = t.s * qxa2 + omc * (a2 * t.d + q2 * av);
+        const double vgv = v0 * gv0 + v1 * gv1 + v2 * gv2;
+        g[0] = (gv0 - v0 * vgv) * t.it + v0 * gth;
+        g[1] = (gv1 - v1 * vgv) * t.it + v1 * gth;
+        g[2] = (gv2 - v2 * vgv) * t.it + v2 * gth;
+    } else {
+        g[9] = a0 - vxa0; g[10] = a1 - vxa1; g[11] = a2 - vxa2;
+        g[0] = qxa0; g[1] = qxa1; g[2] = qxa2;
+    }
+    return E;
+}
+
+double ro_ba_factor_grad_device(const double x[12], double ox, double oy, double g[12])
+{
+    return ba_grad_adjoint_device(x, ox, oy, g, RO_ARITH_RECIPROCAL | RO_ARITH_SINCOS_ANGLE);
 }
 
 /* The reference's own derivative: the chain rule expanded forward, one variable at a time,
@@ -189,10 +286,16 @@ static double chain_to_E(const ba_fwd *t, double f, const double dp[4], const do
     return f * (drx + dry);
 }
 
+static double ba_grad_refchain(const double x[12], double ox, double oy, double g[12], int arith);
 double ro_ba_factor_grad_ref(const double x[12], double ox, double oy, double g[12])
 {
+    return ba_grad_refchain(x, ox, oy, g, 0);
+}
+
+static double ba_grad_refchain(const double x[12], double ox, double oy, double g[12], int arith)
+{
     ba_fwd t;
-    const double E = ba_forward(x, ox, oy, &t);
+    const double E = ba_forward(x, ox, oy, &t, arith);
     const double *q = x + 9, *v = t.v, *P = t.P, *pp = t.pp;
     const double f = x[6], k1 = x[7], k2 = x[8];
     const double r2 = t.r2, dstn = t.dstn, vdp = t.d;
@@ -254,7 +357,7 @@ double ro_ba_factor_grad_ref(const double x[12], double ox, double oy, double g[
 void ro_ba_factor_resjac(const double x[12], double ox, double oy, double res[2], double J[24])
 {
     ba_fwd t;
-    ba_forward(x, ox, oy, &t);
+    ba_forward(x, ox, oy, &t, 0);
     res[0] = t.res[0]; res[1] = t.res[1];
     ba_adjoint(&t, x, 1.0, 0.0, J);
     ba_adjoint(&t, x, 0.0, 1.0, J + 12);
@@ -292,7 +395,8 @@ struct ro_problem {
     /* cached factor values + variable->factor adjacency (Factor.h:228-234,
      * Variable.cpp:66-88) */
     int emulate;
-    int ba_deriv;     /* RO_BA_DERIV_REFCHAIN (default) or RO_BA_DERIV_ADJOINT */
+    int ba_deriv;     /* RO_BA_DERIV_REFCHAIN (default), RO_BA_DERIV_ADJOINT or RO_BA_DERIV_ADJOINT_DEVICE */
+    int arith;        /* RO_ARITH_* flags of the factor arithmetic (default 0: the reference's) */
     int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
     double *fcache;
     uint8_t *fdirty;
@@ -403,10 +507,17 @@ void ro_set_ba_derivative(ro_problem *p, int which)
     p->ba_deriv = which;
 }
 
+void ro_set_arithmetic(ro_problem *p, int flags)
+{
+    p->arith = flags;
+    if (p->fdirty) memset(p->fdirty, 1, (size_t)p->nfac);
+}
+
 static double ba_grad(const ro_problem *p, const double x[12], double ox, double oy, double g[12])
 {
-    return p->ba_deriv == RO_BA_DERIV_ADJOINT ? ro_ba_factor_grad(x, ox, oy, g)
-                                              : ro_ba_factor_grad_ref(x, ox, oy, g);
+    if (p->ba_deriv == RO_BA_DERIV_ADJOINT_DEVICE) return ba_grad_adjoint_device(x, ox, oy, g, p->arith);
+    return p->ba_deriv == RO_BA_DERIV_ADJOINT ? ba_grad_adjoint(x, ox, oy, g, p->arith)
+                                              : ba_grad_refchain(x, ox, oy, g, p->arith);
 }
 
 void ro_set_sum_order(ro_problem *p, int which)
@@ -512,7 +623,7 @@ static double nlp_deriv(const ro_problem *p, int64_t f, int64_t wrt)
 static void ba_bounds(const double x[12], double ox, double oy, double *vb, double *gb)
 {
     ba_fwd t;
-    const double E = ba_forward(x, ox, oy, &t);
+    const double E = ba_forward(x, ox, oy, &t, 0);
     const double *q = x + 9, *tr = x + 3, *v = t.v;
     const double omc = 1 - t.c;
     double a[2], T[3];
@@ -571,8 +682,9 @@ static double factor_value_nocache(const ro_problem *p, int64_t f)
 {
     if (p->kind == RO_KIND_BA) {
         double vals[12];
+        ba_fwd t;
         gather_ba(p, f, vals);
-        return ro_ba_factor_eval(vals, p->obs[2 * f], p->obs[2 * f + 1]);
+        return ba_forward(vals, p->obs[2 * f], p->obs[2 * f + 1], &t, p->arith);
     }
     return nlp_eval(p, f);
 }

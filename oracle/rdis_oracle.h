@@ -56,7 +56,21 @@ double ro_ba_factor_grad_ref(const double vals[12], double obsx, double obsy,
                              double grad[12]);
 double ro_ba_factor_grad(const double vals[12], double obsx, double obsy,
                          double grad[12]);
-enum { RO_BA_DERIV_REFCHAIN = 0, RO_BA_DERIV_ADJOINT = 1 };
+enum { RO_BA_DERIV_REFCHAIN = 0, RO_BA_DERIV_ADJOINT = 1, RO_BA_DERIV_ADJOINT_DEVICE = 2 };
+/* The three named last-place differences between the reference's factor arithmetic and the device's parity option (plan
+ * option factor_rounding = 1, rdis_amd/csrc/factors.hpp compiled without contraction), as run-time switches of THIS
+ * restatement -- so that a device run can be compared with a CPU run end to end with ==, and so that what separates that
+ * CPU run from the reference-pinned one is a closed, named set:
+ *   RO_ARITH_RECIPROCAL    the unit axis and the perspective divide through one reciprocal each (x * (1 / y) for x / y)
+ *   RO_ARITH_SINCOS_ANGLE  sine / cosine of the rotation angle by the device's routine (ro_sincos_angle) for the C library's
+ *   RO_BA_DERIV_ADJOINT_DEVICE (ro_set_ba_derivative)  the adjoint sweep in the device's association for the reference's
+ *                          forward chain
+ * All off = the reference's arithmetic = what every pin of this oracle is made with. */
+#define RO_ARITH_RECIPROCAL 1
+#define RO_ARITH_SINCOS_ANGLE 2
+void ro_sincos_angle(double x, double *sn, double *cs);
+/* value + 12 partials with all three switches on: what one lane of the device's parity option computes */
+double ro_ba_factor_grad_device(const double vals[12], double obsx, double obsy, double grad[12]);
 
 /* ---- problems -------------------------------------------------------------*/
 /* BA: factor i reads the 9 variables cam_vid0[i]..+8 and pt_vid0[i]..+2. */
@@ -83,6 +97,8 @@ void ro_set_emulate_stale_cache(ro_problem *p, int on);
 /* which of the two derivatives the gradient / solver entry points use.  Default
  * RO_BA_DERIV_REFCHAIN (reference-faithful rounding). */
 void ro_set_ba_derivative(ro_problem *p, int which);
+/* RO_ARITH_* flags of the factor arithmetic (default 0: the reference's) */
+void ro_set_arithmetic(ro_problem *p, int flags);
 /* order of the objective's sum over the listed factors: RO_SUM_LIST = list order, one after the other (the
  * reference, src/OptimizableFunction.cpp:95-135; default), RO_SUM_PAIRWISE = a tree over runs of 64 -- an
  * experiment's switch (the rounding a device's reduction has), never used to pin anything */

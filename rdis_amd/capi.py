@@ -70,6 +70,7 @@ SYMBOLS = {
     "rdis_hip_eval_grad_device": (C.c_int, [_vp, _i64, _vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "rdis_hip_eval_each": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rdis_hip_grad_each_ba": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rdis_hip_set_factor_rounding": (C.c_int, [_vp, C.c_int32]),
     "rdis_hip_cgd_batch": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_double,
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdis_hip_plan_create": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
@@ -279,6 +280,10 @@ class Problem:
         if u is not None and u.shape[0] != self.nfac:
             raise ValueError("one flag per factor")
         self.ctx.check(self.ctx.lib.rdis_hip_nlp_set_exponential(self.h, _ptr(u)))
+
+    def set_factor_rounding(self, mode: int):
+        """how eval_each / grad_each_ba round: 0 = fused multiply-adds, 1 = like the reference's build (the parity option's)"""
+        self.ctx.check(self.ctx.lib.rdis_hip_set_factor_rounding(self.h, int(mode)))
 
     def set_x(self, val, vid=None):
         val, vid = _f(val), _i(vid)

@@ -105,6 +105,11 @@ struct PlanView {
     const long long* pm_sg_off;        // [ncomp * K] a workgroup's table in pm_segs
     int* st_ev;           // stale-cache emulation (solver_lds.hpp): per listed factor the assignment of its last value evaluation ...
     double* st_val;       // ... and that value; null unless the plan's option emulate_stale_cache is set
+    // the parity option (plan option factor_rounding = 1; solver_coop.hpp / solver_lds.hpp in refround_kernels.hip): sums in the
+    // reference's order are added from these by one lane / wave
+    double* seq_val;      // [nfac_total] a listed factor's value at the trial point at hand
+    double* seq_ab;       // [2][seq_n] by free index: the terms of gg and dgg (cooperative solver)
+    int seq_n;            // nfree_total
     long long* timing;    // debug counters of the batch solvers (-DRDIS_COOP_TIMING builds), or null
     double* ws;           // 5 vectors per component, component c at 5*free_ptr[c]
     double* dir;          // [N]

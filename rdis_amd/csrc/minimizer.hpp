@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <type_traits>
+#include <utility>
 
 namespace rdis_hip {
 
@@ -658,6 +659,15 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 template <class E, class = void> struct EnvNoSkip { static constexpr bool value = false; };
 template <class E> struct EnvNoSkip<E, std::void_t<decltype(E::NOSKIP)>> { static constexpr bool value = E::NOSKIP; };
 
+// Env::noskip_rt() (optional): the same decided at run time (solver_coop.hpp: the parity option with the stale-cache emulation)
+template <class E, class = void> struct EnvNoSkipRt { static constexpr bool value = false; };
+template <class E> struct EnvNoSkipRt<E, std::void_t<decltype(std::declval<const E&>().noskip_rt())>> { static constexpr bool value = true; };
+template <class Env>
+__device__ __forceinline__ bool env_noskip(const Env& E) {
+    if constexpr (EnvNoSkipRt<Env>::value) return EnvNoSkip<Env>::value || E.noskip_rt();
+    else return EnvNoSkip<Env>::value;
+}
+
 // Env::FUSED_GRADIENT (optional, default false): the environment offers gradient_fused(line_end, amin, reduce, fp, test, gg, dgg)
 template <class E, class = void> struct EnvFusedGradient { static constexpr bool value = false; };
 template <class E> struct EnvFusedGradient<E, std::void_t<decltype(E::FUSED_GRADIENT)>> { static constexpr bool value = E::FUSED_GRADIENT; };
@@ -680,7 +690,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
     // words to the same LDS addresses is a 64-way bank conflict on every store (measured: 1700 of the
     // 2300 cycles of a step); the request reaches everybody, this lane's own wave included, through LDS
     const bool stepper = E.stepper() && E.writer();
-    if (stepper) M.init(maxiters, ftol, EnvNoSkip<Env>::value);
+    if (stepper) M.init(maxiters, ftol, env_noskip(E));
     for (int round = 0;; ++round) {
         const long long ts0 = E.clock();
         if (stepper) {
@@ -772,7 +782,7 @@ __device__ __forceinline__ void run_machine(Env& E, CgdMachine& M /* LDS */, Req
             if constexpr (Env::UNIFORM) break;
             else {
                 if (!E.next_problem(M)) break;
-                if (stepper) M.init(maxiters, ftol, EnvNoSkip<Env>::value);
+                if (stepper) M.init(maxiters, ftol, env_noskip(E));
                 r0 = r1 = r2 = 0.0;
                 continue;
             }

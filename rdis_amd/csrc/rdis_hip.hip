@@ -134,6 +134,7 @@ struct rdis_hip_problem {
     rdis_hip_ctx* ctx = nullptr;
     int kind = KIND_BA;
     int64_t N = 0, F = 0, nnz = 0;
+    int each_rounding = 0;             // rdis_hip_set_factor_rounding: how eval_each / grad_each_ba round (1: like the reference's build)
     DevBuf x, lo, hi, cam, pt, obs, coeff, rowptr, vid, expo, cons, sine;
     DevBuf useexp;                     // per factor: value = coeff * exp(-product) (rdis_hip_nlp_set_exponential)
     std::vector<uint8_t> h_useexp;     // empty: no factor has it
@@ -289,6 +290,7 @@ struct rdis_hip_plan {
     bool coop_reference_rounding() const { return factor_rounding != 0; }
     bool batch_reference_rounding() const { return factor_rounding == 1; }
     DevBuf st_ev, st_val;
+    DevBuf seq_val, seq_ab;           // the parity option's buffers (PlanView::seq_val, seq_ab), allocated at the first solve that needs them
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
     DevBuf lds_ints, lds_obs;
@@ -337,6 +339,7 @@ struct rdis_hip_plan {
         v.pm_rec = pm_rec.as<double>(); v.pm_gh = pm_gh.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
         v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
         v.pm_segs = pm_segs.as<int>(); v.pm_sg_off = pm_sg_off.as<long long>();
+        v.seq_val = seq_val.as<double>(); v.seq_ab = seq_ab.as<double>(); v.seq_n = (int)nfree;
         v.timing = prob->coop_timing.as<long long>();
         v.ws = ws.as<double>(); v.dir = prob->dir.as<double>(); v.gfac = gfac.as<double>();
         v.xstart = xstart.as<double>();
@@ -1043,6 +1046,14 @@ extern "C" int rdis_hip_eval_grad_device(rdis_hip_problem* p, int64_t nf, const 
     return 0;
 }
 
+extern "C" int rdis_hip_set_factor_rounding(rdis_hip_problem* p, int32_t mode) {
+    if (!p) return RDIS_HIP_EINVAL;
+    if (mode != 0 && mode != 1) return fail(p->ctx, RDIS_HIP_EINVAL, "set_factor_rounding: 0 (fused multiply-adds) or 1 (the reference's rounding)");
+    if (mode == 1 && p->kind != KIND_BA) return fail(p->ctx, RDIS_HIP_EINVAL, "set_factor_rounding: bundle adjustment only");
+    p->each_rounding = mode;
+    return 0;
+}
+
 extern "C" int rdis_hip_eval_each(rdis_hip_problem* p, int64_t nf, const int64_t* fac, double* fvals) {
     if (!p || (nf && !fvals)) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
@@ -1055,7 +1066,8 @@ extern "C" int rdis_hip_eval_each(rdis_hip_problem* p, int64_t nf, const int64_t
     if ((rc = ensure(c, p->tmp_out, (size_t)nf * sizeof(double)))) return rc;
     ProblemView V = p->view();
     const int blocks = grid_for(c, nf, 256);
-    if (p->kind == KIND_BA) eval_each_kernel<KIND_BA><<<blocks, 256, 0, c->stream>>>(V, (int)nf, dfac, p->tmp_out.as<double>());
+    if (p->kind == KIND_BA && p->each_rounding == 1) HIPCHK(c, refround_eval_each(blocks, c->stream, &V, (int)nf, dfac, p->tmp_out.as<double>()));
+    else if (p->kind == KIND_BA) eval_each_kernel<KIND_BA><<<blocks, 256, 0, c->stream>>>(V, (int)nf, dfac, p->tmp_out.as<double>());
     else eval_each_kernel<KIND_NLP><<<blocks, 256, 0, c->stream>>>(V, (int)nf, dfac, p->tmp_out.as<double>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(fvals, p->tmp_out.p, (size_t)nf * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1076,10 +1088,14 @@ extern "C" int rdis_hip_grad_each_ba(rdis_hip_problem* p, int64_t nf, const int6
     if ((rc = ensure(c, p->gfac, (size_t)p->nslots() * sizeof(double)))) return rc;
     if ((rc = ensure(c, p->tmp_out, (size_t)nf * 12 * sizeof(double)))) return rc;
     ProblemView V = p->view();
-    partials_kernel<KIND_BA><<<grid_for(c, nf, 256), 256, 0, c->stream>>>(V, (int)nf, dfac, p->gfac.as<double>());
-    HIPCHK(c, hipGetLastError());
-    gather_rows12_kernel<<<grid_for(c, nf * 12, 256), 256, 0, c->stream>>>((int)nf, dfac, p->gfac.as<double>(), p->tmp_out.as<double>());
-    HIPCHK(c, hipGetLastError());
+    if (p->each_rounding == 1) {
+        HIPCHK(c, refround_grad_each(grid_for(c, nf, 256), c->stream, &V, (int)nf, dfac, p->tmp_out.as<double>()));
+    } else {
+        partials_kernel<KIND_BA><<<grid_for(c, nf, 256), 256, 0, c->stream>>>(V, (int)nf, dfac, p->gfac.as<double>());
+        HIPCHK(c, hipGetLastError());
+        gather_rows12_kernel<<<grid_for(c, nf * 12, 256), 256, 0, c->stream>>>((int)nf, dfac, p->gfac.as<double>(), p->tmp_out.as<double>());
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipMemcpyAsync(g12, p->tmp_out.p, (size_t)nf * 12 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1992,7 +2008,7 @@ int prepare_partition(rdis_hip_plan* L) {
                            L->coop_ints.as<int>() + it.lane_var, L->coop_ints.as<int>() + it.wave_var, L->xi_glob.as<double>() + it.xi_off, it.comp,
                            // (a small group's sweep is one entry per lane: polling early costs it less than waiting)
                            it.nwg * (L->coop_lanes() / 64) <= 64 ? std::min(4, L->coop_poll_delay) : L->coop_poll_delay,
-                           L->coop_speculate, L->factor_rounding == 1 ? 1 : 0};
+                           L->coop_speculate, L->factor_rounding == 1 ? 1 : 0, (L->factor_rounding == 1 && L->emulate_stale) ? 1 : 0};
             g.wg0 = cl.total_wg; g.nwg = it.nwg;
             hg.push_back(g);
             hw.insert(hw.end(), (size_t)it.nwg, cl.count);
@@ -2310,13 +2326,13 @@ int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int firs
     return 0;
 }
 int launch_lds(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
-    if (L->emulate_stale) return launch_lds_stale(L, stream, threads, first, grid, maxiters, ftol);
+    if (L->emulate_stale && !L->batch_reference_rounding()) return launch_lds_stale(L, stream, threads, first, grid, maxiters, ftol);
     if (L->batch_reference_rounding()) {
         rdis_hip_ctx* c = L->prob->ctx;
         ProblemView P = L->prob->view();
         PlanView V = L->view();
         V.order += first;
-        HIPCHK(c, refround_launch_lds(L->lds_rot_mode, threads, grid, lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap), stream, &P, &V,
+        HIPCHK(c, refround_launch_lds(L->lds_rot_mode, L->emulate_stale ? 1 : 0, threads, grid, lds_bytes_for(L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap), stream, &P, &V,
                                       maxiters, ftol, L->lds_ns_cap, L->lds_ncb_cap, L->lds_chunk_cap));
         return 0;
     }
@@ -2344,10 +2360,12 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     // cooperative group tables point into)
     if (L->partition_dirty || (!L->coop.empty() && L->coop_state_gen != p->coop_state_gen)) { int rc = prepare_partition(L); if (rc) return rc; }
     if (L->emulate_stale) {
-        // implemented where config 5's components run: the LDS-resident batch solver (and per-factor rotations)
-        if ((size_t)L->rest_lds != L->h_rest.size() || !L->coop.empty() || !L->stream.empty() || L->lds_rot_mode != ROT_PER_FACTOR)
+        // implemented where config 5's components run: the LDS-resident batch solver (and per-factor rotations) -- and, under the
+        // parity option, in the cooperative solver's plain layout
+        if ((size_t)L->rest_lds != L->h_rest.size() || (!L->coop.empty() && L->factor_rounding != 1) || !L->stream.empty() ||
+            (L->rest_lds > 0 && L->lds_rot_mode != ROT_PER_FACTOR))
             return fail(c, RDIS_HIP_EINVAL, "emulate_stale_cache: every component of the plan must run on the LDS-resident batch solver "
-                                            "(bundle adjustment, variables fitting a compute unit's LDS, no cooperative groups)");
+                                            "(bundle adjustment, variables fitting a compute unit's LDS; cooperative groups only with factor_rounding = 1)");
         if (!L->st_ev.p) {
             int rc = plan_alloc(L, L->st_ev, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(int));
             if (!rc) rc = plan_alloc(L, L->st_val, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(double));
@@ -2356,9 +2374,14 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     }
     if (L->factor_rounding == 1) {
         // instantiated for the solvers BASELINE's configs 3 - 5 reach: the cooperative ones and the LDS-resident batch solver
-        if ((size_t)L->rest_lds != L->h_rest.size() || !L->stream.empty() || L->emulate_stale || p->kind != KIND_BA)
+        if ((size_t)L->rest_lds != L->h_rest.size() || !L->stream.empty() || p->kind != KIND_BA)
             return fail(c, RDIS_HIP_EINVAL, "factor_rounding = 1: every component of the plan must run on a cooperative solver or on the "
                                             "LDS-resident batch solver (bundle adjustment; no streaming, tiny-component or plain launches)");
+        if (!L->seq_val.p) {
+            int rc = plan_alloc(L, L->seq_val, (size_t)std::max<int64_t>(L->nfac, 1) * sizeof(double));
+            if (!rc) rc = plan_alloc(L, L->seq_ab, 2 * (size_t)std::max<int64_t>(L->nfree, 1) * sizeof(double));
+            if (rc) return rc;
+        }
     }
     PlanView V = L->view();
     HIPCHK(c, hipEventRecord(p->ev0, c->stream));

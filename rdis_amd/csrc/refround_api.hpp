@@ -19,7 +19,9 @@ int refround_pipe_max_workgroups(int num_cus);
 int refround_launch_coop(hipStream_t stream, int kind, const void* P, const void* V, const void* first_group, const void* groups,
                          const int* wg_group, int ngroups, int total_wg, int threads, int maxiters, double ftol);
 int refround_coop_max_workgroups(int threads, int num_cus);
-hipError_t refround_launch_lds(int rot, int threads, int grid, size_t dyn, hipStream_t stream, const void* P, const void* V,
+hipError_t refround_eval_each(int grid, hipStream_t stream, const void* P, int nf, const int* fac, double* out);
+hipError_t refround_grad_each(int grid, hipStream_t stream, const void* P, int nf, const int* fac, double* out12);
+hipError_t refround_launch_lds(int rot, int stale, int threads, int grid, size_t dyn, hipStream_t stream, const void* P, const void* V,
                                int maxiters, double ftol, int ns_cap, int ncb_cap, int chunk_cap);
 
 }  // namespace rdis_hip

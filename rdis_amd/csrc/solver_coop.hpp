@@ -46,8 +46,11 @@ struct CoopArgs {
     int comp;
     int poll_delay;        // x64 cycles between publishing and the first sweep (a store needs about that long to land)
     int speculate;         // evaluate guesses at the following trial steps with every line-search trial (minimizer.hpp)
-    int reference_slope;   // plan option factor_rounding = 1: a trial's slope formed the reference's way (slope_reference, below;
+    int reference_slope;   // plan option factor_rounding = 1, the PARITY option: every sum a trial or a CG iteration forms is added in the
+                           // reference's order -- the objective over the factors in list order, every variable's partials in factor-list
+                           // order, gradient times direction and the Polak-Ribiere sums over the variables in list order (ordered_sums, below;
                            // looked at by the reference-rounding instantiation only, refround_kernels.hip)
+    int stale;             // ... with it, plan option emulate_stale_cache: the reference's factor cache (Variable.cpp:66-76, Factor.h:228-234)
 };
 
 // the CG recurrence of one free variable
@@ -72,6 +75,27 @@ struct CoopEnv {
     double ox, oy;
     VarState lv;   // lane-owned variable
     VarState wv;   // wave-owned variable (identical in all 64 lanes)
+#ifdef RDIS_REFERENCE_SLOPE
+    // The reference's factor cache as this lane's factor sees it (A.stale): the values its twelve variables were last assigned,
+    // whether one of them has moved by 1e-12 or more since the factor's value was last computed, and that value.  Every lane sees
+    // every assignment (each trial, each gradient), so a variable's history is the same in all the lanes that read it.
+    double prevv[12], fcache;
+    bool fdirty;
+    __device__ __forceinline__ void note_assign(const double (&v)[12]) {
+        if (!A.stale) return;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            if (!(fabs(v[k] - prevv[k]) < 1e-12)) fdirty = true;   // Variable::assign (src/Variable.cpp:70-76)
+            prevv[k] = v[k];
+        }
+    }
+    __device__ __forceinline__ double cached_value(double fj) {   // Factor::eval -> evalFactorCached (src/Factor.h:228-234)
+        if (!A.stale) return fj;
+        if (fdirty) { fcache = fj; fdirty = false; return fj; }
+        return fcache;
+    }
+    __device__ bool noskip_rt() const { return A.reference_slope != 0 && A.stale != 0; }
+#endif
 
     __device__ void trace(int tag, double a, double b, double c) {
         if (tr != nullptr && gt == 0) {
@@ -113,6 +137,9 @@ struct CoopEnv {
                     v[k] = clampd(base[k] + t, lov[k], hiv[k]);
                 }
             }
+#ifdef RDIS_REFERENCE_SLOPE
+            if (A.reference_slope) note_assign(v);
+#endif
             if constexpr (SLOPE) {
                 double g[12];
                 fj = ba_eval_grad(v, ox, oy, g);
@@ -129,9 +156,15 @@ struct CoopEnv {
             } else {
                 fj = ba_eval(v, ox, oy);
             }
+#ifdef RDIS_REFERENCE_SLOPE
+            if (A.reference_slope) {
+                fj = cached_value(fj);
+                store_f64<true>(L.seq_val + c0 + gt, fj);
+            }
+#endif
         }
 #ifdef RDIS_REFERENCE_SLOPE
-        if constexpr (SLOPE) { if (A.reference_slope) sj = slope_reference(); }
+        if (A.reference_slope) ordered_sums<SLOPE>(fj, sj);
 #endif
         X.tm[0] += coop_clock() - tc0;
         X.to_wave0<SLOPE ? 2 : 1>(fj, sj, dummy, SYNC_NONE);  // only the stepping wave consumes a line-search value
@@ -187,22 +220,32 @@ struct CoopEnv {
         }
         return __shfl(acc, 0);
     }
-    __device__ double slope_reference() {
+    // The objective is added the same way (OptimizableFunction::evalFactors, src/OptimizableFunction.cpp:95-135: the listed factors'
+    // values one after the other): every factor lane has left its value -- the cached one under A.stale -- in seq_val, and the
+    // group's first wave adds the m of them in list order.  On return the group's first lane holds the sums, every other lane zeros.
+    template <bool SLOPE>
+    __device__ void ordered_sums(double& fsum, double& ssum) {
 #pragma clang fp contract(off)
         X.barrier(SYNC_DRAIN);
-        const int* vp = L.v2s_ptr + f0;
-        if (lv.li >= 0) {
-            const double t = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]) * lv.xi;
-            store_f64<true>(A.xi_glob + lv.li, t);
+        if constexpr (SLOPE) {
+            const int* vp = L.v2s_ptr + f0;
+            if (lv.li >= 0) {
+                const double t = run_sum_ordered<true>(L.gfac, vp[lv.li], vp[lv.li + 1]) * lv.xi;
+                store_f64<true>(A.xi_glob + lv.li, t);
+            }
+            if (wv.li >= 0) {
+                const double t = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid) * wv.xi;
+                if ((tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, t);
+            }
+            X.barrier(SYNC_DRAIN);
         }
-        if (wv.li >= 0) {
-            const double t = wave_sum_in_order(L.gfac, vp[wv.li], vp[wv.li + 1], tid) * wv.xi;
-            if ((tid & 63) == 0) store_f64<true>(A.xi_glob + wv.li, t);
+        double af = 0.0, as = 0.0;
+        if (gt < 64) {   // (the group's first wave)
+            af = wave_sum_in_order(L.seq_val + c0, 0, m, tid);
+            if constexpr (SLOPE) as = wave_sum_in_order(A.xi_glob, 0, n, tid);
         }
-        X.barrier(SYNC_DRAIN);
-        double acc = 0.0;
-        if (gt < 64) acc = wave_sum_in_order(A.xi_glob, 0, n, tid);   // (the group's first wave)
-        return gt == 0 ? acc : 0.0;   // (the exchange's tree adds zeros to it)
+        fsum = gt == 0 ? af : 0.0;   // (the exchange's tree adds zeros to them)
+        ssum = gt == 0 ? as : 0.0;
     }
 #endif
     // SPEC trial steps at once: the evaluations are independent chains in one instruction stream
@@ -239,6 +282,14 @@ struct CoopEnv {
         for (int c = 0; c < SPEC; ++c) { cf[c] = r[2 * c]; cs[c] = r[2 * c + 1]; }
     }
     __device__ double eval_value(double a, bool restore) {
+#ifdef RDIS_REFERENCE_SLOPE
+        if (restore && A.reference_slope && has_fac) {   // the end point is assigned before the rollback is considered (CGD .cpp:61)
+            double v[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
+            note_assign(v);
+        }
+#endif
         if (restore) load_base(L.xstart + f0);  // objective at clamp(x_init) for the rollback
         double f, s;
         eval_line<false>(restore ? 0.0 : a, f, s);
@@ -276,6 +327,11 @@ struct CoopEnv {
         var_init(lv, A.lane_var[gt]);
         var_init(wv, A.wave_var[gt >> 6]);
         load_base(L.xstart + f0);
+#ifdef RDIS_REFERENCE_SLOPE
+#pragma unroll
+        for (int k = 0; k < 12; ++k) prevv[k] = __builtin_nan("");
+        fcache = 0.0; fdirty = true;   // (a factor's value is computed at its first evaluation)
+#endif
     }
 
     __device__ void gradient_to_xi() {
@@ -284,6 +340,9 @@ struct CoopEnv {
             double v[12], g[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) v[k] = clampd(base[k], lov[k], hiv[k]);
+#ifdef RDIS_REFERENCE_SLOPE
+            if (A.reference_slope) note_assign(v);   // SubfunctionFD::df assigns its point too (.cpp:135-157)
+#endif
             ba_eval_grad(v, ox, oy, g);
             const int* sp = L.slot_pos + L.slot_base[c0 + gt];
             int t[12];  // all twelve destinations first: the loads overlap (the coherent stores
@@ -363,6 +422,19 @@ struct CoopEnv {
             a = a + wv.g * wv.g;
             b = b + (wv.xi + wv.g) * wv.xi;
         }
+#ifdef RDIS_REFERENCE_SLOPE
+        if (A.reference_slope) {   // gg and dgg over the variables in list order (minimize_nrc.h:665-672); the maximum has no order
+            double* sa = L.seq_ab + f0;
+            double* sb = sa + L.seq_n;
+            if (lv.li >= 0) { store_f64<true>(sa + lv.li, lv.g * lv.g); store_f64<true>(sb + lv.li, (lv.xi + lv.g) * lv.xi); }
+            if (wv.li >= 0 && (tid & 63) == 0) { store_f64<true>(sa + wv.li, wv.g * wv.g); store_f64<true>(sb + wv.li, (wv.xi + wv.g) * wv.xi); }
+            X.barrier(SYNC_DRAIN);
+            double ga = 0.0, gb = 0.0;
+            if (gt < 64) { ga = wave_sum_in_order(sa, 0, n, tid); gb = wave_sum_in_order(sb, 0, n, tid); }
+            a = gt == 0 ? ga : 0.0;
+            b = gt == 0 ? gb : 0.0;
+        }
+#endif
         X.to_wave0<3>(a, b, t, SYNC_NONE);
         X.finish_wave0(SYNC_NONE);
         gg = a; dgg = b; test = t;

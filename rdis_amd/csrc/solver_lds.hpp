@@ -268,6 +268,9 @@ struct LdsEnv {
                 if (ev < 0 || moved > ev) fvv[j] = fj; else fj = fvv[j];
                 fev[j] = epoch;
             }
+#ifdef RDIS_REFERENCE_SLOPE
+            L.seq_val[c0 + j] = fj;   // (the parity option adds the listed factors' values in list order: sum_in_order)
+#endif
             af += fj;
             if constexpr (SLOPE) {
                 double d[12];
@@ -356,6 +359,29 @@ struct LdsEnv {
 #endif
 #ifdef RDIS_REFERENCE_SLOPE
     __device__ bool matrix() const { return false; }
+    // The parity option (this instantiation: plan option factor_rounding = 1) adds every sum in the reference's order.
+    // arr[0 .. cnt) added one after the other from 0.0 by the workgroup's first lane (sixteen loads in flight, the additions one
+    // dependent chain: the plain loop's bits); every lane returns the sum.
+    __device__ double sum_in_order(const double* arr, int cnt) {
+#pragma clang fp contract(off)
+        __syncthreads();   // (the entries are written)
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int k0 = 0; k0 < cnt; k0 += 16) {
+                double t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = (k0 + j < cnt) ? arr[k0 + j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (k0 + j < cnt) acc = acc + t[j];
+            }
+            red[parity][0][0] = acc;
+        }
+        __syncthreads();
+        const double r = red[parity][0][0];
+        parity ^= 1;
+        return r;
+    }
 #else
     __device__ bool matrix() const { return !STALE && L.ls_matrix != 0; }
 #endif
@@ -367,10 +393,22 @@ struct LdsEnv {
             sumk<1>(af, as, dummy);
             return af;
         }
+#ifdef RDIS_REFERENCE_SLOPE
+        if (restore) {
+            if constexpr (STALE) assign_p();   // the end point is assigned before the rollback is considered (CGD .cpp:61)
+            assign_start();
+        } else {
+            assign_line(a);
+        }
+        double af = 0.0, as = 0.0;
+        eval_partial<false>(af, as);
+        return sum_in_order(L.seq_val + c0, m);   // OptimizableFunction::evalFactors: in list order (.cpp:95-135)
+#else
         if (restore) assign_start(); else assign_line(a);
         double f, s;
         eval_sum<false>(f, s);
         return f;
+#endif
     }
 #ifdef RDIS_REFERENCE_SLOPE
     // The slope of a trial the way the reference forms it (Df1dim::df, minimize_nrc.h:439-447, over SubfunctionFD::df,
@@ -399,24 +437,33 @@ struct LdsEnv {
             const int fi = SF[s];
             if (fi < 0) continue;
             const int b = vptr[fi], e = vptr[fi + 1];
-            GT[fi] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
+            const double gv = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
+            GT[fi] = gv * XI[s];
+        }
+        return sum_in_order(GT, n);   // by free index: the order of `vars` (Df1dim::df, minimize_nrc.h:443-445)
+    }
+    // SubfunctionFD::df at clamp(p) the same way: every partial through gfac[], every variable's -- a camera's too -- added in
+    // factor-list order by one lane (src/State.h:157-210)
+    __device__ void gradient_ordered() {
+        assign_p();
+        for (int j = tid; j < m; j += nt) {
+            double v[12], gq[12];
+            BaFwd t;
+            int cb, pb;
+            forward(fidx[j], fobs[j], v, t, cb, pb);
+            ba_adjoint(t, v, t.res0, t.res1, gq);
+            const int* sp = L.slot_pos + L.slot_base[c0 + j];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int u = sp[k]; if (u >= 0) L.gfac[u] = gq[k]; }
         }
         __syncthreads();
-        if (tid == 0) {   // (slots in order = variable ids ascending = the order of `vars`)
-            double acc = 0.0;
-            for (int s = 0; s < ns; ++s) {
-                const int fi = SF[s];
-                if (fi < 0) continue;
-                const double t = GT[fi] * XI[s];
-                acc = acc + t;
-            }
-            red[parity][0][0] = acc;
+        for (int s = tid; s < ns; s += nt) {
+            const int fi = SF[s];
+            if (fi < 0) continue;
+            const int b = vptr[fi], e = vptr[fi + 1];
+            XI[s] = b < e ? run_sum_ordered(L.gfac, b, e) : 0.0;
         }
         __syncthreads();
-        const double r = red[parity][0][0];
-        parity ^= 1;
-        __syncthreads();
-        return r;
     }
 #endif
     __device__ void eval_value_slope(double a, double& f, double& s) {
@@ -437,11 +484,11 @@ struct LdsEnv {
         assign_line(a);
         const long long t1 = clock();
 #ifdef RDIS_REFERENCE_SLOPE
-        if constexpr (!STALE) {
+        {   // (with the stale-cache emulation too: a factor's VALUE may be the cached one, gradients are always fresh)
             eval_partial<false>(af, as);
-            sumk<1>(af, as, dummy);
-            f = af;
+            f = sum_in_order(L.seq_val + c0, m);
             s = slope_reference();
+            (void)dummy; (void)t1;
             return;
         }
 #endif
@@ -503,6 +550,10 @@ struct LdsEnv {
     // A camera variable's sum is therefore grouped differently from solver_wg.hpp's (which strides a wave over the
     // run): with free cameras the two solvers agree to rounding, not to the bit.
     __device__ void gradient_to_xi() {
+#ifdef RDIS_REFERENCE_SLOPE
+        gradient_ordered();
+        return;
+#endif
         if (L.ls_cam_gfac) { gradient_via_gfac(); return; }
         const long long tg0 = clock();
         assign_p();
@@ -630,8 +681,18 @@ struct LdsEnv {
             t = fmax(t, fabs(x) * fmax(fabs(Pv[s]), 1.0) / den);
             a = a + gi * gi;
             b = b + (x + gi) * x;
+#ifdef RDIS_REFERENCE_SLOPE
+            // (the parity option: the terms by free index, added in that order below -- minimize_nrc.h:665-672)
+            double* GT = L.ws + 5ll * f0;
+            GT[fi] = gi * gi;
+            GT[n + fi] = (x + gi) * x;
+#endif
         }
         sumk<3>(a, b, t);
+#ifdef RDIS_REFERENCE_SLOPE
+        a = sum_in_order(L.ws + 5ll * f0, n);
+        b = sum_in_order(L.ws + 5ll * f0 + n, n);
+#endif
         gg = a; dgg = b; test = t;
     }
     __device__ void cg_update(double gam) {

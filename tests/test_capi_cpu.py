@@ -101,6 +101,28 @@ def test_matrix_form_of_a_trial_agrees_with_the_vector_form(tmp_path):
     assert "worst relative deviation" in out.stdout
 
 
+def test_oracle_switches_restate_the_device_factor_arithmetic_bit_for_bit(tmp_path):
+    """factors.hpp compiled for the HOST without contraction (what refround_kernels.hip instantiates on the device: the parity
+    option's factor arithmetic) against the oracle's plain-C restatement of it -- RO_ARITH_RECIPROCAL | RO_ARITH_SINCOS_ANGLE,
+    RO_BA_DERIV_ADJOINT_DEVICE -- on 300 000 random cameras / points / observations of ladybug's ranges, rotation angles up to 40
+    radians and theta = 0: value and twelve partials ==, the angle routine == and within one ulp of the C library's
+    (tests/cpp/factors_parity_test.hip).  The GPU suite then shows device == oracle per factor and end to end."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from oracle import oracle as O
+    O.build()
+    exe = str(tmp_path / "factors_parity_test")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "factors_parity_test.hip"), "-L" + odir, "-loracle", "-Wl,-rpath," + odir],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "300000 cases, 0 differences" in out.stdout, out.stdout
+
+
 def test_optba_entry_of_the_host_library():
     """include/rdis_optba.h: the caller-side C entry (optBA's core over the level driver) is exported by librdis_host.so and
     rejects bad calls without touching a device."""

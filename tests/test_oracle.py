@@ -273,6 +273,51 @@ def test_recorded_runs_need_every_reference_detail(golden):
         assert r.fret != c["fret"] and abs(r.fret - c["fret"]) < 0.05 * c["fret"]
 
 
+def test_device_arithmetic_switches_are_the_only_difference(golden):
+    """The CPU side of the end-to-end == tests (tests/test_gpu_parity.py): the oracle with its three named switches for the
+    device's factor arithmetic.  (1) With the switches off it is the reference-pinned oracle (the recorded run, ==).
+    (2) Each switch alone leaves every factor's value / partials within last places of the reference's arithmetic -- the
+    reciprocals move values (1e-11 of a value that is a cancelled residual), the two derivative forms move partials by 2e-15 of
+    a row's largest entry, the angle routine does not move a single one of ladybug's 49 cameras at x0 (it is below 1 ulp, like
+    the C library's).  (3) With all three on, 25 iterations from x0 end where tests/golden/parity_end_values.json says -- numbers
+    that do not depend on the machine (no C-library transcendental is left on the path) and that the device's parity option
+    reproduces bit for bit on the GPU."""
+    import json
+    c = golden["cgd"]["ladybug_5_30"]
+    p = P.load_bal(ncams=5, npts=30)
+    assert O.OracleProblem(p, derivative="refchain", arithmetic="reference").cgd(maxiters=25).fret == c["fret"]
+    full = P.load_bal()
+    ref = O.OracleProblem(full)
+    f0, g0 = ref.eval_each(), ref.grad_each_ba()
+    rowmax = np.max(np.abs(g0), axis=1, keepdims=True)
+    for kw, moves_f, tol_f, tol_g in ((dict(arithmetic="reciprocal"), True, 1e-10, 1e-10), (dict(arithmetic="sincos_angle"), False, 0.0, 0.0),
+                                      (dict(derivative="adjoint_device"), False, 0.0, 1e-14)):
+        o = O.OracleProblem(full, **kw)
+        f, g = o.eval_each(), o.grad_each_ba()
+        assert bool(np.any(f != f0)) == moves_f and np.max(np.abs(f - f0) / np.abs(f0)) <= tol_f, kw
+        assert np.max(np.abs(g - g0) / rowmax) <= tol_g, kw
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        want = json.load(fh)
+    for key in ("ladybug_5_30_stale_cache", "ladybug_5_30"):
+        w = want[key]
+        pp = P.load_bal(ncams=w["ncams"], npts=w["npts"]).single_component()
+        r = O.OracleProblem.device_parity(pp, emulate_stale_cache=w["emulate_stale_cache"]).cgd(x=pp.x0, maxiters=w["maxiters"])
+        assert (r.fret, r.delta, r.iters, r.status, r.nfeval, r.ngeval) == (w["fret"], w["delta"], w["iters"], w["status"], w["nfeval"], w["ngeval"])
+        assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
+        assert r.fret != c["fret"] and abs(r.fret - c["fret"]) < 0.05 * c["fret"]     # another member of the chaotic family
+
+
+def test_device_arithmetic_end_value_on_full_ladybug():
+    """... and BASELINE config 4: 85993.13597324853 after 805 evaluations (the reference's arithmetic: 83227.60422775625 after 825)"""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        w = json.load(fh)["ladybug_full_stale_cache"]
+    pp = P.load_bal().single_component()
+    r = O.OracleProblem.device_parity(pp).cgd(x=pp.x0, maxiters=25)
+    assert (r.fret, r.iters, r.nfeval, r.ngeval) == (w["fret"], w["iters"], w["nfeval"], w["ngeval"])
+    assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
