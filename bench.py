@@ -288,7 +288,7 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
     df, ms_fma = draw({"factor_rounding": 0})
     # ... and a short sample of the parity option (the reference's slope: one sequential sum per trial, 0.18 s a solve; the full
     # sample and the plain two-sample test are tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle)
-    dp, ms_par = draw({"factor_rounding": 1}, n=48)
+    dp, ms_par = draw({"factor_rounding": 1}, n=24)
     plan.set_option("factor_rounding", -1)
     plan.set_start(pp.x0[pp.comp_free_vid])
 
@@ -307,11 +307,11 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
            "ks_device_vs_oracle": ks(de, oe),
            "ks_critical_alpha_0.05": float(1.358 * np.sqrt((len(de) + len(oe)) / (len(de) * len(oe)))),
            "reference_recorded": 83227.604227756252,
-           "device_parity_option": dict(q(dp), rounding="factor_rounding = 1: the reference's rounding AND a trial's slope added in the reference's order",
+           "device_parity_option": dict(q(dp), rounding="factor_rounding = 1: the reference's rounding AND every sum added in the reference's order",
                                         kernel_ms=ms_par, ks_vs_oracle=ks(dp, oe),
                                         ks_critical_alpha_0_05=float(1.358 * np.sqrt((len(dp) + len(oe)) / (len(dp) * len(oe))))),
-           "parity_option": "plan option factor_rounding = 1 adds a trial's slope in the reference's order too (one sequential sum per trial: 0.18 s a solve, "
-                            "so only 48 draws here: device_parity_option); under -m gpu, tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle asserts the plain two-sample "
+           "parity_option": "plan option factor_rounding = 1 adds every sum in the reference's order (two sequential sums per trial: 0.4 s a solve, "
+                            "so only 24 draws here: device_parity_option; its == with the CPU oracle: value_parity_option); under -m gpu, tests/test_gpu_solver.py::test_end_values_distribution_matches_oracle asserts the plain two-sample "
                             "test for it on this workload (measured KS 0.056 at n = 320, critical 0.107) and, for the default drawn here, that the device is no "
                             "further from the oracle than the oracle's own rounding variants are from one another (DESIGN.md section 6)"}
     if len(oc):
@@ -319,6 +319,40 @@ def objective_band(plan, pp, maxiters: int, k_dev: int = 320):
         out["ks_device_vs_oracle_contracted"] = ks(de, oc)
         out["ks_oracle_vs_oracle_contracted"] = ks(oc, oe)
     return out
+
+
+def parity_option(plan, pp, maxiters: int):
+    """The same workload under the PARITY option (plan options factor_rounding = 1, emulate_stale_cache = 1): every product
+    rounded before it is added, every sum in the reference's order, the reference's factor cache.  Its end state is compared, ==,
+    with the committed CPU fixture tests/golden/parity_end_values.json -- what the CPU oracle returns with its three named
+    switches for the device's factor arithmetic on (written by tests/golden/make_parity_end_values.py, pinned by the CPU suite;
+    nothing under oracle/ runs here).  Outside the timed region."""
+    with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json")) as fh:
+        w = json.load(fh)["ladybug_full_stale_cache"]
+    plan.set_option("factor_rounding", 1)
+    plan.set_option("emulate_stale_cache", 1)
+    best, r = None, None
+    for _ in range(2):
+        plan.set_start(pp.x0[pp.comp_free_vid])
+        t = time.perf_counter()
+        plan.solve(maxiters, 3e-8)
+        r = plan.fetch()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    ms = plan.last_kernel_ms()[0]
+    plan.set_option("factor_rounding", -1)
+    plan.set_option("emulate_stale_cache", 0)
+    plan.set_start(pp.x0[pp.comp_free_vid])
+    same = (float(r.fret[0]) == w["fret"] and int(r.iters[0]) == w["iters"] and int(r.nfeval[0]) == w["nfeval"] and
+            int(r.ngeval[0]) == w["ngeval"] and [float(v) for v in r.x[:3]] == w["x_0_2"] and float(r.x[-1]) == w["x_last"])
+    return {"value": (int(r.iters[0]) + 1) / best, "unit": "iters/s", "ms_per_solve": best * 1e3, "kernel_ms": ms,
+            "final_objective": float(r.fret[0]), "f_evals": int(r.nfeval[0]), "grad_evals": int(r.ngeval[0]),
+            "cpu_fixture": {"final_objective": w["fret"], "f_evals": w["nfeval"], "grad_evals": w["ngeval"], "file": "tests/golden/parity_end_values.json"},
+            "bit_identical_to_cpu_fixture": bool(same),
+            "what": "plan options factor_rounding = 1 + emulate_stale_cache = 1: the reference's rounding, every sum in the reference's order, its factor "
+                    "cache; == the CPU oracle with its three named switches for the device's factor arithmetic (own sincos of the rotation angle, "
+                    "reciprocals, adjoint sweep) after 25 iterations from x0, no re-synchronisation (tests/test_gpu_parity.py; DESIGN.md section 6). "
+                    "A parity option: two sequential sums per trial"}
 
 
 def plugin_call(prob, pp, maxiters: int, reps: int = 5):
@@ -622,6 +656,8 @@ def main():
         }
         if world == 1:
             line["plugin_call"] = plugin_call(prob, pp, a.maxiters)
+            if a.workload == "ladybug-full" and a.maxiters == 25:
+                line["value_parity_option"] = parity_option(plan, pp, a.maxiters)
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(pp, a.maxiters)
             if a.workload == "ladybug-full" and not a.no_objective_band and a.maxiters == 25:

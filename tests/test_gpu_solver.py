@@ -263,9 +263,10 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     The default arithmetic is a different population by the causes named above.  On 5 / 30 (fused multiply-adds and the
     factor-by-factor slope in the batch solvers): the locations and a looser bound that covers the 0.15 measured.  On full
     ladybug (the pipelined cooperative solver: the reference's rounding, a parallel reduction's slope): the device must be
-    no further from the reference-faithful oracle than the oracle's own variants -- contraction, slope by factor in list
-    order, slope by factor as a tree: 0.10 .. 0.21 from one another, the last two differing in nothing but the ORDER of one
-    sum -- are from one another."""
+    no further from the reference-faithful oracle than the oracle's own variants -- slope by factor in list order, slope by
+    factor as a tree: 0.10 .. 0.19 from one another, the last two differing in nothing but the ORDER of one sum -- are from
+    one another (the contracted oracle is not one of them: this path does not contract).  Since round 6 the parity option is
+    also compared END TO END with ==, no populations: tests/test_gpu_parity.py."""
     c = golden["cgd"][key]
     fx = _end_value_fixture()
     oe, oc = np.array(fx[key]["end_values"]), np.array(fx[key]["end_values_contracted"])
@@ -298,10 +299,12 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
             # tree 0.18, list order against tree 0.19 -- two samples that differ in nothing but the ORDER of one sum.
             # Asserted: the device is no further from the reference-faithful oracle than the oracle's own variants are from
             # one another (no allowance on top), and its median sits inside theirs.
-            fam = [oe, oc, np.array(fx[key]["end_values_slope_by_factor"]), np.array(fx[key]["end_values_slope_by_factor_tree"])]
+            # (The contracted oracle is NOT in this family: the default cooperative path rounds like the reference, so only the
+            # variants that differ from the reference-faithful sample in the association / order of the slope's sum are.)
+            fam = [oe, np.array(fx[key]["end_values_slope_by_factor"]), np.array(fx[key]["end_values_slope_by_factor_tree"])]
             spread = max(_ks2(a, b)[0] for i, a in enumerate(fam) for b in fam[i + 1:])
             d_fam = [_ks2(de, m)[0] for m in fam]
-            print("%s, %s: KS against the oracle family (reference, contracted, slope by factor, ... as a tree) %s; the family's own spread %.3f" % (
+            print("%s, %s: KS against the oracle family (reference, slope by factor, ... as a tree) %s; the family's own spread %.3f" % (
                 key, name, np.round(d_fam, 3), spread))
             assert d_o <= spread, (name, key, d_o, spread)
             assert min(q(m)[1] for m in fam) * (1 - 2e-3) <= q(de)[1] <= max(q(m)[1] for m in fam) * (1 + 2e-3), (name, [q(m)[1] for m in fam], q(de)[1])
