@@ -96,6 +96,9 @@ struct GridSyncT {
     long long tm[COOP_TM]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
                       // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over,
                       // 10 combine waves, 11 release, 12.. handler cycles: 12 value, 13 value+slope, 14 gradient (+reduce), 17 line end; 22.. their counts
+    bool wg_entry;                      // a workgroup publishes ONE entry (its first wave, values already summed over the workgroup by the
+                                        // caller: every lane holds them) instead of one per wave -- a wide group of solver_ptm.hpp: 256
+                                        // entries to sweep instead of 2048
 
     // ---- inter-workgroup exchange ------------------------------------------------
     __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][w][k]; }
@@ -130,13 +133,16 @@ struct GridSyncT {
         static_assert(N >= 1 && N <= COOP_K && NMAX >= 0 && NMAX <= N, "exchange width");
         const long long t0 = coop_clock();
         long long t2 = t0;
-        const int w = tid >> 6, lane = tid & 63, nwv = blockDim.x >> 6;
+        const int w = tid >> 6, lane = tid & 63, nwv = wg_entry ? 1 : blockDim.x >> 6;
+        if (!wg_entry) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(v[k]) : wave_max(v[k]);
+            for (int k = 0; k < N; ++k) v[k] = k < N - NMAX ? wave_sum(v[k]) : wave_max(v[k]);
+        }
         const int buf = epoch & (COOP_NBUF - 1);
         kused = (kused & ~(0xFFu << (8 * buf))) | ((unsigned)N << (8 * buf));
         if (sync != SYNC_NONE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are out
-        if (lane == 0) {
+        if (wg_entry && sync != SYNC_NONE) __syncthreads();   // ... and every wave's, before the workgroup's one entry says so
+        if (lane == 0 && (!wg_entry || w == 0)) {
             // (this lane's re-arming stores to these granules were issued three exchanges
             // ago and have been waited for, see finish_wave0)
             if (sync == SYNC_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -256,7 +262,7 @@ struct GridSyncT {
         // after its sweep: the sweep of exchange e completing proves that every workgroup has left
         // the sweep of e-1, whose buffer is the one re-armed.  (A wave re-arming its own entry right
         // after publishing could pull a granule from under a slower workgroup's sweep.)
-        const int nwv = blockDim.x >> 6;
+        const int nwv = wg_entry ? 1 : blockDim.x >> 6;
         if (tid < nwv) {
             if (tid == 0 && sync == SYNC_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous re-arming stores: an exchange old

@@ -19,7 +19,7 @@ constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded i
 constexpr int PTM_BLK = RDIS_PTM_BLK;  // slots of a point block asked for (and evaluated) together; pm_cam / pm_obs are padded by 64 (PTM_BLK - 1) entries
 constexpr int PTM_CAM_VECTORS = 7;     // LDS vectors over the camera slots: Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
 constexpr int PTM_SPREAD = 16;         // a component's wave-chunks of equal slot count are dealt out over this many runs of the camera-sorted order
-constexpr int PTM_MAX_GROUP = 16;      // workgroups per component (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
+constexpr int PTM_MAX_GROUP = 16;      // workgroups per component of a launch of many groups (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
 constexpr int PTM_MAX_CAMERAS = 4095;  // camera blocks per component (twelve bits of a factor's slot word; two bytes in the trial stream)
 
 // A camera block's ten LDS slots: [tx ty tz f k1 k2 | rx ry rz | pad] -- the six values every factor reads first, from a
@@ -44,8 +44,8 @@ __host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads) {
 }
 
 struct PtmGroupArgs {
-    SmallCoopState* st;   // one exchange state per group of the launch
-    double* xch;          // [groups][2][K][10 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth)
+    void* st;             // one exchange state per group of the launch: SmallCoopState, or CoopState for a wide group (grid_sync.hpp)
+    double* xch;          // [groups][2 K + 2][10 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth) and their totals
     int K, ngroups;       // workgroups per component, components of the launch
     int poll_delay;
 };
@@ -53,7 +53,9 @@ struct PtmGroupArgs {
 // launches (ptm_kernels.hip); rot = ROT_PER_FACTOR / ROT_RECORDS / ROT_CAMFIX, threads = 256 / 512 / 768
 hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t stream, const ProblemView& P, const PlanView& V,
                       int maxiters, double ftol, int ncb_cap);
-const void* ptmg_kernel_fn(int rot, int threads);   // cgd_ptmg_kernel<threads, rot> (a cooperative launch by the caller)
+const void* ptmg_kernel_fn(int rot, int threads, bool wide = false);   // cgd_ptmg_kernel<threads, rot, wide> (a cooperative launch by the caller; wide: 512 lanes)
+constexpr int PTM_WIDE_THREADS = 512;  // workgroup of a wide group (one per compute unit)
+constexpr int PTM_WIDE_MAX_GROUP = 512;  // ... and their number (COOP_MAX_WG)
 hipError_t ptm_gather_launch(int grid, hipStream_t stream, int n, const int* jg, const unsigned* fidx, const double2* fobs,
                              short* pcam, double2* pobs);
 

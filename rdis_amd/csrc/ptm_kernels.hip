@@ -33,17 +33,18 @@ hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t st
 }
 
 template <int ROT>
-static const void* ptmg_kernel_ptr(int threads) {
+static const void* ptmg_kernel_ptr(int threads, bool wide) {
+    if (wide) return (const void*)cgd_ptmg_kernel<PTM_WIDE_THREADS, ROT, true>;
     switch (threads) {
         case 256: return (const void*)cgd_ptmg_kernel<256, ROT>;
         case 512: return (const void*)cgd_ptmg_kernel<512, ROT>;
         default: return (const void*)cgd_ptmg_kernel<768, ROT>;
     }
 }
-const void* ptmg_kernel_fn(int rot, int threads) {
+const void* ptmg_kernel_fn(int rot, int threads, bool wide) {
     switch (rot) {
-        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads);
-        default: return ptmg_kernel_ptr<ROT_RECORDS>(threads);
+        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads, wide);
+        default: return ptmg_kernel_ptr<ROT_RECORDS>(threads, wide);
     }
 }
 

@@ -290,6 +290,8 @@ struct rdis_hip_plan {
     bool coop_reference_rounding() const { return factor_rounding != 0; }
     bool batch_reference_rounding() const { return factor_rounding == 1; }
     DevBuf st_ev, st_val;
+    bool ptm_wide_wanted = false;     // prepare_partition: a large component joined the batch list for a wide point-major group
+    bool ptm_wide_last = false;       // the last solve ran its point-major launch as wide groups
     DevBuf seq_val, seq_ab;           // the parity option's buffers (PlanView::seq_val, seq_ab), allocated at the first solve that needs them
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
@@ -1463,7 +1465,7 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         if (value < 0 || value > 2) return fail(c, RDIS_HIP_EINVAL, "ptm_stream must be 0 (never), 1 (components too large for the LDS) or 2 (every component its tables fit)");
         L->ptm_stream = (int)value;
     } else if (n == "ptm_group") {
-        if (value < 0 || value > PTM_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16)");
+        if (value < 0 || value > PTM_WIDE_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16; up to 512 for the wide groups of a few large components)");
         L->ptm_group = (int)value;
         return 0;   // (no table depends on it)
     } else if (n == "ptm_threads") {
@@ -1612,6 +1614,27 @@ int prepare_partition(rdis_hip_plan* L) {
     if (L->coop_workgroups > 0) scap = std::min(scap, L->coop_workgroups);
     int64_t max_n = 0;
     ivec blk_all;
+    L->ptm_wide_wanted = false;
+    cvec wide_comp((size_t)L->ncomp, 0);
+    auto wide_ptm_ok = [&](int cc) {
+        if (p->kind != KIND_BA || L->ptm_stream == 0 || p->ncam_blocks <= 0 || L->lds_resident == 0 && L->ptm_stream != 2) return false;
+        if (L->factor_rounding == 1 || L->emulate_stale) return false;   // (instantiated for the cooperative and LDS-resident solvers only)
+        const int c0 = L->h_fac_ptr[(size_t)cc], c1 = L->h_fac_ptr[(size_t)cc + 1];
+        if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
+        const int stamp = ++p->stamp;
+        int ncb = 0;
+        for (int j = c0; j < c1; ++j) {
+            const int b = p->h_cam[(size_t)L->h_fac_id[(size_t)j]];
+            if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; ++ncb; }
+        }
+        for (int i = L->h_free_ptr[(size_t)cc]; i < L->h_free_ptr[(size_t)cc + 1]; ++i) {
+            const int v = L->h_free_vid[(size_t)i];
+            const int b = p->h_block_of[(size_t)v];
+            if (b >= 0) { if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; ++ncb; } }
+            else if (p->h_ptblock_of[(size_t)v] < 0) return false;
+        }
+        return ncb <= PTM_MAX_CAMERAS && ptm_bytes_for(ncb, PTM_WIDE_THREADS) <= c->lds_limit;
+    };
     // (one allocation: growing this by appending costs a transient call on ladybug 1.5 ms in page faults)
     L->h_coop_ints.reserve((size_t)(any_big ? 12 * L->nfac + 4 * (L->nfac + L->nfree) + 4096 * (int64_t)std::min<int64_t>(L->ncomp, 64) : 0));
     for (int cc : L->h_order) {  // heaviest first
@@ -1621,6 +1644,11 @@ int prepare_partition(rdis_hip_plan* L) {
         const bool grouped = m >= group_min;
         const bool big = any_big && (grouped || (m >= L->coop_min_factors && (int)(L->coop.size() + L->stream.size()) < L->coop_max_components));
         const bool take = big && cap > 0 && need <= cap && coop_on;
+        // A bundle-adjustment component too large for a cooperative group whose CAMERA blocks fit a compute unit's LDS goes to the
+        // point-major streaming solver as a wide group -- a workgroup per compute unit on the one component (solver_ptm.hpp: a trial
+        // streams 18 bytes a factor and 48 a point block, nothing is written; the grid solver below forms every trial point in x[]
+        // and gathers 24 doubles a factor through L2).  It joins the batch list; the tables below decide (cameras, LDS).
+        if (!take && big && wide_ptm_ok(cc)) { L->h_rest.push_back(cc); L->ptm_wide_wanted = true; wide_comp[(size_t)cc] = 1; continue; }
         if (!take && big && scap > 0) {
             // too large for the register-resident solver (or not bundle adjustment): the streaming
             // grid solver; about two factors per lane and trial point, at most what is resident
@@ -1745,6 +1773,7 @@ int prepare_partition(rdis_hip_plan* L) {
         cvec kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
         const int ptm_max_threads = L->ptm_threads ? L->ptm_threads : 768;   // (the staging area of its gradient grows with the workgroup)
         ivec ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
+        ivec ls_pidx((size_t)L->nfac, 0);   // (host only) a listed factor's point block within its component: all 31 bits of it
         std::vector<ivec> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
         ivec cams, pts, deg;
         for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
@@ -1765,7 +1794,8 @@ int prepare_partition(rdis_hip_plan* L) {
                 else if (p->h_ptblock_of[(size_t)v] >= 0) note(p->h_ptblock_of[(size_t)v], pts);
                 else ok = false;   // a variable no factor of the problem reads: no block to put it in
             }
-            if (!ok || cams.size() > (size_t)PTM_MAX_CAMERAS || pts.size() >= (1u << 20)) continue;
+            if (!ok || cams.size() > (size_t)PTM_MAX_CAMERAS) continue;
+            const bool many_points = pts.size() >= (1u << 20);   // (beyond the LDS-resident solver's slot word; the streaming tables use ls_pidx)
             const int ncb = (int)cams.size(), npb = (int)pts.size(), ns = 9 * ncb + 3 * npb, m = c1 - c0;
             std::sort(cams.begin(), cams.end());
             for (int k = 0; k < ncb; ++k) p->h_blk_idx[(size_t)cams[(size_t)k]] = k;
@@ -1785,7 +1815,7 @@ int prepare_partition(rdis_hip_plan* L) {
             const int nchunk = (int)gp.size() / 64;
             // (the streaming solver is for what is too LARGE for the LDS: with lds_resident = 0 such components stay with
             // solver_wg.hpp -- the comparison the bit-identity tests make; ptm_stream = 2 sends everything its tables fit)
-            const bool lds_size_ok = lds_bytes_for(ns, ncb, nchunk) <= c->lds_limit;
+            const bool lds_size_ok = !many_points && lds_bytes_for(ns, ncb, nchunk) <= c->lds_limit;
             const bool fits_lds = L->lds_resident != 0 && lds_size_ok && L->ptm_stream != 2;
             const bool fits_ptm = !fits_lds && (L->ptm_stream == 2 || (L->ptm_stream == 1 && !lds_size_ok)) &&
                                   ptm_bytes_for(ncb, ptm_max_threads) <= c->lds_limit;
@@ -1830,8 +1860,23 @@ int prepare_partition(rdis_hip_plan* L) {
                         int a1 = a0;
                         while (a1 < nfull && deg[(size_t)ord[(size_t)(64 * a1)] + 1] - deg[(size_t)ord[(size_t)(64 * a1)]] == T) ++a1;
                         const int mm = a1 - a0, q = (mm + PTM_SPREAD - 1) / PTM_SPREAD;
-                        for (int rr = 0; rr < q; ++rr)
-                            for (int gg = 0; gg < PTM_SPREAD; ++gg) { const int idx = gg * q + rr; if (idx < mm) chunk_of[(size_t)pos++] = a0 + idx; }
+                        if (!wide_comp[(size_t)cc]) {
+                            for (int rr = 0; rr < q; ++rr)
+                                for (int gg = 0; gg < PTM_SPREAD; ++gg) { const int idx = gg * q + rr; if (idx < mm) chunk_of[(size_t)pos++] = a0 + idx; }
+                        } else {
+                            // A wide group deals chunk c to workgroup c mod K, wave (c / K) mod waves -- with K a multiple of
+                            // PTM_SPREAD the round robin above would hand all the waves of a workgroup neighbours of ONE run, i.e.
+                            // one camera: a gradient round's sums (one lane per camera entry, solver_ptm.hpp) 512 rows long, 22 000
+                            // of a round's 26 000 cycles at 8e6 factors.  Here position c takes the next chunk of run h(c), h a
+                            // weighted sum of c's hexadecimal digits mod 16: the positions c, c + K, c + 2 K, ... of a workgroup's
+                            // waves meet different runs for every K that occurs (searched over K = 1 .. 16, 32 .. 512).
+                            int used[PTM_SPREAD] = {};
+                            for (int t = 0; t < mm; ++t) {
+                                int gg = ((pos & 15) + 15 * ((pos >> 4) & 15) + ((pos >> 8) & 15) + 15 * ((pos >> 12) & 15) + ((pos >> 16) & 15) + ((pos >> 20) & 15)) % PTM_SPREAD;
+                                for (int tries = 0; tries < PTM_SPREAD && gg * q + used[gg] >= std::min(mm, (gg + 1) * q); ++tries) gg = (gg + 1) % PTM_SPREAD;
+                                chunk_of[(size_t)pos++] = a0 + gg * q + used[gg]++;
+                            }
+                        }
                         a0 = a1;
                     }
                     ivec ord2(ord);
@@ -1862,6 +1907,7 @@ int prepare_partition(rdis_hip_plan* L) {
             for (int j = c0; j < c1; ++j) {
                 const int f = L->h_fac_id[(size_t)j];
                 ls_fidx[(size_t)j] = (int)((unsigned)p->h_blk_idx[(size_t)p->h_cam[(size_t)f]] | ((unsigned)p->h_blk_idx[(size_t)p->h_pt[(size_t)f]] << 12));
+                ls_pidx[(size_t)j] = p->h_blk_idx[(size_t)p->h_pt[(size_t)f]];
             }
             ls_ncb[(size_t)cc] = ncb;
             ls_gcount[(size_t)cc] = nchunk;
@@ -1877,7 +1923,7 @@ int prepare_partition(rdis_hip_plan* L) {
                 // the point's factors, in listed order (a CSR over the point blocks in their slot order)
                 ivec& pp = pptr_of[(size_t)cc];
                 pp.assign((size_t)npb + 1, 0);
-                for (int j = c0; j < c1; ++j) ++pp[(size_t)(((unsigned)ls_fidx[(size_t)j]) >> 12) + 1];
+                for (int j = c0; j < c1; ++j) ++pp[(size_t)ls_pidx[(size_t)j] + 1];
                 for (int k = 0; k < npb; ++k) pp[(size_t)k + 1] += pp[(size_t)k];
             }
         }
@@ -1920,7 +1966,7 @@ int prepare_partition(rdis_hip_plan* L) {
                 L->h_pm_jg.resize((size_t)e0 + (size_t)cbase[(size_t)npc], -1);
                 ivec fill((size_t)npb, 0);
                 for (int j = c0; j < c1; ++j) {
-                    const int pi = (int)(((unsigned)ls_fidx[(size_t)j]) >> 12);
+                    const int pi = ls_pidx[(size_t)j];
                     const int e = e0 + cbase[(size_t)(pi / 64)] + 64 * fill[(size_t)pi]++ + (pi % 64);
                     L->h_pm_jg[(size_t)e] = j;
                 }
@@ -2261,17 +2307,17 @@ int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int
     return 0;
 }
 // K workgroups per component (cgd_ptmg_kernel): how many groups of K fit the device, and the launch
-int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out) {
+int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out, bool wide = false) {
     rdis_hip_ctx* c = L->prob->ctx;
     const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
-    const void* fn = ptmg_kernel_fn(L->ptm_rot_mode, threads);
+    const void* fn = ptmg_kernel_fn(L->ptm_rot_mode, threads, wide);
     if (dyn > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn));
     *out = per_cu * c->num_cus;
     return 0;
 }
-int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int ngroups, int K, int maxiters, double ftol) {
+int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int ngroups, int K, int maxiters, double ftol, bool wide = false) {
     rdis_hip_ctx* c = L->prob->ctx;
     int rc = ptm_build_rounds(L, threads, K);
     if (rc) return rc;
@@ -2280,24 +2326,27 @@ int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int fir
     V.order += first;
     const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
     int ncc = L->ptm_ncb_cap;
-    if (L->ptm_state.bytes < (size_t)ngroups * sizeof(SmallCoopState)) {
-        rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * sizeof(SmallCoopState));
+    // (a wide group's workgroups and waves outnumber a small state's entries: a CoopState each)
+    const size_t st_bytes = wide ? sizeof(CoopState) : sizeof(SmallCoopState);
+    const size_t abort_off = wide ? offsetof(CoopState, abort_flag) : offsetof(SmallCoopState, abort_flag);
+    if (L->ptm_state.bytes < (size_t)ngroups * st_bytes) {
+        rc = plan_alloc(L, L->ptm_state, (size_t)ngroups * st_bytes);
         if (rc) return rc;
     }
-    const size_t xch_bytes = (size_t)ngroups * 2 * (size_t)K * PTM_CS * (size_t)ncc * sizeof(double);
+    const size_t xch_bytes = (size_t)ngroups * (2 * (size_t)K + 2) * PTM_CS * (size_t)ncc * sizeof(double);
     if (L->ptm_xch.bytes < xch_bytes) {
         rc = plan_alloc(L, L->ptm_xch, xch_bytes);
         if (rc) return rc;
     }
     // arm every granule, clear the abort words
-    HIPCHK(c, hipMemsetAsync(L->ptm_state.p, 0xFF, (size_t)ngroups * sizeof(SmallCoopState), stream));
-    HIPCHK(c, hipMemset2DAsync((char*)L->ptm_state.p + offsetof(SmallCoopState, abort_flag), sizeof(SmallCoopState), 0, 64, (size_t)ngroups, stream));
-    PtmGroupArgs A{L->ptm_state.as<SmallCoopState>(), L->ptm_xch.as<double>(), K, ngroups, std::min(4, L->coop_poll_delay)};
+    HIPCHK(c, hipMemsetAsync(L->ptm_state.p, 0xFF, (size_t)ngroups * st_bytes, stream));
+    HIPCHK(c, hipMemset2DAsync((char*)L->ptm_state.p + abort_off, st_bytes, 0, 64, (size_t)ngroups, stream));
+    PtmGroupArgs A{L->ptm_state.p, L->ptm_xch.as<double>(), K, ngroups, wide ? L->coop_poll_delay : std::min(4, L->coop_poll_delay)};
     int mi = maxiters;
     double ft = ftol;
     void* args[] = {&P, &V, &A, &mi, &ft, &ncc};
-    const int grid = 8 * K * ((ngroups + 7) / 8);
-    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel_fn(L->ptm_rot_mode, threads), dim3(grid), dim3(threads), args, dyn, stream));
+    const int grid = wide ? K * ngroups : 8 * K * ((ngroups + 7) / 8);
+    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel_fn(L->ptm_rot_mode, threads, wide), dim3(grid), dim3(threads), args, dyn, stream));
     return 0;
 }
 int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
@@ -2503,8 +2552,22 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             // ladybug's size 50.4 ms a workgroup of 768 lanes each, 56.0 as pairs of 256)
             if (best_K >= 2 && (L->ptm_group > 1 || best_lanes > threads)) { K = best_K; threads = best_threads; }
         }
+        // A few components and a device: wide groups -- as many workgroups of 512 lanes a component as are resident and have some
+        // twenty wave-chunks of points each (one component of 8e6 factors: 256 workgroups, 15 chunks a wave)
+        bool wide = false;
+        if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty() && L->rest_ptm <= 8 &&
+            (L->ptm_threads == 0 || L->ptm_threads == PTM_WIDE_THREADS)) {
+            int cap = 0;
+            int rc = ptmg_resident_workgroups(L, PTM_WIDE_THREADS, &cap, true);
+            if (rc) return rc;
+            const int useful = (int)std::max<int64_t>(1, (L->ptm_min_points + 63) / 64 / 24);
+            const int fit = std::min(std::min(PTM_WIDE_MAX_GROUP, cap / L->rest_ptm), COOP_MAX_WG * COOP_MAX_WAVES / (PTM_WIDE_THREADS / 64));
+            const int Kw = L->ptm_group > 1 ? std::min(L->ptm_group, fit) : std::min(fit, useful);
+            if (Kw > PTM_MAX_GROUP && Kw * PTM_WIDE_THREADS > K * threads) { K = Kw; threads = PTM_WIDE_THREADS; wide = true; }
+        }
         L->ptm_last_group = std::max(K, 1);
-        int rc = K >= 2 ? launch_ptm_groups(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, K, maxiters, ftol)
+        L->ptm_wide_last = wide;
+        int rc = K >= 2 ? launch_ptm_groups(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, K, maxiters, ftol, wide)
                         : launch_ptm(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, maxiters, ftol);
         if (rc) return rc;
         ++L->last_launches;
@@ -2585,6 +2648,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
     else if (n == "components_tiny") *value = L->rest_tiny;
     else if (n == "components_lds") *value = L->rest_lds;
     else if (n == "components_point_major") *value = L->rest_ptm;
+    else if (n == "point_major_wide") *value = L->ptm_wide_last ? 1 : 0;
     else if (n == "components_plain") *value = rest;
     else if (n == "pipelined") *value = L->pipelined() ? 1 : 0;
     else if (n == "point_major_group") *value = L->ptm_last_group;

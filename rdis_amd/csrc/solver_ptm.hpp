@@ -93,7 +93,7 @@ struct PtRecs {
     double g[3];          // (the gradient pass only) g of the recurrence
 };
 
-template <int ROT, bool GROUP = false>
+template <int ROT, bool GROUP = false, class ST = SmallCoopState>
 struct PtmEnv {
     const ProblemView& P;
     const PlanView& L;
@@ -128,8 +128,8 @@ struct PtmEnv {
     int trn, lm_count;
     // GROUP: rank r of the K workgroups that share the component, their exchange, their partial camera gradients in HBM
     int r, K;
-    GridSyncT<SmallCoopState> GX;
-    double* xch;              // [2][K][xch_stride]
+    GridSyncT<ST> GX;
+    double* xch;              // [2][K][xch_stride] the workgroups' partial camera gradients; behind them [2][xch_stride] their sums (wide groups)
     int xch_stride, gpar;
 #ifdef RDIS_COOP_TIMING
     long long tmv[32];
@@ -163,6 +163,13 @@ struct PtmEnv {
     template <int KK>
     __device__ void sumk(double& a, double& b, double& mx) {
         if constexpr (GROUP) {
+            if (GX.wg_entry) {   // (a wide group: the workgroup's sums first, one entry a workgroup)
+                a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
+                if ((tid & 63) == 0) { red[parity][0][tid >> 6] = a; red[parity][1][tid >> 6] = b; red[parity][2][tid >> 6] = mx; }
+                __syncthreads();
+                combine_waves<3>(red[parity], nwaves, a, b, mx);
+                parity ^= 1;
+            }
             GX.exchange(a, b, mx, SYNC_NONE);
             return;
         }
@@ -735,16 +742,39 @@ struct PtmEnv {
         }
         const long long tg1 = clock();
         __syncthreads();
-        if constexpr (GROUP && CAMS) {   // the workgroups' partial camera gradients, summed in rank order by everybody
+        if constexpr (GROUP && CAMS) {   // the workgroups' partial camera gradients, summed in rank order
             double* buf = xch + (long long)gpar * K * xch_stride;
+            double* tot = xch + 2ll * K * xch_stride + (long long)gpar * xch_stride;
             gpar ^= 1;
             for (int s = tid; s < PTM_CS * ncb; s += nt) buf[(long long)r * xch_stride + s] = XI[s];
             GX.barrier_ordered();
-            for (int s = tid; s < PTM_CS * ncb; s += nt) {
-                if (SF[s] < 0) continue;
-                double sm = buf[s];
-                for (int q = 1; q < K; ++q) sm += buf[(long long)q * xch_stride + s];
-                XI[s] = sm;
+            if (K <= PTM_MAX_GROUP) {   // a few workgroups: everybody adds everything
+                for (int s = tid; s < PTM_CS * ncb; s += nt) {
+                    if (SF[s] < 0) continue;
+                    double sm = buf[s];
+                    for (int q = 1; q < K; ++q) sm += buf[(long long)q * xch_stride + s];
+                    XI[s] = sm;
+                }
+            } else {
+                // a wide group (a whole device on one component): K x 10 ncb doubles read by each of K workgroups would be the
+                // gradient's largest stream -- every workgroup adds a share of the slots (the same rank order: the same bits),
+                // a second barrier, everybody fetches the sums
+                const int S = PTM_CS * ncb, per = (S + K - 1) / K;
+                for (int s = r * per + tid; s < min(S, (r + 1) * per); s += nt) {
+                    double sm = buf[s];
+                    for (int q0 = 1; q0 < K; q0 += 8) {
+                        double tv[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) tv[t] = q0 + t < K ? buf[(long long)(q0 + t) * xch_stride + s] : 0.0;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (q0 + t < K) sm += tv[t];
+                    }
+                    tot[s] = sm;
+                }
+                GX.barrier_ordered();
+                for (int s = tid; s < S; s += nt)
+                    if (SF[s] >= 0) XI[s] = tot[s];
             }
             __syncthreads();
         }
@@ -872,10 +902,10 @@ struct PtmEnv {
 
 // LDS of a workgroup (ptm_bytes_for): [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records][9 (blockDim + 1) staged
 // camera partials][two round lists (16-bit)][10 ncb_cap free indices (int)]
-template <int ROT, bool GROUP>
-__device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
-                                                       int ncb_cap, int r, int K, SmallCoopState* st, double* bcast,
-                                                       int poll_delay, double* xch) {
+template <int ROT, bool GROUP, class ST = SmallCoopState>
+__device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
+                                                           int ncb_cap, int r, int K, ST* st, double* bcast,
+                                                           int poll_delay, double* xch) {
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
     const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp], npb = (ns - PTM_CS * ncb) / 3;
@@ -903,7 +933,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
         rounds = L.pm_rounds + L.pm_rd_off[w];
         nrounds = L.pm_rd_n[w];
     }
-    return PtmEnv<ROT, GROUP>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
+    return PtmEnv<ROT, GROUP, ST>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
                               ncb, npb, (npb + 63) / 64,
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR, CTR, CDR,
@@ -914,7 +944,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP> ptm_env(const ProblemView& P, cons
                               segs, seg_rows, {sg[0], sg[1], sg[2], sg[3], sg[4], sg[5], sg[6], sg[7], sg[8]},
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
-                              r, K, GridSyncT<SmallCoopState>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
+                              r, K, GridSyncT<ST>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}, !std::is_same<ST, SmallCoopState>::value},
                               xch, PTM_CS * ncb_cap, 0
 #ifdef RDIS_COOP_TIMING
                               , {}
@@ -929,7 +959,7 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
     __shared__ double red[2][3][MAX_WAVES];
     const int comp = L.order[blockIdx.x];
     // (a component without factors never gets here: it has no slot table and stays with solver_wg.hpp)
-    PtmEnv<ROT, false> E = ptm_env<ROT, false>(P, L, comp, lds_dyn, red, ncb_cap, 0, 1, nullptr, nullptr, 0, nullptr);
+    PtmEnv<ROT, false> E = ptm_env<ROT, false>(P, L, comp, lds_dyn, red, ncb_cap, 0, 1, (SmallCoopState*)nullptr, nullptr, 0, nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
@@ -953,18 +983,23 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
 // K workgroups per component, the groups of a launch side by side (cooperative launch: every workgroup resident).
 // Block b -> group (b / 8K) * 8 + b mod 8, rank (b / 8) mod K: the workgroups of a group share b mod 8, i.e. the XCD
 // the dispatcher is observed to give them (a matter of speed only); blocks beyond the last group leave at once.
-template <int THREADS, int ROT>
+// WIDE: a group is a large share of the device -- ONE component too large for the register-resident cooperative solver whose
+// cameras fit the LDS (what solver_stream.hpp took before round 6: every trial through x[] in global memory, every gradient's
+// partials through HBM).  Its K workgroups are consecutive blocks, i.e. dealt round robin over the XCDs; the exchange state is a
+// CoopState (every wave an entry: K x waves of them); the partial camera gradients are added by shares (gradient_fused).
+template <int THREADS, int ROT, bool WIDE = false>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double ftol, int ncb_cap) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     __shared__ double bcast[8];
+    using ST = std::conditional_t<WIDE, CoopState, SmallCoopState>;
     const int b = blockIdx.x, K = A.K;
-    const int grp = (b / (8 * K)) * 8 + (b & 7), r = (b >> 3) % K;
+    const int grp = WIDE ? b / K : (b / (8 * K)) * 8 + (b & 7), r = WIDE ? b % K : (b >> 3) % K;
     if (grp >= A.ngroups) return;
     const int comp = L.order[grp];
-    PtmEnv<ROT, true> E = ptm_env<ROT, true>(P, L, comp, lds_dyn, red, ncb_cap, r, K, A.st + grp, bcast, A.poll_delay,
-                                              A.xch ? A.xch + (long long)grp * 2 * K * PTM_CS * ncb_cap : nullptr);
+    PtmEnv<ROT, true, ST> E = ptm_env<ROT, true, ST>(P, L, comp, lds_dyn, red, ncb_cap, r, K, reinterpret_cast<ST*>(A.st) + grp, bcast, A.poll_delay,
+                                              A.xch ? A.xch + (long long)grp * (2 * K + 2) * PTM_CS * ncb_cap : nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];

@@ -723,12 +723,17 @@ STREAM_CASES = {
 }
 
 
+@pytest.mark.parametrize("solver", ["point-major", "grid"])
 @pytest.mark.parametrize("name", list(STREAM_CASES))
-def test_streaming_grid_solver_replays_against_oracle(name, gctx):
-    """components too large for the register-resident solver (or not bundle adjustment) are solved
-    by the streaming multi-workgroup kernel: same algorithm, checked the same way"""
+def test_streaming_grid_solver_replays_against_oracle(name, solver, gctx):
+    """components too large for the register-resident solver (or not bundle adjustment) are solved by a streaming
+    multi-workgroup kernel: same algorithm, checked the same way.  Since round 6 a bundle-adjustment component whose cameras
+    fit the LDS streams through the point-major solver (solver_ptm.hpp: a group of workgroups on the one component, wide
+    groups for the really large ones); ptm_stream = 0 keeps it on the grid solver it replaces (solver_stream.hpp), which
+    still takes nonlinear-product components and components with more cameras than fit."""
     make, mit, opts = STREAM_CASES[name]
     pp = make()
+    opts = dict(opts, **({"ptm_stream": 0} if solver == "grid" else {}))
     g, r, trv = solve(gctx, pp, maxiters=mit, trace=1 << 13, opts=opts)
     check_replay(pp, trv, r, mit)
     assert np.array_equal(g.get_x(), r.x)
@@ -739,6 +744,52 @@ def test_streaming_grid_solver_replays_against_oracle(name, gctx):
     # same problem still replays
     _, r2, trv2 = solve(gctx, pp, maxiters=2, trace=4096, opts={"coop_min_factors": 0})
     check_replay(pp, trv2, r2, 2)
+
+
+def _plan_of(gctx, pp, opts):
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    return g, plan
+
+
+@pytest.mark.parametrize("case", ["ladybug as 64 workgroups", "24 cameras x 30000 points", "more than 2^20 points"])
+def test_wide_point_major_group_on_one_large_component(case, gctx):
+    """ONE bundle-adjustment component on a large share of the device (cgd_ptmg_kernel<512, ., true>: consecutive workgroups
+    over all XCDs, one exchange entry a workgroup, the partial camera gradients added by shares): the solver that takes what
+    is too large for the register-resident cooperative solver when its cameras fit the LDS.  Replayed against the oracle like
+    every solver, the same bits twice, the dispatcher's choice reported."""
+    if case == "ladybug as 64 workgroups":
+        pp, mit, opts, K = P.load_bal(), 4, {"force_stream": 1, "ptm_group": 64}, 64
+    elif case == "24 cameras x 30000 points":
+        pp, mit, opts, K = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4), 3, {}, None
+    else:
+        pp, mit, opts, K = P.make_synthetic_ba(1, 6, (1 << 20) + 4096, obs_per_pt=2), 1, {}, None
+    pp.single_component()
+    g, plan = _plan_of(gctx, pp, dict(opts, trace_records=1 << 13, dump_iters=mit))
+    ends = []
+    for _ in range(2):
+        plan.set_start(pp.x0)
+        plan.solve(mit, 3e-8)
+        r = plan.fetch()
+        ends.append((r.fret[0], r.x.tobytes()))
+    assert ends[0] == ends[1]                                  # fixed order of every sum
+    assert plan.info("components_point_major") == 1 and plan.info("components_grid_stream") == 0 and plan.info("point_major_wide") == 1
+    assert plan.info("point_major_group") == (K or plan.info("point_major_group")) and plan.info("point_major_group") > 16
+    tr, n = plan.get_trace(0, 1 << 13)
+    check_replay(pp, (tr[:n], plan.get_vectors(0, mit)), r, mit)
+    assert r.delta[0] < 0 and np.array_equal(g.get_x(), r.x)
+    # ... and the grid solver it replaces ends where it does after one line minimisation
+    g2, plan2 = _plan_of(gctx, pp, {"ptm_stream": 0, **({"force_stream": 1} if "force_stream" in opts else {})})
+    plan2.set_start(pp.x0)
+    plan2.solve(1, 3e-8)
+    r2 = plan2.fetch()
+    plan.set_start(pp.x0)
+    plan.solve(1, 3e-8)
+    r1 = plan.fetch()
+    assert plan2.info("components_grid_stream") == 1
+    assert abs(r1.fret[0] - r2.fret[0]) <= 1e-6 * abs(r2.fret[0])      # (one line minimisation: Brent's own tolerance)
 
 
 def test_component_beyond_register_capacity_uses_streaming(gctx):
