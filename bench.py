@@ -64,7 +64,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "synthetic-L", "ladybug-components"])
+    ap.add_argument("--workload", default="ladybug-full", choices=["ladybug-full", "synthetic-S", "synthetic-L", "ladybug-components", "large-component"])
+    ap.add_argument("--large-shape", default="64x2000000x4", help="large-component: cameras x points x observations per point of the one component")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs block (BASELINE configs 1, 2, 3, 5-S)")
+    ap.add_argument("--no-large-component", action="store_true", help="skip the large_component block (one component larger than ladybug)")
     ap.add_argument("--components", type=int, default=256, help="synthetic-L: components per rank (weak) / in total (strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the synthetic workloads keep their total size (synthetic-S: 1000 components, synthetic-L: "
@@ -79,8 +82,11 @@ def parse():
     return ap.parse_args()
 
 
-def build_problem(workload: str, rank: int, components: int = 256, world: int = 1, strong: bool = False):
+def build_problem(workload: str, rank: int, components: int = 256, world: int = 1, strong: bool = False, large_shape: str = "64x2000000x4"):
     from rdis_amd import problems as P
+    if workload == "large-component":
+        c, pn, k = (int(v) for v in large_shape.split("x"))
+        return P.make_synthetic_ba(1, c, pn, obs_per_pt=k, first_comp=rank).single_component()
     if strong:   # a fixed decomposition, sharded: components are generated from their ids, so a rank builds only its own
         if workload not in ("synthetic-S", "synthetic-L"):
             raise SystemExit("--scaling strong needs a decomposable workload (synthetic-S / synthetic-L)")
@@ -133,7 +139,7 @@ def strong_scaling_shard(rank: int, world: int, components: int = None):
     return pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads
 
 
-def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, steps=3, warmup=1):
+def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, steps=3, warmup=1, cpu=False):
     """the strong-scaling block of the bench line: the fixed 1000-component decomposition solved by
     all ranks together; barrier + synchronize around exactly `steps` solves, MAX over ranks"""
     from rdis_amd import capi, problems as P
@@ -205,6 +211,19 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
                         "kernel": "cgd_ptm_kernel / cgd_ptmg_kernel (solver_ptm.hpp)", "kernel_ms_avg": kms / max(steps, 1),
                         "algorithmic_bytes_per_launch": abytes / max(steps, 1), "rank": 0}}
     plan.close()
+    if world == 1 and cpu:
+        # the CPU leg of this block: the oracle (a port, one core) on the first three of the 1000 components
+        from oracle import oracle as O
+        o = O.OracleProblem(pp)
+        t0c = time.perf_counter()
+        cits, cfe = 0, 0
+        for c in range(3):
+            fv, fc = pp.component(c)
+            ro = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=maxiters)
+            cits += ro.iters + 1; cfe += ro.nfeval
+        dtc = time.perf_counter() - t0c
+        out["cpu_baseline"] = {"value": cits / dtc, "unit": "iters/s", "cores": 1, "kind": "port", "f_evals_per_s": cfe / dtc,
+                               "sample": "the first 3 of the %d components, dense gradient accumulation" % pp.ncomp}
     if world == 1:
         out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"])
     prob.close()
@@ -236,6 +255,150 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
                      "objective_rank0": float(r.fret.sum())})
         plan.close()
     return rows
+
+
+def latency_floor():
+    """the pieces of ONE dependent evaluation of the cooperative solvers, measured on this device by tools/microbench/eval_floor
+    (built by __graft_entry__.build()): a wave's factor arithmetic, its wave sums, one store-to-load hop between compute units,
+    one step of the control logic.  None when the binary is not there."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "microbench", "bin", "eval_floor")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:   # (a measurement aid: never the reason a bench run fails)
+        return None
+
+
+def _timed_solves(plan, x0, maxiters, steps):
+    plan.set_start(x0); plan.solve(maxiters, 3e-8); plan.fetch()
+    kms, nfe, nge, its = 0.0, 0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.set_start(x0)
+        plan.solve(maxiters, 3e-8)
+        r = plan.fetch()
+        kms += plan.last_kernel_ms()[0]
+        nfe += int(r.nfeval.sum()); nge += int(r.ngeval.sum()); its += int((r.iters.astype(np.int64) + 1).sum())
+    dt = time.perf_counter() - t0
+    return r, dt, kms, nfe, nge, its
+
+
+def configs_block(ctx, maxiters: int, cpu: bool):
+    """One row per BASELINE.json config that is not the headline (config 4) or the strong-scaling block (config 5-L): iterations/s
+    over all components, f-evals/s, final objective, the solver kernel the dispatcher picked, and a one-core CPU leg (the oracle, a
+    port: the same workload, or the stated sample of it).  SURVEY 8d / BASELINE.md section 3."""
+    from rdis_amd import capi, problems as P
+    with open(os.path.join(ROOT, "tests", "golden", "sinusoid_start.json")) as fh:
+        sin_x0 = np.array(json.load(fh)["x0"])
+
+    def sinusoid():
+        pp = P.make_high_dim_sinusoid()
+        pp.x0 = sin_x0
+        return pp.single_component()
+    cases = [
+        ("config 1: testpoly (data/testpoly.txt, 2 variables; the reference runs it on the CPU path only)", lambda: P.load_poly().single_component(), 200, None,
+         "src/main.cpp:180-197"),
+        ("config 2: optSinusoid default high-dim sinusoid (121 variables, 362 nonlinear-product factors, one component), committed full-domain start",
+         sinusoid, 100, None, "src/optimize_sinusoid.cpp:99-233"),
+        ("config 3: ladybug-49-7776 --ncams 5 --npts 30 as one subspace solve (135 variables, 121 factors)", lambda: P.load_bal(ncams=5, npts=30).single_component(), 100, None,
+         "src/bundleadjust/optBA.cpp:117-330"),
+        ("config 5-S: synthetic decomposable BA, 1000 components x (3 cameras, 40 points, 120 observations), one launch", lambda: P.make_synthetic_ba(1000, 3, 40), 10, 250,
+         "src/OptimizableFunctionGenerator.cpp:660-760"),
+    ]
+    kinds = ("components_cooperative", "components_grid_stream", "components_tiny", "components_lds", "components_point_major", "components_plain")
+    rows = []
+    for label, make, steps, cpu_sample, ref in cases:
+        pp = make()
+        prob = capi.Problem(ctx, pp)
+        plan = capi.Plan(prob)
+        x0 = pp.x0[pp.comp_free_vid]
+        r, dt, kms, nfe, nge, its = _timed_solves(plan, x0, maxiters, steps)
+        row = {"config": label, "reference": ref, "components": int(pp.ncomp), "factors": int(pp.nfac), "variables": int(pp.nvars), "steps": steps,
+               "value": its / dt, "unit": "iters/s", "ms_per_step": dt / steps * 1e3, "kernel_ms": kms / steps,
+               "f_evals_per_s": nfe / dt, "grad_evals_per_s": nge / dt, "final_objective": float(r.fret.sum()),
+               "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))},
+               "solver": {k[len("components_"):]: int(plan.info(k)) for k in kinds if plan.info(k)}}
+        plan.close(); prob.close()
+        if cpu:
+            from oracle import oracle as O
+            o = O.OracleProblem(pp)
+            ncomp = pp.ncomp if cpu_sample is None else min(cpu_sample, pp.ncomp)
+            reps = max(1, int(20000 // max(pp.nfac * ncomp // max(pp.ncomp, 1), 1))) if pp.ncomp == 1 else 1
+            t0 = time.perf_counter()
+            cits, cfe, cobj = 0, 0, 0.0
+            for _ in range(reps):
+                cobj = 0.0
+                for c in range(ncomp):
+                    fv, fc = pp.component(c)
+                    o.assign(None, pp.x0)
+                    ro = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=maxiters)
+                    cits += ro.iters + 1; cfe += ro.nfeval; cobj += ro.fret
+            dtc = time.perf_counter() - t0
+            row["cpu_baseline"] = {"value": cits / dtc, "unit": "iters/s", "cores": 1, "kind": "port", "f_evals_per_s": cfe / dtc,
+                                   "sample": ("the workload %d time(s)" % reps) if ncomp == pp.ncomp else "the first %d of %d components" % (ncomp, pp.ncomp),
+                                   "final_objective_of_the_sample": cobj}
+        rows.append(row)
+    return {"what": "BASELINE.json configs 1, 2, 3 and 5-S on one GPU, SSmaxit %d (config 4: the headline; config 5-L: strong_scaling; the recursion over all "
+                    "components of configs 3 and 4: all_components)" % maxiters, "rows": rows}
+
+
+LARGE_SHAPES = [("8e6 factors", 64, 2000000, 4), ("1.2e6 observations", 120, 300000, 4)]
+
+
+def large_component(ctx, maxiters: int, cpu: bool, steps: int = 2):
+    """ONE bundle-adjustment component larger than ladybug (the larger BAL problems): the wide point-major group
+    (solver_ptm.hpp, cgd_ptmg_kernel<512, ., true>: a workgroup per compute unit on the one component) that since round 6 takes
+    what is too large for the register-resident cooperative solver when its cameras fit the LDS.  Per shape: `steps` timed solves
+    of SSmaxit iterations from the resident start (solve + fetch), the kernel's HIP-event time, its algorithmic bytes (24F + 8N + 8
+    a value, 24F + 16N + 8 a value + slope or gradient) against the HBM peak, and a one-core CPU sample (the oracle, ONE CG
+    iteration of the same component)."""
+    from rdis_amd import capi, problems as P
+    rows = []
+    for label, C_, Pn, K_ in LARGE_SHAPES:
+        pp = P.make_synthetic_ba(1, C_, Pn, obs_per_pt=K_).single_component()
+        prob = capi.Problem(ctx, pp)
+        plan = capi.Plan(prob)
+        plan.set_start(pp.x0)
+        t0 = time.perf_counter()
+        plan.solve(maxiters, 3e-8); r = plan.fetch(want_x=False)     # (the first solve builds the solver's tables)
+        first = time.perf_counter() - t0
+        kms, nfe, nge, its = 0.0, 0, 0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.set_start(pp.x0)
+            plan.solve(maxiters, 3e-8)
+            r = plan.fetch(want_x=False)
+            kms += plan.last_kernel_ms()[0]
+            nfe += int(r.nfeval[0]); nge += int(r.ngeval[0]); its += int(r.iters[0]) + 1
+        dt = time.perf_counter() - t0
+        F, N = pp.nfac, pp.nvars
+        abytes = (nfe - nge) * (24.0 * F + 8 * N + 8) + nge * (24.0 * F + 16 * N + 8)
+        ach = abytes / (kms * 1e-3) / 1e9
+        row = {"shape": label, "cameras": C_, "points": Pn, "factors": int(F), "variables": int(N), "steps": steps,
+               "value": its / dt, "unit": "iters/s", "ms_per_solve": dt / steps * 1e3, "kernel_ms": kms / steps,
+               "f_evals_per_solve": nfe / steps, "us_per_evaluation": kms * 1e3 / max(nfe, 1), "f_evals_per_s": nfe / dt,
+               "final_objective": float(r.fret[0]), "first_solve_s": first,
+               "workgroups": int(plan.info("point_major_group")), "wide_group": int(plan.info("point_major_wide")),
+               "solver": "cgd_ptmg_kernel<512, ., true> (solver_ptm.hpp)" if plan.info("components_point_major") else
+                         "cgd_stream_kernel (solver_stream.hpp)" if plan.info("components_grid_stream") else "other",
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": measured_traffic("large-component-%dx%dx%d" % (C_, Pn, K_)),
+                            "kernel_ms_avg": kms / steps, "algorithmic_bytes_per_launch": abytes / steps}}
+        plan.close()
+        prob.close()
+        if cpu:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            ro = O.OracleProblem(pp).cgd(maxiters=1)
+            dtc = time.perf_counter() - t0
+            row["cpu_baseline"] = {"value": (ro.iters + 1) / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
+                                   "sample": "ONE CG iteration of the same component (%d f-evals), dense gradient accumulation" % ro.nfeval,
+                                   "f_evals_per_s": ro.nfeval / dtc}
+        rows.append(row)
+    return {"what": "one bundle-adjustment component larger than ladybug on one GPU, SSmaxit %d" % maxiters, "rows": rows}
 
 
 def host_cpu():
@@ -559,7 +722,7 @@ def main():
     if torch is not None:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
 
-    pp = build_problem(a.workload, rank, a.components, world, a.scaling == "strong")
+    pp = build_problem(a.workload, rank, a.components, world, a.scaling == "strong", a.large_shape)
     prob = capi.Problem(ctx, pp)
     plan = capi.Plan(prob)
     for kv in a.opt:
@@ -631,6 +794,7 @@ def main():
                                     "one such component per GPU") if a.workload == "ladybug-full" else
                        "ladybug-49-7776 with the cameras fixed: 7776 single-point components per GPU, SSmaxit 25" if a.workload == "ladybug-components" else
                        f"synthetic decomposable BA: {pp.ncomp} components x (49 cameras, 7776 points, 31104 observations) per GPU, SSmaxit 25" if a.workload == "synthetic-L" else
+                       f"one synthetic BA component of {a.large_shape} (cameras x points x observations per point) per GPU, SSmaxit {a.maxiters}" if a.workload == "large-component" else
                        "synthetic decomposable BA: 1000 components x (3 cameras, 40 points, 120 observations) per GPU, SSmaxit 25",
                        "decomposition": (f"strong scaling: the components of the whole decomposition are shared out over {world} rank(s); "
                                          "rank 0's share is reported below") if a.scaling == "strong" else "weak scaling: the workload is per GPU",
@@ -641,7 +805,7 @@ def main():
             "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in
                                       zip(*np.unique(r.status & 0xFF, return_counts=True))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload if a.workload != "large-component" else "large-component-" + a.large_shape),
                          "traffic_source": "profiles/traffic.json (PMC passes of the same command in the profile round; not collected in this run)",
                          "kernel": "cgd solver kernel(s)", "kernel_ms_avg": kms / max(klaunch, 1),
                          "algorithmic_bytes_per_launch": abytes / max(klaunch, 1),
@@ -654,6 +818,16 @@ def main():
                                               "governs a single-component solve: DESIGN.md 3.2b; cycle stamps of the pipeline's three sides: profiles/r02_g_pipe_ladybug_stamps.txt)"}
                                      if pp.ncomp == 1 else None)},
         }
+        if world == 1 and pp.ncomp == 1 and line["roofline"]["latency"] is not None:
+            fl = latency_floor()
+            if fl is not None:
+                lat = line["roofline"]["latency"]
+                lat["floor_us"] = fl["floor_us"]
+                lat["floor"] = fl
+                lat["floor_over_measured"] = fl["floor_us"] / lat["us_per_eval"] if lat["us_per_eval"] > 0 else None
+                lat["floor_note"] = ("the floor is that of a strictly serial chain (step -> arithmetic -> reduce -> hop); the pipelined solver evaluates "
+                                     "guessed Brent steps ahead of its control logic (84 % of them hold), which is how the measured figure reaches the "
+                                     "serial floor although every evaluation also pays a sweep over 1000 granules and a request hand-over")
         if world == 1:
             line["plugin_call"] = plugin_call(prob, pp, a.maxiters)
             if a.workload == "ladybug-full" and a.maxiters == 25:
@@ -667,11 +841,15 @@ def main():
     # north_star's scaling workload, in the command the driver runs: for every N, N = 1 included
     if a.workload == "ladybug-full" and not a.no_strong_scaling:
         STRONG.clear(); STRONG.update(STRONG_SIZES[a.strong_size])
-        ss = run_strong_scaling(ctx, rank, world, local_rank, dist, torch, a.maxiters)
+        ss = run_strong_scaling(ctx, rank, world, local_rank, dist, torch, a.maxiters, cpu=not a.no_cpu_baseline and world == 1)
         if rank == 0:
             line["strong_scaling"] = ss
     if a.workload == "ladybug-full" and world == 1 and not a.no_all_components:
         line["all_components"] = all_components(local_rank, a.maxiters)
+    if a.workload == "ladybug-full" and world == 1 and not a.no_configs:
+        line["configs"] = configs_block(ctx, a.maxiters, cpu=not a.no_cpu_baseline)
+    if a.workload == "ladybug-full" and world == 1 and not a.no_large_component:
+        line["large_component"] = large_component(ctx, a.maxiters, cpu=not a.no_cpu_baseline)
     import ctypes
     ctypes.CDLL(None).fflush(None)   # every rank: nothing buffered (RCCL's banner) may surface after rank 0's JSON
     sys.stdout.flush()

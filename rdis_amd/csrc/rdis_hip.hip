@@ -127,6 +127,8 @@ struct GradPlan {
     int64_t nf = 0;
     DevBuf ints, shorts, fac;      // one int32 block, one 16-bit block, the list as int32 (explicit lists)
     DevBuf cstage, pstage, partial;
+    std::vector<int64_t> ids;      // the list itself (explicit lists): compared on a hash hit -- two lists with the same hashes must not share tables
+    size_t device_bytes() const { return ints.bytes + shorts.bytes + fac.bytes + cstage.bytes + pstage.bytes + partial.bytes; }
     rdis_hip::GradTables T{};
 };
 
@@ -692,7 +694,12 @@ int launch_eval_sum(rdis_hip_problem* p, int nf, const int* dfac, int blocks) {
 
 namespace {
 
-constexpr size_t GRAD_PLAN_CACHE = 4;   // factor lists whose tables the problem keeps (least recently used goes)
+// Factor lists whose tables the problem keeps: up to GRAD_PLAN_CACHE of them within GRAD_PLAN_BYTES of device memory (least
+// recently used goes first).  A caller that asks for the gradients of a level's components in turn (computeGradient(facs, pg)
+// per component, as the reference does) cycles through dozens of lists: with room for four (round 5) every call rebuilt and
+// reallocated its tables.  A list of at most one chunk needs none (eval_grad_short).
+constexpr size_t GRAD_PLAN_CACHE = 64;
+constexpr size_t GRAD_PLAN_BYTES = (size_t)1 << 30;
 
 bool fused_path(const rdis_hip_problem* p) { return p->kind == KIND_BA && p->ncam_blocks > 0; }
 
@@ -865,7 +872,10 @@ int build_grad_plan(rdis_hip_problem* p, int64_t nf64, const int64_t* fac, GradP
     if (!rc_) rc_ = dalloc(c, G.cstage, (size_t)std::max(cs_ptr.back(), 1) * 9 * sizeof(double));
     if (!rc_) rc_ = dalloc(c, G.pstage, (size_t)std::max(ps_ptr.back(), 1) * 3 * sizeof(double));
     if (!rc_) rc_ = dalloc(c, G.partial, (size_t)std::max(nchunks, 1) * sizeof(double));
-    if (rc_) return rc_;
+    if (rc_) {   // (the uploads above are asynchronous copies out of host vectors that go out of scope with this call)
+        (void)hipStreamSynchronize(c->stream);
+        return rc_;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host images go out of scope)
     const int* I = G.ints.as<int>();
     const unsigned short* S = G.shorts.as<unsigned short>();
@@ -896,11 +906,16 @@ int grad_plan_for(rdis_hip_problem* p, int64_t nf, const int64_t* fac, GradPlan*
         if (k0 == 0 && k1 == 0) k1 = 1;
     }
     for (auto& g : p->grad_plans)
-        if (g->nf == nf && g->key0 == k0 && g->key1 == k1) { g->used = ++p->grad_tick; *out = g.get(); return 0; }
-    if (p->grad_plans.size() >= GRAD_PLAN_CACHE) {
+        if (g->nf == nf && g->key0 == k0 && g->key1 == k1 &&
+            (fac ? g->ids.size() == (size_t)nf && std::memcmp(g->ids.data(), fac, (size_t)nf * sizeof(int64_t)) == 0 : g->ids.empty())) {
+            g->used = ++p->grad_tick; *out = g.get(); return 0;
+        }
+    auto held = [&]() { size_t b = 0; for (auto& g : p->grad_plans) b += g->device_bytes(); return b; };
+    bool synced = false;
+    while (!p->grad_plans.empty() && (p->grad_plans.size() >= GRAD_PLAN_CACHE || held() > GRAD_PLAN_BYTES)) {
         size_t lru = 0;
         for (size_t i = 1; i < p->grad_plans.size(); ++i) if (p->grad_plans[i]->used < p->grad_plans[lru]->used) lru = i;
-        HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream));   // (a launch that reads its tables may be in flight)
+        if (!synced) { HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream)); synced = true; }   // (a launch that reads its tables may be in flight)
         p->grad_plans.erase(p->grad_plans.begin() + (long)lru);
     }
     std::unique_ptr<GradPlan> G(new (std::nothrow) GradPlan);
@@ -909,6 +924,7 @@ int grad_plan_for(rdis_hip_problem* p, int64_t nf, const int64_t* fac, GradPlan*
     try { rc = build_grad_plan(p, nf, fac, *G); } catch (const std::bad_alloc&) { return fail(p->ctx, RDIS_HIP_ENOMEM, "eval_grad: host allocation"); }
     if (rc) return rc;
     G->key0 = k0; G->key1 = k1; G->used = ++p->grad_tick;
+    if (fac) G->ids.assign(fac, fac + nf);
     *out = G.get();
     p->grad_plans.push_back(std::move(G));
     return 0;
@@ -975,6 +991,37 @@ int eval_grad_two_pass(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
     return 0;
 }
 
+// A list of at most one chunk (GRAD_LANES entries: a component's handful of factors, a single factor) needs no tables: the
+// per-factor partials, then one lane per variable adds its slots in list order -- which for one chunk is exactly the order of the
+// fused pass (one chunk, one tile: every block's rows in list order), the same bits; the value by the chunk kernel rdis_hip_eval
+// uses, the same bits too.  What the fused form would pay for such a list is its table build: six arrays over all N variables,
+// half a dozen allocations, three uploads and two or three synchronisations (advisor, round 5).
+int eval_grad_short(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
+    rdis_hip_ctx* c = p->ctx;
+    int rc;
+    const int* dfac;
+    if ((rc = stage_ids(p, nf, fac, p->F, &dfac))) return rc;
+    ivec ptr, idx;
+    build_v2s(p, nf, fac, ptr, idx);
+    DevBuf lptr, lidx;
+    if ((rc = upload(c, lptr, ptr))) return rc;
+    if ((rc = upload(c, lidx, idx))) { (void)hipStreamSynchronize(c->stream); return rc; }
+    if ((rc = ensure(c, p->partial, sizeof(double)))) { (void)hipStreamSynchronize(c->stream); return rc; }
+    if (!rc) rc = ensure(c, p->gfac, (size_t)p->nslots() * sizeof(double));
+    if (!rc) rc = ensure(c, p->g_all, (size_t)p->N * sizeof(double));
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    ProblemView V = p->view();
+    partials_kernel<KIND_BA><<<grid_for(c, nf, 256), 256, 0, c->stream>>>(V, (int)nf, dfac, p->gfac.as<double>());
+    HIPCHK(c, hipGetLastError());
+    gather_grad_kernel<<<grid_for(c, p->N, 256), 256, 0, c->stream>>>((int)p->N, lptr.as<int>(), lidx.as<int>(), p->gfac.as<double>(), p->g_all.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, eval_chunks_launch(c->stream, 1, V, (int)nf, dfac, p->partial.as<double>()));
+    final_sum_kernel<<<1, 256, 0, c->stream>>>(1, p->partial.as<double>(), p->scalar.as<double>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (lptr / lidx and the host vectors go out of scope)
+    return 0;
+}
+
 int eval_grad_on_device(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
     if (int rc = refuse_exponential(p, nf, fac, "eval_grad")) return rc;
     if (nf == 0) {
@@ -985,6 +1032,7 @@ int eval_grad_on_device(rdis_hip_problem* p, int64_t nf, const int64_t* fac) {
         HIPCHK(c, hipMemsetAsync(p->scalar.p, 0, sizeof(double), c->stream));
         return 0;
     }
+    if (fused_path(p) && fac && nf <= GRAD_LANES) return eval_grad_short(p, nf, fac);
     return fused_path(p) ? eval_grad_fused(p, nf, fac) : eval_grad_two_pass(p, nf, fac);
 }
 
@@ -1771,7 +1819,8 @@ int prepare_partition(rdis_hip_plan* L) {
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }
         const size_t nc = (size_t)L->ncomp;
         cvec kind_of(nc, 0);   // 1 = LDS-resident, 2 = point-major streaming
-        const int ptm_max_threads = L->ptm_threads ? L->ptm_threads : 768;   // (the staging area of its gradient grows with the workgroup)
+        // (the staging area of its gradient grows with the workgroup; a plan with a component meant for a wide group keeps to that group's 512 lanes)
+        const int ptm_max_threads = L->ptm_threads ? L->ptm_threads : L->ptm_wide_wanted ? PTM_WIDE_THREADS : 768;
         ivec ls_ncb(nc, 0), ls_gcount(nc, 0), pm_pt0(nc, 0), ls_fidx((size_t)L->nfac, 0);
         ivec ls_pidx((size_t)L->nfac, 0);   // (host only) a listed factor's point block within its component: all 31 bits of it
         std::vector<ivec> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
@@ -2398,6 +2447,13 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     rdis_hip_problem* p = L->prob;
     rdis_hip_ctx* c = p->ctx;
     HIPCHK(c, hipSetDevice(c->device));
+    // (a plan made before rdis_hip_nlp_set_exponential marked one of its factors: the reference's gradient asserts the flag off,
+    // src/NonlinearProductFactor.cpp:110 -- refused here as at plan_create, not solved with values and slopes of two functions)
+    if (!p->h_useexp.empty())
+        for (int f : L->h_fac_id)
+            if (p->h_useexp[(size_t)f])
+                return fail(c, RDIS_HIP_EINVAL, "plan_solve: factor " + std::to_string(f) + " is exponential (set after the plan was created); "
+                                                "the reference's gradient asserts it is not (NonlinearProductFactor.cpp:110)");
     if (!L->have_start) { int rc = rdis_hip_plan_set_start(L, nullptr); if (rc) return rc; }
     L->last_launches = 0;
     L->timed = false;
@@ -2529,7 +2585,7 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         // loses less to whole wave-chunks -- as long as a workgroup keeps some twenty wave-chunks of points per trial point
         // (below that the exchange costs what the split saves: 125 components of 2048 points 9.6 ms alone, 9.7 as pairs;
         // of 7776 points 35.8 ms alone, 27.7 as groups of four)
-        int threads = L->ptm_threads ? L->ptm_threads : 768;
+        int threads = L->ptm_threads ? L->ptm_threads : L->ptm_wide_wanted ? PTM_WIDE_THREADS : 768;
         int K = 1;
         if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty()) {
             // groups of K workgroups: of 512 lanes (a workgroup per compute unit) or of 256 (two) -- whichever brings more
