@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-objective-band", action="store_true")
     ap.add_argument("--no-all-components", action="store_true", help="skip the all_components block (the recursion's whole call mix)")
     ap.add_argument("--opt", action="append", default=[], help="plan option name=value")
+    ap.add_argument("--collective", default="c-abi", choices=["c-abi", "torch"],
+                    help="how the ranks' objective all-reduce runs: the library's own RCCL entry points (default; no torch in the process) or torch.distributed")
     return ap.parse_args()
 
 
@@ -139,7 +141,91 @@ def strong_scaling_shard(rank: int, world: int, components: int = None):
     return pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads
 
 
-def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, steps=3, warmup=1, cpu=False):
+class RcclCollective:
+    """The ranks' one exchange through the library's own C ABI (include/rdis_hip.h: rdis_hip_comm_*, rdis_hip_allreduce_objective
+    -- ncclAllReduce over RCCL / xGMI on the solver's stream): no torch in the process.  The 128-byte communicator id travels from
+    rank 0 to the others through a file in /dev/shm named after the launcher's pid and port (one node, as the contract says)."""
+    name = "rccl through the C ABI (rdis_hip_allreduce_objective)"
+
+    def __init__(self, capi, ctx, rank, world):
+        self.ctx = ctx
+        key = "rdis_bench_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+        path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
+        if rank == 0:
+            uid = capi.Comm.unique_id()
+            with open(path + ".tmp", "wb") as fh:
+                fh.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    if time.time() - os.path.getmtime(path) < 600:
+                        with open(path, "rb") as fh:
+                            uid = fh.read()
+                        if len(uid) == 128:
+                            break
+                except OSError:
+                    pass
+                if time.time() - t0 > 300:
+                    raise RuntimeError("no communicator id from rank 0 at " + path)
+                time.sleep(0.01)
+        self.comm = capi.Comm(ctx, world, rank, uid)
+        self.comm.barrier()
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def reduce_objective(self, plan):
+        plan.allreduce_objective(self.comm, fetch=False)   # in place on the device, behind the solve on its stream
+
+    def barrier_sync(self):
+        self.comm.barrier()
+        self.ctx.synchronize()
+
+    def allreduce(self, values, op="sum"):
+        return [float(v) for v in self.comm.allreduce(values, op)]
+
+    def close(self):
+        self.comm.barrier()
+        self.comm.close()
+
+
+class TorchCollective:
+    """the same through torch.distributed (backend "nccl" = RCCL): the fallback, --collective torch"""
+    name = "rccl through torch.distributed"
+
+    def __init__(self, ctx, torch, dist, local_rank):
+        self.ctx, self.torch, self.dist, self.dev = ctx, torch, dist, f"cuda:{local_rank}"
+        self.views = {}
+
+    def reduce_objective(self, plan):
+        t = self.views.get(id(plan))
+        if t is None:
+            class _Dev:
+                def __init__(self, ptr):
+                    self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+            t = self.views[id(plan)] = self.torch.as_tensor(_Dev(plan.objective_device_ptr()), device=self.dev)
+        self.dist.all_reduce(t)
+
+    def barrier_sync(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.ctx.synchronize()
+
+    def allreduce(self, values, op="sum"):
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+def run_strong_scaling(ctx, rank, world, coll, maxiters, steps=3, warmup=1, cpu=False):
     """the strong-scaling block of the bench line: the fixed 1000-component decomposition solved by
     all ranks together; barrier + synchronize around exactly `steps` solves, MAX over ranks"""
     from rdis_amd import capi, problems as P
@@ -147,23 +233,16 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
     prob = capi.Problem(ctx, pp)
     plan = capi.Plan(prob, *csr)
     plan.set_start(pp.x0[csr[1]])
-    obj_t = None
-    if torch is not None:
-        class _Dev:
-            def __init__(self, ptr):
-                self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-        obj_t = torch.as_tensor(_Dev(plan.objective_device_ptr()), device=f"cuda:{local_rank}")
 
     def step():
         plan.solve(maxiters, 3e-8)
-        if dist is not None:
-            dist.all_reduce(obj_t)
+        if coll is not None:
+            coll.reduce_objective(plan)
         return plan.fetch()
 
     def sync():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if coll is not None:
+            coll.barrier_sync()
         ctx.synchronize()
     for _ in range(warmup):
         r = step()
@@ -181,13 +260,9 @@ def run_strong_scaling(ctx, rank, world, local_rank, dist, torch, maxiters, step
     dt = time.perf_counter() - t0
     objective = plan.objective()
     kmax = kms / steps
-    if dist is not None:
-        tt = torch.tensor([dt, kmax], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, kmax = (float(v) for v in tt.tolist())
-        it = torch.tensor([float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(it)
-        iters = float(it.item())
+    if coll is not None:
+        dt, kmax = coll.allreduce([dt, kmax], "max")
+        iters = coll.allreduce([float(iters)])[0]
     ncu = 256
     max_comps = max(len(part) for part in P.shard_components(pp.ncomp, np.diff(pp.comp_fac_ptr), world))
     out = {"workload": (f"fixed decomposition of {pp.ncomp} independent synthetic BA components x ({STRONG['ncams']} cameras, "
@@ -708,10 +783,11 @@ def main():
                  f"--nproc-per-node {a.gpus} (WORLD_SIZE is {world})")
     if os.environ.get("RDIS_BENCH_DRY_DIST"):
         return dry_dist(a, rank, world)
-    dist = None
-    torch = None
-    if world > 1 or os.environ.get("RDIS_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path on one GPU
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    coll = None
+    want_coll = world > 1 or os.environ.get("RDIS_BENCH_FORCE_DIST") == "1"   # the env var exercises the RCCL path on one GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch = dist = None
+    if want_coll and a.collective == "torch":
         import torch  # before the HIP library: one HIP runtime per process
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -719,8 +795,11 @@ def main():
 
     from rdis_amd import capi
     ctx = capi.Context(local_rank)
-    if torch is not None:
+    if want_coll and a.collective == "torch":
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
+        coll = TorchCollective(ctx, torch, dist, local_rank)
+    elif want_coll:
+        coll = RcclCollective(capi, ctx, rank, world)           # (no torch in this process)
 
     pp = build_problem(a.workload, rank, a.components, world, a.scaling == "strong", a.large_shape)
     prob = capi.Problem(ctx, pp)
@@ -730,12 +809,6 @@ def main():
         plan.set_option(k, int(v))
     plan.set_start(pp.x0[pp.comp_free_vid])
 
-    class _DevObjective:  # torch view of the device-side objective sum
-        def __init__(self, ptr):
-            self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-    obj_t = torch.as_tensor(_DevObjective(plan.objective_device_ptr()), device=f"cuda:{local_rank}") if torch else None
-
     xstart_host = np.ascontiguousarray(pp.x0[pp.comp_free_vid])
 
     def step():
@@ -743,14 +816,13 @@ def main():
         # start point; the decomposition (plan) is resident, as it is for a caller that solves it again
         plan.set_start(xstart_host)
         plan.solve(a.maxiters, 3e-8)
-        if dist is not None:
-            dist.all_reduce(obj_t)  # top-level objective = sum over components (RDISOptimizer.cpp:1491-1494)
+        if coll is not None:
+            coll.reduce_objective(plan)  # top-level objective = sum over components (RDISOptimizer.cpp:1491-1494)
         return plan.fetch()
 
     def sync():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if coll is not None:
+            coll.barrier_sync()
         ctx.synchronize()
 
     for _ in range(a.warmup):
@@ -772,13 +844,9 @@ def main():
     dt = time.perf_counter() - t0
     objective_sum = plan.objective()  # after the all-reduce: whole-job objective
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        it = torch.tensor([iters_done, float(nfe.sum()), float(nge.sum())], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(it)
-        total_iters, total_nfe, total_nge = (float(v) for v in it.tolist())
+    if coll is not None:
+        dt = coll.allreduce([dt], "max")[0]
+        total_iters, total_nfe, total_nge = coll.allreduce([float(iters_done), float(nfe.sum()), float(nge.sum())])
     else:
         total_iters, total_nfe, total_nge = float(iters_done), float(nfe.sum()), float(nge.sum())
 
@@ -799,7 +867,8 @@ def main():
                        "decomposition": (f"strong scaling: the components of the whole decomposition are shared out over {world} rank(s); "
                                          "rank 0's share is reported below") if a.scaling == "strong" else "weak scaling: the workload is per GPU",
                        "components_per_gpu": pp.ncomp, "factors_per_gpu": pp.nfac, "variables_per_gpu": pp.nvars,
-                       "parallelism": f"{world} x independent components, all-reduce of the objective"},
+                       "parallelism": f"{world} x independent components, all-reduce of the objective",
+                       "collective": coll.name if coll is not None else "none (one rank)"},
             "final_objective": float(r.fret.sum()), "objective_sum_all_ranks": objective_sum,
             "f_evals_per_s": total_nfe / dt, "grad_evals_per_s": total_nge / dt,
             "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in
@@ -841,7 +910,7 @@ def main():
     # north_star's scaling workload, in the command the driver runs: for every N, N = 1 included
     if a.workload == "ladybug-full" and not a.no_strong_scaling:
         STRONG.clear(); STRONG.update(STRONG_SIZES[a.strong_size])
-        ss = run_strong_scaling(ctx, rank, world, local_rank, dist, torch, a.maxiters, cpu=not a.no_cpu_baseline and world == 1)
+        ss = run_strong_scaling(ctx, rank, world, coll, a.maxiters, cpu=not a.no_cpu_baseline and world == 1)
         if rank == 0:
             line["strong_scaling"] = ss
     if a.workload == "ladybug-full" and world == 1 and not a.no_all_components:
@@ -853,9 +922,8 @@ def main():
     import ctypes
     ctypes.CDLL(None).fflush(None)   # every rank: nothing buffered (RCCL's banner) may surface after rank 0's JSON
     sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if coll is not None:
+        coll.close()
     ctx.close()
     if rank == 0:
         # RCCL prints a version banner through C stdio, which is flushed at exit when stdout is a

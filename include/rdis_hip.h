@@ -224,6 +224,32 @@ int rdis_hip_plan_fetch(rdis_hip_plan *plan, double *x_out, double *fret, double
  * returns a device pointer to one double valid until the next plan_solve. */
 int rdis_hip_plan_objective_device(rdis_hip_plan *plan, void **dev_ptr);
 
+/* ---- the path's one collective --------------------------------------------------------
+ * Independent components of a recursion level are sharded over the GPUs of a node (rdis_amd/dist.py, DESIGN.md section 5:
+ * no data-path collective); what the ranks exchange is the top-level objective -- the sum the reference forms on one host
+ * (src/RDISOptimizer.cpp:1491-1494) -- one fp64 all-reduce over RCCL / xGMI, on the stream the solve ran on.
+ *   comm_unique_id   rank 0 makes the 128-byte id the ranks of a communicator share (ncclGetUniqueId); the caller
+ *                    distributes it (a file, a socket, MPI: its business)
+ *   comm_create      one rank per process and GPU (ncclCommInitRank on the context's device); collective over the ranks
+ *   comm_create_all  one process that drives several contexts (rdis::OptimizableFunction::setDevices): one communicator
+ *                    per context, each on a different GPU (ncclCommInitAll)
+ *   allreduce_objective      sum over the ranks of rdis_hip_plan_objective_device's double, in place, asynchronous on the
+ *                    context's stream; sum_out != NULL: copied out (waits).  comm == NULL: a world of one.
+ *   allreduce_objective_all  the same for the plans of one process's contexts (grouped: one thread drives every rank);
+ *                    comms == NULL: the partial sums meet on the host in plan order (no RCCL, or one GPU listed twice)
+ *   comm_allreduce_f64       a few doubles of host memory summed (op 0) or maximised (op 1) over the ranks: counters, and the
+ *                    barrier + maximum of a timed region
+ * RCCL is loaded when the first communicator is made (dlopen): a single-GPU user never maps it. */
+#define RDIS_HIP_COMM_ID_BYTES 128
+typedef struct rdis_hip_comm rdis_hip_comm;
+int rdis_hip_comm_unique_id(void *id128);
+int rdis_hip_comm_create(rdis_hip_ctx *ctx, int32_t world, int32_t rank, const void *id128, rdis_hip_comm **out);
+int rdis_hip_comm_create_all(int32_t n, rdis_hip_ctx *const *ctxs, rdis_hip_comm **comms);
+void rdis_hip_comm_destroy(rdis_hip_comm *comm);
+int rdis_hip_allreduce_objective(rdis_hip_plan *plan, rdis_hip_comm *comm, double *sum_out);
+int rdis_hip_allreduce_objective_all(int32_t n, rdis_hip_plan *const *plans, rdis_hip_comm *const *comms, double *sum_out);
+int rdis_hip_comm_allreduce_f64(rdis_hip_comm *comm, double *inout, int32_t n, int32_t op);
+
 /* tuning / introspection ---------------------------------------------------------- */
 /* option names: "block_threads" (workgroup size of the per-component solver: 64, 128, 256, 512,
  * 768 or 1024; 0 = auto), "coop_min_factors" (bundle-adjustment components with at least this

@@ -40,9 +40,18 @@ extern "C" {
 #endif
 
 #define RDIS_OPTBA_NOUT 10
+/* rdis_optba_run_hist: the same run, and (schedule 1) where its subspace-optimizer calls go: hist_rows rows, one per depth of the
+ * decomposition tree, of RDIS_OPTBA_HIST_COLS doubles -- [0] nodes of that depth, [1] their free variables (a separator's /
+ * a leaf's) in all, the steps of the reference's schedule at that depth by kind (src/RDISOptimizer.cpp:1131-1133): [2] "initial
+ * values", [3] "iterative improvement", [4] "random restart", [5] steps that made no progress beyond steptol (:1086-1101),
+ * [6] evaluations that were a new minimum (updateDomain, :1507-1577). */
+#define RDIS_OPTBA_HIST_COLS 7
 
 int rdis_optba_run(const char *bal_file, int64_t ncams, int64_t npts, int32_t schedule, int32_t nopts,
                    const char *const *opt_names, const double *opt_vals, int32_t device, double *out, double *x_out);
+int rdis_optba_run_hist(const char *bal_file, int64_t ncams, int64_t npts, int32_t schedule, int32_t nopts,
+                        const char *const *opt_names, const double *opt_vals, int32_t device, double *out, double *x_out,
+                        double *hist, int32_t hist_rows);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,13 @@ SYMBOLS = {
     "rdis_hip_plan_solve": (C.c_int, [_vp, C.c_int32, C.c_double]),
     "rdis_hip_plan_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdis_hip_plan_objective_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "rdis_hip_comm_unique_id": (C.c_int, [_vp]),
+    "rdis_hip_comm_create": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
+    "rdis_hip_comm_create_all": (C.c_int, [C.c_int32, _vp, _vp]),
+    "rdis_hip_comm_destroy": (None, [_vp]),
+    "rdis_hip_allreduce_objective": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
+    "rdis_hip_allreduce_objective_all": (C.c_int, [C.c_int32, _vp, _vp, C.POINTER(C.c_double)]),
+    "rdis_hip_comm_allreduce_f64": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32]),
     "rdis_hip_plan_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "rdis_hip_plan_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rdis_hip_plan_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
@@ -125,7 +132,7 @@ class _Cell:
 def _close_all():
     # the HIP runtime must still be loaded when device memory and streams are released
     objs = [r() for r in _live]
-    for cls in ("Plan", "Problem", "Context"):
+    for cls in ("Comm", "Plan", "Problem", "Context"):
         for o in objs:
             if o is not None and type(o).__name__ == cls:
                 try:
@@ -382,6 +389,50 @@ class Problem:
         return r
 
 
+class Comm:
+    """rdis_hip_comm: the communicator of the path's one collective (the objective's all-reduce over RCCL / xGMI).
+    One rank per process and GPU; `unique_id()` on rank 0, its 128 bytes to every rank, `Comm(ctx, world, rank, id)` on all."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        rc = load_library().rdis_hip_comm_unique_id(buf)
+        if rc:
+            raise RdisHipError(rc, "rdis_hip_comm_unique_id (is librccl.so there?)")
+        return bytes(buf)
+
+    def __init__(self, ctx: Context, world: int, rank: int, uid: bytes):
+        assert len(uid) == 128
+        self.ctx, self.world, self.rank = ctx, world, rank
+        h = _vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        ctx.check(ctx.lib.rdis_hip_comm_create(ctx.h, world, rank, buf, C.byref(h)))
+        self._cell = _Cell(h, ctx.lib.rdis_hip_comm_destroy, owner=ctx._cell)   # (closed before its context)
+        _register(self)
+
+    @property
+    def h(self):
+        return self._cell.h
+
+    def close(self):
+        self._cell.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        """a few host doubles summed / maximised over the ranks (counters; barrier + maximum of a timed region)"""
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self.ctx.check(self.ctx.lib.rdis_hip_comm_allreduce_f64(self.h, _ptr(v), v.shape[0], {"sum": 0, "max": 1}[op]))
+        return v
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+
 class Plan:
     """rdis_hip_plan: a decomposition resident on the device, solvable many times."""
 
@@ -439,6 +490,13 @@ class Plan:
     def objective(self) -> float:
         """sum of fret over the plan's components, as computed on the device"""
         return float(np.frombuffer(self.ctx.copy_to_host(self.objective_device_ptr(), 8), dtype=np.float64)[0])
+
+    def allreduce_objective(self, comm: Optional["Comm"], fetch: bool = True):
+        """the objective summed over the ranks of `comm` (None: a world of one), in place on the device, on the context's
+        stream; fetch: copied out (waits)"""
+        out = C.c_double()
+        self.ctx.check(self.ctx.lib.rdis_hip_allreduce_objective(self.h, comm.h if comm is not None else None, C.byref(out) if fetch else None))
+        return out.value if fetch else None
 
     def objective_device_ptr(self) -> int:
         p = _vp()

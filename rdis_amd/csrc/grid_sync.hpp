@@ -83,8 +83,14 @@ struct SmallCoopState {
     unsigned int pad[15];
 };
 
+// ... and for a WIDE group of that solver (a large share of the device on one component): a CoopState whose entries are one per
+// WORKGROUP -- its first wave publishes values the caller has already summed over the workgroup (every lane holds them) --
+// 256 entries to sweep instead of 2048
+struct WideCoopState : CoopState {};
+
 template <class ST>
 struct GridSyncT {
+    static constexpr bool wg_entry = std::is_same<ST, WideCoopState>::value;
     ST* st;
     int tid, nwg, wg;                   // lane in workgroup, #workgroups, my workgroup
     double* bcast;                      // LDS [2][4]
@@ -96,9 +102,7 @@ struct GridSyncT {
     long long tm[COOP_TM]; // cycles: 0 factor arithmetic, 1 workgroup reduce, 2 publish, 3 sweep, 4 tail,
                       // 5 #exchanges, 6 #sweeps, 7 whole kernel, 8 state-machine step, 9 request hand-over,
                       // 10 combine waves, 11 release, 12.. handler cycles: 12 value, 13 value+slope, 14 gradient (+reduce), 17 line end; 22.. their counts
-    bool wg_entry;                      // a workgroup publishes ONE entry (its first wave, values already summed over the workgroup by the
-                                        // caller: every lane holds them) instead of one per wave -- a wide group of solver_ptm.hpp: 256
-                                        // entries to sweep instead of 2048
+
 
     // ---- inter-workgroup exchange ------------------------------------------------
     __device__ gu64* gran(int buf, int k, int w) const { return (gu64*)&st->granule[buf][w][k]; }

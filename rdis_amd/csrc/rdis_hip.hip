@@ -2692,6 +2692,185 @@ extern "C" int rdis_hip_plan_objective_device(rdis_hip_plan* L, void** dev_ptr) 
     return 0;
 }
 
+// =====================================================================================
+// the path's one collective: the all-reduce of the top-level objective (reference src/RDISOptimizer.cpp:1491-1494 adds the
+// components' values on one host; here the components of a level are sharded over GPUs and the partial sums meet over xGMI)
+// =====================================================================================
+// RCCL is loaded at the first communicator (dlopen): a single-GPU user never maps it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct rdis_hip_comm {
+    rdis_hip_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    DevBuf scratch;            // small host-buffer reductions (rdis_hip_comm_allreduce_f64)
+};
+
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl() {
+    static RcclApi A = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.h) break;
+        }
+        if (!a.h) return a;
+#define RDIS_RCCL_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.h, sym))
+        RDIS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RDIS_RCCL_SYM(CommInitRank, "ncclCommInitRank"); RDIS_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+        RDIS_RCCL_SYM(CommDestroy, "ncclCommDestroy"); RDIS_RCCL_SYM(AllReduce, "ncclAllReduce"); RDIS_RCCL_SYM(GroupStart, "ncclGroupStart");
+        RDIS_RCCL_SYM(GroupEnd, "ncclGroupEnd"); RDIS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RDIS_RCCL_SYM
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommInitAll && a.CommDestroy && a.AllReduce && a.GroupStart && a.GroupEnd;
+        return a;
+    }();
+    return A;
+}
+int rccl_fail(rdis_hip_ctx* c, ncclResult_t r, const char* what) {
+    const char* msg = rccl().GetErrorString ? rccl().GetErrorString(r) : "?";
+    if (c) return fail(c, RDIS_HIP_EDEVICE, std::string(what) + ": RCCL: " + msg);
+    return RDIS_HIP_EDEVICE;
+}
+}  // namespace
+
+extern "C" int rdis_hip_comm_unique_id(void* id128) {
+    if (!id128) return RDIS_HIP_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == RDIS_HIP_COMM_ID_BYTES, "RCCL's unique id is 128 bytes");
+    if (!rccl().ok) return RDIS_HIP_EDEVICE;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return RDIS_HIP_EDEVICE;
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int rdis_hip_comm_create(rdis_hip_ctx* c, int32_t world, int32_t rank, const void* id128, rdis_hip_comm** out) {
+    if (!c || !out || world < 1 || rank < 0 || rank >= world || !id128) return RDIS_HIP_EINVAL;
+    if (!rccl().ok) return fail(c, RDIS_HIP_EDEVICE, "comm_create: librccl.so could not be loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::unique_ptr<rdis_hip_comm> m(new (std::nothrow) rdis_hip_comm);
+    if (!m) return fail(c, RDIS_HIP_ENOMEM, "comm_create: host allocation");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    const ncclResult_t r = rccl().CommInitRank(&m->comm, world, id, rank);
+    if (r != ncclSuccess) return rccl_fail(c, r, "comm_create");
+    m->ctx = c; m->world = world; m->rank = rank;
+    *out = m.release();
+    return 0;
+}
+
+extern "C" int rdis_hip_comm_create_all(int32_t n, rdis_hip_ctx* const* ctxs, rdis_hip_comm** comms) {
+    if (n < 1 || !ctxs || !comms) return RDIS_HIP_EINVAL;
+    for (int i = 0; i < n; ++i) if (!ctxs[i]) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c0 = ctxs[0];
+    if (!rccl().ok) return fail(c0, RDIS_HIP_EDEVICE, "comm_create_all: librccl.so could not be loaded");
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        devs[(size_t)i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i]) return fail(c0, RDIS_HIP_EINVAL, "comm_create_all: a device is listed twice (one rank per GPU)");
+    }
+    std::vector<ncclComm_t> cc((size_t)n, nullptr);
+    const ncclResult_t r = rccl().CommInitAll(cc.data(), n, devs.data());
+    if (r != ncclSuccess) return rccl_fail(c0, r, "comm_create_all");
+    for (int i = 0; i < n; ++i) {
+        rdis_hip_comm* m = new (std::nothrow) rdis_hip_comm;
+        if (!m) { for (int j = 0; j < i; ++j) { delete comms[j]; comms[j] = nullptr; } for (ncclComm_t q : cc) rccl().CommDestroy(q); return fail(c0, RDIS_HIP_ENOMEM, "comm_create_all: host allocation"); }
+        m->ctx = ctxs[i]; m->comm = cc[(size_t)i]; m->world = n; m->rank = i;
+        comms[i] = m;
+    }
+    return 0;
+}
+
+extern "C" void rdis_hip_comm_destroy(rdis_hip_comm* m) {
+    if (!m) return;
+    if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+    if (m->comm && rccl().ok) rccl().CommDestroy(m->comm);
+    if (m->scratch.p) (void)hipFree(m->scratch.p);
+    m->scratch.p = nullptr;
+    delete m;
+}
+
+extern "C" int rdis_hip_allreduce_objective(rdis_hip_plan* L, rdis_hip_comm* m, double* sum_out) {
+    if (!L) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = L->prob->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (m) {
+        if (m->ctx != c) return fail(c, RDIS_HIP_EINVAL, "allreduce_objective: the communicator belongs to another context");
+        // in place, on the stream the solve ran on: ordered behind objective_sum_kernel, ahead of whatever reads the sum
+        const ncclResult_t r = rccl().AllReduce(L->objective.p, L->objective.p, 1, ncclDouble, ncclSum, m->comm, c->stream);
+        if (r != ncclSuccess) return rccl_fail(c, r, "allreduce_objective");
+    }
+    if (sum_out) {
+        HIPCHK(c, hipMemcpyAsync(sum_out, L->objective.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int rdis_hip_allreduce_objective_all(int32_t n, rdis_hip_plan* const* plans, rdis_hip_comm* const* comms, double* sum_out) {
+    if (n < 1 || !plans) return RDIS_HIP_EINVAL;
+    for (int i = 0; i < n; ++i) if (!plans[i]) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c0 = plans[0]->prob->ctx;
+    if (comms) {
+        if (!rccl().ok) return fail(c0, RDIS_HIP_EDEVICE, "allreduce_objective_all: librccl.so could not be loaded");
+        for (int i = 0; i < n; ++i) if (!comms[i] || comms[i]->ctx != plans[i]->prob->ctx) return fail(c0, RDIS_HIP_EINVAL, "allreduce_objective_all: communicator i must belong to plan i's context");
+        // one thread drives all the ranks: the calls are grouped, or the first would wait for the others
+        ncclResult_t r = rccl().GroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i) {
+            rdis_hip_ctx* c = plans[i]->prob->ctx;
+            HIPCHK(c, hipSetDevice(c->device));
+            r = rccl().AllReduce(plans[i]->objective.p, plans[i]->objective.p, 1, ncclDouble, ncclSum, comms[i]->comm, c->stream);
+        }
+        const ncclResult_t e = rccl().GroupEnd();
+        if (r != ncclSuccess || e != ncclSuccess) return rccl_fail(c0, r != ncclSuccess ? r : e, "allreduce_objective_all");
+        if (sum_out) {
+            HIPCHK(c0, hipSetDevice(c0->device));
+            HIPCHK(c0, hipMemcpyAsync(sum_out, plans[0]->objective.p, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+            HIPCHK(c0, hipStreamSynchronize(c0->stream));
+        }
+        return 0;
+    }
+    // no communicators (the same device listed twice, or no RCCL): the partial sums meet on the host, in plan order
+    if (sum_out) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) {
+            rdis_hip_ctx* c = plans[i]->prob->ctx;
+            double v = 0.0;
+            HIPCHK(c, hipSetDevice(c->device));
+            HIPCHK(c, hipMemcpyAsync(&v, plans[i]->objective.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            acc += v;
+        }
+        *sum_out = acc;
+    }
+    return 0;
+}
+
+extern "C" int rdis_hip_comm_allreduce_f64(rdis_hip_comm* m, double* inout, int32_t n, int32_t op) {
+    if (!m || !inout || n < 1 || n > 4096 || (op != 0 && op != 1)) return RDIS_HIP_EINVAL;
+    rdis_hip_ctx* c = m->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (m->scratch.bytes < (size_t)n * sizeof(double)) { if (int rc = dalloc(c, m->scratch, 4096 * sizeof(double))) return rc; }
+    HIPCHK(c, hipMemcpyAsync(m->scratch.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t r = rccl().AllReduce(m->scratch.p, m->scratch.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, m->comm, c->stream);
+    if (r != ncclSuccess) return rccl_fail(c, r, "comm_allreduce_f64");
+    HIPCHK(c, hipMemcpyAsync(inout, m->scratch.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_t* value) {
     if (!L || !name || !value) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;

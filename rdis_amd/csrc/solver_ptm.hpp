@@ -163,7 +163,7 @@ struct PtmEnv {
     template <int KK>
     __device__ void sumk(double& a, double& b, double& mx) {
         if constexpr (GROUP) {
-            if (GX.wg_entry) {   // (a wide group: the workgroup's sums first, one entry a workgroup)
+            if constexpr (GridSyncT<ST>::wg_entry) {   // (a wide group: the workgroup's sums first, one entry a workgroup)
                 a = wave_sum(a); b = wave_sum(b); mx = wave_max(mx);
                 if ((tid & 63) == 0) { red[parity][0][tid >> 6] = a; red[parity][1][tid >> 6] = b; red[parity][2][tid >> 6] = mx; }
                 __syncthreads();
@@ -944,7 +944,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, 
                               segs, seg_rows, {sg[0], sg[1], sg[2], sg[3], sg[4], sg[5], sg[6], sg[7], sg[8]},
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
-                              r, K, GridSyncT<ST>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}, !std::is_same<ST, SmallCoopState>::value},
+                              r, K, GridSyncT<ST>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
                               xch, PTM_CS * ncb_cap, 0
 #ifdef RDIS_COOP_TIMING
                               , {}
@@ -993,7 +993,7 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     __shared__ double bcast[8];
-    using ST = std::conditional_t<WIDE, CoopState, SmallCoopState>;
+    using ST = std::conditional_t<WIDE, WideCoopState, SmallCoopState>;
     const int b = blockIdx.x, K = A.K;
     const int grp = WIDE ? b / K : (b / (8 * K)) * 8 + (b & 7), r = WIDE ? b % K : (b >> 3) % K;
     if (grp >= A.ngroups) return;

@@ -112,6 +112,8 @@ OptimizableFunction::~OptimizableFunction() {
     // optimisers that outlive the function must not be left with plans of a freed device problem
     for (HipCGDSubspaceOptimizer* o : plan_holders_) o->functionGone();
     plan_holders_.clear();
+    for (rdis_hip_comm* m : comms_) rdis_hip_comm_destroy(m);
+    comms_.clear();
     if (prob_) rdis_hip_free_problem(prob_);
     if (ctx_) rdis_hip_destroy(ctx_);
     for (Replica& r : replicas_) {
@@ -250,6 +252,22 @@ rdis_hip_ctx* OptimizableFunction::deviceContext(size_t d) const {
     if (d == 0) return deviceContext();
     (void)deviceProblem(d);
     return replicas_.at(d - 1).ctx;
+}
+rdis_hip_comm* const* OptimizableFunction::deviceComms() const {
+    if (!comms_tried_) {
+        comms_tried_ = true;
+        const size_t n = numDevices();
+        bool distinct = n > 1;
+        for (size_t a = 0; a < n && distinct; ++a)
+            for (size_t b = 0; b < a; ++b) if (deviceOrdinal(a) == deviceOrdinal(b)) distinct = false;
+        if (distinct) {
+            std::vector<rdis_hip_ctx*> ctxs(n);
+            for (size_t d = 0; d < n; ++d) ctxs[d] = deviceContext(d);
+            comms_.assign(n, nullptr);
+            if (rdis_hip_comm_create_all((int32_t)n, ctxs.data(), comms_.data()) != 0) comms_.clear();   // (no RCCL: the host sums)
+        }
+    }
+    return comms_.empty() ? nullptr : comms_.data();
 }
 
 void OptimizableFunction::pushAssignments() const {
@@ -685,6 +703,24 @@ void HipCGDSubspaceOptimizer::solveShards(std::vector<Shard>& shards) {
         S.launched = true;   // (also when the solve failed half way: some of its launches may be queued)
         check(ctx, rc, "rdis_hip_plan_solve");
     }
+    // the batch's objective: one fp64 all-reduce between the devices' partial sums (src/RDISOptimizer.cpp:1491-1494 is where the
+    // reference couples siblings), enqueued behind the solves -- over RCCL when every listed device takes part with a resident
+    // plan and the devices are distinct GPUs, on the host otherwise
+    last_batch_objective_ = 0; last_batch_rccl_ = false; last_batch_valid_ = false;
+    {
+        bool all_plans = !shards.empty();
+        for (Shard& S : shards) all_plans = all_plans && S.cp != nullptr && S.launched;
+        if (all_plans) {
+            std::vector<rdis_hip_plan*> plans;
+            std::vector<rdis_hip_comm*> cm;
+            rdis_hip_comm* const* comms = shards.size() == f.numDevices() && shards.size() > 1 ? f.deviceComms() : nullptr;
+            for (Shard& S : shards) { plans.push_back(S.cp->plan); if (comms) cm.push_back(comms[S.dev]); }
+            double sum = 0.0;
+            const int rc = rdis_hip_allreduce_objective_all((int32_t)plans.size(), plans.data(), comms ? cm.data() : nullptr, &sum);
+            check(f.deviceContext(shards[0].dev), rc, "rdis_hip_allreduce_objective_all");
+            last_batch_objective_ = sum; last_batch_rccl_ = comms != nullptr; last_batch_valid_ = true;
+        }
+    }
     for (Shard& S : shards) {
         const size_t nc = S.comps.size();
         S.fret.resize(nc); S.delta.resize(nc); S.iters.resize(nc); S.status.resize(nc); S.nfe.resize(nc); S.nge.resize(nc);
@@ -795,6 +831,7 @@ Numeric HipCGDSubspaceOptimizer::optimizeBatch(std::vector<Component>& comps, co
         }
         total += part;
     }
+    if (!last_batch_valid_) last_batch_objective_ = total;   // (a shard went through the transient path: no resident objective to reduce)
     return total;
 }
 

@@ -33,6 +33,7 @@
 
 struct rdis_hip_ctx;
 struct rdis_hip_problem;
+struct rdis_hip_comm;
 
 namespace rdis {
 
@@ -206,6 +207,10 @@ public:
     int deviceOrdinal(size_t d) const { return d == 0 ? device_ : replicas_.at(d - 1).device; }   // the GPU behind entry d
     rdis_hip_problem* deviceProblem(size_t d) const;   // d = 0: the primary
     rdis_hip_ctx* deviceContext(size_t d) const;
+    // One RCCL communicator per listed device (rdis_hip_comm_create_all), made at first use: what optimizeBatch's objective
+    // all-reduce runs on.  nullptr when the list names a GPU twice or holds one device (RCCL wants one rank per GPU) or RCCL
+    // is not there: the partial sums then meet on the host (rdis_hip_allreduce_objective_all without communicators).
+    rdis_hip_comm* const* deviceComms() const;
 
     // packed (structure-of-arrays) view of the function; what rdis_hip_upload_* takes
     struct Packed {
@@ -245,6 +250,8 @@ private:
     };
     void uploadTo(int device, rdis_hip_ctx*& ctx, rdis_hip_problem*& prob) const;
     mutable std::vector<Replica> replicas_;   // devices 1 .. (setDevices)
+    mutable std::vector<rdis_hip_comm*> comms_;   // one per device once made (deviceComms)
+    mutable bool comms_tried_ = false;
     void fillIds(const FactorPtrVec& f, std::vector<int64_t>& ids) const;
     mutable std::unique_ptr<Packed> packed_;
     mutable rdis_hip_ctx* ctx_;
@@ -334,6 +341,11 @@ public:
         long long nfeval, ngeval;
     };
     Numeric optimizeBatch(std::vector<Component>& comps, const bool printdbg);
+    // the batch's objective as the devices' all-reduce left it (rdis_hip_allreduce_objective_all: RCCL over xGMI between the
+    // listed GPUs, the host where there is no communicator) -- what a caller that keeps its state on the devices reads; the
+    // value optimizeBatch RETURNS is the host sum of the components' values in device order, the same bits whatever the sharing
+    Numeric lastBatchObjective() const { return last_batch_objective_; }
+    bool lastBatchObjectiveOverRccl() const { return last_batch_rccl_; }
 
     // The sibling components themselves: connected components of the factor graph over the
     // variables that are currently unassigned -- what Component::createChildren
@@ -385,6 +397,8 @@ private:
     size_t cache_byte_cap_, cache_bytes_, cache_fallbacks_;
     bool function_alive_;
     std::vector<unsigned> free_stamp_;   // optimizeBatch: variable id -> stamp of the component it is free in
+    Numeric last_batch_objective_ = 0;
+    bool last_batch_rccl_ = false, last_batch_valid_ = false;
     unsigned stamp_;
 };
 

@@ -130,7 +130,7 @@ def test_optba_entry_of_the_host_library():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "rdis_amd", "host")], stdout=subprocess.DEVNULL)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rdis_optba.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(rdis_optba_[a-z_0-9]+)\s*\(", text)))
-    assert names == ["rdis_optba_run"]
+    assert names == ["rdis_optba_run", "rdis_optba_run_hist"]
     lib = C.CDLL(os.path.join(ROOT, "rdis_amd", "lib", "librdis_host.so"))
     for n in names:
         assert getattr(lib, n) is not None

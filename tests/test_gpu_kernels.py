@@ -220,7 +220,8 @@ def test_abi_error_codes(gctx):
 def test_fused_gradient_on_any_list_and_on_the_device(gctx):
     """rdis_hip_eval_grad's one-pass form (rdis_amd/csrc/grad_fused.hpp) builds per-list tables: lists in another
     order than the loader's point-major one, with repeated factors, cut at odd lengths, a single factor; several
-    lists in turn (the problem keeps the tables of the last four), and the device-resident variant."""
+    lists in turn (the problem keeps the tables of up to 64 lists within a byte budget; a list of at most one chunk needs
+    none: rdis_hip.hip eval_grad_short), and the device-resident variant."""
     pp = CASES["ladybug_full"]
     o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
     rng = np.random.default_rng(3)
@@ -251,3 +252,57 @@ def test_fused_gradient_on_any_list_and_on_the_device(gctx):
     f, gg = g.eval_grad()
     go = o.gradient()
     assert np.max(np.abs(gg - go)) <= 1e-12 * np.max(np.abs(go)) and abs(f - o.eval()) <= 1e-12 * f
+
+
+def test_fused_gradient_with_more_cameras_than_a_chunk_holds(gctx):
+    """grad_fused_kernel keeps a chunk's first 56 distinct cameras in its fast rows and sends the rest through the overflow path
+    (cur.extra); ladybug has 49 cameras, so only the point side of that path was exercised.  A synthetic problem with 96
+    cameras, its factors listed in a camera-SCATTERED order (every chunk of 512 entries meets nearly all 96), and a list that
+    cycles through many short and long lists in turn (more than the four tables round 5 kept): value and gradient against
+    the oracle, the same bits twice, zeros where no listed factor reads."""
+    pp = P.make_synthetic_ba(1, 96, 6000, obs_per_pt=4)
+    o, g = O.OracleProblem(pp), capi.Problem(gctx, pp)
+    rng = np.random.default_rng(17)
+    scattered = rng.permutation(pp.nfac).astype(np.int64)
+    assert len(np.unique(pp.cam_vid0[scattered[:512]])) > 56
+    lists = [scattered, scattered[:5000], scattered[:513], scattered[:512], scattered[:40], scattered[7:8]]
+    lists += [rng.choice(pp.nfac, int(n), replace=False).astype(np.int64) for n in rng.integers(600, 3000, size=8)]   # > 4 lists in turn
+    for rep in range(2):
+        for fl in lists:
+            f, gg = g.eval_grad(fl)
+            go = o.gradient(fl)
+            assert f == g.eval(fl)
+            assert abs(f - o.eval(fl)) <= 1e-12 * np.sum(np.abs(o.eval_each(fl)))
+            assert np.max(np.abs(gg - go)) <= 1e-12 * np.max(np.abs(go))
+            assert np.all(gg[go == 0.0] == 0.0)
+            f2, g2 = g.eval_grad(fl)
+            assert f2 == f and np.array_equal(g2, gg)
+    # a short list's table-free path gives the bits of the fused pass: the same 512 entries as the head of a longer list whose
+    # other entries read other blocks
+    far = np.setdiff1d(np.arange(pp.nfac), scattered[:512])
+    far = far[~np.isin(pp.pt_vid0[far], pp.pt_vid0[scattered[:512]])][:100]
+    _, g_short = g.eval_grad(scattered[:512])
+    _, g_long = g.eval_grad(np.concatenate([scattered[:512], far]).astype(np.int64))
+    pts = np.unique(pp.pt_vid0[scattered[:512]])
+    idx = (pts[:, None] + np.arange(3)[None, :]).ravel()
+    assert np.array_equal(g_short[idx], g_long[idx])
+
+
+def test_a_plan_made_before_a_factor_became_exponential_is_refused(gctx):
+    """rdis_hip_nlp_set_exponential after rdis_hip_plan_create: the reference's gradient asserts the flag off
+    (NonlinearProductFactor.cpp:110), so the stale plan's solve is refused like plan_create and eval_grad refuse (advisor,
+    round 5: its value-only trials would have used coeff * exp(-product), its slope trials the plain product)"""
+    pp = P.make_high_dim_sinusoid()
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    plan.set_start(pp.x0)
+    plan.solve(2, 3e-8)
+    plan.fetch()
+    use = np.zeros(pp.nfac, dtype=np.uint8)
+    use[3] = 1
+    g.set_exponential(use)
+    with pytest.raises(capi.RdisHipError):
+        plan.solve(2, 3e-8)
+    g.set_exponential(None)
+    plan.solve(2, 3e-8)
+    plan.fetch()

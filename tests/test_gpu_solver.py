@@ -1317,8 +1317,8 @@ def test_lds_resident_batch_solver_gives_the_bits_of_the_plain_one(gctx):
             ra, xa, _, _ = run({"lds_resident": 0, "ptm_stream": 0, "block_threads": threads, "camera_records": rot})
             # (lds_camera_sums 0: a camera variable's gradient entry summed as the plain solver sums it -- by default
             # the LDS solver sums camera partials across waves that share a camera, another grouping)
-            # (lds_matrix 0: trials in the vector form per factor, the plain solver's arithmetic -- by default the LDS solver's
-            # trials run in matrix form, another association of the same sums: replayed against the oracle below)
+            # (lds_matrix 0, which is also the default: trials in the vector form per factor, the plain solver's arithmetic; the
+            # option's matrix form -- another association of the same sums, measured slower -- is replayed against the oracle below)
             rb, xb, nb, _ = run({"lds_resident": 1, "block_threads": threads, "camera_records": rot, "lds_rot": 1 if rot else 0, "lds_camera_sums": 0, "lds_matrix": 0})
             assert nb == 1
             assert np.array_equal(ra.fret, rb.fret) and np.array_equal(ra.x, rb.x) and np.array_equal(xa, xb), (threads, rot)
