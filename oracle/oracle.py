@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         L.ro_ba_factor_grad_ref.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
         L.ro_set_ba_derivative.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_sum_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
         L.ro_sincos_angle.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -161,6 +162,32 @@ class OracleProblem:
         """the CPU side of the end-to-end == tests: the reference's algorithm, sums and stale factor cache with the three
         named last-place differences of the device's factor arithmetic switched on"""
         return cls(pp, emulate_stale_cache=emulate_stale_cache, derivative="adjoint_device", arithmetic="device")
+
+    @classmethod
+    def device_default(cls, pp, free_vid=None, fac=None):
+        """the CPU side of the == test of the DEFAULT cooperative path (full ladybug's headline solve): the three switches of the
+        device's factor arithmetic, no stale cache, and the cooperative solvers' sum trees (RO_SUM_TOPOLOGY_COOPERATIVE) for the
+        component (free_vid, fac) -- None: all variables, all factors"""
+        o = cls(pp, emulate_stale_cache=False, derivative="adjoint_device", arithmetic="device")
+        o.set_cooperative_topology(free_vid, fac)
+        return o
+
+    def set_cooperative_topology(self, free_vid=None, fac=None) -> None:
+        """wave-owned variables as rdis_hip.hip's prepare_partition picks them: fed by more than 48 listed partials (bundle
+        adjustment: one per listed factor that reads the variable), the longest runs first, ties in list order"""
+        pp = self.pp
+        fv = np.arange(pp.nvars, dtype=np.int64) if free_vid is None else np.asarray(free_vid, dtype=np.int64)
+        fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
+        cnt = np.zeros(pp.nvars, dtype=np.int64)
+        for k in range(9):
+            np.add.at(cnt, pp.cam_vid0[fc] + k, 1)
+        for k in range(3):
+            np.add.at(cnt, pp.pt_vid0[fc] + k, 1)
+        runs = cnt[fv]
+        longv = np.nonzero(runs > 48)[0]
+        longv = longv[np.argsort(-runs[longv], kind="stable")]
+        wave = np.ascontiguousarray(fv[longv], dtype=np.int64)
+        lib().ro_set_sum_topology(self.h, 1, wave.shape[0], wave.ctypes.data_as(C.c_void_p))
 
     def set_arithmetic(self, arithmetic) -> None:
         flags = {"reference": 0, "device": 3, "reciprocal": 1, "sincos_angle": 2}.get(arithmetic, arithmetic)

@@ -45,6 +45,7 @@ typedef struct {
 static int g_experiment = 0;
 void ro_set_experiment(int flags) { g_experiment = flags; }
 static double (*g_slope_by_factor)(void *ctx, const double *xi) = 0;
+static double (*g_slope_topology)(void *ctx, const double *xi) = 0;   /* set for the duration of a solve with RO_SUM_TOPOLOGY_COOPERATIVE */
 
 /* RO_ARITH_SINCOS_ANGLE: sine and cosine of the rotation angle by the DEVICE's routine (rdis_amd/csrc/factors.hpp
  * sincos_angle) instead of the C library's: one Cody-Waite reduction by pi/2 in three pieces (the first product exact in a
@@ -397,6 +398,9 @@ struct ro_problem {
     int emulate;
     int ba_deriv;     /* RO_BA_DERIV_REFCHAIN (default), RO_BA_DERIV_ADJOINT or RO_BA_DERIV_ADJOINT_DEVICE */
     int arith;        /* RO_ARITH_* flags of the factor arithmetic (default 0: the reference's) */
+    int topo;         /* RO_SUM_TOPOLOGY_*: 0 = every sum in the reference's order; 1 = the cooperative device solver's trees */
+    int64_t nwave_owned, *wave_vid;   /* ... its wave-owned variables (ids), in wave order */
+    int64_t *wave_of; /* [nvars] wave that owns the variable, or -1 */
     int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
     double *fcache;
     uint8_t *fdirty;
@@ -487,6 +491,7 @@ void ro_destroy(ro_problem *p)
     free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
     free(p->sine); free(p->useexp); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
+    free(p->wave_vid); free(p->wave_of);
     free(p);
 }
 
@@ -523,6 +528,76 @@ static double ba_grad(const ro_problem *p, const double x[12], double ox, double
 void ro_set_sum_order(ro_problem *p, int which)
 {
     p->sum_order = which;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RO_SUM_TOPOLOGY_COOPERATIVE: the sums of the DEVICE's cooperative solvers (rdis_amd/csrc/solver_coop.hpp, and
+ * solver_pipe.hpp, which gives the same bits), restated entry for entry -- the fourth and last named difference between the
+ * benchmarked default path and the reference (the other three: RO_ARITH_*, RO_BA_DERIV_ADJOINT_DEVICE).  The device adds as
+ * trees, in a fixed order:
+ *   wave     64 lanes as a balanced binary tree in lane order (the DPP butterfly of solver_wg.hpp's wave_sum: every step
+ *            adds a value and its mirror image, and a + b == b + a, so each lane ends with the natural tree's bits);
+ *   grid     wave w of the group publishes its sum as entry w (lane j of the group is factor j, so entry w covers the listed
+ *            factors 64 w .. 64 w + 63); the sweeping wave's lane l adds entries l, l + 64, l + 128, ... one after the
+ *            other from 0.0, then a wave sum over the 64 lanes (grid_sync.hpp: to_wave0_n);
+ *   slope    a factor's term is sum_k partial_k * direction_k over its twelve slots in slot order (from 0.0, every product
+ *            rounded), the terms then added like the values;
+ *   gg, dgg  lane i carries the terms of free variable i unless a wave owns it; wave w's first lane adds the terms of the
+ *            variable it owns; the lanes' terms then added like the values (solver_coop.hpp: cg_reduce);
+ *   gradient a variable fed by more than 48 partials is owned by a wave (the longest runs first, rdis_hip.hip:
+ *            prepare_partition): lane l adds the partials l, l + 64, ... of its run in order from 0.0, then a wave sum; every
+ *            other variable adds its partials in factor-list order like the reference.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static double tree64(const double *v)
+{
+    double a[64];
+    memcpy(a, v, sizeof a);
+    for (int w = 1; w < 64; w *= 2)
+        for (int i = 0; i < 64; i += 2 * w) a[i] = a[i] + a[i + w];
+    return a[0];
+}
+
+/* values[0 .. count) as the group's lanes in order: waves of 64, their sums as entries, the sweep */
+static double coop_tree_sum(const double *values, int64_t count)
+{
+    const int64_t nent = (count + 63) / 64;
+    double lane[64];
+    for (int l = 0; l < 64; ++l) {
+        double acc = 0.0;
+        for (int64_t e = l; e < nent; e += 64) {
+            double v[64];
+            for (int k = 0; k < 64; ++k) v[k] = (64 * e + k < count) ? values[64 * e + k] : 0.0;
+            acc = acc + tree64(v);
+        }
+        lane[l] = acc;
+    }
+    return tree64(lane);
+}
+
+/* a wave-owned variable's run of partials: lane l takes l, l + 64, ... in order from 0.0; then the wave sum */
+static double strided_tree_sum(const double *values, int64_t count)
+{
+    double lane[64];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int64_t k = l; k < count; k += 64) s = s + values[k];
+        lane[l] = s;
+    }
+    return tree64(lane);
+}
+
+void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid)
+{
+    free(p->wave_vid); free(p->wave_of);
+    p->wave_vid = NULL; p->wave_of = NULL; p->nwave_owned = 0;
+    p->topo = kind;
+    if (kind == RO_SUM_TOPOLOGY_COOPERATIVE) {
+        p->nwave_owned = nwave_owned;
+        p->wave_vid = dup_mem(wave_vid, sizeof(int64_t) * (size_t)nwave_owned);
+        p->wave_of = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+        for (int64_t v = 0; v < p->nvars; ++v) p->wave_of[v] = -1;
+        for (int64_t w = 0; w < nwave_owned; ++w) p->wave_of[wave_vid[w]] = w;
+    }
 }
 
 void ro_set_emulate_stale_cache(ro_problem *p, int on)
@@ -720,6 +795,13 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
      * objective sum -- 1e-12 relative in list order over 3e4 terms, 1e-15 as a tree, which is what a device computes --
      * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
     if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
+    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE) {
+        double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
+        for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
+        const double r = coop_tree_sum(vals, nf);
+        free(vals);
+        return r;
+    }
     double feval = 0.0;
     for (int64_t i = 0; i < nf; ++i) feval = feval + factor_value(p, fac ? fac[i] : i);
     return feval;
@@ -781,12 +863,32 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
     if (!merge) {
         uint8_t *seen = calloc((size_t)p->nvars + 1, 1);
         memset(g, 0, sizeof(double) * (size_t)p->nvars);
+        /* RO_SUM_TOPOLOGY_COOPERATIVE: the runs of the wave-owned variables are kept and added the device's way afterwards */
+        double **run = NULL; int64_t *rlen = NULL, *rcap = NULL;
+        if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE && p->nwave_owned > 0) {
+            run = calloc((size_t)p->nwave_owned, sizeof(double *));
+            rlen = calloc((size_t)p->nwave_owned, sizeof(int64_t));
+            rcap = calloc((size_t)p->nwave_owned, sizeof(int64_t));
+        }
         for (int64_t i = 0; i < nf; ++i) {
             const int n = factor_partials(p, fac ? fac[i] : i, vb, xb);
             for (int k = 0; k < n; ++k) {
+                const int64_t w = run ? p->wave_of[vb[k]] : -1;
+                if (w >= 0) {
+                    if (rlen[w] == rcap[w]) { rcap[w] = rcap[w] ? 2 * rcap[w] : 1024; run[w] = realloc(run[w], sizeof(double) * (size_t)rcap[w]); }
+                    run[w][rlen[w]++] = xb[k];
+                    continue;
+                }
                 if (!seen[vb[k]]) { g[vb[k]] = xb[k]; seen[vb[k]] = 1; }
                 else g[vb[k]] = g[vb[k]] + xb[k];
             }
+        }
+        if (run) {
+            for (int64_t w = 0; w < p->nwave_owned; ++w) {
+                if (rlen[w] > 0) g[p->wave_vid[w]] = strided_tree_sum(run[w], rlen[w]);
+                free(run[w]);
+            }
+            free(run); free(rlen); free(rcap);
         }
         free(seen);
     } else {
@@ -846,6 +948,8 @@ typedef struct {
     void (*on_iter)(void *ctx, double *test, double *gg, double *dgg);
     /* start of line minimisation `its`: p, xi (= h) may be inspected / replaced */
     void (*on_vectors)(void *ctx, int its, int n, double *p, double *xi, double *h);
+    /* gg and dgg of the Polak-Ribiere step formed another way (the device's trees) */
+    void (*on_cg_sums)(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg);
 } ro_hooks;
 
 typedef struct {
@@ -874,6 +978,7 @@ static double line_df(line_t *L)
     L->df(L->ctx, L->xt, L->dft);
     for (int j = 0; j < L->n; ++j) s += L->dft[j] * L->xi[j];
     if ((g_experiment & 2) && g_slope_by_factor) s = g_slope_by_factor(L->ctx, L->xi);
+    if (g_slope_topology) s = g_slope_topology(L->ctx, L->xi);
     if (L->hk && L->hk->on_slope) {
         double sabs = 0.0;
         for (int j = 0; j < L->n; ++j) sabs += fabs(L->dft[j] * L->xi[j]);
@@ -1045,6 +1150,7 @@ static int frprmn_ex(int n, double *x, ro_func_cb f, ro_grad_cb df, void *ctx,
             gg += g[j] * g[j];
             dgg += (xi[j] + g[j]) * xi[j];
         }
+        if (hk && hk->on_cg_sums) hk->on_cg_sums(hk->ctx, n, g, xi, &gg, &dgg);
         if (hk && hk->on_iter) hk->on_iter(hk->ctx, &test, &gg, &dgg);
         if (test < GTOL) { reason = RO_EXIT_GTOL; goto done; }
         if (gg == 0.0) { reason = RO_EXIT_GGZERO; goto done; }
@@ -1136,6 +1242,56 @@ static double sub_slope_by_factor(void *ctx, const double *xi)
     return s;
 }
 
+/* RO_SUM_TOPOLOGY_COOPERATIVE: a trial's slope the device's way -- per factor sum_k partial_k direction_k over its twelve slots in
+ * slot order, the factors' terms added like the values (coop_tree_sum) */
+static double sub_slope_topology(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
+    double *terms = malloc(sizeof(double) * (size_t)(S->nf + 1));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    for (int64_t i = 0; i < S->nf; ++i) {
+        const int64_t f = S->fac ? S->fac[i] : i;
+        double x[12], gq[12], acc = 0.0;
+        gather_ba(p, f, x);
+        ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq);
+        /* (the device's loop stands outside the factor arithmetic's no-contraction region: its multiply-adds are fused) */
+        for (int k = 0; k < 12; ++k) acc = fma(gq[k], dir[fac_var(p, f, k)], acc);
+        terms[i] = acc;
+    }
+    const double s = coop_tree_sum(terms, S->nf);
+    free(terms); free(dir);
+    return s;
+}
+
+/* ... and gg, dgg: lane i carries variable i's terms unless a wave owns it, wave w's first lane those of its variable */
+static void sub_cg_sums_topology(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    int64_t lanes = n;
+    if (64 * p->nwave_owned > lanes) lanes = 64 * p->nwave_owned;
+    double *a = calloc((size_t)lanes + 64, sizeof(double)), *b = calloc((size_t)lanes + 64, sizeof(double));
+    for (int64_t i = 0; i < n; ++i) {
+        if (p->wave_of[S->free_vid[i]] >= 0) continue;
+        a[i] = g[i] * g[i];
+        b[i] = (xi[i] + g[i]) * xi[i];
+    }
+    int64_t *li = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+    for (int64_t v = 0; v < p->nvars; ++v) li[v] = -1;
+    for (int64_t i = 0; i < n; ++i) li[S->free_vid[i]] = i;
+    for (int64_t w = 0; w < p->nwave_owned; ++w) {
+        const int64_t i = li[p->wave_vid[w]];
+        if (i < 0) continue;
+        a[64 * w] = a[64 * w] + g[i] * g[i];
+        b[64 * w] = b[64 * w] + (xi[i] + g[i]) * xi[i];
+    }
+    *gg = coop_tree_sum(a, lanes);
+    *dgg = coop_tree_sum(b, lanes);
+    free(a); free(b); free(li);
+}
+
 /* SubfunctionFD::df (.cpp:135-157) */
 static void sub_df(void *ctx, const double *x, double *deriv)
 {
@@ -1165,7 +1321,17 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     memcpy(xw, xval, sizeof(double) * (size_t)nfree);
 
     double fret; int iter;
-    int reason = ro_frprmn((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter);
+    int reason;
+    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE && p->kind == RO_KIND_BA) {
+        ro_hooks hk;
+        memset(&hk, 0, sizeof hk);
+        hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_topology;
+        g_slope_topology = sub_slope_topology;
+        reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+        g_slope_topology = 0;
+    } else {
+        reason = ro_frprmn((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter);
+    }
     if (S.saw_nan) reason = RO_EXIT_NAN;
 
     sub_assign(&S, xw); /* assign gdmin.p with sanitisation (.cpp:61) */
@@ -1377,7 +1543,7 @@ void ro_cgd_replay(ro_problem *p, int64_t nfree, const int64_t *free_vid, int64_
     memcpy(xw, xstart, sizeof(double) * (size_t)nfree);
     replay_t R = { trace, nrec, 0, &S, rep, vdump, dump_iters };
     ro_hooks hk = { &R, replay_on_f, replay_on_slope, replay_on_start, replay_on_linmin, replay_on_iter,
-                    replay_on_vectors };
+                    replay_on_vectors, NULL };
 
     rep->finit = sub_f(&S, xw);
     rep->reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &rep->fret, &rep->iters, &hk);
@@ -1417,7 +1583,7 @@ int64_t ro_cgd_record(ro_problem *p, int64_t nfree, const int64_t *free_vid, int
     double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));
     memcpy(xw, xstart, sizeof(double) * (size_t)nfree);
     recorder_t T = { trace, cap, 0 };
-    ro_hooks hk = { &T, rec_on_f, rec_on_slope, rec_on_start, rec_on_linmin, rec_on_iter, NULL };
+    ro_hooks hk = { &T, rec_on_f, rec_on_slope, rec_on_start, rec_on_linmin, rec_on_iter, NULL, NULL };
     double fret; int iter;
     (void)sub_f(&S, xw);
     (void)frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);

@@ -105,6 +105,17 @@ void ro_set_arithmetic(ro_problem *p, int flags);
 #define RO_SUM_LIST 0
 #define RO_SUM_PAIRWISE 1
 void ro_set_sum_order(ro_problem *p, int which);
+/* The fourth named difference (round 6): how the sums of a solve are ADDED.  RO_SUM_TOPOLOGY_REFERENCE (default): every sum in
+ * the reference's order.  RO_SUM_TOPOLOGY_COOPERATIVE: the trees of the device's cooperative solvers (solver_coop.hpp /
+ * solver_pipe.hpp: waves of 64 as balanced trees, the waves' sums as entries taken l, l + 64, ... by lane l, a wave sum over the
+ * lanes; the slope factor by factor; gg / dgg by owner lane; a wave-owned variable's partials strided over a wave), restated entry
+ * for entry in rdis_oracle.c.  wave_vid: the variables a wave owns, in wave order -- those fed by more than 48 listed partials,
+ * the longest runs first, ties in list order (rdis_hip.hip: prepare_partition).  With it, RO_ARITH_* and
+ * RO_BA_DERIV_ADJOINT_DEVICE on, and the stale cache off, ro_cgd_optimize returns what the device's DEFAULT cooperative path
+ * returns, bit for bit (tests/test_gpu_parity.py).  Bundle adjustment only. */
+#define RO_SUM_TOPOLOGY_REFERENCE 0
+#define RO_SUM_TOPOLOGY_COOPERATIVE 1
+void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid);
 /* process-wide experiment flags; never used to pin anything.  bit 0: reciprocals in place of the projection's divisions, the
  * device's form.  bit 1 (round 5): the slope of a line-search trial added factor by factor, sum_f (sum_k partial_fk xi_k) -- the
  * association the device's fused trials use -- in place of the reference's gradient times direction (Df1dim::df,

@@ -596,6 +596,12 @@ void HipCGDSubspaceOptimizer::setPlanCacheBytes(size_t bytes) {
     while (cache_bytes_ > cache_byte_cap_ && evictOne()) {}
 }
 
+void HipCGDSubspaceOptimizer::setPlanOption(const std::string& name, long long value) {
+    for (auto& kv : plan_options_) if (kv.first == name) { kv.second = value; while (evictOne()) {} return; }
+    plan_options_.emplace_back(name, value);
+    while (evictOne()) {}   // (plans made under the old options)
+}
+
 HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const std::vector<int64_t>& free_ptr, const std::vector<int64_t>& free_vid,
                                                                          const std::vector<int64_t>& fac_ptr, const std::vector<int64_t>& fac_id, size_t dev) {
     if (cache_cap_ == 0) return nullptr;
@@ -627,6 +633,10 @@ HipCGDSubspaceOptimizer::CachedPlan* HipCGDSubspaceOptimizer::cachedPlan(const s
     }
     if (rc == RDIS_HIP_ENOMEM) { delete e; ++cache_fallbacks_; return nullptr; }
     if (rc != 0) { delete e; check(f.deviceContext(dev), rc, "rdis_hip_plan_create"); }
+    for (const auto& kv : plan_options_) {
+        const int ro = rdis_hip_plan_set_option(e->plan, kv.first.c_str(), (int64_t)kv.second);
+        if (ro != 0) { rdis_hip_plan_destroy(e->plan); delete e; check(f.deviceContext(dev), ro, "rdis_hip_plan_set_option"); }
+    }
     (void)rdis_hip_plan_device_bytes(e->plan, &e->bytes);
     if ((size_t)e->bytes > cache_byte_cap_) {   // larger than the whole budget: not kept
         rdis_hip_plan_destroy(e->plan);

@@ -367,6 +367,10 @@ public:
     // creation retried; a call whose plan cannot be kept at all is served by the transient path
     // (rdis_hip_cgd_batch), counted in planCacheFallbacks().
     void setPlanCacheBytes(size_t bytes);
+    // a plan option of include/rdis_hip.h (rdis_hip_plan_set_option) for every plan this optimiser makes from now on -- e.g. the
+    // parity option: setPlanOption("factor_rounding", 1); setPlanOption("emulate_stale_cache", 1).  Plans already
+    // cached are dropped; calls too large to cache (the transient path) take the library's defaults.
+    void setPlanOption(const std::string& name, long long value);
     size_t planCacheHits() const { return cache_hits_; }
     size_t planCacheMisses() const { return cache_misses_; }
     size_t planCacheFallbacks() const { return cache_fallbacks_; }
@@ -397,6 +401,7 @@ private:
     size_t cache_byte_cap_, cache_bytes_, cache_fallbacks_;
     bool function_alive_;
     std::vector<unsigned> free_stamp_;   // optimizeBatch: variable id -> stamp of the component it is free in
+    std::vector<std::pair<std::string, long long> > plan_options_;
     Numeric last_batch_objective_ = 0;
     bool last_batch_rccl_ = false, last_batch_valid_ = false;
     unsigned stamp_;

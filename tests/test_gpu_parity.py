@@ -11,6 +11,9 @@ oracle has as a named run-time switch (oracle/rdis_oracle.h):
     RO_ARITH_RECIPROCAL          x * (1 / y) for x / y in the unit axis and the perspective divide
     RO_BA_DERIV_ADJOINT_DEVICE   the adjoint sweep for the reference's forward chain (BundleAdjustmentFactor.cpp:351-554)
 
+(A fourth switch, RO_SUM_TOPOLOGY_COOPERATIVE -- the device's sum trees restated entry for entry -- makes the oracle return what
+the DEFAULT cooperative path returns: the tests at the end of this file.)
+
 With the three on (OracleProblem.device_parity) the oracle is the reference's algorithm -- CGDSubspaceOptimizer.cpp:19-98,
 minimize_nrc.h:410-447, State.h:157-210, the stale factor cache of Variable.cpp:66-76 -- in the device's factor arithmetic,
 and the tests below assert fret, x, iterations and the f / df call counts with == after 25 iterations from x0 on BASELINE
@@ -157,3 +160,53 @@ def test_parity_option_on_a_batch_of_components(gctx):
         want = orc.cgd(free_vid=fv[fp[c]:fp[c + 1]], fac=ci[cp[c]:cp[c + 1]], x=pp.x0[fv[fp[c]:fp[c + 1]]], maxiters=25)
         assert r.fret[c] == want.fret and int(r.nfeval[c]) == want.nfeval and int(r.iters[c]) == want.iters, c
         assert r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), c
+
+
+# ---- the DEFAULT path: the benchmarked cooperative solvers == the oracle with a fourth switch, the device's sum trees ----------
+
+def _default_path(gctx, pp, maxiters, opts=None, x=None):
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in (opts or {}).items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0 if x is None else x)
+    plan.solve(maxiters, 3e-8)
+    return plan, plan.fetch()
+
+
+@pytest.mark.parametrize("layout", ["pipelined (the default)", "plain"])
+def test_default_cooperative_path_equals_the_oracle_with_the_sum_trees(gctx, layout):
+    """BASELINE config 4 as bench.py runs it -- no option set: the pipelined cooperative solver, the reference's rounding, sums as
+    trees over lanes, waves and workgroups -- against the oracle with FOUR named switches: the three of the factor arithmetic and
+    RO_SUM_TOPOLOGY_COOPERATIVE, the device's trees restated entry for entry (oracle/rdis_oracle.c: a wave of 64 as a balanced
+    tree, the waves' sums taken l, l + 64, ... by lane l, the slope factor by factor, gg / dgg by owner lane, a camera variable's
+    900 partials strided over a wave).  25 iterations from x0, no re-synchronisation: fret, delta, x, iterations, status and the
+    f / df call counts ==.  So the number the driver's line carries (89607.17144518998 after 798 evaluations) is a CPU run's
+    number, bit for bit, and what separates it from the reference's 83227.604227756252 is those four switches and nothing else."""
+    pp = P.load_bal().single_component()
+    want = O.OracleProblem.device_default(pp).cgd(x=pp.x0, maxiters=25)
+    plan, r = _default_path(gctx, pp, 25, {"coop_pipeline": 0} if layout == "plain" else None)
+    assert plan.info("components_cooperative") == 1 and plan.info("pipelined") == (0 if layout == "plain" else 1)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta, (r.fret[0], want.fret)
+    assert int(r.iters[0]) == want.iters and int(r.status[0]) == want.status
+    assert int(r.nfeval[0]) == want.nfeval and int(r.ngeval[0]) == want.ngeval
+    assert r.x.tobytes() == want.x.tobytes()
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_end_values.json")) as fh:
+        w = json.load(fh)["ladybug_full_default_path"]
+    assert r.fret[0] == w["fret"] and int(r.nfeval[0]) == w["nfeval"]      # (the committed CPU fixture: what bench.py compares with)
+
+
+def test_default_cooperative_path_on_other_components_and_starts(gctx):
+    """the same on ladybug's 49 cameras with 500 and with 2000 points (groups of 16 and 46 workgroups, every camera variable
+    wave-owned) from x0 and from two starts moved by 1e-12, and with speculation off (which must not change a bit)"""
+    for npts, seeds in ((500, (None, 1, 2)), (2000, (None,))):
+        for seed in seeds:
+            pp = P.load_bal(ncams=49, npts=npts).single_component()
+            x = pp.x0 if seed is None else pp.x0 * (1 + 1e-12 * np.random.default_rng(seed).standard_normal(pp.nvars))
+            want = O.OracleProblem.device_default(pp).cgd(x=x, maxiters=25)
+            for opts in (None, {"coop_speculate": 0}):
+                plan, r = _default_path(gctx, pp, 25, opts, x=x)
+                assert plan.info("components_cooperative") == 1
+                assert r.fret[0] == want.fret and r.x.tobytes() == want.x.tobytes(), (npts, seed, opts, r.fret[0], want.fret)
+                assert (int(r.iters[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.nfeval, want.ngeval)
