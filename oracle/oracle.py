@@ -164,17 +164,20 @@ class OracleProblem:
         return cls(pp, emulate_stale_cache=emulate_stale_cache, derivative="adjoint_device", arithmetic="device")
 
     @classmethod
-    def device_default(cls, pp, free_vid=None, fac=None):
+    def device_default(cls, pp, free_vid=None, fac=None, lanes_per_workgroup: int = 128):
         """the CPU side of the == test of the DEFAULT cooperative path (full ladybug's headline solve): the three switches of the
         device's factor arithmetic, no stale cache, and the cooperative solvers' sum trees (RO_SUM_TOPOLOGY_COOPERATIVE) for the
         component (free_vid, fac) -- None: all variables, all factors"""
         o = cls(pp, emulate_stale_cache=False, derivative="adjoint_device", arithmetic="device")
-        o.set_cooperative_topology(free_vid, fac)
+        o.set_cooperative_topology(free_vid, fac, lanes_per_workgroup)
         return o
 
-    def set_cooperative_topology(self, free_vid=None, fac=None) -> None:
+    def set_cooperative_topology(self, free_vid=None, fac=None, lanes_per_workgroup: int = 128) -> None:
         """wave-owned variables as rdis_hip.hip's prepare_partition picks them: fed by more than 48 listed partials (bundle
-        adjustment: one per listed factor that reads the variable), the longest runs first, ties in list order"""
+        adjustment: one per listed factor that reads the variable), the longest runs first, ties in list order -- as many as the
+        component's cooperative group has waves: workgroups = max(ceil(max(factors, variables) / lanes), and for groups of fewer
+        than 16 workgroups min(ceil(long runs / waves per workgroup), 2 x that + 2)), lanes = 128 factor lanes per workgroup in
+        the pipelined layout (the default), 256 in the plain one"""
         pp = self.pp
         fv = np.arange(pp.nvars, dtype=np.int64) if free_vid is None else np.asarray(free_vid, dtype=np.int64)
         fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
@@ -186,7 +189,11 @@ class OracleProblem:
         runs = cnt[fv]
         longv = np.nonzero(runs > 48)[0]
         longv = longv[np.argsort(-runs[longv], kind="stable")]
-        wave = np.ascontiguousarray(fv[longv], dtype=np.int64)
+        wpw = lanes_per_workgroup // 64
+        need = -(-max(len(fc), len(fv)) // lanes_per_workgroup)
+        for_long = min(-(-len(longv) // wpw), 2 * need + 2) if need < 16 else 0
+        waves = max(1, need, for_long) * wpw
+        wave = np.ascontiguousarray(fv[longv[:waves]], dtype=np.int64)
         lib().ro_set_sum_topology(self.h, 1, wave.shape[0], wave.ctypes.data_as(C.c_void_p))
 
     def set_arithmetic(self, arithmetic) -> None:

@@ -184,7 +184,7 @@ def test_default_cooperative_path_equals_the_oracle_with_the_sum_trees(gctx, lay
     f / df call counts ==.  So the number the driver's line carries (89607.17144518998 after 798 evaluations) is a CPU run's
     number, bit for bit, and what separates it from the reference's 83227.604227756252 is those four switches and nothing else."""
     pp = P.load_bal().single_component()
-    want = O.OracleProblem.device_default(pp).cgd(x=pp.x0, maxiters=25)
+    want = O.OracleProblem.device_default(pp, lanes_per_workgroup=256 if layout == "plain" else 128).cgd(x=pp.x0, maxiters=25)
     plan, r = _default_path(gctx, pp, 25, {"coop_pipeline": 0} if layout == "plain" else None)
     assert plan.info("components_cooperative") == 1 and plan.info("pipelined") == (0 if layout == "plain" else 1)
     assert r.fret[0] == want.fret and r.delta[0] == want.delta, (r.fret[0], want.fret)
@@ -198,15 +198,18 @@ def test_default_cooperative_path_equals_the_oracle_with_the_sum_trees(gctx, lay
 
 
 def test_default_cooperative_path_on_other_components_and_starts(gctx):
-    """the same on ladybug's 49 cameras with 500 and with 2000 points (groups of 16 and 46 workgroups, every camera variable
-    wave-owned) from x0 and from two starts moved by 1e-12, and with speculation off (which must not change a bit)"""
+    """the same on ladybug's 49 cameras with 500 and with 2000 points from x0 and from two starts moved by 1e-12, and with
+    speculation off (which must not change a bit).  With 500 points the group has 64 waves for 441 camera variables of some 80
+    partials each: the 64 longest runs are strided over a wave, the others added in factor-list order by a lane -- the oracle
+    follows the same rule (OracleProblem.set_cooperative_topology); with 2000 points every camera variable has a wave."""
     for npts, seeds in ((500, (None, 1, 2)), (2000, (None,))):
         for seed in seeds:
             pp = P.load_bal(ncams=49, npts=npts).single_component()
             x = pp.x0 if seed is None else pp.x0 * (1 + 1e-12 * np.random.default_rng(seed).standard_normal(pp.nvars))
-            want = O.OracleProblem.device_default(pp).cgd(x=x, maxiters=25)
-            for opts in (None, {"coop_speculate": 0}):
+            for opts in (None, {"coop_speculate": 0}, {"coop_pipeline": 0}):
+                plain = bool(opts) and opts.get("coop_pipeline") == 0
+                want = O.OracleProblem.device_default(pp, lanes_per_workgroup=256 if plain else 128).cgd(x=x, maxiters=25)
                 plan, r = _default_path(gctx, pp, 25, opts, x=x)
-                assert plan.info("components_cooperative") == 1
+                assert plan.info("components_cooperative") == 1 and plan.info("pipelined") == (0 if plain else 1)
                 assert r.fret[0] == want.fret and r.x.tobytes() == want.x.tobytes(), (npts, seed, opts, r.fret[0], want.fret)
                 assert (int(r.iters[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.nfeval, want.ngeval)
