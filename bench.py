@@ -420,7 +420,8 @@ def configs_block(ctx, maxiters: int, cpu: bool):
                     "components of configs 3 and 4: all_components)" % maxiters, "rows": rows}
 
 
-LARGE_SHAPES = [("8e6 factors", 64, 2000000, 4), ("1.2e6 observations", 120, 300000, 4)]
+LARGE_SHAPES = [("8e6 factors", 64, 2000000, 4), ("1.2e6 observations", 120, 300000, 4),
+                ("356 cameras x 226730 points (more cameras than the LDS holds: local camera numbering)", 356, 226730, 6)]
 
 
 def large_component(ctx, maxiters: int, cpu: bool, steps: int = 2):
@@ -457,6 +458,7 @@ def large_component(ctx, maxiters: int, cpu: bool, steps: int = 2):
                "f_evals_per_solve": nfe / steps, "us_per_evaluation": kms * 1e3 / max(nfe, 1), "f_evals_per_s": nfe / dt,
                "final_objective": float(r.fret[0]), "first_solve_s": first,
                "workgroups": int(plan.info("point_major_group")), "wide_group": int(plan.info("point_major_wide")),
+               "cameras_in_a_workgroups_lds": int(plan.info("point_major_local_cameras")) or C_,
                "solver": "cgd_ptmg_kernel<512, ., true> (solver_ptm.hpp)" if plan.info("components_point_major") else
                          "cgd_stream_kernel (solver_stream.hpp)" if plan.info("components_grid_stream") else "other",
                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

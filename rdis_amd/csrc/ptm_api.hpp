@@ -48,12 +48,20 @@ struct PtmGroupArgs {
     double* xch;          // [groups][2 K + 2][10 ncb_cap] partial camera sums of a group's workgroups (two gradients' worth) and their totals
     int K, ngroups;       // workgroups per component, components of the launch
     int poll_delay;
+    // a wide group with local camera numbering (solver_ptm.hpp: LOCAL; one component a launch): per workgroup a table in `lc` at
+    // lc_off[rank] -- {cameras, first chunk, end chunk, 0, local -> component camera [cameras], speaks-for flags [cameras]} --, per
+    // component camera the (rank << 8 | local number) pairs that hold it, and the buffer of the cameras' summed gradient entries
+    const long long* lc_off;
+    const int* lc;
+    const int* cr_ptr;
+    const int* cr;
+    double* tot;
 };
 
 // launches (ptm_kernels.hip); rot = ROT_PER_FACTOR / ROT_RECORDS / ROT_CAMFIX, threads = 256 / 512 / 768
 hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t stream, const ProblemView& P, const PlanView& V,
                       int maxiters, double ftol, int ncb_cap);
-const void* ptmg_kernel_fn(int rot, int threads, bool wide = false);   // cgd_ptmg_kernel<threads, rot, wide> (a cooperative launch by the caller; wide: 512 lanes)
+const void* ptmg_kernel_fn(int rot, int threads, bool wide = false, bool local = false);   // cgd_ptmg_kernel<threads, rot, wide, local> (a cooperative launch by the caller; wide: 512 lanes)
 constexpr int PTM_WIDE_THREADS = 512;  // workgroup of a wide group (one per compute unit)
 constexpr int PTM_WIDE_MAX_GROUP = 512;  // ... and their number (COOP_MAX_WG)
 hipError_t ptm_gather_launch(int grid, hipStream_t stream, int n, const int* jg, const unsigned* fidx, const double2* fobs,

@@ -33,7 +33,8 @@ hipError_t ptm_launch(int rot, int threads, int grid, size_t dyn, hipStream_t st
 }
 
 template <int ROT>
-static const void* ptmg_kernel_ptr(int threads, bool wide) {
+static const void* ptmg_kernel_ptr(int threads, bool wide, bool local) {
+    if (wide && local) return (const void*)cgd_ptmg_kernel<PTM_WIDE_THREADS, ROT, true, true>;
     if (wide) return (const void*)cgd_ptmg_kernel<PTM_WIDE_THREADS, ROT, true>;
     switch (threads) {
         case 256: return (const void*)cgd_ptmg_kernel<256, ROT>;
@@ -41,10 +42,10 @@ static const void* ptmg_kernel_ptr(int threads, bool wide) {
         default: return (const void*)cgd_ptmg_kernel<768, ROT>;
     }
 }
-const void* ptmg_kernel_fn(int rot, int threads, bool wide) {
+const void* ptmg_kernel_fn(int rot, int threads, bool wide, bool local) {
     switch (rot) {
-        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads, wide);
-        default: return ptmg_kernel_ptr<ROT_RECORDS>(threads, wide);
+        case ROT_CAMFIX: return ptmg_kernel_ptr<ROT_CAMFIX>(threads, wide, local);
+        default: return ptmg_kernel_ptr<ROT_RECORDS>(threads, wide, local);
     }
 }
 

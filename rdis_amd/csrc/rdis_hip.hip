@@ -294,6 +294,14 @@ struct rdis_hip_plan {
     DevBuf st_ev, st_val;
     bool ptm_wide_wanted = false;     // prepare_partition: a large component joined the batch list for a wide point-major group
     bool ptm_wide_last = false;       // the last solve ran its point-major launch as wide groups
+    // a wide group with LOCAL camera numbering (solver_ptm.hpp: a component with more cameras than the LDS holds; one such component a plan)
+    int ptm_local_cameras = -1;       // option "ptm_local_cameras": -1 = where the cameras do not fit, 0 = never, 1 = for every wide component (tests)
+    bool ptm_local = false, ptm_local_off = false;   // the plan has such a component; it was tried and did not fit (then never again)
+    int ptm_local_K = 0, ptm_local_comp = -1;
+    ivec h_lc, h_cr_ptr, h_cr, h_wg_chunk0;          // PtmGroupArgs' tables; the workgroups' chunk ranges
+    std::vector<long long> h_lc_off;
+    std::vector<short> h_pm_lcam;                    // entry of the point-major order -> its camera's number in the owning workgroup
+    DevBuf lc_dev, lc_off_dev, cr_ptr_dev, cr_dev, ptm_tot;
     DevBuf seq_val, seq_ab;           // the parity option's buffers (PlanView::seq_val, seq_ab), allocated at the first solve that needs them
     int lds_ns_cap = 0, lds_ncb_cap = 0, lds_chunk_cap = 0, lds_rot_mode = ROT_PER_FACTOR;
     int64_t lds_max_factors = 0;
@@ -1519,6 +1527,10 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
         L->ptm_threads = (int)value;
+    } else if (n == "ptm_local_cameras") {
+        if (value < -1 || value > 1) return fail(c, RDIS_HIP_EINVAL, "ptm_local_cameras must be -1 (where a wide group's cameras do not fit the LDS), 0 (never) or 1 (every wide group)");
+        L->ptm_local_cameras = (int)value;
+        L->ptm_local_off = false;
     } else if (n == "emulate_stale_cache") {
         L->emulate_stale = value != 0;
     } else if (n == "factor_rounding") {
@@ -1681,7 +1693,8 @@ int prepare_partition(rdis_hip_plan* L) {
             if (b >= 0) { if (p->h_blk_stamp[(size_t)b] != stamp) { p->h_blk_stamp[(size_t)b] = stamp; ++ncb; } }
             else if (p->h_ptblock_of[(size_t)v] < 0) return false;
         }
-        return ncb <= PTM_MAX_CAMERAS && ptm_bytes_for(ncb, PTM_WIDE_THREADS) <= c->lds_limit;
+        // (more cameras than fit: a wide group whose workgroups keep their own cameras only -- decided with the tables below)
+        return ncb <= PTM_MAX_CAMERAS && (ptm_bytes_for(ncb, PTM_WIDE_THREADS) <= c->lds_limit || (L->ptm_local_cameras != 0 && !L->ptm_local_off));
     };
     // (one allocation: growing this by appending costs a transient call on ladybug 1.5 ms in page faults)
     L->h_coop_ints.reserve((size_t)(any_big ? 12 * L->nfac + 4 * (L->nfac + L->nfree) + 4096 * (int64_t)std::min<int64_t>(L->ncomp, 64) : 0));
@@ -1825,6 +1838,10 @@ int prepare_partition(rdis_hip_plan* L) {
         ivec ls_pidx((size_t)L->nfac, 0);   // (host only) a listed factor's point block within its component: all 31 bits of it
         std::vector<ivec> vid_of(nc), free_of(nc), gp_of(nc), pptr_of(nc);
         ivec cams, pts, deg;
+        bool local_failed = false;
+        L->ptm_local = false; L->ptm_local_K = 0; L->ptm_local_comp = -1;
+        L->h_lc.clear(); L->h_lc_off.clear(); L->h_cr_ptr.clear(); L->h_cr.clear(); L->h_wg_chunk0.clear(); L->h_pm_lcam.clear();
+        std::vector<ivec> local_cams;   // per workgroup of the local group: its cameras (component numbers), ascending
         for (size_t r = (size_t)L->rest_tiny; r < L->h_rest.size(); ++r) {
             const int cc = L->h_rest[r];
             const int f0 = L->h_free_ptr[(size_t)cc], f1 = L->h_free_ptr[(size_t)cc + 1];
@@ -1866,8 +1883,11 @@ int prepare_partition(rdis_hip_plan* L) {
             // solver_wg.hpp -- the comparison the bit-identity tests make; ptm_stream = 2 sends everything its tables fit)
             const bool lds_size_ok = !many_points && lds_bytes_for(ns, ncb, nchunk) <= c->lds_limit;
             const bool fits_lds = L->lds_resident != 0 && lds_size_ok && L->ptm_stream != 2;
+            const bool want_local = wide_comp[(size_t)cc] && !L->ptm_local_off && L->ptm_local_cameras != 0 && !local_failed &&
+                                    (L->ptm_local_cameras == 1 || ptm_bytes_for(ncb, PTM_WIDE_THREADS) > c->lds_limit);
             const bool fits_ptm = !fits_lds && (L->ptm_stream == 2 || (L->ptm_stream == 1 && !lds_size_ok)) &&
-                                  ptm_bytes_for(ncb, ptm_max_threads) <= c->lds_limit;
+                                  (want_local || ptm_bytes_for(ncb, ptm_max_threads) <= c->lds_limit);
+            if (want_local && L->ptm_local) { local_failed = true; gp.clear(); continue; }   // (one such component a plan)
             if (!fits_lds && !fits_ptm) { gp.clear(); continue; }
             if (fits_lds) std::sort(pts.begin(), pts.end());
             else {
@@ -1900,7 +1920,69 @@ int prepare_partition(rdis_hip_plan* L) {
                 // Whole wave-chunks of equal slot count are then dealt out over PTM_SPREAD runs of the sorted order: the chunks
                 // that the waves of a workgroup evaluate at the same time come from different runs and meet different cameras
                 // (the gradient's round sums, solver_ptm.hpp, are as long as a round's longest camera segment).
-                {
+                if (want_local) {
+                    // LOCAL: workgroup r owns a CONTIGUOUS slice of every run of chunks of equal slot count (the runs stand in
+                    // camera order: a slice meets few cameras; a slice of every run: equal work), its positions in the chunk order
+                    // are consecutive ([h_wg_chunk0[r], h_wg_chunk0[r + 1])), and inside them wave w (position - first mod 8) takes a
+                    // contiguous eighth of the workgroup's chunks: the waves of a workgroup meet different cameras at a time
+                    const int nfull = npb / 64, npc_all = (npb + 63) / 64;
+                    const int Kl = (int)std::min<int64_t>(std::min<int64_t>(c->num_cus, PTM_WIDE_MAX_GROUP), std::max<int64_t>(1, npc_all / 24));
+                    if (Kl <= PTM_MAX_GROUP) local_failed = true;
+                    else {
+                        std::vector<ivec> wl((size_t)Kl);
+                        for (int a0 = 0; a0 < nfull;) {
+                            const int T = deg[(size_t)ord[(size_t)(64 * a0)] + 1] - deg[(size_t)ord[(size_t)(64 * a0)]];
+                            int a1 = a0;
+                            while (a1 < nfull && deg[(size_t)ord[(size_t)(64 * a1)] + 1] - deg[(size_t)ord[(size_t)(64 * a1)]] == T) ++a1;
+                            const long long mm = a1 - a0;
+                            for (int rk = 0; rk < Kl; ++rk)
+                                for (long long a = a0 + rk * mm / Kl; a < a0 + (rk + 1) * mm / Kl; ++a) wl[(size_t)rk].push_back((int)a);
+                            a0 = a1;
+                        }
+                        ivec chunk_of((size_t)nfull);
+                        L->h_wg_chunk0.assign((size_t)Kl + 1, 0);
+                        int pos = 0;
+                        for (int rk = 0; rk < Kl; ++rk) {
+                            const ivec& li = wl[(size_t)rk];
+                            const int nr = (int)li.size(), nwv = PTM_WIDE_THREADS / 64;
+                            L->h_wg_chunk0[(size_t)rk] = pos;
+                            int taken = 0;
+                            for (int w = 0; w < nwv; ++w) {   // wave w's positions: first + w, first + w + 8, ... -- the next (nr - w + 7) / 8 chunks of the list
+                                const int cnt = nr > w ? (nr - w + nwv - 1) / nwv : 0;
+                                for (int j = 0; j < cnt; ++j) chunk_of[(size_t)(pos + w + nwv * j)] = li[(size_t)(taken + j)];
+                                taken += cnt;
+                            }
+                            pos += nr;
+                        }
+                        L->h_wg_chunk0[(size_t)Kl] = npc_all;   // (the last workgroup also takes the chunk of the npb % 64 blocks left over)
+                        ivec ord2(ord);
+                        for (int a = 0; a < nfull; ++a)
+                            for (int l = 0; l < 64; ++l) ord2[(size_t)(64 * a + l)] = ord[(size_t)(64 * chunk_of[(size_t)a] + l)];
+                        ord.swap(ord2);
+                        // every workgroup's cameras
+                        local_cams.assign((size_t)Kl, ivec());
+                        const size_t cam_cap = [&] { size_t k = 1; while (k < 255 && ptm_bytes_for((int)k + 1, PTM_WIDE_THREADS) <= c->lds_limit) ++k; return k; }();
+                        ivec mark((size_t)ncb, -1);
+                        size_t worst = 0;
+                        for (int rk = 0; rk < Kl && !local_failed; ++rk) {
+                            ivec& lc = local_cams[(size_t)rk];
+                            for (int k = 64 * L->h_wg_chunk0[(size_t)rk]; k < std::min(npb, 64 * L->h_wg_chunk0[(size_t)rk + 1]); ++k) {
+                                const int a = ord[(size_t)k];
+                                for (int t = deg[(size_t)a]; t < deg[(size_t)a + 1]; ++t)
+                                    if (mark[(size_t)pcam[(size_t)t]] != rk) { mark[(size_t)pcam[(size_t)t]] = rk; lc.push_back(pcam[(size_t)t]); }
+                            }
+                            std::sort(lc.begin(), lc.end());
+                            if (lc.empty()) lc.push_back(0);   // (a workgroup without chunks still has its LDS laid out for one camera)
+                            worst = std::max(worst, lc.size());
+                            if (lc.size() > cam_cap) local_failed = true;
+                        }
+                        if (std::getenv("RDIS_HIP_LOCAL_STATS"))
+                            std::fprintf(stderr, "local cameras: %d workgroups over %d chunks, %d cameras in the component, at most %zu in a workgroup (the LDS holds %zu)\n",
+                                         Kl, npc_all, ncb, worst, cam_cap);
+                        if (!local_failed) { L->ptm_local = true; L->ptm_local_K = Kl; L->ptm_local_comp = cc; }
+                    }
+                    if (local_failed) { gp.clear(); continue; }
+                } else {
                     const int nfull = npb / 64;
                     ivec chunk_of((size_t)nfull);
                     int pos = 0;
@@ -1968,7 +2050,11 @@ int prepare_partition(rdis_hip_plan* L) {
                 L->lds_max_factors = std::max<int64_t>(L->lds_max_factors, m);
             } else {
                 kind_of[(size_t)cc] = 2;
-                L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, ncb);
+                if (L->ptm_local && L->ptm_local_comp == cc) {   // (a workgroup's LDS holds its own cameras only)
+                    for (const ivec& lc : local_cams) L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, (int)lc.size());
+                } else {
+                    L->ptm_ncb_cap = std::max(L->ptm_ncb_cap, ncb);
+                }
                 // the point's factors, in listed order (a CSR over the point blocks in their slot order)
                 ivec& pp = pptr_of[(size_t)cc];
                 pp.assign((size_t)npb + 1, 0);
@@ -1983,6 +2069,13 @@ int prepare_partition(rdis_hip_plan* L) {
         auto first_lds = std::stable_partition(first_other, L->h_rest.end(), [&](int cc) { return kind_of[(size_t)cc] == 2; });
         L->rest_ptm = (int)(first_lds - first_other);
         L->rest_lds = (int)(L->h_rest.end() - first_lds);
+        // local camera numbering did not work out (a workgroup's cameras beyond the LDS, too few chunks, a second streaming
+        // component in the plan): once more without it -- the component then takes the grid solver
+        if (local_failed || (L->ptm_local && L->rest_ptm != 1)) {
+            L->ptm_local = false;
+            L->ptm_local_off = true;
+            return prepare_partition(L);
+        }
         if (L->rest_ptm + L->rest_lds > 0) {
             // one int32 block, tables in component order (a component without one has empty ranges)
             ivec sptr(nc + 1, 0), gptr(nc + 1, 0), svid, sfree, gperm;
@@ -2021,6 +2114,35 @@ int prepare_partition(rdis_hip_plan* L) {
                 }
                 for (int k = 0; k <= npc; ++k) cptr.push_back(e0 + cbase[(size_t)k]);
                 L->pm_blocks += npb;
+                if (L->ptm_local && L->ptm_local_comp == (int)cc) {
+                    // the tables of the local group (ptm_api.hpp: PtmGroupArgs): per workgroup its cameras and chunk range, per entry
+                    // of the factor stream the camera's number in the workgroup that owns the chunk, per component camera who holds it
+                    const int Kl = L->ptm_local_K, ncbg = ls_ncb[cc];
+                    L->h_pm_lcam.assign((size_t)cbase[(size_t)npc] + 64 * PTM_BLK, (short)-1);
+                    L->h_lc_off.assign((size_t)Kl, 0);
+                    std::vector<ivec> holders((size_t)ncbg);
+                    ivec g2l((size_t)ncbg, -1);
+                    for (int rk = 0; rk < Kl; ++rk) {
+                        const ivec& lc = local_cams[(size_t)rk];
+                        for (size_t k = 0; k < lc.size(); ++k) g2l[(size_t)lc[k]] = (int)k;
+                        L->h_lc_off[(size_t)rk] = (long long)L->h_lc.size();
+                        L->h_lc.push_back((int)lc.size()); L->h_lc.push_back(L->h_wg_chunk0[(size_t)rk]); L->h_lc.push_back(L->h_wg_chunk0[(size_t)rk + 1]); L->h_lc.push_back(0);
+                        L->h_lc.insert(L->h_lc.end(), lc.begin(), lc.end());
+                        for (size_t k = 0; k < lc.size(); ++k) {   // (the first workgroup that holds a camera speaks for it)
+                            L->h_lc.push_back(holders[(size_t)lc[k]].empty() ? 1 : 0);
+                            holders[(size_t)lc[k]].push_back((rk << 8) | (int)k);
+                        }
+                        for (int e = cbase[(size_t)L->h_wg_chunk0[(size_t)rk]]; e < cbase[(size_t)L->h_wg_chunk0[(size_t)rk + 1]]; ++e) {
+                            const int j = L->h_pm_jg[(size_t)(e0 + e)];
+                            if (j >= 0) L->h_pm_lcam[(size_t)e] = (short)g2l[(size_t)(((unsigned)ls_fidx[(size_t)j]) & 0xFFFu)];
+                        }
+                    }
+                    L->h_cr_ptr.assign(1, 0);
+                    for (int g = 0; g < ncbg; ++g) {
+                        L->h_cr.insert(L->h_cr.end(), holders[(size_t)g].begin(), holders[(size_t)g].end());
+                        L->h_cr_ptr.push_back((int)L->h_cr.size());
+                    }
+                }
             }
             L->pm_entries = (int64_t)L->h_pm_jg.size();
             L->pm_cptr_len = (int64_t)cptr.size();
@@ -2083,6 +2205,20 @@ int prepare_partition(rdis_hip_plan* L) {
         const PlanView V = L->view();
         HIPCHK(c, ptm_gather_launch(grid_for(c, L->pm_entries, 256), c->stream, (int)L->pm_entries, L->lds_ints.as<int>() + L->off_pm_jg, V.ls_fidx, V.ls_obs,
                                     L->pm_cam.as<short>(), L->pm_obs.as<double2>()));
+        if (L->ptm_local) {   // the stream names a factor's camera by its number in the workgroup that owns the chunk; the group's tables
+            HIPCHK(c, hipMemcpyAsync(L->pm_cam.p, L->h_pm_lcam.data(), std::min(L->h_pm_lcam.size(), (size_t)L->pm_entries + 64 * PTM_BLK) * sizeof(short),
+                                     hipMemcpyHostToDevice, c->stream));
+            rc = plan_alloc(L, L->lc_dev, L->h_lc.size() * sizeof(int));
+            if (!rc) rc = plan_alloc(L, L->lc_off_dev, L->h_lc_off.size() * sizeof(long long));
+            if (!rc) rc = plan_alloc(L, L->cr_ptr_dev, L->h_cr_ptr.size() * sizeof(int));
+            if (!rc) rc = plan_alloc(L, L->cr_dev, std::max<size_t>(L->h_cr.size(), 1) * sizeof(int));
+            if (!rc) rc = plan_alloc(L, L->ptm_tot, 2 * (size_t)PTM_CS * (L->h_cr_ptr.size() - 1) * sizeof(double));
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(L->lc_dev.p, L->h_lc.data(), L->h_lc.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L->lc_off_dev.p, L->h_lc_off.data(), L->h_lc_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L->cr_ptr_dev.p, L->h_cr_ptr.data(), L->h_cr_ptr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(L->cr_dev.p, L->h_cr.data(), L->h_cr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
     }
     if (!L->coop.empty()) {
         rc = plan_alloc(L, L->coop_ints, L->h_coop_ints.size() * sizeof(int));
@@ -2214,19 +2350,21 @@ static int ptm_build_segments(rdis_hip_plan* L, int threads, int K) {
         const int cc = L->h_rest[ri];
         const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - PTM_CS * ncb) / 3, npc = (npb + 63) / 64;
         const int* cp = cptr + pm_ch0[cc];
+        const bool local = L->ptm_local && L->ptm_local_comp == cc;   // (a workgroup's chunks: consecutive ones instead of every K-th)
         for (int rk = 0; rk < K; ++rk) {
+            const int ch0 = local ? L->h_wg_chunk0[(size_t)rk] : rk, chend = local ? L->h_wg_chunk0[(size_t)rk + 1] : npc, chstep = local ? 1 : K;
             long long units = 0;
-            for (int ch = rk; ch < npc; ch += K) units += ((cp[ch + 1] - cp[ch]) / 64 + PTM_BLK - 1) / PTM_BLK;
+            for (int ch = ch0; ch < chend; ch += chstep) units += ((cp[ch + 1] - cp[ch]) / 64 + PTM_BLK - 1) / PTM_BLK;
             size_t depth = 0;
             long long u = 0;   // blocks dealt out so far
-            int ch = rk, done = 0;   // the chunk at hand and its blocks already dealt out
+            int ch = ch0, done = 0;   // the chunk at hand and its blocks already dealt out
             for (int w = 0; w < nw; ++w) {
                 ivec& sh = share[(size_t)w];
                 sh.clear();
                 const long long end = units * (w + 1) / nw;
                 while (u < end) {
                     const int nb = ((cp[ch + 1] - cp[ch]) / 64 + PTM_BLK - 1) / PTM_BLK;
-                    if (done >= nb) { ch += K; done = 0; continue; }
+                    if (done >= nb) { ch += chstep; done = 0; continue; }
                     const int take = (int)std::min<long long>(nb - done, end - u);
                     const int e0 = cp[ch] + 64 * PTM_BLK * done, e1 = std::min(cp[ch + 1], e0 + 64 * PTM_BLK * take);
                     sh.push_back(ch); sh.push_back(e0); sh.push_back(e1); sh.push_back(0);
@@ -2278,15 +2416,20 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
     for (size_t ri = r_ptm; ri < r_lds; ++ri) {
         const int cc = L->h_rest[ri];
-        const int ncb = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - PTM_CS * ncb) / 3, npc = (npb + 63) / 64;
+        const int ncb_all = ls_ncb[cc], ns = ls_ptr[cc + 1] - ls_ptr[cc], npb = (ns - PTM_CS * ncb_all) / 3, npc = (npb + 63) / 64;
         const int* cp = cptr + pm_ch0[cc];
-        const size_t stride = (size_t)ptm_round_stride(ncb);
+        const bool local = L->ptm_local && L->ptm_local_comp == cc;
         for (int rk = 0; rk < K; ++rk) {
+            // (a local group: the workgroup's own cameras, under its own numbers; its chunks consecutive, wave w every eighth from the w-th on)
+            const int ncb = local ? L->h_lc[(size_t)L->h_lc_off[(size_t)rk]] : ncb_all;
+            const size_t stride = (size_t)ptm_round_stride(ncb);
+            auto cam_of = [&](int e, int j) { return local ? (int)L->h_pm_lcam[(size_t)e] : (int)(fidx[j] & 0xFFFu); };   // (an entry's camera as the stream names it)
             size_t nrounds = 0;
             for (int w = 0; w < nw; ++w) {
                 ivec& st = steps[(size_t)w];
                 st.clear();
-                for (int ch = rk + K * w; ch < npc; ch += K * nw)
+                const int ch0 = local ? L->h_wg_chunk0[(size_t)rk] + w : rk + K * w, chend = local ? L->h_wg_chunk0[(size_t)rk + 1] : npc, chstep = local ? nw : K * nw;
+                for (int ch = ch0; ch < chend; ch += chstep)
                     for (int e = cp[ch]; e < cp[ch + 1]; e += 64) st.push_back(e);
                 nrounds = std::max(nrounds, st.size());
             }
@@ -2300,7 +2443,7 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
                 for (int w = 0; w < nw; ++w) {
                     if (rr >= steps[(size_t)w].size()) continue;
                     const int e = steps[(size_t)w][rr];
-                    for (int l = 0; l < 64; ++l) { const int j = jg[e + l]; if (j >= 0) ++seg[(size_t)(fidx[j] & 0xFFFu) + 1]; }
+                    for (int l = 0; l < 64; ++l) { const int j = jg[e + l]; if (j >= 0) ++seg[(size_t)cam_of(e + l, j) + 1]; }
                 }
                 for (int k = 0; k < ncb; ++k) seg[(size_t)k + 1] += seg[(size_t)k];
                 for (int k = 0; k <= ncb; ++k) rec[k] = (unsigned short)seg[(size_t)k];
@@ -2310,7 +2453,7 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
                     const int e = steps[(size_t)w][rr];
                     for (int l = 0; l < 64; ++l) {
                         const int j = jg[e + l];
-                        if (j >= 0) grow[(size_t)(e + l)] = (unsigned short)pos[(size_t)(fidx[j] & 0xFFFu)]++;
+                        if (j >= 0) grow[(size_t)(e + l)] = (unsigned short)pos[(size_t)cam_of(e + l, j)]++;
                     }
                 }
             }
@@ -2367,6 +2510,7 @@ int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out, bool wide 
     return 0;
 }
 int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int ngroups, int K, int maxiters, double ftol, bool wide = false) {
+    const bool local = wide && L->ptm_local;
     rdis_hip_ctx* c = L->prob->ctx;
     int rc = ptm_build_rounds(L, threads, K);
     if (rc) return rc;
@@ -2390,12 +2534,19 @@ int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int fir
     // arm every granule, clear the abort words
     HIPCHK(c, hipMemsetAsync(L->ptm_state.p, 0xFF, (size_t)ngroups * st_bytes, stream));
     HIPCHK(c, hipMemset2DAsync((char*)L->ptm_state.p + abort_off, st_bytes, 0, 64, (size_t)ngroups, stream));
-    PtmGroupArgs A{L->ptm_state.p, L->ptm_xch.as<double>(), K, ngroups, wide ? L->coop_poll_delay : std::min(4, L->coop_poll_delay)};
+    PtmGroupArgs A{L->ptm_state.p, L->ptm_xch.as<double>(), K, ngroups, wide ? L->coop_poll_delay : std::min(4, L->coop_poll_delay),
+                   nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (local) {
+        A.lc_off = L->lc_off_dev.as<long long>(); A.lc = L->lc_dev.as<int>(); A.cr_ptr = L->cr_ptr_dev.as<int>(); A.cr = L->cr_dev.as<int>();
+        A.tot = L->ptm_tot.as<double>();
+    }
     int mi = maxiters;
     double ft = ftol;
     void* args[] = {&P, &V, &A, &mi, &ft, &ncc};
     const int grid = wide ? K * ngroups : 8 * K * ((ngroups + 7) / 8);
-    HIPCHK(c, hipLaunchCooperativeKernel(ptmg_kernel_fn(L->ptm_rot_mode, threads, wide), dim3(grid), dim3(threads), args, dyn, stream));
+    const void* fn = ptmg_kernel_fn(L->ptm_rot_mode, threads, wide, local);
+    if (local && dyn > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(grid), dim3(threads), args, dyn, stream));
     return 0;
 }
 int launch_lds_stale(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
@@ -2611,7 +2762,11 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
         // A few components and a device: wide groups -- as many workgroups of 512 lanes a component as are resident and have some
         // twenty wave-chunks of points each (one component of 8e6 factors: 256 workgroups, 15 chunks a wave)
         bool wide = false;
-        if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty() && L->rest_ptm <= 8 &&
+        if (L->ptm_local) {   // (its tables are made for this group size)
+            K = L->ptm_local_K; threads = PTM_WIDE_THREADS; wide = true;
+            if (overlap || !L->coop.empty() || !L->stream.empty())
+                return fail(c, RDIS_HIP_EINVAL, "a wide group with local camera numbering takes the device to itself: no cooperative or grid launch beside it");
+        } else if (L->ptm_group != 1 && !overlap && L->coop.empty() && L->stream.empty() && L->rest_ptm <= 8 &&
             (L->ptm_threads == 0 || L->ptm_threads == PTM_WIDE_THREADS)) {
             int cap = 0;
             int rc = ptmg_resident_workgroups(L, PTM_WIDE_THREADS, &cap, true);
@@ -2884,6 +3039,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
     else if (n == "components_lds") *value = L->rest_lds;
     else if (n == "components_point_major") *value = L->rest_ptm;
     else if (n == "point_major_wide") *value = L->ptm_wide_last ? 1 : 0;
+    else if (n == "point_major_local_cameras") *value = (L->ptm_wide_last && L->ptm_local) ? L->ptm_ncb_cap : 0;
     else if (n == "components_plain") *value = rest;
     else if (n == "pipelined") *value = L->pipelined() ? 1 : 0;
     else if (n == "point_major_group") *value = L->ptm_last_group;

@@ -93,7 +93,21 @@ struct PtRecs {
     double g[3];          // (the gradient pass only) g of the recurrence
 };
 
-template <int ROT, bool GROUP = false, class ST = SmallCoopState>
+// LOCAL (wide groups only): a component with more cameras than a compute unit's LDS holds.  A workgroup then keeps only the
+// cameras its OWN point chunks meet -- it owns a contiguous range of the camera-sorted chunk order, so they are few -- under local
+// numbers (the factor stream names cameras by them); the component's cameras are `ncbg`, and what crosses workgroups (the partial
+// camera gradients) goes through per-camera lists of (rank, local number).
+struct PtmLocal {
+    int ncbg;            // cameras of the component
+    int cbeg, cend;      // this workgroup's chunks [cbeg, cend)
+    const int* cmap;     // [ncb] local -> component camera
+    const int* own;      // [ncb] 1: this workgroup speaks for the camera where a camera counts once (the sums' terms, write-back)
+    const int* cr_ptr;   // [ncbg + 1] per component camera the workgroups that hold it ...
+    const int* cr;       // ... as rank << 8 | local number, ascending rank
+    double* tot;         // [2][PTM_CS ncbg] the cameras' summed gradient entries (two gradients' worth)
+};
+
+template <int ROT, bool GROUP = false, class ST = SmallCoopState, bool LOCAL = false>
 struct PtmEnv {
     const ProblemView& P;
     const PlanView& L;
@@ -131,6 +145,13 @@ struct PtmEnv {
     GridSyncT<ST> GX;
     double* xch;              // [2][K][xch_stride] the workgroups' partial camera gradients; behind them [2][xch_stride] their sums (wide groups)
     int xch_stride, gpar;
+    PtmLocal LC;              // (LOCAL)
+    // the first slot of the point blocks in the component's slot tables (svid, sfree): behind ALL its cameras
+    __device__ __forceinline__ int pslot0() const { return PTM_CS * (LOCAL ? LC.ncbg : ncb); }
+    // the component-wide slot of this workgroup's camera slot s
+    __device__ __forceinline__ int cam_gslot(int s) const { if constexpr (LOCAL) { const int c = s / PTM_CS; return PTM_CS * LC.cmap[c] + (s - PTM_CS * c); } else return s; }
+    // does this workgroup speak for camera slot s where a camera counts once?
+    __device__ __forceinline__ bool speaks_for(int s) const { if constexpr (LOCAL) return LC.own[s / PTM_CS] != 0; else return !GROUP || r == 0; }
 #ifdef RDIS_COOP_TIMING
     long long tmv[32];
     long long wv[32];
@@ -139,13 +160,14 @@ struct PtmEnv {
 #endif
 
     // the wave-chunks of point blocks this wave takes: chunk c belongs to workgroup c mod K, wave (c / K) mod nwaves
-    __device__ __forceinline__ int first_chunk() const { return GROUP ? r + K * (tid >> 6) : (tid >> 6); }
-    __device__ __forceinline__ int chunk_step() const { return GROUP ? K * nwaves : nwaves; }
+    __device__ __forceinline__ int first_chunk() const { return LOCAL ? LC.cbeg + (tid >> 6) : GROUP ? r + K * (tid >> 6) : (tid >> 6); }
+    __device__ __forceinline__ int chunk_step() const { return LOCAL ? nwaves : GROUP ? K * nwaves : nwaves; }
+    __device__ __forceinline__ int chunk_end() const { return LOCAL ? LC.cend : npc; }
     // the point blocks this workgroup owns, a lane each
     template <class Fn>
     __device__ __forceinline__ void my_points(Fn fn) const {
         const int lane = tid & 63;
-        for (int c = first_chunk(); c < npc; c += chunk_step()) {
+        for (int c = first_chunk(); c < chunk_end(); c += chunk_step()) {
             const int ps = 64 * c + lane;
             if (ps < npb) fn(ps);
         }
@@ -300,7 +322,7 @@ struct PtmEnv {
         const double* be = PE + (long long)PT_BND * ps;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
+            const int fi = sfree[pslot0() + 3 * ps + k];
             x[k] = fi >= 0 ? clampd(L.xstart[f0 + fi], be[k], be[3 + k]) : PT[k * pstr + ps];
         }
     }
@@ -441,7 +463,7 @@ struct PtmEnv {
     // ... at clamp(x_start) (the rollback; value only)
     __device__ void eval_start(double& af) {
         const int lane = tid & 63;
-        for (int c = first_chunk(); c < npc; c += chunk_step()) {
+        for (int c = first_chunk(); c < chunk_end(); c += chunk_step()) {
             const int e0 = __builtin_amdgcn_readfirstlane(cptr[c]), e1 = __builtin_amdgcn_readfirstlane(cptr[c + 1]);
             const int ps = 64 * c + lane;
             double x[3] = {0.0, 0.0, 0.0}, dp[3] = {0.0, 0.0, 0.0}, as = 0.0;
@@ -509,7 +531,7 @@ struct PtmEnv {
     __device__ void init_vectors() {   // CGD .cpp:34-39: p = x0 (unclamped); constants hold their assigned value
         const double* xs = L.xstart + f0;
         for (int s = tid; s < PTM_CS * ncb; s += nt) {
-            const int fi = SF[s], v = svid[s];
+            const int fi = SF[s], v = svid[cam_gslot(s)];
             if (fi >= 0) {
                 const double lo = P.lo[v], hi = P.hi[v], x0 = xs[fi];
                 Pv[s] = x0; LO[s] = lo; HI[s] = hi; X[s] = clampd(x0, lo, hi);
@@ -520,7 +542,7 @@ struct PtmEnv {
             XI[s] = 0.0; GC[s] = 0.0; HC[s] = 0.0;
         }
         my_point_vars([&](int ps, int k) {
-            const int s = PTM_CS * ncb + 3 * ps + k, fi = sfree[s], v = svid[s];
+            const int s = pslot0() + 3 * ps + k, fi = sfree[s], v = svid[s];
             double lo = -__builtin_inf(), hi = __builtin_inf();
             if (fi >= 0) { PT[k * pstr + ps] = xs[fi]; lo = P.lo[v]; hi = P.hi[v]; }
             else PT[k * pstr + ps] = P.x[v];
@@ -532,14 +554,14 @@ struct PtmEnv {
         // inside it is strictly inside every block's bounds); blocks' own bounds only where a trial value leaves it
         {
             const int lane = tid & 63;
-            for (int c = first_chunk(); c < npc; c += chunk_step()) {
+            for (int c = first_chunk(); c < chunk_end(); c += chunk_step()) {
                 const int ps = 64 * c + lane;
                 double bl[3], bh[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     double lo = -__builtin_inf(), hi = __builtin_inf();
                     if (ps < npb) {
-                        const int sl = PTM_CS * ncb + 3 * ps + k;
+                        const int sl = pslot0() + 3 * ps + k;
                         if (sfree[sl] >= 0) { const int v = svid[sl]; lo = P.lo[v]; hi = P.hi[v]; }
                     }
                     bl[k] = wave_max((double)inner_lo32(lo));
@@ -603,14 +625,15 @@ struct PtmEnv {
         // that are asked for a block / a chunk ahead; a round evaluates ONE slot (slot ks of the block at hand)
         int cu = __builtin_amdgcn_readfirstlane(first_chunk());
         int e = 0, e1 = 0;
-        if (cu < npc) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
+        const int cend = chunk_end();
+        if (cu < cend) { e = __builtin_amdgcn_readfirstlane(cptr[cu]); e1 = __builtin_amdgcn_readfirstlane(cptr[cu + 1]); }
         bool have = e < e1;
         int cx = cu + cs, ne = 0, ne1 = 0, v0 = 0, v1 = 0;
         PtRecs R = {};
         SlotBlock B = {}, N = {};
         if (have) {
-            if (cx < npc) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
-            if (cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+            if (cx < cend) { ne = __builtin_amdgcn_readfirstlane(cptr[cx]); ne1 = __builtin_amdgcn_readfirstlane(cptr[cx + 1]); }
+            if (cx + cs < cend) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
             load_recs<true>(cu, R);
             load_block<CAMS>(e, N);
         }
@@ -619,7 +642,7 @@ struct PtmEnv {
         double x[3] = {0.0, 0.0, 0.0}, s0 = 0.0, s1 = 0.0, s2 = 0.0, pn[3] = {0.0, 0.0, 0.0}, go[3] = {0.0, 0.0, 0.0};
         // a block's entries are known: its record (new p, gradient), its terms of the sums
         auto finish_block = [&](int ps, const double (&pnew)[3], const double (&gold)[3], double e0, double e1_, double e2) {
-            const int* sf = sfree + PTM_CS * ncb + 3 * ps;
+            const int* sf = sfree + pslot0() + 3 * ps;
             const double en[3] = {sf[0] >= 0 ? e0 : 0.0, sf[1] >= 0 ? e1_ : 0.0, sf[2] >= 0 ? e2 : 0.0};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -680,7 +703,7 @@ struct PtmEnv {
                     cx += cs;
                     ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);
                     v0 = v1 = 0;
-                    if (have && cx + cs < npc) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+                    if (have && cx + cs < cend) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
                 } else if (ks == PTM_BLK) { e += 64 * PTM_BLK; ks = 0; }
             }
             const long long tr1 = clock();
@@ -729,7 +752,7 @@ struct PtmEnv {
             }
         }
         // blocks no listed factor reads (free variables only; their chunks stand last): zero entries
-        for (int c = first_chunk(); c < npc; c += cs) {
+        for (int c = first_chunk(); c < cend; c += cs) {
             if (cptr[c] < cptr[c + 1]) continue;
             const int ps = 64 * c + lane;
             if (ps < npb) {
@@ -748,7 +771,26 @@ struct PtmEnv {
             gpar ^= 1;
             for (int s = tid; s < PTM_CS * ncb; s += nt) buf[(long long)r * xch_stride + s] = XI[s];
             GX.barrier_ordered();
-            if (K <= PTM_MAX_GROUP) {   // a few workgroups: everybody adds everything
+            if constexpr (LOCAL) {
+                // every workgroup holds its own cameras under its own numbers: a share of the component's camera slots each, a
+                // slot's partials from the workgroups that hold the camera (the plan's list, ascending rank: a fixed order), a
+                // second barrier, everybody fetches the sums of its own cameras
+                double* gt = LC.tot + (long long)(gpar ^ 1) * PTM_CS * LC.ncbg;   // (gpar has been flipped above)
+                const int S = PTM_CS * LC.ncbg, per = (S + K - 1) / K;
+                for (int gs = r * per + tid; gs < min(S, (r + 1) * per); gs += nt) {
+                    const int g = gs / PTM_CS, q = gs - PTM_CS * g;
+                    double sm = 0.0;
+                    for (int e = LC.cr_ptr[g], e1 = LC.cr_ptr[g + 1], first = 1; e < e1; ++e, first = 0) {
+                        const int w = LC.cr[e];
+                        const double v = buf[(long long)(w >> 8) * xch_stride + PTM_CS * (w & 255) + q];
+                        sm = first ? v : sm + v;
+                    }
+                    gt[gs] = sm;
+                }
+                GX.barrier_ordered();
+                for (int s = tid; s < PTM_CS * ncb; s += nt)
+                    if (SF[s] >= 0) XI[s] = gt[cam_gslot(s)];
+            } else if (K <= PTM_MAX_GROUP) {   // a few workgroups: everybody adds everything
                 for (int s = tid; s < PTM_CS * ncb; s += nt) {
                     if (SF[s] < 0) continue;
                     double sm = buf[s];
@@ -779,7 +821,7 @@ struct PtmEnv {
             __syncthreads();
         }
         if (RED) {
-            if (!GROUP || r == 0) camera_pass([&](double& p, double& xi, double& gv, double&) { reduce_term(p, xi, gv, den, ra, rb, rt); });
+            camera_pass<true>([&](double& p, double& xi, double& gv, double&) { reduce_term(p, xi, gv, den, ra, rb, rt); });
             sumk<3>(ra, rb, rt);
             gg = ra; dgg = rb; test = rt;
         }
@@ -792,10 +834,11 @@ struct PtmEnv {
     // by free index behind a per-variable table: three dependent round trips per variable, 100 000 cycles a pass).  The
     // entries of a variable that is not free are zero throughout (xi, g, h) and take part as zeros.
     // fn(p, xi, g, h) on every camera slot with a free variable
-    template <class Fn>
+    // ONCE: only the cameras this workgroup speaks for (a camera's terms count once in a group)
+    template <bool ONCE = false, class Fn>
     __device__ __forceinline__ void camera_pass(Fn fn) {
         for (int s = tid; s < PTM_CS * ncb; s += nt)
-            if (SF[s] >= 0) fn(Pv[s], XI[s], GC[s], HC[s]);
+            if (SF[s] >= 0 && (!ONCE || speaks_for(s))) fn(Pv[s], XI[s], GC[s], HC[s]);
     }
     // ... and on the three variables of every point block of this workgroup; WREC / WGH: the pass changes (p, xi) / (g, h)
     template <bool WREC, bool WGH, class Fn>
@@ -825,11 +868,10 @@ struct PtmEnv {
     __device__ void line_begin() {
         if (L.vdump != nullptr && lm_count < L.dump_iters) {   // (tests: p and the direction by free index)
             double* d = L.vdump + 2ll * L.dump_iters * f0 + 2ll * lm_count * n;
-            if (!GROUP || r == 0)
-                for (int s = tid; s < PTM_CS * ncb; s += nt)
-                    if (SF[s] >= 0) { d[SF[s]] = Pv[s]; d[n + SF[s]] = XI[s]; }
+            for (int s = tid; s < PTM_CS * ncb; s += nt)
+                if (SF[s] >= 0 && speaks_for(s)) { d[SF[s]] = Pv[s]; d[n + SF[s]] = XI[s]; }
             my_point_vars([&](int ps, int k) {
-                const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
+                const int fi = sfree[pslot0() + 3 * ps + k];
                 if (fi >= 0) { d[fi] = PT[k * pstr + ps]; d[n + fi] = PT[(3 + k) * pstr + ps]; }
             });
         }
@@ -864,7 +906,7 @@ struct PtmEnv {
         const double den = fmax(fabs(fp), 1.0);
         double a = 0.0, b = 0.0, t = 0.0;
         auto fn = [&](double& p, double& xi, double& gv, double&) { reduce_term(p, xi, gv, den, a, b, t); };
-        if (!GROUP || r == 0) camera_pass(fn);   // (a camera counts once in a group)
+        camera_pass<true>(fn);   // (a camera counts once in a group)
         point_pass<false, false>(fn);
         sumk<3>(a, b, t);
         gg = a; dgg = b; test = t;
@@ -890,11 +932,10 @@ struct PtmEnv {
             P.x[v] = xv;
             L.xout[f0 + fi] = xv;
         };
-        if (!GROUP || r == 0)
-            for (int s = tid; s < PTM_CS * ncb; s += nt)
-                if (SF[s] >= 0) out(SF[s], Pv[s]);
+        for (int s = tid; s < PTM_CS * ncb; s += nt)
+            if (SF[s] >= 0 && speaks_for(s)) out(SF[s], Pv[s]);
         my_point_vars([&](int ps, int k) {
-            const int fi = sfree[PTM_CS * ncb + 3 * ps + k];
+            const int fi = sfree[pslot0() + 3 * ps + k];
             if (fi >= 0) out(fi, PT[k * pstr + ps]);
         });
     }
@@ -902,13 +943,22 @@ struct PtmEnv {
 
 // LDS of a workgroup (ptm_bytes_for): [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records][9 (blockDim + 1) staged
 // camera partials][two round lists (16-bit)][10 ncb_cap free indices (int)]
-template <int ROT, bool GROUP, class ST = SmallCoopState>
-__device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
-                                                           int ncb_cap, int r, int K, ST* st, double* bcast,
-                                                           int poll_delay, double* xch) {
+template <int ROT, bool GROUP, class ST = SmallCoopState, bool LOCAL = false>
+__device__ __forceinline__ PtmEnv<ROT, GROUP, ST, LOCAL> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
+                                                                  int ncb_cap, int r, int K, ST* st, double* bcast,
+                                                                  int poll_delay, double* xch, const PtmGroupArgs* GA = nullptr) {
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
     const int n = L.free_ptr[comp + 1] - f0, m = L.fac_ptr[comp + 1] - c0;
-    const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncb = L.ls_ncb[comp], npb = (ns - PTM_CS * ncb) / 3;
+    const int s0 = L.ls_ptr[comp], ns = L.ls_ptr[comp + 1] - s0, ncbg = L.ls_ncb[comp], npb = (ns - PTM_CS * ncbg) / 3;
+    // (LOCAL: this workgroup's table -- its number of cameras, its chunk range, then local -> component camera, then the cameras it speaks for)
+    PtmLocal LC{ncbg, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ncb = ncbg;
+    if constexpr (LOCAL) {
+        const int* t = GA->lc + GA->lc_off[r];
+        ncb = t[0]; LC.cbeg = t[1]; LC.cend = t[2];
+        LC.cmap = t + 4; LC.own = t + 4 + ncb;
+        LC.cr_ptr = GA->cr_ptr; LC.cr = GA->cr; LC.tot = GA->tot;
+    }
     const int sc = PTM_CS * ncb_cap, nt = (int)blockDim.x;
     double* ROTR = lds + PTM_CAM_VECTORS * sc;
     double* CTR = ROTR + PTM_RS * ncb_cap;
@@ -917,7 +967,11 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, 
     unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * (nt + 1));
     const int rl_cap = ptm_round_stride(ncb_cap);
     int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
-    for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) SF[s] = L.ls_free[s0 + s];
+    for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) {
+        int gs = s;
+        if constexpr (LOCAL) { const int c = s / PTM_CS; gs = PTM_CS * LC.cmap[c] + (s - PTM_CS * c); }
+        SF[s] = L.ls_free[s0 + gs];
+    }
     __syncthreads();
     const int pb0 = L.pm_pt0[comp];
     const int* segs = L.pm_segs + L.pm_sg_off[(long long)comp * K + r];
@@ -933,7 +987,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, 
         rounds = L.pm_rounds + L.pm_rd_off[w];
         nrounds = L.pm_rd_n[w];
     }
-    return PtmEnv<ROT, GROUP, ST>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
+    return PtmEnv<ROT, GROUP, ST, LOCAL>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
                               ncb, npb, (npb + 63) / 64,
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR, CTR, CDR,
@@ -945,7 +999,7 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST> ptm_env(const ProblemView& P, 
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
                               r, K, GridSyncT<ST>{st, (int)threadIdx.x, K, r, bcast, poll_delay, 0, 0u, false, 0u, {}},
-                              xch, PTM_CS * ncb_cap, 0
+                              xch, PTM_CS * ncb_cap, 0, LC
 #ifdef RDIS_COOP_TIMING
                               , {}
 #endif
@@ -987,9 +1041,10 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
 // cameras fit the LDS (what solver_stream.hpp took before round 6: every trial through x[] in global memory, every gradient's
 // partials through HBM).  Its K workgroups are consecutive blocks, i.e. dealt round robin over the XCDs; the exchange state is a
 // CoopState (every wave an entry: K x waves of them); the partial camera gradients are added by shares (gradient_fused).
-template <int THREADS, int ROT, bool WIDE = false>
+template <int THREADS, int ROT, bool WIDE = false, bool LOCAL = false>
 __global__ void __launch_bounds__(THREADS, (THREADS <= 256 ? 2 : 1))
 cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double ftol, int ncb_cap) {
+    static_assert(!LOCAL || WIDE, "local camera numbering is for wide groups");
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
     __shared__ double red[2][3][MAX_WAVES];
     __shared__ double bcast[8];
@@ -998,8 +1053,8 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
     const int grp = WIDE ? b / K : (b / (8 * K)) * 8 + (b & 7), r = WIDE ? b % K : (b >> 3) % K;
     if (grp >= A.ngroups) return;
     const int comp = L.order[grp];
-    PtmEnv<ROT, true, ST> E = ptm_env<ROT, true, ST>(P, L, comp, lds_dyn, red, ncb_cap, r, K, reinterpret_cast<ST*>(A.st) + grp, bcast, A.poll_delay,
-                                              A.xch ? A.xch + (long long)grp * (2 * K + 2) * PTM_CS * ncb_cap : nullptr);
+    PtmEnv<ROT, true, ST, LOCAL> E = ptm_env<ROT, true, ST, LOCAL>(P, L, comp, lds_dyn, red, ncb_cap, r, K, reinterpret_cast<ST*>(A.st) + grp, bcast, A.poll_delay,
+                                              A.xch ? A.xch + (long long)grp * (2 * K + 2) * PTM_CS * ncb_cap : nullptr, &A);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];

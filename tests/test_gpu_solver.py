@@ -792,6 +792,46 @@ def test_wide_point_major_group_on_one_large_component(case, gctx):
     assert abs(r1.fret[0] - r2.fret[0]) <= 1e-6 * abs(r2.fret[0])      # (one line minimisation: Brent's own tolerance)
 
 
+@pytest.mark.parametrize("case", ["300 cameras x 60000 points", "forced on 24 cameras x 30000 points"])
+def test_wide_group_with_local_camera_numbering(case, gctx):
+    """A component with more cameras than a compute unit's LDS holds (about 125): the wide group's workgroups each keep only the
+    cameras their own chunks meet -- contiguous shares of the camera-sorted chunk order -- under local numbers; the partial camera
+    gradients meet through per-camera lists of (rank, local number) (solver_ptm.hpp: LOCAL).  Replayed against the oracle, the
+    same bits twice, against the grid solver after one line minimisation; and forced (option ptm_local_cameras = 1) on a
+    component whose cameras would fit, where it must agree with the all-cameras form to rounding."""
+    if case.startswith("300"):
+        pp, opts = P.make_synthetic_ba(1, 300, 60000, obs_per_pt=4), {}
+    else:
+        pp, opts = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4), {"ptm_local_cameras": 1}
+    pp.single_component()
+    mit = 3
+    g, plan = _plan_of(gctx, pp, dict(opts, trace_records=1 << 13, dump_iters=mit))
+    ends = []
+    for _ in range(2):
+        plan.set_start(pp.x0)
+        plan.solve(mit, 3e-8)
+        r = plan.fetch()
+        ends.append((r.fret[0], r.x.tobytes()))
+    assert ends[0] == ends[1]
+    assert plan.info("components_point_major") == 1 and plan.info("point_major_wide") == 1 and plan.info("components_grid_stream") == 0
+    held = plan.info("point_major_local_cameras")
+    assert 0 < held <= 125 and plan.info("point_major_group") > 16      # (a workgroup's cameras: what its LDS holds)
+    tr, n = plan.get_trace(0, 1 << 13)
+    check_replay(pp, (tr[:n], plan.get_vectors(0, mit)), r, mit)
+    assert r.delta[0] < 0 and np.array_equal(g.get_x(), r.x)
+    others = [{"ptm_stream": 0}] + ([{"ptm_local_cameras": 0}] if opts else [])
+    plan.set_start(pp.x0)
+    plan.solve(1, 3e-8)
+    r1 = plan.fetch()
+    for o in others:
+        g2, plan2 = _plan_of(gctx, pp, o)
+        plan2.set_start(pp.x0)
+        plan2.solve(1, 3e-8)
+        r2 = plan2.fetch()
+        assert plan2.info("point_major_local_cameras") == 0
+        assert abs(r1.fret[0] - r2.fret[0]) <= 1e-6 * abs(r2.fret[0]), o
+
+
 def test_component_beyond_register_capacity_uses_streaming(gctx):
     # one synthetic component with more factors than the register-resident solver has lanes (65536)
     pp = P.make_synthetic_ba(1, 12, 20000, obs_per_pt=4)

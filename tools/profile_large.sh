@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 D=gpurun_out/prof_$1
 mkdir -p $D
 B="python bench.py --workload large-component --steps 3 --warmup 1 --no-cpu-baseline"
-for shape in 64x2000000x4 120x300000x4; do
+for shape in 64x2000000x4 120x300000x4 356x226730x6; do
   T=large_$shape
   rocprofv3 --kernel-trace --stats --output-format csv -d $D -o $T -- $B --large-shape $shape > $D/bench_$T.json 2>> $D/err.txt
   mkdir -p $D/$T
