@@ -298,7 +298,13 @@ int rdis_hip_comm_allreduce_f64(rdis_hip_comm *comm, double *inout, int32_t n, i
  * point blocks from HBM once per trial point, solver_ptm.hpp; 0 = never, 2 = every component whose
  * tables fit), "ptm_threads" (its workgroup size: 0 = auto, 256, 512 or 768), "ptm_group" (workgroups
  * that share one such component when the launch has fewer components than compute units: 0 = auto,
- * 1 = never, k <= 16 = k),
+ * 1 = never, k <= 16 = k; for the WIDE groups of at most eight large components -- a component too large for a
+ * cooperative group whose cameras fit the LDS streams through this solver on as many workgroups of 512 lanes as are resident,
+ * instead of the grid solver -- up to 512),
+ * "ptm_local_cameras" (a wide group whose component has more cameras than a compute unit's LDS holds, about 125: every
+ * workgroup keeps only the cameras its own contiguous share of the camera-sorted chunk order meets, under local numbers;
+ * -1 = default: where the cameras do not fit; 0 = never: such a component takes the grid solver; 1 = every wide group, for
+ * tests.  One such component a plan; falls back to the grid solver when a workgroup's cameras would not fit either),
  * "factor_rounding" (how the factor arithmetic rounds a * b + c: 0 = one fused multiply-add; 1 = the PARITY option: the product
  * is rounded before it is added, like the reference's x86-64 build (g++ emits no fused multiply-add), and EVERY sum of a solve is
  * added in the reference's order by one lane (or one wave feeding one lane): the objective over the listed factors
@@ -324,7 +330,9 @@ int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t valu
 /* which solver the plan's components go to (a test and tuning aid; the partition is computed on demand):
  * "components_cooperative", "components_grid_stream", "components_tiny", "components_lds",
  * "components_point_major", "components_plain" (counts), "pipelined" (0/1: cooperative groups use the
- * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch) */
+ * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch),
+ * "point_major_wide" (0/1: that launch was a wide group), "point_major_local_cameras" (0, or the most cameras a workgroup of
+ * a wide group with local camera numbering holds) */
 int rdis_hip_plan_get_info(rdis_hip_plan *plan, const char *name, int64_t *value);
 /* device memory the plan holds beyond the problem's (index tables, workspace, per-factor
  * partials, results): what a host-side cache of plans budgets with
