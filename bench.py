@@ -313,22 +313,35 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
     every rank); with 125 components a GPU has fewer components than compute units and K workgroups share each."""
     from rdis_amd.dist import rank_decomposition
     rows = [{"world": 1, "components_rank0": int(pp.ncomp), "ms_per_step": ms_world1, "ratio_to_world1": 1.0}]
+    # (round 6: every emulated step carries the objective's all-reduce through the C ABI over a communicator of one rank -- RCCL's
+    # launch and its place on the solver's stream are in the step; what a real job adds is the wire)
+    comm = None
+    try:
+        comm = capi.Comm(prob.ctx, 1, 0, capi.Comm.unique_id())
+    except Exception:
+        comm = None
     for world in (2, 4, 8):
         fp, fv, cp, ci, mine = rank_decomposition(pp, 0, world)
         plan = capi.Plan(prob, fp, fv, cp, ci)
         plan.set_start(pp.x0[fv])
         plan.solve(maxiters, 3e-8); plan.fetch()
+        if comm is not None:
+            plan.allreduce_objective(comm, fetch=False)
         t0 = time.perf_counter()
         kms = 0.0
         for _ in range(steps):
             plan.solve(maxiters, 3e-8)
+            if comm is not None:
+                plan.allreduce_objective(comm, fetch=False)
             r = plan.fetch()
             kms += plan.last_kernel_ms()[0]
         ms = (time.perf_counter() - t0) / steps * 1e3
         rows.append({"world": world, "components_rank0": int(len(mine)), "ms_per_step": ms, "kernel_ms": kms / steps,
                      "workgroups_per_component": int(plan.info("point_major_group")), "ratio_to_world1": ms_world1 / ms,
-                     "objective_rank0": float(r.fret.sum())})
+                     "objective_rank0": float(r.fret.sum()), "all_reduce_in_the_step": comm is not None})
         plan.close()
+    if comm is not None:
+        comm.close()
     return rows
 
 

@@ -33,7 +33,8 @@
 using namespace rdis_hip;
 
 struct rdis_hip_ctx {
-    int device = 0;
+    int device = 0;                   // the device as the caller names it
+    int phys = 0;                     // ... and the GPU behind it (the same, except under RDIS_HIP_VIRTUAL_DEVICES: tests)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 0;
@@ -69,8 +70,21 @@ int fail(rdis_hip_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
 }
+// Several contexts from one thread (OptimizableFunction::setDevices): every entry point must make its context's device current
+// before it allocates or launches.  A box with ONE GPU cannot show a forgotten one -- so RDIS_HIP_VIRTUAL_DEVICES=n (tests) makes
+// the library offer n devices that all stand on GPU 0, remember which of them the calling thread made current last
+// (make_current), and refuse every HIP call issued for a context while another context's device is the current one.
+inline int virtual_devices() {
+    static const int n = [] { const char* e = std::getenv("RDIS_HIP_VIRTUAL_DEVICES"); return e ? std::max(0, std::atoi(e)) : 0; }();
+    return n;
+}
+inline int& current_logical_device() { static thread_local int d = -1; return d; }
+inline hipError_t make_current(const rdis_hip_ctx* c) { current_logical_device() = c->device; return hipSetDevice(c->phys); }
 #define HIPCHK(ctx, expr)                                                                    \
     do {                                                                                     \
+        if (virtual_devices() > 0 && (ctx) != nullptr && current_logical_device() != (ctx)->device)  \
+            return fail((ctx), RDIS_HIP_EDEVICE, std::string(#expr) + ": issued while device " + std::to_string(current_logical_device()) + \
+                        " is current, for a context of device " + std::to_string((ctx)->device) + " (an entry point that did not make its device current)"); \
         hipError_t e__ = (expr);                                                             \
         if (e__ != hipSuccess)                                                               \
             return fail((ctx), e__ == hipErrorOutOfMemory ? RDIS_HIP_ENOMEM : RDIS_HIP_EDEVICE, \
@@ -80,7 +94,11 @@ int fail(rdis_hip_ctx* c, int code, const std::string& msg) {
 // Every entry point makes its context's device the calling thread's current one first: a host that drives several
 // contexts from one thread (rdis::OptimizableFunction::setDevices) would otherwise allocate, create events and launch
 // on whichever device its previous call left current.
-#define USE_DEVICE(ctx) HIPCHK((ctx), hipSetDevice((ctx)->device))
+#define USE_DEVICE(ctx)                                        \
+    do {                                                       \
+        hipError_t d__ = make_current(ctx);                    \
+        HIPCHK((ctx), d__);                                    \
+    } while (0)
 
 int dalloc(rdis_hip_ctx* c, DevBuf& b, size_t bytes) {
     b.release();
@@ -378,19 +396,20 @@ extern "C" int rdis_hip_abi_version(void) { return RDIS_HIP_ABI_VERSION; }
 extern "C" int rdis_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
+    return (n > 0 && virtual_devices() > 0) ? virtual_devices() : n;
 }
 
 extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
     if (!out) return RDIS_HIP_EINVAL;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RDIS_HIP_EDEVICE;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= (virtual_devices() > 0 ? virtual_devices() : n)) return RDIS_HIP_EDEVICE;
     rdis_hip_ctx* c = new (std::nothrow) rdis_hip_ctx;
     if (!c) return RDIS_HIP_ENOMEM;
     c->device = device;
+    c->phys = virtual_devices() > 0 ? 0 : device;
     hipDeviceProp_t prop;
-    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+    if (make_current(c) != hipSuccess || hipGetDeviceProperties(&prop, c->phys) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return RDIS_HIP_EDEVICE;
@@ -405,7 +424,7 @@ extern "C" int rdis_hip_create(int device, rdis_hip_ctx** out) {
 
 extern "C" void rdis_hip_destroy(rdis_hip_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    (void)make_current(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -465,7 +484,7 @@ extern "C" int rdis_hip_upload_ba(rdis_hip_ctx* c, int64_t nvars, const double* 
         (nfac && (!cam_vid0 || !pt_vid0 || !obs)))
         return fail(c, RDIS_HIP_EINVAL, "upload_ba: bad argument");
     if (nvars >= (1ll << 31) - 16 || nfac >= ((1ll << 31) - 16) / 12) return fail(c, RDIS_HIP_ERANGE, "upload_ba: too large for int32 device indices");
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     rdis_hip_problem* p = new (std::nothrow) rdis_hip_problem;
     if (!p) return fail(c, RDIS_HIP_ENOMEM, "upload_ba: host allocation");
     p->ctx = c; p->kind = KIND_BA; p->N = nvars; p->F = nfac;
@@ -528,7 +547,7 @@ extern "C" int rdis_hip_upload_nlp(rdis_hip_ctx* c, int64_t nvars, const double*
     if (nnz < 0 || (nnz && (!vid || !expo || !cons || !sine))) return fail(c, RDIS_HIP_EINVAL, "upload_nlp: bad CSR");
     if (nvars >= (1ll << 31) - 16 || nfac >= (1ll << 31) - 16 || nnz >= (1ll << 31) - 16)
         return fail(c, RDIS_HIP_ERANGE, "upload_nlp: too large for int32 device indices");
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     rdis_hip_problem* p = new (std::nothrow) rdis_hip_problem;
     if (!p) return fail(c, RDIS_HIP_ENOMEM, "upload_nlp: host allocation");
     p->ctx = c; p->kind = KIND_NLP; p->N = nvars; p->F = nfac; p->nnz = nnz;
@@ -575,7 +594,7 @@ extern "C" int rdis_hip_nlp_set_exponential(rdis_hip_problem* p, const uint8_t* 
 
 extern "C" void rdis_hip_free_problem(rdis_hip_problem* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    (void)make_current(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);
     delete p;
 }
@@ -1225,7 +1244,7 @@ static int plan_create_impl(rdis_hip_problem* p, bool transient, int64_t ncomp, 
         return fail(c, RDIS_HIP_EINVAL, "plan_create: bad CSR");
     if (nfree >= (1ll << 31) / 5 || nfac >= ((1ll << 31) - 16) / 12) return fail(c, RDIS_HIP_ERANGE, "plan_create: too large");
     if (int rc = refuse_exponential(p, nfac, fac_id, "plan_create")) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     int rc = ensure_problem_scratch(p);
     if (rc) return rc;
 
@@ -1434,7 +1453,7 @@ extern "C" int rdis_hip_plan_create(rdis_hip_problem* p, int64_t ncomp, const in
 
 extern "C" void rdis_hip_plan_destroy(rdis_hip_plan* L) {
     if (!L) return;
-    if (L->prob) (void)hipSetDevice(L->prob->ctx->device);
+    if (L->prob) (void)make_current(L->prob->ctx);
     if (L->prob && !L->transient) (void)hipStreamSynchronize(L->prob->ctx->stream);
     delete L;
 }
@@ -2597,7 +2616,7 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
     if (!L || maxiters <= 0) return RDIS_HIP_EINVAL;
     rdis_hip_problem* p = L->prob;
     rdis_hip_ctx* c = p->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     // (a plan made before rdis_hip_nlp_set_exponential marked one of its factors: the reference's gradient asserts the flag off,
     // src/NonlinearProductFactor.cpp:110 -- refused here as at plan_create, not solved with values and slopes of two functions)
     if (!p->h_useexp.empty())
@@ -2913,7 +2932,7 @@ extern "C" int rdis_hip_comm_unique_id(void* id128) {
 extern "C" int rdis_hip_comm_create(rdis_hip_ctx* c, int32_t world, int32_t rank, const void* id128, rdis_hip_comm** out) {
     if (!c || !out || world < 1 || rank < 0 || rank >= world || !id128) return RDIS_HIP_EINVAL;
     if (!rccl().ok) return fail(c, RDIS_HIP_EDEVICE, "comm_create: librccl.so could not be loaded");
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     std::unique_ptr<rdis_hip_comm> m(new (std::nothrow) rdis_hip_comm);
     if (!m) return fail(c, RDIS_HIP_ENOMEM, "comm_create: host allocation");
     ncclUniqueId id;
@@ -2932,7 +2951,7 @@ extern "C" int rdis_hip_comm_create_all(int32_t n, rdis_hip_ctx* const* ctxs, rd
     if (!rccl().ok) return fail(c0, RDIS_HIP_EDEVICE, "comm_create_all: librccl.so could not be loaded");
     std::vector<int> devs((size_t)n);
     for (int i = 0; i < n; ++i) {
-        devs[(size_t)i] = ctxs[i]->device;
+        devs[(size_t)i] = ctxs[i]->phys;
         for (int j = 0; j < i; ++j)
             if (devs[(size_t)j] == devs[(size_t)i]) return fail(c0, RDIS_HIP_EINVAL, "comm_create_all: a device is listed twice (one rank per GPU)");
     }
@@ -2950,7 +2969,7 @@ extern "C" int rdis_hip_comm_create_all(int32_t n, rdis_hip_ctx* const* ctxs, rd
 
 extern "C" void rdis_hip_comm_destroy(rdis_hip_comm* m) {
     if (!m) return;
-    if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+    if (m->ctx) { (void)make_current(m->ctx); (void)hipStreamSynchronize(m->ctx->stream); }
     if (m->comm && rccl().ok) rccl().CommDestroy(m->comm);
     if (m->scratch.p) (void)hipFree(m->scratch.p);
     m->scratch.p = nullptr;
@@ -2960,7 +2979,7 @@ extern "C" void rdis_hip_comm_destroy(rdis_hip_comm* m) {
 extern "C" int rdis_hip_allreduce_objective(rdis_hip_plan* L, rdis_hip_comm* m, double* sum_out) {
     if (!L) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = L->prob->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     if (m) {
         if (m->ctx != c) return fail(c, RDIS_HIP_EINVAL, "allreduce_objective: the communicator belongs to another context");
         // in place, on the stream the solve ran on: ordered behind objective_sum_kernel, ahead of whatever reads the sum
@@ -2985,13 +3004,13 @@ extern "C" int rdis_hip_allreduce_objective_all(int32_t n, rdis_hip_plan* const*
         ncclResult_t r = rccl().GroupStart();
         for (int i = 0; i < n && r == ncclSuccess; ++i) {
             rdis_hip_ctx* c = plans[i]->prob->ctx;
-            HIPCHK(c, hipSetDevice(c->device));
+            USE_DEVICE(c);
             r = rccl().AllReduce(plans[i]->objective.p, plans[i]->objective.p, 1, ncclDouble, ncclSum, comms[i]->comm, c->stream);
         }
         const ncclResult_t e = rccl().GroupEnd();
         if (r != ncclSuccess || e != ncclSuccess) return rccl_fail(c0, r != ncclSuccess ? r : e, "allreduce_objective_all");
         if (sum_out) {
-            HIPCHK(c0, hipSetDevice(c0->device));
+            USE_DEVICE(c0);
             HIPCHK(c0, hipMemcpyAsync(sum_out, plans[0]->objective.p, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
             HIPCHK(c0, hipStreamSynchronize(c0->stream));
         }
@@ -3003,7 +3022,7 @@ extern "C" int rdis_hip_allreduce_objective_all(int32_t n, rdis_hip_plan* const*
         for (int i = 0; i < n; ++i) {
             rdis_hip_ctx* c = plans[i]->prob->ctx;
             double v = 0.0;
-            HIPCHK(c, hipSetDevice(c->device));
+            USE_DEVICE(c);
             HIPCHK(c, hipMemcpyAsync(&v, plans[i]->objective.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             acc += v;
@@ -3016,7 +3035,7 @@ extern "C" int rdis_hip_allreduce_objective_all(int32_t n, rdis_hip_plan* const*
 extern "C" int rdis_hip_comm_allreduce_f64(rdis_hip_comm* m, double* inout, int32_t n, int32_t op) {
     if (!m || !inout || n < 1 || n > 4096 || (op != 0 && op != 1)) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = m->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     if (m->scratch.bytes < (size_t)n * sizeof(double)) { if (int rc = dalloc(c, m->scratch, 4096 * sizeof(double))) return rc; }
     HIPCHK(c, hipMemcpyAsync(m->scratch.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const ncclResult_t r = rccl().AllReduce(m->scratch.p, m->scratch.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, m->comm, c->stream);
@@ -3096,7 +3115,7 @@ extern "C" int rdis_hip_lm_optimize(rdis_hip_problem* p, int64_t nfree, const in
     rdis_hip_ctx* c = p->ctx;
     if (p->kind != KIND_BA) return fail(c, RDIS_HIP_EINVAL, "lm_optimize: bundle adjustment problems only");
     if (nfree <= 0 || nf <= 0 || !free_vid || !fac_id || maxiters < 1) return fail(c, RDIS_HIP_EINVAL, "lm_optimize: bad arguments");
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     // cameras occupy the ids below the first point block (BundleAdjustmentFunction.h:88-96)
     int minpt = INT32_MAX;
     for (int64_t f = 0; f < p->F; ++f) minpt = std::min(minpt, p->h_pt[(size_t)f]);
@@ -3140,7 +3159,7 @@ extern "C" int rdis_hip_components(rdis_hip_problem* p, const uint8_t* assigned,
     if (!p) return RDIS_HIP_EINVAL;
     rdis_hip_ctx* c = p->ctx;
     if (!assigned && p->N > 0) return fail(c, RDIS_HIP_EINVAL, "components: assigned is null");
-    HIPCHK(c, hipSetDevice(c->device));
+    USE_DEVICE(c);
     if (p->N >= INT32_MAX || p->F >= INT32_MAX) return fail(c, RDIS_HIP_ERANGE, "components: problem too large for 32-bit ids");
     int rc = dalloc(c, p->assigned, (size_t)std::max<int64_t>(p->N, 1));
     if (rc) return rc;

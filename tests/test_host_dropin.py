@@ -244,6 +244,26 @@ def test_batch_shared_out_over_distinct_gpus(harness, bal_path):
 
 
 @pytest.mark.gpu
+def test_several_device_paths_under_virtual_devices():
+    """The distinct-GPU test above needs two GPUs; a test box has one.  RDIS_HIP_VIRTUAL_DEVICES=3 makes the library offer three
+    devices that all stand on GPU 0, remember which of them the calling thread made current last, and refuse every HIP call issued
+    for a context while another context's device is current (rdis_hip.hip: HIPCHK) -- so an entry point that forgets to make its
+    device current fails here as it would on a real node.  The several-device tests of this file (the distinct-GPU one among them:
+    it no longer skips), the level driver over devices and the collective's several-context path run under it in a process of
+    their own (the switch is read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RDIS_HIP_VIRTUAL_DEVICES="3")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.abspath(__file__) + "::test_batch_shared_out_over_distinct_gpus",
+                          os.path.abspath(__file__) + "::test_batch_shared_out_over_several_devices",
+                          os.path.abspath(__file__) + "::test_level_driver_over_several_devices",
+                          os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_collective.py") + "::test_objective_of_several_contexts_of_one_process"],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and " skipped" not in out.stdout.splitlines()[-1], out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_level_driver_over_several_devices(harness, bal_path):
     """HipRDISLevelOptimizer on a function replicated over two contexts: every level's components go through
     optimizeBatch's sharing-out; the sweeps, the final value and every variable are those of the one-device run."""
