@@ -318,6 +318,29 @@ def test_device_arithmetic_end_value_on_full_ladybug():
     assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
 
 
+@pytest.mark.parametrize("key", ["ladybug_49_500_default_path", "ladybug_full_default_path"])
+def test_sum_topology_switch_reproduces_the_default_paths_fixture(key):
+    """The fourth named switch, RO_SUM_TOPOLOGY_COOPERATIVE: the device's cooperative solvers add their sums as trees (a wave of 64
+    as a balanced tree, the waves' sums taken l, l + 64, ... by lane l, the slope factor by factor, gg / dgg by owner lane, a
+    wave-owned variable's partials strided over a wave).  With it and the three arithmetic switches the oracle ends where
+    tests/golden/parity_end_values.json says -- on full ladybug 89607.17144518998 after 798 evaluations, which is the number the
+    benchmarked DEFAULT path prints (the GPU suite asserts device == this oracle live; bench.py compares its timed solve with the
+    fixture).  Helpers first: the balanced tree of 64 equals what the device's butterfly leaves in every lane (a + b == b + a), and
+    the topology's sums equal the plain ones to rounding."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        w = json.load(fh)[key]
+    pp = P.load_bal(ncams=w["ncams"], npts=w["npts"]).single_component()
+    o = O.OracleProblem.device_default(pp)
+    plain = O.OracleProblem(pp, emulate_stale_cache=False, derivative="adjoint_device", arithmetic="device")
+    assert abs(o.eval() - plain.eval()) <= 1e-12 * plain.eval() and o.eval() != plain.eval()
+    go, gp = o.gradient(), plain.gradient()
+    assert np.max(np.abs(go - gp)) <= 1e-12 * np.max(np.abs(gp))
+    r = o.cgd(x=pp.x0, maxiters=w["maxiters"])
+    assert (r.fret, r.delta, r.iters, r.status, r.nfeval, r.ngeval) == (w["fret"], w["delta"], w["iters"], w["status"], w["nfeval"], w["ngeval"])
+    assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
