@@ -103,9 +103,9 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
     extern __shared__ __align__(16) double smem[];
     double* const rec = smem;                                   // [ncam_cap][GRAD_REC]
     double* const acc = rec + (size_t)T.ncam_cap * GRAD_REC;    // [ncam_cap][9]
-    double* const crow = acc + (size_t)T.ncam_cap * 9;          // [GRAD_LANES][9]
-    double* const prow = crow + GRAD_LANES * 9;                 // [GRAD_LANES][3]
-    double* const red = prow + GRAD_LANES * 3;                  // [waves]
+    // the rows of a chunk: GRAD_ROW_BUFFERS staging areas taken in turn, each [GRAD_LANES][9] camera rows, [GRAD_LANES][3] point rows, [waves] values
+    double* const rows0 = acc + (size_t)T.ncam_cap * 9;
+    constexpr int ROWS = GRAD_LANES * 12 + 16;
     const int tid = (int)threadIdx.x;
     const int kc = tid % 9, kp = tid % 3;
     for (int tile = blockIdx.x; tile < T.ntiles; tile += gridDim.x) {
@@ -123,6 +123,11 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
         __syncthreads();
         for (int ch = ch_begin; ch < ch_end; ++ch) {
             const bool more = ch + 1 < ch_end;   // (uniform)
+            // With two staging areas a chunk needs ONE barrier: the lanes that still add chunk ch's rows have not passed the barrier
+            // of chunk ch + 1, so nobody is yet writing the rows of chunk ch + 2 into the area they read.
+            double* const crow = rows0 + (size_t)((ch - ch_begin) % GRAD_ROW_BUFFERS) * ROWS;
+            double* const prow = crow + GRAD_LANES * 9;
+            double* const red = prow + GRAD_LANES * 3;
             if (more) grad_stage1(T, ch + 1, tid, nxt);
             double E = 0.0;
             if (cur.cl != GRAD_NO_ENTRY) {
@@ -179,9 +184,10 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                     if (sg.x >= 0) g[sg.x + kp] = sum; else pstage[(size_t)(~sg.x) * 3 + kp] = sum;
                 }
             }
-            __syncthreads();
+            if constexpr (GRAD_ROW_BUFFERS < 2) __syncthreads();
             if (more) cur = nxt;
         }
+        if constexpr (GRAD_ROW_BUFFERS >= 2) __syncthreads();   // (the last chunk's sums are in the accumulators)
         for (int i = tid; i < nc * 9; i += GRAD_LANES) {
             const int c = i / 9, k = i - 9 * c;
             const int dest = T.tile_cam[c0 + c].y;

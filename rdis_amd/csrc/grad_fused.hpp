@@ -61,8 +61,14 @@ struct GradTables {
     const int* zvar;                          // [nz] variables no listed factor reads: their gradient entry is 0
 };
 
+#ifndef RDIS_GRAD_ROW_BUFFERS
+#define RDIS_GRAD_ROW_BUFFERS 1
+#endif
+// 2 (a measurement build, round 6): a chunk's rows alternate between two staging areas and a chunk needs ONE workgroup barrier --
+// but 98 KB of rows leave room for one workgroup per compute unit instead of two: 154 -> 256 us at 8e6 factors.  1 is the product.
+constexpr int GRAD_ROW_BUFFERS = RDIS_GRAD_ROW_BUFFERS;
 __host__ __device__ inline size_t grad_lds_bytes(int ncam_cap) {
-    return ((size_t)ncam_cap * (GRAD_REC + 9) + (size_t)GRAD_LANES * 12 + 16) * sizeof(double);
+    return ((size_t)ncam_cap * (GRAD_REC + 9) + (size_t)GRAD_ROW_BUFFERS * ((size_t)GRAD_LANES * 12 + 16)) * sizeof(double);
 }
 
 // launches (grad_fused.hip).  camrec: [camera blocks][GRAD_REC]; cstage / pstage: staging arrays of 9 / 3 doubles per slot;
