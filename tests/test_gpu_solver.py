@@ -832,6 +832,18 @@ def test_wide_group_with_local_camera_numbering(case, gctx):
         assert abs(r1.fret[0] - r2.fret[0]) <= 1e-6 * abs(r2.fret[0]), o
 
 
+@pytest.mark.parametrize("ncams", [24, 300])
+def test_wide_group_with_every_camera_constant(ncams, gctx):
+    """the points of a large problem as ONE component against constant cameras (a caller may pass that): the wide group without
+    gradient rounds or camera exchange (ROT_CAMFIX), with all cameras in the LDS (24) and with local camera numbering (300)"""
+    pp = P.make_synthetic_ba(1, ncams, 60000 if ncams > 100 else 30000, obs_per_pt=4)
+    fv = np.arange(9 * ncams, pp.nvars, dtype=np.int64)
+    fc = np.arange(pp.nfac, dtype=np.int64)
+    g, r, trv = solve(gctx, pp, maxiters=3, free_vid=fv, fac_id=fc, trace=1 << 13)
+    check_replay(pp, trv, r, 3, free_vid=fv, fac_id=fc, x=pp.x0[fv])
+    assert r.delta[0] < 0 and np.array_equal(g.get_x(fv), r.x) and np.array_equal(g.get_x(np.arange(9 * ncams)), pp.x0[:9 * ncams])
+
+
 def test_component_beyond_register_capacity_uses_streaming(gctx):
     # one synthetic component with more factors than the register-resident solver has lanes (65536)
     pp = P.make_synthetic_ba(1, 12, 20000, obs_per_pt=4)
