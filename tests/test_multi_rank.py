@@ -198,3 +198,68 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert line["components_all_ranks"] == 64 and sum(line["factors_per_rank"]) == line["factors_all_ranks"]
+
+
+_BOOTSTRAP = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import bench
+
+    class FakeComm:                       # what capi.Comm offers, without RCCL: the id must be the same 128 bytes on every rank
+        made = None
+        @staticmethod
+        def unique_id():
+            return bytes((i * 7 + 3) % 256 for i in range(128))
+        def __init__(self, ctx, world, rank, uid):      # (ncclCommInitRank is collective: nobody returns before everybody has come with the id)
+            assert len(uid) == 128
+            FakeComm.made = (world, rank, uid)
+            import time
+            open(os.path.join(os.environ["MARKS"], "rank%d" % rank), "w").close()
+            t0 = time.time()
+            while len(os.listdir(os.environ["MARKS"])) < world:
+                assert time.time() - t0 < 60
+                time.sleep(0.01)
+        def barrier(self):
+            pass
+        def allreduce(self, values, op="sum"):
+            return list(values)
+        def close(self):
+            pass
+
+    class FakeCapi:
+        Comm = FakeComm
+
+    class FakeCtx:
+        def synchronize(self):
+            pass
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    c = bench.RcclCollective(FakeCapi, FakeCtx(), rank, world)
+    c.barrier_sync()
+    print(json.dumps({{"rank": rank, "world": FakeComm.made[0], "uid_ok": FakeComm.made[2] == FakeComm.unique_id(), "name": c.name}}))
+    c.close()
+""")
+
+
+def test_bench_collective_bootstrap_without_torch(tmp_path):
+    """bench.py's ranks share RCCL's 128-byte communicator id through a file named after the launcher's pid and port (no torch in
+    the process): three ranks started out of order as children of one process find the same id, and rank 0 removes the file"""
+    script = tmp_path / "boot.py"
+    script.write_text(_BOOTSTRAP.format(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    marks = tmp_path / "marks"
+    marks.mkdir()
+    for rank in (2, 1, 0):            # (rank 0 last: the others wait for its file)
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MARKS=str(marks))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    import json
+    recs = sorted((json.loads(o[0].strip().splitlines()[-1]) for o in outs), key=lambda r: r["rank"])
+    assert [r["rank"] for r in recs] == [0, 1, 2] and all(r["world"] == 3 and r["uid_ok"] for r in recs)
+    assert recs[0]["name"].startswith("rccl through the C ABI")
+    key = "rdis_bench_id_%d_%d" % (port, os.getpid())
+    assert not os.path.exists(os.path.join("/dev/shm", key)) and not os.path.exists(os.path.join("/tmp", key))
