@@ -66,6 +66,29 @@ def build(force: bool = False) -> None:
 
 
 _lib = None
+_FH = os.path.join(os.path.dirname(_HERE), "tests", "cpp", "libfactors_host.so")
+_fh = None
+
+
+class _FactorArith(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("eval_grad", C.c_void_p), ("value_slope", C.c_void_p)]
+
+
+def factors_host():
+    """tests/cpp/factors_host.hip -- rdis_amd/csrc/factors.hpp compiled for the HOST with the device's default contraction (the same
+    front end fuses a * b + c within an expression for either target) -- as an ro_factor_arith for ro_set_factor_arithmetic.
+    Built on demand (hipcc compiles host code without a GPU)."""
+    global _fh
+    if _fh is None:
+        src = os.path.join(os.path.dirname(_FH), "factors_host.hip")
+        hdr = os.path.join(os.path.dirname(_HERE), "rdis_amd", "csrc", "factors.hpp")
+        if not os.path.exists(_FH) or os.path.getmtime(_FH) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-mfma", "-ffp-contract=on", "-fPIC", "-shared",
+                                   "-o", _FH, src], stderr=subprocess.DEVNULL)
+        L = C.CDLL(_FH)
+        arith = _FactorArith(C.cast(L.fh_value, C.c_void_p), C.cast(L.fh_eval_grad, C.c_void_p), C.cast(L.fh_value_slope, C.c_void_p))
+        _fh = (L, arith)
+    return _fh
 
 
 def lib() -> C.CDLL:
@@ -82,6 +105,8 @@ def lib() -> C.CDLL:
         L.ro_set_ba_derivative.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_sum_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        L.ro_set_factor_arithmetic.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
         L.ro_sincos_angle.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -170,6 +195,26 @@ class OracleProblem:
         component (free_vid, fac) -- None: all variables, all factors"""
         o = cls(pp, emulate_stale_cache=False, derivative="adjoint_device", arithmetic="device")
         o.set_cooperative_topology(free_vid, fac, lanes_per_workgroup)
+        return o
+
+    @classmethod
+    def device_lds_default(cls, pp, free_vid=None, fac=None, threads: int = 0):
+        """the CPU side of the == test of the DEFAULT LDS-resident path (BASELINE configs 3 and 5-S): the device's own factor
+        arithmetic with its fused multiply-adds (factors.hpp compiled for the host: factors_host()), no stale cache, and that
+        solver's sum trees for a workgroup of `threads` lanes (0: the dispatcher's rule for a launch whose largest component has
+        this many factors -- 64 up to 64 factors, 128 up to 128, 256 up to 256)"""
+        o = cls(pp, emulate_stale_cache=False)
+        fv = np.arange(pp.nvars, dtype=np.int64) if free_vid is None else np.asarray(free_vid, dtype=np.int64)
+        fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
+        if threads == 0:
+            threads = 64 if len(fc) <= 64 else 128 if len(fc) <= 128 else 256
+        cams = np.unique(pp.cam_vid0[fc])
+        pts = np.unique(pp.pt_vid0[fc])
+        slots = np.concatenate([(cams[:, None] + np.arange(9)[None, :]).ravel(), (pts[:, None] + np.arange(3)[None, :]).ravel()]).astype(np.int64)
+        o._fh = factors_host()
+        lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
+        o._slots = np.ascontiguousarray(slots)
+        lib().ro_set_lds_topology(o.h, int(threads), o._slots.shape[0], o._slots.ctypes.data_as(C.c_void_p))
         return o
 
     def set_cooperative_topology(self, free_vid=None, fac=None, lanes_per_workgroup: int = 128) -> None:

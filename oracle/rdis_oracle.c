@@ -401,6 +401,9 @@ struct ro_problem {
     int topo;         /* RO_SUM_TOPOLOGY_*: 0 = every sum in the reference's order; 1 = the cooperative device solver's trees */
     int64_t nwave_owned, *wave_vid;   /* ... its wave-owned variables (ids), in wave order */
     int64_t *wave_of; /* [nvars] wave that owns the variable, or -1 */
+    const ro_factor_arith *ext;       /* factor arithmetic supplied from outside (ro_set_factor_arithmetic), or NULL */
+    int lds_nt;                       /* RO_SUM_TOPOLOGY_LDS: lanes of the workgroup */
+    int64_t lds_nslots, *lds_slot_vid;/* ... its slots in order: the variable behind each (cameras first, then points) */
     int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
     double *fcache;
     uint8_t *fdirty;
@@ -491,7 +494,7 @@ void ro_destroy(ro_problem *p)
     free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
     free(p->sine); free(p->useexp); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
-    free(p->wave_vid); free(p->wave_of);
+    free(p->wave_vid); free(p->wave_of); free(p->lds_slot_vid);
     free(p);
 }
 
@@ -512,6 +515,12 @@ void ro_set_ba_derivative(ro_problem *p, int which)
     p->ba_deriv = which;
 }
 
+void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext)
+{
+    p->ext = ext;
+    if (p->fdirty) memset(p->fdirty, 1, (size_t)p->nfac);
+}
+
 void ro_set_arithmetic(ro_problem *p, int flags)
 {
     p->arith = flags;
@@ -520,6 +529,7 @@ void ro_set_arithmetic(ro_problem *p, int flags)
 
 static double ba_grad(const ro_problem *p, const double x[12], double ox, double oy, double g[12])
 {
+    if (p->ext) return p->ext->eval_grad(x, ox, oy, g);
     if (p->ba_deriv == RO_BA_DERIV_ADJOINT_DEVICE) return ba_grad_adjoint_device(x, ox, oy, g, p->arith);
     return p->ba_deriv == RO_BA_DERIV_ADJOINT ? ba_grad_adjoint(x, ox, oy, g, p->arith)
                                               : ba_grad_refchain(x, ox, oy, g, p->arith);
@@ -584,6 +594,48 @@ static double strided_tree_sum(const double *values, int64_t count)
         lane[l] = s;
     }
     return tree64(lane);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RO_SUM_TOPOLOGY_LDS: the sums of the device's LDS-resident batch solver (rdis_amd/csrc/solver_lds.hpp: one workgroup of nt
+ * lanes per component -- BASELINE configs 3 and 5-S), restated entry for entry:
+ *   lanes    lane l adds the terms l, l + nt, l + 2 nt, ... one after the other from 0.0 (eval_partial over the listed factors,
+ *            cg_reduce over the component's slots);
+ *   waves    64 lanes as a balanced tree (wave_sum); the waves' sums as a balanced tree over 4 entries (up to four waves) or 16
+ *            (more), zero-padded (combine_waves);
+ *   gradient a camera variable: the listed factors of its camera block, in listed order, padded to whole waves of 64 -- each
+ *            wave's 64 partials as a balanced tree, the waves' sums one after the other (gradient_to_xi: gperm, CG); a point
+ *            variable: in factor-list order like the reference.
+ * ------------------------------------------------------------------------------------------------------------------- */
+static double lds_tree_sum(const double *terms, int64_t count, int nt)
+{
+    const int nw = nt / 64;
+    double wsum[16];
+    for (int w = 0; w < 16; ++w) wsum[w] = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        double lane[64];
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int64_t j = 64 * w + l; j < count; j += nt) acc = acc + terms[j];
+            lane[l] = acc;
+        }
+        wsum[w] = tree64(lane);
+    }
+    if (nw == 1) return wsum[0];
+    if (nw <= 4) return (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    for (int w = 1; w < 16; w *= 2)
+        for (int i = 0; i < 16; i += 2 * w) wsum[i] = wsum[i] + wsum[i + w];
+    return wsum[0];
+}
+
+void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid)
+{
+    ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
+    free(p->lds_slot_vid);
+    p->topo = RO_SUM_TOPOLOGY_LDS;
+    p->lds_nt = nt;
+    p->lds_nslots = nslots;
+    p->lds_slot_vid = dup_mem(slot_vid, sizeof(int64_t) * (size_t)nslots);
 }
 
 void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid)
@@ -759,6 +811,7 @@ static double factor_value_nocache(const ro_problem *p, int64_t f)
         double vals[12];
         ba_fwd t;
         gather_ba(p, f, vals);
+        if (p->ext) return p->ext->value(vals, p->obs[2 * f], p->obs[2 * f + 1]);
         return ba_forward(vals, p->obs[2 * f], p->obs[2 * f + 1], &t, p->arith);
     }
     return nlp_eval(p, f);
@@ -795,10 +848,10 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
      * objective sum -- 1e-12 relative in list order over 3e4 terms, 1e-15 as a tree, which is what a device computes --
      * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
     if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
-    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE) {
+    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS) {
         double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
         for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
-        const double r = coop_tree_sum(vals, nf);
+        const double r = p->topo == RO_SUM_TOPOLOGY_LDS ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
         free(vals);
         return r;
     }
@@ -882,6 +935,39 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
                 if (!seen[vb[k]]) { g[vb[k]] = xb[k]; seen[vb[k]] = 1; }
                 else g[vb[k]] = g[vb[k]] + xb[k];
             }
+        }
+        if (p->topo == RO_SUM_TOPOLOGY_LDS && p->kind == RO_KIND_BA) {
+            /* camera variables again, the LDS solver's way: per camera block its listed factors in listed order, whole waves of 64
+             * (the last one padded with zeros) as balanced trees, the waves' sums one after the other */
+            int64_t *cnt = calloc((size_t)p->nvars + 1, sizeof(int64_t));
+            for (int64_t i = 0; i < nf; ++i) cnt[p->cam[fac ? fac[i] : i]]++;
+            for (int64_t cb = 0; cb < p->nvars; ++cb) {
+                if (!cnt[cb]) continue;
+                const int64_t m = cnt[cb], nch = (m + 63) / 64;
+                double *part = calloc((size_t)(64 * nch) * 9, sizeof(double));
+                int64_t at = 0;
+                for (int64_t i = 0; i < nf; ++i) {
+                    const int64_t f = fac ? fac[i] : i;
+                    if (p->cam[f] != cb) continue;
+                    double x[12], gq[12];
+                    gather_ba(p, f, x);
+                    ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq);
+                    for (int k = 0; k < 9; ++k) part[(size_t)(9 * at + k)] = gq[k];
+                    ++at;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    double sm = 0.0;
+                    for (int64_t ch = 0; ch < nch; ++ch) {
+                        double v[64];
+                        for (int l = 0; l < 64; ++l) v[l] = part[(size_t)(9 * (64 * ch + l) + k)];
+                        const double t = tree64(v);
+                        sm = ch == 0 ? t : sm + t;
+                    }
+                    g[cb + k] = sm;
+                }
+                free(part);
+            }
+            free(cnt);
         }
         if (run) {
             for (int64_t w = 0; w < p->nwave_owned; ++w) {
@@ -1265,6 +1351,64 @@ static double sub_slope_topology(void *ctx, const double *xi)
     return s;
 }
 
+/* RO_SUM_TOPOLOGY_LDS: a trial's slope in the LDS-resident solver -- per factor the forward-mode slope along the direction (the
+ * external arithmetic's value_slope: factors.hpp ba_slope_dir), the factors' terms added like the values (lds_tree_sum) */
+static double sub_slope_lds(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
+    double *terms = malloc(sizeof(double) * (size_t)(S->nf + 1));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    for (int64_t i = 0; i < S->nf; ++i) {
+        const int64_t f = S->fac ? S->fac[i] : i;
+        double x[12], d[12], sl = 0.0;
+        gather_ba(p, f, x);
+        for (int k = 0; k < 12; ++k) d[k] = dir[fac_var(p, f, k)];
+        (void)p->ext->value_slope(x, d, p->obs[2 * f], p->obs[2 * f + 1], 0, &sl);
+        terms[i] = sl;
+    }
+    const double s = lds_tree_sum(terms, S->nf, p->lds_nt);
+    free(terms); free(dir);
+    return s;
+}
+
+/* ... and gg, dgg: lane l adds the terms of the free slots l, l + nt, ... (slot order: camera blocks, then point blocks) */
+static void sub_cg_sums_lds(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    int64_t *li = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+    for (int64_t v = 0; v < p->nvars; ++v) li[v] = -1;
+    for (int64_t i = 0; i < n; ++i) li[S->free_vid[i]] = i;
+    /* (a slot that is not free adds nothing and is skipped by the device's loop: the lane's chain simply does not see it) */
+    const int nt = p->lds_nt, nw = nt / 64;
+    double wa[16], wb[16];
+    for (int w = 0; w < 16; ++w) wa[w] = wb[w] = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        double la[64], lb[64];
+        for (int l = 0; l < 64; ++l) {
+            double a = 0.0, b = 0.0;
+            for (int64_t sidx = 64 * w + l; sidx < p->lds_nslots; sidx += nt) {
+                const int64_t i = li[p->lds_slot_vid[sidx]];
+                if (i < 0) continue;
+                a = a + g[i] * g[i];
+                b = b + (xi[i] + g[i]) * xi[i];
+            }
+            la[l] = a; lb[l] = b;
+        }
+        wa[w] = tree64(la); wb[w] = tree64(lb);
+    }
+    if (nw == 1) { *gg = wa[0]; *dgg = wb[0]; }
+    else if (nw <= 4) { *gg = (wa[0] + wa[1]) + (wa[2] + wa[3]); *dgg = (wb[0] + wb[1]) + (wb[2] + wb[3]); }
+    else {
+        for (int w = 1; w < 16; w *= 2)
+            for (int i = 0; i < 16; i += 2 * w) { wa[i] = wa[i] + wa[i + w]; wb[i] = wb[i] + wb[i + w]; }
+        *gg = wa[0]; *dgg = wb[0];
+    }
+    free(li);
+}
+
 /* ... and gg, dgg: lane i carries variable i's terms unless a wave owns it, wave w's first lane those of its variable */
 static void sub_cg_sums_topology(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
 {
@@ -1327,6 +1471,13 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
         memset(&hk, 0, sizeof hk);
         hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_topology;
         g_slope_topology = sub_slope_topology;
+        reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+        g_slope_topology = 0;
+    } else if (p->topo == RO_SUM_TOPOLOGY_LDS && p->kind == RO_KIND_BA && p->ext) {
+        ro_hooks hk;
+        memset(&hk, 0, sizeof hk);
+        hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_lds;
+        g_slope_topology = sub_slope_lds;
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
         g_slope_topology = 0;
     } else {

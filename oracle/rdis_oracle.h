@@ -115,7 +115,24 @@ void ro_set_sum_order(ro_problem *p, int which);
  * returns, bit for bit (tests/test_gpu_parity.py).  Bundle adjustment only. */
 #define RO_SUM_TOPOLOGY_REFERENCE 0
 #define RO_SUM_TOPOLOGY_COOPERATIVE 1
+#define RO_SUM_TOPOLOGY_LDS 2
 void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid);
+/* RO_SUM_TOPOLOGY_LDS: the trees of the device's LDS-resident batch solver (solver_lds.hpp: a workgroup of nt lanes a component;
+ * BASELINE configs 3 and 5-S), restated entry for entry: lane l adds the terms l, l + nt, ... in order, a wave's 64 lanes as a
+ * balanced tree, the waves' sums as a balanced tree; a camera variable's partials per wave of 64 listed factors of its camera as a
+ * tree, the waves' sums in order.  slot_vid: the component's slots in the solver's order (camera blocks ascending, nine each, then
+ * point blocks ascending, three each).  That solver's DEFAULT arithmetic contracts a * b + c into fused multiply-adds where the
+ * source has them in one expression -- which no C restatement compiled by another compiler reproduces; ro_set_factor_arithmetic
+ * plugs in the factor arithmetic from outside: tests/cpp/factors_host.hip is rdis_amd/csrc/factors.hpp itself compiled for the
+ * HOST by the same front end (per factor == the device, tests/test_gpu_parity.py).  With both, ro_cgd_optimize returns what the
+ * default LDS-resident path returns, bit for bit. */
+typedef struct {
+    double (*value)(const double *x12, double ox, double oy);
+    double (*eval_grad)(const double *x12, double ox, double oy, double *g12);
+    double (*value_slope)(const double *x12, const double *d12, double ox, double oy, int camfix, double *slope);
+} ro_factor_arith;
+void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext);   /* ext must outlive the problem's use; NULL: built in */
+void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid);
 /* process-wide experiment flags; never used to pin anything.  bit 0: reciprocals in place of the projection's divisions, the
  * device's form.  bit 1 (round 5): the slope of a line-search trial added factor by factor, sum_f (sum_k partial_fk xi_k) -- the
  * association the device's fused trials use -- in place of the reference's gradient times direction (Df1dim::df,

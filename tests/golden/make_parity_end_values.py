@@ -37,6 +37,21 @@ for key, (nc, npt) in (("ladybug_full", (0, 0)), ("ladybug_49_500", (49, 500))):
     out[f"{key}_default_path"] = {
         "ncams": nc, "npts": npt, "maxiters": 25, "emulate_stale_cache": False, "sum_topology": "cooperative", "fret": r.fret, "delta": r.delta,
         "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:3]), "x_last": float(r.x[-1])}
+# ... and the DEFAULT LDS-resident path (configs 3 and 5-S): the device's own fused factor arithmetic (factors.hpp compiled for the
+# host, tests/cpp/factors_host.hip) and that solver's sum trees (RO_SUM_TOPOLOGY_LDS)
+pp = P.load_bal(ncams=5, npts=30).single_component()
+r = O.OracleProblem.device_lds_default(pp).cgd(x=pp.x0, maxiters=25)
+out["ladybug_5_30_default_path"] = {
+    "ncams": 5, "npts": 30, "maxiters": 25, "emulate_stale_cache": False, "sum_topology": "lds, 128 lanes", "fret": r.fret, "delta": r.delta,
+    "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:3]), "x_last": float(r.x[-1])}
+pp = P.make_synthetic_ba(1000, 3, 40)
+frets, nfe = [], []
+for c in range(pp.ncomp):
+    fv, fc = pp.component(c)
+    rc = O.OracleProblem.device_lds_default(pp, free_vid=fv, fac=fc).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25)
+    frets.append(rc.fret); nfe.append(rc.nfeval)
+out["synthetic_S_default_path"] = {"components": 1000, "ncams": 3, "npts": 40, "maxiters": 25, "sum_topology": "lds, 128 lanes",
+                                   "fret": frets, "nfeval": nfe}
 with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json"), "w") as fh:
     json.dump(out, fh, indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps({k: (v if k != "synthetic_S_default_path" else "1000 components") for k, v in out.items()}, indent=1))

@@ -213,3 +213,61 @@ def test_default_cooperative_path_on_other_components_and_starts(gctx):
                 assert plan.info("components_cooperative") == 1 and plan.info("pipelined") == (0 if plain else 1)
                 assert r.fret[0] == want.fret and r.x.tobytes() == want.x.tobytes(), (npts, seed, opts, r.fret[0], want.fret)
                 assert (int(r.iters[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.nfeval, want.ngeval)
+
+
+# ---- the DEFAULT LDS-resident path (configs 3 and 5-S): fused multiply-adds and all ------------------------------------------------
+
+def test_fused_factor_arithmetic_is_reproduced_by_the_host_compile(gctx):
+    """The batch solvers' default arithmetic contracts a * b + c where the source has it in one expression.  factors.hpp compiled
+    for the HOST by the same front end (tests/cpp/factors_host.hip, -mfma -ffp-contract=on) gives the device's bits: every factor
+    of ladybug, value and twelve partials, at three points."""
+    import ctypes as C
+    L, _ = O.factors_host()
+    pp = P.load_bal().single_component()
+    g = capi.Problem(gctx, pp)
+    rng = np.random.default_rng(1)
+    for k in range(3):
+        x = pp.x0 if k == 0 else pp.x0 * (1 + 1e-3 * rng.standard_normal(pp.nvars))
+        g.set_x(x)
+        fd, gd = g.eval_each(), g.grad_each_ba()
+        x12 = np.ascontiguousarray(np.concatenate([x[pp.cam_vid0[:, None] + np.arange(9)], x[pp.pt_vid0[:, None] + np.arange(3)]], axis=1))
+        f, g12 = np.empty(pp.nfac), np.empty((pp.nfac, 12))
+        v = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.fh_eval_grad_each(C.c_longlong(pp.nfac), v(x12), v(np.ascontiguousarray(pp.obs)), v(f), v(g12))
+        assert f.tobytes() == fd.tobytes() and g12.tobytes() == gd.tobytes(), k
+
+
+def test_default_lds_path_equals_the_oracle_on_config_3(gctx):
+    """BASELINE config 3 as bench.py and smoke() run it -- no option set: the LDS-resident solver, fused multiply-adds, forward-mode
+    slope, sums as trees -- against the oracle with the device's own factor arithmetic plugged in (ro_set_factor_arithmetic:
+    factors.hpp compiled for the host) and RO_SUM_TOPOLOGY_LDS (that solver's trees restated entry for entry): fret, delta, x,
+    iterations, status, call counts == after 25 iterations from x0 and from four moved starts.  25.168503286225235 after 540
+    evaluations -- the number smoke() and the bench line's configs block print -- is a CPU run's number."""
+    base = P.load_bal(ncams=5, npts=30).single_component()
+    for seed in (None, 0, 1, 2, 3):
+        pp = P.load_bal(ncams=5, npts=30).single_component()
+        x = pp.x0 if seed is None else pp.x0 * (1 + 1e-12 * np.random.default_rng(seed).standard_normal(pp.nvars))
+        want = O.OracleProblem.device_lds_default(pp).cgd(x=x, maxiters=25)
+        plan, r = _default_path(gctx, pp, 25, x=x)
+        assert plan.info("components_lds") == 1
+        assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (seed, r.fret[0], want.fret)
+        assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+    assert base.nfac == 121
+
+
+def test_default_lds_path_equals_the_oracle_on_config_5s(gctx):
+    """... and BASELINE config 5-S: 1000 components x (3 cameras, 40 points, 120 observations) in one launch, every 50th component
+    against its own oracle run"""
+    pp = P.make_synthetic_ba(1000, 3, 40)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_lds") == 1000
+    fp, fv, cp, ci = pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id
+    for c in range(0, 1000, 50):
+        o = O.OracleProblem.device_lds_default(pp, free_vid=fv[fp[c]:fp[c + 1]], fac=ci[cp[c]:cp[c + 1]])
+        want = o.cgd(free_vid=fv[fp[c]:fp[c + 1]], fac=ci[cp[c]:cp[c + 1]], x=pp.x0[fv[fp[c]:fp[c + 1]]], maxiters=25)
+        assert r.fret[c] == want.fret and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
+        assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c

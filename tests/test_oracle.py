@@ -341,6 +341,37 @@ def test_sum_topology_switch_reproduces_the_default_paths_fixture(key):
     assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
 
 
+def test_lds_topology_with_the_host_compiled_arithmetic_reproduces_its_fixture():
+    """The DEFAULT batch path (configs 3, 5-S) contracts a * b + c into fused multiply-adds; a C restatement compiled by another
+    compiler cannot promise those bits, so the oracle takes the factor arithmetic from outside (ro_set_factor_arithmetic):
+    rdis_amd/csrc/factors.hpp itself compiled for the HOST by the same front end (tests/cpp/factors_host.hip; per factor == the
+    device under -m gpu).  With it and RO_SUM_TOPOLOGY_LDS (the LDS-resident solver's trees) the oracle ends where
+    tests/golden/parity_end_values.json says: 25.168503286225235 after 540 evaluations on ladybug 5 / 30 -- what smoke() and the
+    bench line's configs block print --, and the first components of the synthetic decomposition.  The plugged-in arithmetic
+    agrees with the built-in one to rounding (the same model, fused)."""
+    import json
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc to compile factors.hpp for the host")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        fx = json.load(fh)
+    w = fx["ladybug_5_30_default_path"]
+    pp = P.load_bal(ncams=5, npts=30).single_component()
+    o = O.OracleProblem.device_lds_default(pp)
+    ref = O.OracleProblem(pp, emulate_stale_cache=False)
+    fe, fr = o.eval_each(), ref.eval_each()
+    assert np.max(np.abs(fe - fr) / np.abs(fr)) < 1e-9 and np.any(fe != fr)
+    r = o.cgd(x=pp.x0, maxiters=25)
+    assert (r.fret, r.delta, r.iters, r.status, r.nfeval, r.ngeval) == (w["fret"], w["delta"], w["iters"], w["status"], w["nfeval"], w["ngeval"])
+    assert list(r.x[:3]) == w["x_0_2"] and r.x[-1] == w["x_last"]
+    ws = fx["synthetic_S_default_path"]
+    ps = P.make_synthetic_ba(8, 3, 40)
+    for c in range(8):
+        fv, fc = ps.component(c)
+        rc = O.OracleProblem.device_lds_default(ps, free_vid=fv, fac=fc).cgd(free_vid=fv, fac=fc, x=ps.x0[fv], maxiters=25)
+        assert rc.fret == ws["fret"][c] and rc.nfeval == ws["nfeval"][c], c
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
