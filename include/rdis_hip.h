@@ -23,6 +23,11 @@
  *  - one context per GPU; calls on a context are serialised by the caller (the
  *    reference path is single-threaded and not re-entrant either).
  *  - fp64 throughout ("Numeric = double", src/common.h:25).
+ *  - several contexts may be driven from one thread (one per GPU: rdis::OptimizableFunction::setDevices): every entry point
+ *    makes its context's device current first.  Environment RDIS_HIP_VIRTUAL_DEVICES=n (a test aid for boxes with one GPU):
+ *    rdis_hip_device_count() reports n devices that all stand on GPU 0, and every HIP call the library issues for a context
+ *    while another context's device is the current one fails with RDIS_HIP_EDEVICE -- what a forgotten "make current" would
+ *    do on a real node.
  */
 #ifndef RDIS_HIP_H_
 #define RDIS_HIP_H_

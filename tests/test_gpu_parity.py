@@ -271,3 +271,25 @@ def test_default_lds_path_equals_the_oracle_on_config_5s(gctx):
         want = o.cgd(free_vid=fv[fp[c]:fp[c + 1]], fac=ci[cp[c]:cp[c + 1]], x=pp.x0[fv[fp[c]:fp[c + 1]]], maxiters=25)
         assert r.fret[c] == want.fret and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
         assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
+
+
+def test_default_cooperative_groups_side_by_side_equal_the_oracle(gctx):
+    """ladybug with the points held constant: 49 camera components (361 .. 906 factors, nine free variables each) in one plan --
+    by default each gets a cooperative group (five to eight workgroups, every one of its nine variables wave-owned) and the groups
+    run side by side in one launch.  Every seventh component == its own oracle run with the four switches (constants enter the
+    factors; their direction entries are zero)."""
+    pp = P.load_bal()
+    cams, _ = P.ba_alternation_plans(pp)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g, *cams)
+    plan.set_start(pp.x0[cams[1]])
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_cooperative") == 49
+    fp, fv, cp, ci = cams
+    lanes = 128 if plan.info("pipelined") else 256
+    for c in range(0, 49, 7):
+        v, f = fv[fp[c]:fp[c + 1]], ci[cp[c]:cp[c + 1]]
+        want = O.OracleProblem.device_default(pp, free_vid=v, fac=f, lanes_per_workgroup=lanes).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
+        assert r.fret[c] == want.fret and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
+        assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
