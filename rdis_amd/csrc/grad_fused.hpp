@@ -29,7 +29,10 @@
 
 namespace rdis_hip {
 
-constexpr int GRAD_LANES = 512;        // entries of a chunk = lanes of a workgroup (eight waves: two per SIMD, two workgroups per compute unit)
+#ifndef RDIS_GRAD_LANES
+#define RDIS_GRAD_LANES 512
+#endif
+constexpr int GRAD_LANES = RDIS_GRAD_LANES;   // entries of a chunk = lanes of a workgroup (eight waves: two per SIMD, two workgroups per compute unit)
 constexpr int GRAD_REC = 14;           // doubles of a camera's record: [v0 v1 v2 theta 1/theta sin cos | t0 t1 t2 f k1 k2 | pad] -- seven
                                        // 16-byte units, an odd number: lanes that read different cameras stand on different LDS banks
 constexpr int GRAD_MAX_TILE_CHUNKS = 8;
