@@ -150,7 +150,7 @@ struct CoopEnv {
                 {
                     double acc = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: oracle/rdis_oracle.c restates it)
+                    for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: the tests' CPU restatement mirrors exactly this)
                     sj = acc;
                 }
             } else {
@@ -271,7 +271,7 @@ struct CoopEnv {
                 r[2 * c] = ba_eval_grad(v, ox, oy, g);
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: oracle/rdis_oracle.c restates it)
+                for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: the tests' CPU restatement mirrors exactly this)
                 r[2 * c + 1] = acc;
             }
         }

@@ -347,7 +347,7 @@ struct PipeEnv {
                 fj = ba_eval_grad(v, ox, oy, g);
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: oracle/rdis_oracle.c restates it)
+                for (int k = 0; k < 12; ++k) acc = __builtin_fma(g[k], dirv[k], acc);   // (fused on purpose, not by the compiler's leave: the tests' CPU restatement mirrors exactly this)
                 sj = acc;
             } else {
                 fj = ba_eval(v, ox, oy);
