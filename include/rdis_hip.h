@@ -123,7 +123,8 @@ int rdis_hip_get_x(rdis_hip_problem *p, int64_t n, const int64_t *vid, double *o
  *             a point variable's contributions are added in factor-list order like the reference's merge, a camera
  *             variable's in factor-list order within a tile of the list and then tile by tile -- a fixed order, the
  *             same bits run to run; the value is bit for bit what eval returns for the same list.  The tables of
- *             a list are built at its first use and kept (the last four lists; all factors: fac == NULL).
+ *             a list are built at its first use and kept (up to 64 lists within 1 GiB of device memory, least recently used
+ *             first to go; all factors: fac == NULL; an explicit list of at most 512 entries needs no tables and builds none).
  *             Nonlinear-product functions: per-factor partials, then each g[v] in factor-list order.
  * eval_grad_device : the same, results left on the device: *f_dev points to one double, *g_dev to N doubles,
  *             valid until the next evaluation call on this problem; asynchronous on the context's stream
