@@ -141,6 +141,26 @@ def strong_scaling_shard(rank: int, world: int, components: int = None):
     return pp, (free_ptr, free_vid, fac_ptr, fac_id), mine, loads
 
 
+import contextlib
+import ctypes
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL announces its version on the process's STDOUT when it is first used: the contract's one JSON line must stay the only
+    thing there, so file descriptor 1 points at stderr meanwhile"""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)   # (the library writes through C's buffered stdout: out with it while 1 is still stderr)
+        os.dup2(keep, 1)
+        os.close(keep)
+
+
 class RcclCollective:
     """The ranks' one exchange through the library's own C ABI (include/rdis_hip.h: rdis_hip_comm_*, rdis_hip_allreduce_objective
     -- ncclAllReduce over RCCL / xGMI on the solver's stream): no torch in the process.  The 128-byte communicator id travels from
@@ -152,7 +172,8 @@ class RcclCollective:
         key = "rdis_bench_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
         path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
         if rank == 0:
-            uid = capi.Comm.unique_id()
+            with _stdout_to_stderr():
+                uid = capi.Comm.unique_id()
             with open(path + ".tmp", "wb") as fh:
                 fh.write(uid)
             os.replace(path + ".tmp", path)
@@ -170,8 +191,9 @@ class RcclCollective:
                 if time.time() - t0 > 300:
                     raise RuntimeError("no communicator id from rank 0 at " + path)
                 time.sleep(0.01)
-        self.comm = capi.Comm(ctx, world, rank, uid)
-        self.comm.barrier()
+        with _stdout_to_stderr():
+            self.comm = capi.Comm(ctx, world, rank, uid)
+            self.comm.barrier()
         if rank == 0:
             try:
                 os.remove(path)
@@ -317,7 +339,8 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
     # launch and its place on the solver's stream are in the step; what a real job adds is the wire)
     comm = None
     try:
-        comm = capi.Comm(prob.ctx, 1, 0, capi.Comm.unique_id())
+        with _stdout_to_stderr():
+            comm = capi.Comm(prob.ctx, 1, 0, capi.Comm.unique_id())
     except Exception:
         comm = None
     for world in (2, 4, 8):

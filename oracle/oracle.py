@@ -74,6 +74,10 @@ class _FactorArith(C.Structure):
     _fields_ = [("value", C.c_void_p), ("eval_grad", C.c_void_p), ("value_slope", C.c_void_p)]
 
 
+class _PtmArith(C.Structure):
+    _fields_ = [("camera_trial", C.c_void_p), ("camera_trial_dir", C.c_void_p), ("trial", C.c_void_p)]
+
+
 def factors_host():
     """tests/cpp/factors_host.hip -- rdis_amd/csrc/factors.hpp compiled for the HOST with the device's default contraction (the same
     front end fuses a * b + c within an expression for either target) -- as an ro_factor_arith for ro_set_factor_arithmetic.
@@ -87,8 +91,43 @@ def factors_host():
                                    "-o", _FH, src], stderr=subprocess.DEVNULL)
         L = C.CDLL(_FH)
         arith = _FactorArith(C.cast(L.fh_value, C.c_void_p), C.cast(L.fh_eval_grad, C.c_void_p), C.cast(L.fh_value_slope, C.c_void_p))
-        _fh = (L, arith)
+        ptm = _PtmArith(C.cast(L.fh_camera_trial, C.c_void_p), C.cast(L.fh_camera_trial_dir, C.c_void_p), C.cast(L.fh_trial, C.c_void_p))
+        _fh = (L, arith, ptm)
     return _fh
+
+
+def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16):
+    """the point blocks of one component in the point-major streaming solver's order (rdis_hip.hip: prepare_partition), from the
+    component's listed factors' camera / point blocks: by number of listed factors descending, among equals by their cameras (the
+    cameras' ranks, in listed order) lexicographically, ties by id; the whole wave-chunks of 64 blocks whose first blocks have
+    equally many factors are then dealt out round robin over `spread` equal runs of their sorted order (ptm_api.hpp: PTM_SPREAD)"""
+    cams, cam_rank = np.unique(cam_vid0, return_inverse=True)
+    pts, pt_rank = np.unique(pt_vid0, return_inverse=True)
+    npb = len(pts)
+    lists = [[] for _ in range(npb)]
+    for r, b in zip(cam_rank.tolist(), pt_rank.tolist()):
+        lists[b].append(r)
+    order = sorted(range(npb), key=lambda b: (-len(lists[b]), lists[b], b))
+    nfull = npb // 64
+    chunk_of = []
+    a0 = 0
+    while a0 < nfull:
+        T = len(lists[order[64 * a0]])
+        a1 = a0
+        while a1 < nfull and len(lists[order[64 * a1]]) == T:
+            a1 += 1
+        mm = a1 - a0
+        q = -(-mm // spread)
+        for rr in range(q):
+            for gg in range(spread):
+                idx = gg * q + rr
+                if idx < mm:
+                    chunk_of.append(a0 + idx)
+        a0 = a1
+    out = list(order)
+    for a in range(nfull):
+        out[64 * a:64 * a + 64] = order[64 * chunk_of[a]:64 * chunk_of[a] + 64]
+    return cams.astype(np.int64), pts[np.asarray(out, dtype=np.int64)].astype(np.int64)
 
 
 def lib() -> C.CDLL:
@@ -107,6 +146,7 @@ def lib() -> C.CDLL:
         L.ro_set_sum_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_factor_arithmetic.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        L.ro_set_ptm_topology.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
         L.ro_sincos_angle.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -215,6 +255,21 @@ class OracleProblem:
         lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
         o._slots = np.ascontiguousarray(slots)
         lib().ro_set_lds_topology(o.h, int(threads), o._slots.shape[0], o._slots.ctypes.data_as(C.c_void_p))
+        return o
+
+    @classmethod
+    def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2):
+        """the CPU side of the == test of the DEFAULT point-major streaming path (BASELINE config 5-L: a component too large for the
+        LDS-resident solver, one workgroup of `threads` lanes, or a group of `group` of them): the device's own factor arithmetic (factors_host(): the vector form
+        for the gradient, the matrix form for the trials), no stale cache, that solver's layout and sum trees"""
+        o = cls(pp, emulate_stale_cache=False)
+        fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
+        cams, pts = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc])
+        o._fh = factors_host()
+        lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
+        o._cams, o._pts = np.ascontiguousarray(cams), np.ascontiguousarray(pts)
+        lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
+                                  len(pts), o._pts.ctypes.data_as(C.c_void_p), C.addressof(o._fh[2]))
         return o
 
     def set_cooperative_topology(self, free_vid=None, fac=None, lanes_per_workgroup: int = 128) -> None:

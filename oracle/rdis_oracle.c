@@ -404,6 +404,13 @@ struct ro_problem {
     const ro_factor_arith *ext;       /* factor arithmetic supplied from outside (ro_set_factor_arithmetic), or NULL */
     int lds_nt;                       /* RO_SUM_TOPOLOGY_LDS: lanes of the workgroup */
     int64_t lds_nslots, *lds_slot_vid;/* ... its slots in order: the variable behind each (cameras first, then points) */
+    /* RO_SUM_TOPOLOGY_PTM (ro_set_ptm_topology): lanes of the workgroup, slots a block of slots holds, the component's camera blocks
+     * and point blocks (first variable ids) in the solver's order, the trial arithmetic in matrix form; ptm: tables of the solve at hand */
+    int ptm_nt, ptm_blk, ptm_K;       /* ... K workgroups share the component */
+    int64_t ptm_ncb, ptm_npb, *ptm_cam, *ptm_pt;
+    const ro_ptm_arith *ptm_ar;
+    struct ptm_tab *ptm;
+    int ptm_at_start;                 /* the value asked for is the rollback's (other lanes take the factors) */
     int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
     double *fcache;
     uint8_t *fdirty;
@@ -494,7 +501,7 @@ void ro_destroy(ro_problem *p)
     free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
     free(p->sine); free(p->useexp); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
-    free(p->wave_vid); free(p->wave_of); free(p->lds_slot_vid);
+    free(p->wave_vid); free(p->wave_of); free(p->lds_slot_vid); free(p->ptm_cam); free(p->ptm_pt);
     free(p);
 }
 
@@ -636,6 +643,228 @@ void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *s
     p->lds_nt = nt;
     p->lds_nslots = nslots;
     p->lds_slot_vid = dup_mem(slot_vid, sizeof(int64_t) * (size_t)nslots);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RO_SUM_TOPOLOGY_PTM: the sums of the device's point-major streaming solver (rdis_amd/csrc/solver_ptm.hpp, one workgroup of nt
+ * lanes per component -- BASELINE config 5-L, the strong-scaling workload's one-device case), restated entry for entry.
+ *   layout   the component's point blocks in the plan's order (by number of listed factors descending, then by their cameras;
+ *            whole wave-chunks of 64 dealt out over sixteen runs: rdis_hip.hip prepare_partition -- the caller passes the order);
+ *            chunk ch holds blocks 64 ch .. 64 ch + 63, lane l its l-th; a chunk has as many SLOTS as its first block has listed
+ *            factors, slot t of lane l is the t-th listed factor of the lane's block;
+ *   trials   the chunks' slots in blocks of `blk`, the blocks in chunk order dealt to the waves in equal contiguous shares (rows:
+ *            rdis_hip.hip ptm_build_segments); a lane adds its factors' terms row by row, slot by slot, from 0.0; a wave's 64 lanes
+ *            as a balanced tree, the waves' sums as a balanced tree over 16 entries (zero-padded; 4 up to four waves).  Values and
+ *            slopes in matrix form against per-camera records (factors.hpp: ba_camera_trial, ba_trial_value, ba_trial_slope);
+ *   rollback the value at clamp(x_start): wave w takes the chunks w, w + waves, ... whole (eval_start);
+ *   gradient a point variable's partials in factor-list order like the reference (the first copied).  A camera variable's: wave w
+ *            takes the chunks w, w + waves, ..., slot by slot -- its sequence of steps; round r is every wave's r-th step; a
+ *            camera's entry adds, from 0.0, round by round, the partials of the round's factors of that camera by wave, then lane;
+ *   gg, dgg  a lane adds the terms of its blocks' variables as the blocks are finished (the chunks with factors first, then those
+ *            without), then those of the camera slots tid, tid + nt, ... (ten slots a camera: [t f k1 k2 | r | pad]); then the
+ *            trees of the trials.
+ * ------------------------------------------------------------------------------------------------------------------- */
+struct ptm_tab {
+    int64_t nf;
+    const int64_t *fac;
+    int64_t npc;
+    int64_t *fcam;          /* [nf] camera block (index into ptm_cam) of listed factor i */
+    int64_t *pptr, *pidx;   /* block -> its listed factors (indices into the list), in listed order */
+    int64_t *cp;            /* [npc + 1] a chunk's first entry: 64 entries a slot */
+    int64_t *rptr, *rows;   /* wave w of workgroup r: rows rptr[r nw + w] .. rptr[r nw + w + 1]: triples (chunk, first entry, end entry) */
+    int64_t *cam_of_var, *pt_of_var;   /* [nvars] block index or -1 */
+};
+
+static void ptm_free(struct ptm_tab *T)
+{
+    if (!T) return;
+    free(T->fcam); free(T->pptr); free(T->pidx); free(T->cp); free(T->rptr); free(T->rows); free(T->cam_of_var); free(T->pt_of_var);
+    free(T);
+}
+
+static struct ptm_tab *ptm_build(const ro_problem *p, int64_t nf, const int64_t *fac)
+{
+    struct ptm_tab *T = calloc(1, sizeof *T);
+    const int64_t npb = p->ptm_npb, ncb = p->ptm_ncb, npc = (npb + 63) / 64;
+    const int nw = p->ptm_nt / 64, blk = p->ptm_blk, K = p->ptm_K;
+    T->nf = nf; T->fac = fac; T->npc = npc;
+    T->cam_of_var = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+    T->pt_of_var = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+    for (int64_t v = 0; v < p->nvars; ++v) T->cam_of_var[v] = T->pt_of_var[v] = -1;
+    for (int64_t c = 0; c < ncb; ++c) T->cam_of_var[p->ptm_cam[c]] = c;
+    for (int64_t b = 0; b < npb; ++b) T->pt_of_var[p->ptm_pt[b]] = b;
+    T->fcam = malloc(sizeof(int64_t) * (size_t)(nf + 1));
+    T->pptr = calloc((size_t)npb + 2, sizeof(int64_t));
+    T->pidx = malloc(sizeof(int64_t) * (size_t)(nf + 1));
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i;
+        T->fcam[i] = T->cam_of_var[p->cam[f]];
+        T->pptr[T->pt_of_var[p->pt[f]] + 1]++;
+    }
+    for (int64_t b = 0; b < npb; ++b) T->pptr[b + 1] += T->pptr[b];
+    int64_t *fill = calloc((size_t)npb + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i, b = T->pt_of_var[p->pt[f]];
+        T->pidx[T->pptr[b] + fill[b]++] = i;
+    }
+    free(fill);
+    T->cp = calloc((size_t)npc + 2, sizeof(int64_t));
+    for (int64_t ch = 0; ch < npc; ++ch) T->cp[ch + 1] = T->cp[ch] + 64 * (T->pptr[64 * ch + 1] - T->pptr[64 * ch]);
+    /* the waves' rows: workgroup r's chunks r, r + K, ... cut into blocks of slots, the blocks dealt out in equal contiguous shares */
+    T->rptr = calloc((size_t)K * nw + 1, sizeof(int64_t));
+    T->rows = malloc(sizeof(int64_t) * 3 * (size_t)(npc + 2 * (int64_t)K * nw + 2));
+    int64_t nr = 0;
+    for (int rk = 0; rk < K; ++rk) {
+        int64_t units = 0;
+        for (int64_t ch = rk; ch < npc; ch += K) units += ((T->cp[ch + 1] - T->cp[ch]) / 64 + blk - 1) / blk;
+        int64_t u = 0, ch = rk, done = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int64_t end = units * (w + 1) / nw;
+            T->rptr[rk * nw + w] = nr;
+            while (u < end) {
+                const int64_t nb = ((T->cp[ch + 1] - T->cp[ch]) / 64 + blk - 1) / blk;
+                if (done >= nb) { ch += K; done = 0; continue; }
+                const int64_t take = nb - done < end - u ? nb - done : end - u;
+                const int64_t e0 = T->cp[ch] + 64 * blk * done;
+                int64_t e1 = e0 + 64 * blk * take;
+                if (e1 > T->cp[ch + 1]) e1 = T->cp[ch + 1];
+                T->rows[3 * nr] = ch; T->rows[3 * nr + 1] = e0; T->rows[3 * nr + 2] = e1; ++nr;
+                done += take; u += take;
+            }
+        }
+    }
+    T->rptr[K * nw] = nr;
+    return T;
+}
+
+/* the waves' sums (entries: workgroup r's wave w at r nw + w) put together: one workgroup -- a balanced tree over its waves (4
+ * entries up to four waves, else 16, zero-padded: solver_lds.hpp combine_waves); a group -- the sweep of grid_sync.hpp: lane l adds
+ * the entries l, l + 64, ... from 0.0, then a wave sum over the lanes */
+static double ptm_combine(const double *wsum, int nw, int K)
+{
+    if (K > 1) {
+        double lane[64];
+        const int nent = nw * K;
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int e = l; e < nent; e += 64) acc = acc + wsum[e];
+            lane[l] = acc;
+        }
+        return tree64(lane);
+    }
+    double t[16];
+    for (int w = 0; w < 16; ++w) t[w] = w < nw ? wsum[w] : 0.0;
+    if (nw == 1) return t[0];
+    if (nw <= 4) return (t[0] + t[1]) + (t[2] + t[3]);
+    for (int w = 1; w < 16; w *= 2)
+        for (int i = 0; i < 16; i += 2 * w) t[i] = t[i] + t[i + w];
+    return t[0];
+}
+
+/* the component's value (and slope along dir, a dense vector by variable id, or NULL) at the assigned point */
+static double ptm_eval(ro_problem *p, const double *dir, double *slope_out)
+{
+    const struct ptm_tab *T = p->ptm;
+    const ro_ptm_arith *ar = p->ptm_ar;
+    const int64_t ncb = p->ptm_ncb, npb = p->ptm_npb;
+    const int nw = p->ptm_nt / 64, K = p->ptm_K;
+    double *TR = malloc(sizeof(double) * 16 * (size_t)(ncb + 1)), *DR = calloc(10 * (size_t)(ncb + 1), sizeof(double));
+    for (int64_t c = 0; c < ncb; ++c) {
+        const double *xc = p->x + p->ptm_cam[c];
+        ar->camera_trial(xc, TR + 16 * c);
+        if (dir) ar->camera_trial_dir(xc, dir + p->ptm_cam[c], DR + 10 * c);
+    }
+    double *wf = calloc((size_t)K * nw + 16, sizeof(double)), *ws = calloc((size_t)K * nw + 16, sizeof(double));
+    const double zero3[3] = {0.0, 0.0, 0.0};
+    for (int rk = 0; rk < K; ++rk)
+    for (int w = 0; w < nw; ++w) {
+        double af[64], as[64];
+        for (int l = 0; l < 64; ++l) af[l] = as[l] = 0.0;
+        if (!p->ptm_at_start) {
+            for (int64_t r = T->rptr[rk * nw + w]; r < T->rptr[rk * nw + w + 1]; ++r) {
+                const int64_t ch = T->rows[3 * r], t0 = (T->rows[3 * r + 1] - T->cp[ch]) / 64, t1 = (T->rows[3 * r + 2] - T->cp[ch]) / 64;
+                for (int l = 0; l < 64; ++l) {
+                    const int64_t b = 64 * ch + l;
+                    if (b >= npb) continue;
+                    const double *q = p->x + p->ptm_pt[b], *e = dir ? dir + p->ptm_pt[b] : zero3;
+                    const int64_t deg = T->pptr[b + 1] - T->pptr[b];
+                    for (int64_t t = t0; t < t1 && t < deg; ++t) {
+                        const int64_t i = T->pidx[T->pptr[b] + t], f = T->fac ? T->fac[i] : i, c = T->fcam[i];
+                        double sl = 0.0;
+                        af[l] = af[l] + ar->trial(TR + 16 * c, dir ? DR + 10 * c : NULL, q, e, p->obs[2 * f], p->obs[2 * f + 1], dir ? &sl : NULL);
+                        if (dir) as[l] = as[l] + sl;
+                    }
+                }
+            }
+        } else {
+            for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw)
+                for (int l = 0; l < 64; ++l) {
+                    const int64_t b = 64 * ch + l;
+                    if (b >= npb) continue;
+                    const double *q = p->x + p->ptm_pt[b];
+                    for (int64_t k = T->pptr[b]; k < T->pptr[b + 1]; ++k) {
+                        const int64_t i = T->pidx[k], f = T->fac ? T->fac[i] : i, c = T->fcam[i];
+                        af[l] = af[l] + ar->trial(TR + 16 * c, NULL, q, zero3, p->obs[2 * f], p->obs[2 * f + 1], NULL);
+                    }
+                }
+        }
+        wf[rk * nw + w] = tree64(af); ws[rk * nw + w] = tree64(as);
+    }
+    free(TR); free(DR);
+    if (slope_out) *slope_out = ptm_combine(ws, nw, K);
+    const double r = ptm_combine(wf, nw, K);
+    free(wf); free(ws);
+    return r;
+}
+
+/* the camera variables' gradient entries the rounds' way; gq: the listed factors' twelve partials */
+static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g)
+{
+    const struct ptm_tab *T = p->ptm;
+    const int64_t ncb = p->ptm_ncb, npb = p->ptm_npb;
+    const int nw = p->ptm_nt / 64, K = p->ptm_K;
+    double *tot = calloc(9 * (size_t)(ncb + 1), sizeof(double)), *acc = malloc(sizeof(double) * 9 * (size_t)(ncb + 1));
+    int64_t *sptr = calloc((size_t)nw + 1, sizeof(int64_t));
+    int64_t *sch = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1)), *sslot = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1));
+    for (int rk = 0; rk < K; ++rk) {   /* a workgroup's partial sums; the workgroups' then in rank order */
+        int64_t nrounds = 0, at = 0;
+        for (int w = 0; w < nw; ++w) {   /* a wave's steps: (chunk, slot) pairs */
+            sptr[w] = at;
+            for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw)
+                for (int64_t t = 0; t < (T->cp[ch + 1] - T->cp[ch]) / 64; ++t) { sch[at] = ch; sslot[at] = t; ++at; }
+            if (at - sptr[w] > nrounds) nrounds = at - sptr[w];
+        }
+        sptr[nw] = at;
+        for (int64_t k = 0; k < 9 * ncb; ++k) acc[k] = 0.0;
+        for (int64_t rr = 0; rr < nrounds; ++rr)
+            for (int w = 0; w < nw; ++w) {
+                if (rr >= sptr[w + 1] - sptr[w]) continue;
+                const int64_t ch = sch[sptr[w] + rr], t = sslot[sptr[w] + rr];
+                for (int l = 0; l < 64; ++l) {
+                    const int64_t b = 64 * ch + l;
+                    if (b >= npb || t >= T->pptr[b + 1] - T->pptr[b]) continue;
+                    const int64_t i = T->pidx[T->pptr[b] + t], c = T->fcam[i];
+                    /* (within a round a camera's rows stand by wave, then lane: this loop's order, camera by camera) */
+                    for (int k = 0; k < 9; ++k) acc[9 * c + k] = acc[9 * c + k] + gq[12 * i + k];
+                }
+            }
+        for (int64_t k = 0; k < 9 * ncb; ++k) tot[k] = rk == 0 ? acc[k] : tot[k] + acc[k];
+    }
+    for (int64_t c = 0; c < ncb; ++c)
+        for (int k = 0; k < 9; ++k) g[p->ptm_cam[c] + k] = tot[9 * c + k];
+    free(acc); free(tot); free(sptr); free(sch); free(sslot);
+}
+
+void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, const int64_t *cam_vid0, int64_t npb, const int64_t *pt_vid0,
+                         const ro_ptm_arith *ar)
+{
+    p->ptm_K = K < 1 ? 1 : K;
+    ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
+    free(p->ptm_cam); free(p->ptm_pt);
+    p->topo = RO_SUM_TOPOLOGY_PTM;
+    p->ptm_nt = nt; p->ptm_blk = blk; p->ptm_ncb = ncb; p->ptm_npb = npb; p->ptm_ar = ar;
+    p->ptm_cam = dup_mem(cam_vid0, sizeof(int64_t) * (size_t)ncb);
+    p->ptm_pt = dup_mem(pt_vid0, sizeof(int64_t) * (size_t)npb);
 }
 
 void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid)
@@ -848,6 +1077,7 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
      * objective sum -- 1e-12 relative in list order over 3e4 terms, 1e-15 as a tree, which is what a device computes --
      * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
     if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
+    if (p->topo == RO_SUM_TOPOLOGY_PTM && p->ptm && p->ptm->nf == nf && p->ptm->fac == fac) return ptm_eval(p, NULL, NULL);
     if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS) {
         double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
         for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
@@ -968,6 +1198,17 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
                 free(part);
             }
             free(cnt);
+        }
+        if (p->topo == RO_SUM_TOPOLOGY_PTM && p->ptm && p->ptm->nf == nf && p->ptm->fac == fac) {
+            double *gq = malloc(sizeof(double) * 12 * (size_t)(nf + 1));
+            for (int64_t i = 0; i < nf; ++i) {
+                const int64_t f = fac ? fac[i] : i;
+                double x[12];
+                gather_ba(p, f, x);
+                ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq + 12 * i);
+            }
+            ptm_camera_gradient(p, gq, g);
+            free(gq);
         }
         if (run) {
             for (int64_t w = 0; w < p->nwave_owned; ++w) {
@@ -1409,6 +1650,66 @@ static void sub_cg_sums_lds(void *ctx, int n, const double *g, const double *xi,
     free(li);
 }
 
+/* RO_SUM_TOPOLOGY_PTM: a trial's slope in the point-major streaming solver -- with the value, from the cameras' records */
+static double sub_slope_ptm(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    double *dir = calloc((size_t)p->nvars + 12, sizeof(double));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    double s = 0.0;
+    (void)ptm_eval(p, dir, &s);
+    free(dir);
+    return s;
+}
+
+/* ... and gg, dgg: a lane's point blocks as the gradient pass finishes them, then its camera slots (a group: the first workgroup's
+ * lanes speak for the cameras) */
+static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    const struct ptm_tab *T = p->ptm;
+    const int nt = p->ptm_nt, nw = nt / 64, K = p->ptm_K;
+    int64_t *li = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1));
+    for (int64_t v = 0; v < p->nvars; ++v) li[v] = -1;
+    for (int64_t i = 0; i < n; ++i) li[S->free_vid[i]] = i;
+    static const int var_of_slot[10] = {3, 4, 5, 6, 7, 8, 0, 1, 2, -1};   /* [t f k1 k2 | r | pad] */
+    double *wa = calloc((size_t)K * nw + 16, sizeof(double)), *wb = calloc((size_t)K * nw + 16, sizeof(double));
+    for (int rk = 0; rk < K; ++rk)
+    for (int w = 0; w < nw; ++w) {
+        double la[64], lb[64];
+        for (int l = 0; l < 64; ++l) {
+            double a = 0.0, b = 0.0;
+            for (int pass = 0; pass < 2; ++pass)   /* the chunks with factors as the rounds finish them, then those without */
+                for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw) {
+                    const int empty = T->cp[ch] >= T->cp[ch + 1];
+                    if (empty != pass) continue;
+                    const int64_t blkid = 64 * ch + l;
+                    if (blkid >= p->ptm_npb) continue;
+                    for (int k = 0; k < 3; ++k) {
+                        const int64_t i = li[p->ptm_pt[blkid] + k];
+                        if (i < 0) continue;
+                        a = a + g[i] * g[i];
+                        b = b + (xi[i] + g[i]) * xi[i];
+                    }
+                }
+            for (int64_t sidx = 64 * w + l; rk == 0 && sidx < 10 * p->ptm_ncb; sidx += nt) {
+                const int k = var_of_slot[sidx % 10];
+                if (k < 0) continue;
+                const int64_t i = li[p->ptm_cam[sidx / 10] + k];
+                if (i < 0) continue;
+                a = a + g[i] * g[i];
+                b = b + (xi[i] + g[i]) * xi[i];
+            }
+            la[l] = a; lb[l] = b;
+        }
+        wa[rk * nw + w] = tree64(la); wb[rk * nw + w] = tree64(lb);
+    }
+    *gg = ptm_combine(wa, nw, K); *dgg = ptm_combine(wb, nw, K);
+    free(li); free(wa); free(wb);
+}
+
 /* ... and gg, dgg: lane i carries variable i's terms unless a wave owns it, wave w's first lane those of its variable */
 static void sub_cg_sums_topology(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
 {
@@ -1459,6 +1760,7 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     double *xinit = malloc(sizeof(double) * (size_t)(nfree + 1));
     double *xw = malloc(sizeof(double) * (size_t)(nfree + 1));
 
+    if (p->topo == RO_SUM_TOPOLOGY_PTM && p->kind == RO_KIND_BA) { ptm_free(p->ptm); p->ptm = ptm_build(p, nf, fac); p->ptm_at_start = 0; }
     /* SubspaceOptimizer::quickAssignVals(vars, xval, true) then sfd(xval) */
     const double finit = sub_f(&S, xval);
     memcpy(xinit, xval, sizeof(double) * (size_t)nfree);
@@ -1471,6 +1773,13 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
         memset(&hk, 0, sizeof hk);
         hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_topology;
         g_slope_topology = sub_slope_topology;
+        reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+        g_slope_topology = 0;
+    } else if (p->topo == RO_SUM_TOPOLOGY_PTM && p->kind == RO_KIND_BA && p->ext && p->ptm_ar) {
+        ro_hooks hk;
+        memset(&hk, 0, sizeof hk);
+        hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_ptm;
+        g_slope_topology = sub_slope_ptm;
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
         g_slope_topology = 0;
     } else if (p->topo == RO_SUM_TOPOLOGY_LDS && p->kind == RO_KIND_BA && p->ext) {
@@ -1489,7 +1798,9 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     int status = reason;
     if (fret > finit) { /* negative progress: restore (.cpp:66-80) */
         status |= RO_STATUS_ROLLED_BACK;
+        p->ptm_at_start = 1;
         fret = sub_f(&S, xinit);
+        p->ptm_at_start = 0;
     }
     for (int64_t i = 0; i < nfree; ++i) xval[i] = p->x[free_vid[i]]; /* .cpp:84-86 */
 
@@ -1497,6 +1808,7 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
     out->iters = iter; out->status = status;
     out->nfeval = S.nfeval; out->ngeval = S.ngeval;
     free(S.gdense); free(xinit); free(xw);
+    if (p->ptm) { ptm_free(p->ptm); p->ptm = NULL; }
 }
 
 /* ===========================================================================

@@ -133,6 +133,24 @@ typedef struct {
 } ro_factor_arith;
 void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext);   /* ext must outlive the problem's use; NULL: built in */
 void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid);
+/* RO_SUM_TOPOLOGY_PTM: the sums of the device's point-major streaming solver (solver_ptm.hpp: a workgroup of nt lanes a component
+ * whose camera blocks stay in LDS while its point blocks stream -- BASELINE config 5-L), restated entry for entry (rdis_oracle.c).
+ * cam_vid0 / pt_vid0: the component's camera blocks (ascending) and point blocks in the plan's order (by number of listed factors
+ * descending, then by their cameras, whole wave-chunks dealt over sixteen runs: the caller restates rdis_hip.hip's rule); blk: the
+ * slots a wave asks for together (ptm_api.hpp: PTM_BLK); K: the workgroups that share the component (1, or a group of up to 16:
+ * cgd_ptmg_kernel -- chunk c is workgroup c mod K's, every wave of the group an entry of the exchange, the workgroups' partial camera
+ * gradients added in rank order).  That solver evaluates trials in MATRIX form against per-camera records
+ * (factors.hpp: ba_camera_trial, ba_camera_trial_dir, ba_trial_value, ba_trial_slope): `ar` plugs that arithmetic in from outside like
+ * ro_set_factor_arithmetic does for the vector form (which the gradient uses: both must be set). */
+#define RO_SUM_TOPOLOGY_PTM 3
+typedef struct {
+    void (*camera_trial)(const double *xc9, double *TR16);
+    void (*camera_trial_dir)(const double *xc9, const double *dc9, double *DR10);
+    /* value of one factor at point q3; with DR10 and slope != NULL also its slope along (DR10, e3) */
+    double (*trial)(const double *TR16, const double *DR10, const double *q3, const double *e3, double ox, double oy, double *slope);
+} ro_ptm_arith;
+void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, const int64_t *cam_vid0, int64_t npb, const int64_t *pt_vid0,
+                         const ro_ptm_arith *ar);
 /* process-wide experiment flags; never used to pin anything.  bit 0: reciprocals in place of the projection's divisions, the
  * device's form.  bit 1 (round 5): the slope of a line-search trial added factor by factor, sum_f (sum_k partial_fk xi_k) -- the
  * association the device's fused trials use -- in place of the reference's gradient times direction (Df1dim::df,

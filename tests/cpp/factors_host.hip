@@ -31,6 +31,32 @@ double fh_value_slope(const double* x, const double* d, double ox, double oy, in
     *slope = camfix ? ba_slope_dir<true>(t, xx, dd) : ba_slope_dir<false>(t, xx, dd);
     return E;
 }
+// the matrix form of the point-major streaming solver's trials (solver_ptm.hpp): a camera's records at its nine values
+// [r t f k1 k2] (and along its nine direction entries), a factor's value (and slope) against them
+void fh_camera_trial(const double* xc, double* TR) {
+    double x[9];
+    for (int k = 0; k < 9; ++k) x[k] = xc[k];
+    BaFwd rot;
+    ba_rotation(x[0], x[1], x[2], rot);
+    ba_camera_trial(rot, x, TR);
+}
+void fh_camera_trial_dir(const double* xc, const double* dc, double* DR) {
+    double d[9];
+    for (int k = 0; k < 9; ++k) d[k] = dc[k];
+    BaFwd rot;
+    ba_rotation(xc[0], xc[1], xc[2], rot);
+    ba_camera_trial_dir(rot, d, DR);
+}
+double fh_trial(const double* TR, const double* DR, const double* q, const double* e, double ox, double oy, double* slope) {
+    double tr[CAM_TRIAL], dr[CAM_DIR], qq[3], ee[3];
+    for (int k = 0; k < CAM_TRIAL; ++k) tr[k] = TR[k];
+    for (int k = 0; k < CAM_DIR; ++k) dr[k] = DR ? DR[k] : 0.0;
+    for (int k = 0; k < 3; ++k) { qq[k] = q[k]; ee[k] = e[k]; }
+    BaTrial t;
+    const double v = ba_trial_value(tr, qq, ox, oy, t);
+    if (slope && DR) *slope = ba_trial_slope<false>(t, tr, dr, qq, ee);
+    return v;
+}
 void fh_eval_grad_each(long long n, const double* x12, const double* obs2, double* f, double* g12) {
     for (long long i = 0; i < n; ++i) f[i] = fh_eval_grad(x12 + 12 * i, obs2[2 * i], obs2[2 * i + 1], g12 + 12 * i);
 }

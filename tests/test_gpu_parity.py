@@ -293,3 +293,65 @@ def test_default_cooperative_groups_side_by_side_equal_the_oracle(gctx):
         want = O.OracleProblem.device_default(pp, free_vid=v, fac=f, lanes_per_workgroup=lanes).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
         assert r.fret[c] == want.fret and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
         assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
+
+
+def _each_component_equals(pp, r, comps, make):
+    fp, fv, cp, ci = pp.comp_free_ptr, pp.comp_free_vid, pp.comp_fac_ptr, pp.comp_fac_id
+    for c in comps:
+        v, f = fv[fp[c]:fp[c + 1]], ci[cp[c]:cp[c + 1]]
+        want = make(f).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
+        assert r.fret[c] == want.fret and r.delta[c] == want.delta and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
+        assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
+
+
+def test_default_point_major_path_equals_the_oracle_on_config_5l(gctx):
+    """BASELINE config 5-L as bench.py's strong-scaling block runs it on one device -- no option set: more components (49 cameras x
+    7776 points x 4 observations = 31104 factors each) than compute units, so each gets ONE workgroup of 768 lanes of the point-major
+    streaming solver (solver_ptm.hpp: cameras in LDS, points streamed, trials in matrix form, the gradient's camera sums in rounds)
+    -- against the oracle with factors.hpp compiled for the host plugged in (vector form for the gradient, matrix form for the
+    trials) and RO_SUM_TOPOLOGY_PTM, that solver's layout and sums restated entry for entry: every 50th of 300 components ==."""
+    pp = P.make_synthetic_ba(300, 49, 7776, obs_per_pt=4)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_point_major") == 300 and plan.info("point_major_group") == 1
+    _each_component_equals(pp, r, range(0, 300, 50), lambda f: O.OracleProblem.device_ptm_default(pp, fac=f))
+
+
+@pytest.mark.parametrize("group, threads", [(2, 512), (4, 512), (3, 256)])
+def test_default_point_major_groups_equal_the_oracle(gctx, group, threads):
+    """... and as a rank of eight runs its 125 components: K workgroups share a component (cgd_ptmg_kernel: chunk c is workgroup c
+    mod K's, every wave of the group an entry of the exchange, the partial camera gradients added in rank order).  Three components
+    in groups of 2 and 4 x 512 lanes and 3 x 256 == the oracle's run with the same group."""
+    pp = P.make_synthetic_ba(3, 49, 7776, obs_per_pt=4)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in {"coop_min_factors": 0, "coop_group_min_factors": 0, "ptm_group": group, "ptm_threads": threads}.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_point_major") == 3 and plan.info("point_major_group") == group and not plan.info("point_major_wide")
+    _each_component_equals(pp, r, range(3), lambda f: O.OracleProblem.device_ptm_default(pp, fac=f, threads=threads, group=group))
+
+
+@pytest.mark.parametrize("case", ["ladybug", "ladybug 16 / 3000", "small and ragged"])
+def test_point_major_path_on_real_data_equals_the_oracle(gctx, case):
+    """the same solver on the BAL file (points seen by 2 .. 40 cameras: chunks of unequal slot counts, a last chunk of fewer than 64
+    blocks, blocks dealt over sixteen runs of the camera-sorted order) and on a component small enough for the LDS sent there by
+    option: one workgroup of 768 lanes == the oracle"""
+    pp = {"ladybug": lambda: P.load_bal().single_component(), "ladybug 16 / 3000": lambda: P.load_bal(ncams=16, npts=3000).single_component(),
+          "small and ragged": lambda: P.load_bal(ncams=7, npts=200).single_component()}[case]()
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in {"coop_min_factors": 0, "coop_group_min_factors": 0, "ptm_stream": 2, "ptm_group": 1}.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_point_major") == 1 and plan.info("point_major_group") == 1
+    want = O.OracleProblem.device_ptm_default(pp).cgd(x=pp.x0, maxiters=25)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (r.fret[0], want.fret)
+    assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)

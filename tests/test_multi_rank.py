@@ -263,3 +263,21 @@ def test_bench_collective_bootstrap_without_torch(tmp_path):
     assert recs[0]["name"].startswith("rccl through the C ABI")
     key = "rdis_bench_id_%d_%d" % (port, os.getpid())
     assert not os.path.exists(os.path.join("/dev/shm", key)) and not os.path.exists(os.path.join("/tmp", key))
+
+
+def test_bench_keeps_a_library_banner_off_stdout():
+    """RCCL prints its version through C's buffered stdout when first used; the bench's contract is ONE JSON line there: what a
+    library prints inside bench._stdout_to_stderr() lands on stderr, buffered or not"""
+    code = textwrap.dedent('''
+        import ctypes, importlib.util
+        spec = importlib.util.spec_from_file_location("bench", r"%s")
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        libc = ctypes.CDLL(None)
+        with b._stdout_to_stderr():
+            libc.printf(b"RCCL version : banner\\n")
+        print("{}")
+    ''' % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "{}\n"
+    assert "banner" in r.stderr
