@@ -321,13 +321,26 @@ def run_strong_scaling(ctx, rank, world, coll, maxiters, steps=3, warmup=1, cpu=
         dtc = time.perf_counter() - t0c
         out["cpu_baseline"] = {"value": cits / dtc, "unit": "iters/s", "cores": 1, "kind": "port", "f_evals_per_s": cfe / dtc,
                                "sample": "the first 3 of the %d components, dense gradient accumulation" % pp.ncomp}
+        # ... and what the launch above returned for those components against CPU runs of the oracle with the point-major solver's own
+        # arithmetic, layout and sums (oracle/rdis_oracle.h: RO_SUM_TOPOLOGY_PTM): the same bits or not
+        if out["workgroups_per_component"] == 1 and STRONG["npts"] >= 2048:
+            where = {int(c): i for i, c in enumerate(mine)}
+            same = []
+            for c in range(3):
+                fv, fc = pp.component(c)
+                w = O.OracleProblem.device_ptm_default(pp, fac=fc).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=maxiters)
+                i = where[c]
+                same.append(bool(float(r.fret[i]) == w.fret and int(r.nfeval[i]) == w.nfeval and int(r.ngeval[i]) == w.ngeval))
+            out["components_bit_identical_to_cpu"] = {"components": [0, 1, 2], "identical": same,
+                                                      "what": "fret, f and gradient evaluation counts of the timed launch == the oracle's run with the "
+                                                              "device's factor arithmetic (factors.hpp for the host) and the point-major solver's sums"}
     if world == 1:
-        out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"])
+        out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"], cpu=cpu)
     prob.close()
     return out
 
 
-def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
+def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False):
     """rank 0's share of the fixed decomposition for world = 2, 4, 8, run on THIS one GPU: what one GPU of such a job
     does per step -- solve + fetch of its own results (the start is resident, as in the block above; the 8-byte
     all-reduce is not emulated) -- wall clock around exactly `steps` steps after one warm-up, and the ratio to
@@ -362,6 +375,14 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3):
         rows.append({"world": world, "components_rank0": int(len(mine)), "ms_per_step": ms, "kernel_ms": kms / steps,
                      "workgroups_per_component": int(plan.info("point_major_group")), "ratio_to_world1": ms_world1 / ms,
                      "objective_rank0": float(r.fret.sum()), "all_reduce_in_the_step": comm is not None})
+        if cpu and STRONG["npts"] >= 2048 and not plan.info("point_major_wide") and plan.info("components_point_major") == len(mine):
+            # the share's first component against a CPU run of the oracle with this launch's group (RO_SUM_TOPOLOGY_PTM)
+            from oracle import oracle as O
+            K, nt = int(plan.info("point_major_group")), int(plan.info("point_major_threads"))
+            v, f = fv[fp[0]:fp[1]], ci[cp[0]:cp[1]]
+            w = O.OracleProblem.device_ptm_default(pp, fac=f, threads=nt, group=K).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=maxiters)
+            rows[-1]["first_component_bit_identical_to_cpu"] = bool(float(r.fret[0]) == w.fret and int(r.nfeval[0]) == w.nfeval and int(r.ngeval[0]) == w.ngeval)
+            rows[-1]["lanes_per_workgroup"] = nt
         plan.close()
     if comm is not None:
         comm.close()

@@ -284,6 +284,7 @@ struct rdis_hip_plan {
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
     int ptm_last_group = 1;           // what the last solve used (rdis_hip_plan_debug_counters has no slot for it: get_option)
+    int ptm_last_threads = 0;        // ... and their lanes
     int64_t ls_total_chunks = 0;      // gradient chunks of all slot tables
     int64_t ptm_min_points = 0;       // the smallest streaming component's point blocks
     DevBuf ptm_xch, ptm_state;
@@ -2796,6 +2797,7 @@ extern "C" int rdis_hip_plan_solve(rdis_hip_plan* L, int32_t maxiters, double ft
             if (Kw > PTM_MAX_GROUP && Kw * PTM_WIDE_THREADS > K * threads) { K = Kw; threads = PTM_WIDE_THREADS; wide = true; }
         }
         L->ptm_last_group = std::max(K, 1);
+        L->ptm_last_threads = threads;
         L->ptm_wide_last = wide;
         int rc = K >= 2 ? launch_ptm_groups(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, K, maxiters, ftol, wide)
                         : launch_ptm(L, bs, threads, L->rest_tiny + rest, L->rest_ptm, maxiters, ftol);
@@ -3062,6 +3064,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
     else if (n == "components_plain") *value = rest;
     else if (n == "pipelined") *value = L->pipelined() ? 1 : 0;
     else if (n == "point_major_group") *value = L->ptm_last_group;
+    else if (n == "point_major_threads") *value = L->ptm_last_threads;
     else return fail(c, RDIS_HIP_EINVAL, "plan_get_info: unknown name '" + n + "'");
     return 0;
 }

@@ -52,6 +52,23 @@ for c in range(pp.ncomp):
     frets.append(rc.fret); nfe.append(rc.nfeval)
 out["synthetic_S_default_path"] = {"components": 1000, "ncams": 3, "npts": 40, "maxiters": 25, "sum_topology": "lds, 128 lanes",
                                    "fret": frets, "nfeval": nfe}
+# ... and the DEFAULT point-major streaming path (config 5-L: the strong-scaling block's components; ladybug sent there by option):
+# factors.hpp for the host again (vector form for the gradient, matrix form for the trials) and RO_SUM_TOPOLOGY_PTM, for one
+# workgroup of 768 lanes a component and for the groups a rank of eight uses
+pp = P.make_synthetic_ba(3, 49, 7776, obs_per_pt=4)
+rows = []
+for group, threads in ((1, 768), (2, 512), (4, 512)):
+    for c in range(3):
+        fv, fc = pp.component(c)
+        rc = O.OracleProblem.device_ptm_default(pp, fac=fc, threads=threads, group=group).cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25)
+        rows.append({"component": c, "group": group, "threads": threads, "fret": rc.fret, "iters": rc.iters, "nfeval": rc.nfeval, "ngeval": rc.ngeval})
+out["synthetic_L_default_path"] = {"components": 3, "ncams": 49, "npts": 7776, "obs_per_pt": 4, "maxiters": 25, "sum_topology": "point-major",
+                                   "runs": rows}
+pp = P.load_bal().single_component()
+r = O.OracleProblem.device_ptm_default(pp).cgd(x=pp.x0, maxiters=25)
+out["ladybug_full_point_major_path"] = {
+    "ncams": 0, "npts": 0, "maxiters": 25, "emulate_stale_cache": False, "sum_topology": "point-major, 768 lanes", "fret": r.fret, "delta": r.delta,
+    "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:3]), "x_last": float(r.x[-1])}
 with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps({k: (v if k != "synthetic_S_default_path" else "1000 components") for k, v in out.items()}, indent=1))

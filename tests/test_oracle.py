@@ -372,6 +372,35 @@ def test_lds_topology_with_the_host_compiled_arithmetic_reproduces_its_fixture()
         assert rc.fret == ws["fret"][c] and rc.nfeval == ws["nfeval"][c], c
 
 
+def test_point_major_topology_reproduces_its_fixture():
+    """RO_SUM_TOPOLOGY_PTM -- the point-major streaming solver's layout and sums (BASELINE config 5-L), with factors.hpp compiled for
+    the host for both forms of the arithmetic -- ends where tests/golden/parity_end_values.json says: component 0 of the synthetic
+    49 x 7776 x 4 decomposition under one workgroup of 768 lanes and as a pair of 512 (the device returns the same bits under -m
+    gpu, tests/test_gpu_parity.py).  The plan's point order is restated in oracle.py (ptm_point_order): by number of factors
+    descending, whole chunks of 64 dealt over sixteen runs; the matrix form agrees with the vector form to rounding."""
+    import json
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc to compile factors.hpp for the host")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        fx = json.load(fh)
+    pp = P.make_synthetic_ba(1, 49, 7776, obs_per_pt=4)
+    fv, fc = pp.component(0)
+    cams, pts = O.ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc])
+    assert len(cams) == 49 and len(pts) == 7776 and len(set(pts.tolist())) == 7776 and not np.array_equal(pts, np.sort(pts))
+    for w in fx["synthetic_L_default_path"]["runs"]:
+        if w["component"] != 0 or w["group"] > 2:
+            continue
+        o = O.OracleProblem.device_ptm_default(pp, fac=fc, threads=w["threads"], group=w["group"])
+        rc = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=25)
+        assert (rc.fret, rc.iters, rc.nfeval, rc.ngeval) == (w["fret"], w["iters"], w["nfeval"], w["ngeval"]), w
+    # the matrix form's value at x0 against the reference-order sum of the vector form: the same model
+    o = O.OracleProblem.device_ptm_default(pp, fac=fc)
+    ref = O.OracleProblem(pp, emulate_stale_cache=False)
+    r0 = o.cgd(free_vid=fv, fac=fc, x=pp.x0[fv], maxiters=0)
+    assert abs(r0.finit - ref.eval(fc)) <= 1e-11 * abs(r0.finit)
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
