@@ -96,17 +96,21 @@ def factors_host():
     return _fh
 
 
-def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16):
+def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16, wide: bool = False):
     """the point blocks of one component in the point-major streaming solver's order (rdis_hip.hip: prepare_partition), from the
     component's listed factors' camera / point blocks: by number of listed factors descending, among equals by their cameras (the
     cameras' ranks, in listed order) lexicographically, ties by id; the whole wave-chunks of 64 blocks whose first blocks have
-    equally many factors are then dealt out round robin over `spread` equal runs of their sorted order (ptm_api.hpp: PTM_SPREAD)"""
+    equally many factors are then dealt out over `spread` equal runs of their sorted order (ptm_api.hpp: PTM_SPREAD) -- round robin,
+    or, for a component that gets a WIDE group, position c takes the next chunk of run h(c), h a weighted sum of c's hexadecimal
+    digits mod 16 (the first run with chunks left from there on)"""
     cams, cam_rank = np.unique(cam_vid0, return_inverse=True)
     pts, pt_rank = np.unique(pt_vid0, return_inverse=True)
     npb = len(pts)
-    lists = [[] for _ in range(npb)]
-    for r, b in zip(cam_rank.tolist(), pt_rank.tolist()):
-        lists[b].append(r)
+    order_f = np.argsort(pt_rank, kind="stable")            # listed factors by point block, listed order within
+    deg = np.bincount(pt_rank, minlength=npb)
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    crk = cam_rank[order_f]
+    lists = [crk[ptr[b]:ptr[b + 1]].tolist() for b in range(npb)]
     order = sorted(range(npb), key=lambda b: (-len(lists[b]), lists[b], b))
     nfull = npb // 64
     chunk_of = []
@@ -118,11 +122,23 @@ def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16):
             a1 += 1
         mm = a1 - a0
         q = -(-mm // spread)
-        for rr in range(q):
-            for gg in range(spread):
-                idx = gg * q + rr
-                if idx < mm:
-                    chunk_of.append(a0 + idx)
+        if not wide:
+            for rr in range(q):
+                for gg in range(spread):
+                    idx = gg * q + rr
+                    if idx < mm:
+                        chunk_of.append(a0 + idx)
+        else:
+            used = [0] * spread
+            for _ in range(mm):
+                pos = len(chunk_of)
+                gg = ((pos & 15) + 15 * ((pos >> 4) & 15) + ((pos >> 8) & 15) + 15 * ((pos >> 12) & 15) + ((pos >> 16) & 15) + ((pos >> 20) & 15)) % spread
+                for _t in range(spread):
+                    if gg * q + used[gg] < min(mm, (gg + 1) * q):
+                        break
+                    gg = (gg + 1) % spread
+                chunk_of.append(a0 + gg * q + used[gg])
+                used[gg] += 1
         a0 = a1
     out = list(order)
     for a in range(nfull):
@@ -258,17 +274,18 @@ class OracleProblem:
         return o
 
     @classmethod
-    def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2):
+    def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2, wide: bool = False):
         """the CPU side of the == test of the DEFAULT point-major streaming path (BASELINE config 5-L: a component too large for the
-        LDS-resident solver, one workgroup of `threads` lanes, or a group of `group` of them): the device's own factor arithmetic (factors_host(): the vector form
+        LDS-resident solver, one workgroup of `threads` lanes, or a group of `group` of them; wide: one large component on a large share of the device, groups of up
+        to 512 workgroups of 512 lanes, without local camera numbering): the device's own factor arithmetic (factors_host(): the vector form
         for the gradient, the matrix form for the trials), no stale cache, that solver's layout and sum trees"""
         o = cls(pp, emulate_stale_cache=False)
         fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
-        cams, pts = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc])
+        cams, pts = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc], wide=wide)
         o._fh = factors_host()
         lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
         o._cams, o._pts = np.ascontiguousarray(cams), np.ascontiguousarray(pts)
-        lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
+        lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), -int(group) if wide else int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
                                   len(pts), o._pts.ctypes.data_as(C.c_void_p), C.addressof(o._fh[2]))
         return o
 

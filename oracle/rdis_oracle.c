@@ -407,6 +407,7 @@ struct ro_problem {
     /* RO_SUM_TOPOLOGY_PTM (ro_set_ptm_topology): lanes of the workgroup, slots a block of slots holds, the component's camera blocks
      * and point blocks (first variable ids) in the solver's order, the trial arithmetic in matrix form; ptm: tables of the solve at hand */
     int ptm_nt, ptm_blk, ptm_K;       /* ... K workgroups share the component */
+    int ptm_wide;                     /* ... as a wide group: one entry of the exchange a workgroup */
     int64_t ptm_ncb, ptm_npb, *ptm_cam, *ptm_pt;
     const ro_ptm_arith *ptm_ar;
     struct ptm_tab *ptm;
@@ -740,16 +741,30 @@ static struct ptm_tab *ptm_build(const ro_problem *p, int64_t nf, const int64_t 
 /* the waves' sums (entries: workgroup r's wave w at r nw + w) put together: one workgroup -- a balanced tree over its waves (4
  * entries up to four waves, else 16, zero-padded: solver_lds.hpp combine_waves); a group -- the sweep of grid_sync.hpp: lane l adds
  * the entries l, l + 64, ... from 0.0, then a wave sum over the lanes */
-static double ptm_combine(const double *wsum, int nw, int K)
+static double ptm_combine(const double *wsum, int nw, int K, int wide)
 {
     if (K > 1) {
+        /* (a wide group: a workgroup's waves first, as the 16-tree -- one entry a workgroup) */
+        double *ent = NULL;
+        int nent = nw * K;
+        if (wide) {
+            ent = malloc(sizeof(double) * (size_t)K);
+            for (int r = 0; r < K; ++r) {
+                double t[16];
+                for (int w = 0; w < 16; ++w) t[w] = w < nw ? wsum[r * nw + w] : 0.0;
+                for (int w = 1; w < 16; w *= 2)
+                    for (int i = 0; i < 16; i += 2 * w) t[i] = t[i] + t[i + w];
+                ent[r] = t[0];
+            }
+            wsum = ent; nent = K;
+        }
         double lane[64];
-        const int nent = nw * K;
         for (int l = 0; l < 64; ++l) {
             double acc = 0.0;
             for (int e = l; e < nent; e += 64) acc = acc + wsum[e];
             lane[l] = acc;
         }
+        free(ent);
         return tree64(lane);
     }
     double t[16];
@@ -811,8 +826,8 @@ static double ptm_eval(ro_problem *p, const double *dir, double *slope_out)
         wf[rk * nw + w] = tree64(af); ws[rk * nw + w] = tree64(as);
     }
     free(TR); free(DR);
-    if (slope_out) *slope_out = ptm_combine(ws, nw, K);
-    const double r = ptm_combine(wf, nw, K);
+    if (slope_out) *slope_out = ptm_combine(ws, nw, K, p->ptm_wide);
+    const double r = ptm_combine(wf, nw, K, p->ptm_wide);
     free(wf); free(ws);
     return r;
 }
@@ -858,6 +873,8 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
 void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, const int64_t *cam_vid0, int64_t npb, const int64_t *pt_vid0,
                          const ro_ptm_arith *ar)
 {
+    p->ptm_wide = K < 0;   /* (K < 0: -K workgroups as a wide group) */
+    K = K < 0 ? -K : K;
     p->ptm_K = K < 1 ? 1 : K;
     ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
     free(p->ptm_cam); free(p->ptm_pt);
@@ -1706,7 +1723,7 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
         }
         wa[rk * nw + w] = tree64(la); wb[rk * nw + w] = tree64(lb);
     }
-    *gg = ptm_combine(wa, nw, K); *dgg = ptm_combine(wb, nw, K);
+    *gg = ptm_combine(wa, nw, K, p->ptm_wide); *dgg = ptm_combine(wb, nw, K, p->ptm_wide);
     free(li); free(wa); free(wb);
 }
 

@@ -139,7 +139,8 @@ void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *s
  * descending, then by their cameras, whole wave-chunks dealt over sixteen runs: the caller restates rdis_hip.hip's rule); blk: the
  * slots a wave asks for together (ptm_api.hpp: PTM_BLK); K: the workgroups that share the component (1, or a group of up to 16:
  * cgd_ptmg_kernel -- chunk c is workgroup c mod K's, every wave of the group an entry of the exchange, the workgroups' partial camera
- * gradients added in rank order).  That solver evaluates trials in MATRIX form against per-camera records
+ * gradients added in rank order; K < 0: -K workgroups as a WIDE group -- one large component on a large share of the device: a
+ * workgroup's waves are added first, as the 16-tree, and the workgroup is one entry of the exchange).  That solver evaluates trials in MATRIX form against per-camera records
  * (factors.hpp: ba_camera_trial, ba_camera_trial_dir, ba_trial_value, ba_trial_slope): `ar` plugs that arithmetic in from outside like
  * ro_set_factor_arithmetic does for the vector form (which the gradient uses: both must be set). */
 #define RO_SUM_TOPOLOGY_PTM 3

@@ -355,3 +355,27 @@ def test_point_major_path_on_real_data_equals_the_oracle(gctx, case):
     want = O.OracleProblem.device_ptm_default(pp).cgd(x=pp.x0, maxiters=25)
     assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (r.fret[0], want.fret)
     assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+@pytest.mark.parametrize("case", ["ladybug as 64 workgroups", "24 cameras x 30000 points"])
+def test_wide_point_major_group_equals_the_oracle(gctx, case):
+    """ONE component on a large share of the device (solver_ptm.hpp: a wide group -- its chunks dealt to the runs by the hash of
+    their position, a workgroup's waves added first and the workgroup one entry of the exchange, the partial camera gradients added
+    by shares in rank order): 25 iterations == the oracle's run with that group (RO_SUM_TOPOLOGY_PTM, K < 0)."""
+    if case == "ladybug as 64 workgroups":
+        pp, opts = P.load_bal().single_component(), {"force_stream": 1, "ptm_group": 64}
+    else:
+        pp, opts = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4).single_component(), {}
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_point_major") == 1 and plan.info("point_major_wide") == 1 and not plan.info("point_major_local_cameras")
+    K, nt = plan.info("point_major_group"), plan.info("point_major_threads")
+    assert K > 16 and nt == 512
+    want = O.OracleProblem.device_ptm_default(pp, threads=nt, group=K, wide=True).cgd(x=pp.x0, maxiters=25)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (K, r.fret[0], want.fret)
+    assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
