@@ -4,6 +4,15 @@
 
 namespace rdis_hip {
 
+#ifdef RDIS_GRAD_STAMPS
+// (measurement builds only) cycles of the first workgroup's first wave, summed over its chunks: 0 the factors, 1 stage 2 + wave sum +
+// the wait at the first barrier, 2 the segment sums, 3 the wait at the second barrier, 4 chunks, 5 the tile's prologue + epilogue
+__device__ long long grad_stamps[8];
+#define GRAD_STAMP(i, expr) do { const long long t_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) grad_stamps[i] += t_ - tlast; tlast = t_; (void)(expr); } while (0)
+#else
+#define GRAD_STAMP(i, expr) do { } while (0)
+#endif
+
 // one lane per camera block: its record for this call
 __global__ void __launch_bounds__(256)
 grad_camera_records_kernel(const double* __restrict__ x, const int* __restrict__ cam_blocks, int nblocks, double* __restrict__ camrec) {
@@ -58,6 +67,22 @@ __device__ __forceinline__ double add_rows(double s, const double* __restrict__ 
     return s;
 }
 
+// ... the same sum from a staging area in LDS, leaner: the loads are unconditional (eight at immediate offsets from one address;
+// up to seven rows behind the segment are read and not used -- GRAD_ROW_SLACK doubles behind the area keep that inside the
+// workgroup's LDS), a row beyond the segment is left out by selecting the sum before it
+template <int STRIDE>
+__device__ __forceinline__ double add_rows_lds(double s, const double* __restrict__ rows, int r0, int r1, int k) {
+    const double* p = rows + r0 * STRIDE + k;
+    for (int n = r1 - r0; n > 0; n -= 8, p += 8 * STRIDE) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = p[j * STRIDE];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double u = s + t[j]; s = j < n ? u : s; }
+    }
+    return s;
+}
+
 // What a lane needs of a chunk, asked for a chunk ahead.  A workgroup meets at two barriers per chunk, so its waves wait
 // for memory together and only the other workgroup of the compute unit fills the gap: every load of a chunk is issued
 // while the chunk before it is evaluated -- first the list's tables (stage 1), then what their entries point to (stage
@@ -105,13 +130,16 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
     double* const acc = rec + (size_t)T.ncam_cap * GRAD_REC;    // [ncam_cap][9]
     // the rows of a chunk: GRAD_ROW_BUFFERS staging areas taken in turn, each [GRAD_LANES][9] camera rows, [GRAD_LANES][3] point rows, [waves] values
     double* const rows0 = acc + (size_t)T.ncam_cap * 9;
-    constexpr int ROWS = GRAD_LANES * 12 + 16;
+    constexpr int ROWS = GRAD_LANES * 12 + 16 + GRAD_ROW_SLACK;
     const int tid = (int)threadIdx.x;
     const int kc = tid % 9, kp = tid % 3;
     for (int tile = blockIdx.x; tile < T.ntiles; tile += gridDim.x) {
         const int c0 = T.tile_cam0[tile], nc = T.tile_cam0[tile + 1] - c0;
         const int ch_begin = T.tile_chunk0[tile], ch_end = T.tile_chunk0[tile + 1];
         GradEntry cur, nxt;
+#ifdef RDIS_GRAD_STAMPS
+        long long tlast = clock64();
+#endif
         grad_stage1(T, ch_begin, tid, cur);
         // the tile's cameras: records in, accumulators cleared
         for (int i = tid; i < nc * GRAD_REC; i += GRAD_LANES) {
@@ -121,6 +149,7 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
         for (int i = tid; i < nc * 9; i += GRAD_LANES) acc[i] = 0.0;
         grad_stage2(x, obs, cur);
         __syncthreads();
+        GRAD_STAMP(5, 0);
         for (int ch = ch_begin; ch < ch_end; ++ch) {
             const bool more = ch + 1 < ch_end;   // (uniform)
             // With two staging areas a chunk needs ONE barrier: the lanes that still add chunk ch's rows have not passed the barrier
@@ -139,8 +168,15 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                 v[0] = v[1] = v[2] = 0.0;   // (not read: the rotation comes from the record)
                 v[3] = a3.y; v[4] = a4.x; v[5] = a4.y; v[6] = a5.x; v[7] = a5.y; v[8] = a6.x;
                 v[9] = cur.x0; v[10] = cur.x1; v[11] = cur.x2;
+#if defined(RDIS_GRAD_ABLATE) && (RDIS_GRAD_ABLATE == 1 || RDIS_GRAD_ABLATE == 4)
+                // (measurement builds only -- wrong results: no factor arithmetic)
+                E = v[9] * cur.o.x + t.c;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) gr[k] = v[k] * cur.o.y;
+#else
                 E = ba_project(v, cur.o.x, cur.o.y, t);
                 ba_adjoint(t, v, t.res0, t.res1, gr);
+#endif
                 double* cr = crow + (int)cur.rc * 9;
                 double* pr = prow + (int)cur.rp * 3;
 #pragma unroll
@@ -148,16 +184,24 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
 #pragma unroll
                 for (int k = 0; k < 3; ++k) pr[k] = gr[9 + k];
             }
+            GRAD_STAMP(0, 0);
             if (more) grad_stage2(x, obs, nxt);
             E = wave_sum(E);
             if ((tid & 63) == 0) red[tid >> 6] = E;
             __syncthreads();
+            GRAD_STAMP(1, 0);
             if (tid == 0) partial[ch] = chunk_sum_of(red);
+#if defined(RDIS_GRAD_ABLATE) && (RDIS_GRAD_ABLATE == 2 || RDIS_GRAD_ABLATE == 4)
+            // (measurement builds only -- wrong results: no segment sums)
+            if (false) {
+#else
+            {
+#endif
             // cameras: lane (segment, k) adds the segment's rows to the camera's accumulator -- its first segment from the
             // registers asked for a chunk ago, further ones (a chunk with more than GRAD_LANES / 9 cameras) from the tables
             if (cur.cs_end > cur.cs.y) {
                 double* a = acc + cur.cs.x * 9 + kc;
-                *a = add_rows<9>(*a, crow, cur.cs.y, cur.cs_end, kc);
+                *a = add_rows_lds<9>(*a, crow, cur.cs.y, cur.cs_end, kc);
             }
             if (cur.extra) {   // (else nothing here waits for global memory: the list bounds are not even looked at)
                 const int s0 = T.chunk_cseg0[ch], ns = T.chunk_cseg0[ch + 1] - s0 - 1;
@@ -166,12 +210,12 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                     const int2 sg = T.cseg[s0 + sidx];
                     const int r1 = T.cseg[s0 + sidx + 1].y;
                     double* a = acc + sg.x * 9 + kc;
-                    *a = add_rows<9>(*a, crow, sg.y, r1, kc);
+                    *a = add_rows_lds<9>(*a, crow, sg.y, r1, kc);
                 }
             }
             // point blocks: lane (segment, k) forms the block's sum of this chunk
             if (cur.ps_end > cur.ps.y) {
-                const double sum = add_rows<3>(0.0, prow, cur.ps.y, cur.ps_end, kp);
+                const double sum = add_rows_lds<3>(0.0, prow, cur.ps.y, cur.ps_end, kp);
                 if (cur.ps.x >= 0) g[cur.ps.x + kp] = sum; else pstage[(size_t)(~cur.ps.x) * 3 + kp] = sum;
             }
             if (cur.extra) {
@@ -180,11 +224,17 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
                     const int sidx = w / 3;
                     const int2 sg = T.pseg[s0 + sidx];
                     const int r1 = T.pseg[s0 + sidx + 1].y;
-                    const double sum = add_rows<3>(0.0, prow, sg.y, r1, kp);
+                    const double sum = add_rows_lds<3>(0.0, prow, sg.y, r1, kp);
                     if (sg.x >= 0) g[sg.x + kp] = sum; else pstage[(size_t)(~sg.x) * 3 + kp] = sum;
                 }
             }
+            }
+            GRAD_STAMP(2, 0);
             if constexpr (GRAD_ROW_BUFFERS < 2) __syncthreads();
+            GRAD_STAMP(3, 0);
+#ifdef RDIS_GRAD_STAMPS
+            if (blockIdx.x == 0 && threadIdx.x == 0) grad_stamps[4] += 1;
+#endif
             if (more) cur = nxt;
         }
         if constexpr (GRAD_ROW_BUFFERS >= 2) __syncthreads();   // (the last chunk's sums are in the accumulators)
@@ -194,6 +244,7 @@ grad_fused_kernel(GradTables T, const double* __restrict__ x, const double2* __r
             if (dest >= 0) g[dest + k] = acc[i]; else cstage[(size_t)(~dest) * 9 + k] = acc[i];
         }
         __syncthreads();
+        GRAD_STAMP(5, 0);
     }
 }
 
@@ -215,6 +266,15 @@ grad_combine_kernel(GradTables T, const double* __restrict__ cstage, const doubl
     }
 }
 
+#ifdef RDIS_GRAD_STAMPS
+}  // namespace rdis_hip
+extern "C" int rdis_hip_debug_grad_stamps(long long* out, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rdis_hip::grad_stamps), sizeof(long long) * 8);
+    if (e == hipSuccess && clear) { long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(rdis_hip::grad_stamps), z, sizeof z); }
+    return (int)e;
+}
+namespace rdis_hip {
+#endif
 hipError_t grad_camera_records_launch(hipStream_t s, int grid, const double* x, const int* cam_blocks, int nblocks, double* camrec) {
     grad_camera_records_kernel<<<grid, 256, 0, s>>>(x, cam_blocks, nblocks, camrec);
     return hipGetLastError();

@@ -32,6 +32,7 @@ namespace rdis_hip {
 #ifndef RDIS_GRAD_LANES
 #define RDIS_GRAD_LANES 512
 #endif
+constexpr int GRAD_ROW_SLACK = 32;             // doubles behind a staging area that its segment sums may read and not use
 constexpr int GRAD_LANES = RDIS_GRAD_LANES;   // entries of a chunk = lanes of a workgroup (eight waves: two per SIMD, two workgroups per compute unit)
 constexpr int GRAD_REC = 14;           // doubles of a camera's record: [v0 v1 v2 theta 1/theta sin cos | t0 t1 t2 f k1 k2 | pad] -- seven
                                        // 16-byte units, an odd number: lanes that read different cameras stand on different LDS banks
@@ -71,7 +72,7 @@ struct GradTables {
 // but 98 KB of rows leave room for one workgroup per compute unit instead of two: 154 -> 256 us at 8e6 factors.  1 is the product.
 constexpr int GRAD_ROW_BUFFERS = RDIS_GRAD_ROW_BUFFERS;
 __host__ __device__ inline size_t grad_lds_bytes(int ncam_cap) {
-    return ((size_t)ncam_cap * (GRAD_REC + 9) + (size_t)GRAD_ROW_BUFFERS * ((size_t)GRAD_LANES * 12 + 16)) * sizeof(double);
+    return ((size_t)ncam_cap * (GRAD_REC + 9) + (size_t)GRAD_ROW_BUFFERS * ((size_t)GRAD_LANES * 12 + 16 + GRAD_ROW_SLACK)) * sizeof(double);
 }
 
 // launches (grad_fused.hip).  camrec: [camera blocks][GRAD_REC]; cstage / pstage: staging arrays of 9 / 3 doubles per slot;

@@ -1697,7 +1697,7 @@ int prepare_partition(rdis_hip_plan* L) {
     L->ptm_wide_wanted = false;
     cvec wide_comp((size_t)L->ncomp, 0);
     auto wide_ptm_ok = [&](int cc) {
-        if (p->kind != KIND_BA || L->ptm_stream == 0 || p->ncam_blocks <= 0 || L->lds_resident == 0 && L->ptm_stream != 2) return false;
+        if (p->kind != KIND_BA || L->ptm_stream == 0 || p->ncam_blocks <= 0 || (L->lds_resident == 0 && L->ptm_stream != 2)) return false;
         if (L->factor_rounding == 1 || L->emulate_stale) return false;   // (instantiated for the cooperative and LDS-resident solvers only)
         const int c0 = L->h_fac_ptr[(size_t)cc], c1 = L->h_fac_ptr[(size_t)cc + 1];
         if (p->h_blk_stamp.empty()) { p->h_blk_stamp.assign((size_t)p->N, 0); p->h_blk_idx.assign((size_t)p->N, 0); }

@@ -35,6 +35,15 @@ dt = (time.perf_counter() - t0) / REPS
 print("rdis_hip_eval_grad_device: %.3f ms per call to issue, %.3f ms per call with the final wait (host clock); algorithmic %.0f MB -> %.0f GB/s"
       % (t_issue * 1e3, dt * 1e3, alg / 1e6, alg / dt / 1e9))
 fd, gd = g.eval_grad_device()
+if hasattr(ctx.lib, "rdis_hip_debug_grad_stamps"):   # (a -DRDIS_GRAD_STAMPS build: cycles of the first workgroup's first wave)
+    import ctypes
+    st = (ctypes.c_longlong * 8)()
+    ctx.lib.rdis_hip_debug_grad_stamps(st, 1)
+    g.eval_grad_device(); ctx.synchronize()
+    ctx.lib.rdis_hip_debug_grad_stamps(st, 0)
+    v = list(st)
+    print("stamps of one call, first wave of the first workgroup: %d chunks; per chunk: factors %.0f, to the first barrier %.0f, segment sums %.0f, "
+          "second barrier %.0f cycles; prologue + epilogue %d" % (v[4], v[0] / max(v[4], 1), v[1] / max(v[4], 1), v[2] / max(v[4], 1), v[3] / max(v[4], 1), v[5]))
 gg = np.frombuffer(ctx.copy_to_host(gd, 8 * huge.nvars), dtype=np.float64)
 print("same bits as the host variant:", bool(np.array_equal(gg, g0)), " f =", f0, " |g|_inf =", float(np.max(np.abs(g0))))
 # a sub-list in another order: tables of its own
