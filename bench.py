@@ -442,7 +442,8 @@ def configs_block(ctx, maxiters: int, cpu: bool):
     ]
     kinds = ("components_cooperative", "components_grid_stream", "components_tiny", "components_lds", "components_point_major", "components_plain")
     rows = []
-    fixtures = {"config 3": "ladybug_5_30_default_path", "config 5": "synthetic_S_default_path"}
+    fixtures = {"config 1": "testpoly_default_path", "config 2": "sinusoid_default_path", "config 3": "ladybug_5_30_default_path",
+                "config 5": "synthetic_S_default_path"}
     for label, make, steps, cpu_sample, ref in cases:
         fixture_key = next((v for k, v in fixtures.items() if label.startswith(k)) if maxiters == 25 else iter(()), None)
         pp = make()
@@ -456,8 +457,9 @@ def configs_block(ctx, maxiters: int, cpu: bool):
                "exit_status_histogram": {capi.EXIT_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(r.status & 0xFF, return_counts=True))},
                "solver": {k[len("components_"):]: int(plan.info(k)) for k in kinds if plan.info(k)}}
         plan.close(); prob.close()
-        # configs 3 and 5-S: the timed default path against the committed CPU fixture (the oracle with the device's factor arithmetic
-        # and the LDS-resident solver's sum trees; tests/golden/make_parity_end_values.py) -- no oracle in this comparison
+        # the timed default path against the committed CPU fixture (the oracle with the device's factor arithmetic and the sums of the
+        # solver the dispatcher picks: the LDS-resident one for configs 3 and 5-S, the plain workgroup solver for configs 1 and 2;
+        # tests/golden/make_parity_end_values.py) -- no oracle in this comparison
         if fixture_key is not None:
             try:
                 with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json")) as fh:

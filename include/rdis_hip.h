@@ -97,7 +97,10 @@ int rdis_hip_upload_ba(rdis_hip_ctx *ctx, int64_t nvars, const double *x0, const
                        const int64_t *pt_vid0, const double *obs, rdis_hip_problem **out);
 /* upload_nlp replaces F NonlinearProductFactor objects
  * (src/NonlinearProductFactor.h:21-113): factor i = coeff[i] * prod over
- * k in [rowptr[i], rowptr[i+1]) of g((x[vid[k]] - cons[k])^expo[k]), g = sin iff sine[k]. */
+ * k in [rowptr[i], rowptr[i+1]) of g((x[vid[k]] - cons[k])^expo[k]), g = sin iff sine[k].
+ * Arithmetic: exponents 0, 1, 2 as the reference special-cases them (src/util/numeric.cpp:12-23), 3 and 4 by multiplication,
+ * others through pow; sine and cosine by the library's own routine of the rotation angle (below 1 ulp) -- last-place differences
+ * from std::pow / std::sin / std::cos, chosen so that a host can compute the same bits. */
 int rdis_hip_upload_nlp(rdis_hip_ctx *ctx, int64_t nvars, const double *x0, const double *lo,
                         const double *hi, int64_t nfac, const double *coeff,
                         const int64_t *rowptr, const int64_t *vid, const double *expo,

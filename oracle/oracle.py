@@ -162,6 +162,8 @@ def lib() -> C.CDLL:
         L.ro_set_sum_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_factor_arithmetic.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+        L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_topology.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
@@ -287,6 +289,24 @@ class OracleProblem:
         o._cams, o._pts = np.ascontiguousarray(cams), np.ascontiguousarray(pts)
         lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), -int(group) if wide else int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
                                   len(pts), o._pts.ctypes.data_as(C.c_void_p), C.addressof(o._fh[2]))
+        return o
+
+    @classmethod
+    def device_wg_default(cls, pp, free_vid=None, fac=None, threads: int = 0):
+        """the CPU side of the == test of the DEFAULT path of BASELINE configs 1 and 2 (nonlinear-product functions: the plain
+        one-workgroup solver, solver_wg.hpp): the device's sine / cosine (factors.hpp for the host: fh_sincos) and its third and
+        fourth power, no stale cache, that solver's sums for a workgroup of `threads` lanes (0: the dispatcher's rule -- by
+        max(factors, variables / 4): 64 up to 64, 128, 256, 512 up to 512, else 768)"""
+        o = cls(pp, emulate_stale_cache=False)
+        fv = np.arange(pp.nvars, dtype=np.int64) if free_vid is None else np.asarray(free_vid, dtype=np.int64)
+        fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
+        if threads == 0:
+            mf = max(len(fc), len(fv) // 4)
+            threads = 64 if mf <= 64 else 128 if mf <= 128 else 256 if mf <= 256 else 512 if mf <= 512 else 768
+        o._fh = factors_host()
+        lib().ro_set_trig(o.h, C.cast(o._fh[0].fh_sincos, C.c_void_p))
+        lib().ro_set_arithmetic(o.h, 4)
+        lib().ro_set_wg_topology(o.h, int(threads))
         return o
 
     def set_cooperative_topology(self, free_vid=None, fac=None, lanes_per_workgroup: int = 128) -> None:

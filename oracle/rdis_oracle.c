@@ -369,11 +369,15 @@ void ro_ba_factor_resjac(const double x[12], double ox, double oy, double res[2]
  * =========================================================================*/
 
 /* rdis::power, src/util/numeric.cpp:12-23 */
-static double nlp_power(double val, double e)
+static double nlp_power_arith(double val, double e, int arith)
 {
     if (e == 0.) return 1.;
     if (e == 1.) return val;
     if (e == 2.) return val * val;
+    if (arith & RO_ARITH_POW_SMALL_INT) {   /* the device's third and fourth power (factors.hpp: nlp_power) */
+        if (e == 3.) return val * val * val;
+        if (e == 4.) { const double q = val * val; return q * q; }
+    }
     return pow(val, e);
 }
 
@@ -410,6 +414,7 @@ struct ro_problem {
     int ptm_wide;                     /* ... as a wide group: one entry of the exchange a workgroup */
     int64_t ptm_ncb, ptm_npb, *ptm_cam, *ptm_pt;
     const ro_ptm_arith *ptm_ar;
+    void (*trig)(double x, double *sn, double *cs);   /* ro_set_trig: sine and cosine of the nonlinear-product factors from outside, or NULL */
     struct ptm_tab *ptm;
     int ptm_at_start;                 /* the value asked for is the rollback's (other lanes take the factors) */
     int sum_order;    /* RO_SUM_LIST (default: the reference's order) or RO_SUM_PAIRWISE */
@@ -884,6 +889,29 @@ void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, con
     p->ptm_pt = dup_mem(pt_vid0, sizeof(int64_t) * (size_t)npb);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RO_SUM_TOPOLOGY_WG: the sums of the device's plain one-workgroup solver (rdis_amd/csrc/solver_wg.hpp: cgd_wg_kernel, nt lanes --
+ * where BASELINE configs 1 and 2, the nonlinear-product functions, run), restated entry for entry:
+ *   values   lane l adds the listed factors l, l + nt, ... from 0.0; waves and workgroup as trees (lds_tree_sum);
+ *   slope    per factor sum_k (d_k c) dir_k over its variables in row order, each step one fused multiply-add, from 0.0; the
+ *            factors' terms added like the values;
+ *   gradient a variable's partials in factor-list order like the reference, the first copied -- unless more than 64 listed
+ *            partials feed it: then strided over a wave (lane l: l, l + 64, ... from 0.0; a wave sum);
+ *   gg, dgg  lane l adds the terms of the free variables l, l + nt, ...; the trees of the values.
+ * Nonlinear-product problems only. */
+void ro_set_wg_topology(ro_problem *p, int nt)
+{
+    ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
+    p->topo = RO_SUM_TOPOLOGY_WG;
+    p->lds_nt = nt;
+}
+
+void ro_set_trig(ro_problem *p, void (*sincos_fn)(double x, double *sn, double *cs))
+{
+    p->trig = sincos_fn;
+    if (p->fdirty) memset(p->fdirty, 1, (size_t)p->nfac);
+}
+
 void ro_set_sum_topology(ro_problem *p, int kind, int64_t nwave_owned, const int64_t *wave_vid)
 {
     free(p->wave_vid); free(p->wave_of);
@@ -941,6 +969,21 @@ static void gather_ba(const ro_problem *p, int64_t f, double vals[12])
     vals[9] = q[0]; vals[10] = q[1]; vals[11] = q[2];
 }
 
+static double nlp_sin(const ro_problem *p, double v)
+{
+    if (!p->trig) return sin(v);
+    double sn, cs;
+    p->trig(v, &sn, &cs);
+    return sn;
+}
+static double nlp_cos(const ro_problem *p, double v)
+{
+    if (!p->trig) return cos(v);
+    double sn, cs;
+    p->trig(v, &sn, &cs);
+    return cs;
+}
+
 /* NonlinearProductFactor::evalFactor (src/NonlinearProductFactor.cpp:186-209; the same arithmetic as
  * evalFactorNoCache, :119-145), with useExponential (:140, :204) */
 static double nlp_eval(const ro_problem *p, int64_t f)
@@ -949,8 +992,8 @@ static double nlp_eval(const ro_problem *p, int64_t f)
     for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) {
         double val = p->x[p->vid[k]];
         if (p->cons[k] != 0) val -= p->cons[k];
-        if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
-        if (p->sine[k]) val = sin(val);
+        if (p->expo[k] != 1) val = nlp_power_arith(val, p->expo[k], p->arith);
+        if (p->sine[k]) val = nlp_sin(p, val);
         prod *= val;
     }
     if (p->useexp && p->useexp[f]) prod = exp(-prod);
@@ -967,15 +1010,15 @@ static double nlp_deriv(const ro_problem *p, int64_t f, int64_t wrt)
         if (p->vid[k] == wrt) {
             if (p->expo[k] == 1 && !p->sine[k]) continue; /* d/dx (x-k) = 1 */
             val -= p->cons[k];
-            const double inner_e = nlp_power(val, p->expo[k]);
-            val = nlp_power(val, p->expo[k] - 1.0);
+            const double inner_e = nlp_power_arith(val, p->expo[k], p->arith);
+            val = nlp_power_arith(val, p->expo[k] - 1.0, p->arith);
             val *= p->expo[k];
-            if (p->sine[k]) val *= cos(inner_e);
+            if (p->sine[k]) val *= nlp_cos(p, inner_e);
             prod *= val;
         } else {
             if (p->cons[k] != 0) val -= p->cons[k];
-            if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
-            if (p->sine[k]) val = sin(val);
+            if (p->expo[k] != 1) val = nlp_power_arith(val, p->expo[k], p->arith);
+            if (p->sine[k]) val = nlp_sin(p, val);
             prod *= val;
         }
     }
@@ -1025,7 +1068,7 @@ static void nlp_bounds(const ro_problem *p, int64_t f, double *vb, double *gb)
         double val = p->x[p->vid[k]];
         double r = 1.0 + p->expo[k];
         if (p->cons[k] != 0) { const double d = val - p->cons[k]; r += (fabs(val) + fabs(p->cons[k])) / fabs(d); val = d; }
-        if (p->expo[k] != 1) val = nlp_power(val, p->expo[k]);
+        if (p->expo[k] != 1) val = nlp_power_arith(val, p->expo[k], p->arith);
         if (p->sine[k]) {
             const double sn = fabs(sin(val)), cs = fabs(cos(val));
             const double m = sn < cs ? sn : cs;   /* the derivative has the cosine */
@@ -1095,10 +1138,10 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
      * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
     if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
     if (p->topo == RO_SUM_TOPOLOGY_PTM && p->ptm && p->ptm->nf == nf && p->ptm->fac == fac) return ptm_eval(p, NULL, NULL);
-    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS) {
+    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS || p->topo == RO_SUM_TOPOLOGY_WG) {
         double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
         for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
-        const double r = p->topo == RO_SUM_TOPOLOGY_LDS ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
+        const double r = p->topo != RO_SUM_TOPOLOGY_COOPERATIVE ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
         free(vals);
         return r;
     }
@@ -1165,7 +1208,7 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
         memset(g, 0, sizeof(double) * (size_t)p->nvars);
         /* RO_SUM_TOPOLOGY_COOPERATIVE: the runs of the wave-owned variables are kept and added the device's way afterwards */
         double **run = NULL; int64_t *rlen = NULL, *rcap = NULL;
-        if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE && p->nwave_owned > 0) {
+        if ((p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_WG) && p->nwave_owned > 0) {
             run = calloc((size_t)p->nwave_owned, sizeof(double *));
             rlen = calloc((size_t)p->nwave_owned, sizeof(int64_t));
             rcap = calloc((size_t)p->nwave_owned, sizeof(int64_t));
@@ -1727,6 +1770,35 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
     free(li); free(wa); free(wb);
 }
 
+/* RO_SUM_TOPOLOGY_WG: a trial's slope in the plain workgroup solver, nonlinear-product factors */
+static double sub_slope_wg(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
+    double *terms = malloc(sizeof(double) * (size_t)(S->nf + 1));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    for (int64_t i = 0; i < S->nf; ++i) {
+        const int64_t f = S->fac ? S->fac[i] : i;
+        double acc = 0.0;
+        for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) acc = fma(nlp_deriv(p, f, p->vid[k]), dir[p->vid[k]], acc);
+        terms[i] = acc;
+    }
+    const double s = lds_tree_sum(terms, S->nf, p->lds_nt);
+    free(terms); free(dir);
+    return s;
+}
+
+static void sub_cg_sums_wg(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
+{
+    sub_t *S = ctx;
+    double *a = malloc(sizeof(double) * (size_t)(n + 1)), *b = malloc(sizeof(double) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) { a[i] = g[i] * g[i]; b[i] = (xi[i] + g[i]) * xi[i]; }
+    *gg = lds_tree_sum(a, n, S->p->lds_nt);
+    *dgg = lds_tree_sum(b, n, S->p->lds_nt);
+    free(a); free(b);
+}
+
 /* ... and gg, dgg: lane i carries variable i's terms unless a wave owns it, wave w's first lane those of its variable */
 static void sub_cg_sums_topology(void *ctx, int n, const double *g, const double *xi, double *gg, double *dgg)
 {
@@ -1790,6 +1862,25 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
         memset(&hk, 0, sizeof hk);
         hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_topology;
         g_slope_topology = sub_slope_topology;
+        reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+        g_slope_topology = 0;
+    } else if (p->topo == RO_SUM_TOPOLOGY_WG && p->kind == RO_KIND_NLP) {
+        /* the variables fed by more than 64 listed partials: their runs strided over a wave (solver_wg.hpp: WG_LONG_LIST) */
+        int64_t *cnt = calloc((size_t)p->nvars + 1, sizeof(int64_t)), nlong = 0;
+        for (int64_t i = 0; i < nf; ++i) {
+            const int64_t f = fac ? fac[i] : i;
+            for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) cnt[p->vid[k]]++;
+        }
+        int64_t *lv = malloc(sizeof(int64_t) * (size_t)(nfree + 1));
+        for (int64_t i = 0; i < nfree; ++i) if (cnt[free_vid[i]] > 64) lv[nlong++] = free_vid[i];
+        const int nt = p->lds_nt;
+        ro_set_sum_topology(p, RO_SUM_TOPOLOGY_COOPERATIVE, nlong, lv);   /* (borrows the wave-owned variables' bookkeeping) */
+        p->topo = RO_SUM_TOPOLOGY_WG; p->lds_nt = nt;
+        free(cnt); free(lv);
+        ro_hooks hk;
+        memset(&hk, 0, sizeof hk);
+        hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_wg;
+        g_slope_topology = sub_slope_wg;
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
         g_slope_topology = 0;
     } else if (p->topo == RO_SUM_TOPOLOGY_PTM && p->kind == RO_KIND_BA && p->ext && p->ptm_ar) {

@@ -68,6 +68,7 @@ enum { RO_BA_DERIV_REFCHAIN = 0, RO_BA_DERIV_ADJOINT = 1, RO_BA_DERIV_ADJOINT_DE
  * All off = the reference's arithmetic = what every pin of this oracle is made with. */
 #define RO_ARITH_RECIPROCAL 1
 #define RO_ARITH_SINCOS_ANGLE 2
+#define RO_ARITH_POW_SMALL_INT 4   /* nonlinear-product factors: x^3 = x x x, x^4 = (x x)(x x) (the device; the reference: std::pow) */
 void ro_sincos_angle(double x, double *sn, double *cs);
 /* value + 12 partials with all three switches on: what one lane of the device's parity option computes */
 double ro_ba_factor_grad_device(const double vals[12], double obsx, double obsy, double grad[12]);
@@ -133,6 +134,14 @@ typedef struct {
 } ro_factor_arith;
 void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext);   /* ext must outlive the problem's use; NULL: built in */
 void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid);
+/* RO_SUM_TOPOLOGY_WG: the sums of the device's plain one-workgroup solver (solver_wg.hpp: cgd_wg_kernel, nt lanes) on a
+ * nonlinear-product problem -- BASELINE configs 1 and 2 --, restated entry for entry (rdis_oracle.c).  The device's factor
+ * arithmetic there differs from the reference's in two named places: sine and cosine (factors.hpp: nlp_sin / nlp_cos, the routine
+ * of the rotation angle, fused; plugged in from outside with ro_set_trig -- tests/cpp/factors_host.hip: fh_sincos) and the third and
+ * fourth power by multiplication (RO_ARITH_POW_SMALL_INT) where the reference calls std::pow. */
+#define RO_SUM_TOPOLOGY_WG 4
+void ro_set_wg_topology(ro_problem *p, int nt);
+void ro_set_trig(ro_problem *p, void (*sincos_fn)(double x, double *sn, double *cs));
 /* RO_SUM_TOPOLOGY_PTM: the sums of the device's point-major streaming solver (solver_ptm.hpp: a workgroup of nt lanes a component
  * whose camera blocks stay in LDS while its point blocks stream -- BASELINE config 5-L), restated entry for entry (rdis_oracle.c).
  * cam_vid0 / pt_vid0: the component's camera blocks (ascending) and point blocks in the plan's order (by number of listed factors

@@ -462,26 +462,44 @@ __device__ __forceinline__ void ba_residual_jacobian(const double (&x)[12], doub
 }
 
 // ---- nonlinear product factor -------------------------------------------------
-__device__ __forceinline__ double nlp_power(double v, double e) {
+// (round 6) Two last-place differences from the reference's std::pow / std::sin / std::cos, so that a CPU can compute what the device
+// computes (the tests' CPU checker has both as named switches): the third and fourth power by multiplication, and sine /
+// cosine by sincos_angle above (below 1 ulp, one source for host and device) instead of the device library's routines, whose bits no
+// host library promises.
+__host__ __device__ __forceinline__ double nlp_power(double v, double e) {
     if (e == 0.0) return 1.0;
     if (e == 1.0) return v;
     if (e == 2.0) return v * v;
+    if (e == 3.0) return v * v * v;
+    if (e == 4.0) { const double q = v * v; return q * q; }
     return pow(v, e);
 }
+__host__ __device__ __forceinline__ double nlp_sin(double v) {
+    if (!(fabs(v) < 1.0e6)) return sin(v);
+    double sn, cs;
+    sincos_angle(v, &sn, &cs);
+    return sn;
+}
+__host__ __device__ __forceinline__ double nlp_cos(double v) {
+    if (!(fabs(v) < 1.0e6)) return cos(v);
+    double sn, cs;
+    sincos_angle(v, &sn, &cs);
+    return cs;
+}
 
-__device__ __forceinline__ double nlp_term(double v, double e, double k, bool sine) {
+__host__ __device__ __forceinline__ double nlp_term(double v, double e, double k, bool sine) {
     if (k != 0.0) v -= k;
     if (e != 1.0) v = nlp_power(v, e);
-    if (sine) v = sin(v);
+    if (sine) v = nlp_sin(v);
     return v;
 }
 
 // d/dx of one term; `skip` reproduces the reference's "exponent 1, no sine => 1"
-__device__ __forceinline__ double nlp_dterm(double v, double e, double k, bool sine) {
+__host__ __device__ __forceinline__ double nlp_dterm(double v, double e, double k, bool sine) {
     v -= k;
     const double inner_e = nlp_power(v, e);
     double d = nlp_power(v, e - 1.0) * e;
-    if (sine) d *= cos(inner_e);
+    if (sine) d *= nlp_cos(inner_e);
     return d;
 }
 

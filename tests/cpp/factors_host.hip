@@ -57,6 +57,8 @@ double fh_trial(const double* TR, const double* DR, const double* q, const doubl
     if (slope && DR) *slope = ba_trial_slope<false>(t, tr, dr, qq, ee);
     return v;
 }
+// the nonlinear-product factors' sine and cosine (factors.hpp: nlp_sin / nlp_cos -- sincos_angle with the default contraction)
+void fh_sincos(double x, double* sn, double* cs) { *sn = nlp_sin(x); *cs = nlp_cos(x); }
 void fh_eval_grad_each(long long n, const double* x12, const double* obs2, double* f, double* g12) {
     for (long long i = 0; i < n; ++i) f[i] = fh_eval_grad(x12 + 12 * i, obs2[2 * i], obs2[2 * i + 1], g12 + 12 * i);
 }

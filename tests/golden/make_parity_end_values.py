@@ -69,6 +69,17 @@ r = O.OracleProblem.device_ptm_default(pp).cgd(x=pp.x0, maxiters=25)
 out["ladybug_full_point_major_path"] = {
     "ncams": 0, "npts": 0, "maxiters": 25, "emulate_stale_cache": False, "sum_topology": "point-major, 768 lanes", "fret": r.fret, "delta": r.delta,
     "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:3]), "x_last": float(r.x[-1])}
+# ... and the DEFAULT path of configs 1 and 2 (nonlinear-product functions on the plain one-workgroup solver): the device's sine /
+# cosine (factors.hpp for the host), its third and fourth power by multiplication, that solver's sums (RO_SUM_TOPOLOGY_WG)
+import numpy as np                           # noqa: E402
+with open(os.path.join(ROOT, "tests", "golden", "sinusoid_start.json")) as fh:
+    sin_x0 = np.array(json.load(fh)["x0"])
+for key, pp in (("testpoly_default_path", P.load_poly().single_component()), ("sinusoid_default_path", P.make_high_dim_sinusoid().single_component())):
+    if key.startswith("sinusoid"):
+        pp.x0 = sin_x0
+    r = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
+    out[key] = {"maxiters": 25, "emulate_stale_cache": False, "sum_topology": "plain workgroup solver", "fret": r.fret, "delta": r.delta,
+                "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:2]), "x_last": float(r.x[-1])}
 with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps({k: (v if k != "synthetic_S_default_path" else "1000 components") for k, v in out.items()}, indent=1))

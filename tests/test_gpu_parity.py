@@ -20,6 +20,8 @@ and the tests below assert fret, x, iterations and the f / df call counts with =
 config 3 (LDS-resident solver) and config 4 (cooperative solver, plain layout).  With the three off it is the
 reference-pinned oracle (83227.604227756252 ...): tests/test_oracle.py::test_device_arithmetic_switches_are_the_only_difference.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -222,7 +224,7 @@ def test_fused_factor_arithmetic_is_reproduced_by_the_host_compile(gctx):
     for the HOST by the same front end (tests/cpp/factors_host.hip, -mfma -ffp-contract=on) gives the device's bits: every factor
     of ladybug, value and twelve partials, at three points."""
     import ctypes as C
-    L, _ = O.factors_host()
+    L = O.factors_host()[0]
     pp = P.load_bal().single_component()
     g = capi.Problem(gctx, pp)
     rng = np.random.default_rng(1)
@@ -379,3 +381,37 @@ def test_wide_point_major_group_equals_the_oracle(gctx, case):
     want = O.OracleProblem.device_ptm_default(pp, threads=nt, group=K, wide=True).cgd(x=pp.x0, maxiters=25)
     assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (K, r.fret[0], want.fret)
     assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+def _sinusoid_from_the_committed_start():
+    import json
+    pp = P.make_high_dim_sinusoid()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sinusoid_start.json")) as fh:
+        pp.x0 = np.array(json.load(fh)["x0"])
+    return pp.single_component()
+
+
+@pytest.mark.parametrize("case", ["config 1: testpoly", "config 2: sinusoid, the bench's start", "sinusoid from its own x0", "sinusoid, moved starts"])
+def test_default_path_of_the_nonlinear_product_configs_equals_the_oracle(gctx, case):
+    """BASELINE configs 1 and 2 as bench.py runs them -- no option set: the plain one-workgroup solver (solver_wg.hpp) on
+    nonlinear-product factors -- against the oracle with the device's sine / cosine plugged in (ro_set_trig: factors.hpp's nlp_sin /
+    nlp_cos compiled for the host), its third and fourth power (RO_ARITH_POW_SMALL_INT) and that solver's sums
+    (RO_SUM_TOPOLOGY_WG): fret, delta, x, iterations, status and call counts ==."""
+    if case.startswith("config 1"):
+        starts = [P.load_poly().single_component()]
+    elif case.startswith("config 2"):
+        starts = [_sinusoid_from_the_committed_start()]
+    elif case == "sinusoid from its own x0":
+        starts = [P.make_high_dim_sinusoid().single_component()]
+    else:
+        starts = []
+        for seed in range(4):
+            pp = _sinusoid_from_the_committed_start()
+            pp.x0 = pp.x0 * (1 + 1e-9 * np.random.default_rng(seed).standard_normal(pp.nvars))
+            starts.append(pp)
+    for pp in starts:
+        plan, r = _default_path(gctx, pp, 25, x=pp.x0)
+        assert plan.info("components_plain") == 1
+        want = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
+        assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (case, r.fret[0], want.fret)
+        assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)

@@ -401,6 +401,37 @@ def test_point_major_topology_reproduces_its_fixture():
     assert abs(r0.finit - ref.eval(fc)) <= 1e-11 * abs(r0.finit)
 
 
+def test_plain_solver_topology_reproduces_the_nonlinear_product_fixtures():
+    """BASELINE configs 1 and 2 (testpoly; the high-dimensional sinusoid from the committed start): the oracle with the device's sine
+    / cosine (factors.hpp's nlp_sin / nlp_cos compiled for the host, ro_set_trig), its third and fourth power by multiplication
+    (RO_ARITH_POW_SMALL_INT) and the plain workgroup solver's sums (RO_SUM_TOPOLOGY_WG) ends where
+    tests/golden/parity_end_values.json says -- what the device returns under -m gpu and what the bench line's configs rows compare
+    with.  The device's sine agrees with the C library's to an ulp."""
+    import ctypes as C
+    import json
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc to compile factors.hpp for the host")
+    here = os.path.dirname(__file__)
+    with open(os.path.join(here, "golden", "parity_end_values.json")) as fh:
+        fx = json.load(fh)
+    with open(os.path.join(here, "golden", "sinusoid_start.json")) as fh:
+        sin_x0 = np.array(json.load(fh)["x0"])
+    for key, pp in (("testpoly_default_path", P.load_poly().single_component()), ("sinusoid_default_path", P.make_high_dim_sinusoid().single_component())):
+        if key.startswith("sinusoid"):
+            pp.x0 = sin_x0
+        w = fx[key]
+        r = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
+        assert (r.fret, r.delta, r.iters, r.status, r.nfeval, r.ngeval) == (w["fret"], w["delta"], w["iters"], w["status"], w["nfeval"], w["ngeval"]), key
+        assert list(r.x[:2]) == w["x_0_2"] and r.x[-1] == w["x_last"]
+    L = O.factors_host()[0]
+    L.fh_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    sn, cs = C.c_double(), C.c_double()
+    for v in np.random.default_rng(0).uniform(-70.0, 70.0, 2000):
+        L.fh_sincos(float(v), C.byref(sn), C.byref(cs))
+        assert abs(sn.value - np.sin(v)) <= 2.3e-16 and abs(cs.value - np.cos(v)) <= 2.3e-16
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
