@@ -164,6 +164,7 @@ def lib() -> C.CDLL:
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
+        L.ro_set_ptm_round_slots.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_ptm_topology.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
@@ -276,7 +277,8 @@ class OracleProblem:
         return o
 
     @classmethod
-    def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2, wide: bool = False):
+    def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2, wide: bool = False,
+                           round_slots: int = 0, lds_limit: int = 160 * 1024 - 4096):
         """the CPU side of the == test of the DEFAULT point-major streaming path (BASELINE config 5-L: a component too large for the
         LDS-resident solver, one workgroup of `threads` lanes, or a group of `group` of them; wide: one large component on a large share of the device, groups of up
         to 512 workgroups of 512 lanes, without local camera numbering): the device's own factor arithmetic (factors_host(): the vector form
@@ -289,6 +291,13 @@ class OracleProblem:
         o._cams, o._pts = np.ascontiguousarray(cams), np.ascontiguousarray(pts)
         lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), -int(group) if wide else int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
                                   len(pts), o._pts.ctypes.data_as(C.c_void_p), C.addressof(o._fh[2]))
+        if round_slots == 0:
+            # rdis_hip.hip ptm_round_slots_for: a gradient round stages two slots where the LDS holds 2 x threads rows of nine doubles
+            # beside the cameras' vectors and records (ptm_api.hpp: ptm_bytes_for) -- workgroups of up to 512 lanes only; those of 256 stand two to a compute unit
+            ncb = len(cams)
+            lds = ncb * 10 * (7 * 8 + 4) + ncb * (10 + 2 * 18) * 8 + (2 * threads + 1) * 72 + ((2 * ((ncb + 2) & ~1) * 2 + 7) & ~7) + 64
+            round_slots = 2 if threads <= 512 and (2 if threads <= 256 else 1) * lds <= lds_limit else 1
+        lib().ro_set_ptm_round_slots(o.h, int(round_slots))
         return o
 
     @classmethod

@@ -412,6 +412,7 @@ struct ro_problem {
      * and point blocks (first variable ids) in the solver's order, the trial arithmetic in matrix form; ptm: tables of the solve at hand */
     int ptm_nt, ptm_blk, ptm_K;       /* ... K workgroups share the component */
     int ptm_wide;                     /* ... as a wide group: one entry of the exchange a workgroup */
+    int ptm_round_slots;              /* slots a gradient round stages: 1, or 2 (a block of slots) */
     int64_t ptm_ncb, ptm_npb, *ptm_cam, *ptm_pt;
     const ro_ptm_arith *ptm_ar;
     void (*trig)(double x, double *sn, double *cs);   /* ro_set_trig: sine and cosine of the nonlinear-product factors from outside, or NULL */
@@ -665,7 +666,9 @@ void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *s
  *   rollback the value at clamp(x_start): wave w takes the chunks w, w + waves, ... whole (eval_start);
  *   gradient a point variable's partials in factor-list order like the reference (the first copied).  A camera variable's: wave w
  *            takes the chunks w, w + waves, ..., slot by slot -- its sequence of steps; round r is every wave's r-th step; a
- *            camera's entry adds, from 0.0, round by round, the partials of the round's factors of that camera by wave, then lane;
+ *            camera's entry adds, from 0.0, round by round, the partials of the round's factors of that camera by wave, then lane.
+ *            With two slots a round (ro_set_ptm_round_slots: where the device's LDS holds the staging rows) a step is a block of
+ *            up to two slots of one chunk, and within a round the first slots come first, then the second ones;
  *   gg, dgg  a lane adds the terms of its blocks' variables as the blocks are finished (the chunks with factors first, then those
  *            without), then those of the camera slots tid, tid + nt, ... (ten slots a camera: [t f k1 k2 | r | pad]); then the
  *            trees of the trials.
@@ -844,22 +847,25 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
     const int64_t ncb = p->ptm_ncb, npb = p->ptm_npb;
     const int nw = p->ptm_nt / 64, K = p->ptm_K;
     double *tot = calloc(9 * (size_t)(ncb + 1), sizeof(double)), *acc = malloc(sizeof(double) * 9 * (size_t)(ncb + 1));
+    const int rs = p->ptm_round_slots == 2 ? 2 : 1;
     int64_t *sptr = calloc((size_t)nw + 1, sizeof(int64_t));
     int64_t *sch = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1)), *sslot = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1));
     for (int rk = 0; rk < K; ++rk) {   /* a workgroup's partial sums; the workgroups' then in rank order */
         int64_t nrounds = 0, at = 0;
-        for (int w = 0; w < nw; ++w) {   /* a wave's steps: (chunk, slot) pairs */
+        for (int w = 0; w < nw; ++w) {   /* a wave's steps: (chunk, first slot) -- one slot, or a block of up to rs slots of one chunk */
             sptr[w] = at;
             for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw)
-                for (int64_t t = 0; t < (T->cp[ch + 1] - T->cp[ch]) / 64; ++t) { sch[at] = ch; sslot[at] = t; ++at; }
+                for (int64_t t = 0; t < (T->cp[ch + 1] - T->cp[ch]) / 64; t += rs) { sch[at] = ch; sslot[at] = t; ++at; }
             if (at - sptr[w] > nrounds) nrounds = at - sptr[w];
         }
         sptr[nw] = at;
         for (int64_t k = 0; k < 9 * ncb; ++k) acc[k] = 0.0;
         for (int64_t rr = 0; rr < nrounds; ++rr)
+            for (int sl = 0; sl < rs; ++sl)   /* (within a camera: the round's first slots by wave and lane, then its second slots) */
             for (int w = 0; w < nw; ++w) {
                 if (rr >= sptr[w + 1] - sptr[w]) continue;
-                const int64_t ch = sch[sptr[w] + rr], t = sslot[sptr[w] + rr];
+                const int64_t ch = sch[sptr[w] + rr], t = sslot[sptr[w] + rr] + sl;
+                if (t >= (T->cp[ch + 1] - T->cp[ch]) / 64) continue;
                 for (int l = 0; l < 64; ++l) {
                     const int64_t b = 64 * ch + l;
                     if (b >= npb || t >= T->pptr[b + 1] - T->pptr[b]) continue;
@@ -875,9 +881,15 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
     free(acc); free(tot); free(sptr); free(sch); free(sslot);
 }
 
+void ro_set_ptm_round_slots(ro_problem *p, int round_slots)
+{
+    p->ptm_round_slots = round_slots;
+}
+
 void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, const int64_t *cam_vid0, int64_t npb, const int64_t *pt_vid0,
                          const ro_ptm_arith *ar)
 {
+    p->ptm_round_slots = 1;
     p->ptm_wide = K < 0;   /* (K < 0: -K workgroups as a wide group) */
     K = K < 0 ? -K : K;
     p->ptm_K = K < 1 ? 1 : K;

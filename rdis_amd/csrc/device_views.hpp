@@ -98,6 +98,7 @@ struct PlanView {
     const unsigned short* pm_rounds;   // per round ptm_round_stride(ncb) 16-bit words: per camera the first row of its segment [ncb + 1]
     const long long* pm_rd_off;        // [ncomp * K] a workgroup's first word in pm_rounds ...
     const int* pm_rd_n;                // ... and its number of rounds
+    int pm_round_slots;                // slots a round evaluates and stages (1 or 2): what the tables above were built for
     // a trial's work by wave (solver_ptm.hpp: eval_line): rows (wave-chunk, first entry, end entry); wave w of workgroup
     // (component, rank) takes the rows w, w + waves, w + 2 waves, ... up to the first empty one.  A workgroup's table:
     // its number of rows R and three ints of nothing, then the rows' chunks [R], first entries [R], end entries [R]

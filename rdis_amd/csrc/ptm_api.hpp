@@ -18,6 +18,7 @@ constexpr int PT_BND = 6;    // ... its bounds: lo[3], hi[3] -- floats rounded i
 #endif
 constexpr int PTM_BLK = RDIS_PTM_BLK;  // slots of a point block asked for (and evaluated) together; pm_cam / pm_obs are padded by 64 (PTM_BLK - 1) entries
 constexpr int PTM_CAM_VECTORS = 7;     // LDS vectors over the camera slots: Pv, XI, LO, HI, X and g, h of the Polak-Ribiere recurrence
+constexpr int PTM_PAIR_MAX_THREADS = 512;   // the largest workgroup whose gradient rounds may stage two slots (solver_ptm.hpp: PAIR)
 constexpr int PTM_SPREAD = 16;         // a component's wave-chunks of equal slot count are dealt out over this many runs of the camera-sorted order
 constexpr int PTM_MAX_GROUP = 16;      // workgroups per component of a launch of many groups (SMALL_COOP_ENTRIES / 12 waves, rounded down to a power of two)
 constexpr int PTM_MAX_CAMERAS = 4095;  // camera blocks per component (twelve bits of a factor's slot word; two bytes in the trial stream)
@@ -38,9 +39,10 @@ __host__ __device__ inline int ptm_round_stride(int ncb) { return (ncb + 2) & ~1
 
 // LDS of a workgroup: [7 vectors of 10 ncb_cap camera slots][10 ncb_cap rotation records][2 x 18 ncb_cap trial records (factors.hpp)][(threads + 1) x 9 staged camera
 // partials][two round tables][10 ncb_cap free indices (int)]
-__host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads) {
+// (round_slots: the slots a gradient round stages, 1 or 2 -- solver_ptm.hpp: rs)
+__host__ __device__ inline size_t ptm_bytes_for(int ncb, int threads, int round_slots = 1) {
     return (size_t)ncb * PTM_CS * (PTM_CAM_VECTORS * sizeof(double) + sizeof(int)) + (size_t)ncb * (PTM_RS + 2 * PTM_TS) * sizeof(double) +
-           (size_t)(threads + 1) * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
+           (size_t)(round_slots * threads + 1) * 9 * sizeof(double) + (((size_t)2 * ptm_round_stride(ncb) * sizeof(unsigned short) + 7) & ~(size_t)7) + 64;
 }
 
 struct PtmGroupArgs {

@@ -280,7 +280,8 @@ struct rdis_hip_plan {
     int64_t pm_cptr_len = 0;          // entries of pm_cptr (a component's wave-chunks + 1)
     // the gradient's round lists (solver_ptm.hpp), built for one workgroup size and group size at a time (ptm_build_rounds)
     DevBuf pm_rounds, pm_rd_off, pm_rd_n, pm_grow, pm_segs, pm_sg_off;
-    int rounds_threads = 0, rounds_K = 0;
+    int rounds_threads = 0, rounds_K = 0, rounds_slots = 1;   // (slots a round stages: ptm_round_slots_for)
+    int ptm_round_slots = 0;          // option "ptm_round_slots": 0 = two where the LDS holds their staging rows, 1, 2
     // ... shared by several workgroups each (cgd_ptmg_kernel) when a launch has fewer components than compute units
     int ptm_group = 0;                // option "ptm_group": 0 = auto, 1 = never, k = k workgroups per component
     int ptm_last_group = 1;           // what the last solve used (rdis_hip_plan_debug_counters has no slot for it: get_option)
@@ -368,7 +369,7 @@ struct rdis_hip_plan {
         v.st_ev = emulate_stale ? st_ev.as<int>() : nullptr; v.st_val = emulate_stale ? st_val.as<double>() : nullptr;
         v.pm_pt0 = li + off_pm_pt0; v.pm_ch0 = li + off_pm_ch0; v.pm_cptr = li + off_pm_cptr;
         v.pm_rec = pm_rec.as<double>(); v.pm_gh = pm_gh.as<double>(); v.pm_cbox = pm_cbox.as<float>(); v.pm_bex = pm_bex.as<double>(); v.pm_cam = pm_cam.as<short>(); v.pm_obs = pm_obs.as<double2>();
-        v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>();
+        v.pm_grow = pm_grow.as<unsigned short>(); v.pm_rounds = pm_rounds.as<unsigned short>(); v.pm_rd_off = pm_rd_off.as<long long>(); v.pm_rd_n = pm_rd_n.as<int>(); v.pm_round_slots = rounds_slots;
         v.pm_segs = pm_segs.as<int>(); v.pm_sg_off = pm_sg_off.as<long long>();
         v.seq_val = seq_val.as<double>(); v.seq_ab = seq_ab.as<double>(); v.seq_n = (int)nfree;
         v.timing = prob->coop_timing.as<long long>();
@@ -1544,6 +1545,11 @@ extern "C" int rdis_hip_plan_set_option(rdis_hip_plan* L, const char* name, int6
         if (value < 0 || value > PTM_WIDE_MAX_GROUP) return fail(c, RDIS_HIP_EINVAL, "ptm_group must be 0 (auto), 1 (never) or the number of workgroups per component (at most 16; up to 512 for the wide groups of a few large components)");
         L->ptm_group = (int)value;
         return 0;   // (no table depends on it)
+    } else if (n == "ptm_round_slots") {
+        if (value < 0 || value > 2) return fail(c, RDIS_HIP_EINVAL, "ptm_round_slots must be 0 (two where the LDS holds them), 1 or 2");
+        L->ptm_round_slots = (int)value;
+        L->rounds_threads = L->rounds_K = 0;   // (the round tables are built for one choice)
+        return 0;
     } else if (n == "ptm_threads") {
         if (value != 0 && value != 256 && value != 512 && value != 768) return fail(c, RDIS_HIP_EINVAL, "ptm_threads must be 0, 256, 512 or 768");
         L->ptm_threads = (int)value;
@@ -2411,14 +2417,22 @@ static int ptm_build_segments(rdis_hip_plan* L, int threads, int K) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+// the slots a gradient round evaluates and stages (solver_ptm.hpp: rs): two -- a whole block of slots -- where the LDS holds 2 x threads
+// staging rows beside the cameras, else one
+static int ptm_round_slots_for(const rdis_hip_plan* L, int threads) {
+    if (L->ptm_round_slots == 1 || PTM_BLK != 2 || threads > PTM_PAIR_MAX_THREADS) return 1;
+    // (workgroups of 256 lanes stand two to a compute unit: both must keep their place)
+    return (size_t)(threads <= 256 ? 2 : 1) * ptm_bytes_for(L->ptm_ncb_cap, threads, 2) <= (size_t)L->prob->ctx->lds_limit ? 2 : 1;
+}
 int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     rdis_hip_ctx* c = L->prob->ctx;
-    if (L->rounds_threads == threads && L->rounds_K == K) return 0;
+    const int rs = ptm_round_slots_for(L, threads);
+    if (L->rounds_threads == threads && L->rounds_K == K && L->rounds_slots == rs) return 0;
     // (the key is set when everything below has succeeded: a caller that frees memory and solves again after ENOMEM
     // must find the tables either complete or absent, never "already built" with buffers missing)
     L->rounds_threads = L->rounds_K = 0;
     { const int rc = ptm_build_segments(L, threads, K); if (rc) return rc; }
-    if (L->ptm_rot_mode == ROT_CAMFIX) { L->rounds_threads = threads; L->rounds_K = K; return 0; }
+    if (L->ptm_rot_mode == ROT_CAMFIX) { L->rounds_threads = threads; L->rounds_K = K; L->rounds_slots = rs; return 0; }
     const int nw = threads / 64;
     const int* li = L->h_lds_ints.data();
     const int* ls_ptr = li + L->off_ls_ptr;
@@ -2431,7 +2445,7 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     std::vector<long long> off(nwg, 0);
     ivec nr(nwg, 0);
     std::vector<unsigned short> tab, grow((size_t)L->pm_entries + 64 * PTM_BLK, 0);
-    std::vector<ivec> steps((size_t)nw);
+    std::vector<ivec> steps((size_t)nw), step_slots((size_t)nw);
     ivec seg, pos;
     const size_t r_lds = L->h_rest.size() - (size_t)L->rest_lds, r_ptm = r_lds - (size_t)L->rest_ptm;
     for (size_t ri = r_ptm; ri < r_lds; ++ri) {
@@ -2447,10 +2461,12 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
             size_t nrounds = 0;
             for (int w = 0; w < nw; ++w) {
                 ivec& st = steps[(size_t)w];
-                st.clear();
+                ivec& sn = step_slots[(size_t)w];
+                st.clear(); sn.clear();
                 const int ch0 = local ? L->h_wg_chunk0[(size_t)rk] + w : rk + K * w, chend = local ? L->h_wg_chunk0[(size_t)rk + 1] : npc, chstep = local ? nw : K * nw;
+                // (a step: one slot of a chunk, or -- two slots a round -- a block of up to two of ONE chunk)
                 for (int ch = ch0; ch < chend; ch += chstep)
-                    for (int e = cp[ch]; e < cp[ch + 1]; e += 64) st.push_back(e);
+                    for (int e = cp[ch]; e < cp[ch + 1]; e += 64 * rs) { st.push_back(e); sn.push_back(std::min(rs, (cp[ch + 1] - e) / 64)); }
                 nrounds = std::max(nrounds, st.size());
             }
             const size_t base = tab.size();
@@ -2463,19 +2479,22 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
                 for (int w = 0; w < nw; ++w) {
                     if (rr >= steps[(size_t)w].size()) continue;
                     const int e = steps[(size_t)w][rr];
-                    for (int l = 0; l < 64; ++l) { const int j = jg[e + l]; if (j >= 0) ++seg[(size_t)cam_of(e + l, j) + 1]; }
+                    for (int l = 0; l < 64 * step_slots[(size_t)w][rr]; ++l) { const int j = jg[e + l]; if (j >= 0) ++seg[(size_t)cam_of(e + l, j) + 1]; }
                 }
                 for (int k = 0; k < ncb; ++k) seg[(size_t)k + 1] += seg[(size_t)k];
                 for (int k = 0; k <= ncb; ++k) rec[k] = (unsigned short)seg[(size_t)k];
                 pos.assign(seg.begin(), seg.end() - 1);
-                for (int w = 0; w < nw; ++w) {
-                    if (rr >= steps[(size_t)w].size()) continue;
-                    const int e = steps[(size_t)w][rr];
-                    for (int l = 0; l < 64; ++l) {
-                        const int j = jg[e + l];
-                        if (j >= 0) grow[(size_t)(e + l)] = (unsigned short)pos[(size_t)cam_of(e + l, j)]++;
+                // (within a camera: the round's first slots by wave and lane, then its second slots -- with every chunk an even number of
+                // slots long that is the order of one slot a round)
+                for (int sl = 0; sl < rs; ++sl)
+                    for (int w = 0; w < nw; ++w) {
+                        if (rr >= steps[(size_t)w].size() || sl >= step_slots[(size_t)w][rr]) continue;
+                        const int e = steps[(size_t)w][rr] + 64 * sl;
+                        for (int l = 0; l < 64; ++l) {
+                            const int j = jg[e + l];
+                            if (j >= 0) grow[(size_t)(e + l)] = (unsigned short)pos[(size_t)cam_of(e + l, j)]++;
+                        }
                     }
-                }
             }
         }
     }
@@ -2505,7 +2524,7 @@ int ptm_build_rounds(rdis_hip_plan* L, int threads, int K) {
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_off.p, off.data(), nwg * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(L->pm_rd_n.p, nr.data(), nwg * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // (the host tables go out of scope; a launch on another stream follows)
-    L->rounds_threads = threads; L->rounds_K = K;
+    L->rounds_threads = threads; L->rounds_K = K; L->rounds_slots = rs;
     return 0;
 }
 int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int grid, int maxiters, double ftol) {
@@ -2515,13 +2534,13 @@ int launch_ptm(rdis_hip_plan* L, hipStream_t stream, int threads, int first, int
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    HIPCHK(c, ptm_launch(L->ptm_rot_mode, threads, grid, ptm_bytes_for(L->ptm_ncb_cap, threads), stream, P, V, maxiters, ftol, L->ptm_ncb_cap));
+    HIPCHK(c, ptm_launch(L->ptm_rot_mode, threads, grid, ptm_bytes_for(L->ptm_ncb_cap, threads, L->rounds_slots), stream, P, V, maxiters, ftol, L->ptm_ncb_cap));
     return 0;
 }
 // K workgroups per component (cgd_ptmg_kernel): how many groups of K fit the device, and the launch
 int ptmg_resident_workgroups(rdis_hip_plan* L, int threads, int* out, bool wide = false) {
     rdis_hip_ctx* c = L->prob->ctx;
-    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads, ptm_round_slots_for(L, threads));
     const void* fn = ptmg_kernel_fn(L->ptm_rot_mode, threads, wide);
     if (dyn > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int per_cu = 0;
@@ -2537,7 +2556,7 @@ int launch_ptm_groups(rdis_hip_plan* L, hipStream_t stream, int threads, int fir
     ProblemView P = L->prob->view();
     PlanView V = L->view();
     V.order += first;
-    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads);
+    const size_t dyn = ptm_bytes_for(L->ptm_ncb_cap, threads, L->rounds_slots);
     int ncc = L->ptm_ncb_cap;
     // (a wide group's workgroups and waves outnumber a small state's entries: a CoopState each)
     const size_t st_bytes = wide ? sizeof(CoopState) : sizeof(SmallCoopState);
@@ -3065,6 +3084,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
     else if (n == "pipelined") *value = L->pipelined() ? 1 : 0;
     else if (n == "point_major_group") *value = L->ptm_last_group;
     else if (n == "point_major_threads") *value = L->ptm_last_threads;
+    else if (n == "point_major_round_slots") *value = L->rounds_slots;
     else return fail(c, RDIS_HIP_EINVAL, "plan_get_info: unknown name '" + n + "'");
     return 0;
 }

@@ -107,7 +107,9 @@ struct PtmLocal {
     double* tot;         // [2][PTM_CS ncbg] the cameras' summed gradient entries (two gradients' worth)
 };
 
-template <int ROT, bool GROUP = false, class ST = SmallCoopState, bool LOCAL = false>
+// PAIR: the kernel may run its gradient rounds two slots at a time (rs == 2, the plan's choice) -- compiled in for workgroups of up
+// to 512 lanes only: at 768 lanes (168 registers a lane) the second slot's evaluation spills the whole pass.
+template <int ROT, bool GROUP = false, class ST = SmallCoopState, bool LOCAL = false, bool PAIR = false>
 struct PtmEnv {
     const ProblemView& P;
     const PlanView& L;
@@ -117,7 +119,7 @@ struct PtmEnv {
     const int* sfree;         // local free index of a slot, -1 = constant (global copy; the cameras' also in SF)
     double *Pv, *XI, *LO, *HI, *X, *GC, *HC, *ROTR;   // LDS, cameras (GC, HC: g and h of the recurrence)
     double *CTR, *CDR;        // LDS [ncb][PTM_TS] each: the cameras' trial records at the trial point at hand (factors.hpp: CAM_TRIAL)
-    double* STG;              // LDS [nt + 1][9]: the camera partials of a round's factors, grouped by camera (a factor's row: grow); a row of zeros
+    double* STG;              // LDS [rs nt + 1][9]: the camera partials of a round's factors, grouped by camera (a factor's row: grow); a row of zeros
     unsigned short* RL;       // LDS [2][rl_cap]: round tables (per camera the first row of its segment)
     int rl_cap;
     int* SF;                  // LDS: local free index of a camera slot
@@ -132,6 +134,7 @@ struct PtmEnv {
     const unsigned short* grow;     // ... the staging row of their camera partials in the gradient's rounds
     const unsigned short* rounds;   // this workgroup's round tables (per camera the first row of its segment), rl_stride 16-bit words each ...
     int nrounds, rl_stride;         // ... and their number
+    int rs;                         // slots a round evaluates and stages: 1, or 2 (a whole block of slots: half the barriers and sums' heads; the plan's choice, by the LDS)
     const int* segs;                // a trial's work by wave: rows (wave-chunk, first entry, end entry), wave w's at w, w + waves, ...;
     int seg_rows;                   // three planes of seg_rows ints (three loads no pass of the compiler can put together, see PT)
     int sg[9];                      // this wave's first three rows (the same for every trial point of the solve: scalar registers)
@@ -615,7 +618,7 @@ struct PtmEnv {
         unsigned lv0 = 0u, lv1 = 0u;
         if constexpr (CAMS) {
             for (int s = tid; s < PTM_CS * ncb; s += nt) XI[s] = 0.0;
-            for (int k = tid; k < 9; k += nt) STG[9 * nt + k] = 0.0;   // (the row that stands for "no factor" in the sums)
+            for (int k = tid; k < 9; k += nt) STG[9 * (rs * nt) + k] = 0.0;   // (the row that stands for "no factor" in the sums)
             if (nrounds > 0) {
                 if (tid < nd) lv0 = rsrc[tid];
                 if (tid + nt < nd) lv1 = rsrc[tid + nt];
@@ -665,6 +668,37 @@ struct PtmEnv {
             const long long tr0 = clock();
             double gq[12];
             int cc = -1, row = 0;
+            // (rs == 2, cameras only) the block's second slot: evaluated behind the first barrier, straight into its staging row
+            int cb = -1, rowb = 0;
+            double2 ob = make_double2(0.0, 0.0);
+            bool pair_round = false, block_ends_chunk = false;
+            if (CAMS && PAIR && rs == 2) {
+                pair_round = true;
+                if (have) {
+                    const bool first = fresh;
+                    B = N;
+                    if (fresh) {   // a chunk's first block: its blocks' position from the records; the next chunk's records
+                        line_point(R, min(64 * cu + lane, npb - 1), pn, x);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) go[k] = R.g[k];
+                        s0 = s1 = s2 = 0.0;
+                        if (ne < ne1) load_recs<true>(cx, R);
+                        fresh = false;
+                    }
+                    if (e + 64 * PTM_BLK < e1) load_block<CAMS>(e + 64 * PTM_BLK, N);
+                    else if (ne < ne1) load_block<CAMS>(ne, N);
+                    cc = B.c[0]; row = B.r[0];
+                    if (cc >= 0) {
+                        double v[12];
+                        BaFwd t;
+                        forward(cc, B.o[0], x, v, t);
+                        ba_adjoint(t, v, t.res0, t.res1, gq);
+                        s0 = first ? gq[9] : s0 + gq[9]; s1 = first ? gq[10] : s1 + gq[10]; s2 = first ? gq[11] : s2 + gq[11];
+                    }
+                    if (e + 64 < e1) { cb = B.c[1]; rowb = B.r[1]; ob = B.o[1]; block_ends_chunk = e + 128 >= e1; }
+                    else block_ends_chunk = true;
+                }
+            } else
             if (have) {
                 const bool first = fresh;
                 if (ks == 0) {   // a block's first slot
@@ -715,6 +749,28 @@ struct PtmEnv {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) dst[k] = gq[k];
                 }
+                if (pair_round && have) {
+                    if (cb >= 0) {   // the block's second slot (a lane with a factor here had one in the first slot too)
+                        double v[12], g2[12];
+                        BaFwd t;
+                        forward(cb, ob, x, v, t);
+                        ba_adjoint(t, v, t.res0, t.res1, g2);
+                        s0 = s0 + g2[9]; s1 = s1 + g2[10]; s2 = s2 + g2[11];
+                        double* dst = STG + 9 * rowb;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) dst[k] = g2[k];
+                    }
+                    if (block_ends_chunk) {   // the chunk's last block: its blocks' point entries
+                        const int ps = 64 * cu + lane;
+                        if (ps < npb) finish_block(ps, pn, go, s0, s1, s2);
+                        have = ne < ne1;
+                        cu = cx; e = ne; e1 = ne1; fresh = true;
+                        cx += cs;
+                        ne = __builtin_amdgcn_readfirstlane(v0); ne1 = __builtin_amdgcn_readfirstlane(v1);
+                        v0 = v1 = 0;
+                        if (have && cx + cs < cend) { v0 = cptr[cx + cs]; v1 = cptr[cx + cs + 1]; }
+                    } else e += 64 * PTM_BLK;
+                }
                 {   // this round's table into LDS, the next one's on its way
                     unsigned* d = reinterpret_cast<unsigned*>(RL + (rr & 1) * rl_cap);
                     if (tid < nd) d[tid] = lv0;
@@ -741,7 +797,7 @@ struct PtmEnv {
                     for (int q0 = b; q0 < en; q0 += 8) {
                         double tv[8];
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) tv[t] = STG[9 * (q0 + t < en ? q0 + t : nt) + k];
+                        for (int t = 0; t < 8; ++t) tv[t] = STG[9 * (q0 + t < en ? q0 + t : rs * nt) + k];
 #pragma unroll
                         for (int t = 0; t < 8; ++t) sm += tv[t];
                     }
@@ -943,8 +999,8 @@ struct PtmEnv {
 
 // LDS of a workgroup (ptm_bytes_for): [7 vectors of 10 ncb_cap camera slots][8 ncb_cap rotation records][2 x 16 ncb_cap trial records][9 (blockDim + 1) staged
 // camera partials][two round lists (16-bit)][10 ncb_cap free indices (int)]
-template <int ROT, bool GROUP, class ST = SmallCoopState, bool LOCAL = false>
-__device__ __forceinline__ PtmEnv<ROT, GROUP, ST, LOCAL> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
+template <int ROT, bool GROUP, class ST = SmallCoopState, bool LOCAL = false, bool PAIR = false>
+__device__ __forceinline__ PtmEnv<ROT, GROUP, ST, LOCAL, PAIR> ptm_env(const ProblemView& P, const PlanView& L, int comp, double* lds, double (*red)[3][MAX_WAVES],
                                                                   int ncb_cap, int r, int K, ST* st, double* bcast,
                                                                   int poll_delay, double* xch, const PtmGroupArgs* GA = nullptr) {
     const int f0 = L.free_ptr[comp], c0 = L.fac_ptr[comp];
@@ -964,7 +1020,8 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST, LOCAL> ptm_env(const ProblemVi
     double* CTR = ROTR + PTM_RS * ncb_cap;
     double* CDR = CTR + PTM_TS * ncb_cap;
     double* STG = CDR + PTM_TS * ncb_cap;
-    unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * (nt + 1));
+    const int rs = (PAIR && L.pm_round_slots == 2) ? 2 : 1;
+    unsigned short* RL = reinterpret_cast<unsigned short*>(STG + 9 * (rs * nt + 1));
     const int rl_cap = ptm_round_stride(ncb_cap);
     int* SF = reinterpret_cast<int*>(reinterpret_cast<char*>(RL) + (((size_t)2 * rl_cap * sizeof(unsigned short) + 7) & ~(size_t)7));
     for (int s = threadIdx.x; s < PTM_CS * ncb; s += blockDim.x) {
@@ -987,14 +1044,14 @@ __device__ __forceinline__ PtmEnv<ROT, GROUP, ST, LOCAL> ptm_env(const ProblemVi
         rounds = L.pm_rounds + L.pm_rd_off[w];
         nrounds = L.pm_rd_n[w];
     }
-    return PtmEnv<ROT, GROUP, ST, LOCAL>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
+    return PtmEnv<ROT, GROUP, ST, LOCAL, PAIR>{P, L, comp, n, m, f0, c0, (int)threadIdx.x, nt, nt >> 6,
                               ncb, npb, (npb + 63) / 64,
                               L.ls_vid + s0, L.ls_free + s0,
                               lds, lds + sc, lds + 2 * sc, lds + 3 * sc, lds + 4 * sc, lds + 5 * sc, lds + 6 * sc, ROTR, CTR, CDR,
                               STG, RL, rl_cap, SF,
                               L.pm_rec + (long long)PT_REC * pb0, (long long)npb, L.pm_cbox + 8ll * L.pm_ch0[comp], L.pm_bex + (long long)PT_BND * pb0,
                               L.pm_cptr + L.pm_ch0[comp], L.pm_cam, L.pm_obs, L.pm_grow,
-                              rounds, nrounds, ptm_round_stride(ncb),
+                              rounds, nrounds, ptm_round_stride(ncb), rs,
                               segs, seg_rows, {sg[0], sg[1], sg[2], sg[3], sg[4], sg[5], sg[6], sg[7], sg[8]},
                               L.pm_gh + (long long)PT_REC * pb0, red, 0,
                               L.trace ? L.trace + 4ll * L.trace_cap * comp : nullptr, 0, 0,
@@ -1013,7 +1070,8 @@ cgd_ptm_kernel(ProblemView P, PlanView L, int maxiters, double ftol, int ncb_cap
     __shared__ double red[2][3][MAX_WAVES];
     const int comp = L.order[blockIdx.x];
     // (a component without factors never gets here: it has no slot table and stays with solver_wg.hpp)
-    PtmEnv<ROT, false> E = ptm_env<ROT, false>(P, L, comp, lds_dyn, red, ncb_cap, 0, 1, (SmallCoopState*)nullptr, nullptr, 0, nullptr);
+    constexpr bool PAIR = THREADS <= PTM_PAIR_MAX_THREADS;
+    PtmEnv<ROT, false, SmallCoopState, false, PAIR> E = ptm_env<ROT, false, SmallCoopState, false, PAIR>(P, L, comp, lds_dyn, red, ncb_cap, 0, 1, (SmallCoopState*)nullptr, nullptr, 0, nullptr);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
     __shared__ Request Q[2];
@@ -1053,7 +1111,8 @@ cgd_ptmg_kernel(ProblemView P, PlanView L, PtmGroupArgs A, int maxiters, double 
     const int grp = WIDE ? b / K : (b / (8 * K)) * 8 + (b & 7), r = WIDE ? b % K : (b >> 3) % K;
     if (grp >= A.ngroups) return;
     const int comp = L.order[grp];
-    PtmEnv<ROT, true, ST, LOCAL> E = ptm_env<ROT, true, ST, LOCAL>(P, L, comp, lds_dyn, red, ncb_cap, r, K, reinterpret_cast<ST*>(A.st) + grp, bcast, A.poll_delay,
+    constexpr bool PAIR = THREADS <= PTM_PAIR_MAX_THREADS;
+    PtmEnv<ROT, true, ST, LOCAL, PAIR> E = ptm_env<ROT, true, ST, LOCAL, PAIR>(P, L, comp, lds_dyn, red, ncb_cap, r, K, reinterpret_cast<ST*>(A.st) + grp, bcast, A.poll_delay,
                                               A.xch ? A.xch + (long long)grp * (2 * K + 2) * PTM_CS * ncb_cap : nullptr, &A);
     [[maybe_unused]] const long long tk0 = E.clock();
     __shared__ CgdMachine M;
