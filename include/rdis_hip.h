@@ -310,6 +310,8 @@ int rdis_hip_comm_allreduce_f64(rdis_hip_comm *comm, double *inout, int32_t n, i
  * 1 = never, k <= 16 = k; for the WIDE groups of at most eight large components -- a component too large for a
  * cooperative group whose cameras fit the LDS streams through this solver on as many workgroups of 512 lanes as are resident,
  * instead of the grid solver -- up to 512),
+ * "ptm_round_slots" (the slots of factors a round of that solver's gradient pass evaluates and stages: 0 = two where the workgroup
+ * has at most 512 lanes and the LDS holds their staging rows, else one; 1; 2 -- the same bits on chunks of even slot counts),
  * "ptm_local_cameras" (a wide group whose component has more cameras than a compute unit's LDS holds, about 125: every
  * workgroup keeps only the cameras its own contiguous share of the camera-sorted chunk order meets, under local numbers;
  * -1 = default: where the cameras do not fit; 0 = never: such a component takes the grid solver; 1 = every wide group, for
@@ -339,7 +341,7 @@ int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t valu
 /* which solver the plan's components go to (a test and tuning aid; the partition is computed on demand):
  * "components_cooperative", "components_grid_stream", "components_tiny", "components_lds",
  * "components_point_major", "components_plain" (counts), "pipelined" (0/1: cooperative groups use the
- * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch), "point_major_threads" (their lanes),
+ * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch), "point_major_threads" (their lanes), "point_major_round_slots" (slots a gradient round staged),
  * "point_major_wide" (0/1: that launch was a wide group), "point_major_local_cameras" (0, or the most cameras a workgroup of
  * a wide group with local camera numbering holds) */
 int rdis_hip_plan_get_info(rdis_hip_plan *plan, const char *name, int64_t *value);
