@@ -96,13 +96,15 @@ def factors_host():
     return _fh
 
 
-def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16, wide: bool = False):
+def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16, wide: bool = False, local_cus: int = 0):
     """the point blocks of one component in the point-major streaming solver's order (rdis_hip.hip: prepare_partition), from the
     component's listed factors' camera / point blocks: by number of listed factors descending, among equals by their cameras (the
     cameras' ranks, in listed order) lexicographically, ties by id; the whole wave-chunks of 64 blocks whose first blocks have
     equally many factors are then dealt out over `spread` equal runs of their sorted order (ptm_api.hpp: PTM_SPREAD) -- round robin,
     or, for a component that gets a WIDE group, position c takes the next chunk of run h(c), h a weighted sum of c's hexadecimal
-    digits mod 16 (the first run with chunks left from there on)"""
+    digits mod 16 (the first run with chunks left from there on); or, for a wide group with LOCAL camera numbering (local_cus: the
+    device's compute units; returns the workgroups' chunk ranges as a third value), workgroup r of K = min(compute units, 512, chunks /
+    24) takes a contiguous slice of every run, its positions consecutive, wave w of eight the w-th, w + 8-th, ... of them"""
     cams, cam_rank = np.unique(cam_vid0, return_inverse=True)
     pts, pt_rank = np.unique(pt_vid0, return_inverse=True)
     npb = len(pts)
@@ -113,6 +115,37 @@ def ptm_point_order(cam_vid0, pt_vid0, spread: int = 16, wide: bool = False):
     lists = [crk[ptr[b]:ptr[b + 1]].tolist() for b in range(npb)]
     order = sorted(range(npb), key=lambda b: (-len(lists[b]), lists[b], b))
     nfull = npb // 64
+    if local_cus:
+        npc_all = -(-npb // 64)
+        Kl = min(local_cus, 512, max(1, npc_all // 24))
+        wl = [[] for _ in range(Kl)]
+        a0 = 0
+        while a0 < nfull:
+            T = len(lists[order[64 * a0]])
+            a1 = a0
+            while a1 < nfull and len(lists[order[64 * a1]]) == T:
+                a1 += 1
+            mm = a1 - a0
+            for rk in range(Kl):
+                wl[rk].extend(range(a0 + rk * mm // Kl, a0 + (rk + 1) * mm // Kl))
+            a0 = a1
+        chunk_of = [0] * nfull
+        wg_chunk0 = [0] * (Kl + 1)
+        pos, nwv = 0, 8
+        for rk in range(Kl):
+            li, taken = wl[rk], 0
+            wg_chunk0[rk] = pos
+            for w in range(nwv):
+                cnt = (len(li) - w + nwv - 1) // nwv if len(li) > w else 0
+                for j in range(cnt):
+                    chunk_of[pos + w + nwv * j] = li[taken + j]
+                taken += cnt
+            pos += len(li)
+        wg_chunk0[Kl] = npc_all
+        out = list(order)
+        for a in range(nfull):
+            out[64 * a:64 * a + 64] = order[64 * chunk_of[a]:64 * chunk_of[a] + 64]
+        return cams.astype(np.int64), pts[np.asarray(out, dtype=np.int64)].astype(np.int64), np.asarray(wg_chunk0, dtype=np.int64)
     chunk_of = []
     a0 = 0
     while a0 < nfull:
@@ -165,6 +198,7 @@ def lib() -> C.CDLL:
         L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_round_slots.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_ptm_local.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_topology.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.ro_ba_factor_grad_device.restype = C.c_double
         L.ro_ba_factor_grad_device.argtypes = [_f64p, C.c_double, C.c_double, _f64p]
@@ -278,19 +312,30 @@ class OracleProblem:
 
     @classmethod
     def device_ptm_default(cls, pp, fac=None, threads: int = 768, group: int = 1, slots_per_block: int = 2, wide: bool = False,
-                           round_slots: int = 0, lds_limit: int = 160 * 1024 - 4096):
+                           round_slots: int = 0, lds_limit: int = 160 * 1024 - 4096, local_cus: int = 0):
         """the CPU side of the == test of the DEFAULT point-major streaming path (BASELINE config 5-L: a component too large for the
         LDS-resident solver, one workgroup of `threads` lanes, or a group of `group` of them; wide: one large component on a large share of the device, groups of up
-        to 512 workgroups of 512 lanes, without local camera numbering): the device's own factor arithmetic (factors_host(): the vector form
+        to 512 workgroups of 512 lanes; local_cus = the device's compute units: such a group with LOCAL camera numbering, the group size
+        and the workgroups' chunk ranges by rdis_hip.hip's rule): the device's own factor arithmetic (factors_host(): the vector form
         for the gradient, the matrix form for the trials), no stale cache, that solver's layout and sum trees"""
         o = cls(pp, emulate_stale_cache=False)
         fc = np.arange(pp.nfac, dtype=np.int64) if fac is None else np.asarray(fac, dtype=np.int64)
-        cams, pts = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc], wide=wide)
+        wg_chunk0 = None
+        if local_cus:   # a wide group with LOCAL camera numbering: K, the order and the workgroups' chunk ranges follow from the data
+            cams, pts, wg_chunk0 = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc], local_cus=local_cus)
+            wide, group, threads = True, len(wg_chunk0) - 1, 512
+        else:
+            cams, pts = ptm_point_order(pp.cam_vid0[fc], pp.pt_vid0[fc], wide=wide)
         o._fh = factors_host()
         lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
         o._cams, o._pts = np.ascontiguousarray(cams), np.ascontiguousarray(pts)
         lib().ro_set_ptm_topology(o.h, int(threads), int(slots_per_block), -int(group) if wide else int(group), len(cams), o._cams.ctypes.data_as(C.c_void_p),
                                   len(pts), o._pts.ctypes.data_as(C.c_void_p), C.addressof(o._fh[2]))
+        if wg_chunk0 is not None:
+            o._wg_chunk0 = np.ascontiguousarray(wg_chunk0)
+            lib().ro_set_ptm_local(o.h, o._wg_chunk0.ctypes.data_as(C.c_void_p))
+        if round_slots == 0 and wg_chunk0 is not None:
+            round_slots = 2   # (a workgroup holds a few cameras only: the staging rows always fit)
         if round_slots == 0:
             # rdis_hip.hip ptm_round_slots_for: a gradient round stages two slots where the LDS holds 2 x threads rows of nine doubles
             # beside the cameras' vectors and records (ptm_api.hpp: ptm_bytes_for) -- workgroups of up to 512 lanes only; those of 256 stand two to a compute unit

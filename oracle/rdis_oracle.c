@@ -413,6 +413,7 @@ struct ro_problem {
     int ptm_nt, ptm_blk, ptm_K;       /* ... K workgroups share the component */
     int ptm_wide;                     /* ... as a wide group: one entry of the exchange a workgroup */
     int ptm_round_slots;              /* slots a gradient round stages: 1, or 2 (a block of slots) */
+    int64_t *ptm_wg_chunk0;           /* LOCAL (ro_set_ptm_local): [K + 1] workgroup r owns the chunks [r], [r + 1]) of the order, or NULL */
     int64_t ptm_ncb, ptm_npb, *ptm_cam, *ptm_pt;
     const ro_ptm_arith *ptm_ar;
     void (*trig)(double x, double *sn, double *cs);   /* ro_set_trig: sine and cosine of the nonlinear-product factors from outside, or NULL */
@@ -508,7 +509,7 @@ void ro_destroy(ro_problem *p)
     free(p->x); free(p->lo); free(p->hi); free(p->cam); free(p->pt); free(p->obs);
     free(p->coeff); free(p->expo); free(p->cons); free(p->rowptr); free(p->vid);
     free(p->sine); free(p->useexp); free(p->fcache); free(p->fdirty); free(p->v2f_ptr); free(p->v2f_idx);
-    free(p->wave_vid); free(p->wave_of); free(p->lds_slot_vid); free(p->ptm_cam); free(p->ptm_pt);
+    free(p->wave_vid); free(p->wave_of); free(p->lds_slot_vid); free(p->ptm_cam); free(p->ptm_pt); free(p->ptm_wg_chunk0);
     free(p);
 }
 
@@ -691,6 +692,21 @@ static void ptm_free(struct ptm_tab *T)
     free(T);
 }
 
+/* the chunks of workgroup rk's wave w: first, step, end -- chunk c is workgroup c mod K's and wave (c / K) mod waves', or, with LOCAL
+ * camera numbering, the workgroup owns a contiguous range of the order and its wave w takes the w-th, w + waves-th, ... of it */
+static void ptm_wave_chunks(const ro_problem *p, int64_t npc, int rk, int w, int64_t *c0, int64_t *step, int64_t *cend)
+{
+    const int nw = p->ptm_nt / 64, K = p->ptm_K;
+    if (p->ptm_wg_chunk0) { *c0 = p->ptm_wg_chunk0[rk] + w; *step = nw; *cend = p->ptm_wg_chunk0[rk + 1]; }
+    else { *c0 = rk + (int64_t)K * w; *step = (int64_t)K * nw; *cend = npc; }
+}
+/* ... and of the workgroup as a whole (a trial's rows are dealt from them) */
+static void ptm_wg_chunks(const ro_problem *p, int64_t npc, int rk, int64_t *c0, int64_t *step, int64_t *cend)
+{
+    if (p->ptm_wg_chunk0) { *c0 = p->ptm_wg_chunk0[rk]; *step = 1; *cend = p->ptm_wg_chunk0[rk + 1]; }
+    else { *c0 = rk; *step = p->ptm_K; *cend = npc; }
+}
+
 static struct ptm_tab *ptm_build(const ro_problem *p, int64_t nf, const int64_t *fac)
 {
     struct ptm_tab *T = calloc(1, sizeof *T);
@@ -724,15 +740,16 @@ static struct ptm_tab *ptm_build(const ro_problem *p, int64_t nf, const int64_t 
     T->rows = malloc(sizeof(int64_t) * 3 * (size_t)(npc + 2 * (int64_t)K * nw + 2));
     int64_t nr = 0;
     for (int rk = 0; rk < K; ++rk) {
-        int64_t units = 0;
-        for (int64_t ch = rk; ch < npc; ch += K) units += ((T->cp[ch + 1] - T->cp[ch]) / 64 + blk - 1) / blk;
-        int64_t u = 0, ch = rk, done = 0;
+        int64_t units = 0, wc0, wstep, wend;
+        ptm_wg_chunks(p, npc, rk, &wc0, &wstep, &wend);
+        for (int64_t ch = wc0; ch < wend; ch += wstep) units += ((T->cp[ch + 1] - T->cp[ch]) / 64 + blk - 1) / blk;
+        int64_t u = 0, ch = wc0, done = 0;
         for (int w = 0; w < nw; ++w) {
             const int64_t end = units * (w + 1) / nw;
             T->rptr[rk * nw + w] = nr;
             while (u < end) {
                 const int64_t nb = ((T->cp[ch + 1] - T->cp[ch]) / 64 + blk - 1) / blk;
-                if (done >= nb) { ch += K; done = 0; continue; }
+                if (done >= nb) { ch += wstep; done = 0; continue; }
                 const int64_t take = nb - done < end - u ? nb - done : end - u;
                 const int64_t e0 = T->cp[ch] + 64 * blk * done;
                 int64_t e1 = e0 + 64 * blk * take;
@@ -820,7 +837,9 @@ static double ptm_eval(ro_problem *p, const double *dir, double *slope_out)
                 }
             }
         } else {
-            for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw)
+            int64_t c0, cstep, cend;
+            ptm_wave_chunks(p, T->npc, rk, w, &c0, &cstep, &cend);
+            for (int64_t ch = c0; ch < cend; ch += cstep)
                 for (int l = 0; l < 64; ++l) {
                     const int64_t b = 64 * ch + l;
                     if (b >= npb) continue;
@@ -847,6 +866,7 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
     const int64_t ncb = p->ptm_ncb, npb = p->ptm_npb;
     const int nw = p->ptm_nt / 64, K = p->ptm_K;
     double *tot = calloc(9 * (size_t)(ncb + 1), sizeof(double)), *acc = malloc(sizeof(double) * 9 * (size_t)(ncb + 1));
+    uint8_t *held = calloc((size_t)ncb + 1, 1), *seen = calloc((size_t)ncb + 1, 1);
     const int rs = p->ptm_round_slots == 2 ? 2 : 1;
     int64_t *sptr = calloc((size_t)nw + 1, sizeof(int64_t));
     int64_t *sch = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1)), *sslot = malloc(sizeof(int64_t) * (size_t)(T->cp[T->npc] / 64 + 1));
@@ -854,7 +874,9 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
         int64_t nrounds = 0, at = 0;
         for (int w = 0; w < nw; ++w) {   /* a wave's steps: (chunk, first slot) -- one slot, or a block of up to rs slots of one chunk */
             sptr[w] = at;
-            for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw)
+            int64_t c0, cstep, cend;
+            ptm_wave_chunks(p, T->npc, rk, w, &c0, &cstep, &cend);
+            for (int64_t ch = c0; ch < cend; ch += cstep)
                 for (int64_t t = 0; t < (T->cp[ch + 1] - T->cp[ch]) / 64; t += rs) { sch[at] = ch; sslot[at] = t; ++at; }
             if (at - sptr[w] > nrounds) nrounds = at - sptr[w];
         }
@@ -874,11 +896,34 @@ static void ptm_camera_gradient(const ro_problem *p, const double *gq, double *g
                     for (int k = 0; k < 9; ++k) acc[9 * c + k] = acc[9 * c + k] + gq[12 * i + k];
                 }
             }
-        for (int64_t k = 0; k < 9 * ncb; ++k) tot[k] = rk == 0 ? acc[k] : tot[k] + acc[k];
+        /* the workgroups' partial sums in rank order; LOCAL: only the workgroups that HOLD the camera (whose chunks meet it) take part,
+         * the first one's copied */
+        if (!p->ptm_wg_chunk0) { for (int64_t k = 0; k < 9 * ncb; ++k) tot[k] = rk == 0 ? acc[k] : tot[k] + acc[k]; }
+        else {
+            memset(held, 0, (size_t)ncb + 1);
+            int64_t wc0, wstep, wend;
+            ptm_wg_chunks(p, T->npc, rk, &wc0, &wstep, &wend);
+            for (int64_t b = 64 * wc0; b < 64 * wend && b < npb; ++b)
+                for (int64_t k = T->pptr[b]; k < T->pptr[b + 1]; ++k) held[T->fcam[T->pidx[k]]] = 1;
+            for (int64_t c = 0; c < ncb; ++c) {
+                if (!held[c]) continue;
+                for (int k = 0; k < 9; ++k) tot[9 * c + k] = seen[c] ? tot[9 * c + k] + acc[9 * c + k] : acc[9 * c + k];
+                seen[c] = 1;
+            }
+        }
     }
     for (int64_t c = 0; c < ncb; ++c)
         for (int k = 0; k < 9; ++k) g[p->ptm_cam[c] + k] = tot[9 * c + k];
-    free(acc); free(tot); free(sptr); free(sch); free(sslot);
+    free(acc); free(tot); free(sptr); free(sch); free(sslot); free(held); free(seen);
+}
+
+/* LOCAL camera numbering (a wide group whose component has more cameras than a compute unit's LDS holds): workgroup r owns the chunks
+ * [wg_chunk0[r], wg_chunk0[r + 1]) of the order and keeps only the cameras they meet; a camera's partial sums come from the
+ * workgroups that hold it, in rank order; its terms of gg / dgg from the first of them.  After ro_set_ptm_topology (K < 0). */
+void ro_set_ptm_local(ro_problem *p, const int64_t *wg_chunk0)
+{
+    free(p->ptm_wg_chunk0);
+    p->ptm_wg_chunk0 = wg_chunk0 ? dup_mem(wg_chunk0, sizeof(int64_t) * (size_t)(p->ptm_K + 1)) : NULL;
 }
 
 void ro_set_ptm_round_slots(ro_problem *p, int round_slots)
@@ -890,6 +935,7 @@ void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, con
                          const ro_ptm_arith *ar)
 {
     p->ptm_round_slots = 1;
+    free(p->ptm_wg_chunk0); p->ptm_wg_chunk0 = NULL;
     p->ptm_wide = K < 0;   /* (K < 0: -K workgroups as a wide group) */
     K = K < 0 ? -K : K;
     p->ptm_K = K < 1 ? 1 : K;
@@ -1748,13 +1794,35 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
     for (int64_t i = 0; i < n; ++i) li[S->free_vid[i]] = i;
     static const int var_of_slot[10] = {3, 4, 5, 6, 7, 8, 0, 1, 2, -1};   /* [t f k1 k2 | r | pad] */
     double *wa = calloc((size_t)K * nw + 16, sizeof(double)), *wb = calloc((size_t)K * nw + 16, sizeof(double));
+    /* LOCAL: every workgroup's cameras (ascending) and who holds a camera first */
+    int64_t *lptr = NULL, *lcount = NULL, *lcam = NULL, *first_holder = NULL;
+    if (p->ptm_wg_chunk0) {
+        const int64_t ncb = p->ptm_ncb;
+        lptr = calloc((size_t)K + 1, sizeof(int64_t)); lcount = calloc((size_t)K + 1, sizeof(int64_t));
+        lcam = malloc(sizeof(int64_t) * (size_t)K * (size_t)(ncb + 1));
+        first_holder = malloc(sizeof(int64_t) * (size_t)(ncb + 1));
+        for (int64_t c = 0; c < ncb; ++c) first_holder[c] = -1;
+        uint8_t *held = malloc((size_t)ncb + 1);
+        for (int rk = 0; rk < K; ++rk) {
+            memset(held, 0, (size_t)ncb + 1);
+            for (int64_t b = 64 * p->ptm_wg_chunk0[rk]; b < 64 * p->ptm_wg_chunk0[rk + 1] && b < p->ptm_npb; ++b)
+                for (int64_t k = T->pptr[b]; k < T->pptr[b + 1]; ++k) held[T->fcam[T->pidx[k]]] = 1;
+            lptr[rk] = rk * (ncb + 1);
+            for (int64_t c = 0; c < ncb; ++c)
+                if (held[c]) { lcam[lptr[rk] + lcount[rk]++] = c; if (first_holder[c] < 0) first_holder[c] = rk; }
+            if (lcount[rk] == 0) { lcam[lptr[rk]] = 0; lcount[rk] = 1; }   /* (a workgroup without chunks is laid out for one camera) */
+        }
+        free(held);
+    }
     for (int rk = 0; rk < K; ++rk)
     for (int w = 0; w < nw; ++w) {
         double la[64], lb[64];
         for (int l = 0; l < 64; ++l) {
             double a = 0.0, b = 0.0;
+            int64_t c0, cstep, cend;
+            ptm_wave_chunks(p, T->npc, rk, w, &c0, &cstep, &cend);
             for (int pass = 0; pass < 2; ++pass)   /* the chunks with factors as the rounds finish them, then those without */
-                for (int64_t ch = rk + (int64_t)K * w; ch < T->npc; ch += (int64_t)K * nw) {
+                for (int64_t ch = c0; ch < cend; ch += cstep) {
                     const int empty = T->cp[ch] >= T->cp[ch + 1];
                     if (empty != pass) continue;
                     const int64_t blkid = 64 * ch + l;
@@ -1766,10 +1834,15 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
                         b = b + (xi[i] + g[i]) * xi[i];
                     }
                 }
-            for (int64_t sidx = 64 * w + l; rk == 0 && sidx < 10 * p->ptm_ncb; sidx += nt) {
+            /* the camera slots: the first workgroup's lanes over all cameras -- or, LOCAL, every workgroup's lanes over the cameras it
+             * holds (ascending, its own numbering) where it is the first to hold them */
+            const int64_t nloc = p->ptm_wg_chunk0 ? lcount[rk] : p->ptm_ncb;
+            for (int64_t sidx = 64 * w + l; (p->ptm_wg_chunk0 || rk == 0) && sidx < 10 * nloc; sidx += nt) {
                 const int k = var_of_slot[sidx % 10];
                 if (k < 0) continue;
-                const int64_t i = li[p->ptm_cam[sidx / 10] + k];
+                const int64_t cam = p->ptm_wg_chunk0 ? lcam[lptr[rk] + sidx / 10] : sidx / 10;
+                if (p->ptm_wg_chunk0 && first_holder[cam] != rk) continue;
+                const int64_t i = li[p->ptm_cam[cam] + k];
                 if (i < 0) continue;
                 a = a + g[i] * g[i];
                 b = b + (xi[i] + g[i]) * xi[i];
@@ -1779,7 +1852,7 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
         wa[rk * nw + w] = tree64(la); wb[rk * nw + w] = tree64(lb);
     }
     *gg = ptm_combine(wa, nw, K, p->ptm_wide); *dgg = ptm_combine(wb, nw, K, p->ptm_wide);
-    free(li); free(wa); free(wb);
+    free(li); free(wa); free(wb); free(lptr); free(lcount); free(lcam); free(first_holder);
 }
 
 /* RO_SUM_TOPOLOGY_WG: a trial's slope in the plain workgroup solver, nonlinear-product factors */

@@ -159,6 +159,7 @@ typedef struct {
     /* value of one factor at point q3; with DR10 and slope != NULL also its slope along (DR10, e3) */
     double (*trial)(const double *TR16, const double *DR10, const double *q3, const double *e3, double ox, double oy, double *slope);
 } ro_ptm_arith;
+void ro_set_ptm_local(ro_problem *p, const int64_t *wg_chunk0);   /* after ro_set_ptm_topology with K < 0: [K + 1] chunk ranges, LOCAL camera numbering */
 void ro_set_ptm_round_slots(ro_problem *p, int round_slots);   /* after ro_set_ptm_topology; 1 (default) or 2: rdis_oracle.c, "gradient" */
 void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, const int64_t *cam_vid0, int64_t npb, const int64_t *pt_vid0,
                          const ro_ptm_arith *ar);

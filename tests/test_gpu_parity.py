@@ -415,3 +415,28 @@ def test_default_path_of_the_nonlinear_product_configs_equals_the_oracle(gctx, c
         want = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
         assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (case, r.fret[0], want.fret)
         assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+@pytest.mark.parametrize("case", ["forced on 24 cameras x 30000 points", "300 cameras x 60000 points"])
+def test_wide_group_with_local_camera_numbering_equals_the_oracle(gctx, case):
+    """... and with LOCAL camera numbering (a component with more cameras than a compute unit's LDS holds: every workgroup owns a
+    contiguous range of the chunk order and keeps only the cameras it meets; a camera's partial gradient sums come from the workgroups
+    that hold it, in rank order, its terms of gg / dgg from the first of them): == the oracle's run with the same ranges
+    (ro_set_ptm_local; the group size and the ranges restated in oracle.py from the data and the device's 256 compute units)."""
+    if case.startswith("forced"):
+        pp, opts, mit = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4).single_component(), {"ptm_local_cameras": 1}, 25
+    else:
+        pp, opts, mit = P.make_synthetic_ba(1, 300, 60000, obs_per_pt=4).single_component(), {}, 10
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(mit, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_point_major") == 1 and plan.info("point_major_wide") == 1 and plan.info("point_major_local_cameras") > 0
+    o = O.OracleProblem.device_ptm_default(pp, local_cus=256)   # (MI355X: 256 compute units)
+    assert len(o._wg_chunk0) - 1 == plan.info("point_major_group")
+    want = o.cgd(x=pp.x0, maxiters=mit)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (r.fret[0], want.fret)
+    assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
