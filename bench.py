@@ -335,19 +335,19 @@ def run_strong_scaling(ctx, rank, world, coll, maxiters, steps=3, warmup=1, cpu=
                                                       "what": "fret, f and gradient evaluation counts of the timed launch == the oracle's run with the "
                                                               "device's factor arithmetic (factors.hpp for the host) and the point-major solver's sums"}
     if world == 1:
-        out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"], cpu=cpu)
+        out["emulated_ranks"] = emulated_ranks(capi, prob, pp, maxiters, out["ms_per_step"], cpu=cpu, kernel_ms_world1=kmax)
     prob.close()
     return out
 
 
-def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False):
+def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False, kernel_ms_world1=None):
     """rank 0's share of the fixed decomposition for world = 2, 4, 8, run on THIS one GPU: what one GPU of such a job
     does per step -- solve + fetch of its own results (the start is resident, as in the block above; the 8-byte
     all-reduce is not emulated) -- wall clock around exactly `steps` steps after one warm-up, and the ratio to
     the one-rank step above.  The shard is dist.rank_decomposition's (longest processing time first, identical on
     every rank); with 125 components a GPU has fewer components than compute units and K workgroups share each."""
     from rdis_amd.dist import rank_decomposition
-    rows = [{"world": 1, "components_rank0": int(pp.ncomp), "ms_per_step": ms_world1, "ratio_to_world1": 1.0}]
+    rows = [{"world": 1, "components_rank0": int(pp.ncomp), "ms_per_step": ms_world1, "kernel_ms": kernel_ms_world1, "ratio_to_world1": 1.0}]
     # (round 6: every emulated step carries the objective's all-reduce through the C ABI over a communicator of one rank -- RCCL's
     # launch and its place on the solver's stream are in the step; what a real job adds is the wire)
     comm = None
@@ -375,6 +375,8 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False):
         rows.append({"world": world, "components_rank0": int(len(mine)), "ms_per_step": ms, "kernel_ms": kms / steps,
                      "workgroups_per_component": int(plan.info("point_major_group")), "ratio_to_world1": ms_world1 / ms,
                      "objective_rank0": float(r.fret.sum()), "all_reduce_in_the_step": comm is not None})
+        if kernel_ms_world1:   # (a step = the kernel + the copy of the share's solution to the host: the ratio of the kernels alone beside it)
+            rows[-1]["kernel_ratio_to_world1"] = kernel_ms_world1 / (kms / steps)
         if cpu and STRONG["npts"] >= 2048 and not plan.info("point_major_wide") and plan.info("components_point_major") == len(mine):
             # the share's first component against a CPU run of the oracle with this launch's group (RO_SUM_TOPOLOGY_PTM)
             from oracle import oracle as O
