@@ -168,6 +168,8 @@ class RcclCollective:
     name = "rccl through the C ABI (rdis_hip_allreduce_objective)"
 
     def __init__(self, capi, ctx, rank, world):
+        if os.environ.get("RDIS_BENCH_NO_RCCL") == "1":   # (tests: the fallback below)
+            raise RuntimeError("RDIS_BENCH_NO_RCCL=1")
         self.ctx = ctx
         key = "rdis_bench_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
         path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", key)
@@ -213,6 +215,75 @@ class RcclCollective:
     def close(self):
         self.comm.barrier()
         self.comm.close()
+
+
+class FileCollective:
+    """Last resort when RCCL cannot be brought up through the C ABI (the library missing, the communicator refused): the ranks' few
+    scalars through files in /dev/shm -- one node, as the contract says.  No device collective: the objective is read back and summed
+    on the host (one 8-byte copy a step more than the RCCL paths).  The bench line names the collective it ran with."""
+    name = "host files in /dev/shm (fallback: RCCL could not be initialised through the C ABI)"
+
+    def __init__(self, ctx, rank, world, why=""):
+        self.ctx, self.rank, self.world, self.seq, self.why = ctx, rank, world, 0, why
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        self.key = os.path.join(base, "rdis_bench_fc_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid()))
+        self._obj = {}
+
+    def _path(self, seq, rank):
+        return "%s_%d_%d" % (self.key, seq, rank)
+
+    def allreduce(self, values, op="sum"):
+        self.seq += 1
+        mine = np.asarray(list(values), dtype=np.float64)
+        tmp = self._path(self.seq, self.rank) + ".tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(mine.tobytes())
+        os.replace(tmp, self._path(self.seq, self.rank))
+        acc = None
+        t0 = time.time()
+        for r in range(self.world):
+            while True:
+                try:
+                    with open(self._path(self.seq, r), "rb") as fh:
+                        b = fh.read()
+                    if len(b) == mine.nbytes:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > 600:
+                    raise RuntimeError("rank %d never wrote %s" % (r, self._path(self.seq, r)))
+                time.sleep(0.0005)
+            v = np.frombuffer(b, dtype=np.float64)
+            acc = v.copy() if acc is None else (np.maximum(acc, v) if op == "max" else acc + v)   # rank order: the same bits everywhere
+        old = self._path(self.seq - 2, self.rank)   # (everybody has read what is two exchanges old)
+        if self.seq > 2 and os.path.exists(old):
+            os.remove(old)
+        return [float(x) for x in acc]
+
+    def reduce_objective(self, plan):
+        self._obj[id(plan)] = self.allreduce([plan.objective()])[0]
+
+    def objective(self, plan):
+        return self._obj.get(id(plan), plan.objective())
+
+    def barrier_sync(self):
+        self.ctx.synchronize()
+        self.allreduce([0.0])
+
+    def close(self):
+        # a last exchange, a marker "I have read it", and rank 0 -- the last to leave -- removes what is left once every marker is there
+        import glob
+        self.allreduce([0.0])
+        open("%s_done_%d" % (self.key, self.rank), "w").close()
+        if self.rank == 0:
+            t0 = time.time()
+            while len(glob.glob(self.key + "_done_*")) < self.world and time.time() - t0 < 60:
+                time.sleep(0.001)
+            for f in glob.glob(self.key + "_*"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
 
 
 class TorchCollective:
@@ -280,7 +351,7 @@ def run_strong_scaling(ctx, rank, world, coll, maxiters, steps=3, warmup=1, cpu=
         abytes += float(np.sum((r.nfeval - r.ngeval).clip(0) * (24 * Fc + 8 * Nc + 8) + r.ngeval * (24 * Fc + 16 * Nc + 8)))
     sync()
     dt = time.perf_counter() - t0
-    objective = plan.objective()
+    objective = coll.objective(plan) if hasattr(coll, "objective") else plan.objective()
     kmax = kms / steps
     if coll is not None:
         dt, kmax = coll.allreduce([dt, kmax], "max")
@@ -888,7 +959,11 @@ def main():
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # solver + all-reduce on one stream
         coll = TorchCollective(ctx, torch, dist, local_rank)
     elif want_coll:
-        coll = RcclCollective(capi, ctx, rank, world)           # (no torch in this process)
+        try:
+            coll = RcclCollective(capi, ctx, rank, world)       # (no torch in this process)
+        except Exception as exc:   # (every rank sees the same failure: the library is missing or refuses the communicator)
+            print("bench: RCCL through the C ABI failed (%s); the ranks' scalars go through host files" % exc, file=sys.stderr)
+            coll = FileCollective(ctx, rank, world, why=str(exc))
 
     pp = build_problem(a.workload, rank, a.components, world, a.scaling == "strong", a.large_shape)
     prob = capi.Problem(ctx, pp)
@@ -931,7 +1006,7 @@ def main():
         nge += r.ngeval
     sync()
     dt = time.perf_counter() - t0
-    objective_sum = plan.objective()  # after the all-reduce: whole-job objective
+    objective_sum = coll.objective(plan) if hasattr(coll, "objective") else plan.objective()  # after the all-reduce: whole-job objective
 
     if coll is not None:
         dt = coll.allreduce([dt], "max")[0]

@@ -3,6 +3,7 @@ decomposable problem (LPT, identical on every rank), "solve" their shards (here 
 the oracle -- the checker stands in for the GPU solver, this test is about the
 sharding and the objective all-reduce), and the reduced objective equals the
 unsharded one."""
+import json
 import os
 import socket
 import subprocess
@@ -281,3 +282,57 @@ def test_bench_keeps_a_library_banner_off_stdout():
     assert r.returncode == 0, r.stderr
     assert r.stdout == "{}\n"
     assert "banner" in r.stderr
+
+
+_FILECOLL = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import bench
+
+    class FakeCtx:
+        def synchronize(self):
+            pass
+
+    class FakePlan:
+        def __init__(self, v):
+            self.v = v
+        def objective(self):
+            return self.v
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    c = bench.FileCollective(FakeCtx(), rank, world)
+    out = []
+    for step in range(5):
+        out.append(c.allreduce([rank + 1.0, 10.0 * step + rank], "sum"))
+        out.append(c.allreduce([float(rank), -float(rank)], "max"))
+        c.barrier_sync()
+    p = FakePlan(0.1 * (rank + 1))
+    c.reduce_objective(p)
+    out.append([c.objective(p)])
+    c.close()
+    print(json.dumps(out))
+""")
+
+
+def test_bench_fallback_collective_over_host_files(tmp_path):
+    """bench.py's last resort when RCCL cannot be brought up through the C ABI: the ranks' scalars through files in /dev/shm.  Three
+    ranks, sums and maxima in rank order (the same bits on every rank), the objective's sum, nothing left behind"""
+    script = tmp_path / "fc.py"
+    script.write_text(_FILECOLL.format(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in (2, 0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_PORT=str(port))
+        procs.append((rank, subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    outs = {}
+    for rank, p in procs:
+        so, se = p.communicate(timeout=120)
+        assert p.returncode == 0, se
+        outs[rank] = json.loads(so.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0][0] == [6.0, 3.0] and outs[0][1] == [2.0, 0.0] and outs[0][2] == [6.0, 33.0]
+    assert outs[0][-1] == [(0.1 + 0.2) + 0.30000000000000004]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    assert not [f for f in os.listdir(base) if f.startswith("rdis_bench_fc_%d_" % port)]
