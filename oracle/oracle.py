@@ -196,6 +196,7 @@ def lib() -> C.CDLL:
         L.ro_set_factor_arithmetic.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_group_topology.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_round_slots.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_ptm_local.argtypes = [C.c_void_p, C.c_void_p]
@@ -343,6 +344,17 @@ class OracleProblem:
             lds = ncb * 10 * (7 * 8 + 4) + ncb * (10 + 2 * 18) * 8 + (2 * threads + 1) * 72 + ((2 * ((ncb + 2) & ~1) * 2 + 7) & ~7) + 64
             round_slots = 2 if threads <= 512 and (2 if threads <= 256 else 1) * lds <= lds_limit else 1
         lib().ro_set_ptm_round_slots(o.h, int(round_slots))
+        return o
+
+    @classmethod
+    def device_group_default(cls, pp, lanes: int = 16):
+        """the CPU side of the == test of the solver of TINY components (solver_quad.hpp: a point against constant cameras and the
+        like, at most four free variables; `lanes` = 16 a component from 4096 of them in a launch, 4 from 16384): the device's factor
+        arithmetic (factors_host()), no stale cache, that solver's sums"""
+        o = cls(pp, emulate_stale_cache=False)
+        o._fh = factors_host()
+        lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
+        lib().ro_set_group_topology(o.h, int(lanes))
         return o
 
     @classmethod

@@ -964,6 +964,35 @@ void ro_set_wg_topology(ro_problem *p, int nt)
     p->lds_nt = nt;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * RO_SUM_TOPOLOGY_GROUP: the sums of the device's solver of tiny components (rdis_amd/csrc/solver_quad.hpp: G = 4 or 16 lanes a
+ * component -- a point against constant cameras: thousands of them a launch), restated entry for entry:
+ *   values   lane l of the G adds the listed factors l, l + G, ... from 0.0; the G lanes as a balanced tree in lane order;
+ *   slope    per factor sum_k partial_k direction_k over its twelve slots, each step one fused multiply-add, from 0.0 (a slot
+ *            that is not free has direction 0 and leaves the sum as it is); the factors' terms added like the values;
+ *   gradient a variable's partials: lane l adds those of ITS factors in list order from 0.0, the G lanes as the tree;
+ *   gg, dgg  one after the other over the (at most four) variables, like the reference.
+ * Bundle adjustment; the factor arithmetic from outside (ro_set_factor_arithmetic). */
+static double group_tree_sum(const double *terms, int64_t count, int G)
+{
+    double lane[16];
+    for (int l = 0; l < G; ++l) {
+        double acc = 0.0;
+        for (int64_t j = l; j < count; j += G) acc = acc + terms[j];
+        lane[l] = acc;
+    }
+    for (int w = 1; w < G; w *= 2)
+        for (int i = 0; i < G; i += 2 * w) lane[i] = lane[i] + lane[i + w];
+    return lane[0];
+}
+
+void ro_set_group_topology(ro_problem *p, int G)
+{
+    ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
+    p->topo = RO_SUM_TOPOLOGY_GROUP;
+    p->lds_nt = G == 4 ? 4 : 16;
+}
+
 void ro_set_trig(ro_problem *p, void (*sincos_fn)(double x, double *sn, double *cs))
 {
     p->trig = sincos_fn;
@@ -1196,10 +1225,11 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
      * moves the distribution of end values; tests/golden/make_end_values.py).  Not the reference's order. */
     if (p->sum_order == RO_SUM_PAIRWISE) return eval_pairwise(p, 0, nf, fac);
     if (p->topo == RO_SUM_TOPOLOGY_PTM && p->ptm && p->ptm->nf == nf && p->ptm->fac == fac) return ptm_eval(p, NULL, NULL);
-    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS || p->topo == RO_SUM_TOPOLOGY_WG) {
+    if (p->topo == RO_SUM_TOPOLOGY_COOPERATIVE || p->topo == RO_SUM_TOPOLOGY_LDS || p->topo == RO_SUM_TOPOLOGY_WG || p->topo == RO_SUM_TOPOLOGY_GROUP) {
         double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
         for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
-        const double r = p->topo != RO_SUM_TOPOLOGY_COOPERATIVE ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
+        const double r = p->topo == RO_SUM_TOPOLOGY_GROUP ? group_tree_sum(vals, nf, p->lds_nt)
+                       : p->topo != RO_SUM_TOPOLOGY_COOPERATIVE ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
         free(vals);
         return r;
     }
@@ -1316,6 +1346,34 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
                 free(part);
             }
             free(cnt);
+        }
+        if (p->topo == RO_SUM_TOPOLOGY_GROUP && p->kind == RO_KIND_BA) {
+            /* every variable again, the group's way: lane l the partials of its factors l, l + G, ... in list order, then the tree */
+            const int G = p->lds_nt;
+            double *gq = malloc(sizeof(double) * 12 * (size_t)(nf + 1));
+            for (int64_t i = 0; i < nf; ++i) {
+                const int64_t f = fac ? fac[i] : i;
+                double x[12];
+                gather_ba(p, f, x);
+                ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq + 12 * i);
+            }
+            for (int64_t v = 0; v < p->nvars; ++v) {
+                if (!seen[v]) continue;
+                double lane[16];
+                for (int l = 0; l < G; ++l) {
+                    double acc = 0.0;
+                    for (int64_t i = l; i < nf; i += G) {
+                        const int64_t f = fac ? fac[i] : i;
+                        for (int k = 0; k < 12; ++k)
+                            if (fac_var(p, f, k) == v) acc = acc + gq[12 * i + k];
+                    }
+                    lane[l] = acc;
+                }
+                for (int w = 1; w < G; w *= 2)
+                    for (int i = 0; i < G; i += 2 * w) lane[i] = lane[i] + lane[i + w];
+                g[v] = lane[0];
+            }
+            free(gq);
         }
         if (p->topo == RO_SUM_TOPOLOGY_PTM && p->ptm && p->ptm->nf == nf && p->ptm->fac == fac) {
             double *gq = malloc(sizeof(double) * 12 * (size_t)(nf + 1));
@@ -1855,6 +1913,27 @@ static void sub_cg_sums_ptm(void *ctx, int n, const double *g, const double *xi,
     free(li); free(wa); free(wb); free(lptr); free(lcount); free(lcam); free(first_holder);
 }
 
+/* RO_SUM_TOPOLOGY_GROUP: a trial's slope in the solver of tiny components */
+static double sub_slope_group(void *ctx, const double *xi)
+{
+    sub_t *S = ctx;
+    ro_problem *p = S->p;
+    double *dir = calloc((size_t)p->nvars + 1, sizeof(double));
+    double *terms = malloc(sizeof(double) * (size_t)(S->nf + 1));
+    for (int64_t i = 0; i < S->nfree; ++i) dir[S->free_vid[i]] = xi[i];
+    for (int64_t i = 0; i < S->nf; ++i) {
+        const int64_t f = S->fac ? S->fac[i] : i;
+        double x[12], gq[12], acc = 0.0;
+        gather_ba(p, f, x);
+        ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq);
+        for (int k = 0; k < 12; ++k) acc = fma(gq[k], dir[fac_var(p, f, k)], acc);
+        terms[i] = acc;
+    }
+    const double s = group_tree_sum(terms, S->nf, p->lds_nt);
+    free(terms); free(dir);
+    return s;
+}
+
 /* RO_SUM_TOPOLOGY_WG: a trial's slope in the plain workgroup solver, nonlinear-product factors */
 static double sub_slope_wg(void *ctx, const double *xi)
 {
@@ -1948,6 +2027,10 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
         hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_topology;
         g_slope_topology = sub_slope_topology;
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
+        g_slope_topology = 0;
+    } else if (p->topo == RO_SUM_TOPOLOGY_GROUP && p->kind == RO_KIND_BA && p->ext) {
+        g_slope_topology = sub_slope_group;   /* (gg and dgg: the reference's order) */
+        reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, NULL);
         g_slope_topology = 0;
     } else if (p->topo == RO_SUM_TOPOLOGY_WG && p->kind == RO_KIND_NLP) {
         /* the variables fed by more than 64 listed partials: their runs strided over a wave (solver_wg.hpp: WG_LONG_LIST) */

@@ -134,6 +134,11 @@ typedef struct {
 } ro_factor_arith;
 void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext);   /* ext must outlive the problem's use; NULL: built in */
 void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid);
+/* RO_SUM_TOPOLOGY_GROUP: the sums of the device's solver of tiny components (solver_quad.hpp: G = 4 or 16 lanes a component of at
+ * most four free variables -- a point against constant cameras, thousands of them a launch), restated entry for entry
+ * (rdis_oracle.c); bundle adjustment, the factor arithmetic from outside (ro_set_factor_arithmetic). */
+#define RO_SUM_TOPOLOGY_GROUP 5
+void ro_set_group_topology(ro_problem *p, int G);
 /* RO_SUM_TOPOLOGY_WG: the sums of the device's plain one-workgroup solver (solver_wg.hpp: cgd_wg_kernel, nt lanes) on a
  * nonlinear-product problem -- BASELINE configs 1 and 2 --, restated entry for entry (rdis_oracle.c).  The device's factor
  * arithmetic there differs from the reference's in two named places: sine and cosine (factors.hpp: nlp_sin / nlp_cos, the routine

@@ -169,7 +169,7 @@ struct GroupEnv {
                     ba_adjoint(t, v, t.res0, t.res1, gg);
                     double acc = 0.0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) acc += gg[9 + k] * d[k];
+                    for (int k = 0; k < 3; ++k) acc = __builtin_fma(gg[9 + k], d[k], acc);   // (what the compiler made of acc += g d, said out loud)
                     as += acc;
                 }
             }
@@ -198,7 +198,7 @@ struct GroupEnv {
                 af += ba_eval_grad(v, o.x, o.y, gg);
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) acc += gg[k] * d[k];
+                for (int k = 0; k < 12; ++k) acc = __builtin_fma(gg[k], d[k], acc);
                 as += acc;
             } else {
                 af += ba_eval(v, o.x, o.y);

@@ -440,3 +440,30 @@ def test_wide_group_with_local_camera_numbering_equals_the_oracle(gctx, case):
     want = o.cgd(x=pp.x0, maxiters=mit)
     assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (r.fret[0], want.fret)
     assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+@pytest.mark.parametrize("case", ["ladybug's 7776 points, sixteen lanes each", "20000 points, four lanes each"])
+def test_tiny_component_solver_equals_the_oracle(gctx, case):
+    """every point against constant cameras is a component of its own (three free variables, a few factors: by count what RDIS asks
+    the subspace solver for most) -- thousands of them a launch on solver_quad.hpp, 16 or 4 lanes a component.  Samples of the launch
+    == the oracle's run with the device's factor arithmetic and that solver's sums (RO_SUM_TOPOLOGY_GROUP)."""
+    if case.startswith("ladybug"):
+        pp, lanes = P.load_bal(), 16
+    else:
+        pp, lanes = P.make_synthetic_ba(1, 8, 20000, obs_per_pt=3), 4
+    _, pts = P.ba_alternation_plans(pp)
+    fp, fv, cp, ci = pts
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g, *pts)
+    plan.set_start(pp.x0[fv])
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    ncomp = len(fp) - 1
+    assert plan.info("components_tiny") == ncomp
+    o = O.OracleProblem.device_group_default(pp, lanes=lanes)
+    for c in range(0, ncomp, max(1, ncomp // 40)):
+        v, f = fv[fp[c]:fp[c + 1]], ci[cp[c]:cp[c + 1]]
+        want = o.cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
+        o.assign(v, pp.x0[v])   # (the oracle leaves the component assigned at its end point: back to the start, as on the device's other components)
+        assert r.fret[c] == want.fret and r.delta[c] == want.delta and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
+        assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
