@@ -467,3 +467,27 @@ def test_tiny_component_solver_equals_the_oracle(gctx, case):
         o.assign(v, pp.x0[v])   # (the oracle leaves the component assigned at its end point: back to the start, as on the device's other components)
         assert r.fret[c] == want.fret and r.delta[c] == want.delta and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
         assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
+
+
+@pytest.mark.parametrize("ncams, npts, which", [(5, 30, "cameras"), (5, 30, "points"), (12, 300, "points"), (49, 1000, "points")])
+def test_lds_path_with_constants_equals_the_oracle(gctx, ncams, npts, which):
+    """the alternation plans of small problems -- cameras against fixed points, points against fixed cameras: components with
+    constants, a launch of the LDS-resident solver whose cameras' rotations are records (points) or follow the trial point (cameras)
+    -- == the oracle's LDS topology with the constants' slots in place (they enter the factors, their terms are skipped)."""
+    pp = P.load_bal(ncams=ncams, npts=npts)
+    dec = P.ba_alternation_plans(pp)[0 if which == "cameras" else 1]
+    fp, fv, cp, ci = dec
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g, *dec)
+    plan.set_start(pp.x0[fv])
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    ncomp = len(fp) - 1
+    assert plan.info("components_lds") == ncomp
+    mf = int(np.diff(cp).max())
+    threads = 64 if mf <= 64 else 128 if mf <= 128 else 256
+    for c in range(0, ncomp, max(1, ncomp // 12)):
+        v, f = fv[fp[c]:fp[c + 1]], ci[cp[c]:cp[c + 1]]
+        want = O.OracleProblem.device_lds_default(pp, free_vid=v, fac=f, threads=threads).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
+        assert r.fret[c] == want.fret and r.delta[c] == want.delta and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
+        assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
