@@ -189,17 +189,23 @@ def level_plans(nodes: List[Node]):
     return out
 
 
-def sweep(pp, oracle_problem, plans, x, maxiters=25, ftol=3e-8):
+def sweep(pp, oracle_problem, plans, x, maxiters=25, ftol=3e-8, oracle_for=None):
     """one sweep on the CPU oracle: every launch's components one after the other (they are independent), from x;
-    returns (objective after every launch, x after the sweep)"""
+    returns (objective after every launch, x after the sweep).  oracle_for(plan) -> (free_vid, fac) -> OracleProblem: the oracle
+    that stands for the device solver the dispatcher gives that launch's components (its arithmetic and sums), default: the
+    reference-order oracle passed in"""
     x = np.array(x, dtype=np.float64)
     allv = np.arange(pp.nvars, dtype=np.int64)
     oracle_problem.assign(allv, x)
     f = oracle_problem.eval()
     objectives = []
-    for (_d, _k, _idx, fp, fv, cp, ci) in plans:
+    for plan in plans:
+        (_d, _k, _idx, fp, fv, cp, ci) = plan
+        make = oracle_for(plan) if oracle_for is not None else None
         for c in range(len(fp) - 1):
             v, fc = fv[fp[c]:fp[c + 1]], ci[cp[c]:cp[c + 1]]
+            if make is not None:
+                oracle_problem = make(v, fc)
             oracle_problem.assign(allv, x)
             r = oracle_problem.cgd(free_vid=v, fac=fc, x=x[v], maxiters=maxiters, ftol=ftol)
             x[v] = r.x

@@ -376,6 +376,35 @@ def test_level_driver_full_ladybug(harness, bal_path):
 
 
 @pytest.mark.gpu
+def test_level_driver_sweeps_on_full_ladybug_are_a_cpu_run_bit_for_bit(harness, bal_path):
+    """BASELINE config 4 through the level driver, two sweeps: the separator's launch (one component, 417 free variables, 30 313
+    factors: the pipelined cooperative solver) and the leaves' launch (7 775 points on the tiny-component solver, sixteen lanes each,
+    beside three cameras with a cooperative group each) -- every component through the oracle that stands for ITS solver
+    (device_default / device_group_default), from the values the launch before left: the device's point after the sweep, bit for bit."""
+    from oracle import levels as LV
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 0, bal_path, 0, 0, 0.2, 0.0)
+    lb = P.load_bal()
+    nodes, plans, orc = _compare_tree(lb, cpp_nodes, cpp_plans, 0.2, 0.0)
+
+    def oracle_for(plan):
+        fp = plan[3]
+        tiny = O.OracleProblem.device_group_default(lb, lanes=16) if int(np.sum(np.diff(fp) <= 4)) >= 4096 else None
+
+        def make(v, fc):
+            if len(v) <= 4 and tiny is not None:
+                return tiny
+            return O.OracleProblem.device_default(lb, free_vid=v, fac=fc)
+        return make
+    x = lb.x0
+    for _ in range(2):   # (two sweeps: the second starts every component from what the first left)
+        obj, x = LV.sweep(lb, O.OracleProblem(lb, emulate_stale_cache=False), plans, x, maxiters=25, oracle_for=oracle_for)
+    out, tr, xd = _level_driver(harness, bal_path, 0, 0, sweeps=2, nvars=23769)
+    assert len(tr) == 2 * len(plans)
+    differ = np.nonzero(xd != x)[0]
+    assert len(differ) == 0, (len(differ), differ[:10], float(np.max(np.abs(xd - x))))
+
+
+@pytest.mark.gpu
 def test_unchanged_caller_one_call_at_a_time(harness, bal_path):
     """What an unmodified RDISOptimizer would do with the drop-in: 80 calls over (5 cameras + 1 point) and 651
     calls over single points of ladybug 5/30 (the reference's own run), one optimize() at a
@@ -566,6 +595,31 @@ def test_level_tree_of_the_sinusoid_and_first_sweep_against_the_oracle(harness, 
     o2 = O.OracleProblem(lb)
     o2.assign(np.arange(lb.nvars, dtype=np.int64), x)
     assert abs(o2.eval() - obj[-1]) <= 1e-9 * abs(obj[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweeps", [1, 3])
+def test_level_driver_sweeps_on_ladybug_5_30_are_a_cpu_run_bit_for_bit(harness, bal_path, sweeps):
+    """... and with the oracle standing for the solver the dispatcher gives each launch (here the LDS-resident one: the device's
+    factor arithmetic through factors.hpp compiled for the host, its sum trees for the launch's workgroup size --
+    OracleProblem.device_lds_default) the level driver's sweeps over the tree of BASELINE config 3 end at the CPU's point bit for bit:
+    one 48-variable separator solve and 29 point leaves a sweep, every component from the values the launches before it left."""
+    from oracle import levels as LV
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 0, bal_path, 5, 30, 0.2, 0.0)
+    lb = P.load_bal(ncams=5, npts=30)
+    nodes, plans, orc = _compare_tree(lb, cpp_nodes, cpp_plans, 0.2, 0.0)
+
+    def oracle_for(plan):
+        mf = int(np.diff(plan[5]).max())
+        threads = 64 if mf <= 64 else 128 if mf <= 128 else 256
+        return lambda v, fc: O.OracleProblem.device_lds_default(lb, free_vid=v, fac=fc, threads=threads)
+    x = lb.x0
+    for _ in range(sweeps):
+        obj, x = LV.sweep(lb, O.OracleProblem(lb, emulate_stale_cache=False), plans, x, maxiters=25, oracle_for=oracle_for)
+    out, tr, xd = _level_driver(harness, bal_path, 5, 30, sweeps=sweeps, nvars=135)
+    assert len(tr) == sweeps * len(plans)
+    assert np.array_equal(xd, x), float(np.max(np.abs(xd - x)))
+    assert abs(tr[-1, 6] - obj[-1]) <= 1e-12 * abs(obj[-1])     # (the running objective: the launches' deltas added in another order)
 
 
 @pytest.mark.gpu
