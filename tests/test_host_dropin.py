@@ -479,6 +479,33 @@ def test_level_driver_multi_level_tree_on_the_sinusoid(harness):
 
 
 @pytest.mark.gpu
+def test_level_driver_sweeps_on_the_sinusoid_are_a_cpu_run_bit_for_bit(harness):
+    """... and config 2's multi-level tree: two sweeps of the level driver == the oracle's sweeps with every launch's components on
+    the plain workgroup solver's restatement (OracleProblem.device_wg_default: the device's sine / cosine, its sums for the launch's
+    workgroup size)"""
+    import json
+    from oracle import levels as LV
+    with open(os.path.join(ROOT, "tests", "golden", "sinusoid_start.json")) as fh:
+        x0 = np.array(json.load(fh)["x0"])
+    cpp_nodes, cpp_plans = _cpp_tree(harness, 1, None, 0, 0, 0.1, 0.5)
+    pp = P.make_high_dim_sinusoid()
+    nodes, plans, _ = _compare_tree(pp, cpp_nodes, cpp_plans, 0.1, 0.5)
+
+    def oracle_for(plan):
+        fp, cp = plan[3], plan[5]
+        mf = int(max(np.diff(cp).max(), np.diff(fp).max() // 4))
+        threads = 64 if mf <= 64 else 128 if mf <= 128 else 256 if mf <= 256 else 512 if mf <= 512 else 768
+        return lambda v, fc: O.OracleProblem.device_wg_default(pp, free_vid=v, fac=fc, threads=threads)
+    x = x0
+    for _ in range(2):
+        obj, x = LV.sweep(pp, O.OracleProblem(pp, emulate_stale_cache=False), plans, x, maxiters=25, oracle_for=oracle_for)
+    v = lambda a: a.ctypes.data_as(C.c_void_p)
+    out, xd = np.zeros(10), np.zeros(121)
+    assert harness.harness_level_driver_sinusoid(v(x0), 25, 2, C.c_double(0.1), C.c_double(0.5), 1, v(out), v(xd)) == 0
+    assert np.array_equal(xd, x), float(np.max(np.abs(xd - x)))
+
+
+@pytest.mark.gpu
 def test_level_driver_on_a_larger_bal_file(harness, tmp_path):
     """the whole caller side at a size beyond ladybug: a BAL file of 64 cameras x 20000 points (80000
     observations, 60576 variables) written by the saver, read by the C++ loader, decomposed (separator:
@@ -598,12 +625,13 @@ def test_level_tree_of_the_sinusoid_and_first_sweep_against_the_oracle(harness, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweeps", [1, 3])
+@pytest.mark.parametrize("sweeps", [1, 3, 20])
 def test_level_driver_sweeps_on_ladybug_5_30_are_a_cpu_run_bit_for_bit(harness, bal_path, sweeps):
     """... and with the oracle standing for the solver the dispatcher gives each launch (here the LDS-resident one: the device's
     factor arithmetic through factors.hpp compiled for the host, its sum trees for the launch's workgroup size --
     OracleProblem.device_lds_default) the level driver's sweeps over the tree of BASELINE config 3 end at the CPU's point bit for bit:
-    one 48-variable separator solve and 29 point leaves a sweep, every component from the values the launches before it left."""
+    one 48-variable separator solve and 29 point leaves a sweep, every component from the values the launches before it left; sweeps = 20: the WHOLE run of test_level_driver_ladybug_5_30
+    (the value that beats the reference's complete RDIS run), to its last bit."""
     from oracle import levels as LV
     cpp_nodes, cpp_plans = _cpp_tree(harness, 0, bal_path, 5, 30, 0.2, 0.0)
     lb = P.load_bal(ncams=5, npts=30)
@@ -613,11 +641,12 @@ def test_level_driver_sweeps_on_ladybug_5_30_are_a_cpu_run_bit_for_bit(harness, 
         mf = int(np.diff(plan[5]).max())
         threads = 64 if mf <= 64 else 128 if mf <= 128 else 256
         return lambda v, fc: O.OracleProblem.device_lds_default(lb, free_vid=v, fac=fc, threads=threads)
-    x = lb.x0
-    for _ in range(sweeps):
-        obj, x = LV.sweep(lb, O.OracleProblem(lb, emulate_stale_cache=False), plans, x, maxiters=25, oracle_for=oracle_for)
     out, tr, xd = _level_driver(harness, bal_path, 5, 30, sweeps=sweeps, nvars=135)
-    assert len(tr) == sweeps * len(plans)
+    done = int(out[2])      # (sweeps = 20: the whole run -- the driver stops when a sweep gains less than its tolerance)
+    assert len(tr) == done * len(plans) and (done == sweeps or sweeps == 20)
+    x = lb.x0
+    for _ in range(done):
+        obj, x = LV.sweep(lb, O.OracleProblem(lb, emulate_stale_cache=False), plans, x, maxiters=25, oracle_for=oracle_for)
     assert np.array_equal(xd, x), float(np.max(np.abs(xd - x)))
     assert abs(tr[-1, 6] - obj[-1]) <= 1e-12 * abs(obj[-1])     # (the running objective: the launches' deltas added in another order)
 
