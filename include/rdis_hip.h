@@ -341,7 +341,7 @@ int rdis_hip_plan_set_option(rdis_hip_plan *plan, const char *name, int64_t valu
 /* which solver the plan's components go to (a test and tuning aid; the partition is computed on demand):
  * "components_cooperative", "components_grid_stream", "components_tiny", "components_lds",
  * "components_point_major", "components_plain" (counts), "pipelined" (0/1: cooperative groups use the
- * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch), "point_major_threads" (their lanes), "point_major_round_slots" (slots a gradient round staged),
+ * pipelined layout), "point_major_group" (workgroups per component in the last solve's point-major launch), "point_major_threads" (their lanes), "point_major_round_slots" (slots a gradient round staged), "grid_stream_workgroups" (workgroups of the first component on the grid solver),
  * "point_major_wide" (0/1: that launch was a wide group), "point_major_local_cameras" (0, or the most cameras a workgroup of
  * a wide group with local camera numbering holds) */
 int rdis_hip_plan_get_info(rdis_hip_plan *plan, const char *name, int64_t *value);

@@ -197,6 +197,7 @@ def lib() -> C.CDLL:
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_group_topology.argtypes = [C.c_void_p, C.c_int]
+        L.ro_set_stream_topology.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_round_slots.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_ptm_local.argtypes = [C.c_void_p, C.c_void_p]
@@ -358,7 +359,7 @@ class OracleProblem:
         return o
 
     @classmethod
-    def device_wg_default(cls, pp, free_vid=None, fac=None, threads: int = 0):
+    def device_wg_default(cls, pp, free_vid=None, fac=None, threads: int = 0, grid_workgroups: int = 0):
         """the CPU side of the == test of the DEFAULT path of BASELINE configs 1 and 2 (nonlinear-product functions: the plain
         one-workgroup solver, solver_wg.hpp): the device's sine / cosine (factors.hpp for the host: fh_sincos) and its third and
         fourth power, no stale cache, that solver's sums for a workgroup of `threads` lanes (0: the dispatcher's rule -- by
@@ -370,9 +371,15 @@ class OracleProblem:
             mf = max(len(fc), len(fv) // 4)
             threads = 64 if mf <= 64 else 128 if mf <= 128 else 256 if mf <= 256 else 512 if mf <= 512 else 768
         o._fh = factors_host()
-        lib().ro_set_trig(o.h, C.cast(o._fh[0].fh_sincos, C.c_void_p))
-        lib().ro_set_arithmetic(o.h, 4)
-        lib().ro_set_wg_topology(o.h, int(threads))
+        if pp.kind == 0:   # (KIND_BA: bundle adjustment on the fallback solver: the batch solvers' factor arithmetic)
+            lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
+        else:
+            lib().ro_set_trig(o.h, C.cast(o._fh[0].fh_sincos, C.c_void_p))
+            lib().ro_set_arithmetic(o.h, 4)
+        if grid_workgroups > 0:   # the GRID solver (solver_stream.hpp): that many workgroups of 512 lanes on the one component
+            lib().ro_set_stream_topology(o.h, 512, int(grid_workgroups))
+        else:
+            lib().ro_set_wg_topology(o.h, int(threads))
         return o
 
     def set_cooperative_topology(self, free_vid=None, fac=None, lanes_per_workgroup: int = 128) -> None:

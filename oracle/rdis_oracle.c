@@ -407,6 +407,7 @@ struct ro_problem {
     int64_t *wave_of; /* [nvars] wave that owns the variable, or -1 */
     const ro_factor_arith *ext;       /* factor arithmetic supplied from outside (ro_set_factor_arithmetic), or NULL */
     int lds_nt;                       /* RO_SUM_TOPOLOGY_LDS: lanes of the workgroup */
+    int stream_nwg;                   /* RO_SUM_TOPOLOGY_WG on the GRID solver (ro_set_stream_topology): its workgroups, 0 = one workgroup */
     int64_t lds_nslots, *lds_slot_vid;/* ... its slots in order: the variable behind each (cameras first, then points) */
     /* RO_SUM_TOPOLOGY_PTM (ro_set_ptm_topology): lanes of the workgroup, slots a block of slots holds, the component's camera blocks
      * and point blocks (first variable ids) in the solver's order, the trial arithmetic in matrix form; ptm: tables of the solve at hand */
@@ -956,9 +957,50 @@ void ro_set_ptm_topology(ro_problem *p, int nt, int blk, int K, int64_t ncb, con
  *   gradient a variable's partials in factor-list order like the reference, the first copied -- unless more than 64 listed
  *            partials feed it: then strided over a wave (lane l: l, l + 64, ... from 0.0; a wave sum);
  *   gg, dgg  lane l adds the terms of the free variables l, l + nt, ...; the trees of the values.
- * Nonlinear-product problems only. */
+ * Nonlinear-product problems; bundle adjustment (the fallback of components no other solver takes) with the factor arithmetic from
+ * outside (ro_set_factor_arithmetic): the slope per factor in forward mode, as in RO_SUM_TOPOLOGY_LDS. */
+/* the grid solver's sums (solver_stream.hpp: nwg workgroups of nt lanes on ONE component): lane l of the grid adds the terms l,
+ * l + lanes, ... from 0.0; every wave of 64 as a balanced tree -- an entry of the exchange; the sweep: lane l adds the entries l,
+ * l + 64, ... from 0.0, then a wave sum (grid_sync.hpp) */
+static double stream_tree_sum(const double *terms, int64_t count, int nt, int nwg)
+{
+    const int64_t lanes = (int64_t)nt * nwg, nent = lanes / 64;
+    double *ent = malloc(sizeof(double) * (size_t)(nent + 1));
+    for (int64_t e = 0; e < nent; ++e) {
+        double lane[64];
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int64_t j = 64 * e + l; j < count; j += lanes) acc = acc + terms[j];
+            lane[l] = acc;
+        }
+        ent[e] = tree64(lane);
+    }
+    double sw[64];
+    for (int l = 0; l < 64; ++l) {
+        double acc = 0.0;
+        for (int64_t e = l; e < nent; e += 64) acc = acc + ent[e];
+        sw[l] = acc;
+    }
+    free(ent);
+    return tree64(sw);
+}
+/* one workgroup (solver_wg.hpp) or the grid (solver_stream.hpp) */
+static double wg_tree_sum(const ro_problem *p, const double *terms, int64_t count)
+{
+    return p->stream_nwg > 0 ? stream_tree_sum(terms, count, p->lds_nt, p->stream_nwg) : lds_tree_sum(terms, count, p->lds_nt);
+}
+
+/* ... the same solver family on a grid of nwg workgroups of nt lanes (solver_stream.hpp: one component too large for the
+ * register-resident cooperative solver that the point-major solver does not take) */
+void ro_set_stream_topology(ro_problem *p, int nt, int nwg)
+{
+    ro_set_wg_topology(p, nt);
+    p->stream_nwg = nwg;
+}
+
 void ro_set_wg_topology(ro_problem *p, int nt)
 {
+    p->stream_nwg = 0;
     ro_set_sum_topology(p, RO_SUM_TOPOLOGY_REFERENCE, 0, NULL);
     p->topo = RO_SUM_TOPOLOGY_WG;
     p->lds_nt = nt;
@@ -1229,6 +1271,7 @@ double ro_eval_factors(ro_problem *p, int64_t nf, const int64_t *fac)
         double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
         for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value(p, fac ? fac[i] : i);
         const double r = p->topo == RO_SUM_TOPOLOGY_GROUP ? group_tree_sum(vals, nf, p->lds_nt)
+                       : p->topo == RO_SUM_TOPOLOGY_WG ? wg_tree_sum(p, vals, nf)
                        : p->topo != RO_SUM_TOPOLOGY_COOPERATIVE ? lds_tree_sum(vals, nf, p->lds_nt) : coop_tree_sum(vals, nf);
         free(vals);
         return r;
@@ -1785,7 +1828,7 @@ static double sub_slope_lds(void *ctx, const double *xi)
         (void)p->ext->value_slope(x, d, p->obs[2 * f], p->obs[2 * f + 1], 0, &sl);
         terms[i] = sl;
     }
-    const double s = lds_tree_sum(terms, S->nf, p->lds_nt);
+    const double s = p->topo == RO_SUM_TOPOLOGY_WG ? wg_tree_sum(p, terms, S->nf) : lds_tree_sum(terms, S->nf, p->lds_nt);
     free(terms); free(dir);
     return s;
 }
@@ -1948,7 +1991,7 @@ static double sub_slope_wg(void *ctx, const double *xi)
         for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) acc = fma(nlp_deriv(p, f, p->vid[k]), dir[p->vid[k]], acc);
         terms[i] = acc;
     }
-    const double s = lds_tree_sum(terms, S->nf, p->lds_nt);
+    const double s = wg_tree_sum(p, terms, S->nf);
     free(terms); free(dir);
     return s;
 }
@@ -1958,8 +2001,8 @@ static void sub_cg_sums_wg(void *ctx, int n, const double *g, const double *xi, 
     sub_t *S = ctx;
     double *a = malloc(sizeof(double) * (size_t)(n + 1)), *b = malloc(sizeof(double) * (size_t)(n + 1));
     for (int i = 0; i < n; ++i) { a[i] = g[i] * g[i]; b[i] = (xi[i] + g[i]) * xi[i]; }
-    *gg = lds_tree_sum(a, n, S->p->lds_nt);
-    *dgg = lds_tree_sum(b, n, S->p->lds_nt);
+    *gg = wg_tree_sum(S->p, a, n);
+    *dgg = wg_tree_sum(S->p, b, n);
     free(a); free(b);
 }
 
@@ -2032,23 +2075,24 @@ void ro_cgd_optimize(ro_problem *p, int64_t nfree, const int64_t *free_vid,
         g_slope_topology = sub_slope_group;   /* (gg and dgg: the reference's order) */
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, NULL);
         g_slope_topology = 0;
-    } else if (p->topo == RO_SUM_TOPOLOGY_WG && p->kind == RO_KIND_NLP) {
+    } else if (p->topo == RO_SUM_TOPOLOGY_WG && (p->kind == RO_KIND_NLP || p->ext)) {
         /* the variables fed by more than 64 listed partials: their runs strided over a wave (solver_wg.hpp: WG_LONG_LIST) */
         int64_t *cnt = calloc((size_t)p->nvars + 1, sizeof(int64_t)), nlong = 0;
         for (int64_t i = 0; i < nf; ++i) {
             const int64_t f = fac ? fac[i] : i;
-            for (int64_t k = p->rowptr[f]; k < p->rowptr[f + 1]; ++k) cnt[p->vid[k]]++;
+            for (int64_t k = 0, a = fac_arity(p, f); k < a; ++k) cnt[fac_var(p, f, k)]++;
         }
         int64_t *lv = malloc(sizeof(int64_t) * (size_t)(nfree + 1));
         for (int64_t i = 0; i < nfree; ++i) if (cnt[free_vid[i]] > 64) lv[nlong++] = free_vid[i];
         const int nt = p->lds_nt;
         ro_set_sum_topology(p, RO_SUM_TOPOLOGY_COOPERATIVE, nlong, lv);   /* (borrows the wave-owned variables' bookkeeping) */
-        p->topo = RO_SUM_TOPOLOGY_WG; p->lds_nt = nt;
+        p->topo = RO_SUM_TOPOLOGY_WG; p->lds_nt = nt;   /* (stream_nwg is left as it was) */
         free(cnt); free(lv);
         ro_hooks hk;
         memset(&hk, 0, sizeof hk);
         hk.ctx = &S; hk.on_cg_sums = sub_cg_sums_wg;
-        g_slope_topology = sub_slope_wg;
+        /* (bundle adjustment on this solver: the forward-mode slope per factor of the batch solvers, the terms added as the values are) */
+        g_slope_topology = p->kind == RO_KIND_NLP ? sub_slope_wg : sub_slope_lds;
         reason = frprmn_ex((int)nfree, xw, sub_f, sub_df, &S, maxiters, ftol, &fret, &iter, &hk);
         g_slope_topology = 0;
     } else if (p->topo == RO_SUM_TOPOLOGY_PTM && p->kind == RO_KIND_BA && p->ext && p->ptm_ar) {

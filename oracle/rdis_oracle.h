@@ -146,6 +146,9 @@ void ro_set_group_topology(ro_problem *p, int G);
  * fourth power by multiplication (RO_ARITH_POW_SMALL_INT) where the reference calls std::pow. */
 #define RO_SUM_TOPOLOGY_WG 4
 void ro_set_wg_topology(ro_problem *p, int nt);
+/* ... and the grid solver (solver_stream.hpp: nwg workgroups of nt lanes on one component): the same sums over the grid's lanes, every
+ * wave an entry of the exchange */
+void ro_set_stream_topology(ro_problem *p, int nt, int nwg);
 void ro_set_trig(ro_problem *p, void (*sincos_fn)(double x, double *sn, double *cs));
 /* RO_SUM_TOPOLOGY_PTM: the sums of the device's point-major streaming solver (solver_ptm.hpp: a workgroup of nt lanes a component
  * whose camera blocks stay in LDS while its point blocks stream -- BASELINE config 5-L), restated entry for entry (rdis_oracle.c).

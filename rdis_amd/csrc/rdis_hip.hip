@@ -3075,6 +3075,7 @@ extern "C" int rdis_hip_plan_get_info(rdis_hip_plan* L, const char* name, int64_
     const int64_t rest = (int64_t)L->h_rest.size() - L->rest_tiny - L->rest_lds - L->rest_ptm;
     if (n == "components_cooperative") *value = (int64_t)L->coop.size();
     else if (n == "components_grid_stream") *value = (int64_t)L->stream.size();
+    else if (n == "grid_stream_workgroups") *value = L->stream.empty() ? 0 : L->stream.front().nwg;   // (of the first such component)
     else if (n == "components_tiny") *value = L->rest_tiny;
     else if (n == "components_lds") *value = L->rest_lds;
     else if (n == "components_point_major") *value = L->rest_ptm;

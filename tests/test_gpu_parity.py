@@ -491,3 +491,49 @@ def test_lds_path_with_constants_equals_the_oracle(gctx, ncams, npts, which):
         want = O.OracleProblem.device_lds_default(pp, free_vid=v, fac=f, threads=threads).cgd(free_vid=v, fac=f, x=pp.x0[v], maxiters=25)
         assert r.fret[c] == want.fret and r.delta[c] == want.delta and r.x[fp[c]:fp[c + 1]].tobytes() == want.x.tobytes(), (c, r.fret[c], want.fret)
         assert (int(r.iters[c]), int(r.status[c]), int(r.nfeval[c]), int(r.ngeval[c])) == (want.iters, want.status, want.nfeval, want.ngeval), c
+
+
+@pytest.mark.parametrize("ncams, npts", [(5, 30), (12, 300)])
+def test_bundle_adjustment_on_the_plain_solver_equals_the_oracle(gctx, ncams, npts):
+    """the fallback of components no other solver takes (solver_wg.hpp: state in global memory, one workgroup a component), reached
+    here by switching the LDS-resident, streaming and cooperative solvers off: == the oracle's RO_SUM_TOPOLOGY_WG run with the
+    batch solvers' factor arithmetic"""
+    pp = P.load_bal(ncams=ncams, npts=npts).single_component()
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in {"lds_resident": 0, "ptm_stream": 0, "coop_min_factors": 0, "coop_group_min_factors": 0}.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_plain") == 1
+    want = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (r.fret[0], want.fret)
+    assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+@pytest.mark.parametrize("case", ["ladybug 49 / 500", "ladybug", "the sinusoid"])
+def test_grid_solver_equals_the_oracle(gctx, case):
+    """the grid solver (solver_stream.hpp: several workgroups of 512 lanes on ONE component, state in global memory -- what takes a
+    component the cooperative and the point-major solvers do not) == the oracle's RO_SUM_TOPOLOGY_WG run over the grid's lanes
+    (ro_set_stream_topology: every wave an entry of the exchange), bundle adjustment and nonlinear products"""
+    if case == "ladybug 49 / 500":
+        pp, opts = P.load_bal(ncams=49, npts=500).single_component(), {"coop_min_factors": 1000, "force_stream": 1, "ptm_stream": 0}
+    elif case == "ladybug":
+        pp, opts = P.load_bal().single_component(), {"force_stream": 1, "ptm_stream": 0}
+    else:
+        pp, opts = P.make_high_dim_sinusoid().single_component(), {"coop_min_factors": 100}
+        pp.x0 = np.random.default_rng(4).uniform(-6, 6, 121)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    r = plan.fetch()
+    assert plan.info("components_grid_stream") == 1
+    nwg = plan.info("grid_stream_workgroups")
+    assert nwg >= 1
+    want = O.OracleProblem.device_wg_default(pp, grid_workgroups=nwg).cgd(x=pp.x0, maxiters=25)
+    assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (nwg, r.fret[0], want.fret)
+    assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
