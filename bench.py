@@ -327,11 +327,14 @@ def run_strong_scaling(ctx, rank, world, coll, maxiters, steps=3, warmup=1, cpu=
     plan = capi.Plan(prob, *csr)
     plan.set_start(pp.x0[csr[1]])
 
+    keep = [None]
+
     def step():
         plan.solve(maxiters, 3e-8)
         if coll is not None:
             coll.reduce_objective(plan)
-        return plan.fetch()
+        keep[0] = plan.fetch(out=keep[0])   # (the caller's result arrays are its own: written again every step, like the reference's xval)
+        return keep[0]
 
     def sync():
         if coll is not None:
@@ -431,7 +434,7 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False, kern
         fp, fv, cp, ci, mine = rank_decomposition(pp, 0, world)
         plan = capi.Plan(prob, fp, fv, cp, ci)
         plan.set_start(pp.x0[fv])
-        plan.solve(maxiters, 3e-8); plan.fetch()
+        plan.solve(maxiters, 3e-8); r = plan.fetch()
         if comm is not None:
             plan.allreduce_objective(comm, fetch=False)
         t0 = time.perf_counter()
@@ -440,7 +443,7 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False, kern
             plan.solve(maxiters, 3e-8)
             if comm is not None:
                 plan.allreduce_objective(comm, fetch=False)
-            r = plan.fetch()
+            r = plan.fetch(out=r)
             kms += plan.last_kernel_ms()[0]
         ms = (time.perf_counter() - t0) / steps * 1e3
         rows.append({"world": world, "components_rank0": int(len(mine)), "ms_per_step": ms, "kernel_ms": kms / steps,
@@ -478,13 +481,13 @@ def latency_floor():
 
 
 def _timed_solves(plan, x0, maxiters, steps):
-    plan.set_start(x0); plan.solve(maxiters, 3e-8); plan.fetch()
+    plan.set_start(x0); plan.solve(maxiters, 3e-8); r = plan.fetch()
     kms, nfe, nge, its = 0.0, 0, 0, 0
     t0 = time.perf_counter()
     for _ in range(steps):
         plan.set_start(x0)
         plan.solve(maxiters, 3e-8)
-        r = plan.fetch()
+        r = plan.fetch(out=r)
         kms += plan.last_kernel_ms()[0]
         nfe += int(r.nfeval.sum()); nge += int(r.ngeval.sum()); its += int((r.iters.astype(np.int64) + 1).sum())
     dt = time.perf_counter() - t0
@@ -974,6 +977,7 @@ def main():
     plan.set_start(pp.x0[pp.comp_free_vid])
 
     xstart_host = np.ascontiguousarray(pp.x0[pp.comp_free_vid])
+    kept = [None]
 
     def step():
         # the metric is the optimize() / optimize_batch() wall time INCLUDING the H2D copy of the
@@ -982,7 +986,8 @@ def main():
         plan.solve(a.maxiters, 3e-8)
         if coll is not None:
             coll.reduce_objective(plan)  # top-level objective = sum over components (RDISOptimizer.cpp:1491-1494)
-        return plan.fetch()
+        kept[0] = plan.fetch(out=kept[0])   # (into the caller's own arrays, like the reference's xval)
+        return kept[0]
 
     def sync():
         if coll is not None:

@@ -478,11 +478,16 @@ class Plan:
         """asynchronous launch on the context's stream"""
         self.ctx.check(self.ctx.lib.rdis_hip_plan_solve(self.h, maxiters, ftol))
 
-    def fetch(self, want_x=True) -> BatchResult:
+    def fetch(self, want_x=True, out: Optional[BatchResult] = None) -> BatchResult:
+        """the last solve's results; out: a BatchResult of an earlier fetch of this plan to write into -- a caller that solves a plan
+        again keeps its arrays, as the reference's caller keeps its xval (fresh arrays cost a page fault per 4 KiB inside the copy: a
+        24 MB solution 1.2 ms instead of 0.4)"""
         nc = self.ncomp
-        r = BatchResult(np.empty(self.nfree) if want_x else None, np.empty(nc), np.empty(nc),
-                        np.empty(nc, np.int32), np.empty(nc, np.int32), np.empty(nc, np.int64),
-                        np.empty(nc, np.int64))
+        r = out if out is not None else BatchResult(np.empty(self.nfree) if want_x else None, np.empty(nc), np.empty(nc),
+                                                    np.empty(nc, np.int32), np.empty(nc, np.int32), np.empty(nc, np.int64),
+                                                    np.empty(nc, np.int64))
+        if out is not None and (r.fret.shape[0] != nc or (r.x is not None and r.x.shape[0] != self.nfree)):
+            raise ValueError("fetch(out=...): the arrays are another plan's")
         self.ctx.check(self.ctx.lib.rdis_hip_plan_fetch(self.h, _ptr(r.x), _ptr(r.fret), _ptr(r.delta), _ptr(r.iters),
                                                         _ptr(r.status), _ptr(r.nfeval), _ptr(r.ngeval)))
         return r

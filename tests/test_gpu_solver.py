@@ -1627,3 +1627,25 @@ def test_batch_solvers_with_active_bounds_partial_blocks_and_rollback(gctx, solv
         assert (rq.status[c] & 0xFF) == 3 and rq.delta[c] < 0
         assert abs((rq.fret[c] - rq.delta[c]) - ro.finit) <= 1e-12 * ro.finit and abs(rq.fret[c] - ro.fret) <= 0.2 * ro.fret
     pq.close()
+
+
+@pytest.mark.gpu
+def test_fetch_into_the_callers_own_arrays(gctx):
+    """a caller that solves a plan again keeps its result arrays (the reference's caller keeps its xval): fetch(out=...) writes the
+    same values into them as a fresh fetch returns, and refuses another plan's arrays"""
+    pp = P.make_synthetic_ba(40, 3, 40)
+    g = capi.Problem(gctx, pp)
+    plan = capi.Plan(g)
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    fresh = plan.fetch()
+    mine = plan.fetch()
+    mine.x[:] = 0.0; mine.fret[:] = 0.0; mine.nfeval[:] = 0
+    plan.set_start(pp.x0)
+    plan.solve(25, 3e-8)
+    again = plan.fetch(out=mine)
+    assert again is mine
+    assert np.array_equal(mine.x, fresh.x) and np.array_equal(mine.fret, fresh.fret) and np.array_equal(mine.nfeval, fresh.nfeval)
+    other = capi.Plan(capi.Problem(gctx, P.make_synthetic_ba(7, 3, 40)))
+    with pytest.raises(ValueError):
+        other.fetch(out=mine)
