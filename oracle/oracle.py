@@ -197,6 +197,12 @@ def lib() -> C.CDLL:
         L.ro_set_lds_topology.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         L.ro_set_wg_topology.argtypes = [C.c_void_p, C.c_int]
         L.ro_set_group_topology.argtypes = [C.c_void_p, C.c_int]
+        L.ro_eval_device_grid.restype = C.c_double
+        L.ro_eval_device_grid.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        L.ro_eval_device_ba.restype = C.c_double
+        L.ro_eval_device_ba.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        L.ro_eval_grad_device_ba.restype = C.c_double
+        L.ro_eval_grad_device_ba.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ro_set_stream_topology.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ro_set_trig.argtypes = [C.c_void_p, C.c_void_p]
         L.ro_set_ptm_round_slots.argtypes = [C.c_void_p, C.c_int]
@@ -458,6 +464,36 @@ class OracleProblem:
     def eval(self, fac=None) -> float:
         f, fp = _opt_i64(fac)
         return lib().ro_eval_factors(self.h, self.pp.nfac if f is None else f.shape[0], fp)
+
+    @classmethod
+    def device_eval(cls, pp):
+        """the CPU side of the == test of the PUBLIC evaluation entry points on bundle adjustment (rdis_hip_eval, rdis_hip_eval_grad):
+        the device's factor arithmetic (factors_host()); eval_device / eval_grad_device add as those kernels add"""
+        o = cls(pp, emulate_stale_cache=False)
+        o._fh = factors_host()
+        lib().ro_set_factor_arithmetic(o.h, C.addressof(o._fh[1]))
+        return o
+
+    def eval_device(self, fac=None, lanes: int = 512) -> float:
+        f, fp = _opt_i64(fac)
+        return lib().ro_eval_device_ba(self.h, self.pp.nfac if f is None else f.shape[0], None if f is None else f.ctypes.data_as(C.c_void_p), lanes)
+
+    def eval_device_grid(self, fac=None, compute_units: int = 256) -> float:
+        """rdis_hip_eval's value on a nonlinear-product problem (the two-pass form's grid of 256-lane workgroups)"""
+        f, fp = _opt_i64(fac)
+        nf = self.pp.nfac if f is None else f.shape[0]
+        return lib().ro_eval_device_grid(self.h, nf, None if f is None else f.ctypes.data_as(C.c_void_p), max(1, min(-(-nf // 256), 8 * compute_units)))
+
+    def eval_grad_device(self, fac=None, lanes: int = 512, compute_units: int = 256):
+        """(value, gradient) as rdis_hip_eval_grad forms them: chunks of 512 listed factors, tiles of max(1, min(8, chunks / (8 x
+        compute units))) chunks (rdis_hip.hip: grad plan)"""
+        f, fp = _opt_i64(fac)
+        nf = self.pp.nfac if f is None else f.shape[0]
+        nchunks = -(-nf // lanes)
+        g = np.zeros(self.pp.nvars)
+        val = lib().ro_eval_grad_device_ba(self.h, nf, None if f is None else f.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), lanes,
+                                           max(1, min(8, nchunks // (8 * compute_units))))
+        return val, g
 
     def gradient(self, fac=None, merge: bool = False) -> np.ndarray:
         f, fp = _opt_i64(fac)

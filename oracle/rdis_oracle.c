@@ -1476,6 +1476,181 @@ void ro_compute_gradient(ro_problem *p, int64_t nf, const int64_t *fac, double *
     if (vb != vids) { free(vb); free(xb); }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The device's PUBLIC evaluation entry points on bundle adjustment (rdis_hip_eval / rdis_hip_eval_grad: rdis_amd/csrc/grad_fused.hip,
+ * eval_kernels.hpp), restated entry for entry -- the batched factor / gradient evaluation of the path's boundary:
+ *   value    the list in chunks of `lanes` (512) entries, a lane each: a chunk's waves of 64 as balanced trees, the waves' sums one
+ *            after the other from 0.0; the chunks' sums: lane t of 256 adds the chunks t, t + 256, ... from 0.0, the four waves as
+ *            trees, their sums one after the other from 0.0;
+ *   gradient a point block's three entries: per chunk its listed factors' partials one after the other from 0.0 (list order),
+ *            the chunks' sums one after the other from 0.0 where several chunks hold the block; a camera block's nine: per TILE (up
+ *            to tile_chunks consecutive chunks, fewer where a tile would meet more than 192 cameras) one after the other from
+ *            0.0 over the tile's listed factors, the tiles' sums one after the other from 0.0 where several tiles hold the camera.
+ * The factor arithmetic is the one plugged in (ro_set_factor_arithmetic: factors.hpp for the host) or the built-in one. */
+static double chunk_value_sum(const double *vals, int64_t count, int lanes)
+{
+    const int64_t nchunks = (count + lanes - 1) / lanes;
+    double *part = malloc(sizeof(double) * (size_t)(nchunks + 1));
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        double r = 0.0;
+        for (int w = 0; w < lanes / 64; ++w) {
+            double v[64];
+            for (int l = 0; l < 64; ++l) { const int64_t j = ch * lanes + 64 * w + l; v[l] = j < count ? vals[j] : 0.0; }
+            r = r + tree64(v);
+        }
+        part[ch] = r;
+    }
+    double red[4];
+    for (int w = 0; w < 4; ++w) {
+        double lane[64];
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int64_t i = 64 * w + l; i < nchunks; i += 256) acc = acc + part[i];
+            lane[l] = acc;
+        }
+        red[w] = tree64(lane);
+    }
+    free(part);
+    double r = 0.0;
+    for (int w = 0; w < 4; ++w) r = r + red[w];
+    return r;
+}
+
+/* ... and on nonlinear products (eval_kernels.hpp: eval_sum_kernel): `blocks` workgroups of 256 lanes stride over the list -- lane t
+ * of the grid adds the entries t, t + 256 blocks, ... from 0.0 --, a workgroup's four waves as trees added one after the other from
+ * 0.0, the workgroups' sums like the chunks' above.  (The gradient there: per-factor partials, every variable's added in list
+ * order -- the reference's order.) */
+double ro_eval_device_grid(ro_problem *p, int64_t nf, const int64_t *fac, int blocks)
+{
+    const int64_t lanes = 256ll * blocks;
+    double *part = malloc(sizeof(double) * (size_t)(blocks + 1));
+    for (int b = 0; b < blocks; ++b) {
+        double r = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            double v[64];
+            for (int l = 0; l < 64; ++l) {
+                double acc = 0.0;
+                for (int64_t j = 256ll * b + 64 * w + l; j < nf; j += lanes) acc = acc + factor_value_nocache(p, fac ? fac[j] : j);
+                v[l] = acc;
+            }
+            r = r + tree64(v);
+        }
+        part[b] = r;
+    }
+    double red[4];
+    for (int w = 0; w < 4; ++w) {
+        double lane[64];
+        for (int l = 0; l < 64; ++l) {
+            double acc = 0.0;
+            for (int64_t i = 64 * w + l; i < blocks; i += 256) acc = acc + part[i];
+            lane[l] = acc;
+        }
+        red[w] = tree64(lane);
+    }
+    free(part);
+    double r = 0.0;
+    for (int w = 0; w < 4; ++w) r = r + red[w];
+    return r;
+}
+
+double ro_eval_device_ba(ro_problem *p, int64_t nf, const int64_t *fac, int lanes)
+{
+    double *vals = malloc(sizeof(double) * (size_t)(nf + 1));
+    for (int64_t i = 0; i < nf; ++i) vals[i] = factor_value_nocache(p, fac ? fac[i] : i);
+    const double r = chunk_value_sum(vals, nf, lanes);
+    free(vals);
+    return r;
+}
+
+double ro_eval_grad_device_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g, int lanes, int tile_chunks)
+{
+    const int64_t nchunks = (nf + lanes - 1) / lanes;
+    double *vals = malloc(sizeof(double) * (size_t)(nf + 1)), *gq = malloc(sizeof(double) * 12 * (size_t)(nf + 1));
+    for (int64_t i = 0; i < nf; ++i) {
+        const int64_t f = fac ? fac[i] : i;
+        double x[12];
+        gather_ba(p, f, x);
+        vals[i] = ba_grad(p, x, p->obs[2 * f], p->obs[2 * f + 1], gq + 12 * i);
+    }
+    const double value = chunk_value_sum(vals, nf, lanes);
+    memset(g, 0, sizeof(double) * (size_t)p->nvars);
+    /* point blocks: chunk by chunk */
+    {
+        double *acc = calloc((size_t)p->nvars + 3, sizeof(double));      /* the chunk at hand's sum of a block */
+        double *tot = calloc((size_t)p->nvars + 3, sizeof(double));
+        int64_t *last = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1)), *nparts = calloc((size_t)p->nvars + 1, sizeof(int64_t));
+        for (int64_t v = 0; v < p->nvars; ++v) last[v] = -1;
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int64_t j0 = ch * lanes, j1 = j0 + lanes < nf ? j0 + lanes : nf;
+            for (int64_t j = j0; j < j1; ++j) {
+                const int64_t q = p->pt[fac ? fac[j] : j];
+                if (last[q] != ch) {   /* the block's first row of this chunk; what the chunk before left goes to the total first */
+                    if (last[q] >= 0) { for (int k = 0; k < 3; ++k) tot[q + k] = nparts[q] == 0 ? 0.0 + acc[q + k] : tot[q + k] + acc[q + k]; nparts[q]++; }
+                    last[q] = ch;
+                    for (int k = 0; k < 3; ++k) acc[q + k] = 0.0;
+                }
+                for (int k = 0; k < 3; ++k) acc[q + k] = acc[q + k] + gq[12 * j + 9 + k];
+            }
+        }
+        for (int64_t j = 0; j < nf; ++j) {
+            const int64_t q = p->pt[fac ? fac[j] : j];
+            if (last[q] < 0) continue;
+            /* one chunk: its sum IS the entry; several: the chunks' sums one after the other from 0.0 */
+            for (int k = 0; k < 3; ++k) g[q + k] = nparts[q] == 0 ? acc[q + k] : tot[q + k] + acc[q + k];
+            last[q] = -1;
+        }
+        free(acc); free(tot); free(last); free(nparts);
+    }
+    /* camera blocks: tile by tile */
+    {
+        double *acc = calloc((size_t)p->nvars + 9, sizeof(double)), *tot = calloc((size_t)p->nvars + 9, sizeof(double));
+        int64_t *tile_of = malloc(sizeof(int64_t) * (size_t)(p->nvars + 1)), *nparts = calloc((size_t)p->nvars + 1, sizeof(int64_t));
+        for (int64_t v = 0; v < p->nvars; ++v) tile_of[v] = -1;
+        int64_t tile = 0;
+        for (int64_t ch0 = 0; ch0 < nchunks; ++tile) {
+            /* the tile's chunks: up to tile_chunks, fewer where the cameras met would pass 192 (a chunk alone always stands) */
+            int64_t ch1 = ch0, ncam = 0;
+            int64_t *seen_list = malloc(sizeof(int64_t) * (size_t)(lanes * (tile_chunks + 1) + 1));
+            while (ch1 < nchunks && ch1 - ch0 < tile_chunks) {
+                const int64_t j0 = ch1 * lanes, j1 = j0 + lanes < nf ? j0 + lanes : nf, before = ncam;
+                for (int64_t j = j0; j < j1; ++j) {
+                    const int64_t c = p->cam[fac ? fac[j] : j];
+                    if (tile_of[c] != tile) {
+                        if (tile_of[c] >= 0 && tile_of[c] != tile) {   /* what an earlier tile left: to the total */
+                            for (int k = 0; k < 9; ++k) tot[c + k] = nparts[c] == 0 ? 0.0 + acc[c + k] : tot[c + k] + acc[c + k];
+                            nparts[c]++;
+                        }
+                        tile_of[c] = tile;
+                        for (int k = 0; k < 9; ++k) acc[c + k] = 0.0;
+                        seen_list[ncam++] = c;
+                    }
+                }
+                if (ch1 > ch0 && ncam > 192) {   /* too many: this chunk starts the next tile -- undo what it added */
+                    for (int64_t k = before; k < ncam; ++k) tile_of[seen_list[k]] = -2 - tile;   /* (not of this tile; its old sums were already moved) */
+                    ncam = before;
+                    break;
+                }
+                ++ch1;
+            }
+            for (int64_t j = ch0 * lanes; j < (ch1 * lanes < nf ? ch1 * lanes : nf); ++j) {
+                const int64_t c = p->cam[fac ? fac[j] : j];
+                for (int k = 0; k < 9; ++k) acc[c + k] = acc[c + k] + gq[12 * j + k];
+            }
+            free(seen_list);
+            ch0 = ch1;
+        }
+        for (int64_t j = 0; j < nf; ++j) {
+            const int64_t c = p->cam[fac ? fac[j] : j];
+            if (tile_of[c] == -1) continue;
+            for (int k = 0; k < 9; ++k) g[c + k] = nparts[c] == 0 ? acc[c + k] : tot[c + k] + acc[c + k];
+            tile_of[c] = -1;
+        }
+        free(acc); free(tot); free(tile_of); free(nparts);
+    }
+    free(vals); free(gq);
+    return value;
+}
+
 /* ===========================================================================
  * The minimiser: Polak-Ribiere conjugate gradients with a derivative-aware
  * Brent line search (external/include/minimize_nrc.h).  Restated from the

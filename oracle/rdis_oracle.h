@@ -134,6 +134,11 @@ typedef struct {
 } ro_factor_arith;
 void ro_set_factor_arithmetic(ro_problem *p, const ro_factor_arith *ext);   /* ext must outlive the problem's use; NULL: built in */
 void ro_set_lds_topology(ro_problem *p, int nt, int64_t nslots, const int64_t *slot_vid);
+/* the device's public evaluation entry points on bundle adjustment (rdis_hip_eval, rdis_hip_eval_grad), their sums restated entry
+ * for entry (rdis_oracle.c): lanes = 512 entries a chunk; tile_chunks = max(1, min(8, chunks / (8 x the device's compute units))) */
+double ro_eval_device_ba(ro_problem *p, int64_t nf, const int64_t *fac, int lanes);
+double ro_eval_device_grid(ro_problem *p, int64_t nf, const int64_t *fac, int blocks);   /* nonlinear products: blocks = min(ceil(nf / 256), 8 x compute units) */
+double ro_eval_grad_device_ba(ro_problem *p, int64_t nf, const int64_t *fac, double *g, int lanes, int tile_chunks);
 /* RO_SUM_TOPOLOGY_GROUP: the sums of the device's solver of tiny components (solver_quad.hpp: G = 4 or 16 lanes a component of at
  * most four free variables -- a point against constant cameras, thousands of them a launch), restated entry for entry
  * (rdis_oracle.c); bundle adjustment, the factor arithmetic from outside (ro_set_factor_arithmetic). */

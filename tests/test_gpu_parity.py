@@ -537,3 +537,50 @@ def test_grid_solver_equals_the_oracle(gctx, case):
     want = O.OracleProblem.device_wg_default(pp, grid_workgroups=nwg).cgd(x=pp.x0, maxiters=25)
     assert r.fret[0] == want.fret and r.delta[0] == want.delta and r.x.tobytes() == want.x.tobytes(), (nwg, r.fret[0], want.fret)
     assert (int(r.iters[0]), int(r.status[0]), int(r.nfeval[0]), int(r.ngeval[0])) == (want.iters, want.status, want.nfeval, want.ngeval)
+
+
+@pytest.mark.parametrize("case", ["ladybug", "a scattered sub-list", "one chunk", "2.2e6 factors: tiles of two chunks"])
+def test_public_evaluation_entry_points_equal_the_oracle(gctx, case):
+    """rdis_hip_eval and rdis_hip_eval_grad on bundle adjustment -- the batched factor / gradient evaluation of the boundary -- return,
+    bit for bit, what the oracle returns with the device's factor arithmetic and those kernels' sums restated (ro_eval_device_ba,
+    ro_eval_grad_device_ba: chunks of 512 entries, waves as trees; a point block's partials chunk by chunk, a camera's tile by tile,
+    each one after the other in list order)."""
+    fac = None
+    if case == "ladybug":
+        pp = P.load_bal()
+    elif case == "a scattered sub-list":
+        pp = P.load_bal()
+        fac = np.random.default_rng(3).permutation(pp.nfac)[:5000].astype(np.int64)
+    elif case == "one chunk":
+        pp = P.load_bal()
+        fac = np.random.default_rng(4).permutation(pp.nfac)[:300].astype(np.int64)
+    else:
+        pp = P.make_synthetic_ba(70, 49, 7776, obs_per_pt=4)
+    g = capi.Problem(gctx, pp)
+    x = pp.x0 * (1 + 1e-3 * np.random.default_rng(5).standard_normal(pp.nvars))
+    x = np.minimum(np.maximum(x, pp.lo), pp.hi)
+    g.set_x(x)
+    o = O.OracleProblem.device_eval(pp)
+    o.assign(None, x)
+    fd = g.eval(fac)
+    fg, gd = g.eval_grad(fac)
+    fo, go = o.eval_grad_device(fac)
+    assert fd == fg == fo == o.eval_device(fac), (fd, fg, fo)
+    assert gd.tobytes() == go.tobytes() or np.array_equal(gd, go), float(np.max(np.abs(gd - go)))
+
+
+@pytest.mark.parametrize("which", ["testpoly", "the sinusoid"])
+def test_public_evaluation_entry_points_on_nonlinear_products_equal_the_oracle(gctx, which):
+    """... and on the nonlinear-product functions (configs 1 and 2): value and gradient == the oracle with the device's sine / cosine
+    and small powers -- the value by ro_eval_device_grid (a grid of 256-lane workgroups striding over the list), the gradient every
+    variable's partials in list order, which is the reference's order"""
+    pp = P.load_poly() if which == "testpoly" else P.make_high_dim_sinusoid()
+    g = capi.Problem(gctx, pp)
+    x = np.minimum(np.maximum(pp.x0 + 0.37 * np.random.default_rng(6).standard_normal(pp.nvars), pp.lo), pp.hi)
+    g.set_x(x)
+    o = O.OracleProblem.device_wg_default(pp.single_component())
+    o.assign(None, x)
+    fd = g.eval()
+    fg, gd = g.eval_grad()
+    assert fd == fg == o.eval_device_grid(), (fd, fg, o.eval_device_grid())
+    assert np.array_equal(gd, o.gradient()), float(np.max(np.abs(gd - o.gradient())))
