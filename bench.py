@@ -465,6 +465,29 @@ def emulated_ranks(capi, prob, pp, maxiters, ms_world1, steps=3, cpu=False, kern
     return rows
 
 
+def lm_block(ctx, maxiters, steps=5):
+    """north_star's per-component normal-equation solve: Levenberg-Marquardt on full ladybug with pixel residuals (lm_solver.hip --
+    block J^T J, Schur complement on the cameras, the dense 441 x 441 system factored on the device; fp64 MFMA in the Schur product
+    and the trailing updates, where the work is a true contraction).  Wall clock of `steps` solves of `maxiters` iterations; what
+    the matrix cores do in them is in profiles/ (kernel stats and SQ_INSTS_MFMA counter passes of tools/gpu_lm_profile.py)."""
+    from rdis_amd import capi, problems as P
+    pp = P.load_bal()
+    g = capi.Problem(ctx, pp)
+    g.set_x(pp.x0); r = g.lm_optimize(maxiters=maxiters, model=2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.set_x(pp.x0)
+        r = g.lm_optimize(maxiters=maxiters, model=2)
+    dt = (time.perf_counter() - t0) / steps
+    g.close()
+    return {"workload": "Levenberg-Marquardt with pixel residuals, ladybug-49-7776 (23769 variables, 63686 residuals), %d iterations from x0" % maxiters,
+            "reference": "src/optimizers/LMSubspaceOptimizer.cpp (levmar, not in the reference tree: parity unpinned; oracle/lm_oracle.py restates the published algorithm)",
+            "ms_per_solve": dt * 1e3, "iterations": int(r.iters), "damped_solves": int(r.nsolve), "value": (int(r.iters)) / dt, "unit": "iters/s",
+            "objective_start": float(r.fret - r.delta), "objective_end": float(r.fret), "camera_blocks": int(r.camera_blocks), "point_blocks": int(r.point_blocks),
+            "matrix_cores": "v_mfma_f64_16x16x4_f64 in k_schur / k_cam / k_trail (lm_solver.hip); kernel stats and SQ_INSTS_MFMA / SQ_VALU_MFMA_BUSY_CYCLES "
+                            "counter passes: profiles/r06_lm_ladybug_kernel_stats.csv, profiles/r06_lm_ladybug_pmc_mfma.txt"}
+
+
 def latency_floor():
     """the pieces of ONE dependent evaluation of the cooperative solvers, measured on this device by tools/microbench/eval_floor
     (built by __graft_entry__.build()): a wave's factor arithmetic, its wave sums, one store-to-load hop between compute units,
@@ -1103,6 +1126,8 @@ def main():
         line["configs"] = configs_block(ctx, a.maxiters, cpu=not a.no_cpu_baseline)
     if a.workload == "ladybug-full" and world == 1 and not a.no_large_component:
         line["large_component"] = large_component(ctx, a.maxiters, cpu=not a.no_cpu_baseline)
+    if a.workload == "ladybug-full" and world == 1 and not a.no_configs:
+        line["normal_equations"] = lm_block(ctx, a.maxiters)
     import ctypes
     ctypes.CDLL(None).fflush(None)   # every rank: nothing buffered (RCCL's banner) may surface after rank 0's JSON
     sys.stdout.flush()
