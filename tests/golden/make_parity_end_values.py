@@ -80,6 +80,26 @@ for key, pp in (("testpoly_default_path", P.load_poly().single_component()), ("s
     r = O.OracleProblem.device_wg_default(pp).cgd(x=pp.x0, maxiters=25)
     out[key] = {"maxiters": 25, "emulate_stale_cache": False, "sum_topology": "plain workgroup solver", "fret": r.fret, "delta": r.delta,
                 "iters": r.iters, "status": r.status, "nfeval": r.nfeval, "ngeval": r.ngeval, "x_0_2": list(r.x[:2]), "x_last": float(r.x[-1])}
+# ... and one pin each for the remaining restatements: the tiny-component solver (sixteen lanes), bundle adjustment on the plain
+# solver, the grid solver (three workgroups), local camera numbering, and the public evaluation entry points' sums
+lb = P.load_bal()
+_, pts_plan = P.ba_alternation_plans(lb)
+fp, fv, cp, ci = pts_plan
+v, f = fv[fp[0]:fp[1]], ci[cp[0]:cp[1]]
+r = O.OracleProblem.device_group_default(lb, lanes=16).cgd(free_vid=v, fac=f, x=lb.x0[v], maxiters=25)
+out["ladybug_point_0_tiny_solver"] = {"lanes": 16, "fret": r.fret, "nfeval": r.nfeval, "ngeval": r.ngeval}
+s530 = P.load_bal(ncams=5, npts=30).single_component()
+r = O.OracleProblem.device_wg_default(s530).cgd(x=s530.x0, maxiters=25)
+out["ladybug_5_30_plain_solver"] = {"fret": r.fret, "nfeval": r.nfeval, "ngeval": r.ngeval}
+r = O.OracleProblem.device_wg_default(s530, grid_workgroups=3).cgd(x=s530.x0, maxiters=25)
+out["ladybug_5_30_grid_solver_3_workgroups"] = {"fret": r.fret, "nfeval": r.nfeval, "ngeval": r.ngeval}
+w24 = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4).single_component()
+o = O.OracleProblem.device_ptm_default(w24, local_cus=256)
+r = o.cgd(x=w24.x0, maxiters=3)
+out["synthetic_24_30000_local_cameras"] = {"maxiters": 3, "workgroups": int(len(o._wg_chunk0) - 1), "fret": r.fret, "nfeval": r.nfeval, "ngeval": r.ngeval}
+o = O.OracleProblem.device_eval(lb)
+fe, ge = o.eval_grad_device()
+out["ladybug_public_evaluation"] = {"value": fe, "value_again": o.eval_device(), "g_0_2": list(ge[:3]), "g_last": float(ge[-1]), "g_abs_sum": float(np.abs(ge).sum())}
 with open(os.path.join(ROOT, "tests", "golden", "parity_end_values.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps({k: (v if k != "synthetic_S_default_path" else "1000 components") for k, v in out.items()}, indent=1))

@@ -432,6 +432,40 @@ def test_plain_solver_topology_reproduces_the_nonlinear_product_fixtures():
         assert abs(sn.value - np.sin(v)) <= 2.3e-16 and abs(cs.value - np.cos(v)) <= 2.3e-16
 
 
+def test_remaining_solver_restatements_reproduce_their_fixtures():
+    """one pin each for the oracle's other restatements of device solvers (the device returns the same bits under -m gpu,
+    tests/test_gpu_parity.py): the tiny-component solver (RO_SUM_TOPOLOGY_GROUP), bundle adjustment on the plain solver and on the grid
+    solver (RO_SUM_TOPOLOGY_WG, ro_set_stream_topology), a wide point-major group with local camera numbering (ro_set_ptm_local),
+    and the public evaluation entry points' sums (ro_eval_device_ba, ro_eval_grad_device_ba)"""
+    import json
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc to compile factors.hpp for the host")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "parity_end_values.json")) as fh:
+        fx = json.load(fh)
+    lb = P.load_bal()
+    fp, fv, cp, ci = P.ba_alternation_plans(lb)[1]
+    v, f = fv[fp[0]:fp[1]], ci[cp[0]:cp[1]]
+    r = O.OracleProblem.device_group_default(lb, lanes=16).cgd(free_vid=v, fac=f, x=lb.x0[v], maxiters=25)
+    w = fx["ladybug_point_0_tiny_solver"]
+    assert (r.fret, r.nfeval, r.ngeval) == (w["fret"], w["nfeval"], w["ngeval"])
+    s530 = P.load_bal(ncams=5, npts=30).single_component()
+    for key, kw in (("ladybug_5_30_plain_solver", {}), ("ladybug_5_30_grid_solver_3_workgroups", {"grid_workgroups": 3})):
+        r = O.OracleProblem.device_wg_default(s530, **kw).cgd(x=s530.x0, maxiters=25)
+        assert (r.fret, r.nfeval, r.ngeval) == (fx[key]["fret"], fx[key]["nfeval"], fx[key]["ngeval"]), key
+    w24 = P.make_synthetic_ba(1, 24, 30000, obs_per_pt=4).single_component()
+    o = O.OracleProblem.device_ptm_default(w24, local_cus=256)
+    r = o.cgd(x=w24.x0, maxiters=3)
+    w = fx["synthetic_24_30000_local_cameras"]
+    assert (len(o._wg_chunk0) - 1, r.fret, r.nfeval, r.ngeval) == (w["workgroups"], w["fret"], w["nfeval"], w["ngeval"])
+    o = O.OracleProblem.device_eval(lb)
+    fe, ge = o.eval_grad_device()
+    w = fx["ladybug_public_evaluation"]
+    assert fe == w["value"] == o.eval_device() and list(ge[:3]) == w["g_0_2"] and ge[-1] == w["g_last"] and float(np.abs(ge).sum()) == w["g_abs_sum"]
+    ref = O.OracleProblem(lb, emulate_stale_cache=False)
+    assert abs(fe - ref.eval()) <= 1e-12 * fe and np.max(np.abs(ge - ref.gradient())) <= 1e-11 * np.max(np.abs(ge))
+
+
 def test_cgd_is_chaotic():
     """25 unconverged CG iterations are a chaotic map of the start point: a 1e-15 relative
     perturbation moves the end value by far more than 1e-6 relative, while one line minimisation
