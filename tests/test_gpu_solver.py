@@ -276,10 +276,16 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
     dstarts = [ulp_perturbed(pp.x0, np.random.default_rng([fx["seed"], 100000 + k])) for k in range(n)]
     q = lambda v: np.quantile(v, [0.25, 0.5, 0.75])
     from scipy import stats
-    (d_self, crit) = _ks2(oc, oe)
+    (d_self, crit_full) = _ks2(oc, oe)
     for name, opts, slack in (("reference rounding", {"factor_rounding": 1}, 0.0), ("default", {}, 0.07)):
-        de = device_end_values(gctx, pp, dstarts, c["maxiters"], opts)
-        (d_o, _), (d_c, _) = _ks2(de, oe), _ks2(de, oc)
+        crit = crit_full
+        # (the parity option on full ladybug is 0.3 s a solve and, since round 6, pinned with == in tests/test_gpu_parity.py: 96 draws
+        # of it here -- the two-sample test's critical value grows accordingly --, every other sample in full)
+        few = slack == 0.0 and key == "ladybug_full"
+        de = device_end_values(gctx, pp, dstarts[:96] if few else dstarts, c["maxiters"], opts)
+        (d_o, crit_o), (d_c, _) = _ks2(de, oe), _ks2(de, oc)
+        if few:
+            crit = crit_o
         print("%s, %s: end values after %d iterations (n = %d each): oracle quartiles %s, oracle contracted %s, device %s; KS device-oracle %.3f, "
               "device-contracted %.3f, oracle-contracted %.3f (critical at 0.05: %.3f); Mann-Whitney p device-oracle %.3f; "
               "reference %.6g, device range [%.6g, %.6g]" % (key, name, c["maxiters"], n, q(oe), q(oc), q(de), d_o, d_c, d_self, crit,
@@ -308,10 +314,10 @@ def test_end_values_distribution_matches_oracle(key, golden, gctx):
                 key, name, np.round(d_fam, 3), spread))
             assert d_o <= spread, (name, key, d_o, spread)
             assert min(q(m)[1] for m in fam) * (1 - 2e-3) <= q(de)[1] <= max(q(m)[1] for m in fam) * (1 + 2e-3), (name, [q(m)[1] for m in fam], q(de)[1])
-        assert np.all(np.abs(q(de) - q(oe)) <= 0.015 * q(oe)), (name, q(de), q(oe))
+        assert np.all(np.abs(q(de) - q(oe)) <= (0.03 if few else 0.015) * q(oe)), (name, q(de), q(oe))
         lo, hi = min(q(oe)[0], q(oc)[0]), max(q(oe)[2], q(oc)[2])
         assert lo <= q(de)[1] <= hi, (name, q(oe), q(oc), q(de))
-        assert de.min() <= c["fret"] <= de.max(), (name, c["fret"], de.min(), de.max())
+        assert few or de.min() <= c["fret"] <= de.max(), (name, c["fret"], de.min(), de.max())
 
 
 def test_prefix_values_part_from_the_oracle_at_the_rate_of_chaos(gctx):
